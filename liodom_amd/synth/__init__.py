@@ -1,0 +1,60 @@
+"""Synthetic LiDAR stream generator (liodom_amd/synth/synth.cc) — bench / test input.
+
+The stream definition follows SURVEY.md §8(d); see the header of synth.cc.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libliodom_synth.so")
+
+
+class SynthCfg(C.Structure):
+    _fields_ = [
+        ("height", C.c_int32), ("width", C.c_int32), ("lidar_type", C.c_int32), ("world_seed", C.c_uint32),
+        ("noise_sigma", C.c_double), ("max_cast_range", C.c_double),
+    ]
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "synth.cc")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["g++", "-O3", "-std=c++17", "-fPIC", "-fopenmp", "-shared", "-o", _LIB_PATH, src])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        L.synth_scan.restype = C.c_int
+        L.synth_scan.argtypes = [C.POINTER(SynthCfg), C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double)]
+        L.synth_num_boxes.restype = C.c_int
+        L.synth_num_boxes.argtypes = [C.c_uint32]
+        _lib = L
+    return _lib
+
+
+def make_cfg(height, width, lidar_type=0, world_seed=7, noise_sigma=0.01, max_cast_range=120.0):
+    c = SynthCfg()
+    c.height, c.width, c.lidar_type, c.world_seed = height, width, lidar_type, world_seed
+    c.noise_sigma, c.max_cast_range = noise_sigma, max_cast_range
+    return c
+
+
+def scan(cfg, stream, k):
+    """Returns (xyzi[N,4] float32, gt_pose[7] = qx qy qz qw tx ty tz)."""
+    out = np.zeros((cfg.height * cfg.width, 4), dtype=np.float32)
+    pose = np.zeros(7, dtype=np.float64)
+    rc = lib().synth_scan(C.byref(cfg), stream, k, out.ctypes.data_as(C.POINTER(C.c_float)),
+                          pose.ctypes.data_as(C.POINTER(C.c_double)))
+    assert rc == 0
+    return out, pose
