@@ -1,0 +1,179 @@
+/* liodom_hip.h — C-ABI of the MI355X-native LiODOM hot path (libliodom_hip.so).
+ *
+ * The reference (/root/reference, emiliofidalgo/liodom) has no plugin / FFI surface: its hot
+ * path lives in private member functions of two worker classes fed by ROS callbacks.  This
+ * header is the boundary a maintainer binds instead of those members; each entry point names
+ * the reference interface it replaces (paths relative to /root/reference).  INTEGRATION.md
+ * shows the reference-side glue.
+ *
+ * Conventions: plain C, caller-owned buffers with explicit capacities, int status return
+ * (0 = LIODOM_OK, negative = error), no exceptions cross the boundary.  Points are packed
+ * float[4] XYZI (pcl::PointXYZI without padding).  Poses are world<-laser, 7 doubles
+ * [qx qy qz qw tx ty tz] — the storage order of param_q / param_t
+ * (include/liodom/laser_odometry.h:98-99, src/laser_odometry.cc:187-195).
+ *
+ * One handle drives one GPU and `n_streams` independent LiDAR streams that advance in
+ * lock-step (every kernel is launched once over all streams).  n_streams = 1 is the drop-in
+ * case for liodom_node; n_streams > 1 serves replay / multi-sensor batches.  A handle is not
+ * thread-safe.
+ */
+#ifndef LIODOM_HIP_H
+#define LIODOM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LIODOM_OK 0
+#define LIODOM_ERR_INVALID_ARG (-1)
+#define LIODOM_ERR_UNSUPPORTED (-2)   /* parameter combination not implemented yet */
+#define LIODOM_ERR_CAPACITY (-3)      /* caller buffer or configured capacity too small */
+#define LIODOM_ERR_HIP (-4)           /* HIP runtime failure; see liodom_last_error() */
+#define LIODOM_ERR_NO_DEVICE (-5)
+
+/* Sticky per-stream status bits reported in liodom_step_info_t.status */
+#define LIODOM_STATUS_RING_OVERFLOW 1u  /* a ring had more points than max_ring_points; it was skipped */
+#define LIODOM_STATUS_EDGE_OVERFLOW 2u
+#define LIODOM_STATUS_HASH_FULL 4u
+
+/* Field-for-field mirror of liodom::Params (include/liodom/params.h:33-49); defaults are
+ * those of Params::readParams (src/params.cc:40-109). */
+typedef struct liodom_params_t {
+  double min_range;              /* params.h:33  default 3.0  */
+  double max_range;              /* params.h:34  default 75.0 */
+  int32_t lidar_type;            /* params.h:35  0 Velodyne (elevation binning), 1 Ouster (row = ring) */
+  int32_t scan_lines;            /* params.h:36  default 64 */
+  int32_t scan_regions;          /* params.h:37  default 8  */
+  int32_t edges_per_region;      /* params.h:38  default 10 */
+  uint64_t min_points_per_scan;  /* params.h:39  scan_regions*edges_per_region + 10 (params.cc:63) */
+  uint64_t local_map_size;       /* params.h:40  "prev_frames", default 5 */
+  int32_t save_results;          /* params.h:41 */
+  char results_dir[256];         /* params.h:42  default "~/" */
+  char fixed_frame[64];          /* params.h:43  default "odom" */
+  char base_frame[64];           /* params.h:44  default "base_link" */
+  char laser_frame[64];          /* params.h:45  default "" (taken from the header) */
+  int32_t use_imu;               /* params.h:46 */
+  int32_t filter_local_map;      /* params.h:47 */
+  int32_t mapping;               /* params.h:48 */
+  int32_t publish_tf;            /* params.h:49  default true */
+} liodom_params_t;
+
+/* Engine configuration that has no counterpart in the reference. */
+typedef struct liodom_config_t {
+  int32_t device;            /* HIP device ordinal */
+  int32_t n_streams;         /* independent streams advanced in lock-step (>= 1) */
+  int32_t max_points;        /* capacity: points per scan (H*W) */
+  int32_t max_width;         /* expected points per ring; sizes the per-ring LDS tile */
+  int32_t max_ring_points;   /* 0 = derive from max_width (round_up(w + w/8, 256)); <= 6144 */
+  int32_t lm_apply_step_on_ftol; /* 0 = Ceres >= 1.12 behaviour (LM section) */
+  int32_t pose_log_capacity; /* scans kept in the device-side pose log (resident replay) */
+  int32_t debug_buffers;     /* 1 = keep per-ring smoothness dumps for liodom_get_curvature */
+} liodom_config_t;
+
+typedef struct liodom_lm_trace_t {
+  int32_t iterations;        /* trust-region iterations used (<= 4, src/laser_odometry.cc:214) */
+  int32_t accepted;
+  int32_t termination;       /* 0 max-iter 1 param-tol 2 func-tol 3 grad-tol 4 no-residuals 5 eval-failure 6 radius 7 invalid-steps */
+  int32_t pad;
+  double initial_cost;
+  double final_cost;
+} liodom_lm_trace_t;
+
+/* Per-scan diagnostics (what the reference logs with ROS_DEBUG at
+ * feature_extractor.cc:62, laser_odometry.cc:279,297,365). */
+typedef struct liodom_step_info_t {
+  int32_t n_edges;
+  int32_t map_points;        /* local-map points searched by this scan */
+  int32_t matches[2];        /* "Correct matchings" of the two outer iterations */
+  liodom_lm_trace_t lm[2];
+  uint32_t status;
+  int32_t scan_index;
+} liodom_step_info_t;
+
+typedef struct liodom_handle liodom_handle_t;
+
+/* Params::readParams defaults (src/params.cc:40-109). */
+void liodom_params_default(liodom_params_t* p);
+void liodom_config_default(liodom_config_t* c);
+
+/* Replaces the construction of FeatureExtractor + LaserOdometer
+ * (src/liodom_node.cc:85-86; feature_extractor.cc:24-37; laser_odometry.cc:71-95). */
+int liodom_create(const liodom_params_t* params, const liodom_config_t* config, liodom_handle_t** out);
+void liodom_destroy(liodom_handle_t* h);
+const char* liodom_last_error(void);
+
+/* FeatureExtractor::splitPointCloud + extractFeatures (src/feature_extractor.cc:104-254) for one
+ * cloud of stream `stream`.  xyzi: n points (host).  For lidar_type 1, height*width == n and
+ * the cloud is row-major organised.  Outputs (host, capacity `cap` edges): edges in the
+ * reference's output order (ring-major, region-major, pick order); edge_ring / edge_idx /
+ * edge_src (each optional) = ring id, index inside the compacted ring, index into xyzi. */
+int liodom_extract_edges(liodom_handle_t* h, int stream, const float* xyzi, int64_t n,
+                         int height, int width, float* edges_xyzi, int32_t* edge_ring,
+                         int32_t* edge_idx, int32_t* edge_src, int cap, int* n_edges);
+
+/* One iteration of LaserOdometer::operator() (src/laser_odometry.cc:107-267) on an edge cloud
+ * (sensor frame, host memory): first call initialises the window, later calls predict, run
+ * 2 x [addEdgeConstraints + solve], and append the transformed edges to the sliding window. */
+int liodom_odometry_step(liodom_handle_t* h, int stream, const float* edges_xyzi, int n_edges,
+                         double stamp, double* pose_out, liodom_step_info_t* info);
+
+/* lidarClb -> FeatureExtractor -> LaserOdometer for one scan without leaving the device
+ * (src/liodom_node.cc:40-55 + the two worker loops).  pose_out / info / edges outputs optional. */
+int liodom_process_scan(liodom_handle_t* h, int stream, const float* xyzi, int64_t n, int height,
+                        int width, double stamp, double* pose_out, liodom_step_info_t* info);
+
+/* mapClb -> SharedData::setLocalMap (src/liodom_node.cc:57-64).  Only used with mapping=1. */
+int liodom_set_received_map(liodom_handle_t* h, int stream, const float* xyzi, int64_t n);
+
+/* ---- resident replay (bench / batched streams): scans live in HBM before timing starts ---- */
+int liodom_alloc_resident(liodom_handle_t* h, int n_slots);
+int liodom_upload_scan(liodom_handle_t* h, int stream, int slot, const float* xyzi, int64_t n);
+/* Advance every stream by one scan read from resident slot `slot` (n, height, width as above,
+ * identical for all streams).  If poses_out != NULL (n_streams*7 doubles) the call waits for
+ * the poses (per-scan synchronous, as the node publishes ~odom per scan); otherwise it only
+ * enqueues and poses are read later from the device-side log. */
+int liodom_process_resident(liodom_handle_t* h, int slot, int64_t n, int height, int width,
+                            double* poses_out, liodom_step_info_t* infos_out);
+int liodom_sync(liodom_handle_t* h);
+int liodom_get_pose_log(liodom_handle_t* h, int stream, int first, int count, double* poses_out,
+                        liodom_step_info_t* infos_out);
+/* Resets the odometry state (pose, window, map) of every stream; capacities are kept. */
+int liodom_reset(liodom_handle_t* h);
+
+/* ---- inspection (tests, parity checks) ---- */
+/* Edges of the last scan of a stream as left on the device by process_scan / process_resident. */
+int liodom_get_edges(liodom_handle_t* h, int stream, float* edges_xyzi, int32_t* edge_ring,
+                     int32_t* edge_idx, int32_t* edge_src, int cap, int* n_edges);
+/* Sliding-window points in LocalMapManager order (oldest frame first). */
+int liodom_get_window(liodom_handle_t* h, int stream, float* xyzi, int64_t cap, int64_t* n_points,
+                      int* n_frames);
+/* Correspondences of outer iteration `it` (0/1) of the last step: valid flag and window
+ * indices (as in liodom_get_window) of the two line points per edge. */
+int liodom_get_correspondences(liodom_handle_t* h, int stream, int it, int32_t* valid,
+                               int32_t* idx_a, int32_t* idx_b, int cap, int* n);
+/* Smoothness values of the last extracted scan, ring-major over the compacted rings; also the
+ * ring offsets (scan_lines + 1 entries).  NaN where the stencil is undefined. */
+int liodom_get_curvature(liodom_handle_t* h, int stream, double* curv, int64_t cap,
+                         int32_t* ring_offsets);
+
+/* ---- measurement ---- */
+/* When enabled every kernel launch is bracketed by HIP events on the handle's stream. */
+int liodom_set_profiling(liodom_handle_t* h, int enable);
+#define LIODOM_NUM_KERNELS 10
+typedef struct liodom_kernel_stat_t {
+  char name[32];
+  int64_t launches;
+  double total_ms;
+} liodom_kernel_stat_t;
+/* Drains recorded events (synchronises) and accumulates into the per-kernel table. */
+int liodom_get_kernel_stats(liodom_handle_t* h, liodom_kernel_stat_t* stats /*LIODOM_NUM_KERNELS*/);
+int liodom_reset_kernel_stats(liodom_handle_t* h);
+/* Device name and compute-unit count of the handle's GPU. */
+int liodom_device_info(liodom_handle_t* h, char* name, int name_cap, int* compute_units);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIODOM_HIP_H */

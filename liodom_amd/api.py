@@ -1,0 +1,316 @@
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+_LIB = os.path.join(_HERE, "lib", "libliodom_hip.so")
+_SRC = [os.path.join(_HERE, "csrc", f) for f in ("liodom_hip.hip", "liodom_kernels.h", "liodom_math.h")] + [
+    os.path.join(_ROOT, "include", "liodom_hip.h")]
+
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+               "-Wno-unused-value"]
+
+
+class LiodomError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return _LIB
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP library for gfx950 (hipcc cross-compiles without a GPU)."""
+    os.makedirs(os.path.dirname(_LIB), exist_ok=True)
+    newest = max(os.path.getmtime(p) for p in _SRC)
+    if not force and os.path.exists(_LIB) and os.path.getmtime(_LIB) >= newest:
+        return _LIB
+    hipcc = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else "hipcc"
+    cmd = [hipcc] + HIPCC_FLAGS + ["-o", _LIB, _SRC[0]]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return _LIB
+
+
+class Params(C.Structure):
+    """liodom_params_t — mirror of liodom::Params (include/liodom/params.h:33-49)."""
+    _fields_ = [
+        ("min_range", C.c_double), ("max_range", C.c_double),
+        ("lidar_type", C.c_int32), ("scan_lines", C.c_int32), ("scan_regions", C.c_int32),
+        ("edges_per_region", C.c_int32),
+        ("min_points_per_scan", C.c_uint64), ("local_map_size", C.c_uint64),
+        ("save_results", C.c_int32),
+        ("results_dir", C.c_char * 256), ("fixed_frame", C.c_char * 64), ("base_frame", C.c_char * 64),
+        ("laser_frame", C.c_char * 64),
+        ("use_imu", C.c_int32), ("filter_local_map", C.c_int32), ("mapping", C.c_int32), ("publish_tf", C.c_int32),
+    ]
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("device", C.c_int32), ("n_streams", C.c_int32), ("max_points", C.c_int32), ("max_width", C.c_int32),
+        ("max_ring_points", C.c_int32), ("lm_apply_step_on_ftol", C.c_int32), ("pose_log_capacity", C.c_int32),
+        ("debug_buffers", C.c_int32),
+    ]
+
+
+class LmTrace(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("accepted", C.c_int32), ("termination", C.c_int32), ("pad", C.c_int32),
+                ("initial_cost", C.c_double), ("final_cost", C.c_double)]
+
+
+class StepInfo(C.Structure):
+    _fields_ = [("n_edges", C.c_int32), ("map_points", C.c_int32), ("matches", C.c_int32 * 2), ("lm", LmTrace * 2),
+                ("status", C.c_uint32), ("scan_index", C.c_int32)]
+
+
+NUM_KERNELS = 10
+
+
+class KernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 32), ("launches", C.c_int64), ("total_ms", C.c_double)]
+
+
+_lib = None
+
+
+def load():
+    """Load libliodom_hip.so.  Raises LiodomError if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB):
+        raise LiodomError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(the HIP extension is required; there is no CPU fallback)" % _LIB)
+    L = C.CDLL(_LIB, mode=C.RTLD_GLOBAL)
+    fp, dp, ip = C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    vp = C.c_void_p
+    L.liodom_last_error.restype = C.c_char_p
+    L.liodom_params_default.argtypes = [C.POINTER(Params)]
+    L.liodom_config_default.argtypes = [C.POINTER(Config)]
+    L.liodom_create.restype = C.c_int
+    L.liodom_create.argtypes = [C.POINTER(Params), C.POINTER(Config), C.POINTER(vp)]
+    L.liodom_destroy.argtypes = [vp]
+    L.liodom_extract_edges.restype = C.c_int
+    L.liodom_extract_edges.argtypes = [vp, C.c_int, fp, C.c_int64, C.c_int, C.c_int, fp, ip, ip, ip, C.c_int, ip]
+    L.liodom_odometry_step.restype = C.c_int
+    L.liodom_odometry_step.argtypes = [vp, C.c_int, fp, C.c_int, C.c_double, dp, C.POINTER(StepInfo)]
+    L.liodom_process_scan.restype = C.c_int
+    L.liodom_process_scan.argtypes = [vp, C.c_int, fp, C.c_int64, C.c_int, C.c_int, C.c_double, dp, C.POINTER(StepInfo)]
+    L.liodom_set_received_map.restype = C.c_int
+    L.liodom_set_received_map.argtypes = [vp, C.c_int, fp, C.c_int64]
+    L.liodom_alloc_resident.restype = C.c_int
+    L.liodom_alloc_resident.argtypes = [vp, C.c_int]
+    L.liodom_upload_scan.restype = C.c_int
+    L.liodom_upload_scan.argtypes = [vp, C.c_int, C.c_int, fp, C.c_int64]
+    L.liodom_process_resident.restype = C.c_int
+    L.liodom_process_resident.argtypes = [vp, C.c_int, C.c_int64, C.c_int, C.c_int, dp, C.POINTER(StepInfo)]
+    L.liodom_sync.restype = C.c_int
+    L.liodom_sync.argtypes = [vp]
+    L.liodom_get_pose_log.restype = C.c_int
+    L.liodom_get_pose_log.argtypes = [vp, C.c_int, C.c_int, C.c_int, dp, C.POINTER(StepInfo)]
+    L.liodom_reset.restype = C.c_int
+    L.liodom_reset.argtypes = [vp]
+    L.liodom_get_edges.restype = C.c_int
+    L.liodom_get_edges.argtypes = [vp, C.c_int, fp, ip, ip, ip, C.c_int, ip]
+    L.liodom_get_window.restype = C.c_int
+    L.liodom_get_window.argtypes = [vp, C.c_int, fp, C.c_int64, C.POINTER(C.c_int64), ip]
+    L.liodom_get_correspondences.restype = C.c_int
+    L.liodom_get_correspondences.argtypes = [vp, C.c_int, C.c_int, ip, ip, ip, C.c_int, ip]
+    L.liodom_get_curvature.restype = C.c_int
+    L.liodom_get_curvature.argtypes = [vp, C.c_int, dp, C.c_int64, ip]
+    L.liodom_set_profiling.restype = C.c_int
+    L.liodom_set_profiling.argtypes = [vp, C.c_int]
+    L.liodom_get_kernel_stats.restype = C.c_int
+    L.liodom_get_kernel_stats.argtypes = [vp, C.POINTER(KernelStat)]
+    L.liodom_reset_kernel_stats.restype = C.c_int
+    L.liodom_reset_kernel_stats.argtypes = [vp]
+    L.liodom_device_info.restype = C.c_int
+    L.liodom_device_info.argtypes = [vp, C.c_char_p, C.c_int, ip]
+    _lib = L
+    return L
+
+
+EXPORTED_SYMBOLS = [
+    "liodom_params_default", "liodom_config_default", "liodom_create", "liodom_destroy", "liodom_last_error",
+    "liodom_extract_edges", "liodom_odometry_step", "liodom_process_scan", "liodom_set_received_map",
+    "liodom_alloc_resident", "liodom_upload_scan", "liodom_process_resident", "liodom_sync", "liodom_get_pose_log",
+    "liodom_reset", "liodom_get_edges", "liodom_get_window", "liodom_get_correspondences", "liodom_get_curvature",
+    "liodom_set_profiling", "liodom_get_kernel_stats", "liodom_reset_kernel_stats", "liodom_device_info",
+]
+
+
+def make_params(**kw):
+    """Params with the defaults of Params::readParams (src/params.cc:40-109); `prev_frames`
+    is the ROS parameter behind local_map_size."""
+    p = Params()
+    load().liodom_params_default(C.byref(p))
+    if "prev_frames" in kw:
+        kw["local_map_size"] = kw.pop("prev_frames")
+    for k, v in kw.items():
+        setattr(p, k, v)
+    if "min_points_per_scan" not in kw:
+        p.min_points_per_scan = p.scan_regions * p.edges_per_region + 10  # params.cc:63
+    return p
+
+
+def make_config(**kw):
+    c = Config()
+    load().liodom_config_default(C.byref(c))
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+class Liodom:
+    """One handle = one GPU, `n_streams` lock-step LiDAR streams."""
+
+    def __init__(self, params, config):
+        self.L = load()
+        self.params, self.config = params, config
+        h = C.c_void_p()
+        rc = self.L.liodom_create(C.byref(params), C.byref(config), C.byref(h))
+        if rc != 0:
+            raise LiodomError("liodom_create failed (%d): %s" % (rc, self.L.liodom_last_error().decode()))
+        self.h = h
+        self.edge_cap = params.scan_lines * params.scan_regions * (params.edges_per_region + 1) + 64
+
+    def _check(self, rc):
+        if rc != 0:
+            raise LiodomError("libliodom_hip error %d: %s" % (rc, self.L.liodom_last_error().decode()))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.liodom_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # --- FeatureExtractor ---
+    def extract_edges(self, xyzi, height, width, stream=0):
+        x = np.ascontiguousarray(xyzi, dtype=np.float32).reshape(-1, 4)
+        cap = self.edge_cap
+        e = np.zeros((cap, 4), np.float32)
+        ring, idx, src = (np.zeros(cap, np.int32) for _ in range(3))
+        n = C.c_int32()
+        self._check(self.L.liodom_extract_edges(self.h, stream, _fp(x), x.shape[0], height, width, _fp(e), _ip(ring),
+                                                _ip(idx), _ip(src), cap, C.byref(n)))
+        k = n.value
+        return dict(edges=e[:k].copy(), ring=ring[:k].copy(), idx_in_ring=idx[:k].copy(), src=src[:k].copy())
+
+    def get_edges(self, stream=0):
+        cap = self.edge_cap
+        e = np.zeros((cap, 4), np.float32)
+        ring, idx, src = (np.zeros(cap, np.int32) for _ in range(3))
+        n = C.c_int32()
+        self._check(self.L.liodom_get_edges(self.h, stream, _fp(e), _ip(ring), _ip(idx), _ip(src), cap, C.byref(n)))
+        k = n.value
+        return dict(edges=e[:k].copy(), ring=ring[:k].copy(), idx_in_ring=idx[:k].copy(), src=src[:k].copy())
+
+    # --- LaserOdometer ---
+    def odometry_step(self, edges, stamp=0.0, stream=0):
+        e = np.ascontiguousarray(edges, dtype=np.float32).reshape(-1, 4)
+        pose = np.zeros(7)
+        info = StepInfo()
+        self._check(self.L.liodom_odometry_step(self.h, stream, _fp(e), e.shape[0], stamp, _dp(pose), C.byref(info)))
+        return pose, info
+
+    def process_scan(self, xyzi, height, width, stamp=0.0, stream=0):
+        x = np.ascontiguousarray(xyzi, dtype=np.float32).reshape(-1, 4)
+        pose = np.zeros(7)
+        info = StepInfo()
+        self._check(self.L.liodom_process_scan(self.h, stream, _fp(x), x.shape[0], height, width, stamp, _dp(pose),
+                                               C.byref(info)))
+        return pose, info
+
+    # --- resident replay ---
+    def alloc_resident(self, n_slots):
+        self._check(self.L.liodom_alloc_resident(self.h, n_slots))
+
+    def upload_scan(self, stream, slot, xyzi):
+        x = np.ascontiguousarray(xyzi, dtype=np.float32).reshape(-1, 4)
+        self._check(self.L.liodom_upload_scan(self.h, stream, slot, _fp(x), x.shape[0]))
+
+    def process_resident(self, slot, n, height, width, readback=True):
+        S = self.config.n_streams
+        if readback:
+            poses = np.zeros((S, 7))
+            infos = (StepInfo * S)()
+            self._check(self.L.liodom_process_resident(self.h, slot, n, height, width, _dp(poses), infos))
+            return poses, infos
+        self._check(self.L.liodom_process_resident(self.h, slot, n, height, width, None, None))
+        return None, None
+
+    def sync(self):
+        self._check(self.L.liodom_sync(self.h))
+
+    def reset(self):
+        self._check(self.L.liodom_reset(self.h))
+
+    def pose_log(self, stream, first, count):
+        poses = np.zeros((count, 7))
+        infos = (StepInfo * count)()
+        self._check(self.L.liodom_get_pose_log(self.h, stream, first, count, _dp(poses), infos))
+        return poses, infos
+
+    # --- inspection ---
+    def window(self, stream=0):
+        cap = self.edge_cap * int(self.params.local_map_size)
+        w = np.zeros((cap, 4), np.float32)
+        n = C.c_int64()
+        nf = C.c_int32()
+        self._check(self.L.liodom_get_window(self.h, stream, _fp(w), cap, C.byref(n), C.byref(nf)))
+        return w[:n.value].copy(), nf.value
+
+    def correspondences(self, it, stream=0):
+        cap = self.edge_cap
+        v, a, b = (np.zeros(cap, np.int32) for _ in range(3))
+        n = C.c_int32()
+        self._check(self.L.liodom_get_correspondences(self.h, stream, it, _ip(v), _ip(a), _ip(b), cap, C.byref(n)))
+        k = n.value
+        return v[:k].copy(), a[:k].copy(), b[:k].copy()
+
+    def curvature(self, stream=0):
+        cap = int(self.config.max_points) + 16
+        c = np.zeros(cap)
+        offs = np.zeros(self.params.scan_lines + 1, np.int32)
+        self._check(self.L.liodom_get_curvature(self.h, stream, _dp(c), cap, _ip(offs)))
+        return c[:offs[-1]].copy(), offs
+
+    # --- measurement ---
+    def set_profiling(self, on):
+        self._check(self.L.liodom_set_profiling(self.h, int(on)))
+
+    def kernel_stats(self):
+        st = (KernelStat * NUM_KERNELS)()
+        self._check(self.L.liodom_get_kernel_stats(self.h, st))
+        return {s.name.decode(): (int(s.launches), float(s.total_ms)) for s in st}
+
+    def reset_kernel_stats(self):
+        self._check(self.L.liodom_reset_kernel_stats(self.h))
+
+    def device_info(self):
+        buf = C.create_string_buffer(256)
+        cu = C.c_int32()
+        self._check(self.L.liodom_device_info(self.h, buf, 256, C.byref(cu)))
+        return buf.value.decode(), cu.value

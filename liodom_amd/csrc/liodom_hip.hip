@@ -1,0 +1,614 @@
+// liodom_hip.hip — host side of libliodom_hip.so: handle, HBM layout, launch sequencing and the
+// C-ABI declared in include/liodom_hip.h.  No torch types, no CPU fallback: every entry point
+// drives the HIP kernels of liodom_kernels.h or fails with an error code.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "liodom_kernels.h"
+
+using namespace liodom_dev;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess) {                                                                   \
+      char _buf[512];                                                                         \
+      snprintf(_buf, sizeof(_buf), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),    \
+               __FILE__, __LINE__);                                                           \
+      g_last_error = _buf;                                                                    \
+      return LIODOM_ERR_HIP;                                                                  \
+    }                                                                                         \
+  } while (0)
+
+enum KernelId {
+  KID_CLASSIFY = 0, KID_RING_EXTRACT, KID_COMPACT, KID_KNN, KID_LM, KID_HASH_CLEAR,
+  KID_WINDOW_INSERT, KID_HASH_ALLOC, KID_HASH_SCATTER, KID_OTHER
+};
+const char* kKernelNames[LIODOM_NUM_KERNELS] = {
+    "k_classify", "k_ring_extract", "k_compact_edges", "k_knn", "k_lm_solve",
+    "k_hash_clear", "k_window_insert", "k_hash_alloc", "k_hash_scatter", "other"};
+
+struct EventPair { hipEvent_t a, b; int kid; };
+
+}  // namespace
+
+struct liodom_handle {
+  liodom_params_t params;
+  liodom_config_t config;
+  DevView v{};
+  hipStream_t stream = nullptr;
+  hipEvent_t pose_event = nullptr;
+  int S = 1, H = 0, P = 0;
+  size_t ring_lds_bytes = 0;
+  // staging
+  float4* stage_in = nullptr;        // [S][max_points]  (host-provided scans / edges)
+  float4* resident = nullptr;        // [S][n_slots][max_points]
+  int n_slots = 0;
+  void* pinned = nullptr;            // pinned host scratch
+  size_t pinned_bytes = 0;
+  std::vector<void*> allocs;
+  // profiling
+  bool profiling = false;
+  std::vector<EventPair> ev_pool;
+  size_t ev_used = 0;
+  double k_ms[LIODOM_NUM_KERNELS] = {0};
+  long long k_count[LIODOM_NUM_KERNELS] = {0};
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(liodom_handle* h, T** p, size_t count, int memset_value = 0) {
+  void* raw = nullptr;
+  const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+  HIP_TRY(hipMalloc(&raw, bytes));
+  h->allocs.push_back(raw);
+  HIP_TRY(hipMemsetAsync(raw, memset_value, bytes, h->stream));
+  *p = static_cast<T*>(raw);
+  return LIODOM_OK;
+}
+
+int drain_events(liodom_handle* h) {
+  if (h->ev_used == 0) return LIODOM_OK;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  for (size_t i = 0; i < h->ev_used; i++) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev_pool[i].a, h->ev_pool[i].b));
+    h->k_ms[h->ev_pool[i].kid] += ms;
+    h->k_count[h->ev_pool[i].kid] += 1;
+  }
+  h->ev_used = 0;
+  return LIODOM_OK;
+}
+
+struct ProfScope {
+  liodom_handle* h;
+  EventPair* ep = nullptr;
+  ProfScope(liodom_handle* hh, int kid) : h(hh) {
+    if (!h->profiling) return;
+    if (h->ev_used == h->ev_pool.size()) {
+      if (h->ev_pool.size() < 4096) {
+        EventPair e; e.kid = kid;
+        if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
+        h->ev_pool.push_back(e);
+      } else {
+        drain_events(h);
+      }
+    }
+    ep = &h->ev_pool[h->ev_used++];
+    ep->kid = kid;
+    hipEventRecord(ep->a, h->stream);
+  }
+  ~ProfScope() { if (ep) hipEventRecord(ep->b, h->stream); }
+};
+
+inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---- launch sequences -----------------------------------------------------------------------
+// Feature extraction of `count` streams starting at s0; input scan for stream s0+i at in + i*stride.
+int launch_extract(liodom_handle* h, int s0, int count, const float4* in, size_t in_stride, int n,
+                   int height, int width) {
+  const DevView& v = h->v;
+  {
+    ProfScope ps(h, KID_CLASSIFY);
+    dim3 grid(cdiv((long long)n + 256, 256), count);
+    hipLaunchKernelGGL(k_classify, grid, dim3(256), 0, h->stream, v, s0, in, in_stride, n, height, width);
+  }
+  {
+    ProfScope ps(h, KID_RING_EXTRACT);
+    dim3 grid(h->H, count);
+    hipLaunchKernelGGL(k_ring_extract, grid, dim3(256), h->ring_lds_bytes, h->stream, v, s0, in,
+                       in_stride, n, height, width);
+  }
+  {
+    ProfScope ps(h, KID_COMPACT);
+    hipLaunchKernelGGL(k_compact_edges, dim3(count), dim3(256), 0, h->stream, v, s0);
+  }
+  HIP_TRY(hipGetLastError());
+  return LIODOM_OK;
+}
+
+// Odometry on the dense edges already on the device.  If pose_dst != nullptr the poses + infos
+// of the streams are copied to pinned memory right after the solve and pose_event is recorded,
+// so the host can pick them up while the window / hash rebuild still runs.
+int launch_odometry(liodom_handle* h, int s0, int count, bool want_readback) {
+  const DevView& v = h->v;
+  const int knn_blocks = cdiv(v.edge_cap, 256 / kKnnGroup);
+  for (int it = 0; it < 2; it++) {
+    {
+      ProfScope ps(h, KID_KNN);
+      hipLaunchKernelGGL(k_knn, dim3(knn_blocks, count), dim3(256), 0, h->stream, v, s0, it);
+    }
+    {
+      ProfScope ps(h, KID_LM);
+      hipLaunchKernelGGL(k_lm_solve, dim3(count), dim3(kLmThreads), 0, h->stream, v, s0, it);
+    }
+  }
+  if (want_readback) {
+    // StreamState holds the published pose in final_odom and the diagnostics in info
+    HIP_TRY(hipMemcpyAsync(h->pinned, v.state + s0, sizeof(StreamState) * (size_t)count,
+                           hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipEventRecord(h->pose_event, h->stream));
+  }
+  const int map_blocks = cdiv(v.map_cap, 256);
+  {
+    ProfScope ps(h, KID_HASH_CLEAR);
+    hipLaunchKernelGGL(k_hash_clear, dim3(map_blocks, count), dim3(256), 0, h->stream, v, s0);
+  }
+  {
+    ProfScope ps(h, KID_WINDOW_INSERT);
+    hipLaunchKernelGGL(k_window_insert, dim3(map_blocks, count), dim3(256), 0, h->stream, v, s0);
+  }
+  {
+    ProfScope ps(h, KID_HASH_ALLOC);
+    hipLaunchKernelGGL(k_hash_alloc, dim3(map_blocks, count), dim3(256), 0, h->stream, v, s0);
+  }
+  {
+    ProfScope ps(h, KID_HASH_SCATTER);
+    hipLaunchKernelGGL(k_hash_scatter, dim3(map_blocks, count), dim3(256), 0, h->stream, v, s0);
+  }
+  HIP_TRY(hipGetLastError());
+  return LIODOM_OK;
+}
+
+void pose_from_state(const StreamState& st, double* pose, liodom_step_info_t* info) {
+  if (pose) {
+    double q[4];
+    quat_from_rot(st.final_odom, q);
+    pose[0] = q[0]; pose[1] = q[1]; pose[2] = q[2]; pose[3] = q[3];
+    pose[4] = st.final_odom[3]; pose[5] = st.final_odom[7]; pose[6] = st.final_odom[11];
+  }
+  if (info) *info = st.info;
+}
+
+int check_stream(liodom_handle* h, int stream) {
+  if (!h) return LIODOM_ERR_INVALID_ARG;
+  if (stream < 0 || stream >= h->S) { g_last_error = "stream index out of range"; return LIODOM_ERR_INVALID_ARG; }
+  return LIODOM_OK;
+}
+
+int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+int reset_state(liodom_handle* h) {
+  std::vector<StreamState> init((size_t)h->S);
+  for (auto& st : init) {
+    std::memset(&st, 0, sizeof(st));
+    iso_identity(st.odom); iso_identity(st.prev_odom); iso_identity(st.final_odom);
+    st.param_q[3] = 1.0;
+  }
+  HIP_TRY(hipMemcpyAsync(h->v.state, init.data(), sizeof(StreamState) * init.size(), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemsetAsync(h->v.cell_key, 0xFF, sizeof(unsigned long long) * (size_t)h->S * h->v.table_size, h->stream));
+  HIP_TRY(hipMemsetAsync(h->v.cell_cnt, 0, sizeof(unsigned int) * (size_t)h->S * h->v.table_size, h->stream));
+  HIP_TRY(hipMemsetAsync(h->v.cell_fill, 0, sizeof(unsigned int) * (size_t)h->S * h->v.table_size, h->stream));
+  HIP_TRY(hipMemsetAsync(h->v.win_n, 0, sizeof(int) * (size_t)h->S * h->P, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return LIODOM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* liodom_last_error(void) { return g_last_error.c_str(); }
+
+void liodom_params_default(liodom_params_t* p) {
+  if (!p) return;
+  std::memset(p, 0, sizeof(*p));
+  p->min_range = 3.0;            // params.cc:40
+  p->max_range = 75.0;           // params.cc:44
+  p->lidar_type = 0;             // params.cc:48
+  p->scan_lines = 64;            // params.cc:52
+  p->scan_regions = 8;           // params.cc:56
+  p->edges_per_region = 10;      // params.cc:60
+  p->min_points_per_scan = 8 * 10 + 10;  // params.cc:63
+  p->local_map_size = 5;         // params.cc:90-93
+  p->save_results = 0;           // params.cc:66
+  std::strcpy(p->results_dir, "~/");        // params.cc:70
+  std::strcpy(p->fixed_frame, "odom");      // params.cc:74
+  std::strcpy(p->base_frame, "base_link");  // params.cc:78
+  p->laser_frame[0] = 0;                    // params.cc:82
+  p->use_imu = 0; p->filter_local_map = 0; p->mapping = 0;   // params.cc:96,100,104
+  p->publish_tf = 1;                                         // params.cc:108
+}
+
+void liodom_config_default(liodom_config_t* c) {
+  if (!c) return;
+  std::memset(c, 0, sizeof(*c));
+  c->device = 0; c->n_streams = 1; c->max_points = 64 * 1800; c->max_width = 1800;
+  c->max_ring_points = 0; c->lm_apply_step_on_ftol = 0; c->pose_log_capacity = 1024; c->debug_buffers = 0;
+}
+
+int liodom_create(const liodom_params_t* params, const liodom_config_t* config, liodom_handle_t** out) {
+  if (!params || !config || !out) return LIODOM_ERR_INVALID_ARG;
+  *out = nullptr;
+  if (params->scan_lines < 1 || params->scan_lines > 254 || params->scan_regions < 1 ||
+      params->edges_per_region < 0 || params->local_map_size < 1 || params->local_map_size > (uint64_t)kMaxFrames ||
+      config->n_streams < 1 || config->max_points < 1 || !(params->max_range > params->min_range)) {
+    g_last_error = "liodom_create: parameter out of range";
+    return LIODOM_ERR_INVALID_ARG;
+  }
+  if (params->use_imu || params->filter_local_map || params->mapping) {
+    g_last_error = "liodom_create: use_imu / filter_local_map / mapping are not implemented on the GPU path yet";
+    return LIODOM_ERR_UNSUPPORTED;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    g_last_error = "no HIP device available (libliodom_hip has no CPU fallback)";
+    return LIODOM_ERR_NO_DEVICE;
+  }
+  if (config->device < 0 || config->device >= ndev) { g_last_error = "bad device ordinal"; return LIODOM_ERR_INVALID_ARG; }
+  HIP_TRY(hipSetDevice(config->device));
+  liodom_handle* h = new liodom_handle();
+  h->params = *params;
+  h->config = *config;
+  h->S = config->n_streams; h->H = params->scan_lines; h->P = (int)params->local_map_size;
+  int rc = LIODOM_OK;
+  auto fail = [&](int code) { liodom_destroy(h); return code; };
+  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { g_last_error = "hipStreamCreate failed"; return fail(LIODOM_ERR_HIP); }
+  if (hipEventCreateWithFlags(&h->pose_event, hipEventDisableTiming) != hipSuccess) { g_last_error = "hipEventCreate failed"; return fail(LIODOM_ERR_HIP); }
+
+  DevView& v = h->v;
+  v.min_range = params->min_range; v.max_range = params->max_range;
+  v.lidar_type = params->lidar_type; v.scan_lines = params->scan_lines;
+  v.scan_regions = params->scan_regions; v.edges_per_region = params->edges_per_region;
+  v.min_points_per_scan = (long long)params->min_points_per_scan;
+  v.prev_frames = h->P;
+  v.apply_on_ftol = config->lm_apply_step_on_ftol;
+  v.n_streams = h->S;
+  v.max_points = config->max_points;
+  int width = config->max_width > 0 ? config->max_width : std::max(1, config->max_points / params->scan_lines);
+  int ring_cap = config->max_ring_points > 0 ? config->max_ring_points : round_up(width + width / 8, 256);
+  ring_cap = round_up(std::max(ring_cap, 256), 16);
+  if (ring_cap > 6144) { g_last_error = "max_ring_points exceeds the 160 KiB LDS tile (6144 points)"; return fail(LIODOM_ERR_CAPACITY); }
+  v.ring_cap = ring_cap;
+  h->ring_lds_bytes = (size_t)ring_cap * (8 + 12 + 4 + 1) + 64;
+  v.slots_per_ring = params->scan_regions * (params->edges_per_region + 1);
+  v.edge_cap = round_up(std::max(1, h->H * v.slots_per_ring), 64);
+  v.map_cap = v.edge_cap * h->P;
+  int ts = 1024;
+  while (ts < 2 * v.map_cap) ts <<= 1;
+  v.table_size = ts;
+  v.pose_log_cap = std::max(1, config->pose_log_capacity);
+  v.debug = config->debug_buffers;
+  v.ring_id_stride = (size_t)round_up(config->max_points + 512, 256);
+
+  const size_t S = (size_t)h->S;
+#define ALLOC(ptr, count, fill) do { rc = dev_alloc(h, &(ptr), (count), (fill)); if (rc != LIODOM_OK) return fail(rc); } while (0)
+  ALLOC(v.state, S, 0);
+  ALLOC(v.ring_id, S * v.ring_id_stride, 0xFF);
+  ALLOC(v.edges_pad, S * h->H * v.slots_per_ring, 0);
+  ALLOC(v.edges_pad_meta, S * h->H * v.slots_per_ring, 0);
+  ALLOC(v.ring_nedges, S * h->H, 0);
+  ALLOC(v.ring_npoints, S * h->H, 0);
+  if (v.debug) ALLOC(v.curv_dbg, S * h->H * v.ring_cap, 0); else v.curv_dbg = nullptr;
+  ALLOC(v.edges, S * v.edge_cap, 0);
+  ALLOC(v.edges_meta, S * v.edge_cap, 0);
+  ALLOC(v.corr_a, S * v.edge_cap, 0);
+  ALLOC(v.corr_b, S * v.edge_cap, 0);
+  ALLOC(v.corr_idx, S * 2 * v.edge_cap, 0xFF);
+  ALLOC(v.win_pts, S * h->P * v.edge_cap, 0);
+  ALLOC(v.win_n, S * h->P, 0);
+  ALLOC(v.win_base, S * (h->P + 1), 0);
+  ALLOC(v.win_slot, S * h->P, 0);
+  ALLOC(v.cell_key, S * v.table_size, 0xFF);
+  ALLOC(v.cell_cnt, S * v.table_size, 0);
+  ALLOC(v.cell_start, S * v.table_size, 0);
+  ALLOC(v.cell_fill, S * v.table_size, 0);
+  ALLOC(v.used_cells, S * v.map_cap, 0);
+  ALLOC(v.pt_cell, S * v.map_cap, 0xFF);
+  ALLOC(v.sorted_pts, S * v.map_cap, 0);
+  ALLOC(v.pose_log, S * v.pose_log_cap * 7, 0);
+  ALLOC(v.info_log, S * v.pose_log_cap, 0);
+  ALLOC(h->stage_in, S * (size_t)config->max_points, 0);
+#undef ALLOC
+  h->pinned_bytes = std::max<size_t>(sizeof(StreamState) * S, 1 << 16);
+  if (hipHostMalloc(&h->pinned, h->pinned_bytes, hipHostMallocDefault) != hipSuccess) { g_last_error = "hipHostMalloc failed"; return fail(LIODOM_ERR_HIP); }
+  if (h->ring_lds_bytes > 48 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ring_extract), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)h->ring_lds_bytes) != hipSuccess) {
+      g_last_error = "hipFuncSetAttribute(max dynamic LDS) failed"; return fail(LIODOM_ERR_HIP);
+    }
+  }
+  rc = reset_state(h);
+  if (rc != LIODOM_OK) return fail(rc);
+  *out = h;
+  return LIODOM_OK;
+}
+
+void liodom_destroy(liodom_handle_t* h) {
+  if (!h) return;
+  if (h->stream) hipStreamSynchronize(h->stream);
+  for (void* p : h->allocs) hipFree(p);
+  if (h->resident) hipFree(h->resident);
+  if (h->pinned) hipHostFree(h->pinned);
+  for (auto& e : h->ev_pool) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+  if (h->pose_event) hipEventDestroy(h->pose_event);
+  if (h->stream) hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int liodom_reset(liodom_handle_t* h) {
+  if (!h) return LIODOM_ERR_INVALID_ARG;
+  return reset_state(h);
+}
+
+static int copy_edges_out(liodom_handle_t* h, int stream, float* edges_xyzi, int32_t* edge_ring,
+                          int32_t* edge_idx, int32_t* edge_src, int cap, int* n_edges) {
+  StreamState st;
+  HIP_TRY(hipMemcpyAsync(&st, h->v.state + stream, sizeof(st), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  const int E = st.n_edges;
+  if (n_edges) *n_edges = E;
+  if (E > cap) { g_last_error = "edge buffer too small"; return LIODOM_ERR_CAPACITY; }
+  if (E == 0) return LIODOM_OK;
+  if (edges_xyzi)
+    HIP_TRY(hipMemcpyAsync(edges_xyzi, h->v.edges + (size_t)stream * h->v.edge_cap, sizeof(float4) * (size_t)E, hipMemcpyDeviceToHost, h->stream));
+  std::vector<int4> meta;
+  if (edge_ring || edge_idx || edge_src) {
+    meta.resize((size_t)E);
+    HIP_TRY(hipMemcpyAsync(meta.data(), h->v.edges_meta + (size_t)stream * h->v.edge_cap, sizeof(int4) * (size_t)E, hipMemcpyDeviceToHost, h->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  for (int i = 0; i < E && !meta.empty(); i++) {
+    if (edge_ring) edge_ring[i] = meta[i].x;
+    if (edge_idx) edge_idx[i] = meta[i].y;
+    if (edge_src) edge_src[i] = meta[i].z;
+  }
+  return LIODOM_OK;
+}
+
+int liodom_extract_edges(liodom_handle_t* h, int stream, const float* xyzi, int64_t n, int height,
+                         int width, float* edges_xyzi, int32_t* edge_ring, int32_t* edge_idx,
+                         int32_t* edge_src, int cap, int* n_edges) {
+  int rc = check_stream(h, stream);
+  if (rc) return rc;
+  if (n < 0 || n > h->v.max_points || (n > 0 && !xyzi)) { g_last_error = "bad point count"; return LIODOM_ERR_CAPACITY; }
+  float4* in = h->stage_in + (size_t)stream * h->v.max_points;
+  if (n) HIP_TRY(hipMemcpyAsync(in, xyzi, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, h->stream));
+  rc = launch_extract(h, stream, 1, in, 0, (int)n, height, width);
+  if (rc) return rc;
+  return copy_edges_out(h, stream, edges_xyzi, edge_ring, edge_idx, edge_src, cap, n_edges);
+}
+
+int liodom_get_edges(liodom_handle_t* h, int stream, float* edges_xyzi, int32_t* edge_ring,
+                     int32_t* edge_idx, int32_t* edge_src, int cap, int* n_edges) {
+  int rc = check_stream(h, stream);
+  if (rc) return rc;
+  return copy_edges_out(h, stream, edges_xyzi, edge_ring, edge_idx, edge_src, cap, n_edges);
+}
+
+static int wait_pose(liodom_handle_t* h, int s0, int count, double* pose_out, liodom_step_info_t* info) {
+  HIP_TRY(hipEventSynchronize(h->pose_event));
+  const StreamState* st = static_cast<const StreamState*>(h->pinned);
+  for (int i = 0; i < count; i++)
+    pose_from_state(st[i], pose_out ? pose_out + 7 * i : nullptr, info ? info + i : nullptr);
+  (void)s0;
+  return LIODOM_OK;
+}
+
+int liodom_odometry_step(liodom_handle_t* h, int stream, const float* edges_xyzi, int n_edges,
+                         double stamp, double* pose_out, liodom_step_info_t* info) {
+  (void)stamp;
+  int rc = check_stream(h, stream);
+  if (rc) return rc;
+  if (n_edges < 0 || n_edges > h->v.edge_cap || (n_edges > 0 && !edges_xyzi)) { g_last_error = "edge count exceeds capacity"; return LIODOM_ERR_CAPACITY; }
+  if (n_edges)
+    HIP_TRY(hipMemcpyAsync(h->v.edges + (size_t)stream * h->v.edge_cap, edges_xyzi, sizeof(float4) * (size_t)n_edges, hipMemcpyHostToDevice, h->stream));
+  {
+    ProfScope ps(h, KID_OTHER);
+    hipLaunchKernelGGL(k_set_edges, dim3(1), dim3(64), 0, h->stream, h->v, stream, n_edges);
+  }
+  rc = launch_odometry(h, stream, 1, true);
+  if (rc) return rc;
+  return wait_pose(h, stream, 1, pose_out, info);
+}
+
+int liodom_process_scan(liodom_handle_t* h, int stream, const float* xyzi, int64_t n, int height,
+                        int width, double stamp, double* pose_out, liodom_step_info_t* info) {
+  (void)stamp;
+  int rc = check_stream(h, stream);
+  if (rc) return rc;
+  if (n < 0 || n > h->v.max_points || (n > 0 && !xyzi)) { g_last_error = "bad point count"; return LIODOM_ERR_CAPACITY; }
+  float4* in = h->stage_in + (size_t)stream * h->v.max_points;
+  if (n) HIP_TRY(hipMemcpyAsync(in, xyzi, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, h->stream));
+  rc = launch_extract(h, stream, 1, in, 0, (int)n, height, width);
+  if (rc) return rc;
+  rc = launch_odometry(h, stream, 1, true);
+  if (rc) return rc;
+  return wait_pose(h, stream, 1, pose_out, info);
+}
+
+int liodom_set_received_map(liodom_handle_t* h, int stream, const float* xyzi, int64_t n) {
+  (void)xyzi; (void)n;
+  int rc = check_stream(h, stream);
+  if (rc) return rc;
+  g_last_error = "mapping mode is not implemented on the GPU path yet";
+  return LIODOM_ERR_UNSUPPORTED;
+}
+
+int liodom_alloc_resident(liodom_handle_t* h, int n_slots) {
+  if (!h || n_slots < 1) return LIODOM_ERR_INVALID_ARG;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (h->resident) { hipFree(h->resident); h->resident = nullptr; h->n_slots = 0; }
+  const size_t bytes = sizeof(float4) * (size_t)h->S * (size_t)n_slots * (size_t)h->v.max_points;
+  void* raw = nullptr;
+  HIP_TRY(hipMalloc(&raw, bytes));
+  h->resident = static_cast<float4*>(raw);
+  h->n_slots = n_slots;
+  return LIODOM_OK;
+}
+
+int liodom_upload_scan(liodom_handle_t* h, int stream, int slot, const float* xyzi, int64_t n) {
+  int rc = check_stream(h, stream);
+  if (rc) return rc;
+  if (!h->resident || slot < 0 || slot >= h->n_slots || n < 0 || n > h->v.max_points) { g_last_error = "bad resident slot"; return LIODOM_ERR_INVALID_ARG; }
+  float4* dst = h->resident + ((size_t)slot * h->S + stream) * (size_t)h->v.max_points;
+  if (n) HIP_TRY(hipMemcpy(dst, xyzi, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice));
+  return LIODOM_OK;
+}
+
+int liodom_process_resident(liodom_handle_t* h, int slot, int64_t n, int height, int width,
+                            double* poses_out, liodom_step_info_t* infos_out) {
+  if (!h) return LIODOM_ERR_INVALID_ARG;
+  if (!h->resident || slot < 0 || slot >= h->n_slots || n < 0 || n > h->v.max_points) { g_last_error = "bad resident slot"; return LIODOM_ERR_INVALID_ARG; }
+  // resident layout: [slot][stream][max_points] so that one lock-step launch reads a contiguous
+  // block with stride max_points between streams
+  const float4* in = h->resident + (size_t)slot * h->S * (size_t)h->v.max_points;
+  int rc = launch_extract(h, 0, h->S, in, (size_t)h->v.max_points, (int)n, height, width);
+  if (rc) return rc;
+  const bool rb = poses_out != nullptr || infos_out != nullptr;
+  rc = launch_odometry(h, 0, h->S, rb);
+  if (rc) return rc;
+  if (rb) return wait_pose(h, 0, h->S, poses_out, infos_out);
+  return LIODOM_OK;
+}
+
+int liodom_sync(liodom_handle_t* h) {
+  if (!h) return LIODOM_ERR_INVALID_ARG;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return LIODOM_OK;
+}
+
+int liodom_get_pose_log(liodom_handle_t* h, int stream, int first, int count, double* poses_out,
+                        liodom_step_info_t* infos_out) {
+  int rc = check_stream(h, stream);
+  if (rc) return rc;
+  if (first < 0 || count < 0 || first + count > h->v.pose_log_cap) { g_last_error = "pose log range"; return LIODOM_ERR_INVALID_ARG; }
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (poses_out && count)
+    HIP_TRY(hipMemcpy(poses_out, h->v.pose_log + ((size_t)stream * h->v.pose_log_cap + first) * 7, sizeof(double) * 7 * (size_t)count, hipMemcpyDeviceToHost));
+  if (infos_out && count)
+    HIP_TRY(hipMemcpy(infos_out, h->v.info_log + (size_t)stream * h->v.pose_log_cap + first, sizeof(liodom_step_info_t) * (size_t)count, hipMemcpyDeviceToHost));
+  return LIODOM_OK;
+}
+
+int liodom_get_window(liodom_handle_t* h, int stream, float* xyzi, int64_t cap, int64_t* n_points, int* n_frames) {
+  int rc = check_stream(h, stream);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  StreamState st;
+  HIP_TRY(hipMemcpy(&st, h->v.state + stream, sizeof(st), hipMemcpyDeviceToHost));
+  const int P = h->P;
+  std::vector<int> base((size_t)P + 1), slot((size_t)P);
+  HIP_TRY(hipMemcpy(base.data(), h->v.win_base + (size_t)stream * (P + 1), sizeof(int) * (P + 1), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(slot.data(), h->v.win_slot + (size_t)stream * P, sizeof(int) * P, hipMemcpyDeviceToHost));
+  if (n_points) *n_points = st.n_map;
+  if (n_frames) *n_frames = st.n_frames;
+  if (st.n_map > cap) { g_last_error = "window buffer too small"; return LIODOM_ERR_CAPACITY; }
+  for (int j = 0; j < st.n_frames && xyzi; j++) {
+    const int cnt = base[j + 1] - base[j];
+    if (cnt > 0)
+      HIP_TRY(hipMemcpy(xyzi + 4 * (size_t)base[j], h->v.win_pts + ((size_t)stream * P + slot[j]) * h->v.edge_cap,
+                        sizeof(float4) * (size_t)cnt, hipMemcpyDeviceToHost));
+  }
+  return LIODOM_OK;
+}
+
+int liodom_get_correspondences(liodom_handle_t* h, int stream, int it, int32_t* valid, int32_t* idx_a,
+                               int32_t* idx_b, int cap, int* n) {
+  int rc = check_stream(h, stream);
+  if (rc) return rc;
+  if (it < 0 || it > 1) return LIODOM_ERR_INVALID_ARG;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  StreamState st;
+  HIP_TRY(hipMemcpy(&st, h->v.state + stream, sizeof(st), hipMemcpyDeviceToHost));
+  const int E = st.n_edges;
+  if (n) *n = E;
+  if (E > cap) { g_last_error = "correspondence buffer too small"; return LIODOM_ERR_CAPACITY; }
+  std::vector<int2> ci((size_t)std::max(E, 1));
+  if (E) HIP_TRY(hipMemcpy(ci.data(), h->v.corr_idx + ((size_t)stream * 2 + it) * h->v.edge_cap, sizeof(int2) * (size_t)E, hipMemcpyDeviceToHost));
+  for (int i = 0; i < E; i++) {
+    if (valid) valid[i] = ci[i].x >= 0 ? 1 : 0;
+    if (idx_a) idx_a[i] = ci[i].x;
+    if (idx_b) idx_b[i] = ci[i].y;
+  }
+  return LIODOM_OK;
+}
+
+int liodom_get_curvature(liodom_handle_t* h, int stream, double* curv, int64_t cap, int32_t* ring_offsets) {
+  int rc = check_stream(h, stream);
+  if (rc) return rc;
+  if (!h->v.curv_dbg) { g_last_error = "create the handle with debug_buffers = 1"; return LIODOM_ERR_UNSUPPORTED; }
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  std::vector<int> np((size_t)h->H);
+  HIP_TRY(hipMemcpy(np.data(), h->v.ring_npoints + (size_t)stream * h->H, sizeof(int) * h->H, hipMemcpyDeviceToHost));
+  int64_t off = 0;
+  for (int r = 0; r < h->H; r++) {
+    if (ring_offsets) ring_offsets[r] = (int32_t)off;
+    const int cnt = std::min(np[r], h->v.ring_cap);
+    if (off + cnt > cap) { g_last_error = "curvature buffer too small"; return LIODOM_ERR_CAPACITY; }
+    if (cnt && curv)
+      HIP_TRY(hipMemcpy(curv + off, h->v.curv_dbg + ((size_t)stream * h->H + r) * h->v.ring_cap, sizeof(double) * (size_t)cnt, hipMemcpyDeviceToHost));
+    off += cnt;
+  }
+  if (ring_offsets) ring_offsets[h->H] = (int32_t)off;
+  return LIODOM_OK;
+}
+
+int liodom_set_profiling(liodom_handle_t* h, int enable) {
+  if (!h) return LIODOM_ERR_INVALID_ARG;
+  int rc = drain_events(h);
+  h->profiling = enable != 0;
+  return rc;
+}
+
+int liodom_get_kernel_stats(liodom_handle_t* h, liodom_kernel_stat_t* stats) {
+  if (!h || !stats) return LIODOM_ERR_INVALID_ARG;
+  int rc = drain_events(h);
+  if (rc) return rc;
+  for (int i = 0; i < LIODOM_NUM_KERNELS; i++) {
+    std::memset(&stats[i], 0, sizeof(stats[i]));
+    std::strncpy(stats[i].name, kKernelNames[i], sizeof(stats[i].name) - 1);
+    stats[i].launches = h->k_count[i];
+    stats[i].total_ms = h->k_ms[i];
+  }
+  return LIODOM_OK;
+}
+
+int liodom_reset_kernel_stats(liodom_handle_t* h) {
+  if (!h) return LIODOM_ERR_INVALID_ARG;
+  int rc = drain_events(h);
+  for (int i = 0; i < LIODOM_NUM_KERNELS; i++) { h->k_ms[i] = 0; h->k_count[i] = 0; }
+  return rc;
+}
+
+int liodom_device_info(liodom_handle_t* h, char* name, int name_cap, int* compute_units) {
+  if (!h) return LIODOM_ERR_INVALID_ARG;
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, h->config.device));
+  if (name && name_cap > 0) { std::strncpy(name, prop.name, (size_t)name_cap - 1); name[name_cap - 1] = 0; }
+  if (compute_units) *compute_units = prop.multiProcessorCount;
+  return LIODOM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,508 @@
+// liodom_math.h — arithmetic leaf functions of the MI355X path (host + device).
+//
+// Everything here is straight-line FP code without wave intrinsics, so the same source is used
+// by the HIP kernels and can be compiled by g++ for CPU cross-checks against the oracle
+// (tests/hostcheck.cc).  Build with -ffp-contract=off: edge sets and kNN ordering must be
+// bit-exact with the reference's non-FMA x86-64 arithmetic.
+//
+// Reference citations are relative to /root/reference.
+#pragma once
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#define LD_HD __host__ __device__ __forceinline__
+#else
+#define LD_HD inline
+#endif
+
+namespace liodom_dev {
+
+constexpr int kJacobiSweeps = 8;          // fixed sweep count of the 3x3 eigenvalue iteration
+constexpr int kLmMaxIterations = 4;       // src/laser_odometry.cc:214
+constexpr double kHuberA = 0.2;           // src/laser_odometry.cc:201
+constexpr double kPi = 3.14159265358979323846;  // M_PI
+
+// finite test without libm / header dependencies (inf - inf and NaN - NaN are NaN)
+LD_HD bool ld_isfinite(double x) { return (x - x) == 0.0; }
+
+// ---------------------------------------------------------------------------------------
+// Ring split (src/feature_extractor.cc:84-179)
+// ---------------------------------------------------------------------------------------
+// isValidPoint (:84-102).  dist is the XY range.
+LD_HD bool valid_point(double x, double y, double z, double min_range, double max_range,
+                       double* dist) {
+  bool valid = true;
+  if (!(ld_isfinite(x) && ld_isfinite(y) && ld_isfinite(z))) valid = false;
+  *dist = sqrt(x * x + y * y);
+  if (*dist > max_range || *dist < min_range) valid = false;
+  return valid;
+}
+
+// Velodyne elevation binning (:127-151).  Returns -1 when the point is dropped.
+LD_HD int velodyne_ring(double z, double dist, int scan_lines) {
+  const double angle = atan(z / dist) * 180 / kPi;
+  int scan_id;
+  if (scan_lines == 64) {
+    if (angle >= -8.83) scan_id = int((2 - angle) * 3.0 + 0.5);
+    else scan_id = scan_lines / 2 + int((-8.83 - angle) * 2.0 + 0.5);
+    if (angle > 2 || angle < -24.33 || scan_id > 63 || scan_id < 0) return -1;
+  } else if (scan_lines == 32) {
+    scan_id = int((angle + 92.0 / 3.0) * 3.0 / 4.0);
+    if (scan_id > (scan_lines - 1) || scan_id < 0) return -1;
+  } else if (scan_lines == 16) {
+    scan_id = int((angle + 15) / 2 + 0.5);
+    if (scan_id > (scan_lines - 1) || scan_id < 0) return -1;
+  } else {
+    return -1;
+  }
+  return scan_id;
+}
+
+// ---------------------------------------------------------------------------------------
+// Curvature stencil (src/feature_extractor.cc:196-229): FP64, summed left to right.
+// ---------------------------------------------------------------------------------------
+template <typename F>
+LD_HD double stencil_axis(const F* p, int j) {
+  return (double)p[j - 5] + (double)p[j - 4] + (double)p[j - 3] + (double)p[j - 2] +
+         (double)p[j - 1] - 10 * (double)p[j] + (double)p[j + 1] + (double)p[j + 2] +
+         (double)p[j + 3] + (double)p[j + 4] + (double)p[j + 5];
+}
+template <typename F>
+LD_HD double curvature(const F* px, const F* py, const F* pz, int j) {
+  const double dx = stencil_axis(px, j), dy = stencil_axis(py, j), dz = stencil_axis(pz, j);
+  return dx * dx + dy * dy + dz * dz;
+}
+// squared gap between consecutive ring points i and k (:281-289, :297-305)
+template <typename F>
+LD_HD double gap_sq(const F* px, const F* py, const F* pz, int i, int k) {
+  const double dx = (double)px[i] - (double)px[k];
+  const double dy = (double)py[i] - (double)py[k];
+  const double dz = (double)pz[i] - (double)pz[k];
+  return dx * dx + dy * dy + dz * dz;
+}
+
+// ---------------------------------------------------------------------------------------
+// Pose helpers.  T = 3x4 row-major [R | t] (Eigen::Isometry3d::matrix() top rows).
+// ---------------------------------------------------------------------------------------
+LD_HD void iso_identity(double* T) {
+  for (int i = 0; i < 12; i++) T[i] = 0.0;
+  T[0] = T[5] = T[10] = 1.0;
+}
+LD_HD void iso_mul(const double* A, const double* B, double* C) {
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 3; c++)
+      C[r * 4 + c] = A[r * 4 + 0] * B[0 * 4 + c] + A[r * 4 + 1] * B[1 * 4 + c] + A[r * 4 + 2] * B[2 * 4 + c];
+    C[r * 4 + 3] = A[r * 4 + 0] * B[3] + A[r * 4 + 1] * B[7] + A[r * 4 + 2] * B[11] + A[r * 4 + 3];
+  }
+}
+LD_HD void iso_inverse(const double* A, double* C) {
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) C[r * 4 + c] = A[c * 4 + r];
+  for (int r = 0; r < 3; r++)
+    C[r * 4 + 3] = -(C[r * 4 + 0] * A[3] + C[r * 4 + 1] * A[7] + C[r * 4 + 2] * A[11]);
+}
+// Eigen::Quaterniond(Matrix3d) (src/laser_odometry.cc:186); q = [x y z w]
+LD_HD void quat_from_rot(const double* T, double* q) {
+  double t = T[0] + T[5] + T[10];
+  if (t > 0.0) {
+    t = sqrt(t + 1.0);
+    q[3] = 0.5 * t;
+    t = 0.5 / t;
+    q[0] = (T[9] - T[6]) * t;
+    q[1] = (T[2] - T[8]) * t;
+    q[2] = (T[4] - T[1]) * t;
+  } else {
+    int i = 0;
+    if (T[5] > T[0]) i = 1;
+    if (T[10] > T[i * 4 + i]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = sqrt(T[i * 4 + i] - T[j * 4 + j] - T[k * 4 + k] + 1.0);
+    q[i] = 0.5 * t;
+    t = 0.5 / t;
+    q[3] = (T[k * 4 + j] - T[j * 4 + k]) * t;
+    q[j] = (T[j * 4 + i] + T[i * 4 + j]) * t;
+    q[k] = (T[k * 4 + i] + T[i * 4 + k]) * t;
+  }
+}
+// Eigen::Quaterniond::toRotationMatrix + translation (src/laser_odometry.cc:225-227)
+LD_HD void iso_from_qt(const double* q, const double* t, double* T) {
+  const double x = q[0], y = q[1], z = q[2], w = q[3];
+  const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+  const double twx = tx * w, twy = ty * w, twz = tz * w;
+  const double txx = tx * x, txy = ty * x, txz = tz * x;
+  const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  T[0] = 1 - (tyy + tzz); T[1] = txy - twz;       T[2] = txz + twy;        T[3] = t[0];
+  T[4] = txy + twz;       T[5] = 1 - (txx + tzz); T[6] = tyz - twx;        T[7] = t[1];
+  T[8] = txz - twy;       T[9] = tyz + twx;       T[10] = 1 - (txx + tyy); T[11] = t[2];
+}
+// pcl::transformPointCloud, double matrix, float points (src/laser_odometry.cc:232,308)
+LD_HD void transform_point(const double* T, float x, float y, float z, float* ox, float* oy,
+                           float* oz) {
+  const double dx = x, dy = y, dz = z;
+  *ox = (float)(T[0] * dx + T[1] * dy + T[2] * dz + T[3]);
+  *oy = (float)(T[4] * dx + T[5] * dy + T[6] * dz + T[7]);
+  *oz = (float)(T[8] * dx + T[9] * dy + T[10] * dz + T[11]);
+}
+// ceres::EigenQuaternionParameterization::Plus, x = [x y z w]
+LD_HD void quat_plus(const double* x, const double* delta, double* out) {
+  const double nd = sqrt(delta[0] * delta[0] + delta[1] * delta[1] + delta[2] * delta[2]);
+  if (nd > 0.0) {
+    const double s = sin(nd) / nd;
+    const double aw = cos(nd), ax = s * delta[0], ay = s * delta[1], az = s * delta[2];
+    const double bw = x[3], bx = x[0], by = x[1], bz = x[2];
+    out[3] = aw * bw - ax * bx - ay * by - az * bz;
+    out[0] = aw * bx + ax * bw + ay * bz - az * by;
+    out[1] = aw * by + ay * bw + az * bx - ax * bz;
+    out[2] = aw * bz + az * bw + ax * by - ay * bx;
+  } else {
+    out[0] = x[0]; out[1] = x[1]; out[2] = x[2]; out[3] = x[3];
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// kNN distance, FLANN L2_Simple<float> order
+// ---------------------------------------------------------------------------------------
+LD_HD float sqdist_f(float qx, float qy, float qz, float mx, float my, float mz) {
+  const float dx = qx - mx, dy = qy - my, dz = qz - mz;
+  float r = dx * dx;
+  r = r + dy * dy;
+  r = r + dz * dz;
+  return r;
+}
+
+// ---------------------------------------------------------------------------------------
+// Line gate (src/laser_odometry.cc:325-344): centroid and scatter matrix of the five nearest
+// neighbours in FP64, eigenvalues by kJacobiSweeps sweeps of cyclic Jacobi (only + - * / sqrt),
+// accept iff lambda_max > 3 * lambda_mid.
+// ---------------------------------------------------------------------------------------
+LD_HD void jacobi_rot(double& app, double& aqq, double& apq, double& arp, double& arq) {
+  if (apq == 0.0) return;
+  const double theta = (aqq - app) / (2.0 * apq);
+  const double at = fabs(theta);
+  double t = 1.0 / (at + sqrt(theta * theta + 1.0));
+  if (theta < 0.0) t = -t;
+  const double c = 1.0 / sqrt(t * t + 1.0);
+  const double s = t * c;
+  app = app - t * apq;
+  aqq = aqq + t * apq;
+  apq = 0.0;
+  const double nrp = c * arp - s * arq;
+  const double nrq = s * arp + c * arq;
+  arp = nrp; arq = nrq;
+}
+LD_HD void eig3_sym(const double* a, double* ev) {
+  double a00 = a[0], a01 = a[1], a02 = a[2], a11 = a[3], a12 = a[4], a22 = a[5];
+  for (int sweep = 0; sweep < kJacobiSweeps; sweep++) {
+    jacobi_rot(a00, a11, a01, a02, a12);
+    jacobi_rot(a00, a22, a02, a01, a12);
+    jacobi_rot(a11, a22, a12, a01, a02);
+  }
+  double e0 = a00, e1 = a11, e2 = a22, s;
+  if (e0 > e1) { s = e0; e0 = e1; e1 = s; }
+  if (e1 > e2) { s = e1; e1 = e2; e2 = s; }
+  if (e0 > e1) { s = e0; e0 = e1; e1 = s; }
+  ev[0] = e0; ev[1] = e1; ev[2] = e2;
+}
+// nn = 5 points (x,y,z) as floats, in ascending-distance order
+LD_HD bool line_gate(const float* nx, const float* ny, const float* nz) {
+  double cx = 0, cy = 0, cz = 0;
+  for (int j = 0; j < 5; j++) { cx = cx + (double)nx[j]; cy = cy + (double)ny[j]; cz = cz + (double)nz[j]; }
+  cx = cx / 5.0; cy = cy / 5.0; cz = cz / 5.0;
+  double cov[6] = {0, 0, 0, 0, 0, 0};
+  for (int j = 0; j < 5; j++) {
+    const double zx = (double)nx[j] - cx, zy = (double)ny[j] - cy, zz = (double)nz[j] - cz;
+    cov[0] = cov[0] + zx * zx; cov[1] = cov[1] + zx * zy; cov[2] = cov[2] + zx * zz;
+    cov[3] = cov[3] + zy * zy; cov[4] = cov[4] + zy * zz; cov[5] = cov[5] + zz * zz;
+  }
+  double ev[3];
+  eig3_sym(cov, ev);
+  return ev[2] > 3 * ev[1];
+}
+
+// ---------------------------------------------------------------------------------------
+// Point-to-line residual block (include/liodom/factors.hpp:71-105) with the analytic tangent
+// Jacobian of SURVEY.md A.4 and the Huber(0.2) correction, accumulated into the normal
+// equations.  Accumulator layout: v[0] = cost (0.5*sum rho), v[1..6] = g = J^T r,
+// v[7..27] = upper triangle of J^T J (row-major: 00 01 .. 05 11 12 .. 55), v[28] = number of
+// non-finite blocks.
+// ---------------------------------------------------------------------------------------
+constexpr int kAccN = 29;
+
+LD_HD void residual_accumulate(const double* Rm /*3x4*/, const double* p, const double* a,
+                               const double* b, double min_d, double max_d, double* acc) {
+  const double tx = Rm[3], ty = Rm[7], tz = Rm[11];
+  const double Rp0 = Rm[0] * p[0] + Rm[1] * p[1] + Rm[2] * p[2];
+  const double Rp1 = Rm[4] * p[0] + Rm[5] * p[1] + Rm[6] * p[2];
+  const double Rp2 = Rm[8] * p[0] + Rm[9] * p[1] + Rm[10] * p[2];
+  const double lp0 = Rp0 + tx, lp1 = Rp1 + ty, lp2 = Rp2 + tz;
+  const double u0 = lp0 - a[0], u1 = lp1 - a[1], u2 = lp2 - a[2];
+  const double w0 = lp0 - b[0], w1 = lp1 - b[1], w2 = lp2 - b[2];
+  const double nu0 = u1 * w2 - u2 * w1, nu1 = u2 * w0 - u0 * w2, nu2 = u0 * w1 - u1 * w0;
+  const double de0 = a[0] - b[0], de1 = a[1] - b[1], de2 = a[2] - b[2];
+  const double L = sqrt(de0 * de0 + de1 * de1 + de2 * de2);
+  const double cx = p[0] - tx, cy = p[1] - ty;
+  const double rho = sqrt(cx * cx + cy * cy);
+  const double range = max_d - min_d;
+  const double w = 1.01 - (rho - min_d) / range;
+  const double wl = w / L;
+  const double r0 = wl * nu0, r1 = wl * nu1, r2 = wl * nu2;
+  const double s = r0 * r0 + r1 * r1 + r2 * r2;
+  // Jq = (2w/L) [de]x [Rp]x ; [de]x[Rp]x = Rp de^T - (de.Rp) I
+  const double dot = de0 * Rp0 + de1 * Rp1 + de2 * Rp2;
+  const double k2 = 2.0 * wl;
+  double J[18];
+  J[0]  = k2 * (Rp0 * de0 - dot); J[1]  = k2 * (Rp0 * de1);       J[2]  = k2 * (Rp0 * de2);
+  J[6]  = k2 * (Rp1 * de0);       J[7]  = k2 * (Rp1 * de1 - dot); J[8]  = k2 * (Rp1 * de2);
+  J[12] = k2 * (Rp2 * de0);       J[13] = k2 * (Rp2 * de1);       J[14] = k2 * (Rp2 * de2 - dot);
+  // Jt = -(w/L)[de]x + (nu/L) (dw/dt)^T,  dw/dt = (cx, cy, 0) / (rho * range)
+  const double dwx = cx / (rho * range), dwy = cy / (rho * range);
+  const double n0 = nu0 / L, n1 = nu1 / L, n2 = nu2 / L;
+  J[3]  = n0 * dwx;              J[4]  = wl * de2 + n0 * dwy;   J[5]  = -wl * de1;
+  J[9]  = -wl * de2 + n1 * dwx;  J[10] = n1 * dwy;              J[11] = wl * de0;
+  J[15] = wl * de1 + n2 * dwx;   J[16] = -wl * de0 + n2 * dwy;  J[17] = 0.0;
+  // Huber (ceres::HuberLoss): rho'' <= 0 -> residual and Jacobian scaled by sqrt(rho')
+  double rho0, rho1;
+  const double bsq = kHuberA * kHuberA;
+  if (s > bsq) {
+    const double rr = sqrt(s);
+    rho0 = 2.0 * kHuberA * rr - bsq;
+    rho1 = kHuberA / rr;
+    if (rho1 < DBL_MIN) rho1 = DBL_MIN;
+  } else {
+    rho0 = s; rho1 = 1.0;
+  }
+  bool finite = ld_isfinite(s);
+  for (int i = 0; i < 18; i++) finite = finite && ld_isfinite(J[i]);
+  if (!finite) { acc[28] += 1.0; return; }
+  acc[0] += 0.5 * rho0;
+  const double rs0 = rho1 * r0, rs1 = rho1 * r1, rs2 = rho1 * r2;
+  int k = 7;
+  for (int i = 0; i < 6; i++) {
+    acc[1 + i] += J[i] * rs0 + J[6 + i] * rs1 + J[12 + i] * rs2;
+    const double a0 = rho1 * J[i], a1 = rho1 * J[6 + i], a2 = rho1 * J[12 + i];
+    for (int j = i; j < 6; j++) acc[k++] += a0 * J[j] + a1 * J[6 + j] + a2 * J[12 + j];
+  }
+}
+
+// Cost-only variant (candidate evaluation).  Returns false if non-finite.
+LD_HD bool residual_cost(const double* Rm, const double* p, const double* a, const double* b,
+                         double min_d, double max_d, double* cost) {
+  const double tx = Rm[3], ty = Rm[7], tz = Rm[11];
+  const double lp0 = Rm[0] * p[0] + Rm[1] * p[1] + Rm[2] * p[2] + tx;
+  const double lp1 = Rm[4] * p[0] + Rm[5] * p[1] + Rm[6] * p[2] + ty;
+  const double lp2 = Rm[8] * p[0] + Rm[9] * p[1] + Rm[10] * p[2] + tz;
+  const double u0 = lp0 - a[0], u1 = lp1 - a[1], u2 = lp2 - a[2];
+  const double w0 = lp0 - b[0], w1 = lp1 - b[1], w2 = lp2 - b[2];
+  const double nu0 = u1 * w2 - u2 * w1, nu1 = u2 * w0 - u0 * w2, nu2 = u0 * w1 - u1 * w0;
+  const double de0 = a[0] - b[0], de1 = a[1] - b[1], de2 = a[2] - b[2];
+  const double L = sqrt(de0 * de0 + de1 * de1 + de2 * de2);
+  const double cx = p[0] - tx, cy = p[1] - ty;
+  const double rho = sqrt(cx * cx + cy * cy);
+  const double w = 1.01 - (rho - min_d) / (max_d - min_d);
+  const double wl = w / L;
+  const double r0 = wl * nu0, r1 = wl * nu1, r2 = wl * nu2;
+  const double s = r0 * r0 + r1 * r1 + r2 * r2;
+  if (!ld_isfinite(s)) return false;
+  const double bsq = kHuberA * kHuberA;
+  *cost += (s > bsq) ? 0.5 * (2.0 * kHuberA * sqrt(s) - bsq) : 0.5 * s;
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------
+// Trust-region Levenberg-Marquardt controller mirroring ceres::Solve as configured at
+// src/laser_odometry.cc:212-218 (Ceres <= 2.1 defaults): Jacobi scaling from the
+// first Jacobian, radius 1e4, diagonal clamp [1e-6, 1e32], step quality > 1e-3, parameter
+// tolerance 1e-8, function tolerance 1e-6, gradient tolerance 1e-10, max 4 iterations where
+// every trial counts.  DENSE_QR on the stacked system is replaced by a Cholesky solve of the
+// 6x6 normal equations (same minimiser).
+//
+// Usage: lm_begin(st, x0, acc0) -> if LM_NEED_EVAL evaluate acc at st.cand_* and call
+// lm_update(st, acc) until LM_DONE.  The solution is st.q / st.t.
+// ---------------------------------------------------------------------------------------
+enum { LM_DONE = 0, LM_NEED_EVAL = 1 };
+enum {
+  LM_TERM_MAX_ITER = 0, LM_TERM_PARAM_TOL = 1, LM_TERM_FUNC_TOL = 2, LM_TERM_GRAD_TOL = 3,
+  LM_TERM_NO_RESIDUALS = 4, LM_TERM_EVAL_FAILURE = 5, LM_TERM_RADIUS = 6, LM_TERM_INVALID_STEPS = 7
+};
+
+struct LmState {
+  double q[4], t[3];            // current (accepted) point
+  double cand_q[4], cand_t[3];  // candidate to evaluate
+  double cost;                  // cost at the current point
+  double g[6], H[21];           // J^T r and J^T J (unscaled, loss-corrected) at the current point
+  double scale[6];              // Jacobi scaling, fixed per solve
+  double diag[6];
+  double radius, decrease_factor;
+  double x_norm;
+  double model_cost_change;
+  double initial_cost;
+  int reuse_diagonal;
+  int iter, accepted, invalid_run, termination;
+  int apply_on_ftol;
+};
+
+LD_HD int h_idx(int i, int j) {  // upper-triangle index, i <= j
+  return i * 6 - (i * (i - 1)) / 2 + (j - i);
+}
+LD_HD double h_at(const double* H, int i, int j) { return i <= j ? H[h_idx(i, j)] : H[h_idx(j, i)]; }
+
+// Cholesky solve of the 6x6 SPD system A y = b.  Returns false if not positive definite.
+LD_HD bool chol_solve6(const double* A /*6x6 row-major, symmetric*/, const double* b, double* y) {
+  double Lm[36];
+  for (int i = 0; i < 36; i++) Lm[i] = 0.0;
+  for (int j = 0; j < 6; j++) {
+    double d = A[j * 6 + j];
+    for (int k = 0; k < j; k++) d -= Lm[j * 6 + k] * Lm[j * 6 + k];
+    if (!(d > 0.0) || !ld_isfinite(d)) return false;
+    const double l = sqrt(d);
+    Lm[j * 6 + j] = l;
+    for (int i = j + 1; i < 6; i++) {
+      double s = A[i * 6 + j];
+      for (int k = 0; k < j; k++) s -= Lm[i * 6 + k] * Lm[j * 6 + k];
+      Lm[i * 6 + j] = s / l;
+    }
+  }
+  double z[6];
+  for (int i = 0; i < 6; i++) {
+    double s = b[i];
+    for (int k = 0; k < i; k++) s -= Lm[i * 6 + k] * z[k];
+    z[i] = s / Lm[i * 6 + i];
+  }
+  for (int i = 5; i >= 0; i--) {
+    double s = z[i];
+    for (int k = i + 1; k < 6; k++) s -= Lm[k * 6 + i] * y[k];
+    y[i] = s / Lm[i * 6 + i];
+    if (!ld_isfinite(y[i])) return false;
+  }
+  return true;
+}
+
+LD_HD double norm7(const double* q, const double* t) {
+  return sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3] + t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
+}
+
+// Computes the next valid trust-region step and the candidate point.  Invalid steps shrink the
+// radius and consume an iteration each (TrustRegionMinimizer::HandleInvalidStep).
+LD_HD int lm_propose(LmState& st) {
+  while (true) {
+    if (st.iter >= kLmMaxIterations) { st.termination = LM_TERM_MAX_ITER; return LM_DONE; }
+    if (st.radius < 1e-32) { st.termination = LM_TERM_RADIUS; return LM_DONE; }
+    st.iter++;
+    double Hs[36], gs[6];
+    for (int i = 0; i < 6; i++) {
+      gs[i] = st.scale[i] * st.g[i];
+      for (int j = 0; j < 6; j++) Hs[i * 6 + j] = st.scale[i] * st.scale[j] * h_at(st.H, i, j);
+    }
+    if (!st.reuse_diagonal) {
+      for (int j = 0; j < 6; j++) {
+        double d = Hs[j * 6 + j];
+        if (d < 1e-6) d = 1e-6;
+        if (d > 1e32) d = 1e32;
+        st.diag[j] = d;
+      }
+    }
+    double A[36];
+    for (int i = 0; i < 36; i++) A[i] = Hs[i];
+    for (int j = 0; j < 6; j++) A[j * 6 + j] += st.diag[j] / st.radius;
+    double y[6];
+    const bool ok = chol_solve6(A, gs, y);
+    st.reuse_diagonal = 1;
+    double mcc = 0.0;
+    double step[6];
+    if (ok) {
+      double sg = 0.0, shs = 0.0;
+      for (int i = 0; i < 6; i++) step[i] = -y[i];
+      for (int i = 0; i < 6; i++) {
+        sg += step[i] * gs[i];
+        double row = 0.0;
+        for (int j = 0; j < 6; j++) row += Hs[i * 6 + j] * step[j];
+        shs += step[i] * row;
+      }
+      mcc = -sg - 0.5 * shs;
+    }
+    if (!ok || !(mcc > 0.0)) {
+      if (++st.invalid_run >= 5) { st.termination = LM_TERM_INVALID_STEPS; return LM_DONE; }
+      st.radius = st.radius / st.decrease_factor;
+      st.decrease_factor *= 2.0;
+      continue;
+    }
+    st.invalid_run = 0;
+    st.model_cost_change = mcc;
+    double delta[6];
+    for (int j = 0; j < 6; j++) delta[j] = step[j] * st.scale[j];
+    quat_plus(st.q, delta, st.cand_q);
+    for (int k = 0; k < 3; k++) st.cand_t[k] = st.t[k] + delta[3 + k];
+    return LM_NEED_EVAL;
+  }
+}
+
+// acc = accumulator evaluated at (q0, t0); n_blocks = number of residual blocks.
+LD_HD int lm_begin(LmState& st, const double* q0, const double* t0, const double* acc,
+                   int n_blocks, int apply_on_ftol) {
+  for (int k = 0; k < 4; k++) st.q[k] = st.cand_q[k] = q0[k];
+  for (int k = 0; k < 3; k++) st.t[k] = st.cand_t[k] = t0[k];
+  st.iter = 0; st.accepted = 0; st.invalid_run = 0; st.termination = LM_TERM_MAX_ITER;
+  st.apply_on_ftol = apply_on_ftol;
+  st.cost = 0.0; st.initial_cost = 0.0; st.model_cost_change = 0.0;
+  st.radius = 1e4; st.decrease_factor = 2.0; st.reuse_diagonal = 0;
+  for (int j = 0; j < 6; j++) { st.scale[j] = 1.0; st.diag[j] = 0.0; st.g[j] = 0.0; }
+  for (int j = 0; j < 21; j++) st.H[j] = 0.0;
+  st.x_norm = norm7(st.q, st.t);
+  if (n_blocks == 0) { st.termination = LM_TERM_NO_RESIDUALS; return LM_DONE; }
+  if (acc[28] != 0.0) { st.termination = LM_TERM_EVAL_FAILURE; return LM_DONE; }
+  st.cost = acc[0]; st.initial_cost = acc[0];
+  double gmax = 0.0;
+  for (int j = 0; j < 6; j++) { st.g[j] = acc[1 + j]; const double ag = fabs(st.g[j]); if (ag > gmax) gmax = ag; }
+  for (int j = 0; j < 21; j++) st.H[j] = acc[7 + j];
+  for (int j = 0; j < 6; j++) st.scale[j] = 1.0 / (1.0 + sqrt(st.H[h_idx(j, j)]));
+  if (gmax <= 1e-10) { st.termination = LM_TERM_GRAD_TOL; return LM_DONE; }
+  return lm_propose(st);
+}
+
+// acc = accumulator evaluated at the candidate (cost + normal equations).
+LD_HD int lm_update(LmState& st, const double* acc) {
+  const double cand_cost = (acc[28] != 0.0) ? DBL_MAX : acc[0];
+  double dq[4], dt[3];
+  for (int k = 0; k < 4; k++) dq[k] = st.q[k] - st.cand_q[k];
+  for (int k = 0; k < 3; k++) dt[k] = st.t[k] - st.cand_t[k];
+  const double step_norm = norm7(dq, dt);
+  if (step_norm <= 1e-8 * (st.x_norm + 1e-8)) { st.termination = LM_TERM_PARAM_TOL; return LM_DONE; }
+  const double cost_change = st.cost - cand_cost;
+  if (fabs(cost_change) <= 1e-6 * st.cost) {
+    st.termination = LM_TERM_FUNC_TOL;
+    if (st.apply_on_ftol && cost_change > 0.0) {
+      for (int k = 0; k < 4; k++) st.q[k] = st.cand_q[k];
+      for (int k = 0; k < 3; k++) st.t[k] = st.cand_t[k];
+      st.cost = cand_cost;
+    }
+    return LM_DONE;
+  }
+  const double rel = cost_change / st.model_cost_change;
+  if (rel > 1e-3) {
+    for (int k = 0; k < 4; k++) st.q[k] = st.cand_q[k];
+    for (int k = 0; k < 3; k++) st.t[k] = st.cand_t[k];
+    st.x_norm = norm7(st.q, st.t);
+    st.cost = cand_cost;
+    double gmax = 0.0;
+    for (int j = 0; j < 6; j++) { st.g[j] = acc[1 + j]; const double ag = fabs(st.g[j]); if (ag > gmax) gmax = ag; }
+    for (int j = 0; j < 21; j++) st.H[j] = acc[7 + j];
+    st.accepted++;
+    const double c = 2.0 * rel - 1.0;
+    double f = 1.0 - c * c * c;
+    if (f < 1.0 / 3.0) f = 1.0 / 3.0;
+    st.radius = st.radius / f;
+    if (st.radius > 1e16) st.radius = 1e16;
+    st.decrease_factor = 2.0;
+    st.reuse_diagonal = 0;
+    if (gmax <= 1e-10) { st.termination = LM_TERM_GRAD_TOL; return LM_DONE; }
+  } else {
+    st.radius = st.radius / st.decrease_factor;
+    st.decrease_factor *= 2.0;
+    st.reuse_diagonal = 1;
+  }
+  return lm_propose(st);
+}
+
+}  // namespace liodom_dev

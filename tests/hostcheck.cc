@@ -1,0 +1,63 @@
+// tests/hostcheck.cc — compiles the product's arithmetic header (liodom_amd/csrc/liodom_math.h)
+// for the host so that CPU tests can compare its leaf functions with the oracle without a GPU.
+// Test tooling only: the shipped path runs these functions inside HIP kernels.
+#include <cstring>
+#include <vector>
+
+#include "../liodom_amd/csrc/liodom_math.h"
+
+using namespace liodom_dev;
+
+extern "C" {
+
+int hc_velodyne_ring(double x, double y, double z, double min_r, double max_r, int lines) {
+  double d;
+  if (!valid_point(x, y, z, min_r, max_r, &d)) return -2;
+  return velodyne_ring(z, d, lines);
+}
+double hc_curvature(const float* px, const float* py, const float* pz, int j) { return curvature(px, py, pz, j); }
+void hc_eig3(const double* a, double* ev) { eig3_sym(a, ev); }
+int hc_line_gate(const float* nx, const float* ny, const float* nz) { return line_gate(nx, ny, nz) ? 1 : 0; }
+void hc_transform(const double* T, const float* in, int n, float* out) {
+  for (int i = 0; i < n; i++) {
+    transform_point(T, in[4 * i], in[4 * i + 1], in[4 * i + 2], &out[4 * i], &out[4 * i + 1], &out[4 * i + 2]);
+    out[4 * i + 3] = in[4 * i + 3];
+  }
+}
+void hc_pose_ops(const double* q, const double* t, double* T12, double* qback) {
+  iso_from_qt(q, t, T12);
+  quat_from_rot(T12, qback);
+}
+void hc_predict(const double* odom, const double* prev, double* pred) {
+  double inv[12], rel[12];
+  iso_inverse(prev, inv);
+  iso_mul(inv, odom, rel);
+  iso_mul(odom, rel, pred);
+}
+// accumulator (29 doubles) over n blocks of 9 doubles (p, a, b) at pose (q, t)
+void hc_accumulate(const double* blocks9, int n, const double* q, const double* t, double min_d,
+                   double max_d, double* acc) {
+  double Rm[12];
+  iso_from_qt(q, t, Rm);
+  for (int i = 0; i < kAccN; i++) acc[i] = 0.0;
+  for (int i = 0; i < n; i++) residual_accumulate(Rm, blocks9 + 9 * i, blocks9 + 9 * i + 3, blocks9 + 9 * i + 6, min_d, max_d, acc);
+}
+// full solve with the product's controller; returns termination; trace = iterations, accepted
+int hc_lm_solve(const double* blocks9, int n, double* q, double* t, double min_d, double max_d,
+                int apply_on_ftol, int* iterations, int* accepted, double* initial_cost, double* final_cost) {
+  LmState st;
+  double acc[kAccN];
+  hc_accumulate(blocks9, n, q, t, min_d, max_d, acc);
+  int flag = lm_begin(st, q, t, acc, n, apply_on_ftol);
+  while (flag == LM_NEED_EVAL) {
+    hc_accumulate(blocks9, n, st.cand_q, st.cand_t, min_d, max_d, acc);
+    flag = lm_update(st, acc);
+  }
+  for (int k = 0; k < 4; k++) q[k] = st.q[k];
+  for (int k = 0; k < 3; k++) t[k] = st.t[k];
+  *iterations = st.iter; *accepted = st.accepted; *initial_cost = st.initial_cost; *final_cost = st.cost;
+  return st.termination;
+}
+float hc_sqdist(const float* a, const float* b) { return sqdist_f(a[0], a[1], a[2], b[0], b[1], b[2]); }
+
+}  // extern "C"

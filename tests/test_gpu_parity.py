@@ -1,0 +1,241 @@
+"""GPU parity: the HIP path (through the C-ABI of include/liodom_hip.h) against the CPU oracle on
+identical inputs.  Bar: bit-exact edge sets (ring, index, source, XYZI bits) and correspondence
+index sets; pose within 1e-4 m / 1e-4 rad per scan (BASELINE.json north_star).
+Run with -m gpu on an MI355X."""
+import numpy as np
+import pytest
+
+import liodom_amd as la
+import pyref
+
+pytestmark = pytest.mark.gpu
+
+POSE_TOL_T = 1e-4   # metres
+POSE_TOL_R = 1e-4   # radians
+
+
+def rot_angle(qa, qb):
+    d = abs(float(np.dot(qa, qb)) / (np.linalg.norm(qa) * np.linalg.norm(qb)))
+    return 2.0 * np.arccos(min(1.0, d))
+
+
+def mk(orc, H, W, lidar_type=0, R=8, epr=10, P=5, S=1, debug=0, **cfgkw):
+    po = orc.make_params(lidar_type=lidar_type, scan_lines=H, scan_regions=R, edges_per_region=epr, prev_frames=P, knn_mode=1)
+    pg = la.make_params(lidar_type=lidar_type, scan_lines=H, scan_regions=R, edges_per_region=epr, prev_frames=P)
+    cg = la.make_config(n_streams=S, max_points=max(H * W, 16), max_width=max(W, 16), debug_buffers=debug, **cfgkw)
+    return po, la.Liodom(pg, cg)
+
+
+def assert_edges_equal(g, o):
+    assert len(g["ring"]) == len(o["ring"])
+    assert np.array_equal(g["ring"], o["ring"])
+    assert np.array_equal(g["idx_in_ring"], o["idx_in_ring"])
+    assert np.array_equal(g["src"], o["src"])
+    assert np.array_equal(g["edges"].view(np.uint32), o["edges"].view(np.uint32))
+
+
+CONFIGS = [
+    # (H, W, lidar_type, R, epr) — BASELINE.json configs 1-4 at full size
+    (16, 900, 0, 6, 10),
+    (16, 1800, 0, 8, 20),
+    (64, 1800, 0, 8, 10),
+    (128, 2048, 1, 8, 10),
+    (32, 700, 0, 4, 5),
+]
+
+
+@pytest.mark.parametrize("H,W,lt,R,epr", CONFIGS)
+def test_extract_bit_exact(orc, synth, H, W, lt, R, epr):
+    cfg = synth.make_cfg(H, W, lt)
+    po, g = mk(orc, H, W, lt, R, epr, debug=1)
+    for k in (0, 7):
+        x, _ = synth.scan(cfg, 2, k)
+        o = orc.extract(po, x, H, W, want_curv=True)
+        e = g.extract_edges(x, H, W)
+        assert_edges_equal(e, o)
+        assert len(o["ring"]) > 50
+        # FP64 smoothness, bit for bit (NaN where undefined)
+        cg, offs = g.curvature()
+        co = o["curv"][:len(cg)]
+        assert np.array_equal(np.isnan(cg), np.isnan(co))
+        m = ~np.isnan(cg)
+        assert np.array_equal(cg[m].view(np.uint64), co[m].view(np.uint64))
+    g.close()
+
+
+def test_extract_edge_cases(orc):
+    po, g = mk(orc, 16, 1800, 0, 8, 10)
+    # empty cloud, all-NaN cloud
+    assert len(g.extract_edges(np.zeros((0, 4), np.float32), 16, 0)["ring"]) == 0
+    x = np.full((16 * 100, 4), np.nan, np.float32)
+    assert len(g.extract_edges(x, 16, 100)["ring"]) == 0
+    # jagged ring: epr+1 picks per region
+    from test_oracle_extract import _jagged_ring
+    x = _jagged_ring(1800)
+    e = g.extract_edges(x, 16, 0)
+    assert_edges_equal(e, orc.extract(po, x, 16, 0))
+    assert len(e["ring"]) == 88
+    # ragged: ring sizes around the min_points_per_scan threshold (90)
+    for n in (89, 90, 91, 101, 333):
+        x = _jagged_ring(n, seed=n)
+        assert_edges_equal(g.extract_edges(x, 16, 0), orc.extract(po, x, 16, 0))
+    g.close()
+
+
+def test_suppression_carry_across_regions(orc):
+    # SURVEY.md §0 fact 4 — same construction as tests/test_oracle_extract.py
+    n = 910
+    phi = np.linspace(0, 0.5, n)
+    r = np.full(n, 20.0)
+    r[453] += 0.08
+    r[456] += 0.05
+    x = np.zeros((n, 4), np.float32)
+    x[:, 0] = r * np.cos(phi)
+    x[:, 1] = r * np.sin(phi)
+    x[:, 2] = -0.3
+    po, g = mk(orc, 16, 1024, 0, 2, 3)
+    e = g.extract_edges(x, 16, 0)
+    assert_edges_equal(e, orc.extract(po, x, 16, 0))
+    assert 453 in e["idx_in_ring"].tolist() and not any(453 < i <= 458 for i in e["idx_in_ring"].tolist())
+    g.close()
+
+
+def test_ring_overflow_is_reported(orc, synth):
+    # a ring with more points than the configured LDS tile is skipped and flagged, not corrupted
+    from test_oracle_extract import _jagged_ring
+    po, g = mk(orc, 16, 256, 0, 8, 10, max_ring_points=512)
+    x = _jagged_ring(700)
+    e = g.extract_edges(x, 16, 0)
+    assert len(e["ring"]) == 0
+    pose, info = g.process_scan(x, 16, 0)
+    assert info.status & 1
+    g.close()
+
+
+def test_max_ring_size(orc):
+    # largest supported ring (6144 points in one 160 KiB LDS tile)
+    from test_oracle_extract import _jagged_ring
+    po, g = mk(orc, 16, 6144, 0, 8, 10, max_ring_points=6144)
+    x = _jagged_ring(6144, seed=5)
+    assert_edges_equal(g.extract_edges(x, 16, 0), orc.extract(po, x, 16, 0))
+    g.close()
+
+
+def _run_stream(orc, synth, H, W, lt, R, epr, P, nscans, stream=0, use_pipeline=True):
+    cfg = synth.make_cfg(H, W, lt)
+    po, g = mk(orc, H, W, lt, R, epr, P)
+    od = orc.Odometer(po)
+    worst_t, worst_r = 0.0, 0.0
+    for k in range(nscans):
+        x, _ = synth.scan(cfg, stream, k)
+        o = orc.extract(po, x, H, W)
+        pose_o, info_o = od.step(o["edges"])
+        if use_pipeline:
+            pose_g, info_g = g.process_scan(x, H, W)
+            assert_edges_equal(g.get_edges(), o)
+        else:
+            pose_g, info_g = g.odometry_step(o["edges"])
+        dt = np.linalg.norm(pose_g[4:] - pose_o[4:])
+        dr = rot_angle(pose_g[:4], pose_o[:4])
+        worst_t, worst_r = max(worst_t, dt), max(worst_r, dr)
+        assert dt <= POSE_TOL_T and dr <= POSE_TOL_R, "scan %d: dt=%g dr=%g" % (k, dt, dr)
+        assert info_g.n_edges == info_o.n_edges
+        if k > 0:
+            assert info_g.map_points == info_o.map_points
+            for it in (0, 1):
+                vo, ao, bo = od.last_corr(it)
+                vg, ag, bg = g.correspondences(it)
+                # identical correspondence sets unless a 1-ulp pose difference flipped a float cast
+                same = np.array_equal(vo, vg) and np.array_equal(ao[vo == 1], ag[vg == 1]) and np.array_equal(bo[vo == 1], bg[vg == 1])
+                if not same:
+                    diff = int((vo != vg).sum()) + int(((ao != ag) & (vo == 1) & (vg == 1)).sum())
+                    assert diff <= 3, "scan %d it %d: %d correspondences differ" % (k, it, diff)
+                assert abs(info_g.matches[it] - info_o.matches[it]) <= 3
+                assert info_g.lm[it].iterations == info_o.lm[it].iterations
+                assert info_g.lm[it].termination == info_o.lm[it].termination
+        # sliding window: same frames, same points (float rounding of the FP64 transform)
+        wo = od.window()
+        wg, nf = g.window()
+        assert nf == od.window_frames() and wg.shape == wo.shape
+        assert np.allclose(wg, wo, rtol=0, atol=2e-5)
+    g.close()
+    return worst_t, worst_r
+
+
+def test_odometry_parity_cfg1(orc, synth):
+    # BASELINE config 1: 16 x 900, R=6, epr=10, P=5 — 25 scans (window fills and evicts)
+    _run_stream(orc, synth, 16, 900, 0, 6, 10, 5, 25)
+
+
+def test_odometry_step_entry_point(orc, synth):
+    # LaserOdometer boundary alone: oracle edges in, pose out
+    _run_stream(orc, synth, 16, 900, 0, 6, 10, 5, 10, use_pipeline=False)
+
+
+def test_odometry_parity_cfg2(orc, synth):
+    _run_stream(orc, synth, 16, 1800, 0, 8, 20, 10, 16)
+
+
+def test_odometry_parity_headline(orc, synth):
+    # BASELINE config 3 (headline): 64 x 1800, R=8, epr=10, P=20
+    _run_stream(orc, synth, 64, 1800, 0, 8, 10, 20, 30)
+
+
+def test_odometry_parity_ouster(orc, synth):
+    # BASELINE config 4: 128 x 2048 organised cloud, P=30
+    _run_stream(orc, synth, 128, 2048, 1, 8, 10, 30, 8)
+
+
+def test_lockstep_streams_match_single_stream(orc, synth):
+    # n_streams > 1: every stream must give exactly what a single-stream handle gives
+    H, W, R, epr, P, S, K = 16, 900, 6, 10, 5, 3, 9
+    cfg = synth.make_cfg(H, W, 0)
+    scans = [[synth.scan(cfg, s, k)[0] for k in range(K)] for s in range(S)]
+    po, gb = mk(orc, H, W, 0, R, epr, P, S=S)
+    gb.alloc_resident(K)
+    for s in range(S):
+        for k in range(K):
+            gb.upload_scan(s, k, scans[s][k])
+    batch = []
+    for k in range(K):
+        poses, infos = gb.process_resident(k, H * W, H, W, readback=True)
+        batch.append(poses.copy())
+    log0, _ = gb.pose_log(1, 0, K)
+    assert np.array_equal(log0, np.array([b[1] for b in batch]))
+    gb.close()
+    for s in range(S):
+        _, g1 = mk(orc, H, W, 0, R, epr, P)
+        for k in range(K):
+            pose, _ = g1.process_scan(scans[s][k], H, W)
+            assert np.array_equal(pose, batch[k][s])
+        g1.close()
+
+
+def test_async_replay_equals_synchronous(orc, synth):
+    H, W, R, epr, P, K = 16, 900, 6, 10, 5, 8
+    cfg = synth.make_cfg(H, W, 0)
+    po, g = mk(orc, H, W, 0, R, epr, P)
+    g.alloc_resident(K)
+    for k in range(K):
+        g.upload_scan(0, k, synth.scan(cfg, 0, k)[0])
+    sync = [g.process_resident(k, H * W, H, W, readback=True)[0][0].copy() for k in range(K)]
+    g.reset()
+    for k in range(K):
+        g.process_resident(k, H * W, H, W, readback=False)
+    g.sync()
+    log, infos = g.pose_log(0, 0, K)
+    assert np.array_equal(log, np.array(sync))
+    assert [i.scan_index for i in infos] == list(range(K))
+    g.close()
+
+
+def test_static_sensor_stays_put(orc, synth):
+    # idempotence-style property: replaying the same scan keeps the pose at identity (< 1e-6)
+    H, W = 64, 1800
+    cfg = synth.make_cfg(H, W, 0)
+    x, _ = synth.scan(cfg, 0, 0)
+    po, g = mk(orc, H, W, 0, 8, 10, 20)
+    for k in range(6):
+        pose, info = g.process_scan(x, H, W)
+        assert np.linalg.norm(pose[4:]) < 1e-6 and rot_angle(pose[:4], np.array([0, 0, 0, 1.0])) < 1e-6
+    g.close()

@@ -1,0 +1,174 @@
+"""Product arithmetic (liodom_amd/csrc/liodom_math.h, compiled for the host by tests/hostcheck.cc)
+vs the oracle.  CPU only — this is how the analytic Jacobian, the normal-equation accumulator and
+the LM controller that run inside the HIP kernels are checked before any GPU is involved."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from test_oracle_odometry import _make_problem
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def hc():
+    so = os.path.join(HERE, "libhostcheck.so")
+    src = os.path.join(HERE, "hostcheck.cc")
+    hdr = os.path.join(HERE, "..", "liodom_amd", "csrc", "liodom_math.h")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-shared", "-o", so, src])
+    L = C.CDLL(so)
+    dp = C.POINTER(C.c_double)
+    fp = C.POINTER(C.c_float)
+    L.hc_velodyne_ring.restype = C.c_int
+    L.hc_velodyne_ring.argtypes = [C.c_double] * 5 + [C.c_int]
+    L.hc_curvature.restype = C.c_double
+    L.hc_curvature.argtypes = [fp, fp, fp, C.c_int]
+    L.hc_eig3.argtypes = [dp, dp]
+    L.hc_line_gate.restype = C.c_int
+    L.hc_line_gate.argtypes = [fp, fp, fp]
+    L.hc_transform.argtypes = [dp, fp, C.c_int, fp]
+    L.hc_pose_ops.argtypes = [dp, dp, dp, dp]
+    L.hc_predict.argtypes = [dp, dp, dp]
+    L.hc_accumulate.argtypes = [dp, C.c_int, dp, dp, C.c_double, C.c_double, dp]
+    L.hc_lm_solve.restype = C.c_int
+    L.hc_lm_solve.argtypes = [dp, C.c_int, dp, dp, C.c_double, C.c_double, C.c_int,
+                              C.POINTER(C.c_int), C.POINTER(C.c_int), dp, dp]
+    return L
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def test_ring_and_curvature_bitwise(hc, orc, synth):
+    cfg = synth.make_cfg(64, 200, 0)
+    x, _ = synth.scan(cfg, 0, 0)
+    p = orc.make_params(scan_lines=64)
+    offs, order = orc.split(p, x, 64, 200)
+    ring_of = np.full(len(x), -1)
+    for r in range(64):
+        ring_of[order[offs[r]:offs[r + 1]]] = r
+    for i in range(0, len(x), 7):
+        got = hc.hc_velodyne_ring(float(x[i, 0]), float(x[i, 1]), float(x[i, 2]), 3.0, 75.0, 64)
+        assert (got if got >= 0 else -1) == ring_of[i]
+    e = orc.extract(p, x, 64, 200, want_curv=True)
+    r = 40
+    pts = np.ascontiguousarray(x[order[offs[r]:offs[r + 1]]])
+    px, py, pz = [np.ascontiguousarray(pts[:, k]) for k in range(3)]
+    for j in range(5, len(pts) - 5, 3):
+        assert hc.hc_curvature(_fp(px), _fp(py), _fp(pz), j) == e["curv"][offs[r] + j]
+
+
+def test_eig_and_gate_bitwise(hc, orc):
+    rng = np.random.default_rng(0)
+    for _ in range(300):
+        pts = (rng.normal(size=(5, 3)) * rng.uniform(0.001, 1, 3)).astype(np.float32)
+        c = pts.astype(np.float64)
+        cen = np.zeros(3)
+        for j in range(5):
+            cen = cen + c[j]
+        cen = cen / 5.0
+        cov = np.zeros(6)
+        for j in range(5):
+            z = c[j] - cen
+            cov = cov + np.array([z[0] * z[0], z[0] * z[1], z[0] * z[2], z[1] * z[1], z[1] * z[2], z[2] * z[2]])
+        ev_o = orc.eig3(cov)
+        ev_h = np.zeros(3)
+        hc.hc_eig3(_dp(cov), _dp(ev_h))
+        assert np.array_equal(ev_o, ev_h)
+        nx, ny, nz = [np.ascontiguousarray(pts[:, k]) for k in range(3)]
+        assert hc.hc_line_gate(_fp(nx), _fp(ny), _fp(nz)) == int(ev_o[2] > 3 * ev_o[1])
+
+
+def test_transform_pose_bitwise(hc, orc):
+    rng = np.random.default_rng(1)
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    t = rng.normal(size=3) * 10
+    T_o, qb_o = orc.pose_ops(q, t)
+    T_h = np.zeros(12)
+    qb_h = np.zeros(4)
+    hc.hc_pose_ops(_dp(q), _dp(t), _dp(T_h), _dp(qb_h))
+    assert np.array_equal(T_o.reshape(12), T_h) and np.array_equal(qb_o, qb_h)
+    x = np.zeros((64, 4), np.float32)
+    x[:, :3] = rng.normal(size=(64, 3)) * 40
+    out = np.zeros_like(x)
+    hc.hc_transform(_dp(T_h), _fp(x), 64, _fp(out))
+    assert np.array_equal(out, orc.transform(T_o, x))
+
+
+def test_accumulator_matches_oracle_jacobians(hc, orc):
+    rng = np.random.default_rng(2)
+    blocks, q_true, t_true = _make_problem(rng, 60, outliers=10)
+    q = np.array([0.02, -0.01, 0.03, 1.0])
+    q /= np.linalg.norm(q)
+    t = np.array([0.1, -0.1, 0.0])
+    acc = np.zeros(29)
+    hc.hc_accumulate(_dp(blocks), len(blocks), _dp(q), _dp(t), 3.0, 75.0, _dp(acc))
+    cost, g, Hm = 0.0, np.zeros(6), np.zeros((6, 6))
+    for b in blocks:
+        r, J, _ = orc.point2line(q, t, b[:3], b[3:6], b[6:9])
+        s = r @ r
+        rho1 = 1.0 if s <= 0.04 else 0.2 / np.sqrt(s)
+        cost += 0.5 * (s if s <= 0.04 else 2 * 0.2 * np.sqrt(s) - 0.04)
+        g += rho1 * (J.T @ r)
+        Hm += rho1 * (J.T @ J)
+    assert abs(acc[0] - cost) <= 1e-12 * cost
+    assert np.allclose(acc[1:7], g, rtol=1e-10, atol=1e-10 * np.abs(g).max())
+    Hacc = np.zeros((6, 6))
+    k = 7
+    for i in range(6):
+        for j in range(i, 6):
+            Hacc[i, j] = Hacc[j, i] = acc[k]
+            k += 1
+    assert np.allclose(Hacc, Hm, rtol=1e-10, atol=1e-10 * np.abs(Hm).max())
+    assert acc[28] == 0
+
+
+@pytest.mark.parametrize("seed,n,outliers", [(3, 300, 20), (4, 40, 0), (5, 1500, 200), (6, 12, 3)])
+def test_lm_controller_matches_oracle(hc, orc, seed, n, outliers):
+    # same iteration count, termination reason and accepted steps; pose equal to ~1e-10
+    # (normal equations + Cholesky here vs Householder QR on the stacked Jacobian in the oracle)
+    rng = np.random.default_rng(seed)
+    blocks, _, _ = _make_problem(rng, n, outliers=outliers)
+    for apply_ftol in (0, 1):
+        q0 = np.array([0.0, 0.0, 0.0, 1.0])
+        t0 = np.zeros(3)
+        qo, to, tr = orc.lm_solve(blocks, q0, t0, apply_on_ftol=apply_ftol)
+        qh, th = q0.copy(), t0.copy()
+        it, acc_n = C.c_int(), C.c_int()
+        ic, fc = C.c_double(), C.c_double()
+        term = hc.hc_lm_solve(_dp(blocks), len(blocks), _dp(qh), _dp(th), 3.0, 75.0, apply_ftol,
+                              C.byref(it), C.byref(acc_n), C.byref(ic), C.byref(fc))
+        assert (term, it.value, acc_n.value) == (tr.termination, tr.iterations, tr.accepted)
+        assert abs(ic.value - tr.initial_cost) <= 1e-12 * tr.initial_cost
+        assert abs(fc.value - tr.final_cost) <= 1e-9 * max(tr.final_cost, 1e-12)
+        assert np.allclose(qh, qo, atol=1e-9) and np.allclose(th, to, atol=1e-9)
+        # a second solve from the result (the reference's second outer iteration)
+        qo2, to2, tr2 = orc.lm_solve(blocks, qo, to, apply_on_ftol=apply_ftol)
+        term2 = hc.hc_lm_solve(_dp(blocks), len(blocks), _dp(qh), _dp(th), 3.0, 75.0, apply_ftol,
+                               C.byref(it), C.byref(acc_n), C.byref(ic), C.byref(fc))
+        assert np.allclose(qh, qo2, atol=1e-8) and np.allclose(th, to2, atol=1e-8)
+
+
+def test_lm_degenerate_inputs(hc, orc):
+    q = np.array([0.0, 0, 0, 1.0])
+    t = np.zeros(3)
+    it, acc_n = C.c_int(), C.c_int()
+    ic, fc = C.c_double(), C.c_double()
+    term = hc.hc_lm_solve(_dp(np.zeros((1, 9))), 0, _dp(q), _dp(t), 3.0, 75.0, 0, C.byref(it), C.byref(acc_n), C.byref(ic), C.byref(fc))
+    assert term == 4 and it.value == 0
+    # a == b -> |de| = 0 -> non-finite residual: Ceres rejects the evaluation, pose unchanged
+    blk = np.array([[10.0, 1, 0, 10, 1, 1, 10, 1, 1]])
+    term = hc.hc_lm_solve(_dp(blk), 1, _dp(q), _dp(t), 3.0, 75.0, 0, C.byref(it), C.byref(acc_n), C.byref(ic), C.byref(fc))
+    assert term == 5 and q.tolist() == [0, 0, 0, 1]
+    qo, to, tr = orc.lm_solve(blk, [0, 0, 0, 1.0], [0, 0, 0.0])
+    assert tr.termination == 5
