@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""bench.py — LiODOM hot path on MI355X: scans/sec on the BASELINE.json headline workload.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic input: one 64x1800 scan of one
+HDL-64-shape stream per GPU (edge extraction -> 2 x [correspondences + pose solve] -> window
+update), with the pose read back every scan as the ROS node publishes it.  All scans are resident
+in HBM before the timed region.  The path does not shard (each scan depends on the previous pose
+and window), so N > 1 GPUs run N independent replayed streams ("replicas only", no collective on
+the data path); torch.distributed (gloo) is used only for the barrier / max-over-ranks timing.
+
+Output: ONE JSON line on rank 0 with metric/value/... plus
+  roofline      dominant kernel of the timed workload: algorithmic bytes / HIP-event duration
+  cpu_baseline  the CPU oracle ("port", 1 thread) on the same scans, timed on this host
+  parity        GPU-vs-oracle pose difference over the same stream (not timed)
+  batched       lock-step multi-stream run on one GPU (throughput mode) with its own roofline
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")   # generator threads must not spin during timing
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured copy)
+
+WORKLOADS = {
+    # BASELINE.json configs[2] (headline): HDL-64-shape 64x1800, scan_regions=8, prev_frames=20
+    "hdl64": dict(H=64, W=1800, lidar_type=0, R=8, epr=10, P=20,
+                  name="HDL-64-shape 64x1800 synthetic stream, scan_regions=8, edges_per_region=10, prev_frames=20"),
+}
+
+
+def algorithmic_bytes(kernel, N, E, M, C, evals):
+    """SURVEY.md §8(d) per-scan figures, per launch of `kernel` for one stream."""
+    if kernel in ("k_ring_extract", "k_classify"):
+        return 16.0 * N + 24.0 * E            # extract: 16 B/point read, 24 B/edge written
+    if kernel == "k_knn":
+        return 16.0 * (M + E) + 28.0 * E      # one kNN pass: map + queries read, (a, b, flag) written
+    if kernel == "k_lm_solve":
+        return (36.0 * C + 224.0) * max(evals, 1.0)   # per residual/Jacobian evaluation
+    if kernel in ("k_window_insert", "k_hash_scatter", "k_hash_alloc", "k_hash_clear"):
+        return 32.0 * M                       # window / hash rebuild
+    if kernel == "k_compact_edges":
+        return 32.0 * E
+    return 0.0
+
+
+def roofline_from_stats(stats, n_streams, N, E, M, C, evals):
+    """stats: {kernel: (launches, total_ms)} from HIP events on the handle's stream."""
+    tot = sum(ms for _, ms in stats.values()) or 1.0
+    name, (launches, ms) = max(stats.items(), key=lambda kv: kv[1][1])
+    avg_s = ms / max(launches, 1) * 1e-3
+    by = algorithmic_bytes(name, N, E, M, C, evals) * n_streams
+    achieved = by / avg_s / 1e9 if avg_s > 0 else 0.0
+    return {
+        "bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+        "avg_kernel_us": round(avg_s * 1e6, 2), "algorithmic_bytes_per_launch": int(by),
+        "share_of_gpu_time": round(ms / tot, 3),
+        "per_kernel_us": {k: round(v[1] / max(v[0], 1) * 1e3, 2) for k, v in stats.items() if v[0]},
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="hdl64", choices=sorted(WORKLOADS))
+    ap.add_argument("--batched-streams", type=int, default=64, help="lock-step streams of the throughput leg (0 = skip)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    # The HIP library is loaded before torch so that libamdhip64 resolves to /opt/rocm's copy.
+    import liodom_amd as la
+    from liodom_amd import synth
+    from liodom_amd.replicas import Replicas
+    la.load()
+    rep = Replicas()          # one process per GPU; gloo rendezvous only when WORLD_SIZE > 1
+    rank, local_rank, world = rep.rank, rep.local_rank, rep.world
+    if world > 1:
+        args.gpus = world
+
+    wl = WORKLOADS[args.workload]
+    H, W, R, epr, P = wl["H"], wl["W"], wl["R"], wl["epr"], wl["P"]
+    N = H * W
+    K, Wm = args.steps, args.warmup
+    total = K + Wm
+
+    # ---- synthetic stream (stream id = global rank), generated before anything is timed ----
+    cfg = synth.make_cfg(H, W, wl["lidar_type"])
+    scans = [synth.scan(cfg, rep.stream_id, k)[0] for k in range(total)]
+
+    params = la.make_params(lidar_type=wl["lidar_type"], scan_lines=H, scan_regions=R, edges_per_region=epr, prev_frames=P)
+    g = la.Liodom(params, la.make_config(device=local_rank, n_streams=1, max_points=N, max_width=W, pose_log_capacity=total + 8))
+    g.alloc_resident(total)
+    for k in range(total):
+        g.upload_scan(0, k, scans[k])
+    g.sync()
+    time.sleep(0.5)   # let the host settle after the OpenMP-heavy generation (container CPU quota)
+
+    def run(first, count, readback=True):
+        for k in range(first, first + count):
+            g.process_resident(k, N, H, W, readback=readback)
+
+    # ---- timed region: W warm-up steps, then exactly K steps ----
+    run(0, Wm)
+    g.sync()
+    rep.barrier()
+    t0 = time.perf_counter()
+    run(Wm, K)
+    g.sync()
+    rep.barrier()
+    elapsed = rep.max_over_ranks(time.perf_counter() - t0)
+    poses_gpu, infos = g.pose_log(0, 0, total)
+    value = args.gpus * K / elapsed
+
+    # ---- roofline leg: same K steps again with HIP events around every kernel launch ----
+    g.reset()
+    run(0, Wm)
+    g.sync()
+    g.reset_kernel_stats()
+    g.set_profiling(True)
+    run(Wm, K)
+    stats = g.kernel_stats()
+    g.set_profiling(False)
+    meanE = float(np.mean([i.n_edges for i in infos[Wm:]]))
+    meanM = float(np.mean([i.map_points for i in infos[Wm:]]))
+    meanC = float(np.mean([(i.matches[0] + i.matches[1]) / 2.0 for i in infos[Wm:]]))
+    mean_evals = float(np.mean([(i.lm[0].iterations + i.lm[1].iterations + 2) / 2.0 for i in infos[Wm:]]))
+    roofline = roofline_from_stats(stats, 1, N, meanE, meanM, meanC, mean_evals)
+    # asynchronous replay (no per-scan readback) for reference
+    g.reset()
+    run(0, Wm, readback=False)
+    g.sync()
+    t1 = time.perf_counter()
+    run(Wm, K, readback=False)
+    g.sync()
+    async_rate = K / (time.perf_counter() - t1)
+    dev_name, cus = g.device_info()
+    g.close()
+
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "scans/sec (64x1800 cloud, prev_frames=20) at 1 GPU; pose RMSE vs CPU ref",
+            "value": round(value, 2), "unit": "scans/s", "n_gpus": args.gpus, "steps": K, "warmup": Wm,
+            "ms_per_step": round(elapsed / K * 1e3, 5), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": wl["name"], "streams_per_gpu": 1, "points_per_scan": N,
+                       "mode": "per-scan synchronous (pose read back every scan), scans resident in HBM",
+                       "parallelism": "replicas only" if args.gpus > 1 else "single stream",
+                       "mean_edges": round(meanE, 1), "mean_map_points": round(meanM, 1), "mean_matches": round(meanC, 1),
+                       "mean_lm_evals_per_solve": round(mean_evals, 2), "device": dev_name, "compute_units": cus},
+            "async_replay_scans_per_s": round(async_rate, 2),
+            "roofline": roofline,
+        }
+
+    # ---- CPU baseline + parity (rank 0, N = 1 only): the oracle on the same scans ----
+    if rank == 0 and not args.no_cpu_baseline and args.gpus == 1:
+        from oracle import oracle as orc
+        po = orc.make_params(lidar_type=wl["lidar_type"], scan_lines=H, scan_regions=R, edges_per_region=epr,
+                             prev_frames=P, knn_mode=1)
+        od = orc.Odometer(po)
+        poses_cpu = np.zeros((total, 7))
+        tc = 0.0
+        for k in range(total):
+            ts = time.perf_counter()
+            e = orc.extract(po, scans[k], H, W)
+            pose, _ = od.step(e["edges"])
+            te = time.perf_counter()
+            if k >= Wm:
+                tc += te - ts
+            poses_cpu[k] = pose
+        od.close()
+        dt = np.linalg.norm(poses_gpu[:, 4:] - poses_cpu[:, 4:], axis=1)
+        dots = np.abs(np.sum(poses_gpu[:, :4] * poses_cpu[:, :4], axis=1))
+        dr = 2.0 * np.arccos(np.minimum(1.0, dots))
+        out["cpu_baseline"] = {
+            "value": round(K / tc, 3), "unit": "scans/s", "cores": 1, "kind": "port",
+            "sample": "the same %d scans (%d warm-up + %d timed), CPU oracle (oracle/liodom_oracle.cc, kd-tree kNN), 1 thread of %d"
+                      % (total, Wm, K, os.cpu_count()),
+            "gpu_over_cpu": round(value / (K / tc), 1),
+        }
+        out["parity"] = {
+            "pose_trans_rmse_m": float(np.sqrt(np.mean(dt ** 2))), "pose_trans_max_m": float(dt.max()),
+            "pose_rot_rmse_rad": float(np.sqrt(np.mean(dr ** 2))), "pose_rot_max_rad": float(dr.max()),
+            "tolerance": "1e-4 m / 1e-4 rad per scan", "scans_compared": int(total),
+        }
+
+    # ---- batched leg: lock-step streams on one GPU (throughput mode; separately labelled) ----
+    if rank == 0 and args.batched_streams > 0 and args.gpus == 1:
+        S = args.batched_streams
+        Kb, Wb = min(K, 40), min(Wm, 20)
+        tb = Kb + Wb
+        n_data = 2                      # distinct synthetic streams; stream s replays data stream s % 2
+        data = [scans[:tb]] + [[synth.scan(cfg, 1000 + d, k)[0] for k in range(tb)] for d in range(1, n_data)]
+        gb = la.Liodom(params, la.make_config(device=local_rank, n_streams=S, max_points=N, max_width=W, pose_log_capacity=tb + 8))
+        gb.alloc_resident(tb)
+        for s in range(S):
+            for k in range(tb):
+                gb.upload_scan(s, k, data[s % n_data][k])
+        gb.sync()
+        time.sleep(0.5)
+        for k in range(Wb):
+            gb.process_resident(k, N, H, W, readback=True)
+        gb.sync()
+        t2 = time.perf_counter()
+        for k in range(Wb, tb):
+            gb.process_resident(k, N, H, W, readback=True)
+        gb.sync()
+        eb = time.perf_counter() - t2
+        _, binfos = gb.pose_log(0, 0, tb)
+        gb.reset()
+        for k in range(Wb):
+            gb.process_resident(k, N, H, W, readback=True)
+        gb.reset_kernel_stats()
+        gb.set_profiling(True)
+        for k in range(Wb, tb):
+            gb.process_resident(k, N, H, W, readback=True)
+        bstats = gb.kernel_stats()
+        gb.set_profiling(False)
+        gb.close()
+        bE = float(np.mean([i.n_edges for i in binfos[Wb:]]))
+        bM = float(np.mean([i.map_points for i in binfos[Wb:]]))
+        bC = float(np.mean([(i.matches[0] + i.matches[1]) / 2.0 for i in binfos[Wb:]]))
+        bev = float(np.mean([(i.lm[0].iterations + i.lm[1].iterations + 2) / 2.0 for i in binfos[Wb:]]))
+        out["batched"] = {
+            "streams": S, "steps": Kb, "warmup": Wb, "value": round(S * Kb / eb, 1), "unit": "scans/s (aggregate, 1 GPU)",
+            "ms_per_step": round(eb / Kb * 1e3, 4),
+            "note": "lock-step streams in one launch per kernel; %d distinct synthetic streams replayed" % n_data,
+            "roofline": roofline_from_stats(bstats, S, N, bE, bM, bC, bev),
+        }
+
+    rep.close()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -46,6 +47,7 @@ struct liodom_handle {
   liodom_params_t params;
   liodom_config_t config;
   DevView v{};
+  DevView* d_view = nullptr;         // device copy: kernels take a pointer (8-byte kernarg)
   hipStream_t stream = nullptr;
   hipEvent_t pose_event = nullptr;
   int S = 1, H = 0, P = 0;
@@ -54,8 +56,8 @@ struct liodom_handle {
   float4* stage_in = nullptr;        // [S][max_points]  (host-provided scans / edges)
   float4* resident = nullptr;        // [S][n_slots][max_points]
   int n_slots = 0;
-  void* pinned = nullptr;            // pinned host scratch
-  size_t pinned_bytes = 0;
+  HostOut* host_out = nullptr;       // host-mapped pinned result records, one per stream
+  std::vector<int> scans_enqueued;   // per stream: scans launched so far (expected HostOut.seq)
   std::vector<void*> allocs;
   // profiling
   bool profiling = false;
@@ -127,7 +129,7 @@ int launch_extract(liodom_handle* h, int s0, int count, const float4* in, size_t
   {
     ProfScope ps(h, KID_RING_EXTRACT);
     dim3 grid(h->H, count);
-    hipLaunchKernelGGL(k_ring_extract, grid, dim3(256), h->ring_lds_bytes, h->stream, v, s0, in,
+    hipLaunchKernelGGL(k_ring_extract, grid, dim3(kExThreads), h->ring_lds_bytes, h->stream, v, s0, in,
                        in_stride, n, height, width);
   }
   {
@@ -143,7 +145,7 @@ int launch_extract(liodom_handle* h, int s0, int count, const float4* in, size_t
 // so the host can pick them up while the window / hash rebuild still runs.
 int launch_odometry(liodom_handle* h, int s0, int count, bool want_readback) {
   const DevView& v = h->v;
-  const int knn_blocks = cdiv(v.edge_cap, 256 / kKnnGroup);
+  const int knn_blocks = cdiv(h->v.edge_cap, 256 / kKnnGroup);
   for (int it = 0; it < 2; it++) {
     {
       ProfScope ps(h, KID_KNN);
@@ -154,13 +156,9 @@ int launch_odometry(liodom_handle* h, int s0, int count, bool want_readback) {
       hipLaunchKernelGGL(k_lm_solve, dim3(count), dim3(kLmThreads), 0, h->stream, v, s0, it);
     }
   }
-  if (want_readback) {
-    // StreamState holds the published pose in final_odom and the diagnostics in info
-    HIP_TRY(hipMemcpyAsync(h->pinned, v.state + s0, sizeof(StreamState) * (size_t)count,
-                           hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipEventRecord(h->pose_event, h->stream));
-  }
-  const int map_blocks = cdiv(v.map_cap, 256);
+  (void)want_readback;   // results are published by k_lm_solve into host-mapped memory (HostOut)
+  for (int i = 0; i < count; i++) h->scans_enqueued[s0 + i]++;
+  const int map_blocks = cdiv(h->v.map_cap, 256);
   {
     ProfScope ps(h, KID_HASH_CLEAR);
     hipLaunchKernelGGL(k_hash_clear, dim3(map_blocks, count), dim3(256), 0, h->stream, v, s0);
@@ -181,16 +179,6 @@ int launch_odometry(liodom_handle* h, int s0, int count, bool want_readback) {
   return LIODOM_OK;
 }
 
-void pose_from_state(const StreamState& st, double* pose, liodom_step_info_t* info) {
-  if (pose) {
-    double q[4];
-    quat_from_rot(st.final_odom, q);
-    pose[0] = q[0]; pose[1] = q[1]; pose[2] = q[2]; pose[3] = q[3];
-    pose[4] = st.final_odom[3]; pose[5] = st.final_odom[7]; pose[6] = st.final_odom[11];
-  }
-  if (info) *info = st.info;
-}
-
 int check_stream(liodom_handle* h, int stream) {
   if (!h) return LIODOM_ERR_INVALID_ARG;
   if (stream < 0 || stream >= h->S) { g_last_error = "stream index out of range"; return LIODOM_ERR_INVALID_ARG; }
@@ -207,9 +195,13 @@ int reset_state(liodom_handle* h) {
     st.param_q[3] = 1.0;
   }
   HIP_TRY(hipMemcpyAsync(h->v.state, init.data(), sizeof(StreamState) * init.size(), hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(hipMemsetAsync(h->v.cell_key, 0xFF, sizeof(unsigned long long) * (size_t)h->S * h->v.table_size, h->stream));
-  HIP_TRY(hipMemsetAsync(h->v.cell_cnt, 0, sizeof(unsigned int) * (size_t)h->S * h->v.table_size, h->stream));
-  HIP_TRY(hipMemsetAsync(h->v.cell_fill, 0, sizeof(unsigned int) * (size_t)h->S * h->v.table_size, h->stream));
+  {
+    const size_t total = (size_t)h->S * h->v.table_size;
+    hipLaunchKernelGGL(k_init_cells, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, h->v);
+    HIP_TRY(hipGetLastError());
+  }
+  std::memset(h->host_out, 0, sizeof(HostOut) * (size_t)h->S);
+  std::fill(h->scans_enqueued.begin(), h->scans_enqueued.end(), 0);
   HIP_TRY(hipMemsetAsync(h->v.win_n, 0, sizeof(int) * (size_t)h->S * h->P, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   return LIODOM_OK;
@@ -291,15 +283,17 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   ring_cap = round_up(std::max(ring_cap, 256), 16);
   if (ring_cap > 6144) { g_last_error = "max_ring_points exceeds the 160 KiB LDS tile (6144 points)"; return fail(LIODOM_ERR_CAPACITY); }
   v.ring_cap = ring_cap;
-  h->ring_lds_bytes = (size_t)ring_cap * (8 + 12 + 4 + 1) + 64;
   v.slots_per_ring = params->scan_regions * (params->edges_per_region + 1);
+  h->ring_lds_bytes = ring_extract_lds_bytes(ring_cap, v.slots_per_ring, params->scan_regions);
+  if (h->ring_lds_bytes > 160 * 1024) { g_last_error = "ring tile + pick lists exceed 160 KiB of LDS"; return fail(LIODOM_ERR_CAPACITY); }
   v.edge_cap = round_up(std::max(1, h->H * v.slots_per_ring), 64);
   v.map_cap = v.edge_cap * h->P;
   int ts = 1024;
   while (ts < 2 * v.map_cap) ts <<= 1;
   v.table_size = ts;
   v.pose_log_cap = std::max(1, config->pose_log_capacity);
-  v.debug = config->debug_buffers;
+  v.debug = config->debug_buffers & 1;
+  if (const char* ab = getenv("LIODOM_ABLATE")) v.debug |= (atoi(ab) & ~1);   // measurement-only ablation bits
   v.ring_id_stride = (size_t)round_up(config->max_points + 512, 256);
 
   const size_t S = (size_t)h->S;
@@ -320,9 +314,7 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   ALLOC(v.win_n, S * h->P, 0);
   ALLOC(v.win_base, S * (h->P + 1), 0);
   ALLOC(v.win_slot, S * h->P, 0);
-  ALLOC(v.cell_key, S * v.table_size, 0xFF);
-  ALLOC(v.cell_cnt, S * v.table_size, 0);
-  ALLOC(v.cell_start, S * v.table_size, 0);
+  ALLOC(v.cells, S * v.table_size, 0);
   ALLOC(v.cell_fill, S * v.table_size, 0);
   ALLOC(v.used_cells, S * v.map_cap, 0);
   ALLOC(v.pt_cell, S * v.map_cap, 0xFF);
@@ -330,19 +322,30 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   ALLOC(v.pose_log, S * v.pose_log_cap * 7, 0);
   ALLOC(v.info_log, S * v.pose_log_cap, 0);
   ALLOC(h->stage_in, S * (size_t)config->max_points, 0);
-#undef ALLOC
-  h->pinned_bytes = std::max<size_t>(sizeof(StreamState) * S, 1 << 16);
-  if (hipHostMalloc(&h->pinned, h->pinned_bytes, hipHostMallocDefault) != hipSuccess) { g_last_error = "hipHostMalloc failed"; return fail(LIODOM_ERR_HIP); }
+  ALLOC(v.dbg_clk, 4 * 32, 0);
+  {
+    void* hp = nullptr;
+    if (hipHostMalloc(&hp, sizeof(HostOut) * S, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { g_last_error = "hipHostMalloc failed"; return fail(LIODOM_ERR_HIP); }
+    h->host_out = static_cast<HostOut*>(hp);
+    std::memset(hp, 0, sizeof(HostOut) * S);
+    void* dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) { g_last_error = "hipHostGetDevicePointer failed"; return fail(LIODOM_ERR_HIP); }
+    v.host_out = static_cast<HostOut*>(dp);
+    h->scans_enqueued.assign(S, 0);
+  }
   if (h->ring_lds_bytes > 48 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ring_extract), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)h->ring_lds_bytes) != hipSuccess) {
       g_last_error = "hipFuncSetAttribute(max dynamic LDS) failed"; return fail(LIODOM_ERR_HIP);
     }
   }
+  ALLOC(h->d_view, 1, 0);
+  if (hipMemcpy(h->d_view, &h->v, sizeof(DevView), hipMemcpyHostToDevice) != hipSuccess) { g_last_error = "DevView upload failed"; return fail(LIODOM_ERR_HIP); }
   rc = reset_state(h);
   if (rc != LIODOM_OK) return fail(rc);
   *out = h;
   return LIODOM_OK;
+#undef ALLOC
 }
 
 void liodom_destroy(liodom_handle_t* h) {
@@ -350,7 +353,7 @@ void liodom_destroy(liodom_handle_t* h) {
   if (h->stream) hipStreamSynchronize(h->stream);
   for (void* p : h->allocs) hipFree(p);
   if (h->resident) hipFree(h->resident);
-  if (h->pinned) hipHostFree(h->pinned);
+  if (h->host_out) hipHostFree(h->host_out);
   for (auto& e : h->ev_pool) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
   if (h->pose_event) hipEventDestroy(h->pose_event);
   if (h->stream) hipStreamDestroy(h->stream);
@@ -408,11 +411,23 @@ int liodom_get_edges(liodom_handle_t* h, int stream, float* edges_xyzi, int32_t*
 }
 
 static int wait_pose(liodom_handle_t* h, int s0, int count, double* pose_out, liodom_step_info_t* info) {
-  HIP_TRY(hipEventSynchronize(h->pose_event));
-  const StreamState* st = static_cast<const StreamState*>(h->pinned);
-  for (int i = 0; i < count; i++)
-    pose_from_state(st[i], pose_out ? pose_out + 7 * i : nullptr, info ? info + i : nullptr);
-  (void)s0;
+  // zero-copy: k_lm_solve's finalize writes pose + diagnostics into host-mapped memory and
+  // releases HostOut.seq; spin on it (an event / memcpy round trip costs ~15 us on this stack)
+  for (int i = 0; i < count; i++) {
+    volatile HostOut* ho = h->host_out + s0 + i;
+    const int expect = h->scans_enqueued[s0 + i];
+    unsigned long long spins = 0;
+    while (__atomic_load_n(&ho->seq, __ATOMIC_ACQUIRE) != expect) {
+      if ((++spins & 0xFFFFull) == 0) {
+        const hipError_t q = hipStreamQuery(h->stream);
+        if (q != hipErrorNotReady && q != hipSuccess) { g_last_error = std::string("stream error while waiting: ") + hipGetErrorString(q); return LIODOM_ERR_HIP; }
+        if (q == hipSuccess && __atomic_load_n(&ho->seq, __ATOMIC_ACQUIRE) != expect) { g_last_error = "stream drained without publishing the scan result"; return LIODOM_ERR_HIP; }
+      }
+    }
+    const HostOut* r = h->host_out + s0 + i;
+    if (pose_out) std::memcpy(pose_out + 7 * i, r->pose, sizeof(double) * 7);
+    if (info) info[i] = r->info;
+  }
   return LIODOM_OK;
 }
 
@@ -602,11 +617,22 @@ int liodom_reset_kernel_stats(liodom_handle_t* h) {
   return rc;
 }
 
+/* debug: raw phase timestamps (100 MHz) written by the kernels when LIODOM_ABLATE has bit 5 set */
+int liodom_debug_clocks(liodom_handle_t* h, unsigned long long* out128) {
+  if (!h || !out128) return LIODOM_ERR_INVALID_ARG;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(out128, h->v.dbg_clk, sizeof(unsigned long long) * 128, hipMemcpyDeviceToHost));
+  return LIODOM_OK;
+}
+
 int liodom_device_info(liodom_handle_t* h, char* name, int name_cap, int* compute_units) {
   if (!h) return LIODOM_ERR_INVALID_ARG;
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, h->config.device));
-  if (name && name_cap > 0) { std::strncpy(name, prop.name, (size_t)name_cap - 1); name[name_cap - 1] = 0; }
+  if (name && name_cap > 0) {
+    const char* nm = prop.name[0] ? prop.name : prop.gcnArchName;   // some driver stacks leave name empty
+    std::strncpy(name, nm, (size_t)name_cap - 1); name[name_cap - 1] = 0;
+  }
   if (compute_units) *compute_units = prop.multiProcessorCount;
   return LIODOM_OK;
 }

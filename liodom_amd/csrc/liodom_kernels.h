@@ -21,6 +21,7 @@
 
 #include "../../include/liodom_hip.h"
 #include "liodom_math.h"
+#include "wave_ops.h"
 
 namespace liodom_dev {
 
@@ -52,6 +53,22 @@ struct StreamState {
   liodom_step_info_t info;
 };
 
+// One voxel-hash slot (16 B, 16-B aligned).
+struct __attribute__((aligned(16))) CellSlot {
+  unsigned long long key;   // packed cell coordinates or kEmptyKey
+  unsigned int start;       // first point of the cell in sorted_pts
+  unsigned int cnt;         // points in the cell
+};
+
+// Per-stream result record in host-mapped memory.  seq is written last (system-scope release)
+// with the number of scans completed; the host spins on it instead of using events / memcpy.
+struct HostOut {
+  double pose[7];
+  liodom_step_info_t info;
+  int seq;
+  int pad;
+};
+
 // Everything the kernels need (passed by value).
 struct DevView {
   // parameters
@@ -81,19 +98,21 @@ struct DevView {
   int* win_n;               // [S][P]
   int* win_base;            // [S][P+1] logical prefix (oldest first)
   int* win_slot;            // [S][P]  logical frame -> slot
-  unsigned long long* cell_key;  // [S][table_size]
-  unsigned int* cell_cnt;
-  unsigned int* cell_start;
-  unsigned int* cell_fill;
+  CellSlot* cells;          // [S][table_size]  {key, start, cnt}: one 16-B load per probe
+  unsigned int* cell_fill;  // [S][table_size]  scatter cursor per cell
   int* used_cells;          // [S][map_cap]
   int* pt_cell;             // [S][map_cap]
   float4* sorted_pts;       // [S][map_cap]  xyz + window index bits
   double* pose_log;         // [S][pose_log_cap][7]
   liodom_step_info_t* info_log;  // [S][pose_log_cap]
+  HostOut* host_out;        // [S] host-mapped pinned memory, polled by the host (zero-copy)
+  unsigned long long* dbg_clk;  // [4][32] phase timestamps (100 MHz), debug bit 5 only
 };
 
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
+// debug-only phase stamps: kernel slot k, stamp index i (constant 100 MHz wall clock)
+#define DBG_STAMP(v, cond, k, i) do { if (((v).debug & 32) && (cond)) (v).dbg_clk[(k) * 32 + (i)] = wall_clock64(); } while (0)
 
 __device__ __forceinline__ unsigned long long pack_cell(int cx, int cy, int cz) {
   const unsigned long long m = 0x1FFFFFull;  // 21 bits per axis; aliasing only adds far candidates
@@ -132,35 +151,165 @@ __global__ __launch_bounds__(256) void k_classify(DevView v, int s0, const float
 }
 
 // =============================================================================================
-// k_ring_extract: one 256-thread workgroup per (ring, stream).
-//   phase 0  scan the ring-id bytes (16 per lane per step), stable-compact the indices of this
-//            ring's points into LDS (wave prefix via shfl + cross-wave LDS)
+// k_ring_extract: one 512-thread workgroup per (ring, stream).
+//   phase 0  every thread scans a contiguous span of the ring-id bytes (16 B loads, SWAR byte
+//            match), one workgroup-wide exclusive scan (DPP wave scan + LDS), second pass writes
+//            the matching point indices in input order -> stable compaction into LDS
 //   phase 1  gather XYZ of those points (16-B loads) into an SoA LDS tile
 //   phase 2  FP64 11-tap curvature stencil out of LDS
-//   phase 3  wave 0: per region, repeat { wavefront argmax over not-picked items (shfl butterfly,
-//            lowest index on ties); stop below 0.1 or after epr+1 picks; emit; suppress +-5
-//            neighbours while consecutive gaps <= 0.05 (ballot) }.  Regions run in order because
-//            suppression carries across region boundaries.
-// LDS: c[cap] f64 | px py pz [cap] f32 | src[cap] i32 | picked[cap] u8 | scratch
+//   phase 3  selection.  Per region: repeat { wavefront argmax of smoothness over not-picked
+//            items (DPP / permlane-swap butterfly, lowest index on ties); stop below 0.1 or after
+//            epr+1 picks; suppress +-5 neighbours while consecutive gaps <= 0.05 (ballot) }.
+//            The reference walks regions in order because suppression carries across region
+//            boundaries.  Here the 8 waves run the regions speculatively
+//            in parallel (candidates register-resident, 4 or 8 per lane) assuming no carry;
+//            wave 0 then replays the carry in region order and re-runs only regions in which a
+//            speculative pick was suppressed by an earlier region (exact: marking an item that
+//            the speculative run never picked cannot change that run).
+//   phase 4  all threads write the picks in region order.
+// LDS: c[cap] f64 | px py pz [cap] f32 | src[cap] i32 | picked[cap] u8 | pick_idx[slots] i32 |
+//      pick_nfnb[slots] u8 | region_cnt[R] i32 | scratch
 // =============================================================================================
-__device__ __forceinline__ size_t ring_extract_lds_bytes(int cap) {
-  return (size_t)cap * (8 + 12 + 4 + 1) + 64;
+constexpr int kExThreads = 512;
+constexpr int kExWaves = kExThreads / 64;
+
+__host__ __device__ __forceinline__ size_t ring_extract_lds_bytes(int cap, int slots, int regions) {
+  size_t b = (size_t)cap * (8 + 12 + 4 + 1);
+  b += (size_t)slots * 4;
+  b += (size_t)((slots + 15) / 16 * 16);
+  b += (size_t)regions * 4 + 16 * 8 * 4 + 64;
+  return (b + 15) / 16 * 16;
 }
 
-__global__ __launch_bounds__(256) void k_ring_extract(DevView v, int s0, const float4* __restrict__ in,
-                                                       size_t in_stride, int n, int height, int width) {
+// 16-bit mask of the bytes of w equal to `ring` (SWAR exact zero-byte test).
+__device__ __forceinline__ unsigned int match16(const uint4 w, unsigned int pat) {
+  unsigned int m = 0;
+  const unsigned int words[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const unsigned int z = words[k] ^ pat;
+    const unsigned int t = ~(((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z | 0x7F7F7F7Fu);   // 0x80 per zero byte
+    const unsigned int nib = ((t >> 7) & 1u) | ((t >> 14) & 2u) | ((t >> 21) & 4u) | ((t >> 28) & 8u);
+    m |= nib << (4 * k);
+  }
+  return m;
+}
+__device__ __forceinline__ unsigned int range16(int base, int lo, int hi) {
+  if (base >= lo && base + 16 <= hi) return 0xFFFFu;
+  unsigned int m = 0;
+  for (int b = 0; b < 16; b++) if (base + b >= lo && base + b < hi) m |= 1u << b;
+  return m;
+}
+
+// Suppression test around pick j (feature_extractor.cc:280-310): lanes 0-4 test the forward
+// gaps l = 1..5, lanes 8-12 the backward gaps.  Returns nf | nb << 4 (neighbours marked).
+__device__ __forceinline__ int suppression_extent(const float* px, const float* py, const float* pz,
+                                                  int j, int lane) {
+  bool brk = false;
+  const int l = (lane & 7) + 1;
+  if (lane < 5) brk = gap_sq(px, py, pz, j + l, j + l - 1) > 0.05;
+  else if (lane >= 8 && lane < 13) brk = gap_sq(px, py, pz, j - l, j - l + 1) > 0.05;
+  const unsigned long long bal = __ballot(brk);
+  const unsigned int bf = (unsigned int)(bal & 0x1Fu), bb = (unsigned int)((bal >> 8) & 0x1Fu);
+  const int nf = bf ? (__ffs(bf) - 1) : 5;
+  const int nb = bb ? (__ffs(bb) - 1) : 5;
+  return nf | (nb << 4);
+}
+
+// Generic region selection on the shared picked[] array (any region length).  Writes its own
+// suppression marks into picked[].  One wave.  Returns the number of picks.
+__device__ int select_region_lds(const double* c, const float* px, const float* py, const float* pz,
+                                 volatile unsigned char* vpicked, int rs, int re, int epr, int lane,
+                                 int* out_idx, unsigned char* out_nfnb) {
+  int picks = 0;
+  while (true) {
+    unsigned long long bkey = 0;
+    int bidx = 0x7fffffff;
+    for (int k = rs + lane; k < re; k += 64) {
+      const int j = k + 5;
+      if (!vpicked[j]) {
+        const unsigned long long key = (unsigned long long)__double_as_longlong(c[j]);
+        if (bidx == 0x7fffffff || key > bkey) { bkey = key; bidx = j; }
+      }
+    }
+    const unsigned long long has = __ballot(bidx != 0x7fffffff);
+    if (!has) break;                                               // every item already picked
+    const unsigned long long m = wave_max_u64(bidx != 0x7fffffff ? bkey : 0ull);
+    const double best = __longlong_as_double((long long)m);
+    if (best < 0.1 || picks > epr) break;                          // :270
+    const int j = wave_min_i32((bidx != 0x7fffffff && bkey == m) ? bidx : 0x7fffffff);   // ties: lowest index
+    const int ext = suppression_extent(px, py, pz, j, lane);
+    const int nf = ext & 15, nb = ext >> 4;
+    if (lane == 0) { out_idx[picks] = j; out_nfnb[picks] = (unsigned char)ext; vpicked[j] = 1; }   // :275-277
+    if (lane >= 1 && lane <= nf) vpicked[j + lane] = 1;            // :293
+    if (lane >= 9 && lane <= 8 + nb) vpicked[j - (lane - 8)] = 1;  // :309
+    picks++;                                                       // :276
+    __builtin_amdgcn_wave_barrier();
+  }
+  return picks;
+}
+
+// Speculative region selection with register-resident candidates: lane owns IPL consecutive
+// items; no access to picked[] (assumes nothing was suppressed by earlier regions).
+template <int IPL>
+__device__ int select_region_spec(const double* c, const float* px, const float* py, const float* pz,
+                                  int rs, int re, int epr, int lane, int* out_idx, unsigned char* out_nfnb) {
+  unsigned long long ck[IPL];
+  unsigned int pm = 0;                       // bit i set: item i unavailable
+  const int j0 = rs + lane * IPL + 5;        // ring index of this lane's first item
+#pragma unroll
+  for (int i = 0; i < IPL; i++) {
+    const int k = rs + lane * IPL + i;
+    if (k < re) ck[i] = (unsigned long long)__double_as_longlong(c[k + 5]);
+    else { ck[i] = 0; pm |= 1u << i; }
+  }
+  int picks = 0;
+  while (true) {
+    unsigned long long bk = 0;
+    int bi = -1;
+#pragma unroll
+    for (int i = 0; i < IPL; i++) {
+      if (!((pm >> i) & 1u) && (bi < 0 || ck[i] > bk)) { bk = ck[i]; bi = i; }
+    }
+    const unsigned long long m = wave_max_u64(bi >= 0 ? bk : 0ull);
+    const double best = __longlong_as_double((long long)m);
+    // no candidate anywhere -> m == 0 -> best = 0.0 < 0.1 -> stop (same as the reference's
+    // loop running out of items)
+    if (best < 0.1 || picks > epr) break;                          // :270
+    const unsigned long long win = __ballot(bi >= 0 && bk == m);
+    const int wl = __ffsll((long long)win) - 1;                    // lowest lane = lowest index
+    const int j = readlane_i32(j0 + bi, wl);
+    const int ext = suppression_extent(px, py, pz, j, lane);
+    const int nf = ext & 15, nb = ext >> 4;
+    if (lane == 0) { out_idx[picks] = j; out_nfnb[picks] = (unsigned char)ext; }
+#pragma unroll
+    for (int i = 0; i < IPL; i++) {
+      const int idx = j0 + i;
+      if (idx >= j - nb && idx <= j + nf) pm |= 1u << i;
+    }
+    picks++;
+  }
+  return picks;
+}
+
+__global__ __launch_bounds__(kExThreads) void k_ring_extract(DevView v, int s0, const float4* __restrict__ in,
+                                                              size_t in_stride, int n, int height, int width) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int ring = blockIdx.x;
   const int s = s0 + blockIdx.y;
   const int cap = v.ring_cap;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int R = v.scan_regions, epr = v.edges_per_region, slots = v.slots_per_ring;
   double* c = reinterpret_cast<double*>(smem);
   float* px = reinterpret_cast<float*>(c + cap);
   float* py = px + cap;
   float* pz = py + cap;
   int* src = reinterpret_cast<int*>(pz + cap);
   unsigned char* picked = reinterpret_cast<unsigned char*>(src + cap);
-  int* wtot = reinterpret_cast<int*>(picked + cap);   // 4 ints (cap is a multiple of 16)
+  int* pick_idx = reinterpret_cast<int*>(picked + cap);                 // [R][epr+1]
+  unsigned char* pick_nfnb = reinterpret_cast<unsigned char*>(pick_idx + slots);
+  int* region_cnt = reinterpret_cast<int*>(pick_nfnb + (slots + 15) / 16 * 16);   // [R]
+  int* wtot = region_cnt + R;                                            // [16 * kExWaves] scan scratch
 
   const float4* scan = in + (size_t)blockIdx.y * in_stride;
   const unsigned char* ids = v.ring_id + (size_t)s * v.ring_id_stride;
@@ -168,6 +317,8 @@ __global__ __launch_bounds__(256) void k_ring_extract(DevView v, int s0, const f
   int* nedges_out = v.ring_nedges + (size_t)s * H + ring;
   int* npoints_out = v.ring_npoints + (size_t)s * H + ring;
 
+  const bool dbgb = (ring == 40 % H) && (s == 0) && (tid == 0);
+  DBG_STAMP(v, dbgb, 0, 0);
   // ---- phase 0: stable compaction of this ring's point indices ----
   int lo = 0, hi = n;
   if (v.lidar_type != 0) {
@@ -176,43 +327,81 @@ __global__ __launch_bounds__(256) void k_ring_extract(DevView v, int s0, const f
     if (hi > n) hi = n;
     if (lo > hi || ring >= height) { lo = 0; hi = 0; }
   }
-  int count = 0;
-  for (int chunk = lo & ~15; chunk < hi; chunk += 256 * 16) {
-    const int base = chunk + 16 * tid;
-    unsigned int m = 0;
-    if (base < hi) {
-      const uint4 w = *reinterpret_cast<const uint4*>(ids + base);
-      const unsigned int words[4] = {w.x, w.y, w.z, w.w};
+  const int first16 = lo >> 4;
+  const int n16 = (hi > lo) ? (((hi + 15) >> 4) - first16) : 0;     // 16-byte id chunks in range
+  const int per = (n16 + kExThreads - 1) / kExThreads;              // chunks per thread
+  const unsigned int pat = (unsigned int)ring * 0x01010101u;
+  // Chunk u = b * 512 + tid (coalesced: a wave reads 1 KiB of consecutive ids per load, all
+  // loads of a thread in flight together).  Match masks stay in registers for the write pass.
+  // The compaction order is the chunk order, i.e. the input order.
+  constexpr int kIdRegs = 16;
+  int nr = 0;
+  if (per <= kIdRegs) {
+    uint4 w[kIdRegs];
 #pragma unroll
-      for (int b = 0; b < 16; b++) {
-        const unsigned int byte = (words[b >> 2] >> ((b & 3) * 8)) & 0xFFu;
-        const int pos = base + b;
-        if (byte == (unsigned int)ring && pos >= lo && pos < hi) m |= (1u << b);
+    for (int b = 0; b < kIdRegs; b++) {
+      const int u = b * kExThreads + tid;
+      w[b] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+      if (u < n16) w[b] = *reinterpret_cast<const uint4*>(ids + ((first16 + u) << 4));
+    }
+    unsigned int mreg[kIdRegs];
+    int incl[kIdRegs];
+#pragma unroll
+    for (int b = 0; b < kIdRegs; b++) {
+      const int u = b * kExThreads + tid;
+      mreg[b] = (u < n16) ? (match16(w[b], pat) & range16((first16 + u) << 4, lo, hi)) : 0u;
+      incl[b] = (b < per) ? wave_incl_scan_i32(__popc(mreg[b])) : 0;
+      if (lane == 63 && b < per) wtot[b * kExWaves + wave] = incl[b];
+    }
+    __syncthreads();
+    int run = 0;
+#pragma unroll
+    for (int b = 0; b < kIdRegs; b++) {
+      if (b < per) {
+        int pre = 0, tot = 0;
+#pragma unroll
+        for (int q = 0; q < kExWaves; q++) { const int t = wtot[b * kExWaves + q]; if (q < wave) pre += t; tot += t; }
+        int off = run + pre + incl[b] - __popc(mreg[b]);
+        unsigned int m = mreg[b];
+        const int base = (first16 + b * kExThreads + tid) << 4;
+        while (m) {
+          const int bit = __ffs(m) - 1;
+          m &= m - 1;
+          if (off < cap) src[off] = base + bit;
+          off++;
+        }
+        run += tot;
       }
     }
-    const int cnt = __popc(m);
-    int incl = cnt;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const int t = __shfl_up(incl, off);
-      if (lane >= off) incl += t;
+    nr = run;
+  } else {
+    // very long id ranges (> 131072 ids per ring workgroup): contiguous span per thread, re-read
+    const int u0 = tid * per, u1 = (u0 + per < n16) ? (u0 + per) : n16;
+    int cnt = 0;
+    for (int u = u0; u < u1; u++) {
+      const int base = (first16 + u) << 4;
+      const uint4 w = *reinterpret_cast<const uint4*>(ids + base);
+      cnt += __popc(match16(w, pat) & range16(base, lo, hi));
     }
+    const int incl = wave_incl_scan_i32(cnt);
     if (lane == 63) wtot[wave] = incl;
     __syncthreads();
-    int pre = 0, tot = 0;
+    int pre = 0;
 #pragma unroll
-    for (int w = 0; w < 4; w++) { const int t = wtot[w]; if (w < wave) pre += t; tot += t; }
-    int off = count + pre + incl - cnt;
-    while (m) {
-      const int b = __ffs(m) - 1;
-      m &= m - 1;
-      if (off < cap) src[off] = base + b;
-      off++;
+    for (int q = 0; q < kExWaves; q++) { const int t = wtot[q]; if (q < wave) pre += t; nr += t; }
+    int off = pre + incl - cnt;
+    for (int u = u0; u < u1; u++) {
+      const int base = (first16 + u) << 4;
+      const uint4 w = *reinterpret_cast<const uint4*>(ids + base);
+      unsigned int m = match16(w, pat) & range16(base, lo, hi);
+      while (m) {
+        const int b = __ffs(m) - 1;
+        m &= m - 1;
+        if (off < cap) src[off] = base + b;
+        off++;
+      }
     }
-    count += tot;
-    __syncthreads();
   }
-  const int nr = count;
   if (tid == 0) *npoints_out = nr;
   if (nr > cap) {   // ring does not fit the LDS tile: flagged, ring skipped
     if (tid == 0) { atomicOr(&v.state[s].status, LIODOM_STATUS_RING_OVERFLOW); *nedges_out = 0; }
@@ -223,90 +412,128 @@ __global__ __launch_bounds__(256) void k_ring_extract(DevView v, int s0, const f
     if (tid == 0) *nedges_out = 0;
     if (v.debug && v.curv_dbg) {
       double* dbg = v.curv_dbg + ((size_t)s * H + ring) * cap;
-      for (int j = tid; j < nr; j += 256) dbg[j] = __longlong_as_double(0x7ff8000000000000ll);
+      for (int j = tid; j < nr; j += kExThreads) dbg[j] = __longlong_as_double(0x7ff8000000000000ll);
     }
     return;
   }
+  __syncthreads();
+  DBG_STAMP(v, dbgb, 0, 2);
   // ---- phase 1: gather the points ----
-  for (int k = tid; k < nr; k += 256) {
-    const float4 p = scan[src[k]];
-    px[k] = p.x; py[k] = p.y; pz[k] = p.z;
-    picked[k] = 0;
+  for (int k0 = tid; k0 < nr; k0 += 4 * kExThreads) {    // 4 gathers in flight per thread
+    float4 p[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const int k = k0 + u * kExThreads; if (k < nr) p[u] = scan[src[k]]; }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int k = k0 + u * kExThreads;
+      if (k < nr) { px[k] = p[u].x; py[k] = p[u].y; pz[k] = p[u].z; picked[k] = 0; }
+    }
   }
   __syncthreads();
+  DBG_STAMP(v, dbgb, 0, 3);
   // ---- phase 2: curvature ----
-  for (int j = 5 + tid; j < nr - 5; j += 256) c[j] = curvature(px, py, pz, j);
+  for (int j = 5 + tid; j < nr - 5; j += kExThreads) c[j] = curvature(px, py, pz, j);
   __syncthreads();
   if (v.debug && v.curv_dbg) {
     double* dbg = v.curv_dbg + ((size_t)s * H + ring) * cap;
-    for (int j = tid; j < nr; j += 256)
+    for (int j = tid; j < nr; j += kExThreads)
       dbg[j] = (j >= 5 && j < nr - 5) ? c[j] : __longlong_as_double(0x7ff8000000000000ll);
   }
-  if (wave != 0) return;
 
-  // ---- phase 3: selection (wave 0) ----
+  DBG_STAMP(v, dbgb, 0, 4);
+  // ---- phase 3: selection ----
   const int total = nr - 10;                            // :238
-  const int R = v.scan_regions;
   const int sector = total / R;                         // :239
-  const int epr = v.edges_per_region;
-  float4* eout = v.edges_pad + ((size_t)s * H + ring) * v.slots_per_ring;
-  int2* mout = v.edges_pad_meta + ((size_t)s * H + ring) * v.slots_per_ring;
+  const int last_len = total - sector * (R - 1);
+  const int max_len = sector > last_len ? sector : last_len;
+  const int ppr = epr + 1;                              // picks per region (:270)
   volatile unsigned char* vpicked = picked;
-  int nout = 0;
-  for (int reg = 0; reg < R; reg++) {
-    const int rs = sector * reg;
-    const int re = (reg == R - 1) ? total : sector * (reg + 1);   // :242-247
-    int picks = 0;
-    while (true) {
-      // wavefront argmax of smoothness over not-picked items; ties -> lowest index
-      unsigned long long bkey = 0;
-      int bidx = -1;
-      for (int k = rs + lane; k < re; k += 64) {
-        const int j = k + 5;
-        if (!vpicked[j]) {
-          const unsigned long long key = (unsigned long long)__double_as_longlong(c[j]);
-          if (bidx < 0 || key > bkey) { bkey = key; bidx = j; }
+  if (v.debug & 16) {
+    if (tid < R) region_cnt[tid] = 0;
+  } else if (max_len <= 512) {
+    for (int reg = wave; reg < R; reg += kExWaves) {
+      const int rs = sector * reg;
+      const int re = (reg == R - 1) ? total : sector * (reg + 1);   // :242-247
+      int cntp;
+      if (max_len <= 256) cntp = select_region_spec<4>(c, px, py, pz, rs, re, epr, lane, pick_idx + reg * ppr, pick_nfnb + reg * ppr);
+      else cntp = select_region_spec<8>(c, px, py, pz, rs, re, epr, lane, pick_idx + reg * ppr, pick_nfnb + reg * ppr);
+      if (lane == 0) region_cnt[reg] = cntp;
+    }
+    // Forward spill of every region's speculative picks into the following regions.
+    for (int reg = wave; reg < R; reg += kExWaves) {
+      const int end_j = ((reg == R - 1) ? total : sector * (reg + 1)) + 5;   // first ring index after the region
+      const int cntp = region_cnt[reg];
+      for (int k = lane; k < cntp; k += 64) {
+        const int j = pick_idx[reg * ppr + k];
+        const int nf = pick_nfnb[reg * ppr + k] & 15;
+        for (int l = 1; l <= nf; l++) if (j + l >= end_j) vpicked[j + l] = 1;
+      }
+    }
+    if (tid == 0) wtot[0] = 0;
+    __syncthreads();
+    DBG_STAMP(v, dbgb, 0, 5);
+    // A region's speculative result is final unless one of its picks was suppressed by an
+    // earlier region.  No conflict anywhere (the common case) -> all regions are final.
+    for (int reg = wave; reg < R; reg += kExWaves) {
+      const int cntp = region_cnt[reg];
+      bool conflict = false;
+      for (int k = lane; k < cntp; k += 64) conflict = conflict || (vpicked[pick_idx[reg * ppr + k]] != 0);
+      if (__ballot(conflict) && lane == 0) wtot[0] = 1;
+    }
+    __syncthreads();
+    if (wtot[0] != 0) {
+      // rare: replay the carry in region order from a clean picked[] array
+      for (int k = tid; k < nr; k += kExThreads) picked[k] = 0;
+      __syncthreads();
+      if (wave == 0) {
+        for (int reg = 0; reg < R; reg++) {
+          int cntp = region_cnt[reg];
+          bool conflict = false;
+          for (int k = lane; k < cntp; k += 64) conflict = conflict || (vpicked[pick_idx[reg * ppr + k]] != 0);
+          if (__ballot(conflict)) {
+            const int rs = sector * reg;
+            const int re = (reg == R - 1) ? total : sector * (reg + 1);
+            cntp = select_region_lds(c, px, py, pz, vpicked, rs, re, epr, lane, pick_idx + reg * ppr, pick_nfnb + reg * ppr);
+            if (lane == 0) region_cnt[reg] = cntp;
+          } else {
+            for (int k = lane; k < cntp; k += 64) {
+              const int j = pick_idx[reg * ppr + k];
+              const int ext = pick_nfnb[reg * ppr + k];
+              const int nf = ext & 15, nb = ext >> 4;
+              for (int l = -nb; l <= nf; l++) vpicked[j + l] = 1;
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
         }
       }
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) {
-        const unsigned long long ok = __shfl_xor(bkey, off);
-        const int oi = __shfl_xor(bidx, off);
-        const bool better = (oi >= 0) && (bidx < 0 || ok > bkey || (ok == bkey && oi < bidx));
-        if (better) { bkey = ok; bidx = oi; }
-      }
-      if (bidx < 0) break;                                         // every item already picked
-      const double best = __longlong_as_double((long long)bkey);
-      if (best < 0.1 || picks > epr) break;                        // :270
-      const int j = bidx;
-      if (lane == 0) {
-        if (nout < v.slots_per_ring) {
-          const int sidx = src[j];
-          eout[nout] = make_float4(px[j], py[j], pz[j], scan[sidx].w);   // :275
-          mout[nout] = make_int2(j, sidx);
-        }
-      }
-      nout++;
-      picks++;                                                     // :276
-      // suppression: lanes 0-4 test forward gaps l=1..5, lanes 8-12 backward gaps (:280-310)
-      bool brk = false;
-      const int l = (lane & 7) + 1;
-      if (lane < 5) brk = gap_sq(px, py, pz, j + l, j + l - 1) > 0.05;
-      else if (lane >= 8 && lane < 13) brk = gap_sq(px, py, pz, j - l, j - l + 1) > 0.05;
-      const unsigned long long bal = __ballot(brk);
-      const unsigned int bf = (unsigned int)(bal & 0x1Fu), bb = (unsigned int)((bal >> 8) & 0x1Fu);
-      const int nf = bf ? (__ffs(bf) - 1) : 5;    // forward neighbours marked
-      const int nb = bb ? (__ffs(bb) - 1) : 5;
-      if (lane == 0) vpicked[j] = 1;                               // :277
-      if (lane < 5 && (lane & 7) < nf) vpicked[j + l] = 1;         // :293
-      if (lane >= 8 && lane < 13 && (lane & 7) < nb) vpicked[j - l] = 1;   // :309
-      __builtin_amdgcn_wave_barrier();
+    }
+  } else if (wave == 0) {
+    // very long regions: plain in-order selection on the shared picked[] array
+    for (int reg = 0; reg < R; reg++) {
+      const int rs = sector * reg;
+      const int re = (reg == R - 1) ? total : sector * (reg + 1);
+      const int cntp = select_region_lds(c, px, py, pz, vpicked, rs, re, epr, lane, pick_idx + reg * ppr, pick_nfnb + reg * ppr);
+      if (lane == 0) region_cnt[reg] = cntp;
     }
   }
-  if (lane == 0) {
-    if (nout > v.slots_per_ring) { atomicOr(&v.state[s].status, LIODOM_STATUS_EDGE_OVERFLOW); nout = v.slots_per_ring; }
-    *nedges_out = nout;
+  __syncthreads();
+  DBG_STAMP(v, dbgb, 0, 6);
+  // ---- phase 4: emit in region order, pick order (:275) ----
+  float4* eout = v.edges_pad + ((size_t)s * H + ring) * slots;
+  int2* mout = v.edges_pad_meta + ((size_t)s * H + ring) * slots;
+  int base = 0;
+  for (int reg = 0; reg < R; reg++) {
+    const int cntp = region_cnt[reg];
+    for (int k = tid; k < cntp; k += kExThreads) {
+      const int j = pick_idx[reg * ppr + k];
+      const int sidx = src[j];
+      eout[base + k] = make_float4(px[j], py[j], pz[j], scan[sidx].w);
+      mout[base + k] = make_int2(j, sidx);
+    }
+    base += cntp;
   }
+  if (tid == 0) *nedges_out = base;
+  DBG_STAMP(v, dbgb, 0, 7);
 }
 
 // =============================================================================================
@@ -315,13 +542,26 @@ __global__ __launch_bounds__(256) void k_ring_extract(DevView v, int s0, const f
 // =============================================================================================
 __global__ __launch_bounds__(256) void k_compact_edges(DevView v, int s0) {
   __shared__ int pre[257];
+  __shared__ int cntr[256];
   const int s = s0 + blockIdx.x;
   const int H = v.scan_lines;
   const int* rn = v.ring_nedges + (size_t)s * H;
+  {
+    // exclusive prefix over the H <= 256 ring counts: DPP wave scan + 4 wave totals
+    const int mine = ((int)threadIdx.x < H) ? rn[threadIdx.x] : 0;
+    const int incl = wave_incl_scan_i32(mine);
+    if ((threadIdx.x & 63) == 63) cntr[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); w++) base += cntr[w];
+    pre[threadIdx.x] = base + incl - mine;
+    if (threadIdx.x == 255) pre[256] = base + incl;
+    __syncthreads();
+    // threads >= H contribute 0, so pre[H] already equals the total
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
-    int acc = 0;
-    for (int r = 0; r < H; r++) { pre[r] = acc; acc += rn[r]; }
-    pre[H] = acc;
+    const int acc = pre[256];
     StreamState& st = v.state[s];
     st.n_edges = acc > v.edge_cap ? v.edge_cap : acc;
     st.info.n_edges = st.n_edges;
@@ -363,22 +603,110 @@ __global__ void k_set_edges(DevView v, int s0, int n_edges) {
 
 // =============================================================================================
 // k_knn: 32 lanes per edge (8 edges per 256-thread workgroup).
-//   lane c < 27 probes the voxel hash for neighbour cell c of the query's 1 m cell (a 27-cell
-//   search is exact for every edge that can pass the sq_dist[4] < 1.0 gate);
-//   the half-wave then strides over the points of each occupied cell (coalesced 16-B loads),
-//   every lane keeping its own sorted top-5 of (float distance, window index); five shfl
-//   min-reductions merge the 32 lists.  Line gate in FP64, then NN0 / NN1 are written as the
-//   line points (laser_odometry.cc:351-357).
+//   lane c < 27 probes the voxel hash for neighbour cell c of the query's 1 m cell (one 16-B
+//   slot load per probe; a 27-cell search is exact for every edge that can pass the
+//   sq_dist[4] < 1.0 gate).  Phase 1 streams the query's own cell; phase 2 only
+//   the neighbour cells whose box distance is below the current 5th-best distance (exact
+//   pruning, typically 0-3 cells instead of 26).  Cell populations are prefix-summed over the
+//   half-wave (DPP scan) into one flat candidate list; the 32 lanes stride over it with four
+//   independent 16-B loads in flight, each lane keeping a sorted top-5 of (float distance,
+//   window index); five DPP/permlane min-reductions merge the 32 lists.  Line gate in FP64,
+//   then NN0 / NN1 are written as the line points (laser_odometry.cc:351-357).
 // =============================================================================================
+struct Top5 {
+  float d0, d1, d2, d3, d4;
+  int i0, i1, i2, i3, i4;     // window index (tie-break)
+  int p0, p1, p2, p3, p4;     // position in the cell-sorted array
+};
+__device__ __forceinline__ void top5_insert(Top5& t, float d, int wi, int pos) {
+  if (d < t.d4 || (d == t.d4 && wi < t.i4)) {
+    t.d4 = d; t.i4 = wi; t.p4 = pos;
+    if (t.d4 < t.d3 || (t.d4 == t.d3 && t.i4 < t.i3)) { float td = t.d3; t.d3 = t.d4; t.d4 = td; int ti = t.i3; t.i3 = t.i4; t.i4 = ti; ti = t.p3; t.p3 = t.p4; t.p4 = ti; }
+    if (t.d3 < t.d2 || (t.d3 == t.d2 && t.i3 < t.i2)) { float td = t.d2; t.d2 = t.d3; t.d3 = td; int ti = t.i2; t.i2 = t.i3; t.i3 = ti; ti = t.p2; t.p2 = t.p3; t.p3 = ti; }
+    if (t.d2 < t.d1 || (t.d2 == t.d1 && t.i2 < t.i1)) { float td = t.d1; t.d1 = t.d2; t.d2 = td; int ti = t.i1; t.i1 = t.i2; t.i2 = ti; ti = t.p1; t.p1 = t.p2; t.p2 = ti; }
+    if (t.d1 < t.d0 || (t.d1 == t.d0 && t.i1 < t.i0)) { float td = t.d0; t.d0 = t.d1; t.d1 = td; int ti = t.i0; t.i0 = t.i1; t.i1 = ti; ti = t.p0; t.p0 = t.p1; t.p1 = ti; }
+  }
+}
+
+// Streams the candidates of the cells selected by (start, cnt) [one cell per lane of the
+// half-wave] through the per-lane top-5 lists: population prefix (DPP scan) -> flat candidate
+// list -> 32 lanes stride over it, four independent 16-B loads in flight per lane.
+__device__ __forceinline__ void knn_stream_cells(Top5& t, const float4* sp, int* s_incl, int* s_adj,
+                                                 unsigned int start, unsigned int cnt, int hl,
+                                                 float qx, float qy, float qz) {
+  const int incl = half_incl_scan_i32((int)cnt);
+  s_incl[hl] = incl;
+  s_adj[hl] = (int)start - (incl - (int)cnt);
+  __builtin_amdgcn_wave_barrier();
+  const int T = s_incl[kKnnGroup - 1];
+  int c = 0;   // cell cursor (monotone: the flat index only grows)
+  for (int i = hl; i < T; i += 4 * kKnnGroup) {
+    int a[4];
+    bool ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int iu = i + u * kKnnGroup;
+      ok[u] = iu < T;
+      a[u] = 0;
+      if (ok[u]) {
+        while (s_incl[c] <= iu) c++;
+        a[u] = s_adj[c] + iu;
+      }
+    }
+    float4 m[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) if (ok[u]) m[u] = sp[a[u]];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (ok[u]) top5_insert(t, sqdist_f(qx, qy, qz, m[u].x, m[u].y, m[u].z), __float_as_int(m[u].w), a[u]);
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Merges the 32 per-lane lists of a half-wave: afterwards every lane holds the global top-5
+// (ascending by distance, ties by window index) in g.
+__device__ __forceinline__ void knn_merge(Top5& t, Top5& g, int hl, int half_shift) {
+  float gd[5]; int gi[5], gp[5];
+#pragma unroll
+  for (int r = 0; r < 5; r++) {
+    const unsigned long long key = ((unsigned long long)(unsigned int)__float_as_int(t.d0) << 32) | (unsigned int)t.i0;
+    const unsigned long long mk = half_min_u64(key);
+    const unsigned int win = (unsigned int)((__ballot(key == mk) >> half_shift) & 0xFFFFFFFFull);
+    const int wl = __ffs(win) - 1;
+    gp[r] = __shfl(t.p0, wl, kKnnGroup);
+    gd[r] = __int_as_float((int)(mk >> 32));
+    gi[r] = (int)(unsigned int)(mk & 0xFFFFFFFFull);
+    if (hl == wl) {   // pop
+      t.d0 = t.d1; t.d1 = t.d2; t.d2 = t.d3; t.d3 = t.d4; t.d4 = INFINITY;
+      t.i0 = t.i1; t.i1 = t.i2; t.i2 = t.i3; t.i3 = t.i4; t.i4 = 0x7fffffff;
+      t.p0 = t.p1; t.p1 = t.p2; t.p2 = t.p3; t.p3 = t.p4; t.p4 = -1;
+    }
+  }
+  g.d0 = gd[0]; g.d1 = gd[1]; g.d2 = gd[2]; g.d3 = gd[3]; g.d4 = gd[4];
+  g.i0 = gi[0]; g.i1 = gi[1]; g.i2 = gi[2]; g.i3 = gi[3]; g.i4 = gi[4];
+  g.p0 = gp[0]; g.p1 = gp[1]; g.p2 = gp[2]; g.p3 = gp[3]; g.p4 = gp[4];
+}
+__device__ __forceinline__ void top5_clear(Top5& t) {
+  t.d0 = t.d1 = t.d2 = t.d3 = t.d4 = INFINITY;
+  t.i0 = t.i1 = t.i2 = t.i3 = t.i4 = 0x7fffffff;
+  t.p0 = t.p1 = t.p2 = t.p3 = t.p4 = -1;
+}
+
 __global__ __launch_bounds__(256) void k_knn(DevView v, int s0, int outer_it) {
+  __shared__ int s_incl[256 / kKnnGroup][kKnnGroup];   // inclusive candidate prefix per cell
+  __shared__ int s_adj[256 / kKnnGroup][kKnnGroup];    // cell start - exclusive prefix
   const int s = s0 + blockIdx.y;
   StreamState& st = v.state[s];
   if (!st.initialized) return;
   const int E = st.n_edges;
-  const int e = blockIdx.x * (256 / kKnnGroup) + (threadIdx.x / kKnnGroup);
+  const int grp = threadIdx.x / kKnnGroup;
+  const int e = blockIdx.x * (256 / kKnnGroup) + grp;
   if (e >= E) return;
   const int hl = threadIdx.x & (kKnnGroup - 1);
   const int half_shift = (threadIdx.x & 32);     // 0 or 32: which half of the wave
+  const bool dbgb = (blockIdx.x == 20) && (s == 0) && (threadIdx.x == 0) && (outer_it == 0);
+  DBG_STAMP(v, dbgb, 1, 0);
   const float4 p = v.edges[(size_t)s * v.edge_cap + e];
   float qx, qy, qz;
   {
@@ -396,73 +724,54 @@ __global__ __launch_bounds__(256) void k_knn(DevView v, int s0, int outer_it) {
     if (hl == 0) { *ca = make_float4(0, 0, 0, 0); *cb = make_float4(0, 0, 0, 0); *cidx = make_int2(-1, -1); }
     return;
   }
+  DBG_STAMP(v, dbgb, 1, 1);
   const int cx = (int)floorf(qx), cy = (int)floorf(qy), cz = (int)floorf(qz);
   const unsigned int tmask = (unsigned int)v.table_size - 1u;
-  const unsigned long long* keys = v.cell_key + (size_t)s * v.table_size;
+  const CellSlot* cells = v.cells + (size_t)s * v.table_size;
   unsigned int start = 0, cnt = 0;
+  double lb = 0.0;     // lower bound of the float squared distance from q to any point of the cell
   if (hl < 27) {
     const int dx = hl % 3 - 1, dy = (hl / 3) % 3 - 1, dz = hl / 9 - 1;
     const unsigned long long key = pack_cell(cx + dx, cy + dy, cz + dz);
     unsigned int h = hash_cell(key, tmask);
     for (int probe = 0; probe < v.table_size; probe++) {
-      const unsigned long long k = keys[h];
-      if (k == key) {
-        start = v.cell_start[(size_t)s * v.table_size + h];
-        cnt = v.cell_cnt[(size_t)s * v.table_size + h];
-        break;
-      }
+      const uint4 raw = *reinterpret_cast<const uint4*>(cells + h);
+      const unsigned long long k = ((unsigned long long)raw.y << 32) | raw.x;
+      if (k == key) { start = raw.z; cnt = raw.w; break; }
       if (k == kEmptyKey) break;
       h = (h + 1) & tmask;
     }
+    // box distance (FP64) to the cell [c, c+1)^3, shrunk by 1e-5 so that float rounding of the
+    // candidate distances can never make a pruned point look closer than the bound
+    const double lx = (double)(cx + dx), ly = (double)(cy + dy), lz = (double)(cz + dz);
+    const double ex = (double)qx < lx ? lx - (double)qx : ((double)qx > lx + 1.0 ? (double)qx - (lx + 1.0) : 0.0);
+    const double ey = (double)qy < ly ? ly - (double)qy : ((double)qy > ly + 1.0 ? (double)qy - (ly + 1.0) : 0.0);
+    const double ez = (double)qz < lz ? lz - (double)qz : ((double)qz > lz + 1.0 ? (double)qz - (lz + 1.0) : 0.0);
+    lb = (ex * ex + ey * ey + ez * ez) * (1.0 - 1e-5);
   }
-  unsigned int occ = (unsigned int)((__ballot(cnt > 0) >> half_shift) & 0xFFFFFFFFull);
-  // per-lane sorted top-5: distance, window index, position in the cell-sorted array
-  float d0 = INFINITY, d1 = INFINITY, d2 = INFINITY, d3 = INFINITY, d4 = INFINITY;
-  int i0 = 0x7fffffff, i1 = 0x7fffffff, i2 = 0x7fffffff, i3 = 0x7fffffff, i4 = 0x7fffffff;
-  int p0 = -1, p1 = -1, p2 = -1, p3 = -1, p4 = -1;
+  DBG_STAMP(v, dbgb, 1, 2);
+  if (v.debug & 4) cnt = 0;
   const float4* sp = v.sorted_pts + (size_t)s * v.map_cap;
-  while (occ) {
-    const int cl = __ffs(occ) - 1;
-    occ &= occ - 1;
-    const unsigned int cst = __shfl(start, cl, kKnnGroup);
-    const unsigned int ccn = __shfl(cnt, cl, kKnnGroup);
-    for (unsigned int i = hl; i < ccn; i += kKnnGroup) {
-      const float4 m = sp[cst + i];
-      const float d = sqdist_f(qx, qy, qz, m.x, m.y, m.z);
-      const int wi = __float_as_int(m.w);
-      if (d < d4 || (d == d4 && wi < i4)) {
-        d4 = d; i4 = wi; p4 = (int)(cst + i);
-        if (d4 < d3 || (d4 == d3 && i4 < i3)) { float td = d3; d3 = d4; d4 = td; int ti = i3; i3 = i4; i4 = ti; ti = p3; p3 = p4; p4 = ti; }
-        if (d3 < d2 || (d3 == d2 && i3 < i2)) { float td = d2; d2 = d3; d3 = td; int ti = i2; i2 = i3; i3 = ti; ti = p2; p2 = p3; p3 = ti; }
-        if (d2 < d1 || (d2 == d1 && i2 < i1)) { float td = d1; d1 = d2; d2 = td; int ti = i1; i1 = i2; i2 = ti; ti = p1; p1 = p2; p2 = ti; }
-        if (d1 < d0 || (d1 == d0 && i1 < i0)) { float td = d0; d0 = d1; d1 = td; int ti = i0; i0 = i1; i1 = ti; ti = p0; p0 = p1; p1 = ti; }
-      }
-    }
+  Top5 t, g;
+  top5_clear(t);
+  // phase 1: the query's own cell (lane 13 = offset (0,0,0))
+  knn_stream_cells(t, sp, s_incl[grp], s_adj[grp], start, (hl == 13) ? cnt : 0u, hl, qx, qy, qz);
+  DBG_STAMP(v, dbgb, 1, 3);
+  knn_merge(t, g, hl, half_shift);
+  DBG_STAMP(v, dbgb, 1, 4);
+  // phase 2: neighbour cells that can still hold a point closer than the current 5th best (or
+  // than the 1.0 gate: points at >= 1.0 can never be part of an accepted match, :324)
+  const float bound_f = g.d4 < 1.0f ? g.d4 : 1.0f;
+  const bool keep = (hl < 27) && (hl != 13) && (cnt > 0) && !(lb > (double)bound_f);
+  if ((__ballot(keep) >> half_shift) & 0xFFFFFFFFull) {
+    top5_clear(t);
+    if (hl == 0) t = g;       // carry the phase-1 result in one lane's list
+    knn_stream_cells(t, sp, s_incl[grp], s_adj[grp], start, keep ? cnt : 0u, hl, qx, qy, qz);
+    knn_merge(t, g, hl, half_shift);
   }
-  // merge the 32 per-lane lists: 5 rounds of min-reduction over (distance bits, window index)
-  float nd4 = INFINITY;
-  int mypos = -1, mywin = -1;
-#pragma unroll
-  for (int r = 0; r < 5; r++) {
-    const unsigned long long key = ((unsigned long long)(unsigned int)__float_as_int(d0) << 32) | (unsigned int)i0;
-    unsigned long long mk = key;
-#pragma unroll
-    for (int off = 16; off >= 1; off >>= 1) {
-      const unsigned long long o = __shfl_xor(mk, off, kKnnGroup);
-      mk = o < mk ? o : mk;
-    }
-    const unsigned int win = (unsigned int)((__ballot(key == mk) >> half_shift) & 0xFFFFFFFFull);
-    const int wl = __ffs(win) - 1;
-    const int wpos = __shfl(p0, wl, kKnnGroup);
-    if (hl == r) { mypos = wpos; mywin = (int)(unsigned int)(mk & 0xFFFFFFFFull); }
-    if (r == 4) nd4 = __int_as_float((int)(mk >> 32));
-    if (hl == wl) {   // pop
-      d0 = d1; d1 = d2; d2 = d3; d3 = d4; d4 = INFINITY;
-      i0 = i1; i1 = i2; i2 = i3; i3 = i4; i4 = 0x7fffffff;
-      p0 = p1; p1 = p2; p2 = p3; p3 = p4; p4 = -1;
-    }
-  }
-  bool valid = (nd4 < 1.0f);                                     // :324 (inf when < 5 candidates)
+  DBG_STAMP(v, dbgb, 1, 5);
+  bool valid = (g.d4 < 1.0f);                                    // :324 (inf when < 5 candidates)
+  const int mypos = hl == 0 ? g.p0 : hl == 1 ? g.p1 : hl == 2 ? g.p2 : hl == 3 ? g.p3 : g.p4;
   float4 mine = make_float4(0, 0, 0, 0);
   if (valid && hl < 5) mine = sp[mypos];
   float nx[5], ny[5], nz[5];
@@ -472,13 +781,14 @@ __global__ __launch_bounds__(256) void k_knn(DevView v, int s0, int outer_it) {
     ny[j] = __shfl(mine.y, j, kKnnGroup);
     nz[j] = __shfl(mine.z, j, kKnnGroup);
   }
-  const int wa = __shfl(mywin, 0, kKnnGroup), wb = __shfl(mywin, 1, kKnnGroup);
-  if (valid) valid = line_gate(nx, ny, nz);                      // :325-344
+  DBG_STAMP(v, dbgb, 1, 6);
+  if (valid && !(v.debug & 2)) valid = line_gate(nx, ny, nz);    // :325-344 (debug bit 1: ablation)
+  DBG_STAMP(v, dbgb, 1, 7);
   if (hl == 0) {
     if (valid) {
       *ca = make_float4(nx[0], ny[0], nz[0], 1.0f);              // :351-353
       *cb = make_float4(nx[1], ny[1], nz[1], 0.0f);              // :355-357
-      *cidx = make_int2(wa, wb);
+      *cidx = make_int2(g.i0, g.i1);
       atomicAdd(&st.info.matches[outer_it], 1);                  // :346
     } else {
       *ca = make_float4(0, 0, 0, 0); *cb = make_float4(0, 0, 0, 0); *cidx = make_int2(-1, -1);
@@ -496,7 +806,7 @@ __global__ __launch_bounds__(256) void k_knn(DevView v, int s0, int outer_it) {
 //   prediction for the next scan, window bookkeeping, hash-generation counters.
 // =============================================================================================
 __device__ __forceinline__ void lm_eval(const DevView& v, int s, int E, const double* Rm_sh,
-                                        double* part /*[8][kAccN]*/, double* acc_out /*[kAccN]*/) {
+                                        double* part /*[kLmThreads/16][kAccN]*/, double* acc_out /*[kAccN]*/) {
   double Rm[12];
 #pragma unroll
   for (int i = 0; i < 12; i++) Rm[i] = Rm_sh[i];
@@ -517,106 +827,140 @@ __device__ __forceinline__ void lm_eval(const DevView& v, int s, int E, const do
       residual_accumulate(Rm, p, a, b, v.min_range, v.max_range, acc);
     }
   }
+  // reduction: DPP butterfly inside each 16-lane row, one partial per row into LDS, then a
+  // fixed-order sum of the (waves x 4) partials -> deterministic, no atomics
 #pragma unroll
-  for (int i = 0; i < kAccN; i++) {
-    double x = acc[i];
+  for (int i = 0; i < kAccN; i++) acc[i] = row_sum_f64(acc[i]);
+  const int row = threadIdx.x >> 4;
+  if ((threadIdx.x & 15) == 0) {
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off);
-    acc[i] = x;
-  }
-  const int wave = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-    for (int i = 0; i < kAccN; i++) part[wave * kAccN + i] = acc[i];
+    for (int i = 0; i < kAccN; i++) part[row * kAccN + i] = acc[i];
   }
   __syncthreads();
   if (threadIdx.x < kAccN) {
     double x = 0.0;
-    for (int w = 0; w < kLmThreads / 64; w++) x += part[w * kAccN + threadIdx.x];
+    for (int w = 0; w < kLmThreads / 16; w++) x += part[w * kAccN + threadIdx.x];
     acc_out[threadIdx.x] = x;
   }
   __syncthreads();
 }
 
-__device__ void finalize_scan(const DevView& v, int s, StreamState& st) {
-  // pose as published (laser_odometry.cc:403-412 with identity laser_to_base)
-  double q[4];
-  quat_from_rot(st.odom, q);
-  const int k = st.scan_counter;
-  st.info.scan_index = k;
-  st.info.status = st.status;
-  if (k < v.pose_log_cap) {
-    double* pl = v.pose_log + ((size_t)s * v.pose_log_cap + k) * 7;
-    pl[0] = q[0]; pl[1] = q[1]; pl[2] = q[2]; pl[3] = q[3];
-    pl[4] = st.odom[3]; pl[5] = st.odom[7]; pl[6] = st.odom[11];
-    v.info_log[(size_t)s * v.pose_log_cap + k] = st.info;
-  }
-  st.scan_counter = k + 1;
-  for (int i = 0; i < 12; i++) st.final_odom[i] = st.odom[i];
-  // prediction for the next scan: odom * (prev^-1 * odom)   (:148-150)
-  double inv[12], rel[12], pred[12];
-  iso_inverse(st.prev_odom, inv);
-  iso_mul(inv, st.odom, rel);
-  iso_mul(st.odom, rel, pred);
-  for (int i = 0; i < 12; i++) { st.prev_odom[i] = st.odom[i]; st.odom[i] = pred[i]; }
-  quat_from_rot(st.odom, st.param_q);                              // :186-190
-  st.param_t[0] = st.odom[3]; st.param_t[1] = st.odom[7]; st.param_t[2] = st.odom[11];   // :192-195
-  // LocalMapManager::addPointCloud (:34-60) on a ring of P frame slots
+// Called by the whole workgroup.  sh_cnt: LDS scratch of kMaxFrames + 1 ints.
+// Thread 64 publishes the result (pose log, host-mapped record) while thread 0 computes the
+// prediction and the window bookkeeping; the remaining threads fetch the frame sizes.
+__device__ void finalize_scan(const DevView& v, int s, StreamState& st, int* sh_cnt) {
   const int P = v.prev_frames;
-  const int slot = st.frame_count % P;
+  const int tid = threadIdx.x;
+  // LocalMapManager::addPointCloud (:34-60) on a ring of P frame slots: the new frame goes
+  // into slot frame_count % P (overwriting the oldest once the window is full)
+  const int fc_new = st.frame_count + 1;
+  const int nf = fc_new < P ? fc_new : P;
+  const int new_slot = st.frame_count % P;
   int* wn = v.win_n + (size_t)s * P;
-  wn[slot] = st.n_edges;
-  st.frame_count++;
-  st.n_frames = st.frame_count < P ? st.frame_count : P;
   int* wb = v.win_base + (size_t)s * (P + 1);
   int* ws = v.win_slot + (size_t)s * P;
-  int acc = 0;
-  for (int j = 0; j < st.n_frames; j++) {
-    const int sl = (st.frame_count - st.n_frames + j) % P;
-    ws[j] = sl; wb[j] = acc; acc += wn[sl];
+  const int n_edges = st.n_edges;
+  if (tid == 0) { for (int i = 0; i < 12; i++) st.final_odom[i] = st.odom[i]; }
+  __syncthreads();
+  for (int j = tid; j < nf; j += blockDim.x) {
+    const int sl = (fc_new - nf + j) % P;
+    sh_cnt[j] = (sl == new_slot) ? n_edges : wn[sl];     // independent loads, one round trip
+    ws[j] = sl;
   }
-  wb[st.n_frames] = acc;
-  st.n_map = acc;
-  st.n_used_prev = st.n_used;
-  st.n_used = 0;
-  st.cursor = 0;
+  __syncthreads();
+  if (tid == 64) {
+    // pose as published (laser_odometry.cc:403-412 with identity laser_to_base)
+    double q[4];
+    quat_from_rot(st.final_odom, q);
+    const int k = st.scan_counter;
+    st.info.scan_index = k;
+    st.info.status = st.status;
+    if (k < v.pose_log_cap) {
+      double* pl = v.pose_log + ((size_t)s * v.pose_log_cap + k) * 7;
+      pl[0] = q[0]; pl[1] = q[1]; pl[2] = q[2]; pl[3] = q[3];
+      pl[4] = st.final_odom[3]; pl[5] = st.final_odom[7]; pl[6] = st.final_odom[11];
+      v.info_log[(size_t)s * v.pose_log_cap + k] = st.info;
+    }
+    st.scan_counter = k + 1;
+    if (v.host_out) {
+      HostOut* ho = v.host_out + s;
+      ho->pose[0] = q[0]; ho->pose[1] = q[1]; ho->pose[2] = q[2]; ho->pose[3] = q[3];
+      ho->pose[4] = st.final_odom[3]; ho->pose[5] = st.final_odom[7]; ho->pose[6] = st.final_odom[11];
+      ho->info = st.info;
+      __threadfence_system();
+      __hip_atomic_store(&ho->seq, k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  if (tid == 0) {
+    // prediction for the next scan: odom * (prev^-1 * odom)   (:148-150)
+    double inv[12], rel[12], pred[12];
+    iso_inverse(st.prev_odom, inv);
+    iso_mul(inv, st.final_odom, rel);
+    iso_mul(st.final_odom, rel, pred);
+    for (int i = 0; i < 12; i++) { st.prev_odom[i] = st.final_odom[i]; st.odom[i] = pred[i]; }
+    quat_from_rot(pred, st.param_q);                                 // :186-190
+    st.param_t[0] = pred[3]; st.param_t[1] = pred[7]; st.param_t[2] = pred[11];   // :192-195
+    wn[new_slot] = n_edges;
+    st.frame_count = fc_new;
+    st.n_frames = nf;
+    int acc = 0;
+    for (int j = 0; j < nf; j++) { const int c = sh_cnt[j]; sh_cnt[j] = acc; acc += c; }
+    sh_cnt[nf] = acc;
+    st.n_map = acc;
+    st.n_used_prev = st.n_used;
+    st.n_used = 0;
+    st.cursor = 0;
+  }
+  __syncthreads();
+  for (int j = tid; j <= nf; j += blockDim.x) wb[j] = sh_cnt[j];
 }
 
 __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int outer_it) {
   __shared__ double sh_pose[12];
-  __shared__ double sh_part[(kLmThreads / 64) * kAccN];
+  __shared__ double sh_part[(kLmThreads / 16) * kAccN];
   __shared__ double sh_acc[kAccN];
   __shared__ LmState lm;
   __shared__ int sh_flag;
   const int s = s0 + blockIdx.x;
   StreamState& st = v.state[s];
+  __shared__ int sh_cnt[kMaxFrames + 1];
   if (!st.initialized) {
     // first frame (:108-136): no solve; pose stays identity, edges enter the window raw
-    if (outer_it == 1 && threadIdx.x == 0) {
-      st.append_raw = 1;
-      finalize_scan(v, s, st);
-      st.initialized = 1;
+    if (outer_it == 1) {
+      if (threadIdx.x == 0) st.append_raw = 1;
+      finalize_scan(v, s, st, sh_cnt);
+      if (threadIdx.x == 0) st.initialized = 1;
     }
     return;
   }
+  const bool dbgb = (s == 0) && (threadIdx.x == 0) && (outer_it == 1);
+  DBG_STAMP(v, dbgb, 2, 0);
   const int E = st.n_edges;
   const int nblocks = st.info.matches[outer_it];
   if (threadIdx.x == 0) iso_from_qt(st.param_q, st.param_t, sh_pose);
   __syncthreads();
+  DBG_STAMP(v, dbgb, 2, 1);
   lm_eval(v, s, E, sh_pose, sh_part, sh_acc);
+  DBG_STAMP(v, dbgb, 2, 2);
   if (threadIdx.x == 0) {
     sh_flag = lm_begin(lm, st.param_q, st.param_t, sh_acc, nblocks, v.apply_on_ftol);
     if (sh_flag == LM_NEED_EVAL) iso_from_qt(lm.cand_q, lm.cand_t, sh_pose);
   }
   __syncthreads();
-  while (sh_flag == LM_NEED_EVAL) {
+  DBG_STAMP(v, dbgb, 2, 3);
+  int dbg_it = 0;
+  while (sh_flag == LM_NEED_EVAL && !(v.debug & 8)) {
     lm_eval(v, s, E, sh_pose, sh_part, sh_acc);
+    DBG_STAMP(v, dbgb && dbg_it < 5, 2, 4 + 2 * dbg_it);
     if (threadIdx.x == 0) {
       sh_flag = lm_update(lm, sh_acc);
       if (sh_flag == LM_NEED_EVAL) iso_from_qt(lm.cand_q, lm.cand_t, sh_pose);
     }
     __syncthreads();
+    DBG_STAMP(v, dbgb && dbg_it < 5, 2, 5 + 2 * dbg_it);
+    dbg_it++;
   }
+  DBG_STAMP(v, dbgb, 2, 20);
   if (threadIdx.x == 0) {
     for (int k = 0; k < 4; k++) st.param_q[k] = lm.q[k];
     for (int k = 0; k < 3; k++) st.param_t[k] = lm.t[k];
@@ -624,16 +968,26 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
     liodom_lm_trace_t& tr = st.info.lm[outer_it];
     tr.iterations = lm.iter; tr.accepted = lm.accepted; tr.termination = lm.termination; tr.pad = 0;
     tr.initial_cost = lm.initial_cost; tr.final_cost = lm.cost;
-    if (outer_it == 1) {
-      st.append_raw = 0;
-      finalize_scan(v, s, st);
-    }
+    if (outer_it == 1) st.append_raw = 0;
   }
+  DBG_STAMP(v, dbgb, 2, 21);
+  if (outer_it == 1) finalize_scan(v, s, st, sh_cnt);
+  DBG_STAMP(v, dbgb, 2, 22);
 }
 
 // =============================================================================================
 // Sliding window + voxel hash rebuild.
 // =============================================================================================
+// (re)initialise every slot of the voxel hash (handle creation / reset)
+__global__ __launch_bounds__(256) void k_init_cells(DevView v) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t total = (size_t)v.n_streams * v.table_size;
+  if (i >= total) return;
+  CellSlot empty; empty.key = kEmptyKey; empty.start = 0; empty.cnt = 0;
+  v.cells[i] = empty;
+  v.cell_fill[i] = 0;
+}
+
 __global__ __launch_bounds__(256) void k_hash_clear(DevView v, int s0) {
   const int s = s0 + blockIdx.y;
   const StreamState& st = v.state[s];
@@ -641,8 +995,8 @@ __global__ __launch_bounds__(256) void k_hash_clear(DevView v, int s0) {
   if (u >= st.n_used_prev) return;
   const int h = v.used_cells[(size_t)s * v.map_cap + u];
   const size_t ti = (size_t)s * v.table_size + h;
-  v.cell_key[ti] = kEmptyKey;
-  v.cell_cnt[ti] = 0;
+  CellSlot empty; empty.key = kEmptyKey; empty.start = 0; empty.cnt = 0;
+  v.cells[ti] = empty;
   v.cell_fill[ti] = 0;
 }
 
@@ -689,11 +1043,11 @@ __global__ __launch_bounds__(256) void k_window_insert(DevView v, int s0) {
   if (!fin) { *pc = -1; return; }
   const unsigned long long key = pack_cell((int)floorf(pt.x), (int)floorf(pt.y), (int)floorf(pt.z));
   const unsigned int tmask = (unsigned int)v.table_size - 1u;
-  unsigned long long* keys = v.cell_key + (size_t)s * v.table_size;
+  CellSlot* cells = v.cells + (size_t)s * v.table_size;
   unsigned int h = hash_cell(key, tmask);
   int found = -1;
   for (int probe = 0; probe < v.table_size; probe++) {
-    const unsigned long long prev = atomicCAS(&keys[h], kEmptyKey, key);
+    const unsigned long long prev = atomicCAS(&cells[h].key, kEmptyKey, key);
     if (prev == kEmptyKey) {
       const int u = atomicAdd(&st.n_used, 1);
       v.used_cells[(size_t)s * v.map_cap + u] = (int)h;
@@ -704,7 +1058,7 @@ __global__ __launch_bounds__(256) void k_window_insert(DevView v, int s0) {
     h = (h + 1) & tmask;
   }
   if (found < 0) { atomicOr(&st.status, LIODOM_STATUS_HASH_FULL); *pc = -1; return; }
-  atomicAdd(&v.cell_cnt[(size_t)s * v.table_size + found], 1u);
+  atomicAdd(&cells[found].cnt, 1u);
   *pc = found;
 }
 
@@ -714,8 +1068,8 @@ __global__ __launch_bounds__(256) void k_hash_alloc(DevView v, int s0) {
   const int u = blockIdx.x * 256 + threadIdx.x;
   if (u >= st.n_used) return;
   const int h = v.used_cells[(size_t)s * v.map_cap + u];
-  const size_t ti = (size_t)s * v.table_size + h;
-  v.cell_start[ti] = (unsigned int)atomicAdd(&st.cursor, (int)v.cell_cnt[ti]);
+  CellSlot* slot = v.cells + (size_t)s * v.table_size + h;
+  slot->start = (unsigned int)atomicAdd(&st.cursor, (int)slot->cnt);
 }
 
 __global__ __launch_bounds__(256) void k_hash_scatter(DevView v, int s0) {
@@ -737,7 +1091,7 @@ __global__ __launch_bounds__(256) void k_hash_scatter(DevView v, int s0) {
   while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (sbase[mid] <= m) lo = mid; else hi = mid; }
   const float4 pt = v.win_pts[((size_t)s * P + sslot[lo]) * v.edge_cap + (m - sbase[lo])];
   const size_t ti = (size_t)s * v.table_size + h;
-  const unsigned int pos = v.cell_start[ti] + atomicAdd(&v.cell_fill[ti], 1u);
+  const unsigned int pos = v.cells[ti].start + atomicAdd(&v.cell_fill[ti], 1u);
   v.sorted_pts[(size_t)s * v.map_cap + pos] = make_float4(pt.x, pt.y, pt.z, __int_as_float(m));
 }
 

@@ -13,8 +13,16 @@
 
 #if defined(__HIPCC__)
 #define LD_HD __host__ __device__ __forceinline__
+#define LD_UNROLL _Pragma("unroll")
+// The LM evaluation is not on the bit-exact path (pose tolerance 1e-4; the oracle differentiates
+// a different expression tree anyway), so FMA contraction is allowed there: it halves the FP64
+// instruction count of the dominant loop.  Everything else in this header is compiled with
+// -ffp-contract=off.
+#define LD_FP_CONTRACT_FAST _Pragma("clang fp contract(fast)")
 #else
 #define LD_HD inline
+#define LD_UNROLL
+#define LD_FP_CONTRACT_FAST
 #endif
 
 namespace liodom_dev {
@@ -230,8 +238,14 @@ LD_HD bool line_gate(const float* nx, const float* ny, const float* nz) {
 // ---------------------------------------------------------------------------------------
 constexpr int kAccN = 29;
 
+LD_HD int h_idx(int i, int j) {  // upper-triangle index, i <= j
+  return i * 6 - (i * (i - 1)) / 2 + (j - i);
+}
+LD_HD double h_at(const double* H, int i, int j) { return i <= j ? H[h_idx(i, j)] : H[h_idx(j, i)]; }
+
 LD_HD void residual_accumulate(const double* Rm /*3x4*/, const double* p, const double* a,
                                const double* b, double min_d, double max_d, double* acc) {
+  LD_FP_CONTRACT_FAST
   const double tx = Rm[3], ty = Rm[7], tz = Rm[11];
   const double Rp0 = Rm[0] * p[0] + Rm[1] * p[1] + Rm[2] * p[2];
   const double Rp1 = Rm[4] * p[0] + Rm[5] * p[1] + Rm[6] * p[2];
@@ -246,8 +260,10 @@ LD_HD void residual_accumulate(const double* Rm /*3x4*/, const double* p, const 
   const double rho = sqrt(cx * cx + cy * cy);
   const double range = max_d - min_d;
   const double w = 1.01 - (rho - min_d) / range;
-  const double wl = w / L;
-  const double r0 = wl * nu0, r1 = wl * nu1, r2 = wl * nu2;
+  const double invL = 1.0 / L;
+  const double wl = w * invL;
+  const double n0 = nu0 * invL, n1 = nu1 * invL, n2 = nu2 * invL;
+  const double r0 = w * n0, r1 = w * n1, r2 = w * n2;              // factors.hpp:99-101
   const double s = r0 * r0 + r1 * r1 + r2 * r2;
   // Jq = (2w/L) [de]x [Rp]x ; [de]x[Rp]x = Rp de^T - (de.Rp) I
   const double dot = de0 * Rp0 + de1 * Rp1 + de2 * Rp2;
@@ -257,8 +273,8 @@ LD_HD void residual_accumulate(const double* Rm /*3x4*/, const double* p, const 
   J[6]  = k2 * (Rp1 * de0);       J[7]  = k2 * (Rp1 * de1 - dot); J[8]  = k2 * (Rp1 * de2);
   J[12] = k2 * (Rp2 * de0);       J[13] = k2 * (Rp2 * de1);       J[14] = k2 * (Rp2 * de2 - dot);
   // Jt = -(w/L)[de]x + (nu/L) (dw/dt)^T,  dw/dt = (cx, cy, 0) / (rho * range)
-  const double dwx = cx / (rho * range), dwy = cy / (rho * range);
-  const double n0 = nu0 / L, n1 = nu1 / L, n2 = nu2 / L;
+  const double inv_rr = 1.0 / (rho * range);
+  const double dwx = cx * inv_rr, dwy = cy * inv_rr;
   J[3]  = n0 * dwx;              J[4]  = wl * de2 + n0 * dwy;   J[5]  = -wl * de1;
   J[9]  = -wl * de2 + n1 * dwx;  J[10] = n1 * dwy;              J[11] = wl * de0;
   J[15] = wl * de1 + n2 * dwx;   J[16] = -wl * de0 + n2 * dwy;  J[17] = 0.0;
@@ -274,21 +290,24 @@ LD_HD void residual_accumulate(const double* Rm /*3x4*/, const double* p, const 
     rho0 = s; rho1 = 1.0;
   }
   bool finite = ld_isfinite(s);
+  LD_UNROLL
   for (int i = 0; i < 18; i++) finite = finite && ld_isfinite(J[i]);
   if (!finite) { acc[28] += 1.0; return; }
   acc[0] += 0.5 * rho0;
   const double rs0 = rho1 * r0, rs1 = rho1 * r1, rs2 = rho1 * r2;
-  int k = 7;
+  LD_UNROLL
   for (int i = 0; i < 6; i++) {
     acc[1 + i] += J[i] * rs0 + J[6 + i] * rs1 + J[12 + i] * rs2;
     const double a0 = rho1 * J[i], a1 = rho1 * J[6 + i], a2 = rho1 * J[12 + i];
-    for (int j = i; j < 6; j++) acc[k++] += a0 * J[j] + a1 * J[6 + j] + a2 * J[12 + j];
+    LD_UNROLL
+    for (int j = i; j < 6; j++) acc[7 + h_idx(i, j)] += a0 * J[j] + a1 * J[6 + j] + a2 * J[12 + j];
   }
 }
 
 // Cost-only variant (candidate evaluation).  Returns false if non-finite.
 LD_HD bool residual_cost(const double* Rm, const double* p, const double* a, const double* b,
                          double min_d, double max_d, double* cost) {
+  LD_FP_CONTRACT_FAST
   const double tx = Rm[3], ty = Rm[7], tz = Rm[11];
   const double lp0 = Rm[0] * p[0] + Rm[1] * p[1] + Rm[2] * p[2] + tx;
   const double lp1 = Rm[4] * p[0] + Rm[5] * p[1] + Rm[6] * p[2] + ty;
@@ -301,8 +320,8 @@ LD_HD bool residual_cost(const double* Rm, const double* p, const double* a, con
   const double cx = p[0] - tx, cy = p[1] - ty;
   const double rho = sqrt(cx * cx + cy * cy);
   const double w = 1.01 - (rho - min_d) / (max_d - min_d);
-  const double wl = w / L;
-  const double r0 = wl * nu0, r1 = wl * nu1, r2 = wl * nu2;
+  const double invL = 1.0 / L;
+  const double r0 = w * (nu0 * invL), r1 = w * (nu1 * invL), r2 = w * (nu2 * invL);
   const double s = r0 * r0 + r1 * r1 + r2 * r2;
   if (!ld_isfinite(s)) return false;
   const double bsq = kHuberA * kHuberA;
@@ -343,37 +362,44 @@ struct LmState {
   int apply_on_ftol;
 };
 
-LD_HD int h_idx(int i, int j) {  // upper-triangle index, i <= j
-  return i * 6 - (i * (i - 1)) / 2 + (j - i);
-}
-LD_HD double h_at(const double* H, int i, int j) { return i <= j ? H[h_idx(i, j)] : H[h_idx(j, i)]; }
 
 // Cholesky solve of the 6x6 SPD system A y = b.  Returns false if not positive definite.
 LD_HD bool chol_solve6(const double* A /*6x6 row-major, symmetric*/, const double* b, double* y) {
   double Lm[36];
+  double inv[6];             // reciprocals of the diagonal: one division per column
+  LD_UNROLL
   for (int i = 0; i < 36; i++) Lm[i] = 0.0;
+  LD_UNROLL
   for (int j = 0; j < 6; j++) {
     double d = A[j * 6 + j];
+    LD_UNROLL
     for (int k = 0; k < j; k++) d -= Lm[j * 6 + k] * Lm[j * 6 + k];
     if (!(d > 0.0) || !ld_isfinite(d)) return false;
     const double l = sqrt(d);
     Lm[j * 6 + j] = l;
+    inv[j] = 1.0 / l;
+    LD_UNROLL
     for (int i = j + 1; i < 6; i++) {
       double s = A[i * 6 + j];
+      LD_UNROLL
       for (int k = 0; k < j; k++) s -= Lm[i * 6 + k] * Lm[j * 6 + k];
-      Lm[i * 6 + j] = s / l;
+      Lm[i * 6 + j] = s * inv[j];
     }
   }
   double z[6];
+  LD_UNROLL
   for (int i = 0; i < 6; i++) {
     double s = b[i];
+    LD_UNROLL
     for (int k = 0; k < i; k++) s -= Lm[i * 6 + k] * z[k];
-    z[i] = s / Lm[i * 6 + i];
+    z[i] = s * inv[i];
   }
+  LD_UNROLL
   for (int i = 5; i >= 0; i--) {
     double s = z[i];
+    LD_UNROLL
     for (int k = i + 1; k < 6; k++) s -= Lm[k * 6 + i] * y[k];
-    y[i] = s / Lm[i * 6 + i];
+    y[i] = s * inv[i];
     if (!ld_isfinite(y[i])) return false;
   }
   return true;
@@ -391,11 +417,14 @@ LD_HD int lm_propose(LmState& st) {
     if (st.radius < 1e-32) { st.termination = LM_TERM_RADIUS; return LM_DONE; }
     st.iter++;
     double Hs[36], gs[6];
+    LD_UNROLL
     for (int i = 0; i < 6; i++) {
       gs[i] = st.scale[i] * st.g[i];
+      LD_UNROLL
       for (int j = 0; j < 6; j++) Hs[i * 6 + j] = st.scale[i] * st.scale[j] * h_at(st.H, i, j);
     }
     if (!st.reuse_diagonal) {
+      LD_UNROLL
       for (int j = 0; j < 6; j++) {
         double d = Hs[j * 6 + j];
         if (d < 1e-6) d = 1e-6;
@@ -404,7 +433,9 @@ LD_HD int lm_propose(LmState& st) {
       }
     }
     double A[36];
+    LD_UNROLL
     for (int i = 0; i < 36; i++) A[i] = Hs[i];
+    LD_UNROLL
     for (int j = 0; j < 6; j++) A[j * 6 + j] += st.diag[j] / st.radius;
     double y[6];
     const bool ok = chol_solve6(A, gs, y);
@@ -413,10 +444,13 @@ LD_HD int lm_propose(LmState& st) {
     double step[6];
     if (ok) {
       double sg = 0.0, shs = 0.0;
+      LD_UNROLL
       for (int i = 0; i < 6; i++) step[i] = -y[i];
+      LD_UNROLL
       for (int i = 0; i < 6; i++) {
         sg += step[i] * gs[i];
         double row = 0.0;
+        LD_UNROLL
         for (int j = 0; j < 6; j++) row += Hs[i * 6 + j] * step[j];
         shs += step[i] * row;
       }
@@ -431,8 +465,10 @@ LD_HD int lm_propose(LmState& st) {
     st.invalid_run = 0;
     st.model_cost_change = mcc;
     double delta[6];
+    LD_UNROLL
     for (int j = 0; j < 6; j++) delta[j] = step[j] * st.scale[j];
     quat_plus(st.q, delta, st.cand_q);
+    LD_UNROLL
     for (int k = 0; k < 3; k++) st.cand_t[k] = st.t[k] + delta[3 + k];
     return LM_NEED_EVAL;
   }
@@ -441,21 +477,28 @@ LD_HD int lm_propose(LmState& st) {
 // acc = accumulator evaluated at (q0, t0); n_blocks = number of residual blocks.
 LD_HD int lm_begin(LmState& st, const double* q0, const double* t0, const double* acc,
                    int n_blocks, int apply_on_ftol) {
+  LD_UNROLL
   for (int k = 0; k < 4; k++) st.q[k] = st.cand_q[k] = q0[k];
+  LD_UNROLL
   for (int k = 0; k < 3; k++) st.t[k] = st.cand_t[k] = t0[k];
   st.iter = 0; st.accepted = 0; st.invalid_run = 0; st.termination = LM_TERM_MAX_ITER;
   st.apply_on_ftol = apply_on_ftol;
   st.cost = 0.0; st.initial_cost = 0.0; st.model_cost_change = 0.0;
   st.radius = 1e4; st.decrease_factor = 2.0; st.reuse_diagonal = 0;
+  LD_UNROLL
   for (int j = 0; j < 6; j++) { st.scale[j] = 1.0; st.diag[j] = 0.0; st.g[j] = 0.0; }
+  LD_UNROLL
   for (int j = 0; j < 21; j++) st.H[j] = 0.0;
   st.x_norm = norm7(st.q, st.t);
   if (n_blocks == 0) { st.termination = LM_TERM_NO_RESIDUALS; return LM_DONE; }
   if (acc[28] != 0.0) { st.termination = LM_TERM_EVAL_FAILURE; return LM_DONE; }
   st.cost = acc[0]; st.initial_cost = acc[0];
   double gmax = 0.0;
+  LD_UNROLL
   for (int j = 0; j < 6; j++) { st.g[j] = acc[1 + j]; const double ag = fabs(st.g[j]); if (ag > gmax) gmax = ag; }
+  LD_UNROLL
   for (int j = 0; j < 21; j++) st.H[j] = acc[7 + j];
+  LD_UNROLL
   for (int j = 0; j < 6; j++) st.scale[j] = 1.0 / (1.0 + sqrt(st.H[h_idx(j, j)]));
   if (gmax <= 1e-10) { st.termination = LM_TERM_GRAD_TOL; return LM_DONE; }
   return lm_propose(st);
@@ -465,7 +508,9 @@ LD_HD int lm_begin(LmState& st, const double* q0, const double* t0, const double
 LD_HD int lm_update(LmState& st, const double* acc) {
   const double cand_cost = (acc[28] != 0.0) ? DBL_MAX : acc[0];
   double dq[4], dt[3];
+  LD_UNROLL
   for (int k = 0; k < 4; k++) dq[k] = st.q[k] - st.cand_q[k];
+  LD_UNROLL
   for (int k = 0; k < 3; k++) dt[k] = st.t[k] - st.cand_t[k];
   const double step_norm = norm7(dq, dt);
   if (step_norm <= 1e-8 * (st.x_norm + 1e-8)) { st.termination = LM_TERM_PARAM_TOL; return LM_DONE; }
@@ -473,7 +518,9 @@ LD_HD int lm_update(LmState& st, const double* acc) {
   if (fabs(cost_change) <= 1e-6 * st.cost) {
     st.termination = LM_TERM_FUNC_TOL;
     if (st.apply_on_ftol && cost_change > 0.0) {
+      LD_UNROLL
       for (int k = 0; k < 4; k++) st.q[k] = st.cand_q[k];
+      LD_UNROLL
       for (int k = 0; k < 3; k++) st.t[k] = st.cand_t[k];
       st.cost = cand_cost;
     }
@@ -481,12 +528,16 @@ LD_HD int lm_update(LmState& st, const double* acc) {
   }
   const double rel = cost_change / st.model_cost_change;
   if (rel > 1e-3) {
+    LD_UNROLL
     for (int k = 0; k < 4; k++) st.q[k] = st.cand_q[k];
+    LD_UNROLL
     for (int k = 0; k < 3; k++) st.t[k] = st.cand_t[k];
     st.x_norm = norm7(st.q, st.t);
     st.cost = cand_cost;
     double gmax = 0.0;
+    LD_UNROLL
     for (int j = 0; j < 6; j++) { st.g[j] = acc[1 + j]; const double ag = fabs(st.g[j]); if (ag > gmax) gmax = ag; }
+    LD_UNROLL
     for (int j = 0; j < 21; j++) st.H[j] = acc[7 + j];
     st.accepted++;
     const double c = 2.0 * rel - 1.0;

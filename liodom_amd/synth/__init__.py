@@ -16,6 +16,7 @@ class SynthCfg(C.Structure):
     _fields_ = [
         ("height", C.c_int32), ("width", C.c_int32), ("lidar_type", C.c_int32), ("world_seed", C.c_uint32),
         ("noise_sigma", C.c_double), ("max_cast_range", C.c_double),
+        ("yaw_rate_deg", C.c_double), ("speed", C.c_double),
     ]
 
 
@@ -38,15 +39,17 @@ def lib():
         L.synth_scan.restype = C.c_int
         L.synth_scan.argtypes = [C.POINTER(SynthCfg), C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double)]
         L.synth_num_boxes.restype = C.c_int
-        L.synth_num_boxes.argtypes = [C.c_uint32]
+        L.synth_num_boxes.argtypes = []
         _lib = L
     return _lib
 
 
-def make_cfg(height, width, lidar_type=0, world_seed=7, noise_sigma=0.01, max_cast_range=120.0):
+def make_cfg(height, width, lidar_type=0, world_seed=7, noise_sigma=0.01, max_cast_range=120.0,
+             yaw_rate_deg=0.3, speed=0.1):
     c = SynthCfg()
     c.height, c.width, c.lidar_type, c.world_seed = height, width, lidar_type, world_seed
     c.noise_sigma, c.max_cast_range = noise_sigma, max_cast_range
+    c.yaw_rate_deg, c.speed = yaw_rate_deg, speed
     return c
 
 

@@ -2,7 +2,7 @@
 //
 // Implements the synthetic input of SURVEY.md §8(d): a static analytic world (ground plane at
 // z = -1.7 m plus axis-aligned boxes / thin pillars on a jittered grid), a smooth sensor
-// trajectory (0.1 m/scan forward, 0.5 deg/scan yaw, small sinusoidal z / roll / pitch) and a
+// trajectory (0.1 m/scan forward, constant yaw rate, small sinusoidal z / roll / pitch) and a
 // per-scan ray cast of H x W rays with range-only Gaussian noise along the ray.  Rays without a
 // hit give NaN points (exercises the reference's isValidPoint, feature_extractor.cc:84-102).
 //
@@ -15,6 +15,11 @@
 // (feature_extractor.cc:130-148): HDL-64 upper block 1.95 - k/3 deg, lower block
 // -8.78 - k/2 deg; VLP-16 -15 + 2k deg; HDL-32 (-92/3 + 4k/3 + 0.6) deg; 128 rows are
 // row-indexed (lidar_type 1) and span +22.5 .. -22.5 deg.
+//
+// Yaw rate: SURVEY.md §8(d) proposed 0.5 deg/scan; the default here is 0.3 deg/scan so that a
+// 220-scan stream stays below 90 deg of accumulated rotation — beyond that the reference's own
+// pose recursion (un-normalised quaternion <-> matrix round trips, laser_odometry.cc:148-150,
+// 186,225-226) is numerically unstable and no two implementations agree.
 //
 // Determinism: every random number is a pure function of (seed, counter); the output does not
 // depend on the number of OpenMP threads.
@@ -39,17 +44,20 @@ inline double u01(uint64_t h) { return ((h >> 11) + 0.5) * (1.0 / 90071992547409
 struct World {
   std::vector<Box> boxes;
   uint32_t seed = 0;
+  double radius = -1.0;
   bool built = false;
 };
 
-// Boxes on a jittered 10 m grid over [-130, 130]^2; nothing inside a 17 m disc around the
-// centre of the circular trajectory so the sensor never enters an obstacle.
-void build_world(World& w, uint32_t seed) {
+// Boxes on a jittered 10 m grid over [-160, 160]^2; nothing within 5.5 m of the sensor's
+// trajectory (a circle of radius `radius` through the origin, or the x axis when radius <= 0) so
+// the sensor never enters an obstacle.
+void build_world(World& w, uint32_t seed, double radius) {
   w.boxes.clear();
   w.seed = seed;
+  w.radius = radius;
   const double cell = 10.0;
-  const int half = 13;
-  const double traj_cx = 0.0, traj_cy = 0.1 / (0.5 * M_PI / 180.0);  // circle centre
+  const int half = 16;
+  const double traj_cx = 0.0, traj_cy = radius;  // circle centre
   for (int gy = -half; gy < half; ++gy) {
     for (int gx = -half; gx < half; ++gx) {
       uint64_t h = splitmix64(((uint64_t)seed << 32) ^ (uint64_t)((gy + 64) * 256 + (gx + 64)));
@@ -64,7 +72,9 @@ void build_world(World& w, uint32_t seed) {
       double cx = (gx + 0.2 + 0.6 * jx) * cell;
       double cy = (gy + 0.2 + 0.6 * jy) * cell;
       double dx = cx - traj_cx, dy = cy - traj_cy;
-      if (std::sqrt(dx * dx + dy * dy) < 17.0) continue;
+      const double clear = 5.5 + 3.0;   // corridor half-width + largest half-diagonal of a box
+      if (radius > 0.0) { if (std::fabs(std::sqrt(dx * dx + dy * dy) - radius) < clear) continue; }
+      else if (std::fabs(cy) < clear) continue;
       double wx, wy, hz;
       if (kind < 0.35) {            // thin pillar / pole
         wx = 0.15 + 0.25 * s1; wy = 0.15 + 0.25 * s2; hz = 3.0 + 9.0 * s3;
@@ -103,11 +113,11 @@ void ring_elevations(int height, std::vector<double>& el) {
 struct Pose { double R[9]; double t[3]; };
 
 // Ground-truth trajectory: world <- sensor at scan k of a stream.
-void trajectory(int stream, int k, Pose& P, double q_out[4]) {
-  const double dyaw = 0.5 * M_PI / 180.0;
+void trajectory(int stream, int k, double yaw_rate_deg, double speed, Pose& P, double q_out[4]) {
+  const double dyaw = yaw_rate_deg * M_PI / 180.0;
   // position integrates 0.1 m per scan along the current heading
   double x = 0, y = 0;
-  for (int i = 0; i < k; ++i) { x += 0.1 * std::cos(dyaw * i); y += 0.1 * std::sin(dyaw * i); }
+  for (int i = 0; i < k; ++i) { x += speed * std::cos(dyaw * i); y += speed * std::sin(dyaw * i); }
   double ph = 0.37 * stream;
   double z = 0.05 * std::sin(0.1 * k + ph);
   double yaw = dyaw * k;
@@ -159,18 +169,21 @@ struct synth_cfg_t {
   uint32_t world_seed;   // static world layout
   double noise_sigma;    // range noise (m), along the ray
   double max_cast_range; // rays longer than this return NaN
+  double yaw_rate_deg;   // yaw per scan (deg); default 0.3 (see header)
+  double speed;          // forward motion per scan (m); SURVEY.md §8(d): 0.1
 };
 
 // Fills xyzi (height*width*4 floats) for scan `scan` of stream `stream`, and the ground-truth
 // pose gt_pose = [qx qy qz qw tx ty tz] (world <- sensor).  Returns 0.
 int synth_scan(const synth_cfg_t* cfg, int stream, int scan, float* xyzi, double* gt_pose) {
   if (!cfg || !xyzi || cfg->height <= 0 || cfg->width <= 0) return -1;
-  if (!g_world.built || g_world.seed != cfg->world_seed) build_world(g_world, cfg->world_seed);
+  const double radius = cfg->yaw_rate_deg != 0.0 ? cfg->speed / (cfg->yaw_rate_deg * M_PI / 180.0) : -1.0;
+  if (!g_world.built || g_world.seed != cfg->world_seed || g_world.radius != radius) build_world(g_world, cfg->world_seed, radius);
   const int H = cfg->height, W = cfg->width;
   std::vector<double> el;
   ring_elevations(H, el);
   Pose P; double q[4];
-  trajectory(stream, scan, P, q);
+  trajectory(stream, scan, cfg->yaw_rate_deg, cfg->speed, P, q);
   if (gt_pose) {
     gt_pose[0] = q[0]; gt_pose[1] = q[1]; gt_pose[2] = q[2]; gt_pose[3] = q[3];
     gt_pose[4] = P.t[0]; gt_pose[5] = P.t[1]; gt_pose[6] = P.t[2];
@@ -234,9 +247,6 @@ int synth_scan(const synth_cfg_t* cfg, int stream, int scan, float* xyzi, double
   return 0;
 }
 
-int synth_num_boxes(uint32_t world_seed) {
-  if (!g_world.built || g_world.seed != world_seed) build_world(g_world, world_seed);
-  return (int)g_world.boxes.size();
-}
+int synth_num_boxes(void) { return g_world.built ? (int)g_world.boxes.size() : 0; }
 
 }  // extern "C"

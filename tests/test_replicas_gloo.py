@@ -1,0 +1,49 @@
+"""N > 1 path of bench.py: one process per GPU, replicas only.  Covered here with two gloo
+processes on CPU: rendezvous on 127.0.0.1, distinct stream per rank, barrier, max-over-ranks."""
+import os
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_replicas_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(textwrap.dedent("""
+        import sys, time
+        sys.path.insert(0, %r)
+        from liodom_amd.replicas import Replicas
+        rep = Replicas()
+        assert rep.world == 2 and rep.stream_id == rep.rank and rep.device == rep.local_rank
+        rep.barrier()
+        elapsed = 1.0 + rep.rank            # rank 1 is "slower"
+        mx = rep.max_over_ranks(elapsed)
+        total = rep.sum_over_ranks(10 * (rep.rank + 1))
+        assert mx == 2.0 and total == 30.0, (mx, total)
+        # whole-job throughput = units of all ranks / max time
+        print("RANK", rep.rank, "OK", 2 * 100 / mx, flush=True)
+        rep.close()
+    """ % ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "RANK 0 OK 100.0" in out.stdout and "RANK 1 OK 100.0" in out.stdout
+
+
+def test_single_process_is_a_noop():
+    sys.path.insert(0, ROOT)
+    from liodom_amd.replicas import Replicas
+    env_backup = {k: os.environ.pop(k, None) for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    try:
+        rep = Replicas()
+        assert rep.world == 1 and rep.dist is None
+        assert rep.max_over_ranks(3.5) == 3.5
+        rep.barrier()
+        rep.close()
+    finally:
+        for k, v in env_backup.items():
+            if v is not None:
+                os.environ[k] = v

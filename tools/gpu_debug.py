@@ -128,6 +128,129 @@ SECTIONS = {
     "timing_batch": lambda: [sec_timing(S=s, K=40) for s in (8, 64)],
 }
 
+
+
+def sec_syncprof(H=64, W=1800, R=8, epr=10, P=20, K=60):
+    """Kernel durations in per-scan synchronous mode, and host-side timing of each call."""
+    cfg = synth.make_cfg(H, W, 0)
+    po, g = mk(H, W, 0, R, epr, P, pose_log_capacity=4 * K)
+    g.alloc_resident(K)
+    for k in range(K):
+        g.upload_scan(0, k, synth.scan(cfg, 0, k)[0])
+    for k in range(10):
+        g.process_resident(k, H * W, H, W, readback=True)
+    lat = []
+    for k in range(10, K):
+        t = time.perf_counter()
+        g.process_resident(k, H * W, H, W, readback=True)
+        lat.append(time.perf_counter() - t)
+    lat = np.array(lat) * 1e6
+    print("sync call latency us: min %.1f med %.1f mean %.1f max %.1f" % (lat.min(), np.median(lat), lat.mean(), lat.max()))
+    g.reset()
+    g.set_profiling(True)
+    for k in range(K):
+        g.process_resident(k, H * W, H, W, readback=True)
+    st = g.kernel_stats()
+    g.set_profiling(False)
+    for name, (n, ms) in st.items():
+        if n:
+            print("  [sync] %-16s %5d launches  avg %8.2f us" % (name, n, ms / n * 1e3))
+    # sync via stream synchronize instead of polling: enqueue async then sync each scan
+    g.reset()
+    for k in range(10):
+        g.process_resident(k, H * W, H, W, readback=False)
+        g.sync()
+    t = time.perf_counter()
+    for k in range(10, K):
+        g.process_resident(k, H * W, H, W, readback=False)
+        g.sync()
+    print("async+hipStreamSynchronize per scan: %.1f us" % ((time.perf_counter() - t) / (K - 10) * 1e6))
+    # sleep between scans (10 Hz-like pacing shrunk to 2 ms) to see idle-clock effects
+    g.reset()
+    lat = []
+    for k in range(K):
+        time.sleep(0.002)
+        t = time.perf_counter()
+        g.process_resident(k, H * W, H, W, readback=True)
+        lat.append(time.perf_counter() - t)
+    lat = np.array(lat[10:]) * 1e6
+    print("paced (2 ms idle between scans) call latency us: min %.1f med %.1f max %.1f" % (lat.min(), np.median(lat), lat.max()))
+    g.close()
+
+
+SECTIONS["syncprof"] = sec_syncprof
+
+
+def sec_clocks(H=64, W=1800, R=8, epr=10, P=20, K=40):
+    import ctypes as C
+    os.environ["LIODOM_ABLATE"] = str(int(os.environ.get("LIODOM_ABLATE", "0")) | 32)
+    cfg = synth.make_cfg(H, W, 0)
+    po, g = mk(H, W, 0, R, epr, P, pose_log_capacity=4 * K)
+    g.alloc_resident(K)
+    for k in range(K):
+        g.upload_scan(0, k, synth.scan(cfg, 0, k)[0])
+    for k in range(K):
+        g.process_resident(k, H * W, H, W, readback=False)
+    g.sync()
+    buf = (C.c_ulonglong * 128)()
+    g.L.liodom_debug_clocks.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+    g.L.liodom_debug_clocks(g.h, buf)
+    a = np.array(list(buf), dtype=np.int64).reshape(4, 32)
+    names = {0: ["start", "ids loaded+matched", "compacted", "gathered", "stencil", "spec select", "carry replay", "emitted"],
+             1: ["start", "query ready", "hash probed", "centre streamed", "merge1", "phase2 done", "nn fetched", "gate done"],
+             2: ["start", "pose ready", "eval0", "begin", "eval1", "upd1", "eval2", "upd2", "eval3", "upd3", "eval4", "upd4", "", "", "", "", "", "", "", "", "loop end", "pose written", "finalized"]}
+    for k, kn in ((0, "k_ring_extract (ring 40)"), (1, "k_knn (block 20, it 0)"), (2, "k_lm_solve (it 1)")):
+        row = a[k]
+        t0 = row[0]
+        print(kn)
+        prev = t0
+        for i, nm in enumerate(names[k]):
+            if i == 0 or row[i] == 0 or not nm:
+                continue
+            print("   %-22s +%7.2f us  (at %7.2f)" % (nm, (row[i] - prev) / 100.0, (row[i] - t0) / 100.0))
+            prev = row[i]
+    g.close()
+
+
+SECTIONS["clocks"] = sec_clocks
+
+
+def sec_long(H=64, W=1800, R=8, epr=10, P=20, K=220):
+    cfg = synth.make_cfg(H, W, 0)
+    po, g = mk(H, W, 0, R, epr, P)
+    od = orc.Odometer(po)
+    shown = 0
+    for k in range(K):
+        x, gt = synth.scan(cfg, 0, k)
+        o = orc.extract(po, x, H, W)
+        pose_o, io = od.step(o["edges"])
+        pose_g, ig = g.process_scan(x, H, W)
+        dt = np.linalg.norm(pose_g[4:] - pose_o[4:])
+        eg = np.linalg.norm(pose_g[4:] - gt[4:])
+        eo = np.linalg.norm(pose_o[4:] - gt[4:])
+        flag = dt > 1e-9 or ig.n_edges != io.n_edges or list(ig.matches) != list(io.matches)
+        if (flag and shown < 25) or k % 20 == 0:
+            shown += flag
+            nd = []
+            for it in (0, 1):
+                vo, ao, bo = od.last_corr(it)
+                vg, ag, bg = g.correspondences(it)
+                if len(vo) == len(vg):
+                    nd.append(int((vo != vg).sum()) + int(((ao != ag) | (bo != bg))[(vo == 1) & (vg == 1)].sum()))
+                else:
+                    nd.append(-1)
+            print("scan %3d E %d/%d M %d/%d match %s/%s it %s/%s term %s/%s acc %s/%s dt %.2e err_gt gpu %.3f orc %.3f corrdiff %s cost %.6g/%.6g st %d" % (
+                k, ig.n_edges, io.n_edges, ig.map_points, io.map_points, list(ig.matches), list(io.matches),
+                [ig.lm[0].iterations, ig.lm[1].iterations], [io.lm[0].iterations, io.lm[1].iterations],
+                [ig.lm[0].termination, ig.lm[1].termination], [io.lm[0].termination, io.lm[1].termination],
+                [ig.lm[0].accepted, ig.lm[1].accepted], [io.lm[0].accepted, io.lm[1].accepted],
+                dt, eg, eo, nd, ig.lm[1].final_cost, io.lm[1].final_cost, ig.status), flush=True)
+    g.close()
+
+
+SECTIONS["long"] = sec_long
+
+
 if __name__ == "__main__":
     names = sys.argv[1:] or ["extract", "odom", "odom64", "timing"]
     for n in names:
@@ -137,3 +260,6 @@ if __name__ == "__main__":
         except Exception:
             traceback.print_exc()
         sys.stdout.flush()
+
+
+
