@@ -1,0 +1,194 @@
+#include "liodom_host.h"
+
+#include <cstring>
+#include <fstream>
+#include <stdexcept>
+
+namespace liodom {
+
+namespace {
+void check(int rc, const char* what) {
+  if (rc != LIODOM_OK) throw std::runtime_error(std::string(what) + ": " + liodom_last_error());
+}
+}  // namespace
+
+std::array<double, 12> Pose::matrix34() const {
+  // Eigen::Quaterniond::toRotationMatrix + translation (laser_odometry.cc:225-227)
+  const double x = q[0], y = q[1], z = q[2], w = q[3];
+  const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+  const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x;
+  const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  return {1 - (tyy + tzz), txy - twz, txz + twy, t[0],
+          txy + twz, 1 - (txx + tzz), tyz - twx, t[1],
+          txz - twy, tyz + twx, 1 - (txx + tyy), t[2]};
+}
+
+Params* Params::getInstance() { static Params inst; return &inst; }
+
+void Params::readParams(const std::vector<std::string>& kv) {
+  for (const std::string& s : kv) {
+    const size_t eq = s.find('=');
+    if (eq == std::string::npos) continue;
+    const std::string k = s.substr(0, eq), v = s.substr(eq + 1);
+    auto b = [&](const std::string& x) { return x == "true" || x == "1" || x == "True"; };
+    if (k == "min_range") min_range_ = std::stod(v);                 // params.cc:40
+    else if (k == "max_range") max_range_ = std::stod(v);            // :44
+    else if (k == "lidar_type") lidar_type_ = std::stoi(v);          // :48
+    else if (k == "scan_lines") scan_lines_ = std::stoi(v);          // :52
+    else if (k == "scan_regions") scan_regions_ = std::stoi(v);      // :56
+    else if (k == "edges_per_region") edges_per_region_ = std::stoi(v);   // :60
+    else if (k == "save_results") save_results_ = b(v);              // :66
+    else if (k == "save_results_dir") results_dir_ = v;              // :70
+    else if (k == "fixed_frame") fixed_frame_ = v;                   // :74
+    else if (k == "base_frame") base_frame_ = v;                     // :78
+    else if (k == "laser_frame") laser_frame_ = v;                   // :82
+    else if (k == "prev_frames") local_map_size_ = (size_t)std::stoi(v);  // :90-93
+    else if (k == "use_imu") use_imu_ = b(v);                        // :96
+    else if (k == "filter_local_map") filter_local_map_ = b(v);      // :100
+    else if (k == "mapping") mapping_ = b(v);                        // :104
+    else if (k == "publish_tf") publish_tf_ = b(v);                  // :108
+  }
+  min_points_per_scan_ = (size_t)(scan_regions_ * edges_per_region_ + 10);   // :63
+}
+
+liodom_params_t Params::toC() const {
+  liodom_params_t c;
+  liodom_params_default(&c);
+  c.min_range = min_range_; c.max_range = max_range_;
+  c.lidar_type = lidar_type_; c.scan_lines = scan_lines_;
+  c.scan_regions = scan_regions_; c.edges_per_region = edges_per_region_;
+  c.min_points_per_scan = min_points_per_scan_; c.local_map_size = local_map_size_;
+  c.save_results = save_results_;
+  std::strncpy(c.results_dir, results_dir_.c_str(), sizeof(c.results_dir) - 1);
+  std::strncpy(c.fixed_frame, fixed_frame_.c_str(), sizeof(c.fixed_frame) - 1);
+  std::strncpy(c.base_frame, base_frame_.c_str(), sizeof(c.base_frame) - 1);
+  std::strncpy(c.laser_frame, laser_frame_.c_str(), sizeof(c.laser_frame) - 1);
+  c.use_imu = use_imu_; c.filter_local_map = filter_local_map_; c.mapping = mapping_; c.publish_tf = publish_tf_;
+  return c;
+}
+
+Stats* Stats::getInstance() { static Stats inst; return &inst; }
+void Stats::addPose(const std::array<double, 12>& p) { poses_.push_back(p); }
+void Stats::addFeatureExtractionTime(const Clock::time_point& s, const Clock::time_point& e) {
+  feat_extr_.push_back((double)std::chrono::duration_cast<std::chrono::milliseconds>(e - s).count());   // whole ms, stats.cc:42
+}
+void Stats::addLaserOdometryTime(const Clock::time_point& s, const Clock::time_point& e) {
+  laser_odom_.push_back((double)std::chrono::duration_cast<std::chrono::milliseconds>(e - s).count());
+}
+void Stats::addNumOfFeats(const size_t& n) { num_of_features_.push_back(n); }
+void Stats::startFrame(const Clock::time_point& s) { std::lock_guard<std::mutex> l(frame_mutex_); start_times_.push(s); }
+void Stats::stopFrame(const Clock::time_point& stop) {
+  std::lock_guard<std::mutex> l(frame_mutex_);
+  if (!start_times_.empty()) {
+    const Clock::time_point start = start_times_.front();
+    start_times_.pop();
+    frame_times_.push_back((double)std::chrono::duration_cast<std::chrono::milliseconds>(stop - start).count());
+  }
+}
+void Stats::clear() { poses_.clear(); feat_extr_.clear(); laser_odom_.clear(); frame_times_.clear(); num_of_features_.clear(); }
+
+// File formats of Stats::writeResults (stats.cc:73-132): poses.txt = KITTI rows of the top 3x4 of
+// the pose with default ostream precision; the other files one value per line.
+void Stats::writeResults(const std::string& dir) {
+  std::ofstream poses((dir + "poses.txt").c_str(), std::ios::out | std::ios::trunc);
+  for (const auto& p : poses_) {
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 4; j++) {
+        poses << p[i * 4 + j];
+        if (j != 3) poses << " ";
+        else if (i == 2) poses << std::endl;
+        else poses << " ";
+      }
+  }
+  auto dump = [&](const char* name, const std::vector<double>& v) {
+    std::ofstream f((dir + name).c_str(), std::ios::out | std::ios::trunc);
+    for (double x : v) f << x << std::endl;
+  };
+  dump("feat_ext_times.txt", feat_extr_);
+  dump("laser_odom_times.txt", laser_odom_);
+  {
+    std::ofstream f((dir + "nfeats.txt").c_str(), std::ios::out | std::ios::trunc);
+    for (size_t x : num_of_features_) f << x << std::endl;
+  }
+  dump("frame_times.txt", frame_times_);
+}
+
+Engine::Engine(const Params& p, int device, int max_points, int max_width) {
+  liodom_params_t cp = p.toC();
+  liodom_config_t cfg;
+  liodom_config_default(&cfg);
+  cfg.device = device; cfg.n_streams = 1; cfg.max_points = max_points; cfg.max_width = max_width;
+  check(liodom_create(&cp, &cfg, &h_), "liodom_create");
+  edge_cap_ = p.scan_lines_ * p.scan_regions_ * (p.edges_per_region_ + 1) + 64;
+}
+Engine::~Engine() { liodom_destroy(h_); }
+
+FeatureExtractor::FeatureExtractor(std::shared_ptr<Engine> e)
+    : eng_(std::move(e)), params(Params::getInstance()), stats(Stats::getInstance()) {}
+
+void FeatureExtractor::extractFeatures(const PointCloud& pc_in, PointCloud& pc_edges) {
+  const auto start_t = Clock::now();
+  pc_edges.points.resize((size_t)eng_->edge_capacity());
+  int n = 0;
+  check(liodom_extract_edges(eng_->handle(), 0, reinterpret_cast<const float*>(pc_in.points.data()),
+                             (int64_t)pc_in.size(), (int)pc_in.height, (int)pc_in.width,
+                             reinterpret_cast<float*>(pc_edges.points.data()), nullptr, nullptr, nullptr,
+                             eng_->edge_capacity(), &n), "liodom_extract_edges");
+  pc_edges.points.resize((size_t)n);
+  pc_edges.width = (uint32_t)n; pc_edges.height = 1;
+  if (params->save_results_) {                                        // feature_extractor.cc:65-68
+    stats->addFeatureExtractionTime(start_t, Clock::now());
+    stats->addNumOfFeats(pc_edges.size());
+  }
+}
+
+size_t LocalMapManager::getLocalMap(PointCloud& map) {
+  int64_t n = 0; int nf = 0;
+  liodom_get_window(eng_->handle(), 0, nullptr, 0, &n, &nf);         // size query
+  map.points.resize((size_t)n);
+  check(liodom_get_window(eng_->handle(), 0, reinterpret_cast<float*>(map.points.data()), n, &n, &nf), "liodom_get_window");
+  map.width = (uint32_t)n; map.height = 1;
+  return (size_t)nf;
+}
+
+LaserOdometer::LaserOdometer(std::shared_ptr<Engine> e)
+    : lmap_manager(e), eng_(e), params(Params::getInstance()), stats(Stats::getInstance()) {}
+
+Pose LaserOdometer::process(const PointCloud& feats, double stamp, liodom_step_info_t* info) {
+  const auto start_t = Clock::now();
+  double p[7];
+  check(liodom_odometry_step(eng_->handle(), 0, reinterpret_cast<const float*>(feats.points.data()),
+                             (int)feats.size(), stamp, p, info), "liodom_odometry_step");
+  Pose out;
+  std::memcpy(out.q, p, sizeof(double) * 4); std::memcpy(out.t, p + 4, sizeof(double) * 3);
+  if (params->save_results_) {                                        // laser_odometry.cc:259-263
+    const auto end_t = Clock::now();
+    stats->addPose(out.matrix34());
+    stats->addLaserOdometryTime(start_t, end_t);
+    stats->stopFrame(end_t);
+  }
+  return out;
+}
+
+Pose LaserOdometer::processScan(const PointCloud& pc_in, double stamp, liodom_step_info_t* info) {
+  const auto start_t = Clock::now();
+  if (params->save_results_) stats->startFrame(start_t);              // liodom_node.cc:49-52
+  double p[7];
+  liodom_step_info_t local;
+  check(liodom_process_scan(eng_->handle(), 0, reinterpret_cast<const float*>(pc_in.points.data()),
+                            (int64_t)pc_in.size(), (int)pc_in.height, (int)pc_in.width, stamp, p, &local),
+        "liodom_process_scan");
+  if (info) *info = local;
+  Pose out;
+  std::memcpy(out.q, p, sizeof(double) * 4); std::memcpy(out.t, p + 4, sizeof(double) * 3);
+  if (params->save_results_) {
+    const auto end_t = Clock::now();
+    stats->addNumOfFeats((size_t)local.n_edges);
+    stats->addPose(out.matrix34());
+    stats->addLaserOdometryTime(start_t, end_t);
+    stats->stopFrame(end_t);
+  }
+  return out;
+}
+
+}  // namespace liodom

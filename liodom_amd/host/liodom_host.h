@@ -1,0 +1,133 @@
+// liodom_host.h — host-side C++ mirror of the reference's hot-path classes, implemented over the
+// C-ABI of include/liodom_hip.h (no ROS, no PCL, no Eigen, no Ceres).
+//
+// Names, argument meaning and error behaviour follow the reference so that a maintainer can swap
+// the bodies of the corresponding reference classes:
+//   liodom::Params            include/liodom/params.h:30-70, src/params.cc:37-110
+//   liodom::FeatureExtractor  include/liodom/feature_extractor.h:62-85, src/feature_extractor.cc
+//   liodom::LaserOdometer     include/liodom/laser_odometry.h:79-121, src/laser_odometry.cc
+//   liodom::LocalMapManager   include/liodom/laser_odometry.h:62-76 (read-only view of the device window)
+//   liodom::Stats             include/liodom/stats.h:40-80, src/stats.cc (result files)
+// Like the reference the hot-path methods return void and report problems through a log hook;
+// unlike it, failures of the GPU library also raise std::runtime_error (nothing falls back to CPU).
+#pragma once
+#include <array>
+#include <chrono>
+#include <cstdint>
+#include <memory>
+#include <mutex>
+#include <queue>
+#include <string>
+#include <vector>
+
+#include "../../include/liodom_hip.h"
+
+namespace liodom {
+
+typedef std::chrono::high_resolution_clock Clock;   // include/liodom/defs.h:38
+
+// pcl::PointXYZI without padding: the packed float4 the C-ABI takes.
+struct Point { float x, y, z, intensity; };
+struct PointCloud {
+  std::vector<Point> points;
+  uint32_t width = 0, height = 1;     // organised clouds: height rows x width columns (row-major)
+  size_t size() const { return points.size(); }
+};
+
+// Pose as the reference publishes it (world <- laser): quaternion [x y z w] + translation.
+struct Pose { double q[4] = {0, 0, 0, 1}; double t[3] = {0, 0, 0}; std::array<double, 12> matrix34() const; };
+
+// Same public fields as liodom::Params (include/liodom/params.h:33-49).
+class Params {
+ public:
+  double min_range_ = 3.0;
+  double max_range_ = 75.0;
+  int lidar_type_ = 0;
+  int scan_lines_ = 64;
+  int scan_regions_ = 8;
+  int edges_per_region_ = 10;
+  size_t min_points_per_scan_ = 90;
+  size_t local_map_size_ = 5;
+  bool save_results_ = false;
+  std::string results_dir_ = "~/";
+  std::string fixed_frame_ = "odom";
+  std::string base_frame_ = "base_link";
+  std::string laser_frame_ = "";
+  bool use_imu_ = false;
+  bool filter_local_map_ = false;
+  bool mapping_ = false;
+  bool publish_tf_ = true;
+
+  static Params* getInstance();
+  // readParams(nh) of the reference reads ROS parameters; here the same names come from
+  // "name=value" strings (launch-file values), unknown names are ignored like nh.param would.
+  void readParams(const std::vector<std::string>& name_value_pairs);
+  liodom_params_t toC() const;
+};
+
+class Stats {
+ public:
+  static Stats* getInstance();
+  void addPose(const std::array<double, 12>& pose34);                                          // stats.cc:36
+  void addFeatureExtractionTime(const Clock::time_point& start, const Clock::time_point& end);  // :40
+  void addLaserOdometryTime(const Clock::time_point& start, const Clock::time_point& end);      // :45
+  void addNumOfFeats(const size_t& nfeats);                                                     // :50
+  void startFrame(const Clock::time_point& start);                                              // :54
+  void stopFrame(const Clock::time_point& stop);                                                // :60
+  void writeResults(const std::string& dir);                                                    // :73-132
+  void clear();
+ private:
+  std::vector<std::array<double, 12>> poses_;
+  std::vector<double> feat_extr_, laser_odom_, frame_times_;
+  std::vector<size_t> num_of_features_;
+  std::mutex frame_mutex_;
+  std::queue<Clock::time_point> start_times_;
+};
+
+// Owns the GPU handle shared by the extractor and the odometer of one stream.
+class Engine {
+ public:
+  Engine(const Params& p, int device, int max_points, int max_width);
+  ~Engine();
+  liodom_handle_t* handle() const { return h_; }
+  int edge_capacity() const { return edge_cap_; }
+ private:
+  liodom_handle_t* h_ = nullptr;
+  int edge_cap_ = 0;
+};
+
+class FeatureExtractor {
+ public:
+  explicit FeatureExtractor(std::shared_ptr<Engine> engine);
+  // splitPointCloud + extractFeatures (feature_extractor.cc:104-254) for one cloud.
+  void extractFeatures(const PointCloud& pc_in, PointCloud& pc_edges);
+ private:
+  std::shared_ptr<Engine> eng_;
+  Params* params;
+  Stats* stats;
+};
+
+class LocalMapManager {
+ public:
+  explicit LocalMapManager(std::shared_ptr<Engine> engine) : eng_(std::move(engine)) {}
+  // getLocalMap (laser_odometry.cc:62-65): window points oldest frame first; returns nframes_
+  size_t getLocalMap(PointCloud& map);
+ private:
+  std::shared_ptr<Engine> eng_;
+};
+
+class LaserOdometer {
+ public:
+  explicit LaserOdometer(std::shared_ptr<Engine> engine);
+  // One pass of the loop body of LaserOdometer::operator() (laser_odometry.cc:107-267).
+  Pose process(const PointCloud& feats, double stamp, liodom_step_info_t* info = nullptr);
+  // lidarClb -> extractor -> odometer without leaving the device (one H2D copy, one result record)
+  Pose processScan(const PointCloud& pc_in, double stamp, liodom_step_info_t* info = nullptr);
+  LocalMapManager lmap_manager;
+ private:
+  std::shared_ptr<Engine> eng_;
+  Params* params;
+  Stats* stats;
+};
+
+}  // namespace liodom

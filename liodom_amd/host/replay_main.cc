@@ -1,0 +1,62 @@
+// liodom_replay — replays a directory of KITTI-style Velodyne scans (NNNNNN.bin, float32 x y z i)
+// through the GPU path with the reference's parameters and writes the reference's result files
+// (poses.txt in KITTI format, *_times.txt, nfeats.txt; src/stats.cc:73-132).
+//
+//   liodom_replay <scan_dir> <out_dir/> [name=value ...]     e.g. scan_lines=64 prev_frames=20
+#include <algorithm>
+#include <cstdio>
+#include <dirent.h>
+#include <fstream>
+#include <iostream>
+
+#include "liodom_host.h"
+
+int main(int argc, char** argv) {
+  if (argc < 3) { std::fprintf(stderr, "usage: %s <scan_dir> <out_dir/> [name=value ...]\n", argv[0]); return 2; }
+  const std::string dir = argv[1], out = argv[2];
+  std::vector<std::string> kv(argv + 3, argv + argc);
+  kv.push_back("save_results=true");
+  liodom::Params* params = liodom::Params::getInstance();
+  params->readParams(kv);
+
+  std::vector<std::string> files;
+  if (DIR* d = opendir(dir.c_str())) {
+    while (dirent* e = readdir(d)) {
+      const std::string n = e->d_name;
+      if (n.size() > 4 && n.substr(n.size() - 4) == ".bin") files.push_back(dir + "/" + n);
+    }
+    closedir(d);
+  }
+  std::sort(files.begin(), files.end());
+  if (files.empty()) { std::fprintf(stderr, "no .bin scans in %s\n", dir.c_str()); return 1; }
+
+  size_t max_pts = 0;
+  std::vector<liodom::PointCloud> clouds(files.size());
+  for (size_t i = 0; i < files.size(); i++) {
+    std::ifstream f(files[i], std::ios::binary | std::ios::ate);
+    const size_t bytes = (size_t)f.tellg();
+    f.seekg(0);
+    clouds[i].points.resize(bytes / sizeof(liodom::Point));
+    f.read(reinterpret_cast<char*>(clouds[i].points.data()), (std::streamsize)(clouds[i].points.size() * sizeof(liodom::Point)));
+    clouds[i].width = (uint32_t)clouds[i].points.size(); clouds[i].height = 1;
+    if (params->lidar_type_ == 1) {   // organised: rows = scan_lines
+      clouds[i].height = (uint32_t)params->scan_lines_;
+      clouds[i].width = (uint32_t)(clouds[i].points.size() / (size_t)params->scan_lines_);
+    }
+    max_pts = std::max(max_pts, clouds[i].points.size());
+  }
+  try {
+    auto eng = std::make_shared<liodom::Engine>(*params, 0, (int)max_pts, (int)(max_pts / (size_t)params->scan_lines_ + 1));
+    liodom::LaserOdometer odometer(eng);
+    for (size_t i = 0; i < clouds.size(); i++) {
+      liodom_step_info_t info;
+      liodom::Pose p = odometer.processScan(clouds[i], 0.1 * (double)i, &info);
+      if (i % 50 == 0) std::printf("scan %zu: %d edges, %d matches, t = %.3f %.3f %.3f\n", i, info.n_edges, info.matches[1], p.t[0], p.t[1], p.t[2]);
+    }
+    liodom::Stats::getInstance()->writeResults(out);
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "liodom_replay: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}

@@ -239,3 +239,40 @@ def test_static_sensor_stays_put(orc, synth):
         pose, info = g.process_scan(x, H, W)
         assert np.linalg.norm(pose[4:]) < 1e-6 and rot_angle(pose[:4], np.array([0, 0, 0, 1.0])) < 1e-6
     g.close()
+
+
+def test_replay_harness_writes_reference_result_files(orc, synth, tmp_path):
+    """liodom_amd/host (C++ mirror of the reference classes over the C-ABI): replay KITTI-style
+    .bin scans and compare poses.txt (KITTI 3x4 rows, default stream precision, stats.cc:73-96)
+    and nfeats.txt with the oracle."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "liodom_amd", "host", "liodom_replay")
+    if not os.path.exists(exe):
+        pytest.skip("liodom_replay not built (run __graft_entry__.build())")
+    H, W, R, epr, P, K = 16, 900, 6, 10, 5, 8
+    cfg = synth.make_cfg(H, W, 0)
+    po = orc.make_params(scan_lines=H, scan_regions=R, edges_per_region=epr, prev_frames=P, knn_mode=1)
+    od = orc.Odometer(po)
+    scan_dir = tmp_path / "scans"
+    out_dir = tmp_path / "out"
+    scan_dir.mkdir()
+    out_dir.mkdir()
+    rows, nfeats = [], []
+    for k in range(K):
+        x, _ = synth.scan(cfg, 0, k)
+        x.astype(np.float32).tofile(str(scan_dir / ("%06d.bin" % k)))
+        e = orc.extract(po, x, H, W)
+        pose, _ = od.step(e["edges"])
+        T, _ = orc.pose_ops(pose[:4], pose[4:])
+        rows.append(T.reshape(12))
+        nfeats.append(len(e["ring"]))
+    r = subprocess.run([exe, str(scan_dir), str(out_dir) + "/", "scan_lines=16", "scan_regions=6", "edges_per_region=10",
+                        "prev_frames=5"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    got = np.loadtxt(str(out_dir / "poses.txt")).reshape(-1, 12)
+    assert got.shape == (K, 12)
+    assert np.allclose(got, np.array(rows), rtol=2e-5, atol=2e-6)        # 6 significant digits in the file
+    assert np.loadtxt(str(out_dir / "nfeats.txt")).astype(int).tolist() == nfeats
+    for f in ("feat_ext_times.txt", "laser_odom_times.txt", "frame_times.txt"):
+        assert (out_dir / f).exists()
