@@ -161,7 +161,7 @@ int liodom_get_curvature(liodom_handle_t* h, int stream, double* curv, int64_t c
 /* ---- measurement ---- */
 /* When enabled every kernel launch is bracketed by HIP events on the handle's stream. */
 int liodom_set_profiling(liodom_handle_t* h, int enable);
-#define LIODOM_NUM_KERNELS 10
+#define LIODOM_NUM_KERNELS 11
 typedef struct liodom_kernel_stat_t {
   char name[32];
   int64_t launches;

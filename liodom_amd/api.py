@@ -68,7 +68,7 @@ class StepInfo(C.Structure):
                 ("status", C.c_uint32), ("scan_index", C.c_int32)]
 
 
-NUM_KERNELS = 10
+NUM_KERNELS = 11
 
 
 class KernelStat(C.Structure):

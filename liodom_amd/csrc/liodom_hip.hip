@@ -33,11 +33,11 @@ thread_local std::string g_last_error;
 
 enum KernelId {
   KID_CLASSIFY = 0, KID_RING_EXTRACT, KID_COMPACT, KID_KNN, KID_LM, KID_HASH_CLEAR,
-  KID_WINDOW_INSERT, KID_HASH_ALLOC, KID_HASH_SCATTER, KID_OTHER
+  KID_WINDOW_INSERT, KID_HASH_ALLOC, KID_HASH_SCATTER, KID_RING_SCATTER, KID_OTHER
 };
 const char* kKernelNames[LIODOM_NUM_KERNELS] = {
     "k_classify", "k_ring_extract", "k_compact_edges", "k_knn", "k_lm_solve",
-    "k_hash_clear", "k_window_insert", "k_hash_alloc", "k_hash_scatter", "other"};
+    "k_hash_clear", "k_window_insert", "k_hash_alloc", "k_hash_scatter", "k_ring_scatter", "other"};
 
 struct EventPair { hipEvent_t a, b; int kid; };
 
@@ -121,16 +121,19 @@ inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 int launch_extract(liodom_handle* h, int s0, int count, const float4* in, size_t in_stride, int n,
                    int height, int width) {
   const DevView& v = h->v;
+  const int tiles = std::max(1, cdiv(n, kTilePts));
   {
     ProfScope ps(h, KID_CLASSIFY);
-    dim3 grid(cdiv((long long)n + 256, 256), count);
-    hipLaunchKernelGGL(k_classify, grid, dim3(256), 0, h->stream, v, s0, in, in_stride, n, height, width);
+    hipLaunchKernelGGL(k_classify, dim3(tiles, count), dim3(kTileThreads), 0, h->stream, v, s0, in, in_stride, n, height, width);
+  }
+  {
+    ProfScope ps(h, KID_RING_SCATTER);
+    hipLaunchKernelGGL(k_ring_scatter, dim3(tiles, count), dim3(kTileThreads), ring_scatter_lds_bytes(h->H), h->stream, v, s0, in, in_stride, n);
   }
   {
     ProfScope ps(h, KID_RING_EXTRACT);
     dim3 grid(h->H, count);
-    hipLaunchKernelGGL(k_ring_extract, grid, dim3(kExThreads), h->ring_lds_bytes, h->stream, v, s0, in,
-                       in_stride, n, height, width);
+    hipLaunchKernelGGL(k_ring_extract, grid, dim3(kExThreads), h->ring_lds_bytes, h->stream, v, s0);
   }
   {
     ProfScope ps(h, KID_COMPACT);
@@ -300,6 +303,11 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
 #define ALLOC(ptr, count, fill) do { rc = dev_alloc(h, &(ptr), (count), (fill)); if (rc != LIODOM_OK) return fail(rc); } while (0)
   ALLOC(v.state, S, 0);
   ALLOC(v.ring_id, S * v.ring_id_stride, 0xFF);
+  v.tile_cap = std::max(1, cdiv(config->max_points, kTilePts));
+  ALLOC(v.tile_hist, S * (size_t)v.tile_cap * h->H, 0);
+  ALLOC(v.ring_pts, S * (size_t)config->max_points, 0);
+  ALLOC(v.ring_src, S * (size_t)config->max_points, 0);
+  ALLOC(v.ring_start, S * (size_t)(h->H + 1), 0);
   ALLOC(v.edges_pad, S * h->H * v.slots_per_ring, 0);
   ALLOC(v.edges_pad_meta, S * h->H * v.slots_per_ring, 0);
   ALLOC(v.ring_nedges, S * h->H, 0);
@@ -332,6 +340,12 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
     if (hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) { g_last_error = "hipHostGetDevicePointer failed"; return fail(LIODOM_ERR_HIP); }
     v.host_out = static_cast<HostOut*>(dp);
     h->scans_enqueued.assign(S, 0);
+  }
+  if (ring_scatter_lds_bytes(h->H) > 48 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ring_scatter), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)ring_scatter_lds_bytes(h->H)) != hipSuccess) {
+      g_last_error = "hipFuncSetAttribute(max dynamic LDS) failed"; return fail(LIODOM_ERR_HIP);
+    }
   }
   if (h->ring_lds_bytes > 48 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ring_extract), hipFuncAttributeMaxDynamicSharedMemorySize,

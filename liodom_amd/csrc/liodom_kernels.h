@@ -1,8 +1,9 @@
 // liodom_kernels.h — hand-written HIP kernels of the LiODOM hot path for gfx950 (CDNA4).
 //
 // Kernel map (one launch covers all streams: blockIdx.y = stream):
-//   k_classify        A1/A2  isValidPoint + ring id per point      (feature_extractor.cc:84-179)
-//   k_ring_extract    A2-A5  per-ring gather -> LDS tile -> FP64 curvature stencil ->
+//   k_classify        A1/A2  isValidPoint + ring id per point, per-tile ring histogram (feature_extractor.cc:84-179)
+//   k_ring_scatter    A2     stable counting sort of the scan by ring (input order kept per ring)
+//   k_ring_extract    A3-A5  ring -> LDS tile -> FP64 curvature stencil ->
 //                            greedy per-region selection with +-5 suppression (:181-313)
 //   k_compact_edges          ring-padded edges -> dense edge cloud (output order of :186-252)
 //   k_knn             A9     edges -> world, 27-cell voxel-hash 5-NN, FP64 line gate
@@ -84,6 +85,11 @@ struct DevView {
   // per-stream arrays (stride = capacity)
   StreamState* state;
   unsigned char* ring_id;   size_t ring_id_stride;
+  unsigned short* tile_hist; // [S][tile_cap][H] points per (2048-point tile, ring)
+  int tile_cap;
+  float4* ring_pts;         // [S][max_points] the scan sorted by ring (stable) 
+  int* ring_src;            // [S][max_points] source index of every sorted point
+  int* ring_start;          // [S][H+1] offsets of the rings in ring_pts
   float4* edges_pad;        // [S][H][slots_per_ring]
   int2* edges_pad_meta;     // (idx_in_ring, src)
   int* ring_nedges;         // [S][H]
@@ -125,80 +131,164 @@ __device__ __forceinline__ unsigned int hash_cell(unsigned long long k, unsigned
 }
 
 // =============================================================================================
-// k_classify: one thread per point.  Reads 16 B, writes 1 B.  ids beyond n are 0xFF so the ring
-// kernels can read whole 16-byte id chunks.
+// Ring split = stable counting sort of the scan by ring id (the reference appends every valid
+// point to its ring's cloud in input order, feature_extractor.cc:115-175).
+//
+// k_classify      512 threads, one tile of 2048 consecutive points per workgroup: coalesced 16-B
+//                 loads, isValidPoint + elevation bin in FP64, one id byte per point, and the
+//                 tile's ring histogram (LDS atomics) -> tile_hist[tile][ring].
+// k_ring_scatter  same tiling.  Offsets of (tile, ring) = ring start + column prefix of tile_hist
+//                 (every workgroup sums the small table itself: no separate scan launch).  The
+//                 stable rank inside the tile comes from 64-bit lane masks per (wave chunk, ring)
+//                 built with ds_or_b64: rank = popc(mask & lanes_below) + DPP prefix over the 32
+//                 chunks.  Points are re-read coalesced and written to their sorted position, so
+//                 every ring is contiguous for k_ring_extract (no H-fold id scan, no strided
+//                 gathers: 8x less fabric traffic than the first version, profiles/r01_c_*).
 // =============================================================================================
-__global__ __launch_bounds__(256) void k_classify(DevView v, int s0, const float4* __restrict__ in,
-                                                   size_t in_stride, int n, int height, int width) {
+constexpr int kTilePts = 2048;
+constexpr int kTileThreads = 512;
+constexpr int kTileChunks = kTilePts / 64;   // 32
+
+__global__ __launch_bounds__(kTileThreads) void k_classify(DevView v, int s0, const float4* __restrict__ in,
+                                                           size_t in_stride, int n, int height, int width) {
+  __shared__ int hist[256];
   const int s = s0 + blockIdx.y;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  unsigned char id = 0xFF;
-  if (i < n) {
-    const float4 p = in[(size_t)blockIdx.y * in_stride + i];
-    double dist;
-    if (valid_point((double)p.x, (double)p.y, (double)p.z, v.min_range, v.max_range, &dist)) {
-      int r;
-      if (v.lidar_type == 0) {
-        r = velodyne_ring((double)p.z, dist, v.scan_lines);
-      } else {
-        r = (width > 0) ? i / width : -1;     // ring = row (feature_extractor.cc:160-173)
-        if (r >= v.scan_lines || r >= height) r = -1;
+  const int tile = blockIdx.x;
+  const int H = v.scan_lines;
+  if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+  __syncthreads();
+  float4 p[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int i = tile * kTilePts + j * kTileThreads + threadIdx.x;
+    if (i < n) p[j] = in[(size_t)blockIdx.y * in_stride + i];
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int i = tile * kTilePts + j * kTileThreads + threadIdx.x;
+    unsigned char id = 0xFF;
+    if (i < n) {
+      double dist;
+      if (valid_point((double)p[j].x, (double)p[j].y, (double)p[j].z, v.min_range, v.max_range, &dist)) {
+        int r;
+        if (v.lidar_type == 0) {
+          r = velodyne_ring((double)p[j].z, dist, H);
+        } else {
+          r = (width > 0) ? i / width : -1;     // ring = row (feature_extractor.cc:160-173)
+          if (r >= H || r >= height) r = -1;
+        }
+        if (r >= 0) { id = (unsigned char)r; atomicAdd(&hist[r], 1); }
       }
-      if (r >= 0) id = (unsigned char)r;
+      v.ring_id[(size_t)s * v.ring_id_stride + i] = id;
     }
   }
-  if ((size_t)i < v.ring_id_stride) v.ring_id[(size_t)s * v.ring_id_stride + i] = id;
+  __syncthreads();
+  if ((int)threadIdx.x < H)
+    v.tile_hist[((size_t)s * v.tile_cap + tile) * H + threadIdx.x] = (unsigned short)hist[threadIdx.x];
+}
+
+__host__ __device__ __forceinline__ size_t ring_scatter_lds_bytes(int H) {
+  return (size_t)kTileChunks * H * 8 + (size_t)kTileChunks * H * 2 + (size_t)(2 * H + 16) * 4;
+}
+
+__global__ __launch_bounds__(kTileThreads) void k_ring_scatter(DevView v, int s0, const float4* __restrict__ in,
+                                                               size_t in_stride, int n) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int s = s0 + blockIdx.y;
+  const int tile = blockIdx.x, ntiles = gridDim.x;
+  const int H = v.scan_lines;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned long long* wmask = reinterpret_cast<unsigned long long*>(smem);          // [32][H]
+  unsigned short* cbase = reinterpret_cast<unsigned short*>(wmask + kTileChunks * H);  // [32][H]
+  int* rbase = reinterpret_cast<int*>(cbase + kTileChunks * H);                      // [H] ring start + tile prefix
+  int* wtot = rbase + H;                                                             // [8] + total
+  for (int k = tid; k < kTileChunks * H; k += kTileThreads) wmask[k] = 0ull;
+  // column prefix / totals of the histogram table for "my" ring (thread r < H); 8 loads in flight
+  int pre = 0, tot = 0;
+  if (tid < H) {
+    const unsigned short* th = v.tile_hist + (size_t)s * v.tile_cap * H + tid;
+    for (int t0 = 0; t0 < ntiles; t0 += 8) {
+      int c[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) c[u] = (t0 + u < ntiles) ? (int)th[(size_t)(t0 + u) * H] : 0;
+#pragma unroll
+      for (int u = 0; u < 8; u++) { tot += c[u]; if (t0 + u < tile) pre += c[u]; }
+    }
+  }
+  // exclusive scan of the ring totals over the (<= 254) rings
+  const int incl = wave_incl_scan_i32(tot);
+  if (lane == 63) wtot[wave] = incl;
+  __syncthreads();
+  {
+    int base = 0;
+    for (int w = 0; w < wave; w++) base += wtot[w];
+    const int rstart = base + incl - tot;
+    if (tid < H) {
+      rbase[tid] = rstart + pre;
+      if (tile == 0) v.ring_start[(size_t)s * (H + 1) + tid] = rstart;
+    }
+    if (tile == 0 && tid == H - 1) v.ring_start[(size_t)s * (H + 1) + H] = rstart + tot;
+  }
+  // lane masks per (chunk, ring)
+  const unsigned char* ids = v.ring_id + (size_t)s * v.ring_id_stride;
+  unsigned char id[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int i = tile * kTilePts + j * kTileThreads + tid;
+    id[j] = (i < n) ? ids[i] : (unsigned char)0xFF;
+    if (id[j] != 0xFF) atomicOr(&wmask[(j * (kTileThreads / 64) + wave) * H + id[j]], 1ull << lane);
+  }
+  __syncthreads();
+  // prefix over the 32 chunks for every ring: one half-wave per ring
+  for (int r = wave * 2 + (lane >> 5); r < H; r += 2 * (kTileThreads / 64)) {
+    const int c = lane & 31;
+    const int cnt = __popcll(wmask[c * H + r]);
+    const int ic = half_incl_scan_i32(cnt);
+    cbase[c * H + r] = (unsigned short)(ic - cnt);
+  }
+  __syncthreads();
+  float4* out = v.ring_pts + (size_t)s * v.max_points;
+  int* osrc = v.ring_src + (size_t)s * v.max_points;
+  const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int i = tile * kTilePts + j * kTileThreads + tid;
+    if (id[j] != 0xFF) {
+      const int chunk = j * (kTileThreads / 64) + wave;
+      const int dst = rbase[id[j]] + (int)cbase[chunk * H + id[j]] + __popcll(wmask[chunk * H + id[j]] & below);
+      out[dst] = in[(size_t)blockIdx.y * in_stride + i];
+      osrc[dst] = i;
+    }
+  }
 }
 
 // =============================================================================================
 // k_ring_extract: one 512-thread workgroup per (ring, stream).
-//   phase 0  every thread scans a contiguous span of the ring-id bytes (16 B loads, SWAR byte
-//            match), one workgroup-wide exclusive scan (DPP wave scan + LDS), second pass writes
-//            the matching point indices in input order -> stable compaction into LDS
-//   phase 1  gather XYZ of those points (16-B loads) into an SoA LDS tile
+//   phase 1  coalesced load of the ring (contiguous in the ring-sorted copy) into an SoA LDS tile
 //   phase 2  FP64 11-tap curvature stencil out of LDS
 //   phase 3  selection.  Per region: repeat { wavefront argmax of smoothness over not-picked
 //            items (DPP / permlane-swap butterfly, lowest index on ties); stop below 0.1 or after
 //            epr+1 picks; suppress +-5 neighbours while consecutive gaps <= 0.05 (ballot) }.
 //            The reference walks regions in order because suppression carries across region
 //            boundaries.  Here the 8 waves run the regions speculatively
-//            in parallel (candidates register-resident, 4 or 8 per lane) assuming no carry;
-//            wave 0 then replays the carry in region order and re-runs only regions in which a
-//            speculative pick was suppressed by an earlier region (exact: marking an item that
-//            the speculative run never picked cannot change that run).
+//            in parallel (candidates register-resident, 4 or 8 per lane) assuming no carry; each
+//            region then checks whether one of its picks was suppressed by the forward spill of
+//            an earlier region.  No conflict (the common case): all results are final.  Otherwise
+//            wave 0 replays the regions in order, re-running only conflicting ones (exact:
+//            marking an item the speculative run never picked cannot change that run).
 //   phase 4  all threads write the picks in region order.
-// LDS: c[cap] f64 | px py pz [cap] f32 | src[cap] i32 | picked[cap] u8 | pick_idx[slots] i32 |
+// LDS: c[cap] f64 | px py pz [cap] f32 | picked[cap] u8 | pick_idx[slots] i32 |
 //      pick_nfnb[slots] u8 | region_cnt[R] i32 | scratch
 // =============================================================================================
 constexpr int kExThreads = 512;
 constexpr int kExWaves = kExThreads / 64;
 
 __host__ __device__ __forceinline__ size_t ring_extract_lds_bytes(int cap, int slots, int regions) {
-  size_t b = (size_t)cap * (8 + 12 + 4 + 1);
+  size_t b = (size_t)cap * (8 + 12 + 1);
   b += (size_t)slots * 4;
   b += (size_t)((slots + 15) / 16 * 16);
   b += (size_t)regions * 4 + 16 * 8 * 4 + 64;
   return (b + 15) / 16 * 16;
-}
-
-// 16-bit mask of the bytes of w equal to `ring` (SWAR exact zero-byte test).
-__device__ __forceinline__ unsigned int match16(const uint4 w, unsigned int pat) {
-  unsigned int m = 0;
-  const unsigned int words[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const unsigned int z = words[k] ^ pat;
-    const unsigned int t = ~(((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z | 0x7F7F7F7Fu);   // 0x80 per zero byte
-    const unsigned int nib = ((t >> 7) & 1u) | ((t >> 14) & 2u) | ((t >> 21) & 4u) | ((t >> 28) & 8u);
-    m |= nib << (4 * k);
-  }
-  return m;
-}
-__device__ __forceinline__ unsigned int range16(int base, int lo, int hi) {
-  if (base >= lo && base + 16 <= hi) return 0xFFFFu;
-  unsigned int m = 0;
-  for (int b = 0; b < 16; b++) if (base + b >= lo && base + b < hi) m |= 1u << b;
-  return m;
 }
 
 // Suppression test around pick j (feature_extractor.cc:280-310): lanes 0-4 test the forward
@@ -292,8 +382,7 @@ __device__ int select_region_spec(const double* c, const float* px, const float*
   return picks;
 }
 
-__global__ __launch_bounds__(kExThreads) void k_ring_extract(DevView v, int s0, const float4* __restrict__ in,
-                                                              size_t in_stride, int n, int height, int width) {
+__global__ __launch_bounds__(kExThreads) void k_ring_extract(DevView v, int s0) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int ring = blockIdx.x;
   const int s = s0 + blockIdx.y;
@@ -304,104 +393,23 @@ __global__ __launch_bounds__(kExThreads) void k_ring_extract(DevView v, int s0, 
   float* px = reinterpret_cast<float*>(c + cap);
   float* py = px + cap;
   float* pz = py + cap;
-  int* src = reinterpret_cast<int*>(pz + cap);
-  unsigned char* picked = reinterpret_cast<unsigned char*>(src + cap);
+  unsigned char* picked = reinterpret_cast<unsigned char*>(pz + cap);
   int* pick_idx = reinterpret_cast<int*>(picked + cap);                 // [R][epr+1]
   unsigned char* pick_nfnb = reinterpret_cast<unsigned char*>(pick_idx + slots);
   int* region_cnt = reinterpret_cast<int*>(pick_nfnb + (slots + 15) / 16 * 16);   // [R]
   int* wtot = region_cnt + R;                                            // [16 * kExWaves] scan scratch
 
-  const float4* scan = in + (size_t)blockIdx.y * in_stride;
-  const unsigned char* ids = v.ring_id + (size_t)s * v.ring_id_stride;
   const int H = v.scan_lines;
   int* nedges_out = v.ring_nedges + (size_t)s * H + ring;
   int* npoints_out = v.ring_npoints + (size_t)s * H + ring;
 
   const bool dbgb = (ring == 40 % H) && (s == 0) && (tid == 0);
   DBG_STAMP(v, dbgb, 0, 0);
-  // ---- phase 0: stable compaction of this ring's point indices ----
-  int lo = 0, hi = n;
-  if (v.lidar_type != 0) {
-    lo = ring * width;
-    hi = lo + width;
-    if (hi > n) hi = n;
-    if (lo > hi || ring >= height) { lo = 0; hi = 0; }
-  }
-  const int first16 = lo >> 4;
-  const int n16 = (hi > lo) ? (((hi + 15) >> 4) - first16) : 0;     // 16-byte id chunks in range
-  const int per = (n16 + kExThreads - 1) / kExThreads;              // chunks per thread
-  const unsigned int pat = (unsigned int)ring * 0x01010101u;
-  // Chunk u = b * 512 + tid (coalesced: a wave reads 1 KiB of consecutive ids per load, all
-  // loads of a thread in flight together).  Match masks stay in registers for the write pass.
-  // The compaction order is the chunk order, i.e. the input order.
-  constexpr int kIdRegs = 16;
-  int nr = 0;
-  if (per <= kIdRegs) {
-    uint4 w[kIdRegs];
-#pragma unroll
-    for (int b = 0; b < kIdRegs; b++) {
-      const int u = b * kExThreads + tid;
-      w[b] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-      if (u < n16) w[b] = *reinterpret_cast<const uint4*>(ids + ((first16 + u) << 4));
-    }
-    unsigned int mreg[kIdRegs];
-    int incl[kIdRegs];
-#pragma unroll
-    for (int b = 0; b < kIdRegs; b++) {
-      const int u = b * kExThreads + tid;
-      mreg[b] = (u < n16) ? (match16(w[b], pat) & range16((first16 + u) << 4, lo, hi)) : 0u;
-      incl[b] = (b < per) ? wave_incl_scan_i32(__popc(mreg[b])) : 0;
-      if (lane == 63 && b < per) wtot[b * kExWaves + wave] = incl[b];
-    }
-    __syncthreads();
-    int run = 0;
-#pragma unroll
-    for (int b = 0; b < kIdRegs; b++) {
-      if (b < per) {
-        int pre = 0, tot = 0;
-#pragma unroll
-        for (int q = 0; q < kExWaves; q++) { const int t = wtot[b * kExWaves + q]; if (q < wave) pre += t; tot += t; }
-        int off = run + pre + incl[b] - __popc(mreg[b]);
-        unsigned int m = mreg[b];
-        const int base = (first16 + b * kExThreads + tid) << 4;
-        while (m) {
-          const int bit = __ffs(m) - 1;
-          m &= m - 1;
-          if (off < cap) src[off] = base + bit;
-          off++;
-        }
-        run += tot;
-      }
-    }
-    nr = run;
-  } else {
-    // very long id ranges (> 131072 ids per ring workgroup): contiguous span per thread, re-read
-    const int u0 = tid * per, u1 = (u0 + per < n16) ? (u0 + per) : n16;
-    int cnt = 0;
-    for (int u = u0; u < u1; u++) {
-      const int base = (first16 + u) << 4;
-      const uint4 w = *reinterpret_cast<const uint4*>(ids + base);
-      cnt += __popc(match16(w, pat) & range16(base, lo, hi));
-    }
-    const int incl = wave_incl_scan_i32(cnt);
-    if (lane == 63) wtot[wave] = incl;
-    __syncthreads();
-    int pre = 0;
-#pragma unroll
-    for (int q = 0; q < kExWaves; q++) { const int t = wtot[q]; if (q < wave) pre += t; nr += t; }
-    int off = pre + incl - cnt;
-    for (int u = u0; u < u1; u++) {
-      const int base = (first16 + u) << 4;
-      const uint4 w = *reinterpret_cast<const uint4*>(ids + base);
-      unsigned int m = match16(w, pat) & range16(base, lo, hi);
-      while (m) {
-        const int b = __ffs(m) - 1;
-        m &= m - 1;
-        if (off < cap) src[off] = base + b;
-        off++;
-      }
-    }
-  }
+  // ---- the ring's points are contiguous in the ring-sorted copy written by k_ring_scatter ----
+  const int rbeg = v.ring_start[(size_t)s * (H + 1) + ring];
+  const int nr = v.ring_start[(size_t)s * (H + 1) + ring + 1] - rbeg;
+  const float4* rpts = v.ring_pts + (size_t)s * v.max_points + rbeg;
+  const int* rsrc = v.ring_src + (size_t)s * v.max_points + rbeg;
   if (tid == 0) *npoints_out = nr;
   if (nr > cap) {   // ring does not fit the LDS tile: flagged, ring skipped
     if (tid == 0) { atomicOr(&v.state[s].status, LIODOM_STATUS_RING_OVERFLOW); *nedges_out = 0; }
@@ -418,11 +426,11 @@ __global__ __launch_bounds__(kExThreads) void k_ring_extract(DevView v, int s0, 
   }
   __syncthreads();
   DBG_STAMP(v, dbgb, 0, 2);
-  // ---- phase 1: gather the points ----
-  for (int k0 = tid; k0 < nr; k0 += 4 * kExThreads) {    // 4 gathers in flight per thread
+  // ---- phase 1: load the ring into the SoA LDS tile ----
+  for (int k0 = tid; k0 < nr; k0 += 4 * kExThreads) {    // 4 coalesced loads in flight per thread
     float4 p[4];
 #pragma unroll
-    for (int u = 0; u < 4; u++) { const int k = k0 + u * kExThreads; if (k < nr) p[u] = scan[src[k]]; }
+    for (int u = 0; u < 4; u++) { const int k = k0 + u * kExThreads; if (k < nr) p[u] = rpts[k]; }
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       const int k = k0 + u * kExThreads;
@@ -526,9 +534,8 @@ __global__ __launch_bounds__(kExThreads) void k_ring_extract(DevView v, int s0, 
     const int cntp = region_cnt[reg];
     for (int k = tid; k < cntp; k += kExThreads) {
       const int j = pick_idx[reg * ppr + k];
-      const int sidx = src[j];
-      eout[base + k] = make_float4(px[j], py[j], pz[j], scan[sidx].w);
-      mout[base + k] = make_int2(j, sidx);
+      eout[base + k] = rpts[j];                                    // :275 (XYZ + intensity unchanged)
+      mout[base + k] = make_int2(j, rsrc[j]);
     }
     base += cntp;
   }

@@ -22,15 +22,16 @@ def test_two_replicas_gloo(tmp_path):
         total = rep.sum_over_ranks(10 * (rep.rank + 1))
         assert mx == 2.0 and total == 30.0, (mx, total)
         # whole-job throughput = units of all ranks / max time
-        print("RANK", rep.rank, "OK", 2 * 100 / mx, flush=True)
+        open(%r + "/rank%%d.txt" %% rep.rank, "w").write("OK %%.1f" %% (2 * 100 / mx))
         rep.close()
-    """ % ROOT))
+    """ % (ROOT, str(tmp_path))))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                           "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
                          capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
-    assert "RANK 0 OK 100.0" in out.stdout and "RANK 1 OK 100.0" in out.stdout
+    # (stdout of the two ranks may interleave, so each rank reports through its own file)
+    assert (tmp_path / "rank0.txt").read_text() == "OK 100.0" and (tmp_path / "rank1.txt").read_text() == "OK 100.0"
 
 
 def test_single_process_is_a_noop():

@@ -91,9 +91,10 @@ def sec_timing(H=64, W=1800, lt=0, R=8, epr=10, P=20, K=60, S=1):
     po, g = mk(H, W, lt, R, epr, P, S=S, pose_log_capacity=4 * K)
     print("device:", g.device_info())
     g.alloc_resident(K)
+    data = [[synth.scan(cfg, d, k)[0] for k in range(K)] for d in range(min(S, 2))]
     for s in range(S):
         for k in range(K):
-            g.upload_scan(s, k, synth.scan(cfg, s, k)[0])
+            g.upload_scan(s, k, data[s % len(data)][k])
     for mode in ("sync", "async"):
         g.reset()
         for k in range(10):
@@ -196,7 +197,7 @@ def sec_clocks(H=64, W=1800, R=8, epr=10, P=20, K=40):
     g.L.liodom_debug_clocks.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
     g.L.liodom_debug_clocks(g.h, buf)
     a = np.array(list(buf), dtype=np.int64).reshape(4, 32)
-    names = {0: ["start", "ids loaded+matched", "compacted", "gathered", "stencil", "spec select", "carry replay", "emitted"],
+    names = {0: ["start", "", "ring loaded", "(unused)", "stencil", "spec select", "carry check", "emitted"],
              1: ["start", "query ready", "hash probed", "centre streamed", "merge1", "phase2 done", "nn fetched", "gate done"],
              2: ["start", "pose ready", "eval0", "begin", "eval1", "upd1", "eval2", "upd2", "eval3", "upd3", "eval4", "upd4", "", "", "", "", "", "", "", "", "loop end", "pose written", "finalized"]}
     for k, kn in ((0, "k_ring_extract (ring 40)"), (1, "k_knn (block 20, it 0)"), (2, "k_lm_solve (it 1)")):
