@@ -136,6 +136,12 @@ int liodom_upload_scan(liodom_handle_t* h, int stream, int slot, const float* xy
  * enqueues and poses are read later from the device-side log. */
 int liodom_process_resident(liodom_handle_t* h, int slot, int64_t n, int height, int width,
                             double* poses_out, liodom_step_info_t* infos_out);
+/* Same, and additionally issues the extraction of resident slot `next_slot` (if >= 0) on a second
+ * HIP stream so that it overlaps this scan's odometry — the reference's own two-thread pipeline
+ * (FeatureExtractor / LaserOdometer threads, src/liodom_node.cc:89-91).  The following call must
+ * then name that slot. */
+int liodom_process_resident_pipelined(liodom_handle_t* h, int slot, int next_slot, int64_t n, int height,
+                                      int width, double* poses_out, liodom_step_info_t* infos_out);
 int liodom_sync(liodom_handle_t* h);
 int liodom_get_pose_log(liodom_handle_t* h, int stream, int first, int count, double* poses_out,
                         liodom_step_info_t* infos_out);

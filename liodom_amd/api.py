@@ -109,6 +109,8 @@ def load():
     L.liodom_upload_scan.argtypes = [vp, C.c_int, C.c_int, fp, C.c_int64]
     L.liodom_process_resident.restype = C.c_int
     L.liodom_process_resident.argtypes = [vp, C.c_int, C.c_int64, C.c_int, C.c_int, dp, C.POINTER(StepInfo)]
+    L.liodom_process_resident_pipelined.restype = C.c_int
+    L.liodom_process_resident_pipelined.argtypes = [vp, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, dp, C.POINTER(StepInfo)]
     L.liodom_sync.restype = C.c_int
     L.liodom_sync.argtypes = [vp]
     L.liodom_get_pose_log.restype = C.c_int
@@ -138,7 +140,7 @@ def load():
 EXPORTED_SYMBOLS = [
     "liodom_params_default", "liodom_config_default", "liodom_create", "liodom_destroy", "liodom_last_error",
     "liodom_extract_edges", "liodom_odometry_step", "liodom_process_scan", "liodom_set_received_map",
-    "liodom_alloc_resident", "liodom_upload_scan", "liodom_process_resident", "liodom_sync", "liodom_get_pose_log",
+    "liodom_alloc_resident", "liodom_upload_scan", "liodom_process_resident", "liodom_process_resident_pipelined", "liodom_sync", "liodom_get_pose_log",
     "liodom_reset", "liodom_get_edges", "liodom_get_window", "liodom_get_correspondences", "liodom_get_curvature",
     "liodom_set_profiling", "liodom_get_kernel_stats", "liodom_reset_kernel_stats", "liodom_device_info",
 ]
@@ -251,14 +253,15 @@ class Liodom:
         x = np.ascontiguousarray(xyzi, dtype=np.float32).reshape(-1, 4)
         self._check(self.L.liodom_upload_scan(self.h, stream, slot, _fp(x), x.shape[0]))
 
-    def process_resident(self, slot, n, height, width, readback=True):
+    def process_resident(self, slot, n, height, width, readback=True, next_slot=-1):
+        """next_slot >= 0: also issue that slot's extraction on the second stream (pipelined replay)."""
         S = self.config.n_streams
         if readback:
             poses = np.zeros((S, 7))
             infos = (StepInfo * S)()
-            self._check(self.L.liodom_process_resident(self.h, slot, n, height, width, _dp(poses), infos))
+            self._check(self.L.liodom_process_resident_pipelined(self.h, slot, next_slot, n, height, width, _dp(poses), infos))
             return poses, infos
-        self._check(self.L.liodom_process_resident(self.h, slot, n, height, width, None, None))
+        self._check(self.L.liodom_process_resident_pipelined(self.h, slot, next_slot, n, height, width, None, None))
         return None, None
 
     def sync(self):

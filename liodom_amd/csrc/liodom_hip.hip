@@ -48,7 +48,14 @@ struct liodom_handle {
   liodom_config_t config;
   DevView v{};
   DevView* d_view = nullptr;         // device copy: kernels take a pointer (8-byte kernarg)
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;      // odometry (and every non-pipelined call)
+  hipStream_t stream_x = nullptr;    // extraction of the next scan in the pipelined replay
+  hipEvent_t ev_edges[2] = {nullptr, nullptr};   // edge buffer b written
+  hipEvent_t ev_free[2] = {nullptr, nullptr};    // odometry finished reading edge buffer b
+  bool ev_free_valid[2] = {false, false};
+  int parity = 0;                    // edge buffer of the next scan to enter odometry
+  int pf_slot = -1;                  // resident slot whose extraction has been issued ahead
+  int last_eb = 0;                   // edge buffer of the most recent scan (inspection)
   hipEvent_t pose_event = nullptr;
   int S = 1, H = 0, P = 0;
   size_t ring_lds_bytes = 0;
@@ -83,6 +90,7 @@ int dev_alloc(liodom_handle* h, T** p, size_t count, int memset_value = 0) {
 int drain_events(liodom_handle* h) {
   if (h->ev_used == 0) return LIODOM_OK;
   HIP_TRY(hipStreamSynchronize(h->stream));
+  if (h->stream_x) HIP_TRY(hipStreamSynchronize(h->stream_x));
   for (size_t i = 0; i < h->ev_used; i++) {
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, h->ev_pool[i].a, h->ev_pool[i].b));
@@ -96,7 +104,8 @@ int drain_events(liodom_handle* h) {
 struct ProfScope {
   liodom_handle* h;
   EventPair* ep = nullptr;
-  ProfScope(liodom_handle* hh, int kid) : h(hh) {
+  hipStream_t st;
+  ProfScope(liodom_handle* hh, int kid, hipStream_t stream = nullptr) : h(hh), st(stream ? stream : hh->stream) {
     if (!h->profiling) return;
     if (h->ev_used == h->ev_pool.size()) {
       if (h->ev_pool.size() < 4096) {
@@ -109,35 +118,34 @@ struct ProfScope {
     }
     ep = &h->ev_pool[h->ev_used++];
     ep->kid = kid;
-    hipEventRecord(ep->a, h->stream);
+    hipEventRecord(ep->a, st);
   }
-  ~ProfScope() { if (ep) hipEventRecord(ep->b, h->stream); }
+  ~ProfScope() { if (ep) hipEventRecord(ep->b, st); }
 };
 
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // ---- launch sequences -----------------------------------------------------------------------
 // Feature extraction of `count` streams starting at s0; input scan for stream s0+i at in + i*stride.
-int launch_extract(liodom_handle* h, int s0, int count, const float4* in, size_t in_stride, int n,
-                   int height, int width) {
+int launch_extract(liodom_handle* h, hipStream_t q, int eb, int s0, int count, const float4* in, size_t in_stride,
+                   int n, int height, int width) {
   const DevView& v = h->v;
   const int tiles = std::max(1, cdiv(n, kTilePts));
   {
-    ProfScope ps(h, KID_CLASSIFY);
-    hipLaunchKernelGGL(k_classify, dim3(tiles, count), dim3(kTileThreads), 0, h->stream, v, s0, in, in_stride, n, height, width);
+    ProfScope ps(h, KID_CLASSIFY, q);
+    hipLaunchKernelGGL(k_classify, dim3(tiles, count), dim3(kTileThreads), 0, q, v, s0, in, in_stride, n, height, width);
   }
   {
-    ProfScope ps(h, KID_RING_SCATTER);
-    hipLaunchKernelGGL(k_ring_scatter, dim3(tiles, count), dim3(kTileThreads), ring_scatter_lds_bytes(h->H), h->stream, v, s0, in, in_stride, n);
+    ProfScope ps(h, KID_RING_SCATTER, q);
+    hipLaunchKernelGGL(k_ring_scatter, dim3(tiles, count), dim3(kTileThreads), ring_scatter_lds_bytes(h->H), q, v, s0, in, in_stride, n);
   }
   {
-    ProfScope ps(h, KID_RING_EXTRACT);
-    dim3 grid(h->H, count);
-    hipLaunchKernelGGL(k_ring_extract, grid, dim3(kExThreads), h->ring_lds_bytes, h->stream, v, s0);
+    ProfScope ps(h, KID_RING_EXTRACT, q);
+    hipLaunchKernelGGL(k_ring_extract, dim3(h->H, count), dim3(kExThreads), h->ring_lds_bytes, q, v, s0);
   }
   {
-    ProfScope ps(h, KID_COMPACT);
-    hipLaunchKernelGGL(k_compact_edges, dim3(count), dim3(256), 0, h->stream, v, s0);
+    ProfScope ps(h, KID_COMPACT, q);
+    hipLaunchKernelGGL(k_compact_edges, dim3(count), dim3(256), 0, q, v, s0, eb);
   }
   HIP_TRY(hipGetLastError());
   return LIODOM_OK;
@@ -146,20 +154,20 @@ int launch_extract(liodom_handle* h, int s0, int count, const float4* in, size_t
 // Odometry on the dense edges already on the device.  If pose_dst != nullptr the poses + infos
 // of the streams are copied to pinned memory right after the solve and pose_event is recorded,
 // so the host can pick them up while the window / hash rebuild still runs.
-int launch_odometry(liodom_handle* h, int s0, int count, bool want_readback) {
+int launch_odometry(liodom_handle* h, int eb, int s0, int count) {
   const DevView& v = h->v;
-  const int knn_blocks = cdiv(h->v.edge_cap, 256 / kKnnGroup);
+  const int knn_blocks = cdiv(h->v.edge_cap, kKnnQueries);
   for (int it = 0; it < 2; it++) {
     {
       ProfScope ps(h, KID_KNN);
-      hipLaunchKernelGGL(k_knn, dim3(knn_blocks, count), dim3(256), 0, h->stream, v, s0, it);
+      hipLaunchKernelGGL(k_knn, dim3(knn_blocks, count), dim3(kKnnThreads), 0, h->stream, v, s0, it, eb);
     }
     {
       ProfScope ps(h, KID_LM);
-      hipLaunchKernelGGL(k_lm_solve, dim3(count), dim3(kLmThreads), 0, h->stream, v, s0, it);
+      hipLaunchKernelGGL(k_lm_solve, dim3(count), dim3(kLmThreads), 0, h->stream, v, s0, it, eb);
     }
   }
-  (void)want_readback;   // results are published by k_lm_solve into host-mapped memory (HostOut)
+  h->last_eb = eb;       // results are published by k_lm_solve into host-mapped memory (HostOut)
   for (int i = 0; i < count; i++) h->scans_enqueued[s0 + i]++;
   const int map_blocks = cdiv(h->v.map_cap, 256);
   {
@@ -168,7 +176,7 @@ int launch_odometry(liodom_handle* h, int s0, int count, bool want_readback) {
   }
   {
     ProfScope ps(h, KID_WINDOW_INSERT);
-    hipLaunchKernelGGL(k_window_insert, dim3(map_blocks, count), dim3(256), 0, h->stream, v, s0);
+    hipLaunchKernelGGL(k_window_insert, dim3(map_blocks, count), dim3(256), 0, h->stream, v, s0, eb);
   }
   {
     ProfScope ps(h, KID_HASH_ALLOC);
@@ -190,6 +198,27 @@ int check_stream(liodom_handle* h, int stream) {
 
 int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
+// The plain (non-pipelined) entry points run everything on h->stream with edge buffer 0; make
+// sure no extraction issued ahead by the pipelined replay is still in flight.
+int drain_pipeline(liodom_handle* h) {
+  if (h->pf_slot >= 0 || h->parity != 0) {
+    HIP_TRY(hipStreamSynchronize(h->stream_x));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->pf_slot = -1; h->parity = 0; h->ev_free_valid[0] = h->ev_free_valid[1] = false;
+  }
+  return LIODOM_OK;
+}
+
+// Extraction of resident slot `slot` into edge buffer `eb` on the extraction stream.
+int issue_extract(liodom_handle* h, int slot, int eb, int n, int height, int width) {
+  if (h->ev_free_valid[eb]) HIP_TRY(hipStreamWaitEvent(h->stream_x, h->ev_free[eb], 0));
+  const float4* in = h->resident + (size_t)slot * h->S * (size_t)h->v.max_points;
+  int rc = launch_extract(h, h->stream_x, eb, 0, h->S, in, (size_t)h->v.max_points, n, height, width);
+  if (rc) return rc;
+  HIP_TRY(hipEventRecord(h->ev_edges[eb], h->stream_x));
+  return LIODOM_OK;
+}
+
 int reset_state(liodom_handle* h) {
   std::vector<StreamState> init((size_t)h->S);
   for (auto& st : init) {
@@ -203,6 +232,8 @@ int reset_state(liodom_handle* h) {
     hipLaunchKernelGGL(k_init_cells, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, h->v);
     HIP_TRY(hipGetLastError());
   }
+  if (h->stream_x) HIP_TRY(hipStreamSynchronize(h->stream_x));
+  h->pf_slot = -1; h->parity = 0; h->last_eb = 0; h->ev_free_valid[0] = h->ev_free_valid[1] = false;
   std::memset(h->host_out, 0, sizeof(HostOut) * (size_t)h->S);
   std::fill(h->scans_enqueued.begin(), h->scans_enqueued.end(), 0);
   HIP_TRY(hipMemsetAsync(h->v.win_n, 0, sizeof(int) * (size_t)h->S * h->P, h->stream));
@@ -271,6 +302,11 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   auto fail = [&](int code) { liodom_destroy(h); return code; };
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { g_last_error = "hipStreamCreate failed"; return fail(LIODOM_ERR_HIP); }
   if (hipEventCreateWithFlags(&h->pose_event, hipEventDisableTiming) != hipSuccess) { g_last_error = "hipEventCreate failed"; return fail(LIODOM_ERR_HIP); }
+  if (hipStreamCreateWithFlags(&h->stream_x, hipStreamNonBlocking) != hipSuccess) { g_last_error = "hipStreamCreate failed"; return fail(LIODOM_ERR_HIP); }
+  for (int b = 0; b < 2; b++) {
+    if (hipEventCreateWithFlags(&h->ev_edges[b], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_free[b], hipEventDisableTiming) != hipSuccess) { g_last_error = "hipEventCreate failed"; return fail(LIODOM_ERR_HIP); }
+  }
 
   DevView& v = h->v;
   v.min_range = params->min_range; v.max_range = params->max_range;
@@ -313,8 +349,8 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   ALLOC(v.ring_nedges, S * h->H, 0);
   ALLOC(v.ring_npoints, S * h->H, 0);
   if (v.debug) ALLOC(v.curv_dbg, S * h->H * v.ring_cap, 0); else v.curv_dbg = nullptr;
-  ALLOC(v.edges, S * v.edge_cap, 0);
-  ALLOC(v.edges_meta, S * v.edge_cap, 0);
+  ALLOC(v.edges, 2 * S * v.edge_cap, 0);
+  ALLOC(v.edges_meta, 2 * S * v.edge_cap, 0);
   ALLOC(v.corr_a, S * v.edge_cap, 0);
   ALLOC(v.corr_b, S * v.edge_cap, 0);
   ALLOC(v.corr_idx, S * 2 * v.edge_cap, 0xFF);
@@ -324,6 +360,7 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   ALLOC(v.win_slot, S * h->P, 0);
   ALLOC(v.cells, S * v.table_size, 0);
   ALLOC(v.cell_fill, S * v.table_size, 0);
+  ALLOC(v.cell_bits, S * (size_t)(v.table_size / 32), 0);
   ALLOC(v.used_cells, S * v.map_cap, 0);
   ALLOC(v.pt_cell, S * v.map_cap, 0xFF);
   ALLOC(v.sorted_pts, S * v.map_cap, 0);
@@ -364,12 +401,15 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
 
 void liodom_destroy(liodom_handle_t* h) {
   if (!h) return;
+  if (h->stream_x) hipStreamSynchronize(h->stream_x);
   if (h->stream) hipStreamSynchronize(h->stream);
   for (void* p : h->allocs) hipFree(p);
   if (h->resident) hipFree(h->resident);
   if (h->host_out) hipHostFree(h->host_out);
   for (auto& e : h->ev_pool) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
   if (h->pose_event) hipEventDestroy(h->pose_event);
+  for (int b = 0; b < 2; b++) { if (h->ev_edges[b]) hipEventDestroy(h->ev_edges[b]); if (h->ev_free[b]) hipEventDestroy(h->ev_free[b]); }
+  if (h->stream_x) hipStreamDestroy(h->stream_x);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
 }
@@ -384,16 +424,17 @@ static int copy_edges_out(liodom_handle_t* h, int stream, float* edges_xyzi, int
   StreamState st;
   HIP_TRY(hipMemcpyAsync(&st, h->v.state + stream, sizeof(st), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
-  const int E = st.n_edges;
+  const int eb = h->last_eb;
+  const int E = st.n_edges_buf[eb];
   if (n_edges) *n_edges = E;
   if (E > cap) { g_last_error = "edge buffer too small"; return LIODOM_ERR_CAPACITY; }
   if (E == 0) return LIODOM_OK;
   if (edges_xyzi)
-    HIP_TRY(hipMemcpyAsync(edges_xyzi, h->v.edges + (size_t)stream * h->v.edge_cap, sizeof(float4) * (size_t)E, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(edges_xyzi, h->v.edges + ((size_t)eb * h->S + stream) * h->v.edge_cap, sizeof(float4) * (size_t)E, hipMemcpyDeviceToHost, h->stream));
   std::vector<int4> meta;
   if (edge_ring || edge_idx || edge_src) {
     meta.resize((size_t)E);
-    HIP_TRY(hipMemcpyAsync(meta.data(), h->v.edges_meta + (size_t)stream * h->v.edge_cap, sizeof(int4) * (size_t)E, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(meta.data(), h->v.edges_meta + ((size_t)eb * h->S + stream) * h->v.edge_cap, sizeof(int4) * (size_t)E, hipMemcpyDeviceToHost, h->stream));
   }
   HIP_TRY(hipStreamSynchronize(h->stream));
   for (int i = 0; i < E && !meta.empty(); i++) {
@@ -412,8 +453,11 @@ int liodom_extract_edges(liodom_handle_t* h, int stream, const float* xyzi, int6
   if (n < 0 || n > h->v.max_points || (n > 0 && !xyzi)) { g_last_error = "bad point count"; return LIODOM_ERR_CAPACITY; }
   float4* in = h->stage_in + (size_t)stream * h->v.max_points;
   if (n) HIP_TRY(hipMemcpyAsync(in, xyzi, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, h->stream));
-  rc = launch_extract(h, stream, 1, in, 0, (int)n, height, width);
+  rc = drain_pipeline(h);
   if (rc) return rc;
+  rc = launch_extract(h, h->stream, 0, stream, 1, in, 0, (int)n, height, width);
+  if (rc) return rc;
+  h->last_eb = 0;
   return copy_edges_out(h, stream, edges_xyzi, edge_ring, edge_idx, edge_src, cap, n_edges);
 }
 
@@ -451,13 +495,15 @@ int liodom_odometry_step(liodom_handle_t* h, int stream, const float* edges_xyzi
   int rc = check_stream(h, stream);
   if (rc) return rc;
   if (n_edges < 0 || n_edges > h->v.edge_cap || (n_edges > 0 && !edges_xyzi)) { g_last_error = "edge count exceeds capacity"; return LIODOM_ERR_CAPACITY; }
+  rc = drain_pipeline(h);
+  if (rc) return rc;
   if (n_edges)
     HIP_TRY(hipMemcpyAsync(h->v.edges + (size_t)stream * h->v.edge_cap, edges_xyzi, sizeof(float4) * (size_t)n_edges, hipMemcpyHostToDevice, h->stream));
   {
     ProfScope ps(h, KID_OTHER);
-    hipLaunchKernelGGL(k_set_edges, dim3(1), dim3(64), 0, h->stream, h->v, stream, n_edges);
+    hipLaunchKernelGGL(k_set_edges, dim3(1), dim3(64), 0, h->stream, h->v, stream, n_edges, 0);
   }
-  rc = launch_odometry(h, stream, 1, true);
+  rc = launch_odometry(h, 0, stream, 1);
   if (rc) return rc;
   return wait_pose(h, stream, 1, pose_out, info);
 }
@@ -470,9 +516,11 @@ int liodom_process_scan(liodom_handle_t* h, int stream, const float* xyzi, int64
   if (n < 0 || n > h->v.max_points || (n > 0 && !xyzi)) { g_last_error = "bad point count"; return LIODOM_ERR_CAPACITY; }
   float4* in = h->stage_in + (size_t)stream * h->v.max_points;
   if (n) HIP_TRY(hipMemcpyAsync(in, xyzi, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, h->stream));
-  rc = launch_extract(h, stream, 1, in, 0, (int)n, height, width);
+  rc = drain_pipeline(h);
   if (rc) return rc;
-  rc = launch_odometry(h, stream, 1, true);
+  rc = launch_extract(h, h->stream, 0, stream, 1, in, 0, (int)n, height, width);
+  if (rc) return rc;
+  rc = launch_odometry(h, 0, stream, 1);
   if (rc) return rc;
   return wait_pose(h, stream, 1, pose_out, info);
 }
@@ -508,22 +556,41 @@ int liodom_upload_scan(liodom_handle_t* h, int stream, int slot, const float* xy
 
 int liodom_process_resident(liodom_handle_t* h, int slot, int64_t n, int height, int width,
                             double* poses_out, liodom_step_info_t* infos_out) {
+  return liodom_process_resident_pipelined(h, slot, -1, n, height, width, poses_out, infos_out);
+}
+
+int liodom_process_resident_pipelined(liodom_handle_t* h, int slot, int next_slot, int64_t n, int height,
+                                      int width, double* poses_out, liodom_step_info_t* infos_out) {
   if (!h) return LIODOM_ERR_INVALID_ARG;
-  if (!h->resident || slot < 0 || slot >= h->n_slots || n < 0 || n > h->v.max_points) { g_last_error = "bad resident slot"; return LIODOM_ERR_INVALID_ARG; }
-  // resident layout: [slot][stream][max_points] so that one lock-step launch reads a contiguous
-  // block with stride max_points between streams
-  const float4* in = h->resident + (size_t)slot * h->S * (size_t)h->v.max_points;
-  int rc = launch_extract(h, 0, h->S, in, (size_t)h->v.max_points, (int)n, height, width);
+  if (!h->resident || slot < 0 || slot >= h->n_slots || next_slot >= h->n_slots || n < 0 || n > h->v.max_points) {
+    g_last_error = "bad resident slot"; return LIODOM_ERR_INVALID_ARG;
+  }
+  // resident layout: [slot][stream][max_points]: one lock-step launch reads a contiguous block
+  const int eb = h->parity;
+  int rc;
+  if (h->pf_slot != slot) {                       // extraction not issued ahead: do it now
+    rc = issue_extract(h, slot, eb, (int)n, height, width);
+    if (rc) return rc;
+  }
+  h->pf_slot = -1;
+  HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_edges[eb], 0));
+  rc = launch_odometry(h, eb, 0, h->S);
   if (rc) return rc;
-  const bool rb = poses_out != nullptr || infos_out != nullptr;
-  rc = launch_odometry(h, 0, h->S, rb);
-  if (rc) return rc;
-  if (rb) return wait_pose(h, 0, h->S, poses_out, infos_out);
+  HIP_TRY(hipEventRecord(h->ev_free[eb], h->stream));
+  h->ev_free_valid[eb] = true;
+  h->parity = eb ^ 1;
+  if (next_slot >= 0) {                           // overlap the next scan's extraction with this odometry
+    rc = issue_extract(h, next_slot, h->parity, (int)n, height, width);
+    if (rc) return rc;
+    h->pf_slot = next_slot;
+  }
+  if (poses_out != nullptr || infos_out != nullptr) return wait_pose(h, 0, h->S, poses_out, infos_out);
   return LIODOM_OK;
 }
 
 int liodom_sync(liodom_handle_t* h) {
   if (!h) return LIODOM_ERR_INVALID_ARG;
+  HIP_TRY(hipStreamSynchronize(h->stream_x));
   HIP_TRY(hipStreamSynchronize(h->stream));
   return LIODOM_OK;
 }
@@ -571,7 +638,7 @@ int liodom_get_correspondences(liodom_handle_t* h, int stream, int it, int32_t* 
   HIP_TRY(hipStreamSynchronize(h->stream));
   StreamState st;
   HIP_TRY(hipMemcpy(&st, h->v.state + stream, sizeof(st), hipMemcpyDeviceToHost));
-  const int E = st.n_edges;
+  const int E = st.n_edges_buf[h->last_eb];
   if (n) *n = E;
   if (E > cap) { g_last_error = "correspondence buffer too small"; return LIODOM_ERR_CAPACITY; }
   std::vector<int2> ci((size_t)std::max(E, 1));

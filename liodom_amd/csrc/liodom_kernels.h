@@ -43,7 +43,7 @@ struct StreamState {
   int32_t append_raw;     // first frame: edges enter the window untransformed (:123)
   int32_t frame_count;    // frames ever appended
   int32_t n_frames;       // frames in the window (nframes_)
-  int32_t n_edges;        // edges of the current scan
+  int32_t n_edges_buf[2]; // edges of the scan in edge buffer 0 / 1 (extraction of scan k+1 overlaps odometry of scan k)
   int32_t n_map;          // window points covered by the voxel hash
   int32_t n_used;         // occupied hash cells (current build)
   int32_t n_used_prev;    // occupied cells of the previous build (to clear)
@@ -95,8 +95,8 @@ struct DevView {
   int* ring_nedges;         // [S][H]
   int* ring_npoints;        // [S][H]
   double* curv_dbg;         // [S][H][ring_cap] or null
-  float4* edges;            // [S][edge_cap] dense
-  int4* edges_meta;         // (ring, idx_in_ring, src, 0)
+  float4* edges;            // [2][S][edge_cap] dense, double-buffered
+  int4* edges_meta;         // [2][S][edge_cap] (ring, idx_in_ring, src, 0)
   float4* corr_a;           // [S][edge_cap]  xyz of NN0, w = valid
   float4* corr_b;           // [S][edge_cap]  xyz of NN1
   int2* corr_idx;           // [S][2][edge_cap] window indices of (NN0, NN1), debug/parity
@@ -106,6 +106,7 @@ struct DevView {
   int* win_slot;            // [S][P]  logical frame -> slot
   CellSlot* cells;          // [S][table_size]  {key, start, cnt}: one 16-B load per probe
   unsigned int* cell_fill;  // [S][table_size]  scatter cursor per cell
+  unsigned int* cell_bits;  // [S][table_size/32] occupancy bitmap: empty-cell probes stay in a 32 KB array
   int* used_cells;          // [S][map_cap]
   int* pt_cell;             // [S][map_cap]
   float4* sorted_pts;       // [S][map_cap]  xyz + window index bits
@@ -544,10 +545,10 @@ __global__ __launch_bounds__(kExThreads) void k_ring_extract(DevView v, int s0) 
 }
 
 // =============================================================================================
-// k_compact_edges: one workgroup per stream; ring-padded edges -> dense edge cloud in the
-// reference's output order; resets the per-scan diagnostics.
+// k_compact_edges: one workgroup per stream; ring-padded edges -> dense edge cloud (edge buffer
+// `eb`) in the reference's output order.
 // =============================================================================================
-__global__ __launch_bounds__(256) void k_compact_edges(DevView v, int s0) {
+__global__ __launch_bounds__(256) void k_compact_edges(DevView v, int s0, int eb) {
   __shared__ int pre[257];
   __shared__ int cntr[256];
   const int s = s0 + blockIdx.x;
@@ -569,42 +570,28 @@ __global__ __launch_bounds__(256) void k_compact_edges(DevView v, int s0) {
   __syncthreads();
   if (threadIdx.x == 0) {
     const int acc = pre[256];
-    StreamState& st = v.state[s];
-    st.n_edges = acc > v.edge_cap ? v.edge_cap : acc;
-    st.info.n_edges = st.n_edges;
-    st.info.matches[0] = 0; st.info.matches[1] = 0;
-    st.info.map_points = st.n_map;
-    for (int k = 0; k < 2; k++) {
-      st.info.lm[k].iterations = 0; st.info.lm[k].accepted = 0; st.info.lm[k].termination = LM_TERM_NO_RESIDUALS;
-      st.info.lm[k].pad = 0; st.info.lm[k].initial_cost = 0.0; st.info.lm[k].final_cost = 0.0;
-    }
+    v.state[s].n_edges_buf[eb] = acc > v.edge_cap ? v.edge_cap : acc;
   }
-  __syncthreads();
   const int E = pre[H] > v.edge_cap ? v.edge_cap : pre[H];
   for (int e = threadIdx.x; e < E; e += 256) {
     int lo = 0, hi = H;            // largest r with pre[r] <= e
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pre[mid] <= e) lo = mid; else hi = mid; }
     const int r = lo, k = e - pre[r];
     const size_t pi = ((size_t)s * H + r) * v.slots_per_ring + k;
-    v.edges[(size_t)s * v.edge_cap + e] = v.edges_pad[pi];
+    const size_t eo = ((size_t)eb * v.n_streams + s) * v.edge_cap + e;
+    v.edges[eo] = v.edges_pad[pi];
     const int2 m = v.edges_pad_meta[pi];
-    v.edges_meta[(size_t)s * v.edge_cap + e] = make_int4(r, m.x, m.y, 0);
+    v.edges_meta[eo] = make_int4(r, m.x, m.y, 0);
   }
 }
 
 // For liodom_odometry_step (edges supplied by the caller): set counts and reset diagnostics.
-__global__ void k_set_edges(DevView v, int s0, int n_edges) {
+__global__ void k_set_edges(DevView v, int s0, int n_edges, int eb) {
   const int s = s0 + blockIdx.x;
   if (threadIdx.x == 0) {
     StreamState& st = v.state[s];
-    st.n_edges = n_edges;
-    st.info.n_edges = n_edges;
+    st.n_edges_buf[eb] = n_edges;
     st.info.matches[0] = 0; st.info.matches[1] = 0;
-    st.info.map_points = st.n_map;
-    for (int k = 0; k < 2; k++) {
-      st.info.lm[k].iterations = 0; st.info.lm[k].accepted = 0; st.info.lm[k].termination = LM_TERM_NO_RESIDUALS;
-      st.info.lm[k].pad = 0; st.info.lm[k].initial_cost = 0.0; st.info.lm[k].final_cost = 0.0;
-    }
   }
 }
 
@@ -700,107 +687,122 @@ __device__ __forceinline__ void top5_clear(Top5& t) {
   t.p0 = t.p1 = t.p2 = t.p3 = t.p4 = -1;
 }
 
-__global__ __launch_bounds__(256) void k_knn(DevView v, int s0, int outer_it) {
-  __shared__ int s_incl[256 / kKnnGroup][kKnnGroup];   // inclusive candidate prefix per cell
-  __shared__ int s_adj[256 / kKnnGroup][kKnnGroup];    // cell start - exclusive prefix
+constexpr int kKnnThreads = 1024;
+constexpr int kKnnQueries = kKnnThreads / kKnnGroup;   // 32 queries per workgroup
+
+__global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int outer_it, int eb) {
+  __shared__ int s_incl[kKnnQueries][kKnnGroup];   // inclusive candidate prefix per cell
+  __shared__ int s_adj[kKnnQueries][kKnnGroup];    // cell start - exclusive prefix
+  __shared__ float s_nn[kKnnQueries][16];          // the five neighbours of every query (xyz)
+  __shared__ int s_res[kKnnQueries][4];            // distance gate passed, window index of NN0, NN1
   const int s = s0 + blockIdx.y;
   StreamState& st = v.state[s];
-  if (!st.initialized) return;
-  const int E = st.n_edges;
+  if (!st.initialized) return;                     // uniform over the workgroup
+  const int E = st.n_edges_buf[eb];
+  if ((int)(blockIdx.x * kKnnQueries) >= E) return;
   const int grp = threadIdx.x / kKnnGroup;
-  const int e = blockIdx.x * (256 / kKnnGroup) + grp;
-  if (e >= E) return;
+  const int e = blockIdx.x * kKnnQueries + grp;
   const int hl = threadIdx.x & (kKnnGroup - 1);
   const int half_shift = (threadIdx.x & 32);     // 0 or 32: which half of the wave
-  const bool dbgb = (blockIdx.x == 20) && (s == 0) && (threadIdx.x == 0) && (outer_it == 0);
+  const bool dbgb = (blockIdx.x == 5) && (s == 0) && (threadIdx.x == 0) && (outer_it == 0);
   DBG_STAMP(v, dbgb, 1, 0);
-  const float4 p = v.edges[(size_t)s * v.edge_cap + e];
-  float qx, qy, qz;
-  {
+  bool active = e < E;
+  float qx = 0.f, qy = 0.f, qz = 0.f;
+  if (active) {
+    const float4 p = v.edges[((size_t)eb * v.n_streams + s) * v.edge_cap + e];
     double T[12];
 #pragma unroll
     for (int i = 0; i < 12; i++) T[i] = st.odom[i];
     transform_point(T, p.x, p.y, p.z, &qx, &qy, &qz);          // :307-308
-  }
-  float4* ca = v.corr_a + (size_t)s * v.edge_cap + e;
-  float4* cb = v.corr_b + (size_t)s * v.edge_cap + e;
-  int2* cidx = v.corr_idx + ((size_t)s * 2 + outer_it) * v.edge_cap + e;
-  const bool qfinite = ld_isfinite((double)qx) && ld_isfinite((double)qy) && ld_isfinite((double)qz) &&
-                       fabsf(qx) < 1.0e9f && fabsf(qy) < 1.0e9f && fabsf(qz) < 1.0e9f;
-  if (!qfinite) {
-    if (hl == 0) { *ca = make_float4(0, 0, 0, 0); *cb = make_float4(0, 0, 0, 0); *cidx = make_int2(-1, -1); }
-    return;
+    active = ld_isfinite((double)qx) && ld_isfinite((double)qy) && ld_isfinite((double)qz) &&
+             fabsf(qx) < 1.0e9f && fabsf(qy) < 1.0e9f && fabsf(qz) < 1.0e9f;
   }
   DBG_STAMP(v, dbgb, 1, 1);
-  const int cx = (int)floorf(qx), cy = (int)floorf(qy), cz = (int)floorf(qz);
-  const unsigned int tmask = (unsigned int)v.table_size - 1u;
-  const CellSlot* cells = v.cells + (size_t)s * v.table_size;
-  unsigned int start = 0, cnt = 0;
-  double lb = 0.0;     // lower bound of the float squared distance from q to any point of the cell
-  if (hl < 27) {
-    const int dx = hl % 3 - 1, dy = (hl / 3) % 3 - 1, dz = hl / 9 - 1;
-    const unsigned long long key = pack_cell(cx + dx, cy + dy, cz + dz);
-    unsigned int h = hash_cell(key, tmask);
-    for (int probe = 0; probe < v.table_size; probe++) {
-      const uint4 raw = *reinterpret_cast<const uint4*>(cells + h);
-      const unsigned long long k = ((unsigned long long)raw.y << 32) | raw.x;
-      if (k == key) { start = raw.z; cnt = raw.w; break; }
-      if (k == kEmptyKey) break;
-      h = (h + 1) & tmask;
+  if (hl == 0) { s_res[grp][0] = 0; s_res[grp][1] = -1; s_res[grp][2] = -1; }
+  if (active) {                                    // uniform over each 32-lane half
+    const int cx = (int)floorf(qx), cy = (int)floorf(qy), cz = (int)floorf(qz);
+    const unsigned int tmask = (unsigned int)v.table_size - 1u;
+    const CellSlot* cells = v.cells + (size_t)s * v.table_size;
+    const unsigned int* bits = v.cell_bits + (size_t)s * (v.table_size >> 5);
+    unsigned int start = 0, cnt = 0;
+    double lb = 0.0;     // lower bound of the float squared distance from q to any point of the cell
+    if (hl < 27) {
+      const int dx = hl % 3 - 1, dy = (hl / 3) % 3 - 1, dz = hl / 9 - 1;
+      const unsigned long long key = pack_cell(cx + dx, cy + dy, cz + dz);
+      unsigned int h = hash_cell(key, tmask);
+      for (int probe = 0; probe < v.table_size; probe++) {
+        if (!((bits[h >> 5] >> (h & 31)) & 1u)) break;           // empty slot: cell not in the map
+        const uint4 raw = *reinterpret_cast<const uint4*>(cells + h);
+        const unsigned long long k = ((unsigned long long)raw.y << 32) | raw.x;
+        if (k == key) { start = raw.z; cnt = raw.w; break; }
+        h = (h + 1) & tmask;
+      }
+      // box distance (FP64) to the cell [c, c+1)^3, shrunk by 1e-5 so that float rounding of the
+      // candidate distances can never make a pruned point look closer than the bound
+      const double lx = (double)(cx + dx), ly = (double)(cy + dy), lz = (double)(cz + dz);
+      const double ex = (double)qx < lx ? lx - (double)qx : ((double)qx > lx + 1.0 ? (double)qx - (lx + 1.0) : 0.0);
+      const double ey = (double)qy < ly ? ly - (double)qy : ((double)qy > ly + 1.0 ? (double)qy - (ly + 1.0) : 0.0);
+      const double ez = (double)qz < lz ? lz - (double)qz : ((double)qz > lz + 1.0 ? (double)qz - (lz + 1.0) : 0.0);
+      lb = (ex * ex + ey * ey + ez * ez) * (1.0 - 1e-5);
     }
-    // box distance (FP64) to the cell [c, c+1)^3, shrunk by 1e-5 so that float rounding of the
-    // candidate distances can never make a pruned point look closer than the bound
-    const double lx = (double)(cx + dx), ly = (double)(cy + dy), lz = (double)(cz + dz);
-    const double ex = (double)qx < lx ? lx - (double)qx : ((double)qx > lx + 1.0 ? (double)qx - (lx + 1.0) : 0.0);
-    const double ey = (double)qy < ly ? ly - (double)qy : ((double)qy > ly + 1.0 ? (double)qy - (ly + 1.0) : 0.0);
-    const double ez = (double)qz < lz ? lz - (double)qz : ((double)qz > lz + 1.0 ? (double)qz - (lz + 1.0) : 0.0);
-    lb = (ex * ex + ey * ey + ez * ez) * (1.0 - 1e-5);
-  }
-  DBG_STAMP(v, dbgb, 1, 2);
-  if (v.debug & 4) cnt = 0;
-  const float4* sp = v.sorted_pts + (size_t)s * v.map_cap;
-  Top5 t, g;
-  top5_clear(t);
-  // phase 1: the query's own cell (lane 13 = offset (0,0,0))
-  knn_stream_cells(t, sp, s_incl[grp], s_adj[grp], start, (hl == 13) ? cnt : 0u, hl, qx, qy, qz);
-  DBG_STAMP(v, dbgb, 1, 3);
-  knn_merge(t, g, hl, half_shift);
-  DBG_STAMP(v, dbgb, 1, 4);
-  // phase 2: neighbour cells that can still hold a point closer than the current 5th best (or
-  // than the 1.0 gate: points at >= 1.0 can never be part of an accepted match, :324)
-  const float bound_f = g.d4 < 1.0f ? g.d4 : 1.0f;
-  const bool keep = (hl < 27) && (hl != 13) && (cnt > 0) && !(lb > (double)bound_f);
-  if ((__ballot(keep) >> half_shift) & 0xFFFFFFFFull) {
+    DBG_STAMP(v, dbgb, 1, 2);
+    if (v.debug & 4) cnt = 0;
+    const float4* sp = v.sorted_pts + (size_t)s * v.map_cap;
+    Top5 t, g;
     top5_clear(t);
-    if (hl == 0) t = g;       // carry the phase-1 result in one lane's list
-    knn_stream_cells(t, sp, s_incl[grp], s_adj[grp], start, keep ? cnt : 0u, hl, qx, qy, qz);
+    // phase 1: the query's own cell (lane 13 = offset (0,0,0))
+    knn_stream_cells(t, sp, s_incl[grp], s_adj[grp], start, (hl == 13) ? cnt : 0u, hl, qx, qy, qz);
+    DBG_STAMP(v, dbgb, 1, 3);
     knn_merge(t, g, hl, half_shift);
-  }
-  DBG_STAMP(v, dbgb, 1, 5);
-  bool valid = (g.d4 < 1.0f);                                    // :324 (inf when < 5 candidates)
-  const int mypos = hl == 0 ? g.p0 : hl == 1 ? g.p1 : hl == 2 ? g.p2 : hl == 3 ? g.p3 : g.p4;
-  float4 mine = make_float4(0, 0, 0, 0);
-  if (valid && hl < 5) mine = sp[mypos];
-  float nx[5], ny[5], nz[5];
-#pragma unroll
-  for (int j = 0; j < 5; j++) {
-    nx[j] = __shfl(mine.x, j, kKnnGroup);
-    ny[j] = __shfl(mine.y, j, kKnnGroup);
-    nz[j] = __shfl(mine.z, j, kKnnGroup);
-  }
-  DBG_STAMP(v, dbgb, 1, 6);
-  if (valid && !(v.debug & 2)) valid = line_gate(nx, ny, nz);    // :325-344 (debug bit 1: ablation)
-  DBG_STAMP(v, dbgb, 1, 7);
-  if (hl == 0) {
-    if (valid) {
-      *ca = make_float4(nx[0], ny[0], nz[0], 1.0f);              // :351-353
-      *cb = make_float4(nx[1], ny[1], nz[1], 0.0f);              // :355-357
-      *cidx = make_int2(g.i0, g.i1);
-      atomicAdd(&st.info.matches[outer_it], 1);                  // :346
-    } else {
-      *ca = make_float4(0, 0, 0, 0); *cb = make_float4(0, 0, 0, 0); *cidx = make_int2(-1, -1);
+    DBG_STAMP(v, dbgb, 1, 4);
+    // phase 2: neighbour cells that can still hold a point closer than the current 5th best (or
+    // than the 1.0 gate: points at >= 1.0 can never be part of an accepted match, :324)
+    const float bound_f = g.d4 < 1.0f ? g.d4 : 1.0f;
+    const bool keep = (hl < 27) && (hl != 13) && (cnt > 0) && !(lb > (double)bound_f);
+    if ((__ballot(keep) >> half_shift) & 0xFFFFFFFFull) {
+      top5_clear(t);
+      if (hl == 0) t = g;       // carry the phase-1 result in one lane's list
+      knn_stream_cells(t, sp, s_incl[grp], s_adj[grp], start, keep ? cnt : 0u, hl, qx, qy, qz);
+      knn_merge(t, g, hl, half_shift);
+    }
+    DBG_STAMP(v, dbgb, 1, 5);
+    if (g.d4 < 1.0f) {                                           // :324 (inf when < 5 candidates)
+      const int mypos = hl == 0 ? g.p0 : hl == 1 ? g.p1 : hl == 2 ? g.p2 : hl == 3 ? g.p3 : g.p4;
+      if (hl < 5) {
+        const float4 m = sp[mypos];
+        s_nn[grp][hl * 3 + 0] = m.x; s_nn[grp][hl * 3 + 1] = m.y; s_nn[grp][hl * 3 + 2] = m.z;
+      }
+      if (hl == 0) { s_res[grp][0] = 1; s_res[grp][1] = g.i0; s_res[grp][2] = g.i1; }
     }
   }
+  __syncthreads();
+  DBG_STAMP(v, dbgb, 1, 6);
+  // Line gate (:325-344): one lane per query, so the FP64 eigenvalue iteration runs once per 32
+  // queries instead of once per query.
+  if (threadIdx.x < kKnnQueries) {
+    const int q = threadIdx.x;
+    const int eq = blockIdx.x * kKnnQueries + q;
+    bool valid = (eq < E) && (s_res[q][0] != 0);
+    float nx[5], ny[5], nz[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) { nx[j] = s_nn[q][j * 3]; ny[j] = s_nn[q][j * 3 + 1]; nz[j] = s_nn[q][j * 3 + 2]; }
+    if (valid && !(v.debug & 2)) valid = line_gate(nx, ny, nz);
+    if (eq < E) {
+      float4* ca = v.corr_a + (size_t)s * v.edge_cap + eq;
+      float4* cb = v.corr_b + (size_t)s * v.edge_cap + eq;
+      int2* cidx = v.corr_idx + ((size_t)s * 2 + outer_it) * v.edge_cap + eq;
+      if (valid) {
+        *ca = make_float4(nx[0], ny[0], nz[0], 1.0f);              // :351-353
+        *cb = make_float4(nx[1], ny[1], nz[1], 0.0f);              // :355-357
+        *cidx = make_int2(s_res[q][1], s_res[q][2]);
+      } else {
+        *ca = make_float4(0, 0, 0, 0); *cb = make_float4(0, 0, 0, 0); *cidx = make_int2(-1, -1);
+      }
+    }
+    const int nvalid = __popcll(__ballot(valid));
+    if (q == 0 && nvalid) atomicAdd(&st.info.matches[outer_it], nvalid);   // :346
+  }
+  DBG_STAMP(v, dbgb, 1, 7);
 }
 
 // =============================================================================================
@@ -812,7 +814,7 @@ __global__ __launch_bounds__(256) void k_knn(DevView v, int s0, int outer_it) {
 //   finalize (second outer iteration, or the very first frame): pose log, constant-velocity
 //   prediction for the next scan, window bookkeeping, hash-generation counters.
 // =============================================================================================
-__device__ __forceinline__ void lm_eval(const DevView& v, int s, int E, const double* Rm_sh,
+__device__ __forceinline__ void lm_eval(const DevView& v, int s, int eb, int E, const double* Rm_sh,
                                         double* part /*[kLmThreads/16][kAccN]*/, double* acc_out /*[kAccN]*/) {
   double Rm[12];
 #pragma unroll
@@ -820,7 +822,7 @@ __device__ __forceinline__ void lm_eval(const DevView& v, int s, int E, const do
   double acc[kAccN];
 #pragma unroll
   for (int i = 0; i < kAccN; i++) acc[i] = 0.0;
-  const float4* ed = v.edges + (size_t)s * v.edge_cap;
+  const float4* ed = v.edges + ((size_t)eb * v.n_streams + s) * v.edge_cap;
   const float4* ca = v.corr_a + (size_t)s * v.edge_cap;
   const float4* cb = v.corr_b + (size_t)s * v.edge_cap;
   for (int e = threadIdx.x; e < E; e += kLmThreads) {
@@ -855,7 +857,7 @@ __device__ __forceinline__ void lm_eval(const DevView& v, int s, int E, const do
 // Called by the whole workgroup.  sh_cnt: LDS scratch of kMaxFrames + 1 ints.
 // Thread 64 publishes the result (pose log, host-mapped record) while thread 0 computes the
 // prediction and the window bookkeeping; the remaining threads fetch the frame sizes.
-__device__ void finalize_scan(const DevView& v, int s, StreamState& st, int* sh_cnt) {
+__device__ void finalize_scan(const DevView& v, int s, StreamState& st, int* sh_cnt, int eb) {
   const int P = v.prev_frames;
   const int tid = threadIdx.x;
   // LocalMapManager::addPointCloud (:34-60) on a ring of P frame slots: the new frame goes
@@ -866,7 +868,7 @@ __device__ void finalize_scan(const DevView& v, int s, StreamState& st, int* sh_
   int* wn = v.win_n + (size_t)s * P;
   int* wb = v.win_base + (size_t)s * (P + 1);
   int* ws = v.win_slot + (size_t)s * P;
-  const int n_edges = st.n_edges;
+  const int n_edges = st.n_edges_buf[eb];
   if (tid == 0) { for (int i = 0; i < 12; i++) st.final_odom[i] = st.odom[i]; }
   __syncthreads();
   for (int j = tid; j < nf; j += blockDim.x) {
@@ -897,6 +899,7 @@ __device__ void finalize_scan(const DevView& v, int s, StreamState& st, int* sh_
       __threadfence_system();
       __hip_atomic_store(&ho->seq, k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    st.info.matches[0] = 0; st.info.matches[1] = 0;   // counters of the next scan's two kNN passes
   }
   if (tid == 0) {
     // prediction for the next scan: odom * (prev^-1 * odom)   (:148-150)
@@ -922,7 +925,7 @@ __device__ void finalize_scan(const DevView& v, int s, StreamState& st, int* sh_
   for (int j = tid; j <= nf; j += blockDim.x) wb[j] = sh_cnt[j];
 }
 
-__global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int outer_it) {
+__global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int outer_it, int eb) {
   __shared__ double sh_pose[12];
   __shared__ double sh_part[(kLmThreads / 16) * kAccN];
   __shared__ double sh_acc[kAccN];
@@ -931,23 +934,31 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
   const int s = s0 + blockIdx.x;
   StreamState& st = v.state[s];
   __shared__ int sh_cnt[kMaxFrames + 1];
+  if (outer_it == 0 && threadIdx.x == 0) {     // per-scan diagnostics (matches are counted by k_knn)
+    st.info.n_edges = st.n_edges_buf[eb];
+    st.info.map_points = st.n_map;
+    for (int k = 0; k < 2; k++) {
+      st.info.lm[k].iterations = 0; st.info.lm[k].accepted = 0; st.info.lm[k].termination = LM_TERM_NO_RESIDUALS;
+      st.info.lm[k].pad = 0; st.info.lm[k].initial_cost = 0.0; st.info.lm[k].final_cost = 0.0;
+    }
+  }
   if (!st.initialized) {
     // first frame (:108-136): no solve; pose stays identity, edges enter the window raw
     if (outer_it == 1) {
       if (threadIdx.x == 0) st.append_raw = 1;
-      finalize_scan(v, s, st, sh_cnt);
+      finalize_scan(v, s, st, sh_cnt, eb);
       if (threadIdx.x == 0) st.initialized = 1;
     }
     return;
   }
   const bool dbgb = (s == 0) && (threadIdx.x == 0) && (outer_it == 1);
   DBG_STAMP(v, dbgb, 2, 0);
-  const int E = st.n_edges;
+  const int E = st.n_edges_buf[eb];
   const int nblocks = st.info.matches[outer_it];
   if (threadIdx.x == 0) iso_from_qt(st.param_q, st.param_t, sh_pose);
   __syncthreads();
   DBG_STAMP(v, dbgb, 2, 1);
-  lm_eval(v, s, E, sh_pose, sh_part, sh_acc);
+  lm_eval(v, s, eb, E, sh_pose, sh_part, sh_acc);
   DBG_STAMP(v, dbgb, 2, 2);
   if (threadIdx.x == 0) {
     sh_flag = lm_begin(lm, st.param_q, st.param_t, sh_acc, nblocks, v.apply_on_ftol);
@@ -957,7 +968,7 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
   DBG_STAMP(v, dbgb, 2, 3);
   int dbg_it = 0;
   while (sh_flag == LM_NEED_EVAL && !(v.debug & 8)) {
-    lm_eval(v, s, E, sh_pose, sh_part, sh_acc);
+    lm_eval(v, s, eb, E, sh_pose, sh_part, sh_acc);
     DBG_STAMP(v, dbgb && dbg_it < 5, 2, 4 + 2 * dbg_it);
     if (threadIdx.x == 0) {
       sh_flag = lm_update(lm, sh_acc);
@@ -978,7 +989,7 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
     if (outer_it == 1) st.append_raw = 0;
   }
   DBG_STAMP(v, dbgb, 2, 21);
-  if (outer_it == 1) finalize_scan(v, s, st, sh_cnt);
+  if (outer_it == 1) finalize_scan(v, s, st, sh_cnt, eb);
   DBG_STAMP(v, dbgb, 2, 22);
 }
 
@@ -993,6 +1004,7 @@ __global__ __launch_bounds__(256) void k_init_cells(DevView v) {
   CellSlot empty; empty.key = kEmptyKey; empty.start = 0; empty.cnt = 0;
   v.cells[i] = empty;
   v.cell_fill[i] = 0;
+  if ((i & 31) == 0) v.cell_bits[i >> 5] = 0u;
 }
 
 __global__ __launch_bounds__(256) void k_hash_clear(DevView v, int s0) {
@@ -1005,13 +1017,14 @@ __global__ __launch_bounds__(256) void k_hash_clear(DevView v, int s0) {
   CellSlot empty; empty.key = kEmptyKey; empty.start = 0; empty.cnt = 0;
   v.cells[ti] = empty;
   v.cell_fill[ti] = 0;
+  v.cell_bits[ti >> 5] = 0u;   // every set bit of that word belongs to a slot of this list
 }
 
 // One thread per window point (oldest frame first).  Points of the newest frame are produced
 // here: edges transformed by the solved pose in FP64 and rounded to float
 // (laser_odometry.cc:231-232), then stored in the window slot (:235).  Every point is counted
 // into its 1 m cell (atomicCAS insert + atomicAdd count).
-__global__ __launch_bounds__(256) void k_window_insert(DevView v, int s0) {
+__global__ __launch_bounds__(256) void k_window_insert(DevView v, int s0, int eb) {
   __shared__ int sbase[kMaxFrames + 1];
   __shared__ int sslot[kMaxFrames];
   const int s = s0 + blockIdx.y;
@@ -1030,7 +1043,7 @@ __global__ __launch_bounds__(256) void k_window_insert(DevView v, int s0) {
   float4* wp = v.win_pts + ((size_t)s * P + slot) * v.edge_cap + idx;
   float4 pt;
   if (j == nf - 1) {
-    const float4 e = v.edges[(size_t)s * v.edge_cap + idx];
+    const float4 e = v.edges[((size_t)eb * v.n_streams + s) * v.edge_cap + idx];
     if (st.append_raw) {
       pt = e;
     } else {
@@ -1058,6 +1071,7 @@ __global__ __launch_bounds__(256) void k_window_insert(DevView v, int s0) {
     if (prev == kEmptyKey) {
       const int u = atomicAdd(&st.n_used, 1);
       v.used_cells[(size_t)s * v.map_cap + u] = (int)h;
+      atomicOr(&v.cell_bits[((size_t)s * v.table_size + h) >> 5], 1u << (h & 31));
       found = (int)h;
       break;
     }

@@ -95,14 +95,15 @@ def sec_timing(H=64, W=1800, lt=0, R=8, epr=10, P=20, K=60, S=1):
     for s in range(S):
         for k in range(K):
             g.upload_scan(s, k, data[s % len(data)][k])
-    for mode in ("sync", "async"):
+    for mode in ("sync", "async", "sync-pipelined", "async-pipelined"):
         g.reset()
         for k in range(10):
             g.process_resident(k, H * W, H, W, readback=True)
         g.sync()
         t = time.time()
         for k in range(10, K):
-            g.process_resident(k, H * W, H, W, readback=(mode == "sync"))
+            g.process_resident(k, H * W, H, W, readback=mode.startswith("sync"),
+                               next_slot=(k + 1 if ("pipelined" in mode and k + 1 < K) else -1))
         g.sync()
         dt = time.time() - t
         print("S=%d %s: %.1f us/scan-step, %.0f scans/s aggregate" % (S, mode, dt / (K - 10) * 1e6, S * (K - 10) / dt))
