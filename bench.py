@@ -112,6 +112,9 @@ def main():
     rank, local_rank, world = rep.rank, rep.local_rank, rep.world
     if world > 1:
         args.gpus = world
+    ndev = la.device_count()
+    if ndev > 0 and local_rank >= ndev:      # more ranks than GPUs (smoke runs): share devices
+        local_rank = local_rank % ndev
 
     wl = WORKLOADS[args.workload]
     H, W, R, epr, P = wl["H"], wl["W"], wl["R"], wl["epr"], wl["P"]

@@ -176,6 +176,8 @@ typedef struct liodom_kernel_stat_t {
 /* Drains recorded events (synchronises) and accumulates into the per-kernel table. */
 int liodom_get_kernel_stats(liodom_handle_t* h, liodom_kernel_stat_t* stats /*LIODOM_NUM_KERNELS*/);
 int liodom_reset_kernel_stats(liodom_handle_t* h);
+/* Number of HIP devices visible to this process (0 without a GPU). */
+int liodom_device_count(int* count);
 /* Device name and compute-unit count of the handle's GPU. */
 int liodom_device_info(liodom_handle_t* h, char* name, int name_cap, int* compute_units);
 

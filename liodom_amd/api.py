@@ -131,6 +131,8 @@ def load():
     L.liodom_get_kernel_stats.argtypes = [vp, C.POINTER(KernelStat)]
     L.liodom_reset_kernel_stats.restype = C.c_int
     L.liodom_reset_kernel_stats.argtypes = [vp]
+    L.liodom_device_count.restype = C.c_int
+    L.liodom_device_count.argtypes = [ip]
     L.liodom_device_info.restype = C.c_int
     L.liodom_device_info.argtypes = [vp, C.c_char_p, C.c_int, ip]
     _lib = L
@@ -143,7 +145,14 @@ EXPORTED_SYMBOLS = [
     "liodom_alloc_resident", "liodom_upload_scan", "liodom_process_resident", "liodom_process_resident_pipelined", "liodom_sync", "liodom_get_pose_log",
     "liodom_reset", "liodom_get_edges", "liodom_get_window", "liodom_get_correspondences", "liodom_get_curvature",
     "liodom_set_profiling", "liodom_get_kernel_stats", "liodom_reset_kernel_stats", "liodom_device_info",
+    "liodom_device_count",
 ]
+
+
+def device_count():
+    n = C.c_int32()
+    load().liodom_device_count(C.byref(n))
+    return n.value
 
 
 def make_params(**kw):

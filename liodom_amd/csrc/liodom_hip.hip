@@ -164,16 +164,12 @@ int launch_odometry(liodom_handle* h, int eb, int s0, int count) {
     }
     {
       ProfScope ps(h, KID_LM);
-      hipLaunchKernelGGL(k_lm_solve, dim3(count), dim3(kLmThreads), 0, h->stream, v, s0, it, eb);
+      hipLaunchKernelGGL(k_lm_solve, dim3(count), dim3(kLmThreads), (size_t)h->v.edge_cap * sizeof(int), h->stream, v, s0, it, eb);
     }
   }
   h->last_eb = eb;       // results are published by k_lm_solve into host-mapped memory (HostOut)
   for (int i = 0; i < count; i++) h->scans_enqueued[s0 + i]++;
   const int map_blocks = cdiv(h->v.map_cap, 256);
-  {
-    ProfScope ps(h, KID_HASH_CLEAR);
-    hipLaunchKernelGGL(k_hash_clear, dim3(map_blocks, count), dim3(256), 0, h->stream, v, s0);
-  }
   {
     ProfScope ps(h, KID_WINDOW_INSERT);
     hipLaunchKernelGGL(k_window_insert, dim3(map_blocks, count), dim3(256), 0, h->stream, v, s0, eb);
@@ -367,7 +363,7 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   ALLOC(v.pose_log, S * v.pose_log_cap * 7, 0);
   ALLOC(v.info_log, S * v.pose_log_cap, 0);
   ALLOC(h->stage_in, S * (size_t)config->max_points, 0);
-  ALLOC(v.dbg_clk, 4 * 32, 0);
+  ALLOC(v.dbg_clk, 8 * 32, 0);
   {
     void* hp = nullptr;
     if (hipHostMalloc(&hp, sizeof(HostOut) * S, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { g_last_error = "hipHostMalloc failed"; return fail(LIODOM_ERR_HIP); }
@@ -699,10 +695,19 @@ int liodom_reset_kernel_stats(liodom_handle_t* h) {
 }
 
 /* debug: raw phase timestamps (100 MHz) written by the kernels when LIODOM_ABLATE has bit 5 set */
-int liodom_debug_clocks(liodom_handle_t* h, unsigned long long* out128) {
-  if (!h || !out128) return LIODOM_ERR_INVALID_ARG;
+int liodom_debug_clocks(liodom_handle_t* h, unsigned long long* out256) {
+  if (!h || !out256) return LIODOM_ERR_INVALID_ARG;
+  HIP_TRY(hipStreamSynchronize(h->stream_x));
   HIP_TRY(hipStreamSynchronize(h->stream));
-  HIP_TRY(hipMemcpy(out128, h->v.dbg_clk, sizeof(unsigned long long) * 128, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out256, h->v.dbg_clk, sizeof(unsigned long long) * 256, hipMemcpyDeviceToHost));
+  return LIODOM_OK;
+}
+
+int liodom_device_count(int* count) {
+  if (!count) return LIODOM_ERR_INVALID_ARG;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+  *count = n;
   return LIODOM_OK;
 }
 

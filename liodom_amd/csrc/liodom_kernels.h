@@ -20,6 +20,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
+
 #include "../../include/liodom_hip.h"
 #include "liodom_math.h"
 #include "wave_ops.h"
@@ -113,7 +115,7 @@ struct DevView {
   double* pose_log;         // [S][pose_log_cap][7]
   liodom_step_info_t* info_log;  // [S][pose_log_cap]
   HostOut* host_out;        // [S] host-mapped pinned memory, polled by the host (zero-copy)
-  unsigned long long* dbg_clk;  // [4][32] phase timestamps (100 MHz), debug bit 5 only
+  unsigned long long* dbg_clk;  // [8][32] phase timestamps (100 MHz), debug bit 5 only
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -344,15 +346,18 @@ __device__ int select_region_lds(const double* c, const float* px, const float* 
 // items; no access to picked[] (assumes nothing was suppressed by earlier regions).
 template <int IPL>
 __device__ int select_region_spec(const double* c, const float* px, const float* py, const float* pz,
-                                  int rs, int re, int epr, int lane, int* out_idx, unsigned char* out_nfnb) {
+                                  int rs, int re, int epr, int lane, int* out_idx, unsigned char* out_nfnb,
+                                  const volatile unsigned char* premarks = nullptr) {
   unsigned long long ck[IPL];
   unsigned int pm = 0;                       // bit i set: item i unavailable
   const int j0 = rs + lane * IPL + 5;        // ring index of this lane's first item
 #pragma unroll
   for (int i = 0; i < IPL; i++) {
     const int k = rs + lane * IPL + i;
-    if (k < re) ck[i] = (unsigned long long)__double_as_longlong(c[k + 5]);
-    else { ck[i] = 0; pm |= 1u << i; }
+    if (k < re) {
+      ck[i] = (unsigned long long)__double_as_longlong(c[k + 5]);
+      if (premarks && premarks[k + 5]) pm |= 1u << i;   // suppressed by an earlier region's picks
+    } else { ck[i] = 0; pm |= 1u << i; }
   }
   int picks = 0;
   while (true) {
@@ -405,6 +410,7 @@ __global__ __launch_bounds__(kExThreads) void k_ring_extract(DevView v, int s0) 
   int* npoints_out = v.ring_npoints + (size_t)s * H + ring;
 
   const bool dbgb = (ring == 40 % H) && (s == 0) && (tid == 0);
+  const unsigned long long t_begin = (v.debug & 32) ? wall_clock64() : 0ull;
   DBG_STAMP(v, dbgb, 0, 0);
   // ---- the ring's points are contiguous in the ring-sorted copy written by k_ring_scatter ----
   const int rbeg = v.ring_start[(size_t)s * (H + 1) + ring];
@@ -491,26 +497,29 @@ __global__ __launch_bounds__(kExThreads) void k_ring_extract(DevView v, int s0) 
     }
     __syncthreads();
     if (wtot[0] != 0) {
-      // rare: replay the carry in region order from a clean picked[] array
+      // Some region had a pick suppressed by its predecessor: replay the carry in region order.
+      // picked[] is rebuilt to hold only the forward spill of *final* picks; a conflicting
+      // region is re-run with the same register-resident routine, seeded with those marks.
       for (int k = tid; k < nr; k += kExThreads) picked[k] = 0;
       __syncthreads();
       if (wave == 0) {
         for (int reg = 0; reg < R; reg++) {
+          const int rs = sector * reg;
+          const int re = (reg == R - 1) ? total : sector * (reg + 1);
           int cntp = region_cnt[reg];
           bool conflict = false;
           for (int k = lane; k < cntp; k += 64) conflict = conflict || (vpicked[pick_idx[reg * ppr + k]] != 0);
           if (__ballot(conflict)) {
-            const int rs = sector * reg;
-            const int re = (reg == R - 1) ? total : sector * (reg + 1);
-            cntp = select_region_lds(c, px, py, pz, vpicked, rs, re, epr, lane, pick_idx + reg * ppr, pick_nfnb + reg * ppr);
+            if (max_len <= 256) cntp = select_region_spec<4>(c, px, py, pz, rs, re, epr, lane, pick_idx + reg * ppr, pick_nfnb + reg * ppr, vpicked);
+            else cntp = select_region_spec<8>(c, px, py, pz, rs, re, epr, lane, pick_idx + reg * ppr, pick_nfnb + reg * ppr, vpicked);
             if (lane == 0) region_cnt[reg] = cntp;
-          } else {
-            for (int k = lane; k < cntp; k += 64) {
-              const int j = pick_idx[reg * ppr + k];
-              const int ext = pick_nfnb[reg * ppr + k];
-              const int nf = ext & 15, nb = ext >> 4;
-              for (int l = -nb; l <= nf; l++) vpicked[j + l] = 1;
-            }
+            __builtin_amdgcn_wave_barrier();
+          }
+          const int end_j = re + 5;
+          for (int k = lane; k < cntp; k += 64) {
+            const int j = pick_idx[reg * ppr + k];
+            const int nf = pick_nfnb[reg * ppr + k] & 15;
+            for (int l = 1; l <= nf; l++) if (j + l >= end_j) vpicked[j + l] = 1;
           }
           __builtin_amdgcn_wave_barrier();
         }
@@ -542,6 +551,7 @@ __global__ __launch_bounds__(kExThreads) void k_ring_extract(DevView v, int s0) 
   }
   if (tid == 0) *nedges_out = base;
   DBG_STAMP(v, dbgb, 0, 7);
+  if ((v.debug & 32) && s == 0 && tid == 0 && ring < 128) v.dbg_clk[128 + ring] = wall_clock64() - t_begin;
 }
 
 // =============================================================================================
@@ -634,11 +644,12 @@ __device__ __forceinline__ void knn_stream_cells(Top5& t, const float4* sp, int*
   __builtin_amdgcn_wave_barrier();
   const int T = s_incl[kKnnGroup - 1];
   int c = 0;   // cell cursor (monotone: the flat index only grows)
-  for (int i = hl; i < T; i += 4 * kKnnGroup) {
-    int a[4];
-    bool ok[4];
+  constexpr int U = 4;         // independent 16-B loads in flight per lane (8 measured no faster)
+  for (int i = hl; i < T; i += U * kKnnGroup) {
+    int a[U];
+    bool ok[U];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < U; u++) {
       const int iu = i + u * kKnnGroup;
       ok[u] = iu < T;
       a[u] = 0;
@@ -647,12 +658,15 @@ __device__ __forceinline__ void knn_stream_cells(Top5& t, const float4* sp, int*
         a[u] = s_adj[c] + iu;
       }
     }
-    float4 m[4];
+    float4 m[U];
 #pragma unroll
-    for (int u = 0; u < 4; u++) if (ok[u]) m[u] = sp[a[u]];
+    for (int u = 0; u < U; u++) if (ok[u]) m[u] = sp[a[u]];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      if (ok[u]) top5_insert(t, sqdist_f(qx, qy, qz, m[u].x, m[u].y, m[u].z), __float_as_int(m[u].w), a[u]);
+    for (int u = 0; u < U; u++) {
+      if (ok[u]) {
+        const float d = sqdist_f(qx, qy, qz, m[u].x, m[u].y, m[u].z);
+        if (d <= t.d4) top5_insert(t, d, __float_as_int(m[u].w), a[u]);   // cheap reject first
+      }
     }
   }
   __builtin_amdgcn_wave_barrier();
@@ -750,21 +764,44 @@ __global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int oute
     const float4* sp = v.sorted_pts + (size_t)s * v.map_cap;
     Top5 t, g;
     top5_clear(t);
-    // phase 1: the query's own cell (lane 13 = offset (0,0,0))
-    knn_stream_cells(t, sp, s_incl[grp], s_adj[grp], start, (hl == 13) ? cnt : 0u, hl, qx, qy, qz);
-    DBG_STAMP(v, dbgb, 1, 3);
-    knn_merge(t, g, hl, half_shift);
-    DBG_STAMP(v, dbgb, 1, 4);
-    // phase 2: neighbour cells that can still hold a point closer than the current 5th best (or
-    // than the 1.0 gate: points at >= 1.0 can never be part of an accepted match, :324)
-    const float bound_f = g.d4 < 1.0f ? g.d4 : 1.0f;
-    const bool keep = (hl < 27) && (hl != 13) && (cnt > 0) && !(lb > (double)bound_f);
-    if ((__ballot(keep) >> half_shift) & 0xFFFFFFFFull) {
-      top5_clear(t);
-      if (hl == 0) t = g;       // carry the phase-1 result in one lane's list
-      knn_stream_cells(t, sp, s_incl[grp], s_adj[grp], start, keep ? cnt : 0u, hl, qx, qy, qz);
-      knn_merge(t, g, hl, half_shift);
+    // Cells are streamed in rounds of increasing box distance (own cell; within 0.2 m; within
+    // 0.5 m; the rest).  After every round the pruning bound is refreshed: an upper bound of the
+    // final 5th-best distance = the 5th smallest of the lanes' best distances (five distinct
+    // points are at least that close) or any single lane's own 5th entry, never above the 1.0
+    // gate (points at >= 1.0 cannot be part of a match, :324).  A cell is skipped only if its box
+    // distance exceeds the bound, so the result is exact; a typical query ends after its own cell.
+    float bound_f = 1.0f;
+    bool pending = (hl < 27) && (cnt > 0);
+    const double thr[4] = {0.0, 0.04, 0.25, 4.0};
+#pragma unroll
+    for (int round = 0; round < 4; round++) {
+      pending = pending && !(lb > (double)bound_f);              // pruned for good
+      const bool now = pending && (lb <= thr[round]);
+      if ((__ballot(now) >> half_shift) & 0xFFFFFFFFull) {
+        knn_stream_cells(t, sp, s_incl[grp], s_adj[grp], start, now ? cnt : 0u, hl, qx, qy, qz);
+        pending = pending && !now;
+        if (round < 3 && ((__ballot(pending) >> half_shift) & 0xFFFFFFFFull)) {
+          unsigned int bnd = 0x7f800000u;   // +inf
+          bool taken = false;
+          const unsigned int mine = (unsigned int)__float_as_int(t.d0);   // non-negative floats order as uints
+#pragma unroll
+          for (int r = 0; r < 5; r++) {
+            const unsigned int cur = taken ? 0x7f800000u : mine;
+            const unsigned int mn = half_min_u32(cur);
+            if (r == 4) bnd = mn;
+            const unsigned int win = (unsigned int)((__ballot(!taken && cur == mn) >> half_shift) & 0xFFFFFFFFull);
+            if (hl == __ffs(win) - 1) taken = true;
+          }
+          const unsigned int own5 = half_min_u32((unsigned int)__float_as_int(t.d4));
+          bnd = own5 < bnd ? own5 : bnd;
+          const float b = __int_as_float((int)bnd);
+          bound_f = b < bound_f ? b : bound_f;
+        }
+      }
+      if (round == 0) DBG_STAMP(v, dbgb, 1, 3);
+      if (round == 1) DBG_STAMP(v, dbgb, 1, 4);
     }
+    knn_merge(t, g, hl, half_shift);
     DBG_STAMP(v, dbgb, 1, 5);
     if (g.d4 < 1.0f) {                                           // :324 (inf when < 5 candidates)
       const int mypos = hl == 0 ? g.p0 : hl == 1 ? g.p1 : hl == 2 ? g.p2 : hl == 3 ? g.p3 : g.p4;
@@ -814,7 +851,40 @@ __global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int oute
 //   finalize (second outer iteration, or the very first frame): pose log, constant-velocity
 //   prediction for the next scan, window bookkeeping, hash-generation counters.
 // =============================================================================================
-__device__ __forceinline__ void lm_eval(const DevView& v, int s, int eb, int E, const double* Rm_sh,
+// Indices of the edges with an accepted correspondence, in edge order (deterministic), built once
+// per solve in LDS so that every evaluation runs over C dense items instead of E sparse ones.
+__device__ int lm_compact(const DevView& v, int s, int E, int* idx /*LDS [edge_cap]*/, int* wtot /*LDS [4 * 8]*/) {
+  const float4* ca = v.corr_a + (size_t)s * v.edge_cap;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int NW = kLmThreads / 64;
+  int run = 0;
+  for (int base = 0; base < E; base += 4 * kLmThreads) {     // 4 chunks per barrier
+    int f[4], incl[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      const int e = base + b * kLmThreads + threadIdx.x;
+      f[b] = (e < E && ca[e].w != 0.0f) ? 1 : 0;
+    }
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      incl[b] = wave_incl_scan_i32(f[b]);
+      if (lane == 63) wtot[b * NW + wave] = incl[b];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      int pre = 0, tot = 0;
+#pragma unroll
+      for (int w = 0; w < NW; w++) { const int t = wtot[b * NW + w]; if (w < wave) pre += t; tot += t; }
+      if (f[b]) idx[run + pre + incl[b] - 1] = base + b * kLmThreads + threadIdx.x;
+      run += tot;
+    }
+    __syncthreads();
+  }
+  return run;
+}
+
+__device__ __forceinline__ void lm_eval(const DevView& v, int s, int eb, int C, const int* idx, const double* Rm_sh,
                                         double* part /*[kLmThreads/16][kAccN]*/, double* acc_out /*[kAccN]*/) {
   double Rm[12];
 #pragma unroll
@@ -825,16 +895,15 @@ __device__ __forceinline__ void lm_eval(const DevView& v, int s, int eb, int E, 
   const float4* ed = v.edges + ((size_t)eb * v.n_streams + s) * v.edge_cap;
   const float4* ca = v.corr_a + (size_t)s * v.edge_cap;
   const float4* cb = v.corr_b + (size_t)s * v.edge_cap;
-  for (int e = threadIdx.x; e < E; e += kLmThreads) {
+  for (int c = threadIdx.x; c < C; c += kLmThreads) {
+    const int e = idx[c];
     const float4 A = ca[e];
-    if (A.w != 0.0f) {
-      const float4 B = cb[e];
-      const float4 P = ed[e];
-      const double p[3] = {(double)P.x, (double)P.y, (double)P.z};     // :347-349 sensor frame
-      const double a[3] = {(double)A.x, (double)A.y, (double)A.z};
-      const double b[3] = {(double)B.x, (double)B.y, (double)B.z};
-      residual_accumulate(Rm, p, a, b, v.min_range, v.max_range, acc);
-    }
+    const float4 B = cb[e];
+    const float4 P = ed[e];
+    const double p[3] = {(double)P.x, (double)P.y, (double)P.z};     // :347-349 sensor frame
+    const double a[3] = {(double)A.x, (double)A.y, (double)A.z};
+    const double b[3] = {(double)B.x, (double)B.y, (double)B.z};
+    residual_accumulate(Rm, p, a, b, v.min_range, v.max_range, acc);
   }
   // reduction: DPP butterfly inside each 16-lane row, one partial per row into LDS, then a
   // fixed-order sum of the (waves x 4) partials -> deterministic, no atomics
@@ -854,6 +923,27 @@ __device__ __forceinline__ void lm_eval(const DevView& v, int s, int eb, int E, 
   __syncthreads();
 }
 
+// Resets the hash slots occupied by the build that this scan searched (list used_cells[0 .. nup));
+// the last kNN pass of the scan has completed before the finalising k_lm_solve launch starts.
+__device__ void hash_clear_used(const DevView& v, int s, int nup, int t, int nt) {
+  CellSlot empty; empty.key = kEmptyKey; empty.start = 0; empty.cnt = 0;
+  const int* used = v.used_cells + (size_t)s * v.map_cap;
+  for (int u0 = t; u0 < nup; u0 += 8 * nt) {   // 8 index loads in flight per thread
+    int hh[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { const int u = u0 + k * nt; hh[k] = (u < nup) ? used[u] : -1; }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      if (hh[k] >= 0) {
+        const size_t ti = (size_t)s * v.table_size + hh[k];
+        v.cells[ti] = empty;
+        v.cell_fill[ti] = 0;
+        v.cell_bits[ti >> 5] = 0u;   // every set bit of that word belongs to a slot of this list
+      }
+    }
+  }
+}
+
 // Called by the whole workgroup.  sh_cnt: LDS scratch of kMaxFrames + 1 ints.
 // Thread 64 publishes the result (pose log, host-mapped record) while thread 0 computes the
 // prediction and the window bookkeeping; the remaining threads fetch the frame sizes.
@@ -869,6 +959,7 @@ __device__ void finalize_scan(const DevView& v, int s, StreamState& st, int* sh_
   int* wb = v.win_base + (size_t)s * (P + 1);
   int* ws = v.win_slot + (size_t)s * P;
   const int n_edges = st.n_edges_buf[eb];
+  const int nup = st.n_used;      // cells of the build that this scan searched (cleared below)
   if (tid == 0) { for (int i = 0; i < 12; i++) st.final_odom[i] = st.odom[i]; }
   __syncthreads();
   for (int j = tid; j < nf; j += blockDim.x) {
@@ -892,6 +983,7 @@ __device__ void finalize_scan(const DevView& v, int s, StreamState& st, int* sh_
     }
     st.scan_counter = k + 1;
     if (v.host_out) {
+      // zero-copy publication: payload, system-scope fence, then the sequence word the host polls
       HostOut* ho = v.host_out + s;
       ho->pose[0] = q[0]; ho->pose[1] = q[1]; ho->pose[2] = q[2]; ho->pose[3] = q[3];
       ho->pose[4] = st.final_odom[3]; ho->pose[5] = st.final_odom[7]; ho->pose[6] = st.final_odom[11];
@@ -923,6 +1015,8 @@ __device__ void finalize_scan(const DevView& v, int s, StreamState& st, int* sh_
   }
   __syncthreads();
   for (int j = tid; j <= nf; j += blockDim.x) wb[j] = sh_cnt[j];
+  // after the publication: its system-scope fence would otherwise have to write back these lines
+  hash_clear_used(v, s, nup, tid, (int)blockDim.x);
 }
 
 __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int outer_it, int eb) {
@@ -934,6 +1028,7 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
   const int s = s0 + blockIdx.x;
   StreamState& st = v.state[s];
   __shared__ int sh_cnt[kMaxFrames + 1];
+  extern __shared__ __attribute__((aligned(16))) int sh_idx[];   // [edge_cap] compacted correspondence indices
   if (outer_it == 0 && threadIdx.x == 0) {     // per-scan diagnostics (matches are counted by k_knn)
     st.info.n_edges = st.n_edges_buf[eb];
     st.info.map_points = st.n_map;
@@ -956,9 +1051,10 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
   const int E = st.n_edges_buf[eb];
   const int nblocks = st.info.matches[outer_it];
   if (threadIdx.x == 0) iso_from_qt(st.param_q, st.param_t, sh_pose);
+  const int C = lm_compact(v, s, E, sh_idx, sh_cnt);   // (ends with a barrier; sh_cnt doubles as scratch)
   __syncthreads();
   DBG_STAMP(v, dbgb, 2, 1);
-  lm_eval(v, s, eb, E, sh_pose, sh_part, sh_acc);
+  lm_eval(v, s, eb, C, sh_idx, sh_pose, sh_part, sh_acc);
   DBG_STAMP(v, dbgb, 2, 2);
   if (threadIdx.x == 0) {
     sh_flag = lm_begin(lm, st.param_q, st.param_t, sh_acc, nblocks, v.apply_on_ftol);
@@ -968,7 +1064,7 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
   DBG_STAMP(v, dbgb, 2, 3);
   int dbg_it = 0;
   while (sh_flag == LM_NEED_EVAL && !(v.debug & 8)) {
-    lm_eval(v, s, eb, E, sh_pose, sh_part, sh_acc);
+    lm_eval(v, s, eb, C, sh_idx, sh_pose, sh_part, sh_acc);
     DBG_STAMP(v, dbgb && dbg_it < 5, 2, 4 + 2 * dbg_it);
     if (threadIdx.x == 0) {
       sh_flag = lm_update(lm, sh_acc);
@@ -989,7 +1085,9 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
     if (outer_it == 1) st.append_raw = 0;
   }
   DBG_STAMP(v, dbgb, 2, 21);
-  if (outer_it == 1) finalize_scan(v, s, st, sh_cnt, eb);
+  if (outer_it == 1) {
+    finalize_scan(v, s, st, sh_cnt, eb);
+  }
   DBG_STAMP(v, dbgb, 2, 22);
 }
 

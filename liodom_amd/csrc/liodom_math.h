@@ -186,7 +186,9 @@ LD_HD float sqdist_f(float qx, float qy, float qz, float mx, float my, float mz)
 // accept iff lambda_max > 3 * lambda_mid.
 // ---------------------------------------------------------------------------------------
 LD_HD void jacobi_rot(double& app, double& aqq, double& apq, double& arp, double& arq) {
-  if (apq == 0.0) return;
+  // converged pair: rotating further cannot change the eigenvalues at double precision (the
+  // same test, bit for bit, in the oracle and in the GPU path)
+  if (fabs(apq) <= 1e-20 * (fabs(app) + fabs(aqq))) return;
   const double theta = (aqq - app) / (2.0 * apq);
   const double at = fabs(theta);
   double t = 1.0 / (at + sqrt(theta * theta + 1.0));

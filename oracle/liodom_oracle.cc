@@ -402,7 +402,9 @@ struct KdTree {
 // a = {a00, a01, a02, a11, a12, a22}; ev ascending.
 // ------------------------------------------------------------------------------------------
 inline void jacobi_rot(double& app, double& aqq, double& apq, double& arp, double& arq) {
-  if (apq == 0.0) return;
+  // converged pair: rotating further cannot change the eigenvalues at double precision (the
+  // same test, bit for bit, in the oracle and in the GPU path)
+  if (std::fabs(apq) <= 1e-20 * (std::fabs(app) + std::fabs(aqq))) return;
   double theta = (aqq - app) / (2.0 * apq);
   double at = std::fabs(theta);
   double t = 1.0 / (at + std::sqrt(theta * theta + 1.0));

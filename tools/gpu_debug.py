@@ -194,10 +194,12 @@ def sec_clocks(H=64, W=1800, R=8, epr=10, P=20, K=40):
     for k in range(K):
         g.process_resident(k, H * W, H, W, readback=False)
     g.sync()
-    buf = (C.c_ulonglong * 128)()
+    buf = (C.c_ulonglong * 256)()
     g.L.liodom_debug_clocks.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
     g.L.liodom_debug_clocks(g.h, buf)
-    a = np.array(list(buf), dtype=np.int64).reshape(4, 32)
+    allv = np.array(list(buf), dtype=np.int64)
+    print('k_ring_extract per-ring workgroup durations (us), rings 0..63:', np.round(allv[128:192] / 100.0, 1).tolist())
+    a = allv[:128].reshape(4, 32)
     names = {0: ["start", "", "ring loaded", "(unused)", "stencil", "spec select", "carry check", "emitted"],
              1: ["start", "query ready", "hash probed", "centre streamed", "merge1", "phase2 done", "nn fetched", "gate done"],
              2: ["start", "pose ready", "eval0", "begin", "eval1", "upd1", "eval2", "upd2", "eval3", "upd3", "eval4", "upd4", "", "", "", "", "", "", "", "", "loop end", "pose written", "finalized"]}
