@@ -20,7 +20,19 @@ class Replicas:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29512")
             if not dist.is_initialized():
-                dist.init_process_group(backend="gloo", rank=self.rank, world_size=self.world)
+                # gloo prints its "[Gloo] Rank N is connected ..." banner on stdout from C++; the
+                # bench contract is ONE JSON line on stdout, so route fd 1 to stderr meanwhile
+                import sys
+                sys.stdout.flush()
+                saved = os.dup(1)
+                try:
+                    os.dup2(2, 1)
+                    dist.init_process_group(backend="gloo", rank=self.rank, world_size=self.world)
+                    dist.barrier()
+                finally:
+                    sys.stdout.flush()
+                    os.dup2(saved, 1)
+                    os.close(saved)
             self.dist = dist
 
     @property
