@@ -155,8 +155,13 @@ int liodom_get_edges(liodom_handle_t* h, int stream, float* edges_xyzi, int32_t*
 /* Sliding-window points in LocalMapManager order (oldest frame first). */
 int liodom_get_window(liodom_handle_t* h, int stream, float* xyzi, int64_t cap, int64_t* n_points,
                       int* n_frames);
+/* The cloud the next scan's kNN will search (computeLocalMap, src/laser_odometry.cc:274-298): the
+ * window, or — with filter_local_map and a full window — its VoxelGrid(0.4) down-sampling in
+ * PCL's output order (ascending leaf index).  *filtered tells which. */
+int liodom_get_local_map(liodom_handle_t* h, int stream, float* xyzi, int64_t cap, int64_t* n_points, int* filtered);
 /* Correspondences of outer iteration `it` (0/1) of the last step: valid flag and window
- * indices (as in liodom_get_window) of the two line points per edge. */
+ * indices (as in liodom_get_window; PCL leaf indices when the local map is filtered) of the two
+ * line points per edge. */
 int liodom_get_correspondences(liodom_handle_t* h, int stream, int it, int32_t* valid,
                                int32_t* idx_a, int32_t* idx_b, int cap, int* n);
 /* Smoothness values of the last extracted scan, ring-major over the compacted rings; also the

@@ -121,6 +121,8 @@ def load():
     L.liodom_get_edges.argtypes = [vp, C.c_int, fp, ip, ip, ip, C.c_int, ip]
     L.liodom_get_window.restype = C.c_int
     L.liodom_get_window.argtypes = [vp, C.c_int, fp, C.c_int64, C.POINTER(C.c_int64), ip]
+    L.liodom_get_local_map.restype = C.c_int
+    L.liodom_get_local_map.argtypes = [vp, C.c_int, fp, C.c_int64, C.POINTER(C.c_int64), ip]
     L.liodom_get_correspondences.restype = C.c_int
     L.liodom_get_correspondences.argtypes = [vp, C.c_int, C.c_int, ip, ip, ip, C.c_int, ip]
     L.liodom_get_curvature.restype = C.c_int
@@ -143,7 +145,7 @@ EXPORTED_SYMBOLS = [
     "liodom_params_default", "liodom_config_default", "liodom_create", "liodom_destroy", "liodom_last_error",
     "liodom_extract_edges", "liodom_odometry_step", "liodom_process_scan", "liodom_set_received_map",
     "liodom_alloc_resident", "liodom_upload_scan", "liodom_process_resident", "liodom_process_resident_pipelined", "liodom_sync", "liodom_get_pose_log",
-    "liodom_reset", "liodom_get_edges", "liodom_get_window", "liodom_get_correspondences", "liodom_get_curvature",
+    "liodom_reset", "liodom_get_edges", "liodom_get_window", "liodom_get_local_map", "liodom_get_correspondences", "liodom_get_curvature",
     "liodom_set_profiling", "liodom_get_kernel_stats", "liodom_reset_kernel_stats", "liodom_device_info",
     "liodom_device_count",
 ]
@@ -293,6 +295,14 @@ class Liodom:
         nf = C.c_int32()
         self._check(self.L.liodom_get_window(self.h, stream, _fp(w), cap, C.byref(n), C.byref(nf)))
         return w[:n.value].copy(), nf.value
+
+    def local_map(self, stream=0):
+        cap = self.edge_cap * int(self.params.local_map_size)
+        w = np.zeros((cap, 4), np.float32)
+        n = C.c_int64()
+        filt = C.c_int32()
+        self._check(self.L.liodom_get_local_map(self.h, stream, _fp(w), cap, C.byref(n), C.byref(filt)))
+        return w[:n.value].copy(), bool(filt.value)
 
     def correspondences(self, it, stream=0):
         cap = self.edge_cap

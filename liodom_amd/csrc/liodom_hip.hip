@@ -174,6 +174,15 @@ int launch_odometry(liodom_handle* h, int eb, int s0, int count) {
     ProfScope ps(h, KID_WINDOW_INSERT);
     hipLaunchKernelGGL(k_window_insert, dim3(map_blocks, count), dim3(256), 0, h->stream, v, s0, eb);
   }
+  if (v.filter_local_map) {     // VoxelGrid(0.4) of the full window (every kernel exits unless the window is full)
+    ProfScope ps(h, KID_OTHER);
+    hipLaunchKernelGGL(k_voxel_bbox, dim3(count), dim3(1024), 0, h->stream, v, s0);
+    hipLaunchKernelGGL(k_voxel_insert, dim3(map_blocks, count), dim3(256), 0, h->stream, v, s0);
+    hipLaunchKernelGGL(k_voxel_alloc, dim3(map_blocks, count), dim3(256), 0, h->stream, v, s0);
+    hipLaunchKernelGGL(k_voxel_scatter, dim3(map_blocks, count), dim3(256), 0, h->stream, v, s0);
+    hipLaunchKernelGGL(k_voxel_centroid, dim3(cdiv(h->v.map_cap, 8), count), dim3(256), 0, h->stream, v, s0);
+    hipLaunchKernelGGL(k_filt_insert, dim3(map_blocks, count), dim3(256), 0, h->stream, v, s0);
+  }
   {
     ProfScope ps(h, KID_HASH_ALLOC);
     hipLaunchKernelGGL(k_hash_alloc, dim3(map_blocks, count), dim3(256), 0, h->stream, v, s0);
@@ -181,6 +190,7 @@ int launch_odometry(liodom_handle* h, int eb, int s0, int count) {
   {
     ProfScope ps(h, KID_HASH_SCATTER);
     hipLaunchKernelGGL(k_hash_scatter, dim3(map_blocks, count), dim3(256), 0, h->stream, v, s0);
+    if (v.filter_local_map) hipLaunchKernelGGL(k_filt_scatter, dim3(map_blocks, count), dim3(256), 0, h->stream, v, s0);
   }
   HIP_TRY(hipGetLastError());
   return LIODOM_OK;
@@ -279,8 +289,8 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
     g_last_error = "liodom_create: parameter out of range";
     return LIODOM_ERR_INVALID_ARG;
   }
-  if (params->use_imu || params->filter_local_map || params->mapping) {
-    g_last_error = "liodom_create: use_imu / filter_local_map / mapping are not implemented on the GPU path yet";
+  if (params->use_imu || params->mapping) {
+    g_last_error = "liodom_create: use_imu / mapping are not implemented on the GPU path yet";
     return LIODOM_ERR_UNSUPPORTED;
   }
   int ndev = 0;
@@ -311,6 +321,8 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   v.min_points_per_scan = (long long)params->min_points_per_scan;
   v.prev_frames = h->P;
   v.apply_on_ftol = config->lm_apply_step_on_ftol;
+  v.filter_local_map = (params->filter_local_map && !params->mapping) ? 1 : 0;   // laser_odometry.cc:286
+  v.vox_inv = 1.0f / 0.4f;                                                          // setLeafSize(0.4) :290
   v.n_streams = h->S;
   v.max_points = config->max_points;
   int width = config->max_width > 0 ? config->max_width : std::max(1, config->max_points / params->scan_lines);
@@ -360,6 +372,15 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   ALLOC(v.used_cells, S * v.map_cap, 0);
   ALLOC(v.pt_cell, S * v.map_cap, 0xFF);
   ALLOC(v.sorted_pts, S * v.map_cap, 0);
+  if (v.filter_local_map) {
+    ALLOC(v.vox_cells, S * v.table_size, 0);
+    ALLOC(v.vox_fill, S * v.table_size, 0);
+    ALLOC(v.vox_used_list, S * v.map_cap, 0);
+    ALLOC(v.pt_vox, S * v.map_cap, 0xFF);
+    ALLOC(v.vox_pts, S * v.map_cap, 0);
+    ALLOC(v.filt_pts, S * v.map_cap, 0);
+    ALLOC(v.filt_int, S * v.map_cap, 0);
+  }
   ALLOC(v.pose_log, S * v.pose_log_cap * 7, 0);
   ALLOC(v.info_log, S * v.pose_log_cap, 0);
   ALLOC(h->stage_in, S * (size_t)config->max_points, 0);
@@ -622,6 +643,35 @@ int liodom_get_window(liodom_handle_t* h, int stream, float* xyzi, int64_t cap, 
     if (cnt > 0)
       HIP_TRY(hipMemcpy(xyzi + 4 * (size_t)base[j], h->v.win_pts + ((size_t)stream * P + slot[j]) * h->v.edge_cap,
                         sizeof(float4) * (size_t)cnt, hipMemcpyDeviceToHost));
+  }
+  return LIODOM_OK;
+}
+
+int liodom_get_local_map(liodom_handle_t* h, int stream, float* xyzi, int64_t cap, int64_t* n_points, int* filtered) {
+  int rc = check_stream(h, stream);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  StreamState st;
+  HIP_TRY(hipMemcpy(&st, h->v.state + stream, sizeof(st), hipMemcpyDeviceToHost));
+  if (filtered) *filtered = st.n_filt > 0 ? 1 : 0;
+  if (st.n_filt == 0) {
+    int nf = 0;
+    return liodom_get_window(h, stream, xyzi, cap, n_points, &nf);
+  }
+  const int n = st.n_filt;
+  if (n_points) *n_points = n;
+  if (n > cap) { g_last_error = "local-map buffer too small"; return LIODOM_ERR_CAPACITY; }
+  std::vector<float4> pts((size_t)n);
+  std::vector<float> inten((size_t)n);
+  HIP_TRY(hipMemcpy(pts.data(), h->v.filt_pts + (size_t)stream * h->v.map_cap, sizeof(float4) * (size_t)n, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(inten.data(), h->v.filt_int + (size_t)stream * h->v.map_cap, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
+  std::vector<int> order((size_t)n);
+  for (int i = 0; i < n; i++) order[i] = i;
+  auto leaf = [&](int i) { unsigned int u; std::memcpy(&u, &pts[i].w, 4); return u; };
+  std::sort(order.begin(), order.end(), [&](int a, int b) { return leaf(a) < leaf(b); });   // PCL output order
+  for (int i = 0; i < n && xyzi; i++) {
+    const float4& p = pts[order[i]];
+    xyzi[4 * i] = p.x; xyzi[4 * i + 1] = p.y; xyzi[4 * i + 2] = p.z; xyzi[4 * i + 3] = inten[order[i]];
   }
   return LIODOM_OK;
 }

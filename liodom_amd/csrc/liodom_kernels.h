@@ -52,6 +52,13 @@ struct StreamState {
   int32_t cursor;         // allocation cursor into the cell-sorted point array
   int32_t scan_counter;
   uint32_t status;
+  int32_t n_search;       // points covered by the kNN structure (window or filtered local map)
+  // filter_local_map (laser_odometry.cc:286-292): VoxelGrid(0.4) of the full window
+  int32_t n_filt;         // filtered points (0 when the kNN structure holds the raw window)
+  int32_t vox_used;       // occupied voxels of the current voxel-grid build
+  int32_t vox_cursor;
+  int32_t vox_minb[3];    // PCL VoxelGrid min_b_ and div_b_
+  int32_t vox_divb[3];
   int32_t pad;
   liodom_step_info_t info;
 };
@@ -80,6 +87,8 @@ struct DevView {
   long long min_points_per_scan;
   int prev_frames;
   int apply_on_ftol;
+  int filter_local_map;     // params.filter_local_map_ (and !mapping_)
+  float vox_inv;            // 1.0f / 0.4f as PCL computes inverse_leaf_size_
   // capacities
   int n_streams, max_points, ring_cap, slots_per_ring, edge_cap, map_cap, table_size;
   int pose_log_cap;
@@ -115,8 +124,21 @@ struct DevView {
   double* pose_log;         // [S][pose_log_cap][7]
   liodom_step_info_t* info_log;  // [S][pose_log_cap]
   HostOut* host_out;        // [S] host-mapped pinned memory, polled by the host (zero-copy)
+  // filter_local_map: voxel grouping of the window and the filtered cloud
+  CellSlot* vox_cells;      // [S][table_size] key = PCL voxel index
+  unsigned int* vox_fill;   // [S][table_size]
+  int* vox_used_list;       // [S][map_cap]
+  int* pt_vox;              // [S][map_cap] voxel slot of every window point
+  int* vox_pts;             // [S][map_cap] window indices grouped by voxel, ascending inside a voxel
+  float4* filt_pts;         // [S][map_cap] centroid xyz + voxel-index bits
+  float* filt_int;          // [S][map_cap] centroid intensity
   unsigned long long* dbg_clk;  // [8][32] phase timestamps (100 MHz), debug bit 5 only
 };
+
+// computeLocalMap's condition (laser_odometry.cc:286): filter && window full && !mapping
+__device__ __forceinline__ bool filter_active(const DevView& v, const StreamState& st) {
+  return v.filter_local_map != 0 && st.n_frames == v.prev_frames;
+}
 
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
@@ -1031,7 +1053,7 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
   extern __shared__ __attribute__((aligned(16))) int sh_idx[];   // [edge_cap] compacted correspondence indices
   if (outer_it == 0 && threadIdx.x == 0) {     // per-scan diagnostics (matches are counted by k_knn)
     st.info.n_edges = st.n_edges_buf[eb];
-    st.info.map_points = st.n_map;
+    st.info.map_points = st.n_search;
     for (int k = 0; k < 2; k++) {
       st.info.lm[k].iterations = 0; st.info.lm[k].accepted = 0; st.info.lm[k].termination = LM_TERM_NO_RESIDUALS;
       st.info.lm[k].pad = 0; st.info.lm[k].initial_cost = 0.0; st.info.lm[k].final_cost = 0.0;
@@ -1103,6 +1125,7 @@ __global__ __launch_bounds__(256) void k_init_cells(DevView v) {
   v.cells[i] = empty;
   v.cell_fill[i] = 0;
   if ((i & 31) == 0) v.cell_bits[i >> 5] = 0u;
+  if (v.vox_cells) { v.vox_cells[i] = empty; v.vox_fill[i] = 0; }
 }
 
 __global__ __launch_bounds__(256) void k_hash_clear(DevView v, int s0) {
@@ -1155,6 +1178,8 @@ __global__ __launch_bounds__(256) void k_window_insert(DevView v, int s0, int eb
   } else {
     pt = *wp;
   }
+  if (filter_active(v, st)) return;     // the kNN structure is built from the filtered cloud instead
+  if (m == 0) { st.n_search = M; st.n_filt = 0; }
   int* pc = v.pt_cell + (size_t)s * v.map_cap + m;
   const bool fin = ld_isfinite((double)pt.x) && ld_isfinite((double)pt.y) && ld_isfinite((double)pt.z) &&
                    fabsf(pt.x) < 1.0e9f && fabsf(pt.y) < 1.0e9f && fabsf(pt.z) < 1.0e9f;
@@ -1197,7 +1222,7 @@ __global__ __launch_bounds__(256) void k_hash_scatter(DevView v, int s0) {
   const int s = s0 + blockIdx.y;
   const StreamState& st = v.state[s];
   const int M = st.n_map;
-  if ((int)(blockIdx.x * 256) >= M) return;
+  if ((int)(blockIdx.x * 256) >= M || filter_active(v, st)) return;
   const int P = v.prev_frames, nf = st.n_frames;
   for (int j = threadIdx.x; j <= nf; j += 256) sbase[j] = v.win_base[(size_t)s * (P + 1) + j];
   for (int j = threadIdx.x; j < nf; j += 256) sslot[j] = v.win_slot[(size_t)s * P + j];
@@ -1212,6 +1237,264 @@ __global__ __launch_bounds__(256) void k_hash_scatter(DevView v, int s0) {
   const size_t ti = (size_t)s * v.table_size + h;
   const unsigned int pos = v.cells[ti].start + atomicAdd(&v.cell_fill[ti], 1u);
   v.sorted_pts[(size_t)s * v.map_cap + pos] = make_float4(pt.x, pt.y, pt.z, __int_as_float(m));
+}
+
+
+// =============================================================================================
+// filter_local_map (computeLocalMap, laser_odometry.cc:286-292): when the window is full the
+// local map searched by the next scan is pcl::VoxelGrid(0.4 m) of the whole window — one float
+// centroid (x, y, z, intensity) per occupied leaf.  PCL sorts (leaf index, point) pairs and sums
+// each leaf's points in that order in float; here "that order" is ascending window index (the
+// oracle uses a stable sort; std::sort's order inside a leaf is unspecified in the reference).
+//   k_voxel_bbox      one workgroup per stream: clear the previous voxel table, min/max of the
+//                     window -> PCL's min_b_ / div_b_
+//   k_voxel_insert    leaf index per window point, atomicCAS/atomicAdd grouping (as the 1 m cells)
+//   k_voxel_alloc / k_voxel_scatter   window indices grouped by leaf
+//   k_voxel_centroid  half-wave per leaf: rank the leaf's window indices (ascending), then one
+//                     lane sums in that order -> deterministic, PCL's float accumulation
+//   k_filt_insert / k_hash_alloc / k_filt_scatter   1 m cell hash over the filtered points; the
+//                     tie-break index carried by the points is PCL's leaf index (= the rank order
+//                     of the filtered cloud)
+// Every kernel exits immediately unless filter_active().
+// =============================================================================================
+struct WinIndex {
+  int sbase[kMaxFrames + 1];
+  int sslot[kMaxFrames];
+};
+__device__ __forceinline__ void win_index_load(const DevView& v, int s, int nf, WinIndex& w, int tid, int nt) {
+  const int P = v.prev_frames;
+  for (int j = tid; j <= nf; j += nt) w.sbase[j] = v.win_base[(size_t)s * (P + 1) + j];
+  for (int j = tid; j < nf; j += nt) w.sslot[j] = v.win_slot[(size_t)s * P + j];
+}
+__device__ __forceinline__ float4 win_point(const DevView& v, int s, int nf, const WinIndex& w, int m) {
+  int lo = 0, hi = nf;             // largest j with sbase[j] <= m
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (w.sbase[mid] <= m) lo = mid; else hi = mid; }
+  return v.win_pts[((size_t)s * v.prev_frames + w.sslot[lo]) * v.edge_cap + (m - w.sbase[lo])];
+}
+__device__ __forceinline__ bool point_ok(const float4& p) {
+  return ld_isfinite((double)p.x) && ld_isfinite((double)p.y) && ld_isfinite((double)p.z) &&
+         fabsf(p.x) < 1.0e9f && fabsf(p.y) < 1.0e9f && fabsf(p.z) < 1.0e9f;
+}
+
+__global__ __launch_bounds__(1024) void k_voxel_bbox(DevView v, int s0) {
+  __shared__ WinIndex w;
+  __shared__ float red[6][16];
+  const int s = s0 + blockIdx.x;
+  StreamState& st = v.state[s];
+  const int tid = threadIdx.x;
+  // clear the voxel table of the previous build (also when the filter just became inactive)
+  {
+    const int nup = st.vox_used;
+    CellSlot empty; empty.key = kEmptyKey; empty.start = 0; empty.cnt = 0;
+    for (int u = tid; u < nup; u += 1024) {
+      const int h = v.vox_used_list[(size_t)s * v.map_cap + u];
+      v.vox_cells[(size_t)s * v.table_size + h] = empty;
+      v.vox_fill[(size_t)s * v.table_size + h] = 0;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) { st.vox_used = 0; st.vox_cursor = 0; }
+  if (!filter_active(v, st)) return;
+  const int M = st.n_map, nf = st.n_frames;
+  win_index_load(v, s, nf, w, tid, 1024);
+  __syncthreads();
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (int m = tid; m < M; m += 1024) {
+    const float4 p = win_point(v, s, nf, w, m);
+    if (!point_ok(p)) continue;
+    mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
+    mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
+  }
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    for (int off = 32; off >= 1; off >>= 1) {
+      mn[d] = fminf(mn[d], __shfl_xor(mn[d], off));
+      mx[d] = fmaxf(mx[d], __shfl_xor(mx[d], off));
+    }
+    if ((tid & 63) == 0) { red[d][tid >> 6] = mn[d]; red[3 + d][tid >> 6] = mx[d]; }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    for (int d = 0; d < 3; d++) {
+      float a = red[d][0], b = red[3 + d][0];
+      for (int k = 1; k < 16; k++) { a = fminf(a, red[d][k]); b = fmaxf(b, red[3 + d][k]); }
+      const int minb = (int)floorf(a * v.vox_inv);            // PCL: floor(min_p * inverse_leaf_size_)
+      const int maxb = (int)floorf(b * v.vox_inv);
+      st.vox_minb[d] = minb;
+      st.vox_divb[d] = maxb - minb + 1;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_voxel_insert(DevView v, int s0) {
+  __shared__ WinIndex w;
+  const int s = s0 + blockIdx.y;
+  StreamState& st = v.state[s];
+  if (!filter_active(v, st)) return;
+  const int M = st.n_map, nf = st.n_frames;
+  if ((int)(blockIdx.x * 256) >= M) return;
+  win_index_load(v, s, nf, w, threadIdx.x, 256);
+  __syncthreads();
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  const float4 p = win_point(v, s, nf, w, m);
+  int* pv = v.pt_vox + (size_t)s * v.map_cap + m;
+  if (!point_ok(p)) { *pv = -1; return; }
+  const int i0 = (int)floorf(p.x * v.vox_inv) - st.vox_minb[0];
+  const int i1 = (int)floorf(p.y * v.vox_inv) - st.vox_minb[1];
+  const int i2 = (int)floorf(p.z * v.vox_inv) - st.vox_minb[2];
+  const unsigned int idx = (unsigned int)(i0 + i1 * st.vox_divb[0] + i2 * st.vox_divb[0] * st.vox_divb[1]);
+  const unsigned long long key = (unsigned long long)idx;
+  const unsigned int tmask = (unsigned int)v.table_size - 1u;
+  CellSlot* cells = v.vox_cells + (size_t)s * v.table_size;
+  unsigned int h = hash_cell(key, tmask);
+  int found = -1;
+  for (int probe = 0; probe < v.table_size; probe++) {
+    const unsigned long long prev = atomicCAS(&cells[h].key, kEmptyKey, key);
+    if (prev == kEmptyKey) {
+      const int u = atomicAdd(&st.vox_used, 1);
+      v.vox_used_list[(size_t)s * v.map_cap + u] = (int)h;
+      found = (int)h;
+      break;
+    }
+    if (prev == key) { found = (int)h; break; }
+    h = (h + 1) & tmask;
+  }
+  if (found < 0) { atomicOr(&st.status, LIODOM_STATUS_HASH_FULL); *pv = -1; return; }
+  atomicAdd(&cells[found].cnt, 1u);
+  *pv = found;
+}
+
+__global__ __launch_bounds__(256) void k_voxel_alloc(DevView v, int s0) {
+  const int s = s0 + blockIdx.y;
+  StreamState& st = v.state[s];
+  if (!filter_active(v, st)) return;
+  const int u = blockIdx.x * 256 + threadIdx.x;
+  if (u >= st.vox_used) return;
+  CellSlot* slot = v.vox_cells + (size_t)s * v.table_size + v.vox_used_list[(size_t)s * v.map_cap + u];
+  slot->start = (unsigned int)atomicAdd(&st.vox_cursor, (int)slot->cnt);
+}
+
+__global__ __launch_bounds__(256) void k_voxel_scatter(DevView v, int s0) {
+  const int s = s0 + blockIdx.y;
+  const StreamState& st = v.state[s];
+  if (!filter_active(v, st)) return;
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= st.n_map) return;
+  const int h = v.pt_vox[(size_t)s * v.map_cap + m];
+  if (h < 0) return;
+  const size_t ti = (size_t)s * v.table_size + h;
+  const unsigned int pos = v.vox_cells[ti].start + atomicAdd(&v.vox_fill[ti], 1u);
+  v.vox_pts[(size_t)s * v.map_cap + pos] = m;
+}
+
+// 32 lanes per leaf, 8 leaves per workgroup.
+__global__ __launch_bounds__(256) void k_voxel_centroid(DevView v, int s0) {
+  __shared__ WinIndex w;
+  constexpr int CAP = 512;
+  __shared__ int ord[8][CAP];
+  const int s = s0 + blockIdx.y;
+  StreamState& st = v.state[s];
+  if (!filter_active(v, st)) return;
+  const int nvox = st.vox_used;
+  if ((int)(blockIdx.x * 8) >= nvox) return;
+  const int nf = st.n_frames;
+  win_index_load(v, s, nf, w, threadIdx.x, 256);
+  __syncthreads();
+  const int grp = threadIdx.x >> 5, hl = threadIdx.x & 31;
+  const int u = blockIdx.x * 8 + grp;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { st.n_filt = nvox; st.n_search = nvox; }
+  if (u >= nvox) return;
+  const CellSlot slot = v.vox_cells[(size_t)s * v.table_size + v.vox_used_list[(size_t)s * v.map_cap + u]];
+  const int cnt = (int)slot.cnt;
+  int* list = v.vox_pts + (size_t)s * v.map_cap + slot.start;
+  // rank sort of the leaf's window indices (all distinct): rank = number of smaller indices
+  if (cnt <= CAP) {
+    for (int i = hl; i < cnt; i += 32) ord[grp][i] = list[i];
+    __builtin_amdgcn_wave_barrier();
+    int mine[CAP / 32], rank[CAP / 32];
+#pragma unroll
+    for (int k = 0; k < CAP / 32; k++) { const int i = hl + 32 * k; mine[k] = (i < cnt) ? ord[grp][i] : 0x7fffffff; rank[k] = 0; }
+    for (int j = 0; j < cnt; j++) {
+      const int o = ord[grp][j];
+#pragma unroll
+      for (int k = 0; k < CAP / 32; k++) rank[k] += (o < mine[k]) ? 1 : 0;
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < CAP / 32; k++) { const int i = hl + 32 * k; if (i < cnt) list[rank[k]] = mine[k]; }
+  } else {
+    // very crowded leaf: rank against the list in global memory, result staged through ord/global
+    for (int i = hl; i < cnt; i += 32) {
+      const int mi = list[i];
+      int r = 0;
+      for (int j = 0; j < cnt; j++) r += (list[j] < mi) ? 1 : 0;
+      v.pt_vox[(size_t)s * v.map_cap + slot.start + r] = mi;      // pt_vox is free again: scratch
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    for (int i = hl; i < cnt; i += 32) list[i] = v.pt_vox[(size_t)s * v.map_cap + slot.start + i];
+  }
+  __builtin_amdgcn_wave_barrier();
+  __threadfence_block();
+  if (hl == 0) {
+    float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
+    for (int i0 = 0; i0 < cnt; i0 += 8) {       // 8 loads in flight, summed in order
+      float4 p[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) if (i0 + k < cnt) p[k] = win_point(v, s, nf, w, list[i0 + k]);
+#pragma unroll
+      for (int k = 0; k < 8; k++) if (i0 + k < cnt) { sx += p[k].x; sy += p[k].y; sz += p[k].z; si += p[k].w; }
+    }
+    const float c = (float)cnt;
+    v.filt_pts[(size_t)s * v.map_cap + u] = make_float4(sx / c, sy / c, sz / c, __int_as_float((int)(unsigned int)slot.key));
+    v.filt_int[(size_t)s * v.map_cap + u] = si / c;
+  }
+}
+
+// 1 m cell hash over the filtered cloud (same slot protocol as k_window_insert).
+__global__ __launch_bounds__(256) void k_filt_insert(DevView v, int s0) {
+  const int s = s0 + blockIdx.y;
+  StreamState& st = v.state[s];
+  if (!filter_active(v, st)) return;
+  const int u = blockIdx.x * 256 + threadIdx.x;
+  if (u >= st.n_filt) return;
+  const float4 pt = v.filt_pts[(size_t)s * v.map_cap + u];
+  int* pc = v.pt_cell + (size_t)s * v.map_cap + u;
+  if (!point_ok(pt)) { *pc = -1; return; }
+  const unsigned long long key = pack_cell((int)floorf(pt.x), (int)floorf(pt.y), (int)floorf(pt.z));
+  const unsigned int tmask = (unsigned int)v.table_size - 1u;
+  CellSlot* cells = v.cells + (size_t)s * v.table_size;
+  unsigned int h = hash_cell(key, tmask);
+  int found = -1;
+  for (int probe = 0; probe < v.table_size; probe++) {
+    const unsigned long long prev = atomicCAS(&cells[h].key, kEmptyKey, key);
+    if (prev == kEmptyKey) {
+      const int k = atomicAdd(&st.n_used, 1);
+      v.used_cells[(size_t)s * v.map_cap + k] = (int)h;
+      atomicOr(&v.cell_bits[((size_t)s * v.table_size + h) >> 5], 1u << (h & 31));
+      found = (int)h;
+      break;
+    }
+    if (prev == key) { found = (int)h; break; }
+    h = (h + 1) & tmask;
+  }
+  if (found < 0) { atomicOr(&st.status, LIODOM_STATUS_HASH_FULL); *pc = -1; return; }
+  atomicAdd(&cells[found].cnt, 1u);
+  *pc = found;
+}
+
+__global__ __launch_bounds__(256) void k_filt_scatter(DevView v, int s0) {
+  const int s = s0 + blockIdx.y;
+  const StreamState& st = v.state[s];
+  if (!filter_active(v, st)) return;
+  const int u = blockIdx.x * 256 + threadIdx.x;
+  if (u >= st.n_filt) return;
+  const int h = v.pt_cell[(size_t)s * v.map_cap + u];
+  if (h < 0) return;
+  const size_t ti = (size_t)s * v.table_size + h;
+  const unsigned int pos = v.cells[ti].start + atomicAdd(&v.cell_fill[ti], 1u);
+  v.sorted_pts[(size_t)s * v.map_cap + pos] = v.filt_pts[(size_t)s * v.map_cap + u];
 }
 
 }  // namespace liodom_dev

@@ -229,6 +229,41 @@ def test_async_replay_equals_synchronous(orc, synth):
     g.close()
 
 
+def test_filter_local_map_voxelgrid(orc, synth):
+    """computeLocalMap with filter_local_map (laser_odometry.cc:286-292): once the window is full
+    the kNN map is VoxelGrid(0.4) of the window.  Filtered cloud bit-exact in PCL's output order,
+    poses within tolerance, same match counts and LM iterations."""
+    H, W, R, epr, P, K = 16, 900, 6, 10, 4, 12
+    cfg = synth.make_cfg(H, W, 0)
+    po = orc.make_params(scan_lines=H, scan_regions=R, edges_per_region=epr, prev_frames=P, knn_mode=1, filter_local_map=True)
+    g = la.Liodom(la.make_params(scan_lines=H, scan_regions=R, edges_per_region=epr, prev_frames=P, filter_local_map=1),
+                  la.make_config(max_points=H * W, max_width=W))
+    od = orc.Odometer(po)
+    seen_filtered = 0
+    for k in range(K):
+        x, _ = synth.scan(cfg, 0, k)
+        o = orc.extract(po, x, H, W)
+        pose_o, info_o = od.step(o["edges"])
+        pose_g, info_g = g.process_scan(x, H, W)
+        assert np.linalg.norm(pose_g[4:] - pose_o[4:]) <= POSE_TOL_T and rot_angle(pose_g[:4], pose_o[:4]) <= POSE_TOL_R, k
+        if k > 0:
+            assert info_g.map_points == info_o.map_points, (k, info_g.map_points, info_o.map_points)
+            assert list(info_g.matches) == list(info_o.matches)
+            assert [info_g.lm[0].iterations, info_g.lm[1].iterations] == [info_o.lm[0].iterations, info_o.lm[1].iterations]
+        lm, filtered = g.local_map()
+        wo = od.window()
+        if od.window_frames() == P:
+            assert filtered
+            ref = orc.voxel_grid(wo, 0.4)
+            assert lm.shape == ref.shape
+            assert np.array_equal(lm.view(np.uint32), ref.view(np.uint32))
+            seen_filtered += 1
+        else:
+            assert not filtered and lm.shape == wo.shape
+    assert seen_filtered >= 5
+    g.close()
+
+
 def test_pipelined_replay_equals_serial(orc, synth):
     # extraction of scan k+1 on the second stream while odometry k runs: same poses, bit for bit
     H, W, R, epr, P, K = 16, 900, 6, 10, 5, 12
