@@ -24,7 +24,9 @@
 #include <cstring>
 #include <deque>
 #include <limits>
+#include <map>
 #include <queue>
+#include <tuple>
 #include <vector>
 
 extern "C" {
@@ -818,6 +820,85 @@ void voxel_grid(const std::vector<P4>& in, float leaf, std::vector<P4>& out) {
 }
 
 // ------------------------------------------------------------------------------------------
+// A12-A14  Map / Cell / HashKey                  src/map.cc:24-189, include/liodom/map.h:58-116
+// Coarse hash cells (default 40 x 40 x 50 m) each holding a VoxelGrid(resolution)-filtered cloud.
+// The unordered_map only serves lookups; iteration uses cells_vector_ (insertion order), so an
+// ordered map is an equivalent restatement.
+// ------------------------------------------------------------------------------------------
+struct MapCell { std::vector<P4> points; bool modified = false; };
+struct MapO {
+  double voxel_xysize, inv_voxel_xysize, voxel_xysize_half, voxel_zsize, inv_voxel_zsize, voxel_zsize_half;
+  float resolution;
+  std::map<std::tuple<int, int, int>, int> cells;     // HashMap cells_ (map.h:91)
+  std::vector<MapCell> cells_vector;                  // cells_vector_ (map.h:115)
+  MapO(double xy, double z, double res)
+      : voxel_xysize(xy), inv_voxel_xysize(1.0 / xy), voxel_xysize_half(xy / 2.0), voxel_zsize(z),
+        inv_voxel_zsize(1.0 / z), voxel_zsize_half(z / 2.0), resolution((float)res) {}    // map.cc:70-81
+
+  void updateMap(const std::vector<P4>& pc_in, const Iso& pose) {                     // map.cc:90-129
+    for (size_t i = 0; i < pc_in.size(); i++) {
+      const P4 point = transform_point(pose, pc_in[i]);                               // :93-94
+      int voxel_x = int(std::floor(point.x * inv_voxel_xysize) * voxel_xysize + (voxel_xysize_half));   // :103
+      int voxel_y = int(std::floor(point.y * inv_voxel_xysize) * voxel_xysize + (voxel_xysize_half));   // :104
+      int voxel_z = int(std::floor(point.z * inv_voxel_zsize) * voxel_zsize + (voxel_zsize_half));      // :105
+      auto key = std::make_tuple(voxel_x, voxel_y, voxel_z);
+      auto it = cells.find(key);
+      int ci;
+      if (it == cells.end()) {                                                        // :110-114
+        ci = (int)cells_vector.size();
+        cells[key] = ci;
+        cells_vector.push_back(MapCell());
+      } else {
+        ci = it->second;                                                              // :117
+      }
+      cells_vector[ci].points.push_back(point);                                       // :120
+      cells_vector[ci].modified = true;
+    }
+    for (size_t i = 0; i < cells_vector.size(); i++) {                                // :124-128
+      if (cells_vector[i].modified) {
+        std::vector<P4> f;
+        voxel_grid(cells_vector[i].points, resolution, f);                            // Cell::filter, :56-60
+        cells_vector[i].points.swap(f);
+        cells_vector[i].modified = false;
+      }
+    }
+  }
+
+  void getLocalMap(const Iso& pose, int cells_xy, int cells_z, std::vector<P4>& total_points) const {   // map.cc:141-189
+    total_points.clear();
+    int x = (int)pose.m[3];                                                           // :144 (truncation)
+    int voxel_x = int(std::floor(x * inv_voxel_xysize) * voxel_xysize + (voxel_xysize_half));
+    int y = (int)pose.m[7];                                                           // :147
+    int voxel_y = int(std::floor(y * inv_voxel_xysize) * voxel_xysize + (voxel_xysize_half));
+    int z = (int)pose.m[11];                                                          // :150
+    int voxel_z = int(std::floor(z * inv_voxel_zsize) * voxel_zsize + (voxel_zsize_half));
+    int init_x = voxel_x - cells_xy * voxel_xysize;                                   // :157-160
+    int end_x = voxel_x + cells_xy * voxel_xysize;
+    int init_y = voxel_y - cells_xy * voxel_xysize;
+    int end_y = voxel_y + cells_xy * voxel_xysize;
+    for (int i = init_x; i <= end_x; i += voxel_xysize) {                             // :162
+      for (int j = init_y; j <= end_y; j += voxel_xysize) {                           // :163
+        auto it = cells.find(std::make_tuple(i, j, voxel_z));
+        if (it != cells.end()) {
+          const std::vector<P4>& c = cells_vector[it->second].points;
+          total_points.insert(total_points.end(), c.begin(), c.end());                // :169
+        }
+      }
+    }
+    int init_z = voxel_z - cells_z * voxel_xysize;                                    // :175 (xy size: reference quirk)
+    int end_z = voxel_z + cells_z * voxel_xysize;                                     // :176
+    for (int i = init_z; i <= end_z; i += voxel_zsize) {                              // :178
+      auto it = cells.find(std::make_tuple(voxel_x, voxel_y, i));
+      if (it != cells.end()) {
+        const std::vector<P4>& c = cells_vector[it->second].points;
+        total_points.insert(total_points.end(), c.begin(), c.end());                  // :184
+      }
+    }
+  }
+  size_t total() const { size_t n = 0; for (const auto& c : cells_vector) n += c.points.size(); return n; }
+};
+
+// ------------------------------------------------------------------------------------------
 // A6  LocalMapManager                            src/laser_odometry.cc:24-69
 // ------------------------------------------------------------------------------------------
 struct LocalMapManager {
@@ -852,6 +933,11 @@ struct Odometer {
   double param_q[4] = {0, 0, 0, 1}, param_t[3] = {0, 0, 0};
   LocalMapManager lmap;
   std::vector<P4> received_map;                       // SharedData::setLocalMap (mapClb)
+  // mapping = true: the liodom_mapping node (src/liodom_mapping_node.cc:45-90, defaults :115-134)
+  // replayed synchronously — the reference is asynchronous / non-deterministic here (SURVEY.md
+  // §3.3): after scan k, updateMap(edges_k, pose_k); scan k+1 receives getLocalMap(pose_k, 2, 1).
+  MapO mapper{40.0, 50.0, 0.4};
+  int cells_xy = 2, cells_z = 1;
   // debug capture of the last step
   std::vector<int32_t> corr_valid[2], corr_a[2], corr_b[2];
   StepInfo info{};
@@ -921,7 +1007,7 @@ struct Odometer {
       } else {
         gen = lmap.total_points;                                                       // :294
       }
-      info.map_points = (int)gen.size();
+      info.map_points = (int)gen.size() + (prm.mapping ? (int)received_map.size() : 0);
       // predict (:148-150)
       Iso pred = iso_mul(odom, iso_mul(iso_inverse(prev_odom), odom));
       prev_odom = odom;
@@ -939,6 +1025,10 @@ struct Odometer {
       std::vector<P4> edges_map(feats.size());
       for (size_t i = 0; i < feats.size(); i++) edges_map[i] = transform_point(odom, feats[i]);  // :231-232
       lmap.addPointCloud(edges_map);                                                   // :235
+    }
+    if (prm.mapping) {
+      mapper.updateMap(feats, odom);                          // liodom_mapping_node.cc:69
+      mapper.getLocalMap(odom, cells_xy, cells_z, received_map);   // :82 -> mapClb (liodom_node.cc:57-64)
     }
     // pose as published: quaternion of odom_ (publishOdom :403 with identity laser_to_base)
     double q[4];
@@ -1060,6 +1150,42 @@ void orc_odom_set_received_map(void* h, const float* xyzi, int64_t n) {
   o->received_map.resize((size_t)n);
   if (n) std::memcpy(o->received_map.data(), xyzi, sizeof(P4) * (size_t)n);
 }
+int64_t orc_odom_get_received_map(void* h, float* xyzi, int64_t cap) {
+  Odometer* o = static_cast<Odometer*>(h);
+  int64_t n = (int64_t)o->received_map.size();
+  if (n > cap) return -n;
+  if (n) std::memcpy(xyzi, o->received_map.data(), sizeof(P4) * (size_t)n);
+  return n;
+}
+// --- Map (mapping node) unit-level entry points ---------------------------------------------
+void* orc_map_create(double xy, double z, double res) { return new MapO(xy, z, res); }
+void orc_map_destroy(void* m) { delete static_cast<MapO*>(m); }
+void orc_map_update(void* m, const float* xyzi, int64_t n, const double* T12) {
+  std::vector<P4> pc((size_t)n);
+  if (n) std::memcpy(pc.data(), xyzi, sizeof(P4) * (size_t)n);
+  Iso T; std::memcpy(T.m, T12, sizeof(double) * 12);
+  static_cast<MapO*>(m)->updateMap(pc, T);
+}
+int64_t orc_map_get_local(void* m, const double* T12, int cells_xy, int cells_z, float* out, int64_t cap) {
+  Iso T; std::memcpy(T.m, T12, sizeof(double) * 12);
+  std::vector<P4> o;
+  static_cast<MapO*>(m)->getLocalMap(T, cells_xy, cells_z, o);
+  if ((int64_t)o.size() > cap) return -(int64_t)o.size();
+  if (!o.empty()) std::memcpy(out, o.data(), sizeof(P4) * o.size());
+  return (int64_t)o.size();
+}
+int64_t orc_map_get_all(void* m, float* out, int64_t cap) {            // Map::getMap, map.cc:131-139
+  MapO* M = static_cast<MapO*>(m);
+  int64_t n = 0;
+  for (const auto& c : M->cells_vector) {
+    if (n + (int64_t)c.points.size() > cap) return -1;
+    if (!c.points.empty()) std::memcpy(out + 4 * n, c.points.data(), sizeof(P4) * c.points.size());
+    n += (int64_t)c.points.size();
+  }
+  return n;
+}
+int orc_map_num_cells(void* m) { return (int)static_cast<MapO*>(m)->cells_vector.size(); }
+int64_t orc_odom_map_total(void* h) { return (int64_t)static_cast<Odometer*>(h)->mapper.total(); }
 void orc_odom_get_state(void* h, double* odom12, double* prev12) {
   Odometer* o = static_cast<Odometer*>(h);
   std::memcpy(odom12, o->odom.m, sizeof(double) * 12);

@@ -82,6 +82,20 @@ def lib():
         L.orc_odom_get_window.argtypes = [C.c_void_p, fp, C.c_int64]
         L.orc_odom_set_received_map.argtypes = [C.c_void_p, fp, C.c_int64]
         L.orc_odom_get_state.argtypes = [C.c_void_p, dp, dp]
+        L.orc_odom_get_received_map.restype = C.c_int64
+        L.orc_odom_get_received_map.argtypes = [C.c_void_p, fp, C.c_int64]
+        L.orc_odom_map_total.restype = C.c_int64
+        L.orc_odom_map_total.argtypes = [C.c_void_p]
+        L.orc_map_create.restype = C.c_void_p
+        L.orc_map_create.argtypes = [C.c_double, C.c_double, C.c_double]
+        L.orc_map_destroy.argtypes = [C.c_void_p]
+        L.orc_map_update.argtypes = [C.c_void_p, fp, C.c_int64, dp]
+        L.orc_map_get_local.restype = C.c_int64
+        L.orc_map_get_local.argtypes = [C.c_void_p, dp, C.c_int, C.c_int, fp, C.c_int64]
+        L.orc_map_get_all.restype = C.c_int64
+        L.orc_map_get_all.argtypes = [C.c_void_p, fp, C.c_int64]
+        L.orc_map_num_cells.restype = C.c_int
+        L.orc_map_num_cells.argtypes = [C.c_void_p]
         L.orc_knn5.argtypes = [fp, C.c_int64, fp, C.c_int64, C.c_int, ip, fp]
         L.orc_eig3.argtypes = [dp, dp]
         L.orc_point2line.restype = C.c_int
@@ -196,6 +210,15 @@ class Odometer:
     def window_frames(self):
         return lib().orc_odom_window_frames(self.h)
 
+    def received_map(self):
+        cap = 1 << 20
+        w = np.zeros((cap, 4), dtype=np.float32)
+        n = lib().orc_odom_get_received_map(self.h, _fp(w), cap)
+        return w[:max(n, 0)].copy()
+
+    def map_total(self):
+        return lib().orc_odom_map_total(self.h)
+
     def set_received_map(self, xyzi):
         xyzi = np.ascontiguousarray(xyzi, dtype=np.float32).reshape(-1, 4)
         lib().orc_odom_set_received_map(self.h, _fp(xyzi), xyzi.shape[0])
@@ -205,6 +228,38 @@ class Odometer:
         b = np.zeros(12)
         lib().orc_odom_get_state(self.h, _dp(a), _dp(b))
         return a.reshape(3, 4), b.reshape(3, 4)
+
+
+class Map:
+    """liodom::Map restatement (src/map.cc:70-189)."""
+
+    def __init__(self, xy=40.0, z=50.0, res=0.4):
+        self.h = lib().orc_map_create(xy, z, res)
+
+    def __del__(self):
+        try:
+            lib().orc_map_destroy(self.h)
+        except Exception:
+            pass
+
+    def update(self, xyzi, T34=None):
+        x = np.ascontiguousarray(xyzi, dtype=np.float32).reshape(-1, 4)
+        T = np.ascontiguousarray(np.eye(4)[:3] if T34 is None else T34, dtype=np.float64).reshape(12)
+        lib().orc_map_update(self.h, _fp(x), x.shape[0], _dp(T))
+
+    def local(self, T34=None, cells_xy=2, cells_z=1):
+        T = np.ascontiguousarray(np.eye(4)[:3] if T34 is None else T34, dtype=np.float64).reshape(12)
+        out = np.zeros((1 << 18, 4), dtype=np.float32)
+        n = lib().orc_map_get_local(self.h, _dp(T), cells_xy, cells_z, _fp(out), out.shape[0])
+        return out[:n].copy()
+
+    def all(self):
+        out = np.zeros((1 << 18, 4), dtype=np.float32)
+        n = lib().orc_map_get_all(self.h, _fp(out), out.shape[0])
+        return out[:n].copy()
+
+    def num_cells(self):
+        return lib().orc_map_num_cells(self.h)
 
 
 def knn5(map_xyzi, q_xyzi, mode=0):
