@@ -37,6 +37,7 @@ extern "C" {
 #define LIODOM_STATUS_RING_OVERFLOW 1u  /* a ring had more points than max_ring_points; it was skipped */
 #define LIODOM_STATUS_EDGE_OVERFLOW 2u
 #define LIODOM_STATUS_HASH_FULL 4u
+#define LIODOM_STATUS_LM_SYNC_TIMEOUT 8u  /* cooperating LM workgroups did not all arrive (result invalid) */
 
 /* Field-for-field mirror of liodom::Params (include/liodom/params.h:33-49); defaults are
  * those of Params::readParams (src/params.cc:40-109). */
@@ -70,6 +71,8 @@ typedef struct liodom_config_t {
   int32_t lm_apply_step_on_ftol; /* 0 = Ceres >= 1.12 behaviour (LM section) */
   int32_t pose_log_capacity; /* scans kept in the device-side pose log (resident replay) */
   int32_t debug_buffers;     /* 1 = keep per-ring smoothness dumps for liodom_get_curvature */
+  int32_t lm_workgroups;     /* workgroups (CUs) per stream for the pose solve: 0 = auto (8 for <= 4 streams of >= 8192 possible edges, else 1), 1 or 8 */
+  int32_t reserved;
 } liodom_config_t;
 
 typedef struct liodom_lm_trace_t {

@@ -54,7 +54,7 @@ class Config(C.Structure):
     _fields_ = [
         ("device", C.c_int32), ("n_streams", C.c_int32), ("max_points", C.c_int32), ("max_width", C.c_int32),
         ("max_ring_points", C.c_int32), ("lm_apply_step_on_ftol", C.c_int32), ("pose_log_capacity", C.c_int32),
-        ("debug_buffers", C.c_int32),
+        ("debug_buffers", C.c_int32), ("lm_workgroups", C.c_int32), ("reserved", C.c_int32),
     ]
 
 

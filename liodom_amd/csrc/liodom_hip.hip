@@ -164,7 +164,7 @@ int launch_odometry(liodom_handle* h, int eb, int s0, int count) {
     }
     {
       ProfScope ps(h, KID_LM);
-      hipLaunchKernelGGL(k_lm_solve, dim3(count), dim3(kLmThreads), (size_t)h->v.edge_cap * sizeof(int), h->stream, v, s0, it, eb);
+      hipLaunchKernelGGL(k_lm_solve, dim3(h->v.lm_groups, count), dim3(kLmThreads), (size_t)h->v.edge_cap * sizeof(int), h->stream, v, s0, it, eb);
     }
   }
   h->last_eb = eb;       // results are published by k_lm_solve into host-mapped memory (HostOut)
@@ -240,6 +240,7 @@ int reset_state(liodom_handle* h) {
   }
   if (h->stream_x) HIP_TRY(hipStreamSynchronize(h->stream_x));
   h->pf_slot = -1; h->parity = 0; h->last_eb = 0; h->ev_free_valid[0] = h->ev_free_valid[1] = false;
+  HIP_TRY(hipMemsetAsync(h->v.lm_xch, 0, sizeof(unsigned long long) * (size_t)h->S * 2 * kLmGroupsMax * 64, h->stream));
   std::memset(h->host_out, 0, sizeof(HostOut) * (size_t)h->S);
   std::fill(h->scans_enqueued.begin(), h->scans_enqueued.end(), 0);
   HIP_TRY(hipMemsetAsync(h->v.win_n, 0, sizeof(int) * (size_t)h->S * h->P, h->stream));
@@ -278,6 +279,7 @@ void liodom_config_default(liodom_config_t* c) {
   std::memset(c, 0, sizeof(*c));
   c->device = 0; c->n_streams = 1; c->max_points = 64 * 1800; c->max_width = 1800;
   c->max_ring_points = 0; c->lm_apply_step_on_ftol = 0; c->pose_log_capacity = 1024; c->debug_buffers = 0;
+  c->lm_workgroups = 0;
 }
 
 int liodom_create(const liodom_params_t* params, const liodom_config_t* config, liodom_handle_t** out) {
@@ -322,6 +324,10 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   v.prev_frames = h->P;
   v.apply_on_ftol = config->lm_apply_step_on_ftol;
   v.filter_local_map = (params->filter_local_map && !params->mapping) ? 1 : 0;   // laser_odometry.cc:286
+  // auto: several CUs per solve pay off only when one CU would spend >> the ~4.5 us in-launch
+  // exchange on an evaluation (measured: ~2000 edges -> no gain; Ouster-128 shape -> yes)
+  v.lm_groups = config->lm_workgroups == 0 ? ((config->n_streams <= 4 && params->scan_lines * params->scan_regions * (params->edges_per_region + 1) >= 8192) ? kLmGroupsMax : 1)
+                                           : (config->lm_workgroups >= kLmGroupsMax ? kLmGroupsMax : 1);
   v.vox_inv = 1.0f / 0.4f;                                                          // setLeafSize(0.4) :290
   v.n_streams = h->S;
   v.max_points = config->max_points;
@@ -385,6 +391,7 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   ALLOC(v.info_log, S * v.pose_log_cap, 0);
   ALLOC(h->stage_in, S * (size_t)config->max_points, 0);
   ALLOC(v.dbg_clk, 8 * 32, 0);
+  ALLOC(v.lm_xch, S * 2 * kLmGroupsMax * 64, 0);
   {
     void* hp = nullptr;
     if (hipHostMalloc(&hp, sizeof(HostOut) * S, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { g_last_error = "hipHostMalloc failed"; return fail(LIODOM_ERR_HIP); }

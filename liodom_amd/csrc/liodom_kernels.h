@@ -31,6 +31,7 @@ namespace liodom_dev {
 constexpr int kWave = 64;
 constexpr uint64_t kEmptyKey = 0xFFFFFFFFFFFFFFFFull;
 constexpr int kLmThreads = 512;
+constexpr int kLmGroupsMax = 8;
 constexpr int kKnnGroup = 32;            // lanes cooperating on one query
 constexpr int kMaxFrames = 256;          // window frames supported by the LDS prefix tables
 
@@ -88,6 +89,7 @@ struct DevView {
   int prev_frames;
   int apply_on_ftol;
   int filter_local_map;     // params.filter_local_map_ (and !mapping_)
+  int lm_groups;            // workgroups cooperating on one stream's solve (1 or kLmGroupsMax)
   float vox_inv;            // 1.0f / 0.4f as PCL computes inverse_leaf_size_
   // capacities
   int n_streams, max_points, ring_cap, slots_per_ring, edge_cap, map_cap, table_size;
@@ -132,6 +134,7 @@ struct DevView {
   int* vox_pts;             // [S][map_cap] window indices grouped by voxel, ascending inside a voxel
   float4* filt_pts;         // [S][map_cap] centroid xyz + voxel-index bits
   float* filt_int;          // [S][map_cap] centroid intensity
+  unsigned long long* lm_xch;   // [S][2][kLmGroupsMax][64] tagged granules: partial sums exchanged between the LM workgroups
   unsigned long long* dbg_clk;  // [8][32] phase timestamps (100 MHz), debug bit 5 only
 };
 
@@ -875,12 +878,12 @@ __global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int oute
 // =============================================================================================
 // Indices of the edges with an accepted correspondence, in edge order (deterministic), built once
 // per solve in LDS so that every evaluation runs over C dense items instead of E sparse ones.
-__device__ int lm_compact(const DevView& v, int s, int E, int* idx /*LDS [edge_cap]*/, int* wtot /*LDS [4 * 8]*/) {
+__device__ int lm_compact(const DevView& v, int s, int e_begin, int E, int* idx /*LDS [edge_cap]*/, int* wtot /*LDS [4 * 8]*/) {
   const float4* ca = v.corr_a + (size_t)s * v.edge_cap;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   constexpr int NW = kLmThreads / 64;
   int run = 0;
-  for (int base = 0; base < E; base += 4 * kLmThreads) {     // 4 chunks per barrier
+  for (int base = e_begin; base < E; base += 4 * kLmThreads) {     // 4 chunks per barrier
     int f[4], incl[4];
 #pragma unroll
     for (int b = 0; b < 4; b++) {
@@ -1041,17 +1044,59 @@ __device__ void finalize_scan(const DevView& v, int s, StreamState& st, int* sh_
   hash_clear_used(v, s, nup, tid, (int)blockDim.x);
 }
 
+// All-to-all exchange of the 29 partial sums between the G workgroups of a stream, inside the
+// launch (MI355X guide, G16 form R2: the data is the flag).  Every double travels as two 8-byte
+// granules {epoch tag, 32 data bits} written and read with relaxed agent-scope atomics (sc1, L2
+// write-through / L1 bypass): no fences, no separate flag, placement independent.  Buffers are
+// double-buffered by epoch parity (a workgroup cannot publish epoch e+2 before it has read every
+// epoch e+1, which the others publish only after reading epoch e).  Every workgroup adds the G
+// partials in the same order and so continues with bit-identical totals.  Spins are bounded.
+__device__ void lm_exchange(const DevView& v, int s, int g, int G, unsigned int epoch,
+                            const double* acc_local, double* acc_total, unsigned int* status) {
+  typedef __attribute__((address_space(1))) unsigned long long gu64;
+  unsigned long long* base = v.lm_xch + ((size_t)s * 2 + (epoch & 1u)) * kLmGroupsMax * 64;
+  const int tid = threadIdx.x;
+  if (tid < 2 * kAccN) {
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(acc_local[tid >> 1]);
+    const unsigned long long half = (tid & 1) ? (bits >> 32) : (bits & 0xFFFFFFFFull);
+    __hip_atomic_store((gu64*)(base + g * 64 + tid), ((unsigned long long)epoch << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (tid < 64) {
+    double tot = 0.0;
+    unsigned int spins = 0;
+    while (true) {
+      bool ok = true;
+      tot = 0.0;
+      if (tid < kAccN) {
+        for (int gg = 0; gg < G; gg++) {
+          const unsigned long long lo = __hip_atomic_load((gu64*)(base + gg * 64 + 2 * tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned long long hi = __hip_atomic_load((gu64*)(base + gg * 64 + 2 * tid + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = ok && ((unsigned int)(lo >> 32) == epoch) && ((unsigned int)(hi >> 32) == epoch);
+          tot += __longlong_as_double((long long)((hi << 32) | (lo & 0xFFFFFFFFull)));
+        }
+      }
+      if (__all(ok)) break;
+      if (++spins > 4000000u) { if (tid == 0) atomicOr(status, LIODOM_STATUS_LM_SYNC_TIMEOUT); break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (tid < kAccN) acc_total[tid] = tot;
+  }
+  __syncthreads();
+}
+
 __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int outer_it, int eb) {
   __shared__ double sh_pose[12];
   __shared__ double sh_part[(kLmThreads / 16) * kAccN];
   __shared__ double sh_acc[kAccN];
   __shared__ LmState lm;
   __shared__ int sh_flag;
-  const int s = s0 + blockIdx.x;
+  const int s = s0 + blockIdx.y;
+  const int g = blockIdx.x, G = gridDim.x;      // G cooperating workgroups per stream
   StreamState& st = v.state[s];
   __shared__ int sh_cnt[kMaxFrames + 1];
+  __shared__ double sh_loc[kAccN];
   extern __shared__ __attribute__((aligned(16))) int sh_idx[];   // [edge_cap] compacted correspondence indices
-  if (outer_it == 0 && threadIdx.x == 0) {     // per-scan diagnostics (matches are counted by k_knn)
+  if (outer_it == 0 && threadIdx.x == 0 && g == 0) {     // per-scan diagnostics (matches are counted by k_knn)
     st.info.n_edges = st.n_edges_buf[eb];
     st.info.map_points = st.n_search;
     for (int k = 0; k < 2; k++) {
@@ -1061,22 +1106,29 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
   }
   if (!st.initialized) {
     // first frame (:108-136): no solve; pose stays identity, edges enter the window raw
-    if (outer_it == 1) {
+    if (outer_it == 1 && g == 0) {
       if (threadIdx.x == 0) st.append_raw = 1;
       finalize_scan(v, s, st, sh_cnt, eb);
       if (threadIdx.x == 0) st.initialized = 1;
     }
     return;
   }
-  const bool dbgb = (s == 0) && (threadIdx.x == 0) && (outer_it == 1);
+  const bool dbgb = (s == 0) && (g == 0) && (threadIdx.x == 0) && (outer_it == 1);
   DBG_STAMP(v, dbgb, 2, 0);
   const int E = st.n_edges_buf[eb];
   const int nblocks = st.info.matches[outer_it];
   if (threadIdx.x == 0) iso_from_qt(st.param_q, st.param_t, sh_pose);
-  const int C = lm_compact(v, s, E, sh_idx, sh_cnt);   // (ends with a barrier; sh_cnt doubles as scratch)
+  // this workgroup's contiguous share of the edges
+  const int chunk = (E + G - 1) / G;
+  const int e_lo = g * chunk < E ? g * chunk : E;
+  const int e_hi = (g + 1) * chunk < E ? (g + 1) * chunk : E;
+  const unsigned int epoch0 = ((unsigned int)(st.scan_counter + 1) << 6) | ((unsigned int)outer_it << 5);
+  unsigned int n_eval = 0;
+  const int C = lm_compact(v, s, e_lo, e_hi, sh_idx, sh_cnt);   // (ends with a barrier; sh_cnt doubles as scratch)
   __syncthreads();
   DBG_STAMP(v, dbgb, 2, 1);
-  lm_eval(v, s, eb, C, sh_idx, sh_pose, sh_part, sh_acc);
+  if (G > 1) { lm_eval(v, s, eb, C, sh_idx, sh_pose, sh_part, sh_loc); lm_exchange(v, s, g, G, epoch0 | ++n_eval, sh_loc, sh_acc, &st.status); }
+  else lm_eval(v, s, eb, C, sh_idx, sh_pose, sh_part, sh_acc);
   DBG_STAMP(v, dbgb, 2, 2);
   if (threadIdx.x == 0) {
     sh_flag = lm_begin(lm, st.param_q, st.param_t, sh_acc, nblocks, v.apply_on_ftol);
@@ -1086,7 +1138,8 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
   DBG_STAMP(v, dbgb, 2, 3);
   int dbg_it = 0;
   while (sh_flag == LM_NEED_EVAL && !(v.debug & 8)) {
-    lm_eval(v, s, eb, C, sh_idx, sh_pose, sh_part, sh_acc);
+    if (G > 1) { lm_eval(v, s, eb, C, sh_idx, sh_pose, sh_part, sh_loc); lm_exchange(v, s, g, G, epoch0 | ++n_eval, sh_loc, sh_acc, &st.status); }
+    else lm_eval(v, s, eb, C, sh_idx, sh_pose, sh_part, sh_acc);
     DBG_STAMP(v, dbgb && dbg_it < 5, 2, 4 + 2 * dbg_it);
     if (threadIdx.x == 0) {
       sh_flag = lm_update(lm, sh_acc);
@@ -1097,6 +1150,7 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
     dbg_it++;
   }
   DBG_STAMP(v, dbgb, 2, 20);
+  if (g != 0) return;        // every workgroup reached the same result; workgroup 0 records it
   if (threadIdx.x == 0) {
     for (int k = 0; k < 4; k++) st.param_q[k] = lm.q[k];
     for (int k = 0; k < 3; k++) st.param_t[k] = lm.t[k];

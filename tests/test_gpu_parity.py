@@ -264,6 +264,23 @@ def test_filter_local_map_voxelgrid(orc, synth):
     g.close()
 
 
+def test_multi_workgroup_solve(orc, synth):
+    # lm_workgroups = 8: the solve is split over 8 CUs exchanging partial sums inside the launch
+    H, W, R, epr, P, K = 16, 900, 6, 10, 5, 10
+    cfg = synth.make_cfg(H, W, 0)
+    po, g8 = mk(orc, H, W, 0, R, epr, P, lm_workgroups=8)
+    od = orc.Odometer(po)
+    for k in range(K):
+        x, _ = synth.scan(cfg, 0, k)
+        pose_o, info_o = od.step(orc.extract(po, x, H, W)["edges"])
+        pose_g, info_g = g8.process_scan(x, H, W)
+        assert np.linalg.norm(pose_g[4:] - pose_o[4:]) <= POSE_TOL_T and rot_angle(pose_g[:4], pose_o[:4]) <= POSE_TOL_R
+        assert not (info_g.status & 8)
+        if k > 0:
+            assert [info_g.lm[0].iterations, info_g.lm[1].iterations] == [info_o.lm[0].iterations, info_o.lm[1].iterations]
+    g8.close()
+
+
 def test_pipelined_replay_equals_serial(orc, synth):
     # extraction of scan k+1 on the second stream while odometry k runs: same poses, bit for bit
     H, W, R, epr, P, K = 16, 900, 6, 10, 5, 12
