@@ -41,7 +41,11 @@ WORKLOADS = {
 
 def algorithmic_bytes(kernel, N, E, M, C, evals):
     """SURVEY.md §8(d) per-scan figures, per launch of `kernel` for one stream."""
-    if kernel in ("k_ring_extract", "k_classify"):
+    if kernel == "k_classify":
+        return 17.0 * N                       # 16 B/point read, 1 id byte written
+    if kernel == "k_ring_scatter":
+        return 37.0 * N                       # 16 B + id read, 16 B + 4 B source index written
+    if kernel == "k_ring_extract":
         return 16.0 * N + 24.0 * E            # extract: 16 B/point read, 24 B/edge written
     if kernel == "k_knn":
         return 16.0 * (M + E) + 28.0 * E      # one kNN pass: map + queries read, (a, b, flag) written
@@ -90,6 +94,9 @@ def roofline_from_stats(stats, n_streams, N, E, M, C, evals):
         "avg_kernel_us": round(avg_s * 1e6, 2), "algorithmic_bytes_per_launch": int(by),
         "share_of_gpu_time": round(ms / tot, 3),
         "per_kernel_us": {k: round(v[1] / max(v[0], 1) * 1e3, 2) for k, v in stats.items() if v[0]},
+        # every kernel against the same roof: algorithmic GB/s and fraction of the 8 TB/s peak
+        "per_kernel_frac": {k: round(algorithmic_bytes(k, N, E, M, C, evals) * n_streams / (v[1] / v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+                            for k, v in stats.items() if v[0] and v[1] > 0 and algorithmic_bytes(k, N, E, M, C, evals) > 0},
     }
 
 

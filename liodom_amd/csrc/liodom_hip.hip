@@ -68,6 +68,7 @@ struct liodom_handle {
   std::vector<void*> allocs;
   // profiling
   bool profiling = false;
+  bool lds_hash_build = false;  // k_hash_build (one workgroup per stream, LDS) instead of the 3 global-atomic kernels
   std::vector<EventPair> ev_pool;
   size_t ev_used = 0;
   double k_ms[LIODOM_NUM_KERNELS] = {0};
@@ -170,27 +171,41 @@ int launch_odometry(liodom_handle* h, int eb, int s0, int count) {
   h->last_eb = eb;       // results are published by k_lm_solve into host-mapped memory (HostOut)
   for (int i = 0; i < count; i++) h->scans_enqueued[s0 + i]++;
   const int map_blocks = cdiv(h->v.map_cap, 256);
-  {
-    ProfScope ps(h, KID_WINDOW_INSERT);
-    hipLaunchKernelGGL(k_window_insert, dim3(map_blocks, count), dim3(256), 0, h->stream, v, s0, eb);
+  if (h->lds_hash_build) {
+    ProfScope ps(h, KID_WINDOW_INSERT);     // window append + LDS-built cell hash, one workgroup per stream
+    hipLaunchKernelGGL(k_hash_build, dim3(count), dim3(kBuildThreads), hash_build_lds_bytes(), h->stream, v, s0, eb);
+  } else {
+    {
+      ProfScope ps(h, KID_WINDOW_INSERT);   // window append + cell hash in global memory, map_blocks workgroups per stream
+      hipLaunchKernelGGL(k_window_insert, dim3(map_blocks, count), dim3(256), 0, h->stream, v, s0, eb);
+    }
+    {
+      ProfScope ps(h, KID_HASH_ALLOC);
+      hipLaunchKernelGGL(k_hash_alloc, dim3(map_blocks, count), dim3(256), 0, h->stream, v, s0);
+    }
+    {
+      ProfScope ps(h, KID_HASH_SCATTER);
+      hipLaunchKernelGGL(k_hash_scatter, dim3(map_blocks, count), dim3(256), 0, h->stream, v, s0);
+    }
   }
   if (v.filter_local_map) {     // VoxelGrid(0.4) of the full window (every kernel exits unless the window is full)
-    ProfScope ps(h, KID_OTHER);
-    hipLaunchKernelGGL(k_voxel_bbox, dim3(count), dim3(1024), 0, h->stream, v, s0);
-    hipLaunchKernelGGL(k_voxel_insert, dim3(map_blocks, count), dim3(256), 0, h->stream, v, s0);
-    hipLaunchKernelGGL(k_voxel_alloc, dim3(map_blocks, count), dim3(256), 0, h->stream, v, s0);
-    hipLaunchKernelGGL(k_voxel_scatter, dim3(map_blocks, count), dim3(256), 0, h->stream, v, s0);
-    hipLaunchKernelGGL(k_voxel_centroid, dim3(cdiv(h->v.map_cap, 8), count), dim3(256), 0, h->stream, v, s0);
-    hipLaunchKernelGGL(k_filt_insert, dim3(map_blocks, count), dim3(256), 0, h->stream, v, s0);
-  }
-  {
-    ProfScope ps(h, KID_HASH_ALLOC);
-    hipLaunchKernelGGL(k_hash_alloc, dim3(map_blocks, count), dim3(256), 0, h->stream, v, s0);
-  }
-  {
-    ProfScope ps(h, KID_HASH_SCATTER);
-    hipLaunchKernelGGL(k_hash_scatter, dim3(map_blocks, count), dim3(256), 0, h->stream, v, s0);
-    if (v.filter_local_map) hipLaunchKernelGGL(k_filt_scatter, dim3(map_blocks, count), dim3(256), 0, h->stream, v, s0);
+    {
+      ProfScope ps(h, KID_OTHER);
+      hipLaunchKernelGGL(k_voxel_bbox, dim3(count), dim3(1024), 0, h->stream, v, s0);
+      hipLaunchKernelGGL(k_voxel_insert, dim3(map_blocks, count), dim3(256), 0, h->stream, v, s0);
+      hipLaunchKernelGGL(k_voxel_alloc, dim3(map_blocks, count), dim3(256), 0, h->stream, v, s0);
+      hipLaunchKernelGGL(k_voxel_scatter, dim3(map_blocks, count), dim3(256), 0, h->stream, v, s0);
+      hipLaunchKernelGGL(k_voxel_centroid, dim3(cdiv(h->v.map_cap, 8), count), dim3(256), 0, h->stream, v, s0);
+      hipLaunchKernelGGL(k_filt_insert, dim3(map_blocks, count), dim3(256), 0, h->stream, v, s0);
+    }
+    {
+      ProfScope ps(h, KID_HASH_ALLOC);
+      hipLaunchKernelGGL(k_filt_alloc, dim3(map_blocks, count), dim3(256), 0, h->stream, v, s0);
+    }
+    {
+      ProfScope ps(h, KID_HASH_SCATTER);
+      hipLaunchKernelGGL(k_filt_scatter, dim3(map_blocks, count), dim3(256), 0, h->stream, v, s0);
+    }
   }
   HIP_TRY(hipGetLastError());
   return LIODOM_OK;
@@ -217,11 +232,14 @@ int drain_pipeline(liodom_handle* h) {
 
 // Extraction of resident slot `slot` into edge buffer `eb` on the extraction stream.
 int issue_extract(liodom_handle* h, int slot, int eb, int n, int height, int width) {
-  if (h->ev_free_valid[eb]) HIP_TRY(hipStreamWaitEvent(h->stream_x, h->ev_free[eb], 0));
+  // while per-kernel profiling is on, everything runs on one stream so that the HIP-event
+  // durations are not inflated by kernels of the other stream sharing the GPU
+  hipStream_t q = h->profiling ? h->stream : h->stream_x;
+  if (h->ev_free_valid[eb]) HIP_TRY(hipStreamWaitEvent(q, h->ev_free[eb], 0));
   const float4* in = h->resident + (size_t)slot * h->S * (size_t)h->v.max_points;
-  int rc = launch_extract(h, h->stream_x, eb, 0, h->S, in, (size_t)h->v.max_points, n, height, width);
+  int rc = launch_extract(h, q, eb, 0, h->S, in, (size_t)h->v.max_points, n, height, width);
   if (rc) return rc;
-  HIP_TRY(hipEventRecord(h->ev_edges[eb], h->stream_x));
+  HIP_TRY(hipEventRecord(h->ev_edges[eb], q));
   return LIODOM_OK;
 }
 
@@ -231,6 +249,7 @@ int reset_state(liodom_handle* h) {
     std::memset(&st, 0, sizeof(st));
     iso_identity(st.odom); iso_identity(st.prev_odom); iso_identity(st.final_odom);
     st.param_q[3] = 1.0;
+    st.table_mask = (uint32_t)h->v.table_size - 1u;
   }
   HIP_TRY(hipMemcpyAsync(h->v.state, init.data(), sizeof(StreamState) * init.size(), hipMemcpyHostToDevice, h->stream));
   {
@@ -326,6 +345,11 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   v.filter_local_map = (params->filter_local_map && !params->mapping) ? 1 : 0;   // laser_odometry.cc:286
   // auto: several CUs per solve pay off only when one CU would spend >> the ~4.5 us in-launch
   // exchange on an evaluation (measured: ~2000 edges -> no gain; Ouster-128 shape -> yes)
+  // Measured on MI355X (headline shape): one stream rebuilds its hash in 28 us with the three
+  // global-atomic kernels (many workgroups) but needs 86 us as a single LDS workgroup; 64 lock-step
+  // streams need 247 us (L2-atomic bound) against 103 us with one LDS workgroup each.
+  h->lds_hash_build = config->n_streams >= 16;
+  if (const char* e = std::getenv("LIODOM_HASH_BUILD")) h->lds_hash_build = std::strcmp(e, "global") != 0;
   v.lm_groups = config->lm_workgroups == 0 ? ((config->n_streams <= 4 && params->scan_lines * params->scan_regions * (params->edges_per_region + 1) >= 8192) ? kLmGroupsMax : 1)
                                            : (config->lm_workgroups >= kLmGroupsMax ? kLmGroupsMax : 1);
   v.vox_inv = 1.0f / 0.4f;                                                          // setLeafSize(0.4) :290
@@ -373,7 +397,7 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   ALLOC(v.win_base, S * (h->P + 1), 0);
   ALLOC(v.win_slot, S * h->P, 0);
   ALLOC(v.cells, S * v.table_size, 0);
-  ALLOC(v.cell_fill, S * v.table_size, 0);
+  ALLOC(v.pt_rank, S * v.map_cap, 0);
   ALLOC(v.cell_bits, S * (size_t)(v.table_size / 32), 0);
   ALLOC(v.used_cells, S * v.map_cap, 0);
   ALLOC(v.pt_cell, S * v.map_cap, 0xFF);
@@ -407,6 +431,10 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
                             (int)ring_scatter_lds_bytes(h->H)) != hipSuccess) {
       g_last_error = "hipFuncSetAttribute(max dynamic LDS) failed"; return fail(LIODOM_ERR_HIP);
     }
+  }
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hash_build), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)hash_build_lds_bytes()) != hipSuccess) {
+    g_last_error = "hipFuncSetAttribute(max dynamic LDS) failed"; return fail(LIODOM_ERR_HIP);
   }
   if (h->ring_lds_bytes > 48 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ring_extract), hipFuncAttributeMaxDynamicSharedMemorySize,

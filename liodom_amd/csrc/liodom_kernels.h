@@ -54,6 +54,7 @@ struct StreamState {
   int32_t scan_counter;
   uint32_t status;
   int32_t n_search;       // points covered by the kNN structure (window or filtered local map)
+  uint32_t table_mask;    // slots - 1 of the cell hash currently in v.cells (LDS-built tables are smaller)
   // filter_local_map (laser_odometry.cc:286-292): VoxelGrid(0.4) of the full window
   int32_t n_filt;         // filtered points (0 when the kNN structure holds the raw window)
   int32_t vox_used;       // occupied voxels of the current voxel-grid build
@@ -118,7 +119,7 @@ struct DevView {
   int* win_base;            // [S][P+1] logical prefix (oldest first)
   int* win_slot;            // [S][P]  logical frame -> slot
   CellSlot* cells;          // [S][table_size]  {key, start, cnt}: one 16-B load per probe
-  unsigned int* cell_fill;  // [S][table_size]  scatter cursor per cell
+  int* pt_rank;  // [S][map_cap]  rank of each point inside its cell (old value of the count atomic)
   unsigned int* cell_bits;  // [S][table_size/32] occupancy bitmap: empty-cell probes stay in a 32 KB array
   int* used_cells;          // [S][map_cap]
   int* pt_cell;             // [S][map_cap]
@@ -760,7 +761,7 @@ __global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int oute
   if (hl == 0) { s_res[grp][0] = 0; s_res[grp][1] = -1; s_res[grp][2] = -1; }
   if (active) {                                    // uniform over each 32-lane half
     const int cx = (int)floorf(qx), cy = (int)floorf(qy), cz = (int)floorf(qz);
-    const unsigned int tmask = (unsigned int)v.table_size - 1u;
+    const unsigned int tmask = st.table_mask;
     const CellSlot* cells = v.cells + (size_t)s * v.table_size;
     const unsigned int* bits = v.cell_bits + (size_t)s * (v.table_size >> 5);
     unsigned int start = 0, cnt = 0;
@@ -962,7 +963,6 @@ __device__ void hash_clear_used(const DevView& v, int s, int nup, int t, int nt)
       if (hh[k] >= 0) {
         const size_t ti = (size_t)s * v.table_size + hh[k];
         v.cells[ti] = empty;
-        v.cell_fill[ti] = 0;
         v.cell_bits[ti >> 5] = 0u;   // every set bit of that word belongs to a slot of this list
       }
     }
@@ -1177,7 +1177,6 @@ __global__ __launch_bounds__(256) void k_init_cells(DevView v) {
   if (i >= total) return;
   CellSlot empty; empty.key = kEmptyKey; empty.start = 0; empty.cnt = 0;
   v.cells[i] = empty;
-  v.cell_fill[i] = 0;
   if ((i & 31) == 0) v.cell_bits[i >> 5] = 0u;
   if (v.vox_cells) { v.vox_cells[i] = empty; v.vox_fill[i] = 0; }
 }
@@ -1191,7 +1190,6 @@ __global__ __launch_bounds__(256) void k_hash_clear(DevView v, int s0) {
   const size_t ti = (size_t)s * v.table_size + h;
   CellSlot empty; empty.key = kEmptyKey; empty.start = 0; empty.cnt = 0;
   v.cells[ti] = empty;
-  v.cell_fill[ti] = 0;
   v.cell_bits[ti >> 5] = 0u;   // every set bit of that word belongs to a slot of this list
 }
 
@@ -1256,7 +1254,9 @@ __global__ __launch_bounds__(256) void k_window_insert(DevView v, int s0, int eb
     h = (h + 1) & tmask;
   }
   if (found < 0) { atomicOr(&st.status, LIODOM_STATUS_HASH_FULL); *pc = -1; return; }
-  atomicAdd(&cells[found].cnt, 1u);
+  // the value the count had before this point is its rank inside the cell: the scatter pass
+  // needs no second atomic (and no per-cell fill counter to keep clean)
+  v.pt_rank[(size_t)s * v.map_cap + m] = (int)atomicAdd(&cells[found].cnt, 1u);
   *pc = found;
 }
 
@@ -1289,27 +1289,24 @@ __global__ __launch_bounds__(256) void k_hash_scatter(DevView v, int s0) {
   while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (sbase[mid] <= m) lo = mid; else hi = mid; }
   const float4 pt = v.win_pts[((size_t)s * P + sslot[lo]) * v.edge_cap + (m - sbase[lo])];
   const size_t ti = (size_t)s * v.table_size + h;
-  const unsigned int pos = v.cells[ti].start + atomicAdd(&v.cell_fill[ti], 1u);
+  const unsigned int pos = v.cells[ti].start + (unsigned int)v.pt_rank[(size_t)s * v.map_cap + m];
   v.sorted_pts[(size_t)s * v.map_cap + pos] = make_float4(pt.x, pt.y, pt.z, __int_as_float(m));
 }
 
 
 // =============================================================================================
-// filter_local_map (computeLocalMap, laser_odometry.cc:286-292): when the window is full the
-// local map searched by the next scan is pcl::VoxelGrid(0.4 m) of the whole window — one float
-// centroid (x, y, z, intensity) per occupied leaf.  PCL sorts (leaf index, point) pairs and sums
-// each leaf's points in that order in float; here "that order" is ascending window index (the
-// oracle uses a stable sort; std::sort's order inside a leaf is unspecified in the reference).
-//   k_voxel_bbox      one workgroup per stream: clear the previous voxel table, min/max of the
-//                     window -> PCL's min_b_ / div_b_
-//   k_voxel_insert    leaf index per window point, atomicCAS/atomicAdd grouping (as the 1 m cells)
-//   k_voxel_alloc / k_voxel_scatter   window indices grouped by leaf
-//   k_voxel_centroid  half-wave per leaf: rank the leaf's window indices (ascending), then one
-//                     lane sums in that order -> deterministic, PCL's float accumulation
-//   k_filt_insert / k_hash_alloc / k_filt_scatter   1 m cell hash over the filtered points; the
-//                     tie-break index carried by the points is PCL's leaf index (= the rank order
-//                     of the filtered cloud)
-// Every kernel exits immediately unless filter_active().
+// k_hash_build: window append + complete rebuild of the 1 m cell hash by ONE workgroup per stream,
+// with LDS atomics.  The table of one stream is small (headline: ~3 500 occupied cells for 37 000
+// points), so an 8192-slot table {key u64, cnt u32, cursor u32} = 128 KiB fits the 160 KiB LDS of
+// a CU: slot claim (ds_cmpst_b64) and counting (ds_add) never leave the CU, the exclusive prefix
+// over the slots runs in place, points are scattered to cell-contiguous order with LDS cursors,
+// and the finished table is written out once (it replaces the previous one wholesale: nothing to
+// clear).  One launch instead of three, no L2 atomics: the multi-block version spent ~450 us on
+// 64 lock-step streams (L2-atomic bound), this one works on 64 CUs in parallel.
+// If more than kLdsCellsMax cells are occupied the workgroup falls back to the global-memory
+// table (full v.table_size, global atomics), which any map size fits.
+// With filter_local_map active only the new frame is stored here; the k_voxel_* / k_filt_*
+// kernels build the table from the filtered cloud.
 // =============================================================================================
 struct WinIndex {
   int sbase[kMaxFrames + 1];
@@ -1330,6 +1327,213 @@ __device__ __forceinline__ bool point_ok(const float4& p) {
          fabsf(p.x) < 1.0e9f && fabsf(p.y) < 1.0e9f && fabsf(p.z) < 1.0e9f;
 }
 
+constexpr int kLdsSlots = 8192;
+constexpr int kLdsCellsMax = 6144;
+constexpr int kBuildThreads = 1024;
+constexpr int kBuildUnroll = 4;
+__host__ __device__ __forceinline__ size_t hash_build_lds_bytes() { return (size_t)kLdsSlots * 16 + 64; }
+
+__device__ __forceinline__ float4 window_point_produce(const DevView& v, int s, const StreamState& st, int eb,
+                                                       const WinIndex& w, int nf, int m) {
+  int lo = 0, hi = nf;             // largest j with sbase[j] <= m
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (w.sbase[mid] <= m) lo = mid; else hi = mid; }
+  const int j = lo, idx = m - w.sbase[j];
+  float4* wp = v.win_pts + ((size_t)s * v.prev_frames + w.sslot[j]) * v.edge_cap + idx;
+  if (j != nf - 1) return *wp;
+  // newest frame: edges transformed by the solved pose in FP64, rounded to float (:231-232), stored (:235)
+  const float4 e = v.edges[((size_t)eb * v.n_streams + s) * v.edge_cap + idx];
+  float4 pt = e;
+  if (!st.append_raw) {
+    double T[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) T[i] = st.final_odom[i];
+    transform_point(T, e.x, e.y, e.z, &pt.x, &pt.y, &pt.z);
+    pt.w = e.w;
+  }
+  *wp = pt;
+  return pt;
+}
+
+__global__ __launch_bounds__(kBuildThreads) void k_hash_build(DevView v, int s0, int eb) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ WinIndex w;
+  __shared__ int sh_used, sh_over, sh_wtot[kBuildThreads / 64];
+  unsigned long long* lkey = reinterpret_cast<unsigned long long*>(smem);           // [kLdsSlots]
+  unsigned int* lcnt = reinterpret_cast<unsigned int*>(lkey + kLdsSlots);           // [kLdsSlots]
+  unsigned int* lstart = lcnt + kLdsSlots;                                          // [kLdsSlots]
+  const int s = s0 + blockIdx.x;
+  StreamState& st = v.state[s];
+  const int tid = threadIdx.x;
+  const int M = st.n_map, nf = st.n_frames;
+  const bool filt = filter_active(v, st);
+  win_index_load(v, s, nf, w, tid, kBuildThreads);
+  if (tid == 0) { sh_used = 0; sh_over = 0; }
+  if (!filt) for (int i = tid; i < kLdsSlots; i += kBuildThreads) { lkey[i] = kEmptyKey; lcnt[i] = 0; }
+  __syncthreads();
+  CellSlot* cells = v.cells + (size_t)s * v.table_size;
+  unsigned int* bits = v.cell_bits + (size_t)s * (v.table_size >> 5);
+  int* pcell = v.pt_cell + (size_t)s * v.map_cap;
+  int* prank = v.pt_rank + (size_t)s * v.map_cap;
+  if (filt) {
+    // store the new frame only; hand a clean global table to the filtered-cloud build
+    const int first_new = w.sbase[nf - 1];
+    for (int m = first_new + tid; m < M; m += kBuildThreads) (void)window_point_produce(v, s, st, eb, w, nf, m);
+    if (st.table_mask != (unsigned int)v.table_size - 1u) {
+      CellSlot empty; empty.key = kEmptyKey; empty.start = 0; empty.cnt = 0;
+      for (int i = tid; i < kLdsSlots; i += kBuildThreads) { cells[i] = empty; }
+      for (int i = tid; i < kLdsSlots / 32; i += kBuildThreads) bits[i] = 0u;
+      __syncthreads();
+      if (tid == 0) { st.table_mask = (unsigned int)v.table_size - 1u; st.n_used = 0; }
+    }
+    return;
+  }
+  // ---- insert + count in LDS (kBuildUnroll point loads in flight per thread) ----
+  const unsigned int lmask = kLdsSlots - 1;
+  for (int m0 = tid; m0 < M; m0 += kBuildUnroll * kBuildThreads) {
+    float4 pt[kBuildUnroll];
+#pragma unroll
+    for (int k = 0; k < kBuildUnroll; k++) {
+      const int m = m0 + k * kBuildThreads;
+      if (m < M) pt[k] = window_point_produce(v, s, st, eb, w, nf, m);
+    }
+#pragma unroll
+    for (int k = 0; k < kBuildUnroll; k++) {
+      const int m = m0 + k * kBuildThreads;
+      if (m >= M) continue;
+      int found = -1;
+      if (point_ok(pt[k])) {
+        const unsigned long long key = pack_cell((int)floorf(pt[k].x), (int)floorf(pt[k].y), (int)floorf(pt[k].z));
+        unsigned int h = hash_cell(key, lmask);
+        for (int probe = 0; probe < kLdsSlots; probe++) {
+          const unsigned long long prev = atomicCAS(&lkey[h], kEmptyKey, key);
+          if (prev == kEmptyKey) { if (atomicAdd(&sh_used, 1) >= kLdsCellsMax) sh_over = 1; found = (int)h; break; }
+          if (prev == key) { found = (int)h; break; }
+          if (*(volatile int*)&sh_over) break;      // the global-table fallback redoes everything
+          h = (h + 1) & lmask;
+        }
+        if (found >= 0) prank[m] = (int)atomicAdd(&lcnt[found], 1u);   // rank inside the cell
+      }
+      pcell[m] = found;
+    }
+  }
+  __syncthreads();
+  if (sh_over) {
+    // ---- fallback: too many occupied cells for the LDS table -> global table, global atomics ----
+    CellSlot empty; empty.key = kEmptyKey; empty.start = 0; empty.cnt = 0;
+    if (st.table_mask != (unsigned int)v.table_size - 1u) {
+      for (int i = tid; i < kLdsSlots; i += kBuildThreads) { cells[i] = empty; }
+      for (int i = tid; i < kLdsSlots / 32; i += kBuildThreads) bits[i] = 0u;
+    }
+    __syncthreads();
+    if (tid == 0) { st.table_mask = (unsigned int)v.table_size - 1u; st.n_used = 0; st.cursor = 0; st.n_search = M; st.n_filt = 0; }
+    __syncthreads();
+    const unsigned int gmask = (unsigned int)v.table_size - 1u;
+    for (int m = tid; m < M; m += kBuildThreads) {
+      const float4 pt = win_point(v, s, nf, w, m);
+      int found = -1;
+      if (point_ok(pt)) {
+        const unsigned long long key = pack_cell((int)floorf(pt.x), (int)floorf(pt.y), (int)floorf(pt.z));
+        unsigned int h = hash_cell(key, gmask);
+        for (int probe = 0; probe < v.table_size; probe++) {
+          const unsigned long long prev = atomicCAS(&cells[h].key, kEmptyKey, key);
+          if (prev == kEmptyKey) {
+            const int u = atomicAdd(&st.n_used, 1);
+            v.used_cells[(size_t)s * v.map_cap + u] = (int)h;
+            atomicOr(&bits[h >> 5], 1u << (h & 31));
+            found = (int)h;
+            break;
+          }
+          if (prev == key) { found = (int)h; break; }
+          h = (h + 1) & gmask;
+        }
+        if (found >= 0) prank[m] = (int)atomicAdd(&cells[found].cnt, 1u);
+        else atomicOr(&st.status, LIODOM_STATUS_HASH_FULL);
+      }
+      pcell[m] = found;
+    }
+    __threadfence();
+    __syncthreads();
+    const int nu = *(volatile int*)&st.n_used;
+    for (int u = tid; u < nu; u += kBuildThreads) {
+      CellSlot* slot = cells + v.used_cells[(size_t)s * v.map_cap + u];
+      slot->start = (unsigned int)atomicAdd(&st.cursor, (int)*(volatile unsigned int*)&slot->cnt);
+    }
+    __threadfence();
+    __syncthreads();
+    for (int m = tid; m < M; m += kBuildThreads) {
+      const int h = pcell[m];
+      if (h < 0) continue;
+      const float4 pt = win_point(v, s, nf, w, m);
+      const unsigned int pos = *(volatile unsigned int*)&cells[h].start + (unsigned int)prank[m];
+      v.sorted_pts[(size_t)s * v.map_cap + pos] = make_float4(pt.x, pt.y, pt.z, __int_as_float(m));
+    }
+    return;
+  }
+  // ---- exclusive prefix of the counts over the slots (8 consecutive slots per thread) ----
+  {
+    constexpr int PER = kLdsSlots / kBuildThreads;   // 8
+    unsigned int c[PER];
+    int sum = 0;
+#pragma unroll
+    for (int k = 0; k < PER; k++) { c[k] = lcnt[tid * PER + k]; sum += (int)c[k]; }
+    const int incl = wave_incl_scan_i32(sum);
+    if ((tid & 63) == 63) sh_wtot[tid >> 6] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int q = 0; q < (tid >> 6); q++) base += sh_wtot[q];
+    int run = base + incl - sum;
+#pragma unroll
+    for (int k = 0; k < PER; k++) { lstart[tid * PER + k] = (unsigned int)run; run += (int)c[k]; }
+  }
+  __syncthreads();
+  // ---- scatter to cell-contiguous order: position = start of the cell + rank of the point ----
+  for (int m0 = tid; m0 < M; m0 += kBuildUnroll * kBuildThreads) {
+    float4 pt[kBuildUnroll];
+    int hc[kBuildUnroll], rk[kBuildUnroll];
+#pragma unroll
+    for (int k = 0; k < kBuildUnroll; k++) {
+      const int m = m0 + k * kBuildThreads;
+      hc[k] = -1;
+      if (m < M) { hc[k] = pcell[m]; rk[k] = prank[m]; pt[k] = win_point(v, s, nf, w, m); }
+    }
+#pragma unroll
+    for (int k = 0; k < kBuildUnroll; k++) {
+      if (hc[k] < 0) continue;
+      v.sorted_pts[(size_t)s * v.map_cap + lstart[hc[k]] + (unsigned int)rk[k]] =
+          make_float4(pt[k].x, pt[k].y, pt[k].z, __int_as_float(m0 + k * kBuildThreads));
+    }
+  }
+  // ---- publish the table: slots [0, 8192) of the stream's global table + occupancy bits ----
+  for (int i = tid; i < kLdsSlots; i += kBuildThreads) {
+    CellSlot o; o.key = lkey[i]; o.cnt = lcnt[i]; o.start = lstart[i];
+    cells[i] = o;
+  }
+  for (int i = tid; i < kLdsSlots / 32; i += kBuildThreads) {
+    unsigned int word = 0;
+#pragma unroll
+    for (int b = 0; b < 32; b++) word |= (lkey[i * 32 + b] != kEmptyKey) ? (1u << b) : 0u;
+    bits[i] = word;
+  }
+  if (tid == 0) { st.table_mask = lmask; st.n_used = 0; st.cursor = 0; st.n_search = M; st.n_filt = 0; }
+}
+
+// =============================================================================================
+// filter_local_map (computeLocalMap, laser_odometry.cc:286-292): when the window is full the
+// local map searched by the next scan is pcl::VoxelGrid(0.4 m) of the whole window — one float
+// centroid (x, y, z, intensity) per occupied leaf.  PCL sorts (leaf index, point) pairs and sums
+// each leaf's points in that order in float; here "that order" is ascending window index (the
+// oracle uses a stable sort; std::sort's order inside a leaf is unspecified in the reference).
+//   k_voxel_bbox      one workgroup per stream: clear the previous voxel table, min/max of the
+//                     window -> PCL's min_b_ / div_b_
+//   k_voxel_insert    leaf index per window point, atomicCAS/atomicAdd grouping (as the 1 m cells)
+//   k_voxel_alloc / k_voxel_scatter   window indices grouped by leaf
+//   k_voxel_centroid  half-wave per leaf: rank the leaf's window indices (ascending), then one
+//                     lane sums in that order -> deterministic, PCL's float accumulation
+//   k_filt_insert / k_hash_alloc / k_filt_scatter   1 m cell hash over the filtered points; the
+//                     tie-break index carried by the points is PCL's leaf index (= the rank order
+//                     of the filtered cloud)
+// Every kernel exits immediately unless filter_active().
+// =============================================================================================
 __global__ __launch_bounds__(1024) void k_voxel_bbox(DevView v, int s0) {
   __shared__ WinIndex w;
   __shared__ float red[6][16];
@@ -1534,8 +1738,18 @@ __global__ __launch_bounds__(256) void k_filt_insert(DevView v, int s0) {
     h = (h + 1) & tmask;
   }
   if (found < 0) { atomicOr(&st.status, LIODOM_STATUS_HASH_FULL); *pc = -1; return; }
-  atomicAdd(&cells[found].cnt, 1u);
+  v.pt_rank[(size_t)s * v.map_cap + u] = (int)atomicAdd(&cells[found].cnt, 1u);
   *pc = found;
+}
+
+__global__ __launch_bounds__(256) void k_filt_alloc(DevView v, int s0) {
+  const int s = s0 + blockIdx.y;
+  StreamState& st = v.state[s];
+  if (!filter_active(v, st)) return;
+  const int u = blockIdx.x * 256 + threadIdx.x;
+  if (u >= st.n_used) return;
+  CellSlot* slot = v.cells + (size_t)s * v.table_size + v.used_cells[(size_t)s * v.map_cap + u];
+  slot->start = (unsigned int)atomicAdd(&st.cursor, (int)slot->cnt);
 }
 
 __global__ __launch_bounds__(256) void k_filt_scatter(DevView v, int s0) {
@@ -1547,7 +1761,7 @@ __global__ __launch_bounds__(256) void k_filt_scatter(DevView v, int s0) {
   const int h = v.pt_cell[(size_t)s * v.map_cap + u];
   if (h < 0) return;
   const size_t ti = (size_t)s * v.table_size + h;
-  const unsigned int pos = v.cells[ti].start + atomicAdd(&v.cell_fill[ti], 1u);
+  const unsigned int pos = v.cells[ti].start + (unsigned int)v.pt_rank[(size_t)s * v.map_cap + u];
   v.sorted_pts[(size_t)s * v.map_cap + pos] = v.filt_pts[(size_t)s * v.map_cap + u];
 }
 
