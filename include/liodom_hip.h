@@ -189,6 +189,46 @@ int liodom_device_count(int* count);
 /* Device name and compute-unit count of the handle's GPU. */
 int liodom_device_info(liodom_handle_t* h, char* name, int name_cap, int* compute_units);
 
+
+/* ---- liodom::Map on the device (mapping node, src/map.cc, src/liodom_mapping_node.cc) ---- */
+typedef struct liodom_map liodom_map_t;
+typedef struct liodom_map_config_t {
+  int32_t device;              /* HIP device ordinal */
+  int32_t max_cells;           /* coarse cells the map can hold (cells_vector_) */
+  double voxel_xysize;         /* ~voxel_xysize, liodom_mapping_node.cc:115-117  default 40 */
+  double voxel_zsize;          /* ~voxel_zsize,  :119-121  default 50 */
+  double resolution;           /* ~resolution,   :123-125  default 0.4 */
+  int32_t cell_capacity;       /* points per cell (after filtering, and filtered + appended during an update) */
+  int32_t max_update_points;   /* points per updateMap call */
+  int32_t max_modified_cells;  /* cells touched by one updateMap call (<= 256) */
+  int32_t reserved;
+} liodom_map_config_t;
+/* status bits of liodom_map_status */
+#define LIODOM_MAP_UPDATE_OVERFLOW 1u
+#define LIODOM_MAP_CELLS_FULL 2u
+#define LIODOM_MAP_MODIFIED_FULL 4u
+#define LIODOM_MAP_CELL_OVERFLOW 8u
+#define LIODOM_MAP_LEAF_RANGE 16u
+#define LIODOM_MAP_KEY_RANGE 32u
+#define LIODOM_MAP_RESULT_OVERFLOW 64u
+
+void liodom_map_config_default(liodom_map_config_t* c);
+/* Map::Map (src/map.cc:70-81) */
+int liodom_map_create(const liodom_map_config_t* config, liodom_map_t** out);
+void liodom_map_destroy(liodom_map_t* m);
+/* Map::updateMap (src/map.cc:90-129): xyzi = n sensor-frame points (host), T = world<-sensor
+ * isometry as 12 doubles, row-major 3 x 4 (the Eigen::Isometry3d of liodom_mapping_node.cc:63-64). */
+int liodom_map_update(liodom_map_t* m, const float* xyzi, int64_t n, const double* T);
+/* Map::getLocalMap (src/map.cc:141-189) with the node's ~cells_xy / ~cells_z
+ * (liodom_mapping_node.cc:130-134, defaults 2 and 1).  Output order = the reference's loops. */
+int liodom_map_get_local(liodom_map_t* m, const double* T, int cells_xy, int cells_z, float* xyzi,
+                         int64_t cap, int64_t* n_points);
+/* Map::getMap (src/map.cc:131-139): every cell in creation order. */
+int liodom_map_get_all(liodom_map_t* m, float* xyzi, int64_t cap, int64_t* n_points);
+int liodom_map_num_cells(liodom_map_t* m, int* n_cells);
+/* Sticky LIODOM_MAP_* bits raised by the device since creation. */
+int liodom_map_status(liodom_map_t* m, uint32_t* status);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,7 +7,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 _LIB = os.path.join(_HERE, "lib", "libliodom_hip.so")
-_SRC = [os.path.join(_HERE, "csrc", f) for f in ("liodom_hip.hip", "liodom_kernels.h", "liodom_math.h")] + [
+_SRC = [os.path.join(_HERE, "csrc", f) for f in ("liodom_hip.hip", "liodom_kernels.h", "liodom_math.h", "wave_ops.h",
+                                                  "liodom_map.h", "liodom_map_host.h")] + [
     os.path.join(_ROOT, "include", "liodom_hip.h")]
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
@@ -69,6 +70,14 @@ class StepInfo(C.Structure):
 
 
 NUM_KERNELS = 11
+
+
+class MapConfig(C.Structure):
+    """liodom_map_config_t — the mapping node's parameters (liodom_mapping_node.cc:115-125) + capacities."""
+    _fields_ = [("device", C.c_int32), ("max_cells", C.c_int32),
+                ("voxel_xysize", C.c_double), ("voxel_zsize", C.c_double), ("resolution", C.c_double),
+                ("cell_capacity", C.c_int32), ("max_update_points", C.c_int32), ("max_modified_cells", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class KernelStat(C.Structure):
@@ -137,6 +146,21 @@ def load():
     L.liodom_device_count.argtypes = [ip]
     L.liodom_device_info.restype = C.c_int
     L.liodom_device_info.argtypes = [vp, C.c_char_p, C.c_int, ip]
+    i64p = C.POINTER(C.c_int64)
+    L.liodom_map_config_default.argtypes = [C.POINTER(MapConfig)]
+    L.liodom_map_create.restype = C.c_int
+    L.liodom_map_create.argtypes = [C.POINTER(MapConfig), C.POINTER(vp)]
+    L.liodom_map_destroy.argtypes = [vp]
+    L.liodom_map_update.restype = C.c_int
+    L.liodom_map_update.argtypes = [vp, fp, C.c_int64, dp]
+    L.liodom_map_get_local.restype = C.c_int
+    L.liodom_map_get_local.argtypes = [vp, dp, C.c_int, C.c_int, fp, C.c_int64, i64p]
+    L.liodom_map_get_all.restype = C.c_int
+    L.liodom_map_get_all.argtypes = [vp, fp, C.c_int64, i64p]
+    L.liodom_map_num_cells.restype = C.c_int
+    L.liodom_map_num_cells.argtypes = [vp, ip]
+    L.liodom_map_status.restype = C.c_int
+    L.liodom_map_status.argtypes = [vp, C.POINTER(C.c_uint32)]
     _lib = L
     return L
 
@@ -148,6 +172,8 @@ EXPORTED_SYMBOLS = [
     "liodom_reset", "liodom_get_edges", "liodom_get_window", "liodom_get_local_map", "liodom_get_correspondences", "liodom_get_curvature",
     "liodom_set_profiling", "liodom_get_kernel_stats", "liodom_reset_kernel_stats", "liodom_device_info",
     "liodom_device_count",
+    "liodom_map_config_default", "liodom_map_create", "liodom_map_destroy", "liodom_map_update", "liodom_map_get_local",
+    "liodom_map_get_all", "liodom_map_num_cells", "liodom_map_status",
 ]
 
 
@@ -336,3 +362,68 @@ class Liodom:
         cu = C.c_int32()
         self._check(self.L.liodom_device_info(self.h, buf, 256, C.byref(cu)))
         return buf.value.decode(), cu.value
+
+
+class Map:
+    """liodom::Map on the device (src/map.cc): updateMap / getLocalMap / getMap of the mapping node."""
+
+    def __init__(self, xy=40.0, z=50.0, res=0.4, **caps):
+        L = load()
+        c = MapConfig()
+        L.liodom_map_config_default(C.byref(c))
+        c.voxel_xysize, c.voxel_zsize, c.resolution = xy, z, res
+        for k, v in caps.items():
+            if not hasattr(c, k):
+                raise KeyError(k)
+            setattr(c, k, v)
+        self.h = C.c_void_p()
+        self._L = L
+        self._chk(L.liodom_map_create(C.byref(c), C.byref(self.h)))
+        self.result_capacity = 1 << 18
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise LiodomError("liodom_map error %d: %s" % (rc, (self._L.liodom_last_error() or b"").decode()))
+
+    def close(self):
+        if self.h:
+            self._L.liodom_map_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _T(T34):
+        return np.ascontiguousarray(np.eye(4)[:3] if T34 is None else T34, dtype=np.float64).reshape(12)
+
+    def update(self, xyzi, T34=None):
+        x = np.ascontiguousarray(xyzi, dtype=np.float32).reshape(-1, 4)
+        T = self._T(T34)
+        self._chk(self._L.liodom_map_update(self.h, _fp(x), x.shape[0], _dp(T)))
+
+    def local(self, T34=None, cells_xy=2, cells_z=1):
+        T = self._T(T34)
+        out = np.zeros((self.result_capacity, 4), dtype=np.float32)
+        n = C.c_int64(0)
+        self._chk(self._L.liodom_map_get_local(self.h, _dp(T), cells_xy, cells_z, _fp(out), out.shape[0], C.byref(n)))
+        return out[:n.value].copy()
+
+    def all(self):
+        out = np.zeros((self.result_capacity, 4), dtype=np.float32)
+        n = C.c_int64(0)
+        self._chk(self._L.liodom_map_get_all(self.h, _fp(out), out.shape[0], C.byref(n)))
+        return out[:n.value].copy()
+
+    def num_cells(self):
+        n = C.c_int32(0)
+        self._chk(self._L.liodom_map_num_cells(self.h, C.byref(n)))
+        return n.value
+
+    def status(self):
+        s = C.c_uint32(0)
+        self._chk(self._L.liodom_map_status(self.h, C.byref(s)))
+        return s.value

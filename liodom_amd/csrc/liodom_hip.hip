@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -42,6 +43,8 @@ const char* kKernelNames[LIODOM_NUM_KERNELS] = {
 struct EventPair { hipEvent_t a, b; int kid; };
 
 }  // namespace
+
+#include "liodom_map_host.h"
 
 struct liodom_handle {
   liodom_params_t params;
@@ -350,6 +353,8 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   // streams need 247 us (L2-atomic bound) against 103 us with one LDS workgroup each.
   h->lds_hash_build = config->n_streams >= 16;
   if (const char* e = std::getenv("LIODOM_HASH_BUILD")) h->lds_hash_build = std::strcmp(e, "global") != 0;
+  v.lds_cells_max = kLdsCellsMax;
+  if (const char* e = std::getenv("LIODOM_LDS_CELLS_MAX")) v.lds_cells_max = std::max(1, std::min(kLdsCellsMax, std::atoi(e)));
   v.lm_groups = config->lm_workgroups == 0 ? ((config->n_streams <= 4 && params->scan_lines * params->scan_regions * (params->edges_per_region + 1) >= 8192) ? kLmGroupsMax : 1)
                                            : (config->lm_workgroups >= kLmGroupsMax ? kLmGroupsMax : 1);
   v.vox_inv = 1.0f / 0.4f;                                                          // setLeafSize(0.4) :290

@@ -119,6 +119,7 @@ struct DevView {
   int* win_base;            // [S][P+1] logical prefix (oldest first)
   int* win_slot;            // [S][P]  logical frame -> slot
   CellSlot* cells;          // [S][table_size]  {key, start, cnt}: one 16-B load per probe
+  int lds_cells_max;   // occupied-cell limit of the LDS-built table (kLdsCellsMax; lowered by tests)
   int* pt_rank;  // [S][map_cap]  rank of each point inside its cell (old value of the count atomic)
   unsigned int* cell_bits;  // [S][table_size/32] occupancy bitmap: empty-cell probes stay in a 32 KB array
   int* used_cells;          // [S][map_cap]
@@ -1406,7 +1407,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_hash_build(DevView v, int s0,
         unsigned int h = hash_cell(key, lmask);
         for (int probe = 0; probe < kLdsSlots; probe++) {
           const unsigned long long prev = atomicCAS(&lkey[h], kEmptyKey, key);
-          if (prev == kEmptyKey) { if (atomicAdd(&sh_used, 1) >= kLdsCellsMax) sh_over = 1; found = (int)h; break; }
+          if (prev == kEmptyKey) { if (atomicAdd(&sh_used, 1) >= v.lds_cells_max) sh_over = 1; found = (int)h; break; }
           if (prev == key) { found = (int)h; break; }
           if (*(volatile int*)&sh_over) break;      // the global-table fallback redoes everything
           h = (h + 1) & lmask;

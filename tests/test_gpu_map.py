@@ -1,0 +1,131 @@
+"""Device liodom::Map (liodom_map_* of the C-ABI; src/map.cc rows A12-A14) against the CPU oracle's
+restatement: bit-exact clouds in the reference's output order."""
+import numpy as np
+import pytest
+
+import liodom_amd as la
+
+pytestmark = pytest.mark.gpu
+
+
+def P(*rows):
+    a = np.zeros((len(rows), 4), np.float32)
+    for i, r in enumerate(rows):
+        a[i, :len(r)] = r
+    return a
+
+
+def same(a, b):
+    return a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def pose(yaw, t):
+    T = np.eye(4)[:3].copy()
+    c, s = np.cos(yaw), np.sin(yaw)
+    T[:2, :2] = [[c, -s], [s, c]]
+    T[:, 3] = t
+    return T
+
+
+def test_cell_keys_and_voxel_merge(orc):
+    for pts in (P((-0.1, 0.1, 0.1, 1.0), (0.1, 0.1, 0.1, 2.0)),
+                P((1.0, 1.0, 1.0, 0.0), (1.1, 1.0, 1.0, 0.0))):
+        mo, mg = orc.Map(40.0, 50.0, 0.4), la.Map(40.0, 50.0, 0.4, max_cells=64, cell_capacity=4096)
+        mo.update(pts); mg.update(pts)
+        assert mg.num_cells() == mo.num_cells()
+        assert same(mg.all(), mo.all())
+        # a later update treats the centroid as ONE point; untouched cells are not re-filtered
+        for more in (P((1.15, 1.0, 1.0, 0.0),), P((100.0, 0.0, 0.0, 0.0),), P()):
+            mo.update(more); mg.update(more)
+            assert mg.num_cells() == mo.num_cells() and same(mg.all(), mo.all())
+        assert mg.status() == 0
+        mg.close()
+
+
+def test_get_local_map_quirks(orc):
+    pts = []
+    for cx in range(-3, 4):
+        for cy in range(-3, 4):
+            pts.append((cx * 40.0 + 20.0, cy * 40.0 + 20.0, 1.0, float((cx + 3) * 10 + cy + 3)))
+    mo, mg = orc.Map(40.0, 50.0, 0.4), la.Map(40.0, 50.0, 0.4, max_cells=128, cell_capacity=1024)
+    mo.update(P(*pts)); mg.update(P(*pts))
+    assert mg.num_cells() == 49
+    for t in ([0.9, -0.9, 0.5], [-0.9, 0.9, -0.5], [45.0, -41.0, 3.0], [-39.5, 80.2, 51.0], [1000.0, 0.0, 0.0]):
+        for cxy, cz in ((2, 1), (1, 0), (0, 2), (3, 1)):
+            T = pose(0.3, t)
+            assert same(mg.local(T, cxy, cz), mo.local(T, cxy, cz)), (t, cxy, cz)
+    assert same(mg.all(), mo.all())
+    mg.close()
+    # equal xy / z sizes: the z column hits real cells and the centre cell is appended twice (map.cc:175-186)
+    mo2, mg2 = orc.Map(40.0, 40.0, 0.4), la.Map(40.0, 40.0, 0.4, max_cells=64, cell_capacity=1024)
+    q = P((1.0, 1.0, 1.0, 7.0), (1.0, 1.0, 41.0, 8.0), (1.0, 1.0, -39.0, 9.0), (41.0, 1.0, 1.0, 10.0))
+    mo2.update(q); mg2.update(q)
+    loc = mg2.local(None, 2, 1)
+    assert same(loc, mo2.local(None, 2, 1)) and loc[:, 3].tolist().count(7.0) == 2
+    mg2.close()
+
+
+@pytest.mark.parametrize("sizes", [(40.0, 50.0, 0.4), (10.0, 10.0, 0.25), (25.0, 30.0, 0.3)])
+def test_random_updates_bit_exact(orc, sizes):
+    """Many updates of random clouds under moving poses: cells are created in first-appearance
+    order, leaves merge old centroids with several new points (float sums in cloud order)."""
+    rng = np.random.default_rng(7)
+    xy, z, res = sizes
+    mo = orc.Map(xy, z, res)
+    mg = la.Map(xy, z, res, max_cells=512, cell_capacity=32768, max_update_points=4096, max_modified_cells=128)
+    for k in range(25):
+        n = int(rng.integers(1, 3000))
+        # clustered points so that many share a leaf, some exactly on leaf / cell boundaries
+        centres = rng.uniform(-30, 30, size=(40, 3)) * [1, 1, 0.2]
+        pts = centres[rng.integers(0, 40, n)] + rng.normal(0, 0.35, size=(n, 3))
+        pts[: n // 20] = np.round(pts[: n // 20] / res) * res
+        x = np.zeros((n, 4), np.float32)
+        x[:, :3] = pts
+        x[:, 3] = rng.uniform(0, 100, n)
+        T = pose(0.02 * k, [0.8 * k, 0.1 * k, 0.01 * k])
+        mo.update(x, T); mg.update(x, T)
+        assert mg.num_cells() == mo.num_cells(), k
+        a, b = mg.all(), mo.all()
+        assert same(a, b), (k, a.shape, b.shape)
+        assert same(mg.local(T, 2, 1), mo.local(T, 2, 1)), k
+    assert mg.status() == 0
+    mg.close()
+
+
+def test_replayed_edge_clouds(orc, synth):
+    """The mapping node's real input: the odometer's edge clouds and poses (liodom_mapping_node.cc:45-82)."""
+    H, W = 16, 900
+    cfg = synth.make_cfg(H, W, 0)
+    po = orc.make_params(scan_lines=H, scan_regions=6, edges_per_region=10, prev_frames=5, knn_mode=1)
+    od = orc.Odometer(po)
+    mo, mg = orc.Map(), la.Map(max_cells=256, cell_capacity=32768)
+    for k in range(12):
+        x, _ = synth.scan(cfg, 0, k)
+        e = orc.extract(po, x, H, W)["edges"]
+        pq, _ = od.step(e)
+        T = orc.iso_from_qt(pq[:4], pq[4:]) if hasattr(orc, "iso_from_qt") else None
+        if T is None:
+            qx, qy, qz, qw = pq[:4]
+            R = np.array([[1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw)],
+                          [2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw)],
+                          [2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy)]])
+            T = np.concatenate([R, np.array(pq[4:]).reshape(3, 1)], axis=1)
+        mo.update(e, T); mg.update(e, T)
+        assert same(mg.all(), mo.all()), k
+        assert same(mg.local(T, 2, 1), mo.local(T, 2, 1)), k
+    assert mg.status() == 0 and mg.num_cells() == mo.num_cells()
+    mg.close()
+
+
+def test_capacity_overflow_is_reported(orc):
+    mg = la.Map(40.0, 50.0, 0.4, max_cells=4, cell_capacity=64, max_update_points=256, max_modified_cells=4)
+    x = np.zeros((200, 4), np.float32)
+    x[:, 0] = np.linspace(0, 39, 200)        # 98 distinct leaves in one cell > 64
+    mg.update(x)
+    assert mg.status() & 8
+    y = P(*[(50.0 * i, 0.0, 0.0, 0.0) for i in range(8)])      # 8 cells > max_cells / max_modified_cells
+    mg.update(y)
+    assert mg.status() & (2 | 4)
+    with pytest.raises(la.LiodomError):
+        mg.update(np.zeros((300, 4), np.float32))
+    mg.close()

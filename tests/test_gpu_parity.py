@@ -264,6 +264,26 @@ def test_filter_local_map_voxelgrid(orc, synth):
     g.close()
 
 
+@pytest.mark.parametrize("cells_max", [None, "40", "400"])
+def test_lds_hash_build(orc, synth, monkeypatch, cells_max):
+    """k_hash_build (one workgroup per stream builds the 1 m cell hash in LDS; default for
+    handles with >= 16 streams) gives the same trajectory as the global-atomic build, including
+    its in-kernel fall-back to the global table when the LDS table overflows (forced with 40
+    cells) and the transitions LDS -> fall-back across scans as the window grows."""
+    monkeypatch.setenv("LIODOM_HASH_BUILD", "lds")
+    if cells_max:
+        monkeypatch.setenv("LIODOM_LDS_CELLS_MAX", cells_max)
+    _run_stream(orc, synth, 16, 900, 0, 6, 10, 5, 14)
+    if cells_max is None:
+        _run_stream(orc, synth, 64, 1800, 0, 8, 10, 20, 6)
+
+
+def test_lds_hash_build_with_filter(orc, synth, monkeypatch):
+    # LDS-built table while the window fills, filtered-cloud table (global) afterwards
+    monkeypatch.setenv("LIODOM_HASH_BUILD", "lds")
+    test_filter_local_map_voxelgrid(orc, synth)
+
+
 def test_multi_workgroup_solve(orc, synth):
     # lm_workgroups = 8: the solve is split over 8 CUs exchanging partial sums inside the launch
     H, W, R, epr, P, K = 16, 900, 6, 10, 5, 10
