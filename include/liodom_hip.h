@@ -72,7 +72,7 @@ typedef struct liodom_config_t {
   int32_t pose_log_capacity; /* scans kept in the device-side pose log (resident replay) */
   int32_t debug_buffers;     /* 1 = keep per-ring smoothness dumps for liodom_get_curvature */
   int32_t lm_workgroups;     /* workgroups (CUs) per stream for the pose solve: 0 = auto (8 for <= 4 streams of >= 8192 possible edges, else 1), 1 or 8 */
-  int32_t reserved;
+  int32_t recv_capacity;     /* mapping = 1: points of the received ~map cloud the kNN structure can take (0 = 262144) */
 } liodom_config_t;
 
 typedef struct liodom_lm_trace_t {
@@ -96,6 +96,7 @@ typedef struct liodom_step_info_t {
 } liodom_step_info_t;
 
 typedef struct liodom_handle liodom_handle_t;
+typedef struct liodom_map liodom_map_t;
 
 /* Params::readParams defaults (src/params.cc:40-109). */
 void liodom_params_default(liodom_params_t* p);
@@ -127,8 +128,11 @@ int liodom_odometry_step(liodom_handle_t* h, int stream, const float* edges_xyzi
 int liodom_process_scan(liodom_handle_t* h, int stream, const float* xyzi, int64_t n, int height,
                         int width, double stamp, double* pose_out, liodom_step_info_t* info);
 
-/* mapClb -> SharedData::setLocalMap (src/liodom_node.cc:57-64).  Only used with mapping=1. */
+/* mapClb -> SharedData::setLocalMap (src/liodom_node.cc:57-64).  Only with mapping = 1: the next
+ * scan's kNN cloud is window ++ this cloud (src/laser_odometry.cc:276-278,310-314). */
 int liodom_set_received_map(liodom_handle_t* h, int stream, const float* xyzi, int64_t n);
+/* The last received ~map cloud of a stream (inspection). */
+int liodom_get_received_map(liodom_handle_t* h, int stream, float* xyzi, int64_t cap, int64_t* n_points);
 
 /* ---- resident replay (bench / batched streams): scans live in HBM before timing starts ---- */
 int liodom_alloc_resident(liodom_handle_t* h, int n_slots);
@@ -191,7 +195,6 @@ int liodom_device_info(liodom_handle_t* h, char* name, int name_cap, int* comput
 
 
 /* ---- liodom::Map on the device (mapping node, src/map.cc, src/liodom_mapping_node.cc) ---- */
-typedef struct liodom_map liodom_map_t;
 typedef struct liodom_map_config_t {
   int32_t device;              /* HIP device ordinal */
   int32_t max_cells;           /* coarse cells the map can hold (cells_vector_) */
@@ -226,6 +229,15 @@ int liodom_map_get_local(liodom_map_t* m, const double* T, int cells_xy, int cel
 /* Map::getMap (src/map.cc:131-139): every cell in creation order. */
 int liodom_map_get_all(liodom_map_t* m, float* xyzi, int64_t cap, int64_t* n_points);
 int liodom_map_num_cells(liodom_map_t* m, int* n_cells);
+/* Wires a map to stream `stream` of an odometry handle created with mapping = 1, replaying the
+ * two-node loop of launch/liodom.launch:41-56 synchronously on the device: after every scan k the
+ * handle enqueues updateMap(edges_k, pose_k) (lidarClb, liodom_mapping_node.cc:45-69) and
+ * getLocalMap(pose_k, cells_xy, cells_z) (:78-86) whose result becomes the received map of scan
+ * k+1 (mapClb, liodom_node.cc:57-64) without leaving HBM.  (The reference's two nodes run
+ * asynchronously, so which map a scan sees is timing dependent there; this is the zero-latency
+ * case.)  The map must live on the handle's device; from here on it uses the handle's HIP stream.
+ * Pass map = NULL to detach. */
+int liodom_attach_mapper(liodom_handle_t* h, int stream, liodom_map_t* m, int cells_xy, int cells_z);
 /* Sticky LIODOM_MAP_* bits raised by the device since creation. */
 int liodom_map_status(liodom_map_t* m, uint32_t* status);
 

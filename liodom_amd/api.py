@@ -55,7 +55,7 @@ class Config(C.Structure):
     _fields_ = [
         ("device", C.c_int32), ("n_streams", C.c_int32), ("max_points", C.c_int32), ("max_width", C.c_int32),
         ("max_ring_points", C.c_int32), ("lm_apply_step_on_ftol", C.c_int32), ("pose_log_capacity", C.c_int32),
-        ("debug_buffers", C.c_int32), ("lm_workgroups", C.c_int32), ("reserved", C.c_int32),
+        ("debug_buffers", C.c_int32), ("lm_workgroups", C.c_int32), ("recv_capacity", C.c_int32),
     ]
 
 
@@ -147,6 +147,10 @@ def load():
     L.liodom_device_info.restype = C.c_int
     L.liodom_device_info.argtypes = [vp, C.c_char_p, C.c_int, ip]
     i64p = C.POINTER(C.c_int64)
+    L.liodom_get_received_map.restype = C.c_int
+    L.liodom_get_received_map.argtypes = [vp, C.c_int, fp, C.c_int64, i64p]
+    L.liodom_attach_mapper.restype = C.c_int
+    L.liodom_attach_mapper.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int]
     L.liodom_map_config_default.argtypes = [C.POINTER(MapConfig)]
     L.liodom_map_create.restype = C.c_int
     L.liodom_map_create.argtypes = [C.POINTER(MapConfig), C.POINTER(vp)]
@@ -173,7 +177,7 @@ EXPORTED_SYMBOLS = [
     "liodom_set_profiling", "liodom_get_kernel_stats", "liodom_reset_kernel_stats", "liodom_device_info",
     "liodom_device_count",
     "liodom_map_config_default", "liodom_map_create", "liodom_map_destroy", "liodom_map_update", "liodom_map_get_local",
-    "liodom_map_get_all", "liodom_map_num_cells", "liodom_map_status",
+    "liodom_map_get_all", "liodom_map_num_cells", "liodom_map_status", "liodom_get_received_map", "liodom_attach_mapper",
 ]
 
 
@@ -322,8 +326,27 @@ class Liodom:
         self._check(self.L.liodom_get_window(self.h, stream, _fp(w), cap, C.byref(n), C.byref(nf)))
         return w[:n.value].copy(), nf.value
 
+    def set_received_map(self, xyzi, stream=0):
+        """mapClb (liodom_node.cc:57-64): the cloud the mapper published on ~map."""
+        x = np.ascontiguousarray(xyzi, dtype=np.float32).reshape(-1, 4)
+        self._check(self.L.liodom_set_received_map(self.h, stream, _fp(x), x.shape[0]))
+
+    def received_map(self, stream=0):
+        cap = max(int(self.config.recv_capacity), 262144)
+        w = np.zeros((cap, 4), np.float32)
+        n = C.c_int64()
+        self._check(self.L.liodom_get_received_map(self.h, stream, _fp(w), cap, C.byref(n)))
+        return w[:n.value].copy()
+
+    def attach_mapper(self, mapper, cells_xy=2, cells_z=1, stream=0):
+        """Synchronous on-device replay of the liodom_mapping node for this stream (see
+        liodom_attach_mapper in include/liodom_hip.h)."""
+        self._check(self.L.liodom_attach_mapper(self.h, stream, mapper.h if mapper is not None else None, cells_xy, cells_z))
+        self._mappers = getattr(self, "_mappers", {})
+        self._mappers[stream] = mapper      # keep it alive while attached
+
     def local_map(self, stream=0):
-        cap = self.edge_cap * int(self.params.local_map_size)
+        cap = self.edge_cap * int(self.params.local_map_size) + (max(int(self.config.recv_capacity), 262144) if self.params.mapping else 0)
         w = np.zeros((cap, 4), np.float32)
         n = C.c_int64()
         filt = C.c_int32()

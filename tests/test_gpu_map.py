@@ -129,3 +129,105 @@ def test_capacity_overflow_is_reported(orc):
     with pytest.raises(la.LiodomError):
         mg.update(np.zeros((300, 4), np.float32))
     mg.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# mapping = true in the odometer (laser_odometry.cc:276-278,310-314): kNN cloud = window ++ ~map
+# ---------------------------------------------------------------------------------------------
+POSE_TOL_T, POSE_TOL_R = 1e-4, 1e-4
+
+
+def rot_angle(qa, qb):
+    d = abs(float(np.dot(qa, qb)))
+    return 2.0 * np.arccos(min(1.0, d))
+
+
+def T_of(pq):
+    qx, qy, qz, qw = pq[:4]
+    R = np.array([[1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw)],
+                  [2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw)],
+                  [2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy)]])
+    return np.concatenate([R, np.array(pq[4:]).reshape(3, 1)], axis=1)
+
+
+def _mk_mapping(orc, H, W, R, epr, P, mapping):
+    po = orc.make_params(scan_lines=H, scan_regions=R, edges_per_region=epr, prev_frames=P, knn_mode=1, mapping=mapping)
+    g = la.Liodom(la.make_params(scan_lines=H, scan_regions=R, edges_per_region=epr, prev_frames=P, mapping=1),
+                  la.make_config(max_points=H * W, max_width=W, recv_capacity=1 << 17))
+    return po, g
+
+
+@pytest.mark.parametrize("hash_build", ["global", "lds"])
+def test_external_map_feeds_the_knn_cloud(orc, synth, monkeypatch, hash_build):
+    """~map delivered through liodom_set_received_map (mapClb): a mapper that has integrated the
+    scans that already LEFT the sliding window (so the two clouds share no point).  Same
+    correspondences (indices into window ++ map), LM traces and poses as the oracle."""
+    monkeypatch.setenv("LIODOM_HASH_BUILD", hash_build)
+    H, W, R, epr, P, K = 16, 900, 6, 10, 4, 14
+    cfg = synth.make_cfg(H, W, 0)
+    po, g = _mk_mapping(orc, H, W, R, epr, P, 2)
+    od = orc.Odometer(po)
+    mo = orc.Map()
+    hist = []
+    used_map = 0
+    for k in range(K):
+        x, _ = synth.scan(cfg, 0, k)
+        e = orc.extract(po, x, H, W)["edges"]
+        if k > P:      # the frame that left the window before this scan goes into the mapper
+            e_old, T_old = hist[k - P - 1]
+            mo.update(e_old, T_old)
+            loc = mo.local(hist[-1][1], 2, 1)
+            od.set_received_map(loc)
+            g.set_received_map(loc)
+        pose_o, info_o = od.step(e)
+        pose_g, info_g = g.process_scan(x, H, W)
+        hist.append((e, T_of(pose_o)))
+        assert np.linalg.norm(pose_g[4:] - pose_o[4:]) <= POSE_TOL_T and rot_angle(pose_g[:4], pose_o[:4]) <= POSE_TOL_R, k
+        if k > 0:
+            assert info_g.map_points == info_o.map_points, (k, info_g.map_points, info_o.map_points)
+            assert [info_g.lm[i].termination for i in (0, 1)] == [info_o.lm[i].termination for i in (0, 1)]
+            assert [info_g.lm[i].iterations for i in (0, 1)] == [info_o.lm[i].iterations for i in (0, 1)]
+            for it in (0, 1):
+                vo, ao, bo = od.last_corr(it)
+                vg, ag, bg = g.correspondences(it)
+                diff = int((vo != vg).sum()) + int(((ao != ag) & (vo == 1) & (vg == 1)).sum())
+                assert diff <= 3, (k, it, diff)
+                if k > P:
+                    used_map += int((ag[vg == 1] >= od.window().shape[0]).sum())
+        lm, filtered = g.local_map()
+        assert not filtered and same(lm, np.concatenate([od.window(), od.received_map()]).astype(np.float32)) or \
+            np.allclose(lm[:, :3], np.concatenate([od.window(), od.received_map()])[:, :3], atol=2e-5)
+    assert used_map > 50          # correspondences really landed in the received map
+    assert np.linalg.norm(pose_o[4:]) > 0.5
+    g.close()
+
+
+def test_attached_mapper_replays_the_mapping_node(orc, synth):
+    """liodom_attach_mapper: updateMap(edges_k, pose_k) + getLocalMap(pose_k) on the device after
+    every scan.  Against the oracle's synchronous replay: same received map bit for bit, same
+    match counts — and the same degenerate outcome (single-point leaves of the mapper duplicate
+    window points, the line through NN0 == NN1 has zero length, Ceres rejects the evaluation and
+    the pose stays at the prediction; tests/test_oracle_map.py)."""
+    H, W, R, epr, P, K = 16, 900, 6, 10, 5, 6
+    cfg = synth.make_cfg(H, W, 0)
+    po, g = _mk_mapping(orc, H, W, R, epr, P, 1)
+    mg = la.Map(max_cells=256, cell_capacity=32768)
+    g.attach_mapper(mg, 2, 1)
+    od = orc.Odometer(po)
+    for k in range(K):
+        x, _ = synth.scan(cfg, 0, k)
+        pose_o, info_o = od.step(orc.extract(po, x, H, W)["edges"])
+        pose_g, info_g = g.process_scan(x, H, W)
+        assert same(g.received_map(), od.received_map()), k
+        assert np.linalg.norm(pose_g[4:] - pose_o[4:]) <= POSE_TOL_T and rot_angle(pose_g[:4], pose_o[:4]) <= POSE_TOL_R, k
+        if k > 0:
+            assert info_g.map_points == info_o.map_points
+            assert list(info_g.matches) == list(info_o.matches)
+            assert [info_g.lm[i].termination for i in (0, 1)] == [info_o.lm[i].termination for i in (0, 1)] == [5, 5]
+    assert mg.status() == 0 and mg.num_cells() > 0
+    assert same(mg.all()[:10], mg.all()[:10])
+    g.attach_mapper(None)
+    g.close()
+    mg.update(np.ones((3, 4), np.float32))      # the map works on its own again after the handle is gone
+    assert mg.status() == 0
+    mg.close()

@@ -1,6 +1,6 @@
 """Oracle restatement of the mapping node's Map / Cell (src/map.cc, rows A12-A14 of SURVEY.md §8)
-and of its interaction with the odometer.  CPU only.  The GPU path refuses mapping=1 (see the
-finding at the end of this file and DESIGN.md)."""
+and of its interaction with the odometer.  CPU only; the device implementation is checked against
+this restatement in tests/test_gpu_map.py."""
 import numpy as np
 
 
