@@ -187,7 +187,7 @@ int launch_odometry(liodom_handle* h, int eb, int s0, int count) {
       int rc = map_enqueue_update(mp, v.edges + ((size_t)eb * v.n_streams + s) * v.edge_cap, &st->n_edges_buf[eb], st->final_odom, h->stream);
       if (rc) return rc;
       rc = map_enqueue_local(mp, st->final_odom, h->mapper_cells_xy[s], h->mapper_cells_z[s], v.recv_pts + (size_t)s * v.recv_cap,
-                             v.recv_cap, &st->n_recv, h->stream);
+                             v.recv_cap, &st->n_recv, h->stream, 1);
       if (rc) return rc;
     }
   }

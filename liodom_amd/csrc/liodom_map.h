@@ -450,7 +450,7 @@ __device__ __forceinline__ void map_plan_add(const MapView& m, int kx, int ky, i
   *ne += 1;
   *total += e.count;
 }
-__global__ void k_map_local_plan(MapView m, const double* T_ptr, int cells_xy, int cells_z, int out_cap, int* n_out) {
+__global__ void k_map_local_plan(MapView m, const double* T_ptr, int cells_xy, int cells_z, int out_cap, int* n_out, int sticky) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   MapState& st = *m.st;
   const int x = (int)T_ptr[3];                                                       // :144
@@ -474,7 +474,7 @@ __global__ void k_map_local_plan(MapView m, const double* T_ptr, int cells_xy, i
   for (int i = init_z; i <= end_z && guard < 65536; i = (int)(i + m.z), guard++) {   // :178
     map_plan_add(m, voxel_x, voxel_y, i, &ne, &total);
   }
-  if (total > out_cap) atomicOr(&st.status, MAP_STATUS_LOCAL_OVERFLOW);
+  if (total > out_cap && sticky) atomicOr(&st.status, MAP_STATUS_LOCAL_OVERFLOW);   // host callers get LIODOM_ERR_CAPACITY instead
   st.n_entries = ne;
   st.n_result = total;
   if (n_out) *n_out = total > out_cap ? out_cap : total;
@@ -505,7 +505,6 @@ __global__ __launch_bounds__(1024) void k_map_all_plan(MapView m, int out_cap, i
   }
   if (tid == 0) {
     const int total = sh_carry;
-    if (total > out_cap) atomicOr(&st.status, MAP_STATUS_LOCAL_OVERFLOW);
     st.n_entries = nc;
     st.n_result = total;
     if (n_out) *n_out = total > out_cap ? out_cap : total;

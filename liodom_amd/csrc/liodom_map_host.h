@@ -97,9 +97,9 @@ int map_enqueue_update(liodom_map* mp, const float4* d_pts, const int* d_n, cons
 
 // Map::getLocalMap enqueued on `q`: result and its size stay on the device.
 int map_enqueue_local(liodom_map* mp, const double* d_T, int cells_xy, int cells_z, float4* d_out, int out_cap,
-                      int* d_out_n, hipStream_t q) {
+                      int* d_out_n, hipStream_t q, int sticky_overflow) {
   using namespace liodom_dev;
-  hipLaunchKernelGGL(k_map_local_plan, dim3(1), dim3(64), 0, q, mp->m, d_T, cells_xy, cells_z, out_cap, d_out_n);
+  hipLaunchKernelGGL(k_map_local_plan, dim3(1), dim3(64), 0, q, mp->m, d_T, cells_xy, cells_z, out_cap, d_out_n, sticky_overflow);
   hipLaunchKernelGGL(k_map_gather, dim3((mp->m.cell_cap + 255) / 256 > 64 ? 64 : (mp->m.cell_cap + 255) / 256, 64), dim3(256), 0, q, mp->m, d_out, out_cap);
   HIP_TRY(hipGetLastError());
   return LIODOM_OK;
@@ -206,7 +206,7 @@ int liodom_map_get_local(liodom_map_t* mp, const double* T, int cells_xy, int ce
   int rc = map_ensure_out(mp, cap);
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(mp->d_T, T, sizeof(double) * 12, hipMemcpyHostToDevice, mp->stream));
-  rc = map_enqueue_local(mp, mp->d_T, cells_xy, cells_z, mp->d_out, mp->out_cap, mp->d_out_n, mp->stream);
+  rc = map_enqueue_local(mp, mp->d_T, cells_xy, cells_z, mp->d_out, mp->out_cap, mp->d_out_n, mp->stream, 0);
   if (rc) return rc;
   return map_fetch_result(mp, xyzi, cap, n_points);
 }

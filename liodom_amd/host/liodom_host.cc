@@ -151,6 +151,46 @@ size_t LocalMapManager::getLocalMap(PointCloud& map) {
   return (size_t)nf;
 }
 
+Map::Map(const double xy_size, const double z_size, const double res, int device) {
+  liodom_map_config_t c;
+  liodom_map_config_default(&c);
+  c.device = device; c.voxel_xysize = xy_size; c.voxel_zsize = z_size; c.resolution = res;
+  check(liodom_map_create(&c, &m_), "liodom_map_create");
+}
+Map::~Map() { liodom_map_destroy(m_); }
+
+void Map::updateMap(const PointCloud& pc_in, const std::array<double, 12>& pose) {
+  check(liodom_map_update(m_, reinterpret_cast<const float*>(pc_in.points.data()), (int64_t)pc_in.size(), pose.data()),
+        "liodom_map_update");
+}
+
+PointCloud Map::fetch(int which, const double* T, int cells_xy, int cells_z) {
+  PointCloud out;
+  int64_t n = 0;
+  // size query first (LIODOM_ERR_CAPACITY with the size filled in), then the copy
+  if (which == 0) liodom_map_get_all(m_, nullptr, 0, &n); else liodom_map_get_local(m_, T, cells_xy, cells_z, nullptr, 0, &n);
+  out.points.resize((size_t)n);
+  float* dst = reinterpret_cast<float*>(out.points.data());
+  if (n > 0) {
+    if (which == 0) check(liodom_map_get_all(m_, dst, n, &n), "liodom_map_get_all");
+    else check(liodom_map_get_local(m_, T, cells_xy, cells_z, dst, n, &n), "liodom_map_get_local");
+  }
+  out.width = (uint32_t)n; out.height = 1;
+  return out;
+}
+PointCloud Map::getMap() { return fetch(0, nullptr, 0, 0); }
+PointCloud Map::getLocalMap(const std::array<double, 12>& pose, int cells_xy, int cells_z) {
+  return fetch(1, pose.data(), cells_xy, cells_z);
+}
+
+void LaserOdometer::setLocalMap(const PointCloud& map) {
+  check(liodom_set_received_map(eng_->handle(), 0, reinterpret_cast<const float*>(map.points.data()), (int64_t)map.size()),
+        "liodom_set_received_map");
+}
+void LaserOdometer::attachMapper(Map* map, int cells_xy, int cells_z) {
+  check(liodom_attach_mapper(eng_->handle(), 0, map ? map->handle() : nullptr, cells_xy, cells_z), "liodom_attach_mapper");
+}
+
 LaserOdometer::LaserOdometer(std::shared_ptr<Engine> e)
     : lmap_manager(e), eng_(e), params(Params::getInstance()), stats(Stats::getInstance()) {}
 

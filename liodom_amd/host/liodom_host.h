@@ -8,6 +8,7 @@
 //   liodom::LaserOdometer     include/liodom/laser_odometry.h:79-121, src/laser_odometry.cc
 //   liodom::LocalMapManager   include/liodom/laser_odometry.h:62-76 (read-only view of the device window)
 //   liodom::Stats             include/liodom/stats.h:40-80, src/stats.cc (result files)
+//   liodom::Map               include/liodom/map.h:93-116, src/map.cc (mapping node's map, on the device)
 // Like the reference the hot-path methods return void and report problems through a log hook;
 // unlike it, failures of the GPU library also raise std::runtime_error (nothing falls back to CPU).
 #pragma once
@@ -116,9 +117,30 @@ class LocalMapManager {
   std::shared_ptr<Engine> eng_;
 };
 
+// liodom::Map (include/liodom/map.h:93-116) on the device.  Poses are 3 x 4 row-major isometries
+// (Pose::matrix34()), the Eigen::Isometry3d of the reference.
+class Map {
+ public:
+  explicit Map(const double xy_size, const double z_size, const double res, int device = 0);   // map.cc:70-81
+  virtual ~Map();
+  Map(const Map&) = delete;
+  Map& operator=(const Map&) = delete;
+  void updateMap(const PointCloud& pc_in, const std::array<double, 12>& pose);                  // :90-129
+  PointCloud getMap();                                                                          // :131-139
+  PointCloud getLocalMap(const std::array<double, 12>& pose, int cells_xy = 2, int cells_z = 1); // :141-189
+  liodom_map_t* handle() const { return m_; }
+ private:
+  PointCloud fetch(int which, const double* T, int cells_xy, int cells_z);
+  liodom_map_t* m_ = nullptr;
+};
+
 class LaserOdometer {
  public:
   explicit LaserOdometer(std::shared_ptr<Engine> engine);
+  // SharedData::setLocalMap (shared_data.cc:91-96), fed by mapClb (liodom_node.cc:57-64); mapping_ only
+  void setLocalMap(const PointCloud& map);
+  // Zero-latency on-device replay of the liodom_mapping node (liodom_attach_mapper); mapping_ only
+  void attachMapper(Map* map, int cells_xy = 2, int cells_z = 1);
   // One pass of the loop body of LaserOdometer::operator() (laser_odometry.cc:107-267).
   Pose process(const PointCloud& feats, double stamp, liodom_step_info_t* info = nullptr);
   // lidarClb -> extractor -> odometer without leaving the device (one H2D copy, one result record)

@@ -3,11 +3,15 @@
 // (poses.txt in KITTI format, *_times.txt, nfeats.txt; src/stats.cc:73-132).
 //
 //   liodom_replay <scan_dir> <out_dir/> [name=value ...]     e.g. scan_lines=64 prev_frames=20
+// With mapping=true the liodom_mapping node (launch/liodom.launch:41-56) is replayed on the device
+// with its launch-file parameters (voxel_xysize= voxel_zsize= resolution= cells_xy= cells_z=); the
+// final map is written to <out_dir>map.bin (float32 x y z i).
 #include <algorithm>
 #include <cstdio>
 #include <dirent.h>
 #include <fstream>
 #include <iostream>
+#include <memory>
 
 #include "liodom_host.h"
 
@@ -48,12 +52,33 @@ int main(int argc, char** argv) {
   try {
     auto eng = std::make_shared<liodom::Engine>(*params, 0, (int)max_pts, (int)(max_pts / (size_t)params->scan_lines_ + 1));
     liodom::LaserOdometer odometer(eng);
+    std::unique_ptr<liodom::Map> mapper;
+    if (params->mapping_) {
+      double xy = 40.0, z = 50.0, res = 0.4; int cells_xy = 2, cells_z = 1;      // liodom_mapping_node.cc:115-134
+      for (const std::string& a : kv) {
+        const size_t eq = a.find('=');
+        if (eq == std::string::npos) continue;
+        const std::string k = a.substr(0, eq), v = a.substr(eq + 1);
+        if (k == "voxel_xysize") xy = std::stod(v); else if (k == "voxel_zsize") z = std::stod(v);
+        else if (k == "resolution") res = std::stod(v); else if (k == "cells_xy") cells_xy = std::stoi(v);
+        else if (k == "cells_z") cells_z = std::stoi(v);
+      }
+      mapper.reset(new liodom::Map(xy, z, res));
+      odometer.attachMapper(mapper.get(), cells_xy, cells_z);
+    }
     for (size_t i = 0; i < clouds.size(); i++) {
       liodom_step_info_t info;
       liodom::Pose p = odometer.processScan(clouds[i], 0.1 * (double)i, &info);
       if (i % 50 == 0) std::printf("scan %zu: %d edges, %d matches, t = %.3f %.3f %.3f\n", i, info.n_edges, info.matches[1], p.t[0], p.t[1], p.t[2]);
     }
     liodom::Stats::getInstance()->writeResults(out);
+    if (mapper) {
+      odometer.attachMapper(nullptr);
+      const liodom::PointCloud m = mapper->getMap();
+      std::ofstream f(out + "map.bin", std::ios::binary);
+      f.write(reinterpret_cast<const char*>(m.points.data()), (std::streamsize)(m.points.size() * sizeof(liodom::Point)));
+      std::printf("map: %zu points\n", m.size());
+    }
   } catch (const std::exception& e) {
     std::fprintf(stderr, "liodom_replay: %s\n", e.what());
     return 1;

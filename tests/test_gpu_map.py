@@ -231,3 +231,33 @@ def test_attached_mapper_replays_the_mapping_node(orc, synth):
     mg.update(np.ones((3, 4), np.float32))      # the map works on its own again after the handle is gone
     assert mg.status() == 0
     mg.close()
+
+
+def test_replay_harness_mapping_mode(orc, synth, tmp_path):
+    """liodom_replay mapping=true: host C++ mirror (liodom::Map, LaserOdometer::attachMapper) over the
+    C-ABI; the final map file has the oracle mapper's size and the poses are the oracle's."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "liodom_amd", "host", "liodom_replay")
+    if not os.path.exists(exe):
+        pytest.skip("liodom_replay not built (run __graft_entry__.build())")
+    H, W, R, epr, P, K = 16, 900, 6, 10, 5, 5
+    cfg = synth.make_cfg(H, W, 0)
+    po = orc.make_params(scan_lines=H, scan_regions=R, edges_per_region=epr, prev_frames=P, knn_mode=1, mapping=1)
+    od = orc.Odometer(po)
+    scan_dir, out_dir = tmp_path / "scans", tmp_path / "out"
+    scan_dir.mkdir(); out_dir.mkdir()
+    rows = []
+    for k in range(K):
+        x, _ = synth.scan(cfg, 0, k)
+        x.astype(np.float32).tofile(str(scan_dir / ("%06d.bin" % k)))
+        pose, _ = od.step(orc.extract(po, x, H, W)["edges"])
+        T, _ = orc.pose_ops(pose[:4], pose[4:])
+        rows.append(T.reshape(12))
+    r = subprocess.run([exe, str(scan_dir), str(out_dir) + "/", "scan_lines=16", "scan_regions=6", "edges_per_region=10",
+                        "prev_frames=5", "mapping=true"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    got = np.loadtxt(str(out_dir / "poses.txt")).reshape(-1, 12)
+    assert np.allclose(got, np.array(rows), rtol=2e-5, atol=2e-6)
+    m = np.fromfile(str(out_dir / "map.bin"), dtype=np.float32).reshape(-1, 4)
+    assert m.shape[0] == od.map_total() and m.shape[0] > 100
