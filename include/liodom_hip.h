@@ -131,6 +131,13 @@ int liodom_process_scan(liodom_handle_t* h, int stream, const float* xyzi, int64
 /* mapClb -> SharedData::setLocalMap (src/liodom_node.cc:57-64).  Only with mapping = 1: the next
  * scan's kNN cloud is window ++ this cloud (src/laser_odometry.cc:276-278,310-314). */
 int liodom_set_received_map(liodom_handle_t* h, int stream, const float* xyzi, int64_t n);
+/* imuClb -> SharedData::setLastIMUOri (src/liodom_node.cc:66-70): latest IMU orientation [x y z w].
+ * With use_imu = 1 the roll and pitch of every predicted pose are replaced by the IMU's before the
+ * solve (src/laser_odometry.cc:152-183).  Identity until first set. */
+int liodom_set_imu_orientation(liodom_handle_t* h, int stream, const double* q_xyzw);
+/* laser_to_base_ (TF lookup at src/laser_odometry.cc:110-119): 3 x 4 row-major, identity by default.
+ * It enters the IMU override only; poses are returned in the laser frame (odom_). */
+int liodom_set_laser_to_base(liodom_handle_t* h, const double* T);
 /* The last received ~map cloud of a stream (inspection). */
 int liodom_get_received_map(liodom_handle_t* h, int stream, float* xyzi, int64_t cap, int64_t* n_points);
 

@@ -149,6 +149,10 @@ def load():
     i64p = C.POINTER(C.c_int64)
     L.liodom_get_received_map.restype = C.c_int
     L.liodom_get_received_map.argtypes = [vp, C.c_int, fp, C.c_int64, i64p]
+    L.liodom_set_imu_orientation.restype = C.c_int
+    L.liodom_set_imu_orientation.argtypes = [vp, C.c_int, dp]
+    L.liodom_set_laser_to_base.restype = C.c_int
+    L.liodom_set_laser_to_base.argtypes = [vp, dp]
     L.liodom_attach_mapper.restype = C.c_int
     L.liodom_attach_mapper.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int]
     L.liodom_map_config_default.argtypes = [C.POINTER(MapConfig)]
@@ -178,6 +182,7 @@ EXPORTED_SYMBOLS = [
     "liodom_device_count",
     "liodom_map_config_default", "liodom_map_create", "liodom_map_destroy", "liodom_map_update", "liodom_map_get_local",
     "liodom_map_get_all", "liodom_map_num_cells", "liodom_map_status", "liodom_get_received_map", "liodom_attach_mapper",
+    "liodom_set_imu_orientation", "liodom_set_laser_to_base",
 ]
 
 
@@ -325,6 +330,15 @@ class Liodom:
         nf = C.c_int32()
         self._check(self.L.liodom_get_window(self.h, stream, _fp(w), cap, C.byref(n), C.byref(nf)))
         return w[:n.value].copy(), nf.value
+
+    def set_imu(self, q_xyzw, stream=0):
+        """imuClb (liodom_node.cc:66-70): latest IMU orientation, used when params.use_imu."""
+        q = np.ascontiguousarray(q_xyzw, dtype=np.float64)
+        self._check(self.L.liodom_set_imu_orientation(self.h, stream, _dp(q)))
+
+    def set_laser_to_base(self, T34):
+        T = np.ascontiguousarray(T34, dtype=np.float64).reshape(12)
+        self._check(self.L.liodom_set_laser_to_base(self.h, _dp(T)))
 
     def set_received_map(self, xyzi, stream=0):
         """mapClb (liodom_node.cc:57-64): the cloud the mapper published on ~map."""

@@ -163,6 +163,10 @@ int launch_extract(liodom_handle* h, hipStream_t q, int eb, int s0, int count, c
 int launch_odometry(liodom_handle* h, int eb, int s0, int count) {
   const DevView& v = h->v;
   const int knn_blocks = cdiv(h->v.edge_cap, kKnnQueries);
+  if (v.use_imu) {
+    ProfScope ps(h, KID_OTHER);
+    hipLaunchKernelGGL(k_imu_override, dim3(cdiv(count, 64)), dim3(64), 0, h->stream, v, s0, count);
+  }
   for (int it = 0; it < 2; it++) {
     {
       ProfScope ps(h, KID_KNN);
@@ -273,6 +277,11 @@ int reset_state(liodom_handle* h) {
   }
   HIP_TRY(hipMemcpyAsync(h->v.state, init.data(), sizeof(StreamState) * init.size(), hipMemcpyHostToDevice, h->stream));
   {
+    std::vector<double> qid((size_t)h->S * 4, 0.0);          // IMU orientation: identity until imuClb delivers one
+    for (int s = 0; s < h->S; s++) qid[(size_t)s * 4 + 3] = 1.0;
+    HIP_TRY(hipMemcpy(h->v.imu_q, qid.data(), sizeof(double) * qid.size(), hipMemcpyHostToDevice));
+  }
+  {
     const size_t total = (size_t)h->S * h->v.table_size;
     hipLaunchKernelGGL(k_init_cells, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, h->v);
     HIP_TRY(hipGetLastError());
@@ -330,10 +339,6 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
     g_last_error = "liodom_create: parameter out of range";
     return LIODOM_ERR_INVALID_ARG;
   }
-  if (params->use_imu) {
-    g_last_error = "liodom_create: use_imu is not implemented on the GPU path yet";
-    return LIODOM_ERR_UNSUPPORTED;
-  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
     g_last_error = "no HIP device available (libliodom_hip has no CPU fallback)";
@@ -386,6 +391,8 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   h->ring_lds_bytes = ring_extract_lds_bytes(ring_cap, v.slots_per_ring, params->scan_regions);
   if (h->ring_lds_bytes > 160 * 1024) { g_last_error = "ring tile + pick lists exceed 160 KiB of LDS"; return fail(LIODOM_ERR_CAPACITY); }
   v.edge_cap = round_up(std::max(1, h->H * v.slots_per_ring), 64);
+  v.use_imu = params->use_imu ? 1 : 0;
+  iso_identity(v.laser_to_base);
   v.mapping = params->mapping ? 1 : 0;
   v.recv_cap = v.mapping ? (config->recv_capacity > 0 ? config->recv_capacity : 262144) : 0;
   v.map_cap = v.edge_cap * h->P + v.recv_cap;
@@ -426,6 +433,7 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   ALLOC(v.used_cells, S * v.map_cap, 0);
   ALLOC(v.pt_cell, S * v.map_cap, 0xFF);
   if (v.recv_cap) ALLOC(v.recv_pts, S * v.recv_cap, 0);
+  ALLOC(v.imu_q, S * 4, 0);
   ALLOC(v.sorted_pts, S * v.map_cap, 0);
   if (v.filter_local_map) {
     ALLOC(v.vox_cells, S * v.table_size, 0);
@@ -637,6 +645,21 @@ int liodom_set_received_map(liodom_handle_t* h, int stream, const float* xyzi, i
   rc = rebuild_search_structure(h, stream);
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(h->stream));        // xyzi / ni are the caller's and this frame's memory
+  return LIODOM_OK;
+}
+
+int liodom_set_imu_orientation(liodom_handle_t* h, int stream, const double* q_xyzw) {
+  int rc = check_stream(h, stream);
+  if (rc) return rc;
+  if (!q_xyzw) return LIODOM_ERR_INVALID_ARG;
+  // pageable-memory async copies are staged by the runtime before the call returns
+  HIP_TRY(hipMemcpyAsync(h->v.imu_q + (size_t)stream * 4, q_xyzw, sizeof(double) * 4, hipMemcpyHostToDevice, h->stream));
+  return LIODOM_OK;
+}
+
+int liodom_set_laser_to_base(liodom_handle_t* h, const double* T) {
+  if (!h || !T) return LIODOM_ERR_INVALID_ARG;
+  for (int k = 0; k < 12; k++) h->v.laser_to_base[k] = T[k];      // kernels take the view by value
   return LIODOM_OK;
 }
 

@@ -119,6 +119,9 @@ struct DevView {
   int* win_base;            // [S][P+1] logical prefix (oldest first)
   int* win_slot;            // [S][P]  logical frame -> slot
   CellSlot* cells;          // [S][table_size]  {key, start, cnt}: one 16-B load per probe
+  int use_imu;              // params.use_imu_ (laser_odometry.cc:152)
+  double laser_to_base[12]; // laser_to_base_ (laser_odometry.cc:110-119), identity unless liodom_set_laser_to_base
+  double* imu_q;            // [S][4] last IMU orientation [x y z w] (SharedData::last_IMU_ori_)
   int mapping;              // params.mapping_: the kNN cloud is window + received map (laser_odometry.cc:310-314)
   int recv_cap;
   float4* recv_pts;         // [S][recv_cap] last received ~map cloud (world frame)
@@ -1086,6 +1089,25 @@ __device__ void lm_exchange(const DevView& v, int s, int g, int G, unsigned int 
     if (tid < kAccN) acc_total[tid] = tot;
   }
   __syncthreads();
+}
+
+// use_imu (laser_odometry.cc:152-183): the prediction (made when the previous scan finished) gets
+// the roll and pitch of the latest IMU orientation before the first kNN pass; one thread per stream.
+__global__ void k_imu_override(DevView v, int s0, int count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  StreamState& st = v.state[s0 + i];
+  if (!st.initialized) return;
+  double odom[12], out[12], l2b[12], q[4];
+#pragma unroll
+  for (int k = 0; k < 12; k++) { odom[k] = st.odom[k]; l2b[k] = v.laser_to_base[k]; }
+#pragma unroll
+  for (int k = 0; k < 4; k++) q[k] = v.imu_q[(size_t)(s0 + i) * 4 + k];
+  imu_override(odom, q, l2b, out);
+#pragma unroll
+  for (int k = 0; k < 12; k++) st.odom[k] = out[k];
+  quat_from_rot(out, st.param_q);                                                  // :186-190
+  st.param_t[0] = out[3]; st.param_t[1] = out[7]; st.param_t[2] = out[11];         // :192-195
 }
 
 __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int outer_it, int eb) {

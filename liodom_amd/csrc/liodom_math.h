@@ -153,6 +153,78 @@ LD_HD void transform_point(const double* T, float x, float y, float z, float* ox
   *oy = (float)(T[4] * dx + T[5] * dy + T[6] * dz + T[7]);
   *oz = (float)(T[8] * dx + T[9] * dy + T[10] * dz + T[11]);
 }
+// ---- IMU roll / pitch override of the prediction (src/laser_odometry.cc:152-183) ----
+// tf::Matrix3x3 (ROS tf LinearMath = Bullet btMatrix3x3, tfScalar = double): setRotation, getRPY
+// (getEulerYPR solution 1), setRPY (setEulerYPR), getRotation.  3 x 3 row-major.
+LD_HD void tf_matrix_from_quat(const double* q, double* m) {
+  const double d = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  const double s = 2.0 / d;
+  const double xs = q[0] * s, ys = q[1] * s, zs = q[2] * s;
+  const double wx = q[3] * xs, wy = q[3] * ys, wz = q[3] * zs;
+  const double xx = q[0] * xs, xy = q[0] * ys, xz = q[0] * zs;
+  const double yy = q[1] * ys, yz = q[1] * zs, zz = q[2] * zs;
+  m[0] = 1.0 - (yy + zz); m[1] = xy - wz;         m[2] = xz + wy;
+  m[3] = xy + wz;         m[4] = 1.0 - (xx + zz); m[5] = yz - wx;
+  m[6] = xz - wy;         m[7] = yz + wx;         m[8] = 1.0 - (xx + yy);
+}
+LD_HD void tf_get_rpy(const double* m, double* roll, double* pitch, double* yaw) {
+  const double kPi = 3.14159265358979323846;
+  if (fabs(m[6]) >= 1) {            // gimbal lock
+    *yaw = 0;
+    *roll = atan2(m[7], m[8]);
+    *pitch = m[6] < 0 ? kPi / 2.0 : -kPi / 2.0;
+  } else {
+    *pitch = -asin(m[6]);
+    const double cp = cos(*pitch);
+    *roll = atan2(m[7] / cp, m[8] / cp);
+    *yaw = atan2(m[3] / cp, m[0] / cp);
+  }
+}
+LD_HD void tf_set_rpy(double roll, double pitch, double yaw, double* m) {
+  const double ci = cos(roll), cj = cos(pitch), ch = cos(yaw);
+  const double si = sin(roll), sj = sin(pitch), sh = sin(yaw);
+  const double cc = ci * ch, cs = ci * sh, sc = si * ch, ss = si * sh;
+  m[0] = cj * ch; m[1] = sj * sc - cs; m[2] = sj * cc + ss;
+  m[3] = cj * sh; m[4] = sj * ss + cc; m[5] = sj * cs - sc;
+  m[6] = -sj;     m[7] = cj * si;      m[8] = cj * ci;
+}
+LD_HD void tf_quat_from_matrix(const double* m, double* q) {
+  const double trace = m[0] + m[4] + m[8];
+  if (trace > 0.0) {
+    double s = sqrt(trace + 1.0);
+    q[3] = s * 0.5;
+    s = 0.5 / s;
+    q[0] = (m[7] - m[5]) * s;
+    q[1] = (m[2] - m[6]) * s;
+    q[2] = (m[3] - m[1]) * s;
+  } else {
+    const int i = m[0] < m[4] ? (m[4] < m[8] ? 2 : 1) : (m[0] < m[8] ? 2 : 0);
+    const int j = (i + 1) % 3, k = (i + 2) % 3;
+    double s = sqrt(m[i * 3 + i] - m[j * 3 + j] - m[k * 3 + k] + 1.0);
+    q[i] = s * 0.5;
+    s = 0.5 / s;
+    q[3] = (m[k * 3 + j] - m[j * 3 + k]) * s;
+    q[j] = (m[j * 3 + i] + m[i * 3 + j]) * s;
+    q[k] = (m[k * 3 + i] + m[i * 3 + k]) * s;
+  }
+}
+// odom (3 x 4, world <- laser) with the roll and pitch of its base_link orientation replaced by the IMU's
+LD_HD void imu_override(const double* odom, const double* imu_q, const double* laser_to_base, double* out) {
+  double m[9], imu_roll, imu_pitch, imu_yaw, bl_roll, bl_pitch, bl_yaw;
+  tf_matrix_from_quat(imu_q, m);
+  tf_get_rpy(m, &imu_roll, &imu_pitch, &imu_yaw);                 // :155-161
+  double odom_bl[12], q_bl[4], q_new[4], l2b_inv[12];
+  iso_mul(odom, laser_to_base, odom_bl);                          // :164
+  quat_from_rot(odom_bl, q_bl);                                   // :165
+  tf_matrix_from_quat(q_bl, m);
+  tf_get_rpy(m, &bl_roll, &bl_pitch, &bl_yaw);                    // :166-169
+  tf_set_rpy(imu_roll, imu_pitch, bl_yaw, m);                     // :174
+  tf_quat_from_matrix(m, q_new);                                  // :177
+  const double t_bl[3] = {odom_bl[3], odom_bl[7], odom_bl[11]};
+  iso_from_qt(q_new, t_bl, odom_bl);                              // :178-179
+  iso_inverse(laser_to_base, l2b_inv);
+  iso_mul(odom_bl, l2b_inv, out);                                 // :182
+}
 // ceres::EigenQuaternionParameterization::Plus, x = [x y z w]
 LD_HD void quat_plus(const double* x, const double* delta, double* out) {
   const double nd = sqrt(delta[0] * delta[0] + delta[1] * delta[1] + delta[2] * delta[2]);

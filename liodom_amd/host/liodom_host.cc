@@ -187,6 +187,12 @@ void LaserOdometer::setLocalMap(const PointCloud& map) {
   check(liodom_set_received_map(eng_->handle(), 0, reinterpret_cast<const float*>(map.points.data()), (int64_t)map.size()),
         "liodom_set_received_map");
 }
+void LaserOdometer::setLastIMUOri(const double q_xyzw[4]) {
+  check(liodom_set_imu_orientation(eng_->handle(), 0, q_xyzw), "liodom_set_imu_orientation");
+}
+void LaserOdometer::setLaserToBase(const std::array<double, 12>& T) {
+  check(liodom_set_laser_to_base(eng_->handle(), T.data()), "liodom_set_laser_to_base");
+}
 void LaserOdometer::attachMapper(Map* map, int cells_xy, int cells_z) {
   check(liodom_attach_mapper(eng_->handle(), 0, map ? map->handle() : nullptr, cells_xy, cells_z), "liodom_attach_mapper");
 }

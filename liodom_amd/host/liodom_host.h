@@ -139,6 +139,10 @@ class LaserOdometer {
   explicit LaserOdometer(std::shared_ptr<Engine> engine);
   // SharedData::setLocalMap (shared_data.cc:91-96), fed by mapClb (liodom_node.cc:57-64); mapping_ only
   void setLocalMap(const PointCloud& map);
+  // SharedData::setLastIMUOri (shared_data.cc:107-111), fed by imuClb (liodom_node.cc:66-70); use_imu_ only
+  void setLastIMUOri(const double q_xyzw[4]);
+  // laser_to_base_ (TF lookup, laser_odometry.cc:110-119); identity by default
+  void setLaserToBase(const std::array<double, 12>& T);
   // Zero-latency on-device replay of the liodom_mapping node (liodom_attach_mapper); mapping_ only
   void attachMapper(Map* map, int cells_xy = 2, int cells_z = 1);
   // One pass of the loop body of LaserOdometer::operator() (laser_odometry.cc:107-267).

@@ -284,6 +284,94 @@ inline Iso iso_from_qt(const double q[4], const double t[3]) {
   return T;
 }
 
+// ------------------------------------------------------------------------------------------
+// IMU roll / pitch override of the predicted pose        src/laser_odometry.cc:152-183
+// The reference goes through ROS tf's LinearMath (tf::Quaternion, tf::Matrix3x3: getRPY, setRPY,
+// getRotation).  tf is a third-party dependency that is NOT in /root/reference and is not version
+// pinned (package.xml lists `tf`; ROS Noetic ships geometry 1.13.x).  The three functions below
+// restate the published algorithms of tf/LinearMath/Matrix3x3.h (Bullet's btMatrix3x3, tfScalar =
+// double): parity unpinned, cross-checked against scipy's fixed-axis Euler conversion in
+// tests/test_oracle_odometry.py.
+// ------------------------------------------------------------------------------------------
+struct Mat3 { double e[3][3]; };
+// tf::Matrix3x3::setRotation(q): not Eigen's toRotationMatrix — it divides by |q|^2.
+inline Mat3 tf_matrix_from_quat(const double q[4]) {
+  const double x = q[0], y = q[1], z = q[2], w = q[3];
+  const double d = x * x + y * y + z * z + w * w;
+  const double sc = 2.0 / d;
+  const double xs = x * sc, ys = y * sc, zs = z * sc;
+  const double wx = w * xs, wy = w * ys, wz = w * zs;
+  const double xx = x * xs, xy = x * ys, xz = x * zs;
+  const double yy = y * ys, yz = y * zs, zz = z * zs;
+  Mat3 m;
+  m.e[0][0] = 1.0 - (yy + zz); m.e[0][1] = xy - wz;         m.e[0][2] = xz + wy;
+  m.e[1][0] = xy + wz;         m.e[1][1] = 1.0 - (xx + zz); m.e[1][2] = yz - wx;
+  m.e[2][0] = xz - wy;         m.e[2][1] = yz + wx;         m.e[2][2] = 1.0 - (xx + yy);
+  return m;
+}
+// tf::Matrix3x3::getRPY = getEulerYPR, solution 1 (including its gimbal-lock branch)
+inline void tf_get_rpy(const Mat3& m, double* roll, double* pitch, double* yaw) {
+  if (std::fabs(m.e[2][0]) >= 1) {
+    *yaw = 0;
+    const double delta = std::atan2(m.e[2][1], m.e[2][2]);
+    if (m.e[2][0] < 0) { *pitch = M_PI / 2.0; *roll = delta; }
+    else { *pitch = -M_PI / 2.0; *roll = delta; }
+  } else {
+    *pitch = -std::asin(m.e[2][0]);
+    const double cp = std::cos(*pitch);
+    *roll = std::atan2(m.e[2][1] / cp, m.e[2][2] / cp);
+    *yaw = std::atan2(m.e[1][0] / cp, m.e[0][0] / cp);
+  }
+}
+// tf::Matrix3x3::setRPY(roll, pitch, yaw) = setEulerYPR(yaw, pitch, roll)
+inline Mat3 tf_set_rpy(double roll, double pitch, double yaw) {
+  const double ci = std::cos(roll), cj = std::cos(pitch), ch = std::cos(yaw);
+  const double si = std::sin(roll), sj = std::sin(pitch), sh = std::sin(yaw);
+  const double cc = ci * ch, cs = ci * sh, sc = si * ch, ss = si * sh;
+  Mat3 m;
+  m.e[0][0] = cj * ch; m.e[0][1] = sj * sc - cs; m.e[0][2] = sj * cc + ss;
+  m.e[1][0] = cj * sh; m.e[1][1] = sj * ss + cc; m.e[1][2] = sj * cs - sc;
+  m.e[2][0] = -sj;     m.e[2][1] = cj * si;      m.e[2][2] = cj * ci;
+  return m;
+}
+// tf::Matrix3x3::getRotation(q), q = [x y z w]
+inline void tf_quat_from_matrix(const Mat3& m, double q[4]) {
+  const double trace = m.e[0][0] + m.e[1][1] + m.e[2][2];
+  if (trace > 0.0) {
+    double sq = std::sqrt(trace + 1.0);
+    q[3] = sq * 0.5;
+    sq = 0.5 / sq;
+    q[0] = (m.e[2][1] - m.e[1][2]) * sq;
+    q[1] = (m.e[0][2] - m.e[2][0]) * sq;
+    q[2] = (m.e[1][0] - m.e[0][1]) * sq;
+  } else {
+    const int i = m.e[0][0] < m.e[1][1] ? (m.e[1][1] < m.e[2][2] ? 2 : 1) : (m.e[0][0] < m.e[2][2] ? 2 : 0);
+    const int j = (i + 1) % 3, k = (i + 2) % 3;
+    double sq = std::sqrt(m.e[i][i] - m.e[j][j] - m.e[k][k] + 1.0);
+    q[i] = sq * 0.5;
+    sq = 0.5 / sq;
+    q[3] = (m.e[k][j] - m.e[j][k]) * sq;
+    q[j] = (m.e[j][i] + m.e[i][j]) * sq;
+    q[k] = (m.e[k][i] + m.e[i][k]) * sq;
+  }
+}
+// src/laser_odometry.cc:152-183, steps 1-5 as numbered there
+inline Iso imu_override(const Iso& odom, const double imu_q[4], const Iso& laser_to_base) {
+  double imu_roll, imu_pitch, imu_yaw;
+  tf_get_rpy(tf_matrix_from_quat(imu_q), &imu_roll, &imu_pitch, &imu_yaw);            // :155-161
+  Iso odom_bl = iso_mul(odom, laser_to_base);                                         // :164
+  double q_bl[4];
+  quat_from_rot(odom_bl, q_bl);                                                       // :165
+  double bl_roll, bl_pitch, bl_yaw;
+  tf_get_rpy(tf_matrix_from_quat(q_bl), &bl_roll, &bl_pitch, &bl_yaw);                // :166-169
+  const Mat3 m = tf_set_rpy(imu_roll, imu_pitch, bl_yaw);                             // :174
+  double q_new[4];
+  tf_quat_from_matrix(m, q_new);                                                      // :177
+  const double t_bl[3] = {odom_bl.m[3], odom_bl.m[7], odom_bl.m[11]};
+  odom_bl = iso_from_qt(q_new, t_bl);                                                 // :178-179 (Eigen toRotationMatrix)
+  return iso_mul(odom_bl, iso_inverse(laser_to_base));                                // :182
+}
+
 // pcl::transformPointCloud with a double matrix (src/laser_odometry.cc:232,308): PCL 1.10
 // detail::Transformer<double>::se3 — each coordinate in FP64, left to right, cast to float;
 // intensity copied.
@@ -933,6 +1021,9 @@ struct Odometer {
   double param_q[4] = {0, 0, 0, 1}, param_t[3] = {0, 0, 0};
   LocalMapManager lmap;
   std::vector<P4> received_map;                       // SharedData::setLocalMap (mapClb)
+  bool use_imu = false;                               // params->use_imu_ (params.cc:96)
+  double imu_q[4] = {0, 0, 0, 1};                     // SharedData::last_IMU_ori_ (imuClb, liodom_node.cc:66-70), [x y z w]
+  Iso laser_to_base = iso_identity();                 // laser_to_base_ (laser_odometry.cc:110-119)
   // mapping = true: the liodom_mapping node (src/liodom_mapping_node.cc:45-90, defaults :115-134)
   // replayed synchronously — the reference is asynchronous / non-deterministic here (SURVEY.md
   // §3.3): after scan k, updateMap(edges_k, pose_k); scan k+1 receives getLocalMap(pose_k, 2, 1).
@@ -1012,6 +1103,7 @@ struct Odometer {
       Iso pred = iso_mul(odom, iso_mul(iso_inverse(prev_odom), odom));
       prev_odom = odom;
       odom = pred;
+      if (use_imu) odom = imu_override(odom, imu_q, laser_to_base);                      // :152-183
       // initial guess (:186-195)
       quat_from_rot(odom, param_q);
       param_t[0] = odom.m[3]; param_t[1] = odom.m[7]; param_t[2] = odom.m[11];
@@ -1144,6 +1236,22 @@ int64_t orc_odom_get_window(void* h, float* xyzi, int64_t cap) {
   if (n > cap) return -n;
   if (n) std::memcpy(xyzi, o->lmap.total_points.data(), sizeof(P4) * (size_t)n);
   return n;
+}
+void orc_odom_set_imu(void* h, int use_imu, const double* q_xyzw) {
+  Odometer* o = static_cast<Odometer*>(h);
+  o->use_imu = use_imu != 0;
+  if (q_xyzw) for (int k = 0; k < 4; k++) o->imu_q[k] = q_xyzw[k];
+}
+void orc_odom_set_laser_to_base(void* h, const double* T12) {
+  Odometer* o = static_cast<Odometer*>(h);
+  for (int k = 0; k < 12; k++) o->laser_to_base.m[k] = T12[k];
+}
+// the override alone (unit tests): T12 in, T12 out
+void orc_imu_override(const double* T12, const double* imu_q, const double* l2b12, double* out12) {
+  Iso T, L;
+  for (int k = 0; k < 12; k++) { T.m[k] = T12[k]; L.m[k] = l2b12[k]; }
+  const Iso R = imu_override(T, imu_q, L);
+  for (int k = 0; k < 12; k++) out12[k] = R.m[k];
 }
 void orc_odom_set_received_map(void* h, const float* xyzi, int64_t n) {
   Odometer* o = static_cast<Odometer*>(h);

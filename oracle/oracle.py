@@ -70,6 +70,9 @@ def lib():
         L.orc_odom_create.restype = C.c_void_p
         L.orc_odom_create.argtypes = [C.POINTER(OrcParams)]
         L.orc_odom_destroy.argtypes = [C.c_void_p]
+        L.orc_odom_set_imu.argtypes = [C.c_void_p, C.c_int, dp]
+        L.orc_odom_set_laser_to_base.argtypes = [C.c_void_p, dp]
+        L.orc_imu_override.argtypes = [dp, dp, dp, dp]
         L.orc_odom_step.restype = C.c_int
         L.orc_odom_step.argtypes = [C.c_void_p, fp, C.c_int, dp, C.POINTER(StepInfo)]
         L.orc_odom_last_corr.restype = C.c_int
@@ -220,6 +223,15 @@ class Odometer:
     def map_total(self):
         return lib().orc_odom_map_total(self.h)
 
+    def set_imu(self, q_xyzw, use_imu=True):
+        """imuClb -> SharedData::setLastIMUOri (liodom_node.cc:66-70); use_imu = params->use_imu_."""
+        q = np.ascontiguousarray(q_xyzw, dtype=np.float64)
+        lib().orc_odom_set_imu(self.h, int(use_imu), _dp(q))
+
+    def set_laser_to_base(self, T34):
+        T = np.ascontiguousarray(T34, dtype=np.float64).reshape(12)
+        lib().orc_odom_set_laser_to_base(self.h, _dp(T))
+
     def set_received_map(self, xyzi):
         xyzi = np.ascontiguousarray(xyzi, dtype=np.float32).reshape(-1, 4)
         lib().orc_odom_set_received_map(self.h, _fp(xyzi), xyzi.shape[0])
@@ -261,6 +273,16 @@ class Map:
 
     def num_cells(self):
         return lib().orc_map_num_cells(self.h)
+
+
+def imu_override(T34, imu_q, l2b34=None):
+    """laser_odometry.cc:152-183 on one pose."""
+    T = np.ascontiguousarray(T34, dtype=np.float64).reshape(12)
+    q = np.ascontiguousarray(imu_q, dtype=np.float64)
+    L = np.ascontiguousarray(np.eye(4)[:3] if l2b34 is None else l2b34, dtype=np.float64).reshape(12)
+    out = np.zeros(12)
+    lib().orc_imu_override(_dp(T), _dp(q), _dp(L), _dp(out))
+    return out.reshape(3, 4)
 
 
 def knn5(map_xyzi, q_xyzi, mode=0):

@@ -369,3 +369,40 @@ def test_replay_harness_writes_reference_result_files(orc, synth, tmp_path):
     assert np.loadtxt(str(out_dir / "nfeats.txt")).astype(int).tolist() == nfeats
     for f in ("feat_ext_times.txt", "laser_odom_times.txt", "frame_times.txt"):
         assert (out_dir / f).exists()
+
+
+def test_use_imu_roll_pitch_override(orc, synth):
+    """use_imu (laser_odometry.cc:152-183): roll / pitch of every prediction replaced by the IMU's,
+    in the base_link frame (non-identity laser_to_base), before the solve.  IMU = ground-truth
+    orientation with a small perturbation so that the override visibly changes the start pose."""
+    H, W, R, epr, P, K = 16, 900, 6, 10, 5, 12
+    cfg = synth.make_cfg(H, W, 0)
+    po = orc.make_params(scan_lines=H, scan_regions=R, edges_per_region=epr, prev_frames=P, knn_mode=1)
+    g = la.Liodom(la.make_params(scan_lines=H, scan_regions=R, edges_per_region=epr, prev_frames=P, use_imu=1),
+                  la.make_config(max_points=H * W, max_width=W))
+    od = orc.Odometer(po)
+    od_plain = orc.Odometer(po)
+    c, s = np.cos(0.05), np.sin(0.05)
+    L = np.array([[c, 0, s, 0.3], [0, 1, 0, -0.1], [-s, 0, c, 0.8]], dtype=np.float64)
+    od.set_laser_to_base(L)
+    g.set_laser_to_base(L)
+    rng = np.random.default_rng(11)
+    differs = 0
+    for k in range(K):
+        x, gt = synth.scan(cfg, 0, k)
+        q = gt[:4] + rng.normal(0, 2e-3, 4)
+        q /= np.linalg.norm(q)
+        od.set_imu(q)
+        g.set_imu(q)
+        e = orc.extract(po, x, H, W)["edges"]
+        pose_o, info_o = od.step(e)
+        pose_p, _ = od_plain.step(e)
+        pose_g, info_g = g.process_scan(x, H, W)
+        assert np.linalg.norm(pose_g[4:] - pose_o[4:]) <= POSE_TOL_T and rot_angle(pose_g[:4], pose_o[:4]) <= POSE_TOL_R, k
+        if k > 0:
+            assert abs(info_g.matches[0] - info_o.matches[0]) <= 3
+            assert info_g.lm[0].iterations == info_o.lm[0].iterations
+            assert abs(info_g.lm[0].initial_cost - info_o.lm[0].initial_cost) <= 1e-6 * max(1.0, info_o.lm[0].initial_cost)
+            differs += int(np.linalg.norm(pose_p - pose_o) > 1e-9)      # the override is not a no-op
+    assert differs > 0
+    g.close()

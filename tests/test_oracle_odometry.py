@@ -257,3 +257,49 @@ def test_odometer_tracks_synthetic_stream(orc, synth):
         assert np.linalg.norm(pose[4:6] - gt[4:6]) < 0.15 and abs(pose[6] - gt[6]) < 0.15
         dq = min(np.linalg.norm(pose[:4] - gt[:4]), np.linalg.norm(pose[:4] + gt[:4]))
         assert dq < 0.01
+
+
+def test_imu_roll_pitch_override_matches_fixed_axis_euler(orc):
+    """laser_odometry.cc:152-183 through the restated tf::Matrix3x3 getRPY / setRPY / getRotation:
+    cross-check against scipy's extrinsic x-y-z (= fixed-axis roll, pitch, yaw) conversion."""
+    from scipy.spatial.transform import Rotation as Rsc
+    rng = np.random.default_rng(3)
+    for trial in range(200):
+        rpy_odom = rng.uniform([-0.5, -0.5, -3.1], [0.5, 0.5, 3.1])
+        rpy_imu = rng.uniform([-0.6, -0.6, -3.1], [0.6, 0.6, 3.1])
+        T = np.zeros((3, 4))
+        T[:, :3] = Rsc.from_euler("xyz", rpy_odom).as_matrix()
+        T[:, 3] = rng.uniform(-50, 50, 3)
+        q_imu = Rsc.from_euler("xyz", rpy_imu).as_quat()          # [x y z w]
+        out = orc.imu_override(T, q_imu)
+        want = Rsc.from_euler("xyz", [rpy_imu[0], rpy_imu[1], rpy_odom[2]]).as_matrix()
+        assert np.allclose(out[:, :3], want, atol=1e-12), trial
+        assert np.array_equal(out[:, 3], T[:, 3])
+        # with a laser -> base_link mounting transform the override acts in the base_link frame
+        L = np.zeros((3, 4))
+        L[:, :3] = Rsc.from_euler("xyz", rng.uniform(-0.3, 0.3, 3)).as_matrix()
+        L[:, 3] = rng.uniform(-1, 1, 3)
+        out2 = orc.imu_override(T, q_imu, L)
+        T4, L4 = np.vstack([T, [0, 0, 0, 1]]), np.vstack([L, [0, 0, 0, 1]])
+        bl = T4 @ L4
+        yaw_bl = Rsc.from_matrix(bl[:3, :3]).as_euler("xyz")[2]
+        bl[:3, :3] = Rsc.from_euler("xyz", [rpy_imu[0], rpy_imu[1], yaw_bl]).as_matrix()
+        assert np.allclose(out2, (bl @ np.linalg.inv(L4))[:3], atol=1e-10), trial
+
+
+def test_odometer_with_imu_keeps_roll_and_pitch(orc, synth):
+    """use_imu: the prediction's roll / pitch are replaced by the IMU's before the solve; with a
+    perfect IMU the trajectory stays as accurate as without."""
+    H, W = 16, 900
+    cfg = synth.make_cfg(H, W, 0)
+    po = orc.make_params(scan_lines=H, scan_regions=6, edges_per_region=10, prev_frames=5, knn_mode=1)
+    od = orc.Odometer(po)
+    gt0 = None
+    for k in range(8):
+        x, gt = synth.scan(cfg, 0, k)
+        if gt0 is None:
+            gt0 = gt
+        od.set_imu(gt[:4])
+        pose, info = od.step(orc.extract(po, x, H, W)["edges"])
+    assert info.matches[1] > 30
+    assert np.linalg.norm(pose[4:] - (gt[4:] - gt0[4:])) < 0.2
