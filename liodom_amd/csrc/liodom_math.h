@@ -225,6 +225,23 @@ LD_HD void imu_override(const double* odom, const double* imu_q, const double* l
   iso_inverse(laser_to_base, l2b_inv);
   iso_mul(odom_bl, l2b_inv, out);                                 // :182
 }
+// LaserOdometer::publishOdom (src/laser_odometry.cc:395-436): pose in the base_link frame and the
+// finite-difference twist.  out: orientation x y z w, position, twist.linear, twist.angular (13).
+LD_HD void odom_message(const double* prev_odom, const double* odom, const double* laser_to_base,
+                        double delta_time, double* out) {
+  double bl[12], pbl[12], pinv[12], d[12], qd[4], m[9], roll, pitch, yaw;
+  iso_mul(odom, laser_to_base, bl);                 // :403
+  quat_from_rot(bl, out);                           // :404
+  out[4] = bl[3]; out[5] = bl[7]; out[6] = bl[11];  // :405
+  iso_mul(prev_odom, laser_to_base, pbl);
+  iso_inverse(pbl, pinv);
+  iso_mul(pinv, bl, d);                             // :416
+  out[7] = d[3] / delta_time; out[8] = d[7] / delta_time; out[9] = d[11] / delta_time;   // :417-420
+  quat_from_rot(d, qd);                             // :421
+  tf_matrix_from_quat(qd, m);
+  tf_get_rpy(m, &roll, &pitch, &yaw);               // :423-426
+  out[10] = roll / delta_time; out[11] = pitch / delta_time; out[12] = yaw / delta_time;
+}
 // ceres::EigenQuaternionParameterization::Plus, x = [x y z w]
 LD_HD void quat_plus(const double* x, const double* delta, double* out) {
   const double nd = sqrt(delta[0] * delta[0] + delta[1] * delta[1] + delta[2] * delta[2]);

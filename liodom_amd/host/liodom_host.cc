@@ -1,4 +1,5 @@
 #include "liodom_host.h"
+#include "../csrc/liodom_math.h"   // odom_message: the same header the kernels use
 
 #include <cstring>
 #include <fstream>
@@ -192,6 +193,27 @@ void LaserOdometer::setLastIMUOri(const double q_xyzw[4]) {
 }
 void LaserOdometer::setLaserToBase(const std::array<double, 12>& T) {
   check(liodom_set_laser_to_base(eng_->handle(), T.data()), "liodom_set_laser_to_base");
+  laser_to_base_ = T;
+}
+
+OdometryMsg LaserOdometer::publishOdom(double stamp, const Pose& pose) {
+  OdometryMsg msg;
+  msg.frame_id = params->fixed_frame_;             // :398
+  msg.child_frame_id = params->base_frame_;        // :399
+  msg.stamp = stamp;                               // :400
+  const std::array<double, 12> cur = pose.matrix34();
+  // first frame: prev_stamp_ is set to the frame's own stamp before publishing (:125,136), so the
+  // first twist is 0 / 0 = NaN exactly as the reference publishes it
+  if (!published_) { prev_stamp_ = stamp; published_ = true; }
+  double out[13];
+  liodom_dev::odom_message(prev_odom_.data(), cur.data(), laser_to_base_.data(), stamp - prev_stamp_, out);
+  std::memcpy(msg.orientation, out, sizeof(double) * 4);
+  std::memcpy(msg.position, out + 4, sizeof(double) * 3);
+  std::memcpy(msg.linear, out + 7, sizeof(double) * 3);
+  std::memcpy(msg.angular, out + 10, sizeof(double) * 3);
+  prev_odom_ = cur;                                // the reference's prev_odom_ (:149) is the pose of the previous scan here
+  prev_stamp_ = stamp;                             // :266
+  return msg;
 }
 void LaserOdometer::attachMapper(Map* map, int cells_xy, int cells_z) {
   check(liodom_attach_mapper(eng_->handle(), 0, map ? map->handle() : nullptr, cells_xy, cells_z), "liodom_attach_mapper");

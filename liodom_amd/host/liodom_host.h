@@ -134,9 +134,22 @@ class Map {
   liodom_map_t* m_ = nullptr;
 };
 
+// The numbers LaserOdometer::publishOdom puts into nav_msgs/Odometry, geometry_msgs/TwistStamped
+// and the fixed_frame -> base_frame TF (laser_odometry.cc:395-446).
+struct OdometryMsg {
+  std::string frame_id, child_frame_id;   // params->fixed_frame_, params->base_frame_
+  double stamp = 0;
+  double orientation[4] = {0, 0, 0, 1};   // x y z w, pose * laser_to_base_
+  double position[3] = {0, 0, 0};
+  double linear[3] = {0, 0, 0};           // delta translation / delta stamp
+  double angular[3] = {0, 0, 0};          // tf RPY of the delta rotation / delta stamp
+};
+
 class LaserOdometer {
  public:
   explicit LaserOdometer(std::shared_ptr<Engine> engine);
+  // publishOdom (laser_odometry.cc:395-446) for the pose returned by the last process / processScan
+  OdometryMsg publishOdom(double stamp, const Pose& pose);
   // SharedData::setLocalMap (shared_data.cc:91-96), fed by mapClb (liodom_node.cc:57-64); mapping_ only
   void setLocalMap(const PointCloud& map);
   // SharedData::setLastIMUOri (shared_data.cc:107-111), fed by imuClb (liodom_node.cc:66-70); use_imu_ only
@@ -154,6 +167,10 @@ class LaserOdometer {
   std::shared_ptr<Engine> eng_;
   Params* params;
   Stats* stats;
+  std::array<double, 12> prev_odom_{{1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0}};      // laser_odometry.h:95
+  std::array<double, 12> laser_to_base_{{1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0}};  // laser_odometry.h:104
+  double prev_stamp_ = 0.0;                                                     // laser_odometry.h:97
+  bool published_ = false;
 };
 
 }  // namespace liodom

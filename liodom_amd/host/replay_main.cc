@@ -66,9 +66,18 @@ int main(int argc, char** argv) {
       mapper.reset(new liodom::Map(xy, z, res));
       odometer.attachMapper(mapper.get(), cells_xy, cells_z);
     }
+    std::ofstream odom_log(out + "odom.txt");      // stamp, orientation xyzw, position, twist linear, twist angular
+    odom_log.precision(12);
     for (size_t i = 0; i < clouds.size(); i++) {
       liodom_step_info_t info;
       liodom::Pose p = odometer.processScan(clouds[i], 0.1 * (double)i, &info);
+      const liodom::OdometryMsg msg = odometer.publishOdom(0.1 * (double)i, p);      // ~odom / ~twist numbers
+      odom_log << msg.stamp;
+      for (double v : msg.orientation) odom_log << ' ' << v;
+      for (double v : msg.position) odom_log << ' ' << v;
+      for (double v : msg.linear) odom_log << ' ' << v;
+      for (double v : msg.angular) odom_log << ' ' << v;
+      odom_log << '\n';
       if (i % 50 == 0) std::printf("scan %zu: %d edges, %d matches, t = %.3f %.3f %.3f\n", i, info.n_edges, info.matches[1], p.t[0], p.t[1], p.t[2]);
     }
     liodom::Stats::getInstance()->writeResults(out);

@@ -1253,6 +1253,21 @@ void orc_imu_override(const double* T12, const double* imu_q, const double* l2b1
   const Iso R = imu_override(T, imu_q, L);
   for (int k = 0; k < 12; k++) out12[k] = R.m[k];
 }
+// LaserOdometer::publishOdom (src/laser_odometry.cc:395-436): the nav_msgs/Odometry numbers.
+// out[0..3] orientation x y z w, out[4..6] position, out[7..9] twist.linear, out[10..12] twist.angular
+void orc_publish_odom(const double* prev12, const double* cur12, const double* l2b12, double delta_time, double* out) {
+  Iso P, T, L;
+  for (int k = 0; k < 12; k++) { P.m[k] = prev12[k]; T.m[k] = cur12[k]; L.m[k] = l2b12[k]; }
+  const Iso odom_base_link = iso_mul(T, L);                                   // :403
+  quat_from_rot(odom_base_link, out);                                         // :404
+  out[4] = odom_base_link.m[3]; out[5] = odom_base_link.m[7]; out[6] = odom_base_link.m[11];   // :405
+  const Iso delta_odom = iso_mul(iso_inverse(iso_mul(P, L)), odom_base_link); // :416
+  out[7] = delta_odom.m[3] / delta_time; out[8] = delta_odom.m[7] / delta_time; out[9] = delta_odom.m[11] / delta_time;  // :417-420
+  double qd[4], roll, pitch, yaw;
+  quat_from_rot(delta_odom, qd);                                              // :421
+  tf_get_rpy(tf_matrix_from_quat(qd), &roll, &pitch, &yaw);                   // :423-426
+  out[10] = roll / delta_time; out[11] = pitch / delta_time; out[12] = yaw / delta_time;       // :427-429
+}
 void orc_odom_set_received_map(void* h, const float* xyzi, int64_t n) {
   Odometer* o = static_cast<Odometer*>(h);
   o->received_map.resize((size_t)n);

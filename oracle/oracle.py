@@ -73,6 +73,7 @@ def lib():
         L.orc_odom_set_imu.argtypes = [C.c_void_p, C.c_int, dp]
         L.orc_odom_set_laser_to_base.argtypes = [C.c_void_p, dp]
         L.orc_imu_override.argtypes = [dp, dp, dp, dp]
+        L.orc_publish_odom.argtypes = [dp, dp, dp, C.c_double, dp]
         L.orc_odom_step.restype = C.c_int
         L.orc_odom_step.argtypes = [C.c_void_p, fp, C.c_int, dp, C.POINTER(StepInfo)]
         L.orc_odom_last_corr.restype = C.c_int
@@ -283,6 +284,16 @@ def imu_override(T34, imu_q, l2b34=None):
     out = np.zeros(12)
     lib().orc_imu_override(_dp(T), _dp(q), _dp(L), _dp(out))
     return out.reshape(3, 4)
+
+
+def publish_odom(prev34, cur34, dt, l2b34=None):
+    """publishOdom (laser_odometry.cc:395-436): orientation[4], position[3], linear[3], angular[3]."""
+    P = np.ascontiguousarray(prev34, dtype=np.float64).reshape(12)
+    T = np.ascontiguousarray(cur34, dtype=np.float64).reshape(12)
+    L = np.ascontiguousarray(np.eye(4)[:3] if l2b34 is None else l2b34, dtype=np.float64).reshape(12)
+    out = np.zeros(13)
+    lib().orc_publish_odom(_dp(P), _dp(T), _dp(L), float(dt), _dp(out))
+    return out
 
 
 def knn5(map_xyzi, q_xyzi, mode=0):

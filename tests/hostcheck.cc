@@ -28,6 +28,10 @@ void hc_pose_ops(const double* q, const double* t, double* T12, double* qback) {
   iso_from_qt(q, t, T12);
   quat_from_rot(T12, qback);
 }
+void hc_imu_override(const double* T12, const double* imu_q, const double* l2b, double* out12) { imu_override(T12, imu_q, l2b, out12); }
+void hc_odom_message(const double* prev12, const double* cur12, const double* l2b, double dt, double* out13) {
+  odom_message(prev12, cur12, l2b, dt, out13);
+}
 void hc_predict(const double* odom, const double* prev, double* pred) {
   double inv[12], rel[12];
   iso_inverse(prev, inv);

@@ -33,6 +33,8 @@ def hc():
     L.hc_transform.argtypes = [dp, fp, C.c_int, fp]
     L.hc_pose_ops.argtypes = [dp, dp, dp, dp]
     L.hc_predict.argtypes = [dp, dp, dp]
+    L.hc_imu_override.argtypes = [dp, dp, dp, dp]
+    L.hc_odom_message.argtypes = [dp, dp, dp, C.c_double, dp]
     L.hc_accumulate.argtypes = [dp, C.c_int, dp, dp, C.c_double, C.c_double, dp]
     L.hc_lm_solve.restype = C.c_int
     L.hc_lm_solve.argtypes = [dp, C.c_int, dp, dp, C.c_double, C.c_double, C.c_int,
@@ -172,3 +174,34 @@ def test_lm_degenerate_inputs(hc, orc):
     assert term == 5 and q.tolist() == [0, 0, 0, 1]
     qo, to, tr = orc.lm_solve(blk, [0, 0, 0, 1.0], [0, 0, 0.0])
     assert tr.termination == 5
+
+
+def test_imu_override_and_odom_message(hc, orc):
+    """use_imu override (laser_odometry.cc:152-183) and publishOdom's numbers (:395-436): the
+    product's header against the oracle, plus scipy for the twist of a known motion."""
+    from scipy.spatial.transform import Rotation as Rsc
+    rng = np.random.default_rng(5)
+    for trial in range(100):
+        def rand_iso(ang, tr):
+            T = np.zeros((3, 4))
+            T[:, :3] = Rsc.from_euler("xyz", rng.uniform(-ang, ang, 3)).as_matrix()
+            T[:, 3] = rng.uniform(-tr, tr, 3)
+            return T
+        T, L = rand_iso(3.0 if trial % 2 else 0.4, 40.0), rand_iso(0.3, 1.0)
+        q = Rsc.from_euler("xyz", rng.uniform(-0.7, 0.7, 3)).as_quat()
+        got = np.zeros(12)
+        hc.hc_imu_override(_dp(T.reshape(12).copy()), _dp(q.copy()), _dp(L.reshape(12).copy()), _dp(got))
+        assert np.allclose(got.reshape(3, 4), orc.imu_override(T, q, L), atol=1e-13)
+        # publishOdom: previous pose -> current pose = previous * known motion
+        step = rand_iso(0.05, 0.3)
+        T4, S4 = np.vstack([T, [0, 0, 0, 1]]), np.vstack([step, [0, 0, 0, 1]])
+        cur = (T4 @ S4)[:3]
+        msg = np.zeros(13)
+        hc.hc_odom_message(_dp(T.reshape(12).copy()), _dp(cur.reshape(12).copy()), _dp(L.reshape(12).copy()), 0.1, _dp(msg))
+        assert np.allclose(msg, orc.publish_odom(T, cur, 0.1, L), atol=1e-12)
+    # identity mounting: twist = motion / dt, orientation = pose quaternion
+    I = np.eye(4)[:3]
+    step = np.zeros((3, 4)); step[:, :3] = Rsc.from_euler("xyz", [0.01, -0.02, 0.03]).as_matrix(); step[:, 3] = [0.1, 0.02, -0.01]
+    msg = orc.publish_odom(I, step, 0.1)
+    assert np.allclose(msg[7:10], step[:, 3] / 0.1) and np.allclose(msg[10:13], np.array([0.01, -0.02, 0.03]) / 0.1, atol=1e-12)
+    assert np.allclose(msg[:4], Rsc.from_matrix(step[:, :3]).as_quat(), atol=1e-12)
