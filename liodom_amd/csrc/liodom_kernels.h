@@ -920,26 +920,54 @@ __device__ int lm_compact(const DevView& v, int s, int e_begin, int E, int* idx 
   return run;
 }
 
+// The correspondences of a solve do not change between its evaluations: every thread keeps its
+// first kLmCached triples (p, a, b) in registers (loaded once by lm_cache_load), so an evaluation
+// of up to kLmCached * kLmThreads blocks touches no memory before the reduction.
+constexpr int kLmCached = 1;
+struct LmCache { float4 P[kLmCached], A[kLmCached], B[kLmCached]; };
+__device__ __forceinline__ void lm_cache_load(const DevView& v, int s, int eb, int C, const int* idx, LmCache& k) {
+  const float4* ed = v.edges + ((size_t)eb * v.n_streams + s) * v.edge_cap;
+  const float4* ca = v.corr_a + (size_t)s * v.edge_cap;
+  const float4* cb = v.corr_b + (size_t)s * v.edge_cap;
+#pragma unroll
+  for (int j = 0; j < kLmCached; j++) {
+    const int c = threadIdx.x + j * kLmThreads;
+    if (c < C) { const int e = idx[c]; k.A[j] = ca[e]; k.B[j] = cb[e]; k.P[j] = ed[e]; }
+  }
+}
+
 __device__ __forceinline__ void lm_eval(const DevView& v, int s, int eb, int C, const int* idx, const double* Rm_sh,
-                                        double* part /*[kLmThreads/16][kAccN]*/, double* acc_out /*[kAccN]*/) {
+                                        double* part /*[kLmThreads/16][kAccN]*/, double* acc_out /*[kAccN]*/,
+                                        const LmCache& k) {
   double Rm[12];
 #pragma unroll
   for (int i = 0; i < 12; i++) Rm[i] = Rm_sh[i];
   double acc[kAccN];
 #pragma unroll
   for (int i = 0; i < kAccN; i++) acc[i] = 0.0;
-  const float4* ed = v.edges + ((size_t)eb * v.n_streams + s) * v.edge_cap;
-  const float4* ca = v.corr_a + (size_t)s * v.edge_cap;
-  const float4* cb = v.corr_b + (size_t)s * v.edge_cap;
-  for (int c = threadIdx.x; c < C; c += kLmThreads) {
-    const int e = idx[c];
-    const float4 A = ca[e];
-    const float4 B = cb[e];
-    const float4 P = ed[e];
-    const double p[3] = {(double)P.x, (double)P.y, (double)P.z};     // :347-349 sensor frame
-    const double a[3] = {(double)A.x, (double)A.y, (double)A.z};
-    const double b[3] = {(double)B.x, (double)B.y, (double)B.z};
-    residual_accumulate(Rm, p, a, b, v.min_range, v.max_range, acc);
+#pragma unroll
+  for (int j = 0; j < kLmCached; j++) {
+    if ((int)threadIdx.x + j * kLmThreads < C) {
+      const double p[3] = {(double)k.P[j].x, (double)k.P[j].y, (double)k.P[j].z};     // :347-349 sensor frame
+      const double a[3] = {(double)k.A[j].x, (double)k.A[j].y, (double)k.A[j].z};
+      const double b[3] = {(double)k.B[j].x, (double)k.B[j].y, (double)k.B[j].z};
+      residual_accumulate(Rm, p, a, b, v.min_range, v.max_range, acc);
+    }
+  }
+  if (C > kLmCached * kLmThreads) {
+    const float4* ed = v.edges + ((size_t)eb * v.n_streams + s) * v.edge_cap;
+    const float4* ca = v.corr_a + (size_t)s * v.edge_cap;
+    const float4* cb = v.corr_b + (size_t)s * v.edge_cap;
+    for (int c = threadIdx.x + kLmCached * kLmThreads; c < C; c += kLmThreads) {
+      const int e = idx[c];
+      const float4 A = ca[e];
+      const float4 B = cb[e];
+      const float4 P = ed[e];
+      const double p[3] = {(double)P.x, (double)P.y, (double)P.z};
+      const double a[3] = {(double)A.x, (double)A.y, (double)A.z};
+      const double b[3] = {(double)B.x, (double)B.y, (double)B.z};
+      residual_accumulate(Rm, p, a, b, v.min_range, v.max_range, acc);
+    }
   }
   // reduction: DPP butterfly inside each 16-lane row, one partial per row into LDS, then a
   // fixed-order sum of the (waves x 4) partials -> deterministic, no atomics
@@ -1155,9 +1183,11 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
   unsigned int n_eval = 0;
   const int C = lm_compact(v, s, e_lo, e_hi, sh_idx, sh_cnt);   // (ends with a barrier; sh_cnt doubles as scratch)
   __syncthreads();
+  LmCache cache;
+  lm_cache_load(v, s, eb, C, sh_idx, cache);
   DBG_STAMP(v, dbgb, 2, 1);
-  if (G > 1) { lm_eval(v, s, eb, C, sh_idx, sh_pose, sh_part, sh_loc); lm_exchange(v, s, g, G, epoch0 | ++n_eval, sh_loc, sh_acc, &st.status); }
-  else lm_eval(v, s, eb, C, sh_idx, sh_pose, sh_part, sh_acc);
+  if (G > 1) { lm_eval(v, s, eb, C, sh_idx, sh_pose, sh_part, sh_loc, cache); lm_exchange(v, s, g, G, epoch0 | ++n_eval, sh_loc, sh_acc, &st.status); }
+  else lm_eval(v, s, eb, C, sh_idx, sh_pose, sh_part, sh_acc, cache);
   DBG_STAMP(v, dbgb, 2, 2);
   if (threadIdx.x == 0) {
     sh_flag = lm_begin(lm, st.param_q, st.param_t, sh_acc, nblocks, v.apply_on_ftol);
@@ -1167,8 +1197,8 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
   DBG_STAMP(v, dbgb, 2, 3);
   int dbg_it = 0;
   while (sh_flag == LM_NEED_EVAL && !(v.debug & 8)) {
-    if (G > 1) { lm_eval(v, s, eb, C, sh_idx, sh_pose, sh_part, sh_loc); lm_exchange(v, s, g, G, epoch0 | ++n_eval, sh_loc, sh_acc, &st.status); }
-    else lm_eval(v, s, eb, C, sh_idx, sh_pose, sh_part, sh_acc);
+    if (G > 1) { lm_eval(v, s, eb, C, sh_idx, sh_pose, sh_part, sh_loc, cache); lm_exchange(v, s, g, G, epoch0 | ++n_eval, sh_loc, sh_acc, &st.status); }
+    else lm_eval(v, s, eb, C, sh_idx, sh_pose, sh_part, sh_acc, cache);
     DBG_STAMP(v, dbgb && dbg_it < 5, 2, 4 + 2 * dbg_it);
     if (threadIdx.x == 0) {
       sh_flag = lm_update(lm, sh_acc);
@@ -1275,17 +1305,28 @@ __global__ __launch_bounds__(256) void k_window_insert(DevView v, int s0, int eb
   CellSlot* cells = v.cells + (size_t)s * v.table_size;
   unsigned int h = hash_cell(key, tmask);
   int found = -1;
+  bool created = false;
   for (int probe = 0; probe < v.table_size; probe++) {
     const unsigned long long prev = atomicCAS(&cells[h].key, kEmptyKey, key);
     if (prev == kEmptyKey) {
-      const int u = atomicAdd(&st.n_used, 1);
-      v.used_cells[(size_t)s * v.map_cap + u] = (int)h;
       atomicOr(&v.cell_bits[((size_t)s * v.table_size + h) >> 5], 1u << (h & 31));
       found = (int)h;
+      created = true;
       break;
     }
     if (prev == key) { found = (int)h; break; }
     h = (h + 1) & tmask;
+  }
+  // list of occupied slots: one atomic per wave for all the slots its lanes created
+  {
+    const unsigned long long cm = __ballot(created);
+    if (cm) {
+      const int lane = threadIdx.x & 63;
+      int base = 0;
+      if (lane == (int)__builtin_ctzll(cm)) base = atomicAdd(&st.n_used, (int)__popcll(cm));
+      base = __shfl(base, (int)__builtin_ctzll(cm));
+      if (created) v.used_cells[(size_t)s * v.map_cap + base + (int)__popcll(cm & ((1ull << lane) - 1ull))] = (int)h;
+    }
   }
   if (found < 0) { atomicOr(&st.status, LIODOM_STATUS_HASH_FULL); *pc = -1; return; }
   // the value the count had before this point is its rank inside the cell: the scatter pass
@@ -1294,14 +1335,27 @@ __global__ __launch_bounds__(256) void k_window_insert(DevView v, int s0, int eb
   *pc = found;
 }
 
+// Start offsets of the occupied cells (any order: only contiguity per cell matters).  One atomic
+// per wave: the 64 counts are scanned in the wave and lane 0 reserves the wave's total — 3 500
+// same-address atomics serialise in L2 (measured 7.5 us for this launch), 55 do not.
 __global__ __launch_bounds__(256) void k_hash_alloc(DevView v, int s0) {
   const int s = s0 + blockIdx.y;
   StreamState& st = v.state[s];
+  const int nu = st.n_used;
+  if ((int)(blockIdx.x * 256) >= nu) return;
   const int u = blockIdx.x * 256 + threadIdx.x;
-  if (u >= st.n_used) return;
-  const int h = v.used_cells[(size_t)s * v.map_cap + u];
-  CellSlot* slot = v.cells + (size_t)s * v.table_size + h;
-  slot->start = (unsigned int)atomicAdd(&st.cursor, (int)slot->cnt);
+  CellSlot* slot = nullptr;
+  int cnt = 0;
+  if (u < nu) {
+    slot = v.cells + (size_t)s * v.table_size + v.used_cells[(size_t)s * v.map_cap + u];
+    cnt = (int)slot->cnt;
+  }
+  const int incl = wave_incl_scan_i32(cnt);
+  const int total = readlane_i32(incl, 63);
+  int base = 0;
+  if ((threadIdx.x & 63) == 0 && total > 0) base = atomicAdd(&st.cursor, total);
+  base = __builtin_amdgcn_readfirstlane(base);
+  if (slot) slot->start = (unsigned int)(base + incl - cnt);
 }
 
 __global__ __launch_bounds__(256) void k_hash_scatter(DevView v, int s0) {

@@ -111,7 +111,19 @@ LD_HD void iso_inverse(const double* A, double* C) {
   for (int r = 0; r < 3; r++)
     C[r * 4 + 3] = -(C[r * 4 + 0] * A[3] + C[r * 4 + 1] * A[7] + C[r * 4 + 2] * A[11]);
 }
-// Eigen::Quaterniond(Matrix3d) (src/laser_odometry.cc:186); q = [x y z w]
+// Eigen::Quaterniond(Matrix3d) (src/laser_odometry.cc:186); q = [x y z w].  The branch on the
+// largest diagonal element is spelled out per case: run-time indices would push T and q to scratch
+// memory on the GPU.
+template <int I>
+LD_HD void quat_from_rot_case(const double* T, double* q) {
+  constexpr int J = (I + 1) % 3, K = (J + 1) % 3;
+  double t = sqrt(T[I * 4 + I] - T[J * 4 + J] - T[K * 4 + K] + 1.0);
+  q[I] = 0.5 * t;
+  t = 0.5 / t;
+  q[3] = (T[K * 4 + J] - T[J * 4 + K]) * t;
+  q[J] = (T[J * 4 + I] + T[I * 4 + J]) * t;
+  q[K] = (T[K * 4 + I] + T[I * 4 + K]) * t;
+}
 LD_HD void quat_from_rot(const double* T, double* q) {
   double t = T[0] + T[5] + T[10];
   if (t > 0.0) {
@@ -124,14 +136,10 @@ LD_HD void quat_from_rot(const double* T, double* q) {
   } else {
     int i = 0;
     if (T[5] > T[0]) i = 1;
-    if (T[10] > T[i * 4 + i]) i = 2;
-    const int j = (i + 1) % 3, k = (j + 1) % 3;
-    t = sqrt(T[i * 4 + i] - T[j * 4 + j] - T[k * 4 + k] + 1.0);
-    q[i] = 0.5 * t;
-    t = 0.5 / t;
-    q[3] = (T[k * 4 + j] - T[j * 4 + k]) * t;
-    q[j] = (T[j * 4 + i] + T[i * 4 + j]) * t;
-    q[k] = (T[k * 4 + i] + T[i * 4 + k]) * t;
+    if (T[10] > (i == 0 ? T[0] : T[5])) i = 2;
+    if (i == 0) quat_from_rot_case<0>(T, q);
+    else if (i == 1) quat_from_rot_case<1>(T, q);
+    else quat_from_rot_case<2>(T, q);
   }
 }
 // Eigen::Quaterniond::toRotationMatrix + translation (src/laser_odometry.cc:225-227)
@@ -314,6 +322,28 @@ LD_HD bool line_gate(const float* nx, const float* ny, const float* nz) {
     const double zx = (double)nx[j] - cx, zy = (double)ny[j] - cy, zz = (double)nz[j] - cz;
     cov[0] = cov[0] + zx * zx; cov[1] = cov[1] + zx * zy; cov[2] = cov[2] + zx * zz;
     cov[3] = cov[3] + zy * zy; cov[4] = cov[4] + zy * zz; cov[5] = cov[5] + zz * zz;
+  }
+  // The gate needs a decision, not eigenvalues: the closed-form (trigonometric) eigenvalues of a
+  // symmetric 3 x 3 matrix cost ~60 flops + acos + 2 cos on the one lane that evaluates the gate,
+  // the iterative solver ~4 us of dependent FP64 latency.  Their absolute error is a few ulp of
+  // the largest eigenvalue, so the closed form decides whenever lambda2 - 3*lambda1 is not within
+  // 1e-9 * lambda2 of zero; the (rare) rest goes through the iterative solver as before.
+  const double p1 = cov[1] * cov[1] + cov[2] * cov[2] + cov[4] * cov[4];
+  const double q = (cov[0] + cov[3] + cov[5]) / 3.0;
+  const double d0 = cov[0] - q, d1 = cov[3] - q, d2 = cov[5] - q;
+  const double p2 = d0 * d0 + d1 * d1 + d2 * d2 + 2.0 * p1;
+  const double pp = sqrt(p2 / 6.0);
+  if (pp > 0.0 && ld_isfinite(pp)) {
+    const double ip = 1.0 / pp;
+    const double b00 = d0 * ip, b11 = d1 * ip, b22 = d2 * ip, b01 = cov[1] * ip, b02 = cov[2] * ip, b12 = cov[4] * ip;
+    double r = 0.5 * (b00 * (b11 * b22 - b12 * b12) - b01 * (b01 * b22 - b12 * b02) + b02 * (b01 * b12 - b11 * b02));
+    r = r < -1.0 ? -1.0 : (r > 1.0 ? 1.0 : r);
+    const double phi = acos(r) / 3.0;
+    const double e_max = q + 2.0 * pp * cos(phi);
+    const double e_min = q + 2.0 * pp * cos(phi + 2.0943951023931954923);   // + 2 pi / 3
+    const double e_mid = 3.0 * q - e_max - e_min;
+    const double diff = e_max - 3.0 * e_mid;
+    if (fabs(diff) > 1e-9 * e_max) return diff > 0.0;
   }
   double ev[3];
   eig3_sym(cov, ev);
