@@ -650,6 +650,17 @@ __global__ void k_set_edges(DevView v, int s0, int n_edges, int eb) {
 //   window index); five DPP/permlane min-reductions merge the 32 lists.  Line gate in FP64,
 //   then NN0 / NN1 are written as the line points (laser_odometry.cc:351-357).
 // =============================================================================================
+// Cell edge of the kNN hash.  1 m: the 27-cell neighbourhood covers the sq_dist[4] < 1.0 gate
+// (:324) exactly.  0.5 m cells (kCellInv = 2, 125-cell neighbourhood in two shells, code below) were
+// measured and rejected: own cells shrink 8x and the slowest workgroup drops from 35 to 30 us, but
+// the typical query needs more streaming rounds (phase 2: 5.0 -> 7.3 us), the kernel gets slower
+// (27.5 -> 29.3 us on one stream, 214 -> 328 us on 64) and the 3x more cells overflow the LDS-built
+// table.
+constexpr float kCellInv = 1.0f;
+constexpr double kCellSize = 1.0;
+// The 98 cells of the outer shell (max |d| = 2) as indices into the 5 x 5 x 5 cube, x fastest.
+__device__ const unsigned char kKnnOuterCells[98] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 34, 35, 39, 40, 44, 45, 46, 47, 48, 49, 50, 51, 52, 53, 54, 55, 59, 60, 64, 65, 69, 70, 71, 72, 73, 74, 75, 76, 77, 78, 79, 80, 84, 85, 89, 90, 94, 95, 96, 97, 98, 99, 100, 101, 102, 103, 104, 105, 106, 107, 108, 109, 110, 111, 112, 113, 114, 115, 116, 117, 118, 119, 120, 121, 122, 123, 124};
+
 struct Top5 {
   float d0, d1, d2, d3, d4;
   int i0, i1, i2, i3, i4;     // window index (tie-break)
@@ -755,6 +766,7 @@ __global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int oute
   const int hl = threadIdx.x & (kKnnGroup - 1);
   const int half_shift = (threadIdx.x & 32);     // 0 or 32: which half of the wave
   const bool dbgb = (blockIdx.x == 5) && (s == 0) && (threadIdx.x == 0) && (outer_it == 0);
+  const unsigned long long t_blk = (v.debug & 32) ? wall_clock64() : 0ull;
   DBG_STAMP(v, dbgb, 1, 0);
   bool active = e < E;
   float qx = 0.f, qy = 0.f, qz = 0.f;
@@ -770,30 +782,36 @@ __global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int oute
   DBG_STAMP(v, dbgb, 1, 1);
   if (hl == 0) { s_res[grp][0] = 0; s_res[grp][1] = -1; s_res[grp][2] = -1; }
   if (active) {                                    // uniform over each 32-lane half
-    const int cx = (int)floorf(qx), cy = (int)floorf(qy), cz = (int)floorf(qz);
+    const int cx = (int)floorf(qx * kCellInv), cy = (int)floorf(qy * kCellInv), cz = (int)floorf(qz * kCellInv);
     const unsigned int tmask = st.table_mask;
     const CellSlot* cells = v.cells + (size_t)s * v.table_size;
     const unsigned int* bits = v.cell_bits + (size_t)s * (v.table_size >> 5);
-    unsigned int start = 0, cnt = 0;
-    double lb = 0.0;     // lower bound of the float squared distance from q to any point of the cell
-    if (hl < 27) {
-      const int dx = hl % 3 - 1, dy = (hl / 3) % 3 - 1, dz = hl / 9 - 1;
+    auto probe = [&](int dx, int dy, int dz, unsigned int& start, unsigned int& cnt) {
       const unsigned long long key = pack_cell(cx + dx, cy + dy, cz + dz);
       unsigned int h = hash_cell(key, tmask);
-      for (int probe = 0; probe < v.table_size; probe++) {
+      for (int pr = 0; pr < v.table_size; pr++) {
         if (!((bits[h >> 5] >> (h & 31)) & 1u)) break;           // empty slot: cell not in the map
         const uint4 raw = *reinterpret_cast<const uint4*>(cells + h);
         const unsigned long long k = ((unsigned long long)raw.y << 32) | raw.x;
         if (k == key) { start = raw.z; cnt = raw.w; break; }
         h = (h + 1) & tmask;
       }
-      // box distance (FP64) to the cell [c, c+1)^3, shrunk by 1e-5 so that float rounding of the
-      // candidate distances can never make a pruned point look closer than the bound
-      const double lx = (double)(cx + dx), ly = (double)(cy + dy), lz = (double)(cz + dz);
-      const double ex = (double)qx < lx ? lx - (double)qx : ((double)qx > lx + 1.0 ? (double)qx - (lx + 1.0) : 0.0);
-      const double ey = (double)qy < ly ? ly - (double)qy : ((double)qy > ly + 1.0 ? (double)qy - (ly + 1.0) : 0.0);
-      const double ez = (double)qz < lz ? lz - (double)qz : ((double)qz > lz + 1.0 ? (double)qz - (lz + 1.0) : 0.0);
-      lb = (ex * ex + ey * ey + ez * ez) * (1.0 - 1e-5);
+    };
+    // box distance (FP64) to the cell [c, c + 0.5)^3, shrunk by 1e-5 so that float rounding of the
+    // candidate distances can never make a pruned point look closer than the bound
+    auto box_lb = [&](int dx, int dy, int dz) -> double {
+      const double lx = (double)(cx + dx) * kCellSize, ly = (double)(cy + dy) * kCellSize, lz = (double)(cz + dz) * kCellSize;
+      const double ex = (double)qx < lx ? lx - (double)qx : ((double)qx > lx + kCellSize ? (double)qx - (lx + kCellSize) : 0.0);
+      const double ey = (double)qy < ly ? ly - (double)qy : ((double)qy > ly + kCellSize ? (double)qy - (ly + kCellSize) : 0.0);
+      const double ez = (double)qz < lz ? lz - (double)qz : ((double)qz > lz + kCellSize ? (double)qz - (lz + kCellSize) : 0.0);
+      return (ex * ex + ey * ey + ez * ez) * (1.0 - 1e-5);
+    };
+    unsigned int start = 0, cnt = 0;
+    double lb = 0.0;     // lower bound of the float squared distance from q to any point of the cell
+    if (hl < 27) {       // inner shell: the query's cell and its 26 neighbours
+      const int dx = hl % 3 - 1, dy = (hl / 3) % 3 - 1, dz = hl / 9 - 1;
+      probe(dx, dy, dz, start, cnt);
+      lb = box_lb(dx, dy, dz);
     }
     DBG_STAMP(v, dbgb, 1, 2);
     if (v.debug & 4) cnt = 0;
@@ -801,12 +819,30 @@ __global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int oute
     Top5 t, g;
     top5_clear(t);
     // Cells are streamed in rounds of increasing box distance (own cell; within 0.2 m; within
-    // 0.5 m; the rest).  After every round the pruning bound is refreshed: an upper bound of the
-    // final 5th-best distance = the 5th smallest of the lanes' best distances (five distinct
-    // points are at least that close) or any single lane's own 5th entry, never above the 1.0
-    // gate (points at >= 1.0 cannot be part of a match, :324).  A cell is skipped only if its box
-    // distance exceeds the bound, so the result is exact; a typical query ends after its own cell.
+    // 0.5 m; the rest of the inner shell; then, only if still needed, the outer shell).  After
+    // every round the pruning bound is refreshed: an upper bound of the final 5th-best distance =
+    // the 5th smallest of the lanes' best distances (five distinct points are at least that close)
+    // or any single lane's own 5th entry, never above the 1.0 gate (points at >= 1.0 cannot be part
+    // of a match, :324).  A cell is skipped only if its box distance exceeds the bound, so the
+    // result is exact; a typical query ends after its own cell.
     float bound_f = 1.0f;
+    auto refresh_bound = [&]() {
+      unsigned int bnd = 0x7f800000u;   // +inf
+      bool taken = false;
+      const unsigned int mine = (unsigned int)__float_as_int(t.d0);   // non-negative floats order as uints
+#pragma unroll
+      for (int r = 0; r < 5; r++) {
+        const unsigned int cur = taken ? 0x7f800000u : mine;
+        const unsigned int mn = half_min_u32(cur);
+        if (r == 4) bnd = mn;
+        const unsigned int win = (unsigned int)((__ballot(!taken && cur == mn) >> half_shift) & 0xFFFFFFFFull);
+        if (hl == __ffs(win) - 1) taken = true;
+      }
+      const unsigned int own5 = half_min_u32((unsigned int)__float_as_int(t.d4));
+      bnd = own5 < bnd ? own5 : bnd;
+      const float b = __int_as_float((int)bnd);
+      bound_f = b < bound_f ? b : bound_f;
+    };
     bool pending = (hl < 27) && (cnt > 0);
     const double thr[4] = {0.0, 0.04, 0.25, 4.0};
 #pragma unroll
@@ -816,26 +852,46 @@ __global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int oute
       if ((__ballot(now) >> half_shift) & 0xFFFFFFFFull) {
         knn_stream_cells(t, sp, s_incl[grp], s_adj[grp], start, now ? cnt : 0u, hl, qx, qy, qz);
         pending = pending && !now;
-        if (round < 3 && ((__ballot(pending) >> half_shift) & 0xFFFFFFFFull)) {
-          unsigned int bnd = 0x7f800000u;   // +inf
-          bool taken = false;
-          const unsigned int mine = (unsigned int)__float_as_int(t.d0);   // non-negative floats order as uints
-#pragma unroll
-          for (int r = 0; r < 5; r++) {
-            const unsigned int cur = taken ? 0x7f800000u : mine;
-            const unsigned int mn = half_min_u32(cur);
-            if (r == 4) bnd = mn;
-            const unsigned int win = (unsigned int)((__ballot(!taken && cur == mn) >> half_shift) & 0xFFFFFFFFull);
-            if (hl == __ffs(win) - 1) taken = true;
-          }
-          const unsigned int own5 = half_min_u32((unsigned int)__float_as_int(t.d4));
-          bnd = own5 < bnd ? own5 : bnd;
-          const float b = __int_as_float((int)bnd);
-          bound_f = b < bound_f ? b : bound_f;
-        }
+        if (round < 3 && ((__ballot(pending) >> half_shift) & 0xFFFFFFFFull)) refresh_bound();
       }
       if (round == 0) DBG_STAMP(v, dbgb, 1, 3);
       if (round == 1) DBG_STAMP(v, dbgb, 1, 4);
+    }
+    // Outer shell for 0.5 m cells only (max |d| = 2, 98 cells, up to four per lane): every one of
+    // them is at least 0.5 m from the query, so it matters only while the bound is still above 0.25.
+    if (kCellSize < 1.0 && bound_f > 0.2499f) refresh_bound();      // (uniform over the half-wave)
+    if (kCellSize < 1.0 && bound_f > 0.2499f) {
+      unsigned int ostart[4], ocnt[4];
+      double olb[4];
+      bool opend[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int j = k * 32 + hl;
+        ostart[k] = 0; ocnt[k] = 0; olb[k] = 1.0e30; opend[k] = false;
+        if (j < 98) {
+          const int c = kKnnOuterCells[j];
+          const int dx = c % 5 - 2, dy = (c / 5) % 5 - 2, dz = c / 25 - 2;
+          olb[k] = box_lb(dx, dy, dz);
+          if (!(olb[k] > (double)bound_f)) { probe(dx, dy, dz, ostart[k], ocnt[k]); opend[k] = ocnt[k] > 0; }
+        }
+      }
+      if (v.debug & 4) { for (int k = 0; k < 4; k++) opend[k] = false; }
+#pragma unroll
+      for (int round = 0; round < 2; round++) {
+        bool streamed = false;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          opend[k] = opend[k] && !(olb[k] > (double)bound_f);
+          const bool now = opend[k] && (round == 1 || olb[k] <= 0.5);
+          if ((__ballot(now) >> half_shift) & 0xFFFFFFFFull) {
+            knn_stream_cells(t, sp, s_incl[grp], s_adj[grp], ostart[k], now ? ocnt[k] : 0u, hl, qx, qy, qz);
+            opend[k] = opend[k] && !now;
+            streamed = true;
+          }
+        }
+        const bool left = opend[0] || opend[1] || opend[2] || opend[3];
+        if (round == 0 && streamed && ((__ballot(left) >> half_shift) & 0xFFFFFFFFull)) refresh_bound();
+      }
     }
     knn_merge(t, g, hl, half_shift);
     DBG_STAMP(v, dbgb, 1, 5);
@@ -876,6 +932,11 @@ __global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int oute
     if (q == 0 && nvalid) atomicAdd(&st.info.matches[outer_it], nvalid);   // :346
   }
   DBG_STAMP(v, dbgb, 1, 7);
+  if ((v.debug & 32) && s == 0 && threadIdx.x == 0) {      // histogram of workgroup durations, 1 us bins
+    const unsigned long long d = wall_clock64() - t_blk;
+    const int bin = (int)(d / 100ull);
+    atomicAdd(&v.dbg_clk[192 + (bin < 63 ? bin : 63)], 1ull);
+  }
 }
 
 // =============================================================================================
@@ -1300,7 +1361,7 @@ __global__ __launch_bounds__(256) void k_window_insert(DevView v, int s0, int eb
   const bool fin = ld_isfinite((double)pt.x) && ld_isfinite((double)pt.y) && ld_isfinite((double)pt.z) &&
                    fabsf(pt.x) < 1.0e9f && fabsf(pt.y) < 1.0e9f && fabsf(pt.z) < 1.0e9f;
   if (!fin) { *pc = -1; return; }
-  const unsigned long long key = pack_cell((int)floorf(pt.x), (int)floorf(pt.y), (int)floorf(pt.z));
+  const unsigned long long key = pack_cell((int)floorf(pt.x * kCellInv), (int)floorf(pt.y * kCellInv), (int)floorf(pt.z * kCellInv));
   const unsigned int tmask = (unsigned int)v.table_size - 1u;
   CellSlot* cells = v.cells + (size_t)s * v.table_size;
   unsigned int h = hash_cell(key, tmask);
@@ -1516,7 +1577,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_hash_build(DevView v, int s0,
       if (m >= M) continue;
       int found = -1;
       if (point_ok(pt[k])) {
-        const unsigned long long key = pack_cell((int)floorf(pt[k].x), (int)floorf(pt[k].y), (int)floorf(pt[k].z));
+        const unsigned long long key = pack_cell((int)floorf(pt[k].x * kCellInv), (int)floorf(pt[k].y * kCellInv), (int)floorf(pt[k].z * kCellInv));
         unsigned int h = hash_cell(key, lmask);
         for (int probe = 0; probe < kLdsSlots; probe++) {
           const unsigned long long prev = atomicCAS(&lkey[h], kEmptyKey, key);
@@ -1546,7 +1607,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_hash_build(DevView v, int s0,
       const float4 pt = m < Mw ? win_point(v, s, nf, w, m) : recv[m - Mw];
       int found = -1;
       if (point_ok(pt)) {
-        const unsigned long long key = pack_cell((int)floorf(pt.x), (int)floorf(pt.y), (int)floorf(pt.z));
+        const unsigned long long key = pack_cell((int)floorf(pt.x * kCellInv), (int)floorf(pt.y * kCellInv), (int)floorf(pt.z * kCellInv));
         unsigned int h = hash_cell(key, gmask);
         for (int probe = 0; probe < v.table_size; probe++) {
           const unsigned long long prev = atomicCAS(&cells[h].key, kEmptyKey, key);
@@ -1834,7 +1895,7 @@ __global__ __launch_bounds__(256) void k_filt_insert(DevView v, int s0) {
   const float4 pt = v.filt_pts[(size_t)s * v.map_cap + u];
   int* pc = v.pt_cell + (size_t)s * v.map_cap + u;
   if (!point_ok(pt)) { *pc = -1; return; }
-  const unsigned long long key = pack_cell((int)floorf(pt.x), (int)floorf(pt.y), (int)floorf(pt.z));
+  const unsigned long long key = pack_cell((int)floorf(pt.x * kCellInv), (int)floorf(pt.y * kCellInv), (int)floorf(pt.z * kCellInv));
   const unsigned int tmask = (unsigned int)v.table_size - 1u;
   CellSlot* cells = v.cells + (size_t)s * v.table_size;
   unsigned int h = hash_cell(key, tmask);

@@ -199,6 +199,7 @@ def sec_clocks(H=64, W=1800, R=8, epr=10, P=20, K=40):
     g.L.liodom_debug_clocks(g.h, buf)
     allv = np.array(list(buf), dtype=np.int64)
     print('k_ring_extract per-ring workgroup durations (us), rings 0..63:', np.round(allv[128:192] / 100.0, 1).tolist())
+    print('k_knn workgroup-duration histogram (1 us bins, all scans):', allv[192:256].tolist())
     a = allv[:128].reshape(4, 32)
     names = {0: ["start", "", "ring loaded", "(unused)", "stencil", "spec select", "carry check", "emitted"],
              1: ["start", "query ready", "hash probed", "centre streamed", "merge1", "phase2 done", "nn fetched", "gate done"],
