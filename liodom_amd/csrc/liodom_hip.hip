@@ -174,7 +174,7 @@ int launch_odometry(liodom_handle* h, int eb, int s0, int count) {
     }
     {
       ProfScope ps(h, KID_LM);
-      hipLaunchKernelGGL(k_lm_solve, dim3(h->v.lm_groups, count), dim3(kLmThreads), (size_t)h->v.edge_cap * sizeof(int), h->stream, v, s0, it, eb);
+      hipLaunchKernelGGL(k_lm_solve, dim3(h->v.lm_groups, count), dim3(kLmThreads), lm_lds_bytes(h->v.edge_cap), h->stream, v, s0, it, eb);
     }
   }
   h->last_eb = eb;       // results are published by k_lm_solve into host-mapped memory (HostOut)
@@ -468,6 +468,12 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   }
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hash_build), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)hash_build_lds_bytes()) != hipSuccess) {
+    g_last_error = "hipFuncSetAttribute(max dynamic LDS) failed"; return fail(LIODOM_ERR_HIP);
+  }
+  v.lm_lds_reduce = lm_lds_reduce_fits(v.edge_cap) ? 1 : 0;
+  if (lm_lds_bytes(v.edge_cap) + 4096 > 160 * 1024) { g_last_error = "liodom_create: edge capacity too large for the solve's LDS tile"; return fail(LIODOM_ERR_INVALID_ARG); }
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lm_solve), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)lm_lds_bytes(h->v.edge_cap)) != hipSuccess) {
     g_last_error = "hipFuncSetAttribute(max dynamic LDS) failed"; return fail(LIODOM_ERR_HIP);
   }
   if (h->ring_lds_bytes > 48 * 1024) {

@@ -119,6 +119,7 @@ struct DevView {
   int* win_base;            // [S][P+1] logical prefix (oldest first)
   int* win_slot;            // [S][P]  logical frame -> slot
   CellSlot* cells;          // [S][table_size]  {key, start, cnt}: one 16-B load per probe
+  int lm_lds_reduce;        // k_lm_solve reduces through the transposed LDS matrix (fits for edge_cap <= ~10 000)
   int use_imu;              // params.use_imu_ (laser_odometry.cc:152)
   double laser_to_base[12]; // laser_to_base_ (laser_odometry.cc:110-119), identity unless liodom_set_laser_to_base
   double* imu_q;            // [S][4] last IMU orientation [x y z w] (SharedData::last_IMU_ori_)
@@ -950,6 +951,16 @@ __global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int oute
 // =============================================================================================
 // Indices of the edges with an accepted correspondence, in edge order (deterministic), built once
 // per solve in LDS so that every evaluation runs over C dense items instead of E sparse ones.
+// dynamic LDS of k_lm_solve: index list + reduction scratch (full transposed matrix if it fits the
+// 160 KB of a CU next to ~3 KB of static LDS, else one partial per 16-lane row)
+__host__ __device__ __forceinline__ bool lm_lds_reduce_fits(int edge_cap) {
+  return (size_t)((edge_cap + 3) & ~3) * sizeof(int) + (size_t)kAccN * kLmThreads * sizeof(double) + 4096 <= 160 * 1024;
+}
+__host__ __device__ __forceinline__ size_t lm_lds_bytes(int edge_cap) {
+  return (size_t)((edge_cap + 3) & ~3) * sizeof(int) +
+         (lm_lds_reduce_fits(edge_cap) ? (size_t)kAccN * kLmThreads : (size_t)(kLmThreads / 16) * kAccN) * sizeof(double);
+}
+
 __device__ int lm_compact(const DevView& v, int s, int e_begin, int E, int* idx /*LDS [edge_cap]*/, int* wtot /*LDS [4 * 8]*/) {
   const float4* ca = v.corr_a + (size_t)s * v.edge_cap;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -998,7 +1009,7 @@ __device__ __forceinline__ void lm_cache_load(const DevView& v, int s, int eb, i
 }
 
 __device__ __forceinline__ void lm_eval(const DevView& v, int s, int eb, int C, const int* idx, const double* Rm_sh,
-                                        double* part /*[kLmThreads/16][kAccN]*/, double* acc_out /*[kAccN]*/,
+                                        double* part /*[kAccN][kLmThreads] or [kLmThreads/16][kAccN]*/, double* acc_out /*[kAccN]*/,
                                         const LmCache& k) {
   double Rm[12];
 #pragma unroll
@@ -1030,8 +1041,29 @@ __device__ __forceinline__ void lm_eval(const DevView& v, int s, int eb, int C, 
       residual_accumulate(Rm, p, a, b, v.min_range, v.max_range, acc);
     }
   }
-  // reduction: DPP butterfly inside each 16-lane row, one partial per row into LDS, then a
-  // fixed-order sum of the (waves x 4) partials -> deterministic, no atomics
+  if (v.lm_lds_reduce) {
+    // Reduction through LDS, transposed: every thread stores its 29 partial sums as column t of
+    // red[29][kLmThreads] (conflict-free 8-byte stores); then thread (v, r) = (t / 16, t % 16) sums
+    // the elements r, r + 16, r + 32, ... of row v (conflict-free loads, 32 adds), a 4-step DPP row
+    // sum finishes row v.  Fixed order -> deterministic, no atomics.  Replaces 29 x 4 DPP steps per
+    // wave (8 waves' worth of 64-bit DPP moves serialised on 4 SIMDs).
+#pragma unroll
+    for (int i = 0; i < kAccN; i++) part[i * kLmThreads + threadIdx.x] = acc[i];
+    __syncthreads();
+    const int vrow = threadIdx.x >> 4, r = threadIdx.x & 15;
+    double x = 0.0;
+    if (vrow < kAccN) {
+      const double* rowp = part + vrow * kLmThreads + r;
+#pragma unroll 8
+      for (int k = 0; k < kLmThreads / 16; k++) x += rowp[k * 16];
+    }
+    x = row_sum_f64(x);
+    if (vrow < kAccN && r == 0) acc_out[vrow] = x;
+    __syncthreads();
+    return;
+  }
+  // Large edge capacities (the 118 KB matrix no longer fits beside the index list): DPP butterfly
+  // inside each 16-lane row, one partial per row into LDS, then a fixed-order sum of the partials.
 #pragma unroll
   for (int i = 0; i < kAccN; i++) acc[i] = row_sum_f64(acc[i]);
   const int row = threadIdx.x >> 4;
@@ -1204,7 +1236,6 @@ __global__ void k_imu_override(DevView v, int s0, int count) {
 
 __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int outer_it, int eb) {
   __shared__ double sh_pose[12];
-  __shared__ double sh_part[(kLmThreads / 16) * kAccN];
   __shared__ double sh_acc[kAccN];
   __shared__ LmState lm;
   __shared__ int sh_flag;
@@ -1213,7 +1244,8 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
   StreamState& st = v.state[s];
   __shared__ int sh_cnt[kMaxFrames + 1];
   __shared__ double sh_loc[kAccN];
-  extern __shared__ __attribute__((aligned(16))) int sh_idx[];   // [edge_cap] compacted correspondence indices
+  extern __shared__ __attribute__((aligned(16))) int sh_idx[];   // [edge_cap] compacted correspondence indices, then the reduction matrix
+  double* sh_part = reinterpret_cast<double*>(sh_idx + ((v.edge_cap + 3) & ~3));   // [kAccN][kLmThreads]
   if (outer_it == 0 && threadIdx.x == 0 && g == 0) {     // per-scan diagnostics (matches are counted by k_knn)
     st.info.n_edges = st.n_edges_buf[eb];
     st.info.map_points = st.n_search;

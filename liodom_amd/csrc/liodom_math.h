@@ -254,8 +254,21 @@ LD_HD void odom_message(const double* prev_odom, const double* odom, const doubl
 LD_HD void quat_plus(const double* x, const double* delta, double* out) {
   const double nd = sqrt(delta[0] * delta[0] + delta[1] * delta[1] + delta[2] * delta[2]);
   if (nd > 0.0) {
-    const double s = sin(nd) / nd;
-    const double aw = cos(nd), ax = s * delta[0], ay = s * delta[1], az = s * delta[2];
+    // sin(nd)/nd and cos(nd).  LM steps are small rotations: below 0.5 rad the Taylor series in
+    // nd^2 (9 terms, truncation error < 1e-19) replaces the two ~170-instruction library calls on
+    // the single lane that runs the controller; larger steps take the library path.
+    double s, aw;
+    if (nd < 0.5) {
+      const double u = nd * nd;
+      s = 1.0 + u * (-1.0 / 6.0 + u * (1.0 / 120.0 + u * (-1.0 / 5040.0 + u * (1.0 / 362880.0 + u * (-1.0 / 39916800.0 +
+          u * (1.0 / 6227020800.0 + u * (-1.0 / 1307674368000.0 + u * (1.0 / 355687428096000.0))))))));
+      aw = 1.0 + u * (-0.5 + u * (1.0 / 24.0 + u * (-1.0 / 720.0 + u * (1.0 / 40320.0 + u * (-1.0 / 3628800.0 +
+           u * (1.0 / 479001600.0 + u * (-1.0 / 87178291200.0 + u * (1.0 / 20922789888000.0))))))));
+    } else {
+      s = sin(nd) / nd;
+      aw = cos(nd);
+    }
+    const double ax = s * delta[0], ay = s * delta[1], az = s * delta[2];
     const double bw = x[3], bx = x[0], by = x[1], bz = x[2];
     out[3] = aw * bw - ax * bx - ay * by - az * bz;
     out[0] = aw * bx + ax * bw + ay * bz - az * by;
@@ -496,9 +509,11 @@ LD_HD bool chol_solve6(const double* A /*6x6 row-major, symmetric*/, const doubl
     LD_UNROLL
     for (int k = 0; k < j; k++) d -= Lm[j * 6 + k] * Lm[j * 6 + k];
     if (!(d > 0.0) || !ld_isfinite(d)) return false;
-    const double l = sqrt(d);
-    Lm[j * 6 + j] = l;
-    inv[j] = 1.0 / l;
+#if defined(__HIP_DEVICE_COMPILE__)
+    inv[j] = rsqrt(d);             // only the reciprocal of the pivot is ever used
+#else
+    inv[j] = 1.0 / sqrt(d);
+#endif
     LD_UNROLL
     for (int i = j + 1; i < 6; i++) {
       double s = A[i * 6 + j];
@@ -556,8 +571,9 @@ LD_HD int lm_propose(LmState& st) {
     double A[36];
     LD_UNROLL
     for (int i = 0; i < 36; i++) A[i] = Hs[i];
+    const double inv_radius = 1.0 / st.radius;
     LD_UNROLL
-    for (int j = 0; j < 6; j++) A[j * 6 + j] += st.diag[j] / st.radius;
+    for (int j = 0; j < 6; j++) A[j * 6 + j] += st.diag[j] * inv_radius;
     double y[6];
     const bool ok = chol_solve6(A, gs, y);
     st.reuse_diagonal = 1;
