@@ -24,6 +24,13 @@
 #define LD_UNROLL
 #define LD_FP_CONTRACT_FAST
 #endif
+// reciprocal square root: one v_rsq_f64 + refinement on the device instead of a square root
+// followed by a division (each ~25 instructions in FP64)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LD_RSQRT(x) rsqrt(x)
+#else
+#define LD_RSQRT(x) (1.0 / sqrt(x))
+#endif
 
 namespace liodom_dev {
 
@@ -389,12 +396,13 @@ LD_HD void residual_accumulate(const double* Rm /*3x4*/, const double* p, const 
   const double w0 = lp0 - b[0], w1 = lp1 - b[1], w2 = lp2 - b[2];
   const double nu0 = u1 * w2 - u2 * w1, nu1 = u2 * w0 - u0 * w2, nu2 = u0 * w1 - u1 * w0;
   const double de0 = a[0] - b[0], de1 = a[1] - b[1], de2 = a[2] - b[2];
-  const double L = sqrt(de0 * de0 + de1 * de1 + de2 * de2);
+  const double invL = LD_RSQRT(de0 * de0 + de1 * de1 + de2 * de2);      // 1 / ||de||  (factors.hpp:100)
   const double cx = p[0] - tx, cy = p[1] - ty;
-  const double rho = sqrt(cx * cx + cy * cy);
-  const double range = max_d - min_d;
-  const double w = 1.01 - (rho - min_d) / range;
-  const double invL = 1.0 / L;
+  const double rho_sq = cx * cx + cy * cy;
+  const double inv_rho = LD_RSQRT(rho_sq);
+  const double rho = rho_sq * inv_rho;                                  // (0 * inf = NaN at rho = 0, like 0 / 0 below)
+  const double inv_range = 1.0 / (max_d - min_d);                       // uniform: hoisted out of the loop
+  const double w = 1.01 - (rho - min_d) * inv_range;
   const double wl = w * invL;
   const double n0 = nu0 * invL, n1 = nu1 * invL, n2 = nu2 * invL;
   const double r0 = w * n0, r1 = w * n1, r2 = w * n2;              // factors.hpp:99-101
@@ -407,7 +415,7 @@ LD_HD void residual_accumulate(const double* Rm /*3x4*/, const double* p, const 
   J[6]  = k2 * (Rp1 * de0);       J[7]  = k2 * (Rp1 * de1 - dot); J[8]  = k2 * (Rp1 * de2);
   J[12] = k2 * (Rp2 * de0);       J[13] = k2 * (Rp2 * de1);       J[14] = k2 * (Rp2 * de2 - dot);
   // Jt = -(w/L)[de]x + (nu/L) (dw/dt)^T,  dw/dt = (cx, cy, 0) / (rho * range)
-  const double inv_rr = 1.0 / (rho * range);
+  const double inv_rr = inv_rho * inv_range;
   const double dwx = cx * inv_rr, dwy = cy * inv_rr;
   J[3]  = n0 * dwx;              J[4]  = wl * de2 + n0 * dwy;   J[5]  = -wl * de1;
   J[9]  = -wl * de2 + n1 * dwx;  J[10] = n1 * dwy;              J[11] = wl * de0;
@@ -416,17 +424,19 @@ LD_HD void residual_accumulate(const double* Rm /*3x4*/, const double* p, const 
   double rho0, rho1;
   const double bsq = kHuberA * kHuberA;
   if (s > bsq) {
-    const double rr = sqrt(s);
-    rho0 = 2.0 * kHuberA * rr - bsq;
-    rho1 = kHuberA / rr;
+    const double inv_rr2 = LD_RSQRT(s);
+    rho0 = 2.0 * kHuberA * (s * inv_rr2) - bsq;
+    rho1 = kHuberA * inv_rr2;
     if (rho1 < DBL_MIN) rho1 = DBL_MIN;
   } else {
     rho0 = s; rho1 = 1.0;
   }
-  bool finite = ld_isfinite(s);
+  // any non-finite residual or Jacobian entry invalidates the block (ceres IsEvaluationValid):
+  // x * 0 is NaN exactly for x = +-inf / NaN, so one FMA chain + one compare test all 19 values
+  double z = s * 0.0;
   LD_UNROLL
-  for (int i = 0; i < 18; i++) finite = finite && ld_isfinite(J[i]);
-  if (!finite) { acc[28] += 1.0; return; }
+  for (int i = 0; i < 18; i++) z += J[i] * 0.0;
+  if (!(z == 0.0)) { acc[28] += 1.0; return; }
   acc[0] += 0.5 * rho0;
   const double rs0 = rho1 * r0, rs1 = rho1 * r1, rs2 = rho1 * r2;
   LD_UNROLL
