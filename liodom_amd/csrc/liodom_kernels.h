@@ -849,7 +849,14 @@ __global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int oute
 #pragma unroll
     for (int round = 0; round < 4; round++) {
       pending = pending && !(lb > (double)bound_f);              // pruned for good
-      const bool now = pending && (lb <= thr[round]);
+      // few candidates left (<= 8 per lane): one pass over all of them is cheaper than the
+      // remaining rounds with their bound refreshes
+      bool all_now = false;
+      if (round == 1 || round == 2) {
+        const int left = __shfl(half_incl_scan_i32(pending ? (int)cnt : 0), kKnnGroup - 1, kKnnGroup);
+        all_now = left <= 8 * kKnnGroup;
+      }
+      const bool now = pending && (all_now || lb <= thr[round]);
       if ((__ballot(now) >> half_shift) & 0xFFFFFFFFull) {
         knn_stream_cells(t, sp, s_incl[grp], s_adj[grp], start, now ? cnt : 0u, hl, qx, qy, qz);
         pending = pending && !now;
