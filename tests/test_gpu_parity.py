@@ -406,3 +406,51 @@ def test_use_imu_roll_pitch_override(orc, synth):
             differs += int(np.linalg.norm(pose_p - pose_o) > 1e-9)      # the override is not a no-op
     assert differs > 0
     g.close()
+
+
+def test_odometry_degenerate_inputs(orc, synth):
+    """Empty edge clouds, scans without a single valid point, a window with fewer than five points
+    (the reference would read sq_dist[4] out of bounds, :324; oracle and GPU skip such edges) and
+    edges far from every map point: no correspondences -> Ceres 'no residuals', pose = prediction."""
+    H, W, R, epr, P = 16, 900, 6, 10, 3
+    cfg = synth.make_cfg(H, W, 0)
+    po, g = mk(orc, H, W, 0, R, epr, P)
+    od = orc.Odometer(po)
+
+    calls = [0]
+
+    def both(edges):
+        e = np.ascontiguousarray(edges, dtype=np.float32).reshape(-1, 4)
+        pose_o, info_o = od.step(e)
+        pose_g, info_g = g.odometry_step(e)
+        assert np.allclose(pose_g, pose_o, rtol=0, atol=1e-9), (pose_g, pose_o)
+        assert info_g.n_edges == info_o.n_edges == e.shape[0]
+        assert list(info_g.matches) == list(info_o.matches)
+        if calls[0] > 0:      # the first frame only initialises the window (:108-136): no solve, no trace
+            assert [info_g.lm[i].termination for i in (0, 1)] == [info_o.lm[i].termination for i in (0, 1)]
+        calls[0] += 1
+        wg, nf = g.window()
+        assert nf == od.window_frames() and wg.shape == od.window().shape
+        return info_g
+
+    x0, _ = synth.scan(cfg, 0, 0)
+    real = orc.extract(po, x0, H, W)["edges"]
+    both(np.zeros((0, 4)))                      # first frame empty: the window starts with an empty frame
+    both(real[:3])                              # 3 map points... next scan searches a 3-point window
+    i = both(real)                              # < 5 neighbours for every edge
+    assert list(i.matches) == [0, 0] and i.lm[0].termination == 4
+    i = both(real + np.float32([500, 0, 0, 0]))  # far away from the map: gate sq_dist[4] < 1 fails everywhere
+    assert list(i.matches) == [0, 0]
+    both(np.zeros((0, 4)))                      # empty scan in steady state
+    i = both(real)                              # and the stream recovers
+    assert i.matches[1] > 20
+    g.close()
+    # whole pipeline on scans without valid points
+    po, g = mk(orc, H, W, 0, R, epr, P)
+    od = orc.Odometer(po)
+    for x in (np.full((H * W, 4), np.nan, np.float32), np.zeros((H * W, 4), np.float32), x0, np.zeros((0, 4), np.float32), x0):
+        o = orc.extract(po, x, H, W if len(x) else 0)
+        pose_o, info_o = od.step(o["edges"])
+        pose_g, info_g = g.process_scan(x, H, W if len(x) else 0)
+        assert np.allclose(pose_g, pose_o, rtol=0, atol=1e-9) and info_g.n_edges == info_o.n_edges
+    g.close()
