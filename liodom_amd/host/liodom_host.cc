@@ -143,6 +143,15 @@ void FeatureExtractor::extractFeatures(const PointCloud& pc_in, PointCloud& pc_e
   }
 }
 
+void FeatureExtractor::lastEdges(PointCloud& pc_edges) {
+  pc_edges.points.resize((size_t)eng_->edge_capacity());
+  int n = 0;
+  check(liodom_get_edges(eng_->handle(), 0, reinterpret_cast<float*>(pc_edges.points.data()), nullptr, nullptr, nullptr,
+                         eng_->edge_capacity(), &n), "liodom_get_edges");
+  pc_edges.points.resize((size_t)n);
+  pc_edges.width = (uint32_t)n; pc_edges.height = 1;
+}
+
 size_t LocalMapManager::getLocalMap(PointCloud& map) {
   int64_t n = 0; int nf = 0;
   liodom_get_window(eng_->handle(), 0, nullptr, 0, &n, &nf);         // size query

@@ -102,6 +102,8 @@ class FeatureExtractor {
   explicit FeatureExtractor(std::shared_ptr<Engine> engine);
   // splitPointCloud + extractFeatures (feature_extractor.cc:104-254) for one cloud.
   void extractFeatures(const PointCloud& pc_in, PointCloud& pc_edges);
+  // the edges of the last scan that went through LaserOdometer::processScan (the ~edges topic, :70-75)
+  void lastEdges(PointCloud& pc_edges);
  private:
   std::shared_ptr<Engine> eng_;
   Params* params;
