@@ -224,8 +224,19 @@ __global__ __launch_bounds__(kTileThreads) void k_classify(DevView v, int s0, co
     v.tile_hist[((size_t)s * v.tile_cap + tile) * H + threadIdx.x] = (unsigned short)hist[threadIdx.x];
 }
 
+// Row stride of the (chunk, ring) tables in LDS: odd, so that the per-ring prefix pass (32 lanes =
+// 32 chunks of one ring) does not land all its 8-byte reads on one bank pair.
+__host__ __device__ __forceinline__ int ring_scatter_stride(int H) { return H | 1; }
+// LDS: phase A = lane masks [32][Hp] u64 + chunk prefixes [32][Hp] u16; phase B reuses the same
+// bytes as the staging tile {float4 point, int dst, int src} x 2048; then rbase / lofs / wtot.
+__host__ __device__ __forceinline__ size_t ring_scatter_stage_bytes(int H) {
+  const int Hp = ring_scatter_stride(H);
+  const size_t a = (size_t)kTileChunks * Hp * 8 + (size_t)((kTileChunks * Hp * 2 + 15) & ~15);
+  const size_t b = (size_t)kTilePts * 24;
+  return a > b ? a : b;
+}
 __host__ __device__ __forceinline__ size_t ring_scatter_lds_bytes(int H) {
-  return (size_t)kTileChunks * H * 8 + (size_t)kTileChunks * H * 2 + (size_t)(2 * H + 16) * 4;
+  return ring_scatter_stage_bytes(H) + (size_t)(2 * H + 2 * 16) * 4;
 }
 
 __global__ __launch_bounds__(kTileThreads) void k_ring_scatter(DevView v, int s0, const float4* __restrict__ in,
@@ -235,13 +246,19 @@ __global__ __launch_bounds__(kTileThreads) void k_ring_scatter(DevView v, int s0
   const int tile = blockIdx.x, ntiles = gridDim.x;
   const int H = v.scan_lines;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  unsigned long long* wmask = reinterpret_cast<unsigned long long*>(smem);          // [32][H]
-  unsigned short* cbase = reinterpret_cast<unsigned short*>(wmask + kTileChunks * H);  // [32][H]
-  int* rbase = reinterpret_cast<int*>(cbase + kTileChunks * H);                      // [H] ring start + tile prefix
-  int* wtot = rbase + H;                                                             // [8] + total
-  for (int k = tid; k < kTileChunks * H; k += kTileThreads) wmask[k] = 0ull;
+  const int Hp = ring_scatter_stride(H);
+  unsigned long long* wmask = reinterpret_cast<unsigned long long*>(smem);          // [32][Hp]   (phase A)
+  unsigned short* cbase = reinterpret_cast<unsigned short*>(wmask + kTileChunks * Hp);  // [32][Hp]   (phase A)
+  float4* spts = reinterpret_cast<float4*>(smem);                                   // [2048]     (phase B, same bytes)
+  int* sdst = reinterpret_cast<int*>(smem + (size_t)kTilePts * 16);                 // [2048]
+  int* ssrc = sdst + kTilePts;                                                      // [2048]
+  int* rbase = reinterpret_cast<int*>(smem + ring_scatter_stage_bytes(H));          // [H] ring start + tile prefix
+  int* lofs = rbase + H;                                                            // [H] first staging slot of the ring
+  int* wtot = lofs + H;                                                             // [8] ring totals per wave
+  int* wloc = wtot + 16;                                                            // [8] this tile's counts per wave
+  for (int k = tid; k < kTileChunks * Hp; k += kTileThreads) wmask[k] = 0ull;
   // column prefix / totals of the histogram table for "my" ring (thread r < H); 8 loads in flight
-  int pre = 0, tot = 0;
+  int pre = 0, tot = 0, mine = 0;
   if (tid < H) {
     const unsigned short* th = v.tile_hist + (size_t)s * v.tile_cap * H + tid;
     for (int t0 = 0; t0 < ntiles; t0 += 8) {
@@ -249,53 +266,76 @@ __global__ __launch_bounds__(kTileThreads) void k_ring_scatter(DevView v, int s0
 #pragma unroll
       for (int u = 0; u < 8; u++) c[u] = (t0 + u < ntiles) ? (int)th[(size_t)(t0 + u) * H] : 0;
 #pragma unroll
-      for (int u = 0; u < 8; u++) { tot += c[u]; if (t0 + u < tile) pre += c[u]; }
+      for (int u = 0; u < 8; u++) { tot += c[u]; if (t0 + u < tile) pre += c[u]; if (t0 + u == tile) mine = c[u]; }
     }
   }
-  // exclusive scan of the ring totals over the (<= 254) rings
+  // exclusive scans over the (<= 254) rings: ring totals -> ring starts; this tile's counts -> staging offsets
   const int incl = wave_incl_scan_i32(tot);
-  if (lane == 63) wtot[wave] = incl;
+  const int incl_l = wave_incl_scan_i32(mine);
+  if (lane == 63) { wtot[wave] = incl; wloc[wave] = incl_l; }
   __syncthreads();
   {
-    int base = 0;
-    for (int w = 0; w < wave; w++) base += wtot[w];
+    int base = 0, base_l = 0;
+    for (int w = 0; w < wave; w++) { base += wtot[w]; base_l += wloc[w]; }
     const int rstart = base + incl - tot;
     if (tid < H) {
       rbase[tid] = rstart + pre;
+      lofs[tid] = base_l + incl_l - mine;
       if (tile == 0) v.ring_start[(size_t)s * (H + 1) + tid] = rstart;
     }
     if (tile == 0 && tid == H - 1) v.ring_start[(size_t)s * (H + 1) + H] = rstart + tot;
   }
   // lane masks per (chunk, ring)
   const unsigned char* ids = v.ring_id + (size_t)s * v.ring_id_stride;
-  unsigned char id[4];
+  int id[4];
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const int i = tile * kTilePts + j * kTileThreads + tid;
-    id[j] = (i < n) ? ids[i] : (unsigned char)0xFF;
-    if (id[j] != 0xFF) atomicOr(&wmask[(j * (kTileThreads / 64) + wave) * H + id[j]], 1ull << lane);
+    id[j] = (i < n) ? (int)ids[i] : 0xFF;
+    if (id[j] != 0xFF) atomicOr(&wmask[(j * (kTileThreads / 64) + wave) * Hp + id[j]], 1ull << lane);
   }
   __syncthreads();
   // prefix over the 32 chunks for every ring: one half-wave per ring
   for (int r = wave * 2 + (lane >> 5); r < H; r += 2 * (kTileThreads / 64)) {
     const int c = lane & 31;
-    const int cnt = __popcll(wmask[c * H + r]);
+    const int cnt = __popcll(wmask[c * Hp + r]);
     const int ic = half_incl_scan_i32(cnt);
-    cbase[c * H + r] = (unsigned short)(ic - cnt);
+    cbase[c * Hp + r] = (unsigned short)(ic - cnt);
   }
   __syncthreads();
-  float4* out = v.ring_pts + (size_t)s * v.max_points;
-  int* osrc = v.ring_src + (size_t)s * v.max_points;
+  // rank of every point inside (tile, ring) -> staging slot and final position
   const unsigned long long below = (1ull << lane) - 1ull;
+  int slot[4], dst[4];
 #pragma unroll
   for (int j = 0; j < 4; j++) {
-    const int i = tile * kTilePts + j * kTileThreads + tid;
+    slot[j] = -1; dst[j] = 0;
     if (id[j] != 0xFF) {
       const int chunk = j * (kTileThreads / 64) + wave;
-      const int dst = rbase[id[j]] + (int)cbase[chunk * H + id[j]] + __popcll(wmask[chunk * H + id[j]] & below);
-      out[dst] = in[(size_t)blockIdx.y * in_stride + i];
-      osrc[dst] = i;
+      const int rank = (int)cbase[chunk * Hp + id[j]] + __popcll(wmask[chunk * Hp + id[j]] & below);
+      slot[j] = lofs[id[j]] + rank;
+      dst[j] = rbase[id[j]] + rank;
     }
+  }
+  __syncthreads();                  // masks / prefixes are dead: their bytes become the staging tile
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    if (slot[j] >= 0) {
+      const int i = tile * kTilePts + j * kTileThreads + tid;
+      spts[slot[j]] = in[(size_t)blockIdx.y * in_stride + i];       // coalesced read
+      sdst[slot[j]] = dst[j];
+      ssrc[slot[j]] = i;
+    }
+  }
+  __syncthreads();
+  // Staging slots are ring-major, so consecutive lanes now write consecutive positions of a ring:
+  // ~32-point (512-byte) runs instead of 64 different rings per wave store.
+  float4* out = v.ring_pts + (size_t)s * v.max_points;
+  int* osrc = v.ring_src + (size_t)s * v.max_points;
+  const int nvalid = wloc[0] + wloc[1] + wloc[2] + wloc[3] + wloc[4] + wloc[5] + wloc[6] + wloc[7];
+  for (int p = tid; p < nvalid; p += kTileThreads) {
+    const int d = sdst[p];
+    out[d] = spts[p];
+    osrc[d] = ssrc[p];
   }
 }
 
