@@ -729,7 +729,10 @@ __device__ __forceinline__ void knn_stream_cells(Top5& t, const float4* sp, int*
   __builtin_amdgcn_wave_barrier();
   const int T = s_incl[kKnnGroup - 1];
   int c = 0;   // cell cursor (monotone: the flat index only grows)
-  constexpr int U = 4;         // independent 16-B loads in flight per lane (8 measured no faster)
+  // independent 16-B loads in flight per lane.  Measured 1 / 2 / 4 / 8 / 16: 27.6 / 26.1 / 27.3 / 28.0 / 28.8 us on one
+  // stream, 176 / 183 / 209 / 284 / 528 us on 64: the kernel is VALU-issue bound (PMC: SQ_INSTS_VALU x 4 cycles =
+  // 63 % of the SIMD cycles), wider unrolls only add predicated-off work.
+  constexpr int U = 2;
   for (int i = hl; i < T; i += U * kKnnGroup) {
     int a[U];
     bool ok[U];
