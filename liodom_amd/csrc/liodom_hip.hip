@@ -352,9 +352,16 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   h->S = config->n_streams; h->H = params->scan_lines; h->P = (int)params->local_map_size;
   int rc = LIODOM_OK;
   auto fail = [&](int code) { liodom_destroy(h); return code; };
-  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { g_last_error = "hipStreamCreate failed"; return fail(LIODOM_ERR_HIP); }
+  // The odometry chain is the critical path; the extraction of the next scan only has to finish
+  // before that chain ends.  Stream priorities let the chain's kernels win the CUs when both want them.
+  int prio_least = 0, prio_greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+  const bool use_prio = std::getenv("LIODOM_NO_STREAM_PRIORITY") == nullptr && prio_least != prio_greatest;
+  if ((use_prio ? hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_greatest)
+                : hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) { g_last_error = "hipStreamCreate failed"; return fail(LIODOM_ERR_HIP); }
   if (hipEventCreateWithFlags(&h->pose_event, hipEventDisableTiming) != hipSuccess) { g_last_error = "hipEventCreate failed"; return fail(LIODOM_ERR_HIP); }
-  if (hipStreamCreateWithFlags(&h->stream_x, hipStreamNonBlocking) != hipSuccess) { g_last_error = "hipStreamCreate failed"; return fail(LIODOM_ERR_HIP); }
+  if ((use_prio ? hipStreamCreateWithPriority(&h->stream_x, hipStreamNonBlocking, prio_least)
+                : hipStreamCreateWithFlags(&h->stream_x, hipStreamNonBlocking)) != hipSuccess) { g_last_error = "hipStreamCreate failed"; return fail(LIODOM_ERR_HIP); }
   for (int b = 0; b < 2; b++) {
     if (hipEventCreateWithFlags(&h->ev_edges[b], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_free[b], hipEventDisableTiming) != hipSuccess) { g_last_error = "hipEventCreate failed"; return fail(LIODOM_ERR_HIP); }
