@@ -454,3 +454,33 @@ def test_odometry_degenerate_inputs(orc, synth):
         pose_g, info_g = g.process_scan(x, H, W if len(x) else 0)
         assert np.allclose(pose_g, pose_o, rtol=0, atol=1e-9) and info_g.n_edges == info_o.n_edges
     g.close()
+
+
+def test_soak_long_stream(orc, synth):
+    """400 scans of one stream (slow turn: 0.1 deg/scan keeps the reference's pose recursion in its
+    stable range): the window evicts hundreds of frames, the hash is rebuilt 400
+    times, the device pose log (capacity 256 here) fills up and stops logging.  Status stays clean,
+    the GPU tracks the oracle to the tolerance at every scan and both track the ground truth."""
+    H, W, R, epr, P, K = 16, 900, 6, 10, 5, 400
+    cfg = synth.make_cfg(H, W, 0, yaw_rate_deg=0.1, speed=0.05)
+    po = orc.make_params(scan_lines=H, scan_regions=R, edges_per_region=epr, prev_frames=P, knn_mode=1)
+    g = la.Liodom(la.make_params(scan_lines=H, scan_regions=R, edges_per_region=epr, prev_frames=P),
+                  la.make_config(max_points=H * W, max_width=W, pose_log_capacity=256))
+    od = orc.Odometer(po)
+    gt0 = None
+    worst_t = worst_r = 0.0
+    for k in range(K):
+        x, gt = synth.scan(cfg, 0, k)
+        gt0 = gt if gt0 is None else gt0
+        pose_o, info_o = od.step(orc.extract(po, x, H, W)["edges"])
+        pose_g, info_g = g.process_scan(x, H, W)
+        assert info_g.status == 0 and info_g.scan_index == k
+        dt, dr = np.linalg.norm(pose_g[4:] - pose_o[4:]), rot_angle(pose_g[:4], pose_o[:4])
+        worst_t, worst_r = max(worst_t, dt), max(worst_r, dr)
+        assert dt <= POSE_TOL_T and dr <= POSE_TOL_R, (k, dt, dr)
+    assert info_g.matches[1] > 30
+    # odometry drift (mostly z with 16 rings and a 5-frame window) is the algorithm's, not checked tightly
+    assert np.linalg.norm(pose_g[4:6] - (gt[4:6] - gt0[4:6])) < 1.5       # still on the trajectory after 20 m
+    log, infos = g.pose_log(0, 0, 256)
+    assert [i.scan_index for i in infos] == list(range(256))
+    g.close()
