@@ -484,3 +484,27 @@ def test_soak_long_stream(orc, synth):
     log, infos = g.pose_log(0, 0, 256)
     assert [i.scan_index for i in infos] == list(range(256))
     g.close()
+
+
+def test_velodyne_32_ring_formula(orc):
+    """scan_lines = 32 uses its own elevation binning, id = int((angle + 92/3) * 3/4)
+    (feature_extractor.cc:139-143); unsupported line counts yield no points (:149-151)."""
+    rng = np.random.default_rng(32)
+    W = 1200
+    az = np.linspace(-np.pi, np.pi, W, endpoint=False)
+    pts = []
+    for col in range(W):                       # firing order: all rings of one azimuth, then the next
+        for ring in range(32):
+            elev = np.deg2rad(-30.67 + (ring + 0.5) * 4.0 / 3.0 + rng.normal(0, 0.15))     # some land in neighbouring bins
+            rng_m = 12.0 + 6.0 * np.sin(5 * az[col] + ring) + (2.0 if (col // 37) % 2 else 0.0) + rng.normal(0, 0.01)
+            pts.append((rng_m * np.cos(elev) * np.cos(az[col]), rng_m * np.cos(elev) * np.sin(az[col]), rng_m * np.sin(elev), ring))
+    x = np.array(pts, dtype=np.float32)
+    po, g = mk(orc, 32, W + 200, 0, 8, 10)
+    e, o = g.extract_edges(x, 32, 0), orc.extract(po, x, 32, 0)
+    assert_edges_equal(e, o)
+    assert len(e["ring"]) > 500 and len(set(e["ring"].tolist())) >= 30
+    g.close()
+    # a line count the reference does not know: every point is dropped (and nothing crashes)
+    po, g = mk(orc, 24, 1700, 0, 8, 10)
+    assert len(g.extract_edges(x, 24, 0)["ring"]) == 0 and len(orc.extract(po, x, 24, 0)["ring"]) == 0
+    g.close()
