@@ -570,8 +570,72 @@ __global__ __launch_bounds__(kExThreads) void k_ring_extract(DevView v, int s0) 
       if (__ballot(conflict) && lane == 0) wtot[0] = 1;
     }
     __syncthreads();
-    if (wtot[0] != 0) {
-      // Some region had a pick suppressed by its predecessor: replay the carry in region order.
+    if (wtot[0] != 0 && sector >= 5 && 2 * R <= 96) {
+      // Some region had a pick suppressed by its predecessor.  The reference's in-order walk is a
+      // fixed point of "region r = select(region r | forward spill of region r-1)", and a spill
+      // reaches at most the first 5 items of the next region (a 5-bit mask).  So: iterate in
+      // parallel — every region whose incoming mask changed is re-run (one wave per region) with
+      // that mask as pre-marks — until no mask changes.  Region 0 is final after the speculative
+      // pass, region r after at most r more rounds; typically one or two rounds instead of a
+      // sequential replay of all regions by one wave (noisy ground rings: 35 -> ~15 us).
+      // A region whose picks came from an unmarked run is not re-run if the mask does not hit any
+      // of its picks (marking an item that a run never picked cannot change that run).
+      int* used_mask = wtot + 16;          // [R] pre-marks of the run that produced the current picks
+      int* new_mask = wtot + 16 + R;       // [R] spill of the predecessor's current picks
+      for (int k = tid; k < nr; k += kExThreads) picked[k] = 0;
+      if (tid < R) { used_mask[tid] = 0; new_mask[tid] = 0; }
+      __syncthreads();
+      for (int round = 0; round <= R; round++) {
+        for (int reg = wave; reg + 1 < R; reg += kExWaves) {       // spill of region reg into region reg + 1
+          const int end_j = sector * (reg + 1) + 5;
+          const int cntp = region_cnt[reg];
+          int m = 0;
+          for (int k = lane; k < cntp; k += 64) {
+            const int j = pick_idx[reg * ppr + k];
+            const int nf = pick_nfnb[reg * ppr + k] & 15;
+            for (int l = 1; l <= nf; l++) if (j + l >= end_j) m |= 1 << (j + l - end_j);
+          }
+          {
+            int r5 = 0;
+#pragma unroll
+            for (int b = 0; b < 5; b++) if (__ballot((m >> b) & 1)) r5 |= 1 << b;
+            m = r5;
+          }
+          if (lane == 0) new_mask[reg + 1] = m;
+        }
+        if (tid == 0) wtot[1] = 0;
+        __syncthreads();
+        for (int reg = wave; reg < R; reg += kExWaves) {
+          const int m = new_mask[reg], um = used_mask[reg];
+          if (m == um) continue;
+          const int rs = sector * reg;
+          const int re = (reg == R - 1) ? total : sector * (reg + 1);
+          int cntp = region_cnt[reg];
+          bool need = true;
+          if (um == 0) {
+            bool hit = false;
+            for (int k = lane; k < cntp; k += 64) {
+              const int o = pick_idx[reg * ppr + k] - (rs + 5);
+              hit = hit || (o < 5 && ((m >> o) & 1));
+            }
+            need = __ballot(hit) != 0ull;
+          }
+          if (need) {
+            if (lane < 5) vpicked[rs + 5 + lane] = (unsigned char)((m >> lane) & 1);
+            __builtin_amdgcn_wave_barrier();
+            if (max_len <= 256) cntp = select_region_spec<4>(c, px, py, pz, rs, re, epr, lane, pick_idx + reg * ppr, pick_nfnb + reg * ppr, vpicked);
+            else cntp = select_region_spec<8>(c, px, py, pz, rs, re, epr, lane, pick_idx + reg * ppr, pick_nfnb + reg * ppr, vpicked);
+            if (lane == 0) { region_cnt[reg] = cntp; used_mask[reg] = m; wtot[1] = 1; }
+          } else if (lane == 0) {
+            used_mask[reg] = 0;          // still the unmarked run's picks, valid for this mask too
+          }
+        }
+        __syncthreads();
+        if (wtot[1] == 0) break;
+        __syncthreads();
+      }
+    } else if (wtot[0] != 0) {
+      // (regions shorter than a spill, or too many of them for the scratch: replay in region order)
       // picked[] is rebuilt to hold only the forward spill of *final* picks; a conflicting
       // region is re-run with the same register-resident routine, seeded with those marks.
       for (int k = tid; k < nr; k += kExThreads) picked[k] = 0;

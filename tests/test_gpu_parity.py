@@ -508,3 +508,23 @@ def test_velodyne_32_ring_formula(orc):
     po, g = mk(orc, 24, 1700, 0, 8, 10)
     assert len(g.extract_edges(x, 24, 0)["ring"]) == 0 and len(orc.extract(po, x, 24, 0)["ring"]) == 0
     g.close()
+
+
+@pytest.mark.parametrize("R,epr", [(1, 10), (3, 4), (12, 6), (20, 3), (40, 2)])
+def test_extract_region_counts(orc, synth, R, epr):
+    """Region counts other than the default 8: one region, more regions than waves (several regions
+    per wave in the parallel carry resolution), regions shorter than 64 items, and regions so short
+    (R = 40 on sparse rings) that the in-order replay path is taken."""
+    from test_oracle_extract import _jagged_ring
+    H, W = 16, 1800
+    cfg = synth.make_cfg(H, W, 0)
+    po, g = mk(orc, H, W, 0, R, epr)
+    for k in range(3):
+        x, _ = synth.scan(cfg, 2, k)
+        assert_edges_equal(g.extract_edges(x, H, W), orc.extract(po, x, H, W))
+    for n, seed in ((1800, 1), (700, 2), (R * epr + 12, 3)):
+        if n < R * epr + 10:
+            continue
+        x = _jagged_ring(n, seed=seed)
+        assert_edges_equal(g.extract_edges(x, H, 0), orc.extract(po, x, H, 0))
+    g.close()
