@@ -12,9 +12,14 @@
 //                            whole Ceres-style LM solve in one workgroup per stream; second call
 //                            also finalises the scan (pose log, prediction :148-150, window
 //                            bookkeeping :34-60)
-//   k_hash_clear / k_window_insert / k_hash_alloc / k_hash_scatter
+//   k_window_insert / k_hash_alloc / k_hash_scatter
 //                     A6     append transformed edges to the sliding window (:231-235) and
 //                            rebuild the flat voxel hash the next scan's kNN searches
+//   k_hash_build      A6     the same as ONE workgroup per stream with LDS atomics (handles with
+//                            >= 16 streams)
+//   k_voxel_* / k_filt_*  A7 filter_local_map: VoxelGrid(0.4) of the full window (:286-292)
+//   k_imu_override    A8     use_imu: roll / pitch of the prediction from the IMU (:152-183)
+//   (liodom_map.h)    A12-A14 the mapping node's Map: updateMap / getLocalMap / getMap
 //
 // All FP on the parity-critical paths is compiled with -ffp-contract=off.
 #pragma once
@@ -1445,18 +1450,6 @@ __global__ __launch_bounds__(256) void k_init_cells(DevView v) {
   v.cells[i] = empty;
   if ((i & 31) == 0) v.cell_bits[i >> 5] = 0u;
   if (v.vox_cells) { v.vox_cells[i] = empty; v.vox_fill[i] = 0; }
-}
-
-__global__ __launch_bounds__(256) void k_hash_clear(DevView v, int s0) {
-  const int s = s0 + blockIdx.y;
-  const StreamState& st = v.state[s];
-  const int u = blockIdx.x * 256 + threadIdx.x;
-  if (u >= st.n_used_prev) return;
-  const int h = v.used_cells[(size_t)s * v.map_cap + u];
-  const size_t ti = (size_t)s * v.table_size + h;
-  CellSlot empty; empty.key = kEmptyKey; empty.start = 0; empty.cnt = 0;
-  v.cells[ti] = empty;
-  v.cell_bits[ti >> 5] = 0u;   // every set bit of that word belongs to a slot of this list
 }
 
 // One thread per window point (oldest frame first).  Points of the newest frame are produced

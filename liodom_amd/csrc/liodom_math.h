@@ -448,31 +448,6 @@ LD_HD void residual_accumulate(const double* Rm /*3x4*/, const double* p, const 
   }
 }
 
-// Cost-only variant (candidate evaluation).  Returns false if non-finite.
-LD_HD bool residual_cost(const double* Rm, const double* p, const double* a, const double* b,
-                         double min_d, double max_d, double* cost) {
-  LD_FP_CONTRACT_FAST
-  const double tx = Rm[3], ty = Rm[7], tz = Rm[11];
-  const double lp0 = Rm[0] * p[0] + Rm[1] * p[1] + Rm[2] * p[2] + tx;
-  const double lp1 = Rm[4] * p[0] + Rm[5] * p[1] + Rm[6] * p[2] + ty;
-  const double lp2 = Rm[8] * p[0] + Rm[9] * p[1] + Rm[10] * p[2] + tz;
-  const double u0 = lp0 - a[0], u1 = lp1 - a[1], u2 = lp2 - a[2];
-  const double w0 = lp0 - b[0], w1 = lp1 - b[1], w2 = lp2 - b[2];
-  const double nu0 = u1 * w2 - u2 * w1, nu1 = u2 * w0 - u0 * w2, nu2 = u0 * w1 - u1 * w0;
-  const double de0 = a[0] - b[0], de1 = a[1] - b[1], de2 = a[2] - b[2];
-  const double L = sqrt(de0 * de0 + de1 * de1 + de2 * de2);
-  const double cx = p[0] - tx, cy = p[1] - ty;
-  const double rho = sqrt(cx * cx + cy * cy);
-  const double w = 1.01 - (rho - min_d) / (max_d - min_d);
-  const double invL = 1.0 / L;
-  const double r0 = w * (nu0 * invL), r1 = w * (nu1 * invL), r2 = w * (nu2 * invL);
-  const double s = r0 * r0 + r1 * r1 + r2 * r2;
-  if (!ld_isfinite(s)) return false;
-  const double bsq = kHuberA * kHuberA;
-  *cost += (s > bsq) ? 0.5 * (2.0 * kHuberA * sqrt(s) - bsq) : 0.5 * s;
-  return true;
-}
-
 // ---------------------------------------------------------------------------------------
 // Trust-region Levenberg-Marquardt controller mirroring ceres::Solve as configured at
 // src/laser_odometry.cc:212-218 (Ceres <= 2.1 defaults): Jacobi scaling from the
