@@ -771,20 +771,40 @@ constexpr double kCellSize = 1.0;
 // The 98 cells of the outer shell (max |d| = 2) as indices into the 5 x 5 x 5 cube, x fastest.
 __device__ const unsigned char kKnnOuterCells[98] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 34, 35, 39, 40, 44, 45, 46, 47, 48, 49, 50, 51, 52, 53, 54, 55, 59, 60, 64, 65, 69, 70, 71, 72, 73, 74, 75, 76, 77, 78, 79, 80, 84, 85, 89, 90, 94, 95, 96, 97, 98, 99, 100, 101, 102, 103, 104, 105, 106, 107, 108, 109, 110, 111, 112, 113, 114, 115, 116, 117, 118, 119, 120, 121, 122, 123, 124};
 
+// Per-lane sorted list of the five best candidates.  Key = (float distance bits << 32) | window
+// index: distances are non-negative, so the unsigned 64-bit order is exactly "distance, then window
+// index" (FLANN result order with the lower index winning ties).
 struct Top5 {
-  float d0, d1, d2, d3, d4;
-  int i0, i1, i2, i3, i4;     // window index (tie-break)
-  int p0, p1, p2, p3, p4;     // position in the cell-sorted array
+  unsigned long long k0, k1, k2, k3, k4;   // ascending
+  int p0, p1, p2, p3, p4;                  // position in the cell-sorted array
 };
+constexpr unsigned long long kTop5Empty = (0x7f800000ull << 32) | 0x7fffffffull;   // (+inf, INT_MAX)
+__device__ __forceinline__ float top5_dist(unsigned long long k) { return __int_as_float((int)(k >> 32)); }
+__device__ __forceinline__ int top5_index(unsigned long long k) { return (int)(unsigned int)(k & 0xFFFFFFFFull); }
+// One compare-exchange stage: the smaller of (slot, carry) stays in the slot, the larger is carried on.
+#define TOP5_STAGE(K, P)                                          \
+  {                                                               \
+    const bool lt = ck < (K);                                     \
+    const unsigned long long nk = lt ? ck : (K);                  \
+    const int np = lt ? cp : (P);                                 \
+    ck = lt ? (K) : ck;                                           \
+    cp = lt ? (P) : cp;                                           \
+    (K) = nk; (P) = np;                                           \
+  }
+// Branch-free insertion (the kernel is VALU-issue bound and most waves have some lane inserting in
+// every iteration: 5 x (one 64-bit compare + 6 selects) instead of a nest of exec-mask branches).
 __device__ __forceinline__ void top5_insert(Top5& t, float d, int wi, int pos) {
-  if (d < t.d4 || (d == t.d4 && wi < t.i4)) {
-    t.d4 = d; t.i4 = wi; t.p4 = pos;
-    if (t.d4 < t.d3 || (t.d4 == t.d3 && t.i4 < t.i3)) { float td = t.d3; t.d3 = t.d4; t.d4 = td; int ti = t.i3; t.i3 = t.i4; t.i4 = ti; ti = t.p3; t.p3 = t.p4; t.p4 = ti; }
-    if (t.d3 < t.d2 || (t.d3 == t.d2 && t.i3 < t.i2)) { float td = t.d2; t.d2 = t.d3; t.d3 = td; int ti = t.i2; t.i2 = t.i3; t.i3 = ti; ti = t.p2; t.p2 = t.p3; t.p3 = ti; }
-    if (t.d2 < t.d1 || (t.d2 == t.d1 && t.i2 < t.i1)) { float td = t.d1; t.d1 = t.d2; t.d2 = td; int ti = t.i1; t.i1 = t.i2; t.i2 = ti; ti = t.p1; t.p1 = t.p2; t.p2 = ti; }
-    if (t.d1 < t.d0 || (t.d1 == t.d0 && t.i1 < t.i0)) { float td = t.d0; t.d0 = t.d1; t.d1 = td; int ti = t.i0; t.i0 = t.i1; t.i1 = ti; ti = t.p0; t.p0 = t.p1; t.p1 = ti; }
+  unsigned long long ck = ((unsigned long long)(unsigned int)__float_as_int(d) << 32) | (unsigned int)wi;
+  int cp = pos;
+  if (ck < t.k4) {
+    TOP5_STAGE(t.k0, t.p0)
+    TOP5_STAGE(t.k1, t.p1)
+    TOP5_STAGE(t.k2, t.p2)
+    TOP5_STAGE(t.k3, t.p3)
+    TOP5_STAGE(t.k4, t.p4)
   }
 }
+#undef TOP5_STAGE
 
 // Streams the candidates of the cells selected by (start, cnt) [one cell per lane of the
 // half-wave] through the per-lane top-5 lists: population prefix (DPP scan) -> flat candidate
@@ -822,7 +842,7 @@ __device__ __forceinline__ void knn_stream_cells(Top5& t, const float4* sp, int*
     for (int u = 0; u < U; u++) {
       if (ok[u]) {
         const float d = sqdist_f(qx, qy, qz, m[u].x, m[u].y, m[u].z);
-        if (d <= t.d4) top5_insert(t, d, __float_as_int(m[u].w), a[u]);   // cheap reject first
+        if (d <= top5_dist(t.k4)) top5_insert(t, d, __float_as_int(m[u].w), a[u]);   // cheap reject first
       }
     }
   }
@@ -832,29 +852,25 @@ __device__ __forceinline__ void knn_stream_cells(Top5& t, const float4* sp, int*
 // Merges the 32 per-lane lists of a half-wave: afterwards every lane holds the global top-5
 // (ascending by distance, ties by window index) in g.
 __device__ __forceinline__ void knn_merge(Top5& t, Top5& g, int hl, int half_shift) {
-  float gd[5]; int gi[5], gp[5];
+  unsigned long long gk[5]; int gp[5];
 #pragma unroll
   for (int r = 0; r < 5; r++) {
-    const unsigned long long key = ((unsigned long long)(unsigned int)__float_as_int(t.d0) << 32) | (unsigned int)t.i0;
+    const unsigned long long key = t.k0;
     const unsigned long long mk = half_min_u64(key);
     const unsigned int win = (unsigned int)((__ballot(key == mk) >> half_shift) & 0xFFFFFFFFull);
     const int wl = __ffs(win) - 1;
     gp[r] = __shfl(t.p0, wl, kKnnGroup);
-    gd[r] = __int_as_float((int)(mk >> 32));
-    gi[r] = (int)(unsigned int)(mk & 0xFFFFFFFFull);
+    gk[r] = mk;
     if (hl == wl) {   // pop
-      t.d0 = t.d1; t.d1 = t.d2; t.d2 = t.d3; t.d3 = t.d4; t.d4 = INFINITY;
-      t.i0 = t.i1; t.i1 = t.i2; t.i2 = t.i3; t.i3 = t.i4; t.i4 = 0x7fffffff;
+      t.k0 = t.k1; t.k1 = t.k2; t.k2 = t.k3; t.k3 = t.k4; t.k4 = kTop5Empty;
       t.p0 = t.p1; t.p1 = t.p2; t.p2 = t.p3; t.p3 = t.p4; t.p4 = -1;
     }
   }
-  g.d0 = gd[0]; g.d1 = gd[1]; g.d2 = gd[2]; g.d3 = gd[3]; g.d4 = gd[4];
-  g.i0 = gi[0]; g.i1 = gi[1]; g.i2 = gi[2]; g.i3 = gi[3]; g.i4 = gi[4];
+  g.k0 = gk[0]; g.k1 = gk[1]; g.k2 = gk[2]; g.k3 = gk[3]; g.k4 = gk[4];
   g.p0 = gp[0]; g.p1 = gp[1]; g.p2 = gp[2]; g.p3 = gp[3]; g.p4 = gp[4];
 }
 __device__ __forceinline__ void top5_clear(Top5& t) {
-  t.d0 = t.d1 = t.d2 = t.d3 = t.d4 = INFINITY;
-  t.i0 = t.i1 = t.i2 = t.i3 = t.i4 = 0x7fffffff;
+  t.k0 = t.k1 = t.k2 = t.k3 = t.k4 = kTop5Empty;
   t.p0 = t.p1 = t.p2 = t.p3 = t.p4 = -1;
 }
 
@@ -942,7 +958,7 @@ __global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int oute
     auto refresh_bound = [&]() {
       unsigned int bnd = 0x7f800000u;   // +inf
       bool taken = false;
-      const unsigned int mine = (unsigned int)__float_as_int(t.d0);   // non-negative floats order as uints
+      const unsigned int mine = (unsigned int)(t.k0 >> 32);   // non-negative floats order as uints
 #pragma unroll
       for (int r = 0; r < 5; r++) {
         const unsigned int cur = taken ? 0x7f800000u : mine;
@@ -951,7 +967,7 @@ __global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int oute
         const unsigned int win = (unsigned int)((__ballot(!taken && cur == mn) >> half_shift) & 0xFFFFFFFFull);
         if (hl == __ffs(win) - 1) taken = true;
       }
-      const unsigned int own5 = half_min_u32((unsigned int)__float_as_int(t.d4));
+      const unsigned int own5 = half_min_u32((unsigned int)(t.k4 >> 32));
       bnd = own5 < bnd ? own5 : bnd;
       const float b = __int_as_float((int)bnd);
       bound_f = b < bound_f ? b : bound_f;
@@ -1015,13 +1031,13 @@ __global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int oute
     }
     knn_merge(t, g, hl, half_shift);
     DBG_STAMP(v, dbgb, 1, 5);
-    if (g.d4 < 1.0f) {                                           // :324 (inf when < 5 candidates)
+    if (top5_dist(g.k4) < 1.0f) {                                // :324 (inf when < 5 candidates)
       const int mypos = hl == 0 ? g.p0 : hl == 1 ? g.p1 : hl == 2 ? g.p2 : hl == 3 ? g.p3 : g.p4;
       if (hl < 5) {
         const float4 m = sp[mypos];
         s_nn[grp][hl * 3 + 0] = m.x; s_nn[grp][hl * 3 + 1] = m.y; s_nn[grp][hl * 3 + 2] = m.z;
       }
-      if (hl == 0) { s_res[grp][0] = 1; s_res[grp][1] = g.i0; s_res[grp][2] = g.i1; }
+      if (hl == 0) { s_res[grp][0] = 1; s_res[grp][1] = top5_index(g.k0); s_res[grp][2] = top5_index(g.k1); }
     }
   }
   __syncthreads();
