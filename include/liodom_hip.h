@@ -28,7 +28,7 @@ extern "C" {
 
 #define LIODOM_OK 0
 #define LIODOM_ERR_INVALID_ARG (-1)
-#define LIODOM_ERR_UNSUPPORTED (-2)   /* parameter combination not implemented yet */
+#define LIODOM_ERR_UNSUPPORTED (-2)   /* call not valid for the way the handle was created (e.g. mapping = 0) */
 #define LIODOM_ERR_CAPACITY (-3)      /* caller buffer or configured capacity too small */
 #define LIODOM_ERR_HIP (-4)           /* HIP runtime failure; see liodom_last_error() */
 #define LIODOM_ERR_NO_DEVICE (-5)
