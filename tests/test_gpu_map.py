@@ -261,3 +261,41 @@ def test_replay_harness_mapping_mode(orc, synth, tmp_path):
     assert np.allclose(got, np.array(rows), rtol=2e-5, atol=2e-6)
     m = np.fromfile(str(out_dir / "map.bin"), dtype=np.float32).reshape(-1, 4)
     assert m.shape[0] == od.map_total() and m.shape[0] > 100
+
+
+def test_two_streams_with_their_own_mappers(orc, synth):
+    """n_streams = 2, mapping = 1, one device map attached per stream: each stream's received map
+    and pose log equal those of a single-stream handle fed the same scans."""
+    H, W, R, epr, P, K = 16, 900, 6, 10, 4, 5
+    cfg = synth.make_cfg(H, W, 0)
+    scans = [[synth.scan(cfg, s, k)[0] for k in range(K)] for s in range(2)]
+    prm = la.make_params(scan_lines=H, scan_regions=R, edges_per_region=epr, prev_frames=P, mapping=1)
+    single = []
+    for s in range(2):
+        g = la.Liodom(prm, la.make_config(max_points=H * W, max_width=W, recv_capacity=1 << 16))
+        m = la.Map(max_cells=128, cell_capacity=16384)
+        g.attach_mapper(m, 2, 1)
+        poses = [g.process_scan(scans[s][k], H, W)[0].copy() for k in range(K)]
+        single.append((np.array(poses), g.received_map(), m.all()))
+        g.attach_mapper(None)
+        g.close(); m.close()
+    gb = la.Liodom(prm, la.make_config(n_streams=2, max_points=H * W, max_width=W, recv_capacity=1 << 16, pose_log_capacity=K + 4))
+    maps = [la.Map(max_cells=128, cell_capacity=16384) for _ in range(2)]
+    for s in range(2):
+        gb.attach_mapper(maps[s], 2, 1, stream=s)
+    gb.alloc_resident(K)
+    for s in range(2):
+        for k in range(K):
+            gb.upload_scan(s, k, scans[s][k])
+    for k in range(K):
+        gb.process_resident(k, H * W, H, W, readback=True)
+    for s in range(2):
+        log, _ = gb.pose_log(s, 0, K)
+        assert np.array_equal(log, single[s][0]), s
+        assert same(gb.received_map(stream=s), single[s][1]), s
+        assert same(maps[s].all(), single[s][2]), s
+    for s in range(2):
+        gb.attach_mapper(None, stream=s)
+    gb.close()
+    for m in maps:
+        m.close()
