@@ -218,6 +218,8 @@ def sec_clocks(H=64, W=1800, R=8, epr=10, P=20, K=40):
 
 
 SECTIONS["clocks"] = sec_clocks
+SECTIONS["timing_ouster"] = lambda: sec_timing(H=128, W=2048, lt=1, R=8, epr=10, P=30, K=45)
+SECTIONS["timing_vlp16"] = lambda: sec_timing(H=16, W=1800, lt=0, R=8, epr=20, P=10, K=60)
 
 
 def sec_long(H=64, W=1800, R=8, epr=10, P=20, K=220):
