@@ -151,7 +151,7 @@ int launch_extract(liodom_handle* h, hipStream_t q, int eb, int s0, int count, c
   }
   {
     ProfScope ps(h, KID_COMPACT, q);
-    hipLaunchKernelGGL(k_compact_edges, dim3(count), dim3(256), 0, q, v, s0, eb);
+    hipLaunchKernelGGL(k_compact_edges, dim3(kCompactBlocks, count), dim3(256), 0, q, v, s0, eb);
   }
   HIP_TRY(hipGetLastError());
   return LIODOM_OK;

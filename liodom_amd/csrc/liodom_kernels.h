@@ -701,10 +701,13 @@ __global__ __launch_bounds__(kExThreads) void k_ring_extract(DevView v, int s0) 
 // k_compact_edges: one workgroup per stream; ring-padded edges -> dense edge cloud (edge buffer
 // `eb`) in the reference's output order.
 // =============================================================================================
+// grid (kCompactBlocks, streams): every workgroup scans the <= 256 ring counts itself (cheaper than a
+// second launch) and copies its interleaved share of the edges.
+constexpr int kCompactBlocks = 8;
 __global__ __launch_bounds__(256) void k_compact_edges(DevView v, int s0, int eb) {
   __shared__ int pre[257];
   __shared__ int cntr[256];
-  const int s = s0 + blockIdx.x;
+  const int s = s0 + blockIdx.y;
   const int H = v.scan_lines;
   const int* rn = v.ring_nedges + (size_t)s * H;
   {
@@ -720,13 +723,12 @@ __global__ __launch_bounds__(256) void k_compact_edges(DevView v, int s0, int eb
     __syncthreads();
     // threads >= H contribute 0, so pre[H] already equals the total
   }
-  __syncthreads();
-  if (threadIdx.x == 0) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
     const int acc = pre[256];
     v.state[s].n_edges_buf[eb] = acc > v.edge_cap ? v.edge_cap : acc;
   }
   const int E = pre[H] > v.edge_cap ? v.edge_cap : pre[H];
-  for (int e = threadIdx.x; e < E; e += 256) {
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < E; e += kCompactBlocks * 256) {
     int lo = 0, hi = H;            // largest r with pre[r] <= e
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pre[mid] <= e) lo = mid; else hi = mid; }
     const int r = lo, k = e - pre[r];
