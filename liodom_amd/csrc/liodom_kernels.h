@@ -682,17 +682,23 @@ __global__ __launch_bounds__(kExThreads) void k_ring_extract(DevView v, int s0) 
   // ---- phase 4: emit in region order, pick order (:275) ----
   float4* eout = v.edges_pad + ((size_t)s * H + ring) * slots;
   int2* mout = v.edges_pad_meta + ((size_t)s * H + ring) * slots;
-  int base = 0;
-  for (int reg = 0; reg < R; reg++) {
-    const int cntp = region_cnt[reg];
-    for (int k = tid; k < cntp; k += kExThreads) {
-      const int j = pick_idx[reg * ppr + k];
+  // one flat pass over all pick slots (region-major): slot (reg, k) goes to position
+  // sum of the earlier regions' counts + k — one round of loads instead of one per region
+  int total_picks = 0;
+  for (int q = tid; q < R * ppr; q += kExThreads) {
+    const int reg = q / ppr, k = q - reg * ppr;
+    if (k < region_cnt[reg]) {
+      int base = 0;
+      for (int r2 = 0; r2 < reg; r2++) base += region_cnt[r2];
+      const int j = pick_idx[q];
       eout[base + k] = rpts[j];                                    // :275 (XYZ + intensity unchanged)
       mout[base + k] = make_int2(j, rsrc[j]);
     }
-    base += cntp;
   }
-  if (tid == 0) *nedges_out = base;
+  if (tid == 0) {
+    for (int r2 = 0; r2 < R; r2++) total_picks += region_cnt[r2];
+    *nedges_out = total_picks;
+  }
   DBG_STAMP(v, dbgb, 0, 7);
   if ((v.debug & 32) && s == 0 && tid == 0 && ring < 128) v.dbg_clk[128 + ring] = wall_clock64() - t_begin;
 }
