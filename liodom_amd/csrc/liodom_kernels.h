@@ -1653,9 +1653,10 @@ __device__ __forceinline__ void win_index_load(const DevView& v, int s, int nf, 
   for (int j = tid; j <= nf; j += nt) w.sbase[j] = v.win_base[(size_t)s * (P + 1) + j];
   for (int j = tid; j < nf; j += nt) w.sslot[j] = v.win_slot[(size_t)s * P + j];
 }
-__device__ __forceinline__ float4 win_point(const DevView& v, int s, int nf, const WinIndex& w, int m) {
+__device__ __forceinline__ float4 win_point(const DevView& v, int s, int nf, const WinIndex& w, int m, int* jc = nullptr) {
   int lo = 0, hi = nf;             // largest j with sbase[j] <= m
-  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (w.sbase[mid] <= m) lo = mid; else hi = mid; }
+  if (jc) { lo = *jc; while (lo + 1 < nf && w.sbase[lo + 1] <= m) lo++; *jc = lo; }
+  else { while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (w.sbase[mid] <= m) lo = mid; else hi = mid; } }
   return v.win_pts[((size_t)s * v.prev_frames + w.sslot[lo]) * v.edge_cap + (m - w.sbase[lo])];
 }
 __device__ __forceinline__ bool point_ok(const float4& p) {
@@ -1669,10 +1670,12 @@ constexpr int kBuildThreads = 1024;
 constexpr int kBuildUnroll = 4;
 __host__ __device__ __forceinline__ size_t hash_build_lds_bytes() { return (size_t)kLdsSlots * 16 + 64; }
 
+// (jc: optional frame cursor of a thread whose m only grows: replaces the binary search by a step)
 __device__ __forceinline__ float4 window_point_produce(const DevView& v, int s, const StreamState& st, int eb,
-                                                       const WinIndex& w, int nf, int m) {
+                                                       const WinIndex& w, int nf, int m, int* jc = nullptr) {
   int lo = 0, hi = nf;             // largest j with sbase[j] <= m
-  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (w.sbase[mid] <= m) lo = mid; else hi = mid; }
+  if (jc) { lo = *jc; while (lo + 1 < nf && w.sbase[lo + 1] <= m) lo++; *jc = lo; }
+  else { while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (w.sbase[mid] <= m) lo = mid; else hi = mid; } }
   const int j = lo, idx = m - w.sbase[j];
   float4* wp = v.win_pts + ((size_t)s * v.prev_frames + w.sslot[j]) * v.edge_cap + idx;
   if (j != nf - 1 || eb < 0) return *wp;
@@ -1727,12 +1730,13 @@ __global__ __launch_bounds__(kBuildThreads) void k_hash_build(DevView v, int s0,
   }
   // ---- insert + count in LDS (kBuildUnroll point loads in flight per thread) ----
   const unsigned int lmask = kLdsSlots - 1;
+  int jc = 0;                      // frame cursor: this thread's m only grows
   for (int m0 = tid; m0 < M; m0 += kBuildUnroll * kBuildThreads) {
     float4 pt[kBuildUnroll];
 #pragma unroll
     for (int k = 0; k < kBuildUnroll; k++) {
       const int m = m0 + k * kBuildThreads;
-      if (m < M) pt[k] = m < Mw ? window_point_produce(v, s, st, eb, w, nf, m) : recv[m - Mw];
+      if (m < M) pt[k] = m < Mw ? window_point_produce(v, s, st, eb, w, nf, m, &jc) : recv[m - Mw];
     }
 #pragma unroll
     for (int k = 0; k < kBuildUnroll; k++) {
@@ -1825,6 +1829,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_hash_build(DevView v, int s0,
   }
   __syncthreads();
   // ---- scatter to cell-contiguous order: position = start of the cell + rank of the point ----
+  jc = 0;
   for (int m0 = tid; m0 < M; m0 += kBuildUnroll * kBuildThreads) {
     float4 pt[kBuildUnroll];
     int hc[kBuildUnroll], rk[kBuildUnroll];
@@ -1832,7 +1837,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_hash_build(DevView v, int s0,
     for (int k = 0; k < kBuildUnroll; k++) {
       const int m = m0 + k * kBuildThreads;
       hc[k] = -1;
-      if (m < M) { hc[k] = pcell[m]; rk[k] = prank[m]; pt[k] = m < Mw ? win_point(v, s, nf, w, m) : recv[m - Mw]; }
+      if (m < M) { hc[k] = pcell[m]; rk[k] = prank[m]; pt[k] = m < Mw ? win_point(v, s, nf, w, m, &jc) : recv[m - Mw]; }
     }
 #pragma unroll
     for (int k = 0; k < kBuildUnroll; k++) {
