@@ -864,8 +864,17 @@ __device__ __forceinline__ void knn_merge(Top5& t, Top5& g, int hl, int half_shi
 #pragma unroll
   for (int r = 0; r < 5; r++) {
     const unsigned long long key = t.k0;
-    const unsigned long long mk = half_min_u64(key);
-    const unsigned int win = (unsigned int)((__ballot(key == mk) >> half_shift) & 0xFFFFFFFFull);
+    // reduce on the 32-bit distance (half the DPP traffic of a 64-bit reduction); only when several
+    // lanes tie on the distance the full (distance, index) key decides
+    const unsigned int dmin = half_min_u32((unsigned int)(key >> 32));
+    unsigned int win = (unsigned int)((__ballot((unsigned int)(key >> 32) == dmin) >> half_shift) & 0xFFFFFFFFull);
+    unsigned long long mk;
+    if (__popc(win) == 1) {
+      mk = ((unsigned long long)dmin << 32) | (unsigned int)__shfl((int)(unsigned int)(key & 0xFFFFFFFFull), __ffs(win) - 1, kKnnGroup);
+    } else {
+      mk = half_min_u64(key);
+      win = (unsigned int)((__ballot(key == mk) >> half_shift) & 0xFFFFFFFFull);
+    }
     const int wl = __ffs(win) - 1;
     gp[r] = __shfl(t.p0, wl, kKnnGroup);
     gk[r] = mk;
