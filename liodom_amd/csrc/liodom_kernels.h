@@ -1255,7 +1255,7 @@ __device__ void hash_clear_used(const DevView& v, int s, int nup, int t, int nt)
 // Called by the whole workgroup.  sh_cnt: LDS scratch of kMaxFrames + 1 ints.
 // Thread 64 publishes the result (pose log, host-mapped record) while thread 0 computes the
 // prediction and the window bookkeeping; the remaining threads fetch the frame sizes.
-__device__ void finalize_scan(const DevView& v, int s, StreamState& st, int* sh_cnt, int eb) {
+__device__ void finalize_scan(const DevView& v, int s, StreamState& st, int* sh_cnt, int eb, bool clear_hash) {
   const int P = v.prev_frames;
   const int tid = threadIdx.x;
   // LocalMapManager::addPointCloud (:34-60) on a ring of P frame slots: the new frame goes
@@ -1323,8 +1323,9 @@ __device__ void finalize_scan(const DevView& v, int s, StreamState& st, int* sh_
   }
   __syncthreads();
   for (int j = tid; j <= nf; j += blockDim.x) wb[j] = sh_cnt[j];
-  // after the publication: its system-scope fence would otherwise have to write back these lines
-  hash_clear_used(v, s, nup, tid, (int)blockDim.x);
+  // (first frame only; in steady state the finalising solve clears the table beside its first
+  // controller step instead of extending the kernel by ~4.5 us here)
+  if (clear_hash) hash_clear_used(v, s, nup, tid, (int)blockDim.x);
 }
 
 // All-to-all exchange of the 29 partial sums between the G workgroups of a stream, inside the
@@ -1410,7 +1411,7 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
     // first frame (:108-136): no solve; pose stays identity, edges enter the window raw
     if (outer_it == 1 && g == 0) {
       if (threadIdx.x == 0) st.append_raw = 1;
-      finalize_scan(v, s, st, sh_cnt, eb);
+      finalize_scan(v, s, st, sh_cnt, eb, true);
       if (threadIdx.x == 0) st.initialized = 1;
     }
     return;
@@ -1437,6 +1438,11 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
   if (threadIdx.x == 0) {
     sh_flag = lm_begin(lm, st.param_q, st.param_t, sh_acc, nblocks, v.apply_on_ftol);
     if (sh_flag == LM_NEED_EVAL) iso_from_qt(lm.cand_q, lm.cand_t, sh_pose);
+  } else if (outer_it == 1 && g == 0 && threadIdx.x >= 64) {
+    // The second kNN pass of this scan has completed, the cell hash it searched is no longer needed:
+    // waves 1.. reset its occupied slots while lane 0 of wave 0 runs the first controller step
+    // (they would idle at the barrier otherwise; at the end of the kernel this cost 4.5 us).
+    hash_clear_used(v, s, st.n_used, (int)threadIdx.x - 64, (int)blockDim.x - 64);
   }
   __syncthreads();
   DBG_STAMP(v, dbgb, 2, 3);
@@ -1466,7 +1472,7 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
   }
   DBG_STAMP(v, dbgb, 2, 21);
   if (outer_it == 1) {
-    finalize_scan(v, s, st, sh_cnt, eb);
+    finalize_scan(v, s, st, sh_cnt, eb, false);
   }
   DBG_STAMP(v, dbgb, 2, 22);
 }
