@@ -1446,6 +1446,18 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
     }
     return;
   }
+  // (finalising solve) slots of the cell hash to reset later, 8 per thread of waves 1..: loads only
+  int clr[8];
+  int clr_n = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) clr[k] = -1;
+  if (outer_it == 1 && g == 0 && threadIdx.x >= 64) {
+    clr_n = st.n_used;
+    const int nt = (int)blockDim.x - 64, t0 = (int)threadIdx.x - 64;
+    const int* used = v.used_cells + (size_t)s * v.map_cap;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { const int u = t0 + k * nt; if (u < clr_n) clr[k] = used[u]; }
+  }
   const bool dbgb = (s == 0) && (g == 0) && (threadIdx.x == 0) && (outer_it == 1);
   DBG_STAMP(v, dbgb, 2, 0);
   const int E = st.n_edges_buf[eb];
@@ -1471,8 +1483,26 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
   } else if (outer_it == 1 && g == 0 && threadIdx.x >= 64) {
     // The second kNN pass of this scan has completed, the cell hash it searched is no longer needed:
     // waves 1.. reset its occupied slots while lane 0 of wave 0 runs the first controller step
-    // (they would idle at the barrier otherwise; at the end of the kernel this cost 4.5 us).
-    hash_clear_used(v, s, st.n_used, (int)threadIdx.x - 64, (int)blockDim.x - 64);
+    // (they would idle at the barrier otherwise; at the end of the kernel this cost 4.5 us).  The slot
+    // indices were fetched at kernel start, so only stores are issued here.
+    CellSlot empty; empty.key = kEmptyKey; empty.start = 0; empty.cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      if (clr[k] >= 0) {
+        const size_t ti = (size_t)s * v.table_size + clr[k];
+        v.cells[ti] = empty;
+        v.cell_bits[ti >> 5] = 0u;   // every set bit of that word belongs to a slot of the list being cleared
+      }
+    }
+    if (clr_n > 8 * ((int)blockDim.x - 64)) {      // longer lists: the rest the ordinary way
+      const int nt = (int)blockDim.x - 64, t0 = (int)threadIdx.x - 64;
+      const int* used = v.used_cells + (size_t)s * v.map_cap;
+      for (int u = 8 * nt + t0; u < clr_n; u += nt) {
+        const size_t ti = (size_t)s * v.table_size + used[u];
+        v.cells[ti] = empty;
+        v.cell_bits[ti >> 5] = 0u;
+      }
+    }
   }
   __syncthreads();
   DBG_STAMP(v, dbgb, 2, 3);
