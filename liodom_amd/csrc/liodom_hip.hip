@@ -162,7 +162,8 @@ int launch_extract(liodom_handle* h, hipStream_t q, int eb, int s0, int count, c
 // so the host can pick them up while the window / hash rebuild still runs.
 int launch_odometry(liodom_handle* h, int eb, int s0, int count) {
   const DevView& v = h->v;
-  const int knn_blocks = cdiv(h->v.edge_cap, kKnnQueries);
+  const bool knn_small = h->S >= 16;            // many streams: 4 queries per workgroup, else 8
+  const int knn_blocks = cdiv(h->v.edge_cap, knn_small ? 4 : 8);
   if (v.use_imu) {
     ProfScope ps(h, KID_OTHER);
     hipLaunchKernelGGL(k_imu_override, dim3(cdiv(count, 64)), dim3(64), 0, h->stream, v, s0, count);
@@ -170,7 +171,8 @@ int launch_odometry(liodom_handle* h, int eb, int s0, int count) {
   for (int it = 0; it < 2; it++) {
     {
       ProfScope ps(h, KID_KNN);
-      hipLaunchKernelGGL(k_knn, dim3(knn_blocks, count), dim3(kKnnThreads), 0, h->stream, v, s0, it, eb);
+      if (knn_small) hipLaunchKernelGGL(k_knn<128>, dim3(knn_blocks, count), dim3(128), 0, h->stream, v, s0, it, eb);
+      else hipLaunchKernelGGL(k_knn<256>, dim3(knn_blocks, count), dim3(256), 0, h->stream, v, s0, it, eb);
     }
     {
       ProfScope ps(h, KID_LM);

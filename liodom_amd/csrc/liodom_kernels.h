@@ -921,13 +921,14 @@ __device__ __forceinline__ void top5_clear(Top5& t) {
   t.p0 = t.p1 = t.p2 = t.p3 = t.p4 = -1;
 }
 
-#ifndef LIODOM_KNN_THREADS
-#define LIODOM_KNN_THREADS 256     // 8 queries per workgroup: measured 1024 -> 256: 332 -> 242 us per pass on 64 lock-step streams (a workgroup lasts as long as its slowest query), 31.5 -> 29.7 us on one
-#endif
-constexpr int kKnnThreads = LIODOM_KNN_THREADS;
-constexpr int kKnnQueries = kKnnThreads / kKnnGroup;   // 32 queries per workgroup
-
+// Workgroup size = 32 lanes x queries.  A workgroup lasts as long as its slowest query, so few queries
+// per workgroup win: measured 1024 -> 256 threads: 332 -> 242 us per pass on 64 lock-step streams,
+// 31.5 -> 29.7 us on one.  Later (cheaper insertion, cell-major lists) 128 threads beat 256 on many
+// streams (scan step 686 vs 707 us on 64) and lose slightly on one (129.2 vs 127.6 us): two instances,
+// chosen by the host from the stream count.
+template <int kKnnThreads>
 __global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int outer_it, int eb) {
+  constexpr int kKnnQueries = kKnnThreads / kKnnGroup;
   __shared__ int s_incl[kKnnQueries][kKnnGroup];   // inclusive candidate prefix per cell
   __shared__ int s_adj[kKnnQueries][kKnnGroup];    // cell start - exclusive prefix
   __shared__ float s_nn[kKnnQueries][16];          // the five neighbours of every query (xyz)

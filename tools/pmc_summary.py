@@ -15,7 +15,7 @@ def load(dirname, counter):
     db = sqlite3.connect(f)
     rows = db.execute("select kernel_name, grid_size, count(*), avg(value) from counters_collection "
                       "where counter_name=? group by kernel_name, grid_size", (counter,)).fetchall()
-    return {(k.split("(")[0].replace("liodom_dev::", ""), g): (n, v) for k, g, n, v in rows if "liodom_dev" in k}
+    return {(k.split("(")[0].split("<")[0].replace("void ", "").replace("liodom_dev::", ""), g): (n, v) for k, g, n, v in rows if "liodom_dev" in k}
 
 
 if __name__ == "__main__":
