@@ -56,6 +56,7 @@ class Config(C.Structure):
         ("device", C.c_int32), ("n_streams", C.c_int32), ("max_points", C.c_int32), ("max_width", C.c_int32),
         ("max_ring_points", C.c_int32), ("lm_apply_step_on_ftol", C.c_int32), ("pose_log_capacity", C.c_int32),
         ("debug_buffers", C.c_int32), ("lm_workgroups", C.c_int32), ("recv_capacity", C.c_int32),
+        ("pose_rotation_mode", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 

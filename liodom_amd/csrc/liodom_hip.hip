@@ -330,6 +330,7 @@ void liodom_config_default(liodom_config_t* c) {
   c->device = 0; c->n_streams = 1; c->max_points = 64 * 1800; c->max_width = 1800;
   c->max_ring_points = 0; c->lm_apply_step_on_ftol = 0; c->pose_log_capacity = 1024; c->debug_buffers = 0;
   c->lm_workgroups = 0;
+  c->pose_rotation_mode = 1;    // Eigen 3.3.x Transform::rotation()
 }
 
 int liodom_create(const liodom_params_t* params, const liodom_config_t* config, liodom_handle_t** out) {
@@ -376,6 +377,7 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   v.min_points_per_scan = (long long)params->min_points_per_scan;
   v.prev_frames = h->P;
   v.apply_on_ftol = config->lm_apply_step_on_ftol;
+  v.rotation_mode = config->pose_rotation_mode != 0 ? 1 : 0;
   v.filter_local_map = (params->filter_local_map && !params->mapping) ? 1 : 0;   // laser_odometry.cc:286
   // auto: several CUs per solve pay off only when one CU would spend >> the ~4.5 us in-launch
   // exchange on an evaluation (measured: ~2000 edges -> no gain; Ouster-128 shape -> yes)

@@ -94,6 +94,7 @@ struct DevView {
   long long min_points_per_scan;
   int prev_frames;
   int apply_on_ftol;
+  int rotation_mode;        // what Eigen's Transform::rotation() returns: 1 polar factor (Eigen 3.3.x), 0 linear() (>= 3.4)
   int filter_local_map;     // params.filter_local_map_ (and !mapping_)
   int lm_groups;            // workgroups cooperating on one stream's solve (1 or kLmGroupsMax)
   float vox_inv;            // 1.0f / 0.4f as PCL computes inverse_leaf_size_
@@ -1310,7 +1311,7 @@ __device__ void finalize_scan(const DevView& v, int s, StreamState& st, int* sh_
   if (tid == 64) {
     // pose as published (laser_odometry.cc:403-412 with identity laser_to_base)
     double q[4];
-    quat_from_rot(st.final_odom, q);
+    quat_from_pose(st.final_odom, v.rotation_mode, q);             // :403 q_current(odom_base_link.rotation())
     const int k = st.scan_counter;
     st.info.scan_index = k;
     st.info.status = st.status;
@@ -1339,7 +1340,7 @@ __device__ void finalize_scan(const DevView& v, int s, StreamState& st, int* sh_
     iso_mul(inv, st.final_odom, rel);
     iso_mul(st.final_odom, rel, pred);
     for (int i = 0; i < 12; i++) { st.prev_odom[i] = st.final_odom[i]; st.odom[i] = pred[i]; }
-    quat_from_rot(pred, st.param_q);                                 // :186-190
+    quat_from_pose(pred, v.rotation_mode, st.param_q);               // :186-190 q_curr(odom_.rotation())
     st.param_t[0] = pred[3]; st.param_t[1] = pred[7]; st.param_t[2] = pred[11];   // :192-195
     wn[new_slot] = n_edges;
     st.frame_count = fc_new;
@@ -1411,10 +1412,10 @@ __global__ void k_imu_override(DevView v, int s0, int count) {
   for (int k = 0; k < 12; k++) { odom[k] = st.odom[k]; l2b[k] = v.laser_to_base[k]; }
 #pragma unroll
   for (int k = 0; k < 4; k++) q[k] = v.imu_q[(size_t)(s0 + i) * 4 + k];
-  imu_override(odom, q, l2b, out);
+  imu_override(odom, q, l2b, v.rotation_mode, out);
 #pragma unroll
   for (int k = 0; k < 12; k++) st.odom[k] = out[k];
-  quat_from_rot(out, st.param_q);                                                  // :186-190
+  quat_from_pose(out, v.rotation_mode, st.param_q);                                // :186-190
   st.param_t[0] = out[3]; st.param_t[1] = out[7]; st.param_t[2] = out[11];         // :192-195
 }
 

@@ -76,26 +76,35 @@ LD_HD int velodyne_ring(double z, double dist, int scan_lines) {
 }
 
 // ---------------------------------------------------------------------------------------
-// Curvature stencil (src/feature_extractor.cc:196-229): FP64, summed left to right.
+// Curvature stencil (src/feature_extractor.cc:196-229).  All eleven operands are
+// pcl::PointXYZI floats and `10 * x` is int * float, so the reference sums in FLOAT, left to
+// right, and only the finished sum is widened to double (`double diff_x = ...`); the three squares
+// and their sum (:229) are double.  (The reference build is x86-64 SSE: float expressions are
+// evaluated in float, FLT_EVAL_METHOD = 0.)
 // ---------------------------------------------------------------------------------------
-template <typename F>
-LD_HD double stencil_axis(const F* p, int j) {
-  return (double)p[j - 5] + (double)p[j - 4] + (double)p[j - 3] + (double)p[j - 2] +
-         (double)p[j - 1] - 10 * (double)p[j] + (double)p[j + 1] + (double)p[j + 2] +
-         (double)p[j + 3] + (double)p[j + 4] + (double)p[j + 5];
+LD_HD double stencil_sum(float m5, float m4, float m3, float m2, float m1, float c, float p1,
+                         float p2, float p3, float p4, float p5) {
+  const float s = m5 + m4 + m3 + m2 + m1 - 10 * c + p1 + p2 + p3 + p4 + p5;
+  return (double)s;
 }
-template <typename F>
-LD_HD double curvature(const F* px, const F* py, const F* pz, int j) {
+LD_HD double stencil_axis(const float* p, int j) {
+  return stencil_sum(p[j - 5], p[j - 4], p[j - 3], p[j - 2], p[j - 1], p[j], p[j + 1], p[j + 2],
+                     p[j + 3], p[j + 4], p[j + 5]);
+}
+LD_HD double curvature(const float* px, const float* py, const float* pz, int j) {
   const double dx = stencil_axis(px, j), dy = stencil_axis(py, j), dz = stencil_axis(pz, j);
   return dx * dx + dy * dy + dz * dz;
 }
-// squared gap between consecutive ring points i and k (:281-289, :297-305)
-template <typename F>
-LD_HD double gap_sq(const F* px, const F* py, const F* pz, int i, int k) {
-  const double dx = (double)px[i] - (double)px[k];
-  const double dy = (double)py[i] - (double)py[k];
-  const double dz = (double)pz[i] - (double)pz[k];
+// squared gap between consecutive ring points (:281-289, :297-305): float differences
+// (`double diff_x = p[i].x - p[k].x` subtracts two floats), squares and sum in double
+LD_HD double gap_sq3(float xi, float yi, float zi, float xk, float yk, float zk) {
+  const double dx = (double)(xi - xk);
+  const double dy = (double)(yi - yk);
+  const double dz = (double)(zi - zk);
   return dx * dx + dy * dy + dz * dz;
+}
+LD_HD double gap_sq(const float* px, const float* py, const float* pz, int i, int k) {
+  return gap_sq3(px[i], py[i], pz[i], px[k], py[k], pz[k]);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -159,6 +168,53 @@ LD_HD void iso_from_qt(const double* q, const double* t, double* T) {
   T[0] = 1 - (tyy + tzz); T[1] = txy - twz;       T[2] = txz + twy;        T[3] = t[0];
   T[4] = txy + twz;       T[5] = 1 - (txx + tzz); T[6] = tyz - twx;        T[7] = t[1];
   T[8] = txz - twy;       T[9] = tyz + twx;       T[10] = 1 - (txx + tyy); T[11] = t[2];
+}
+// Eigen::Transform::rotation() (src/laser_odometry.cc:164,186,403,420).  Eigen 3.3.x (the
+// README's platform: Ubuntu 20.04 ships 3.3.7) implements it for every Mode as
+// computeRotationScaling(): JacobiSVD of linear(), R = U V^T (made proper) — the orthonormal polar
+// factor.  Eigen >= 3.4 returns linear() itself for an Isometry.  mode 1 = polar factor, 0 = linear().
+// The polar factor is computed by Newton's iteration X <- (X + X^-T) / 2 (quadratic; the poses on
+// this path are orthonormal to ~1e-8 or better, so two steps reach rounding level); the oracle uses
+// a Jacobi SVD — the factor is unique, both agree to ~1e-16.  det(linear) > 0 is assumed (always
+// true for matrices built by toRotationMatrix and their products).
+LD_HD void rotation_of(const double* T, int mode, double* R /*3x4, translation copied*/) {
+  double x[9] = {T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]};
+  if (mode != 0) {
+    for (int it = 0; it < 24; it++) {
+      double c[9];
+      c[0] = x[4] * x[8] - x[5] * x[7]; c[1] = x[5] * x[6] - x[3] * x[8]; c[2] = x[3] * x[7] - x[4] * x[6];
+      c[3] = x[2] * x[7] - x[1] * x[8]; c[4] = x[0] * x[8] - x[2] * x[6]; c[5] = x[1] * x[6] - x[0] * x[7];
+      c[6] = x[1] * x[5] - x[2] * x[4]; c[7] = x[2] * x[3] - x[0] * x[5]; c[8] = x[0] * x[4] - x[1] * x[3];
+      const double det = x[0] * c[0] + x[1] * c[1] + x[2] * c[2];
+      if (!(det > 0.0) || !ld_isfinite(det)) break;          // singular / improper / NaN: leave as is
+      // far from orthonormal (never on a healthy trajectory): Frobenius scaling keeps the iteration fast
+      double nx = 0.0, nc = 0.0;
+      LD_UNROLL
+      for (int i = 0; i < 9; i++) { nx += x[i] * x[i]; nc += c[i] * c[i]; }
+      double g = 1.0;
+      if (fabs(nx - 3.0) > 0.1) g = sqrt(sqrt(nc / (det * det)) / sqrt(nx));   // sqrt(|X^-1|_F / |X|_F)
+      const double a = 0.5 * g, b = 0.5 / (g * det);
+      double change = 0.0;
+      LD_UNROLL
+      for (int i = 0; i < 9; i++) {
+        const double nv = a * x[i] + b * c[i];
+        const double d = fabs(nv - x[i]);
+        if (d > change) change = d;
+        x[i] = nv;
+      }
+      if (change <= 4e-16) break;
+    }
+  }
+  R[0] = x[0]; R[1] = x[1]; R[2] = x[2]; R[3] = T[3];
+  R[4] = x[3]; R[5] = x[4]; R[6] = x[5]; R[7] = T[7];
+  R[8] = x[6]; R[9] = x[7]; R[10] = x[8]; R[11] = T[11];
+}
+// Eigen::Quaterniond(T.rotation())
+LD_HD void quat_from_pose(const double* T, int rotation_mode, double* q) {
+  if (rotation_mode == 0) { quat_from_rot(T, q); return; }
+  double R[12];
+  rotation_of(T, rotation_mode, R);
+  quat_from_rot(R, q);
 }
 // pcl::transformPointCloud, double matrix, float points (src/laser_odometry.cc:232,308)
 LD_HD void transform_point(const double* T, float x, float y, float z, float* ox, float* oy,
@@ -224,13 +280,13 @@ LD_HD void tf_quat_from_matrix(const double* m, double* q) {
   }
 }
 // odom (3 x 4, world <- laser) with the roll and pitch of its base_link orientation replaced by the IMU's
-LD_HD void imu_override(const double* odom, const double* imu_q, const double* laser_to_base, double* out) {
+LD_HD void imu_override(const double* odom, const double* imu_q, const double* laser_to_base, int rotation_mode, double* out) {
   double m[9], imu_roll, imu_pitch, imu_yaw, bl_roll, bl_pitch, bl_yaw;
   tf_matrix_from_quat(imu_q, m);
   tf_get_rpy(m, &imu_roll, &imu_pitch, &imu_yaw);                 // :155-161
   double odom_bl[12], q_bl[4], q_new[4], l2b_inv[12];
   iso_mul(odom, laser_to_base, odom_bl);                          // :164
-  quat_from_rot(odom_bl, q_bl);                                   // :165
+  quat_from_pose(odom_bl, rotation_mode, q_bl);                   // :165 Quaterniond(odom_bl.rotation())
   tf_matrix_from_quat(q_bl, m);
   tf_get_rpy(m, &bl_roll, &bl_pitch, &bl_yaw);                    // :166-169
   tf_set_rpy(imu_roll, imu_pitch, bl_yaw, m);                     // :174
@@ -243,16 +299,16 @@ LD_HD void imu_override(const double* odom, const double* imu_q, const double* l
 // LaserOdometer::publishOdom (src/laser_odometry.cc:395-436): pose in the base_link frame and the
 // finite-difference twist.  out: orientation x y z w, position, twist.linear, twist.angular (13).
 LD_HD void odom_message(const double* prev_odom, const double* odom, const double* laser_to_base,
-                        double delta_time, double* out) {
+                        double delta_time, int rotation_mode, double* out) {
   double bl[12], pbl[12], pinv[12], d[12], qd[4], m[9], roll, pitch, yaw;
   iso_mul(odom, laser_to_base, bl);                 // :403
-  quat_from_rot(bl, out);                           // :404
+  quat_from_pose(bl, rotation_mode, out);           // :403 q_current(odom_base_link.rotation())
   out[4] = bl[3]; out[5] = bl[7]; out[6] = bl[11];  // :405
   iso_mul(prev_odom, laser_to_base, pbl);
   iso_inverse(pbl, pinv);
   iso_mul(pinv, bl, d);                             // :416
   out[7] = d[3] / delta_time; out[8] = d[7] / delta_time; out[9] = d[11] / delta_time;   // :417-420
-  quat_from_rot(d, qd);                             // :421
+  quat_from_pose(d, rotation_mode, qd);             // :420 q_delta(delta_odom.rotation())
   tf_matrix_from_quat(qd, m);
   tf_get_rpy(m, &roll, &pitch, &yaw);               // :423-426
   out[10] = roll / delta_time; out[11] = pitch / delta_time; out[12] = yaw / delta_time;
@@ -579,9 +635,11 @@ LD_HD int lm_propose(LmState& st) {
       mcc = -sg - 0.5 * shs;
     }
     if (!ok || !(mcc > 0.0)) {
+      // TrustRegionMinimizer::HandleInvalidStep (max_num_consecutive_invalid_steps = 5), then
+      // LevenbergMarquardtStrategy::StepIsInvalid(): radius *= 0.5, reuse_diagonal = true;
+      // decrease_factor belongs to StepRejected / StepAccepted only
       if (++st.invalid_run >= 5) { st.termination = LM_TERM_INVALID_STEPS; return LM_DONE; }
-      st.radius = st.radius / st.decrease_factor;
-      st.decrease_factor *= 2.0;
+      st.radius = st.radius * 0.5;
       continue;
     }
     st.invalid_run = 0;

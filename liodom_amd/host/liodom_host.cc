@@ -114,11 +114,12 @@ void Stats::writeResults(const std::string& dir) {
   dump("frame_times.txt", frame_times_);
 }
 
-Engine::Engine(const Params& p, int device, int max_points, int max_width) {
+Engine::Engine(const Params& p, int device, int max_points, int max_width, int pose_rotation_mode) {
   liodom_params_t cp = p.toC();
   liodom_config_t cfg;
   liodom_config_default(&cfg);
   cfg.device = device; cfg.n_streams = 1; cfg.max_points = max_points; cfg.max_width = max_width;
+  cfg.pose_rotation_mode = pose_rotation_mode; rotation_mode_ = pose_rotation_mode != 0 ? 1 : 0;
   check(liodom_create(&cp, &cfg, &h_), "liodom_create");
   edge_cap_ = p.scan_lines_ * p.scan_regions_ * (p.edges_per_region_ + 1) + 64;
 }
@@ -215,7 +216,7 @@ OdometryMsg LaserOdometer::publishOdom(double stamp, const Pose& pose) {
   // first twist is 0 / 0 = NaN exactly as the reference publishes it
   if (!published_) { prev_stamp_ = stamp; published_ = true; }
   double out[13];
-  liodom_dev::odom_message(prev_odom_.data(), cur.data(), laser_to_base_.data(), stamp - prev_stamp_, out);
+  liodom_dev::odom_message(prev_odom_.data(), cur.data(), laser_to_base_.data(), stamp - prev_stamp_, eng_->rotation_mode(), out);
   std::memcpy(msg.orientation, out, sizeof(double) * 4);
   std::memcpy(msg.position, out + 4, sizeof(double) * 3);
   std::memcpy(msg.linear, out + 7, sizeof(double) * 3);

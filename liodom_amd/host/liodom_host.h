@@ -88,13 +88,16 @@ class Stats {
 // Owns the GPU handle shared by the extractor and the odometer of one stream.
 class Engine {
  public:
-  Engine(const Params& p, int device, int max_points, int max_width);
+  // pose_rotation_mode: see liodom_config_t (1 = Eigen 3.3.x Transform::rotation(), the default)
+  Engine(const Params& p, int device, int max_points, int max_width, int pose_rotation_mode = 1);
   ~Engine();
   liodom_handle_t* handle() const { return h_; }
   int edge_capacity() const { return edge_cap_; }
+  int rotation_mode() const { return rotation_mode_; }
  private:
   liodom_handle_t* h_ = nullptr;
   int edge_cap_ = 0;
+  int rotation_mode_ = 1;
 };
 
 class FeatureExtractor {

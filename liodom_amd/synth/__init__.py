@@ -45,7 +45,7 @@ def lib():
 
 
 def make_cfg(height, width, lidar_type=0, world_seed=7, noise_sigma=0.01, max_cast_range=120.0,
-             yaw_rate_deg=0.3, speed=0.1):
+             yaw_rate_deg=0.5, speed=0.1):
     c = SynthCfg()
     c.height, c.width, c.lidar_type, c.world_seed = height, width, lidar_type, world_seed
     c.noise_sigma, c.max_cast_range = noise_sigma, max_cast_range

@@ -16,10 +16,10 @@
 // -8.78 - k/2 deg; VLP-16 -15 + 2k deg; HDL-32 (-92/3 + 4k/3 + 0.6) deg; 128 rows are
 // row-indexed (lidar_type 1) and span +22.5 .. -22.5 deg.
 //
-// Yaw rate: SURVEY.md §8(d) proposed 0.5 deg/scan; the default here is 0.3 deg/scan so that a
-// 220-scan stream stays below 90 deg of accumulated rotation — beyond that the reference's own
-// pose recursion (un-normalised quaternion <-> matrix round trips, laser_odometry.cc:148-150,
-// 186,225-226) is numerically unstable and no two implementations agree.
+// Yaw rate: 0.5 deg/scan, SURVEY.md §8(d) (110 deg over a 220-scan stream).  With Eigen 3.3's
+// Transform::rotation() (polar factor, the default pose_rotation_mode) the reference's pose recursion
+// is stable through any accumulated rotation; with the Eigen >= 3.4 alias semantics it loses track
+// beyond ~90 deg (tests/test_oracle_odometry.py::test_rotation_mode_soak).
 //
 // Determinism: every random number is a pure function of (seed, counter); the output does not
 // depend on the number of OpenMP threads.
@@ -169,7 +169,7 @@ struct synth_cfg_t {
   uint32_t world_seed;   // static world layout
   double noise_sigma;    // range noise (m), along the ray
   double max_cast_range; // rays longer than this return NaN
-  double yaw_rate_deg;   // yaw per scan (deg); default 0.3 (see header)
+  double yaw_rate_deg;   // yaw per scan (deg); default 0.5 (see header)
   double speed;          // forward motion per scan (m); SURVEY.md §8(d): 0.1
 };
 

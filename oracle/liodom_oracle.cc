@@ -48,6 +48,12 @@ struct orc_params_t {
   // function-tolerance stop the candidate step is NOT applied (Ceres >= 1.12 behaviour).
   int32_t lm_apply_step_on_ftol;
   int32_t knn_mode;            // 0 brute force (checker), 1 kd-tree (baseline timing)
+  // Eigen::Transform::rotation() at src/laser_odometry.cc:164,186,403,420.  1 = Eigen 3.3.x (the
+  // README's platform, Ubuntu 20.04 = Eigen 3.3.7): computeRotationScaling(), i.e. the orthonormal
+  // polar factor U V^T of linear() from a JacobiSVD, for every Mode.  0 = Eigen >= 3.4, where
+  // rotation() of an Isometry is an alias of linear().  No Eigen source in this image: declared.
+  int32_t pose_rotation_mode;
+  int32_t pad_;
 };
 
 }  // extern "C"
@@ -153,16 +159,17 @@ void extract_from_region(const orc_params_t& p, const std::vector<P4>& ring_pts,
       picked_edges++;                                                                  // :276
       picked[point_index] = 1;                                                         // :277
       for (int l = 1; l <= 5; l++) {                                                   // :280
-        double dx = (double)ring_pts[point_index + l].x - (double)ring_pts[point_index + l - 1].x;
-        double dy = (double)ring_pts[point_index + l].y - (double)ring_pts[point_index + l - 1].y;
-        double dz = (double)ring_pts[point_index + l].z - (double)ring_pts[point_index + l - 1].z;
+        // float - float is a float subtraction; the result is then widened (:281-286)
+        double dx = ring_pts[point_index + l].x - ring_pts[point_index + l - 1].x;
+        double dy = ring_pts[point_index + l].y - ring_pts[point_index + l - 1].y;
+        double dz = ring_pts[point_index + l].z - ring_pts[point_index + l - 1].z;
         if (dx * dx + dy * dy + dz * dz > 0.05) break;                                 // :289-291
         picked[point_index + l] = 1;                                                   // :293
       }
       for (int l = -1; l >= -5; l--) {                                                 // :296
-        double dx = (double)ring_pts[point_index + l].x - (double)ring_pts[point_index + l + 1].x;
-        double dy = (double)ring_pts[point_index + l].y - (double)ring_pts[point_index + l + 1].y;
-        double dz = (double)ring_pts[point_index + l].z - (double)ring_pts[point_index + l + 1].z;
+        double dx = ring_pts[point_index + l].x - ring_pts[point_index + l + 1].x;     // :297-302, float subtraction
+        double dy = ring_pts[point_index + l].y - ring_pts[point_index + l + 1].y;
+        double dz = ring_pts[point_index + l].z - ring_pts[point_index + l + 1].z;
         if (dx * dx + dy * dy + dz * dz > 0.05) break;                                 // :305-307
         picked[point_index + l] = 1;                                                   // :309
       }
@@ -188,18 +195,18 @@ void extract_features(const orc_params_t& p, const P4* pc,
     std::vector<uint8_t> picked(n, 0);  // picked_ is reset only for j in [5, n-5) (:230);
                                         // entries outside are written but never read.
     for (int64_t j = 5; j < n - 5; j++) {                                              // :195
-      double diff_x = (double)pts[j - 5].x + (double)pts[j - 4].x + (double)pts[j - 3].x +
-                      (double)pts[j - 2].x + (double)pts[j - 1].x - 10 * (double)pts[j].x +
-                      (double)pts[j + 1].x + (double)pts[j + 2].x + (double)pts[j + 3].x +
-                      (double)pts[j + 4].x + (double)pts[j + 5].x;                     // :196-206
-      double diff_y = (double)pts[j - 5].y + (double)pts[j - 4].y + (double)pts[j - 3].y +
-                      (double)pts[j - 2].y + (double)pts[j - 1].y - 10 * (double)pts[j].y +
-                      (double)pts[j + 1].y + (double)pts[j + 2].y + (double)pts[j + 3].y +
-                      (double)pts[j + 4].y + (double)pts[j + 5].y;                     // :207-217
-      double diff_z = (double)pts[j - 5].z + (double)pts[j - 4].z + (double)pts[j - 3].z +
-                      (double)pts[j - 2].z + (double)pts[j - 1].z - 10 * (double)pts[j].z +
-                      (double)pts[j + 1].z + (double)pts[j + 2].z + (double)pts[j + 3].z +
-                      (double)pts[j + 4].z + (double)pts[j + 5].z;                     // :218-228
+      // The operands are pcl::PointXYZI floats and `10 * x` is int * float, so each sum is a
+      // FLOAT expression evaluated left to right (x86-64 SSE, FLT_EVAL_METHOD 0) and only the
+      // result is widened by the `double diff_x =` initialisation (:196-228).
+      double diff_x = pts[j - 5].x + pts[j - 4].x + pts[j - 3].x + pts[j - 2].x + pts[j - 1].x -
+                      10 * pts[j].x + pts[j + 1].x + pts[j + 2].x + pts[j + 3].x + pts[j + 4].x +
+                      pts[j + 5].x;                                                    // :196-206
+      double diff_y = pts[j - 5].y + pts[j - 4].y + pts[j - 3].y + pts[j - 2].y + pts[j - 1].y -
+                      10 * pts[j].y + pts[j + 1].y + pts[j + 2].y + pts[j + 3].y + pts[j + 4].y +
+                      pts[j + 5].y;                                                    // :207-217
+      double diff_z = pts[j - 5].z + pts[j - 4].z + pts[j - 3].z + pts[j - 2].z + pts[j - 1].z -
+                      10 * pts[j].z + pts[j + 1].z + pts[j + 2].z + pts[j + 3].z + pts[j + 4].z +
+                      pts[j + 5].z;                                                    // :218-228
       smooths_aux[j].point_index = (int)j;
       smooths_aux[j].smoothness = diff_x * diff_x + diff_y * diff_y + diff_z * diff_z; // :229
       picked[j] = 0;                                                                   // :230
@@ -284,6 +291,62 @@ inline Iso iso_from_qt(const double q[4], const double t[3]) {
   return T;
 }
 
+// Eigen 3.3 Transform::rotation() -> computeRotationScaling(&R, 0) (Eigen/src/Geometry/Transform.h):
+//   JacobiSVD svd(linear(), ComputeFullU | ComputeFullV);
+//   x = (U * V^T).determinant();  m = U;  m.col(0) /= x;  R = m * V^T
+// i.e. the orthonormal polar factor of linear(), made a proper rotation.  Restated with a one-sided
+// (Hestenes) Jacobi SVD — only + - * / sqrt; Eigen's two-sided sweep order differs, but the polar
+// factor of a nonsingular matrix is unique, so the results agree to rounding (~1e-16).
+inline void svd3(const double A[9], double U[9], double S[3], double V[9]) {
+  double W[9];
+  for (int i = 0; i < 9; i++) { W[i] = A[i]; V[i] = (i % 4 == 0) ? 1.0 : 0.0; }
+  for (int sweep = 0; sweep < 30; sweep++) {
+    bool rotated = false;
+    for (int p = 0; p < 2; p++) {
+      for (int q = p + 1; q < 3; q++) {
+        double alpha = 0, beta = 0, gamma = 0;
+        for (int i = 0; i < 3; i++) { alpha += W[i * 3 + p] * W[i * 3 + p]; beta += W[i * 3 + q] * W[i * 3 + q]; gamma += W[i * 3 + p] * W[i * 3 + q]; }
+        if (std::fabs(gamma) <= 1e-17 * std::sqrt(alpha * beta) || gamma == 0.0) continue;
+        rotated = true;
+        const double zeta = (beta - alpha) / (2.0 * gamma);
+        double t = 1.0 / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+        if (zeta < 0.0) t = -t;
+        const double c = 1.0 / std::sqrt(1.0 + t * t), sn = c * t;
+        for (int i = 0; i < 3; i++) {
+          const double wp = W[i * 3 + p], wq = W[i * 3 + q];
+          W[i * 3 + p] = c * wp - sn * wq; W[i * 3 + q] = sn * wp + c * wq;
+          const double vp = V[i * 3 + p], vq = V[i * 3 + q];
+          V[i * 3 + p] = c * vp - sn * vq; V[i * 3 + q] = sn * vp + c * vq;
+        }
+      }
+    }
+    if (!rotated) break;
+  }
+  for (int j = 0; j < 3; j++) {
+    double n = 0;
+    for (int i = 0; i < 3; i++) n += W[i * 3 + j] * W[i * 3 + j];
+    n = std::sqrt(n);
+    S[j] = n;
+    for (int i = 0; i < 3; i++) U[i * 3 + j] = W[i * 3 + j] / n;
+  }
+}
+inline double det3(const double M[9]) {
+  return M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) + M[2] * (M[3] * M[7] - M[4] * M[6]);
+}
+// T with its linear part replaced by what Transform::rotation() returns (mode 1), or T itself (mode 0).
+inline Iso rotation_of(const Iso& T, int mode) {
+  if (mode == 0) return T;
+  double A[9], U[9], S[3], V[9], UVt[9];
+  for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) A[r * 3 + c] = R_(T, r, c);
+  svd3(A, U, S, V);
+  for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) UVt[r * 3 + c] = U[r * 3 + 0] * V[c * 3 + 0] + U[r * 3 + 1] * V[c * 3 + 1] + U[r * 3 + 2] * V[c * 3 + 2];
+  const double x = det3(UVt);                      // +-1
+  for (int r = 0; r < 3; r++) U[r * 3 + 0] /= x;   // m.col(0) /= x
+  Iso R = T;
+  for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) R.m[r * 4 + c] = U[r * 3 + 0] * V[c * 3 + 0] + U[r * 3 + 1] * V[c * 3 + 1] + U[r * 3 + 2] * V[c * 3 + 2];
+  return R;
+}
+
 // ------------------------------------------------------------------------------------------
 // IMU roll / pitch override of the predicted pose        src/laser_odometry.cc:152-183
 // The reference goes through ROS tf's LinearMath (tf::Quaternion, tf::Matrix3x3: getRPY, setRPY,
@@ -356,12 +419,12 @@ inline void tf_quat_from_matrix(const Mat3& m, double q[4]) {
   }
 }
 // src/laser_odometry.cc:152-183, steps 1-5 as numbered there
-inline Iso imu_override(const Iso& odom, const double imu_q[4], const Iso& laser_to_base) {
+inline Iso imu_override(const Iso& odom, const double imu_q[4], const Iso& laser_to_base, int rotation_mode) {
   double imu_roll, imu_pitch, imu_yaw;
   tf_get_rpy(tf_matrix_from_quat(imu_q), &imu_roll, &imu_pitch, &imu_yaw);            // :155-161
   Iso odom_bl = iso_mul(odom, laser_to_base);                                         // :164
   double q_bl[4];
-  quat_from_rot(odom_bl, q_bl);                                                       // :165
+  quat_from_rot(rotation_of(odom_bl, rotation_mode), q_bl);                           // :165 Quaterniond(odom_bl.rotation())
   double bl_roll, bl_pitch, bl_yaw;
   tf_get_rpy(tf_matrix_from_quat(q_bl), &bl_roll, &bl_pitch, &bl_yaw);                // :166-169
   const Mat3 m = tf_set_rpy(imu_roll, imu_pitch, bl_yaw);                             // :174
@@ -671,7 +734,11 @@ inline bool eval_block(const Corr& c, const double q[4], const double t[3], doub
 
 // Householder QR least squares: minimise ||A y - b|| for A (m x 6, row-major), m >= 6.
 // Stands in for Ceres' DENSE_QR (src/laser_odometry.cc:213) on the stacked system [J; D].
+// Fault injection (tests only): the next g_fail_linear_solves calls report LINEAR_SOLVER_FAILURE, which
+// TrustRegionMinimizer treats as an invalid step.
+static int g_fail_linear_solves = 0;
 bool qr_solve6(std::vector<double>& A, std::vector<double>& b, int m, double y[6]) {
+  if (g_fail_linear_solves > 0) { g_fail_linear_solves--; return false; }
   const int n = 6;
   for (int k = 0; k < n; k++) {
     double norm = 0;
@@ -807,8 +874,11 @@ void lm_solve(const std::vector<Corr>& blocks, double q[4], double t[3], double 
       model_cost_change = -acc;
     }
     if (!ok || !(model_cost_change > 0.0)) {
+      // TrustRegionMinimizer::HandleInvalidStep: max_num_consecutive_invalid_steps = 5, then
+      // LevenbergMarquardtStrategy::StepIsInvalid(): radius *= 0.5, reuse_diagonal = true
+      // (decrease_factor is only touched by StepRejected / StepAccepted)
       if (++invalid_run >= 5) { T.termination = 7; break; }
-      radius = radius / decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true;
+      radius = radius * 0.5; reuse_diagonal = true;
       continue;
     }
     invalid_run = 0;
@@ -1103,9 +1173,9 @@ struct Odometer {
       Iso pred = iso_mul(odom, iso_mul(iso_inverse(prev_odom), odom));
       prev_odom = odom;
       odom = pred;
-      if (use_imu) odom = imu_override(odom, imu_q, laser_to_base);                      // :152-183
+      if (use_imu) odom = imu_override(odom, imu_q, laser_to_base, prm.pose_rotation_mode);   // :152-183
       // initial guess (:186-195)
-      quat_from_rot(odom, param_q);
+      quat_from_rot(rotation_of(odom, prm.pose_rotation_mode), param_q);               // :186 q_curr(odom_.rotation())
       param_t[0] = odom.m[3]; param_t[1] = odom.m[7]; param_t[2] = odom.m[11];
       for (int optim_it = 0; optim_it < 2; optim_it++) {                               // :198
         std::vector<Corr> blocks;
@@ -1122,9 +1192,10 @@ struct Odometer {
       mapper.updateMap(feats, odom);                          // liodom_mapping_node.cc:69
       mapper.getLocalMap(odom, cells_xy, cells_z, received_map);   // :82 -> mapClb (liodom_node.cc:57-64)
     }
-    // pose as published: quaternion of odom_ (publishOdom :403 with identity laser_to_base)
+    // pose as published: Quaterniond((odom_ * laser_to_base_).rotation()) (publishOdom :402-403);
+    // laser_to_base_ is left out here as in the C-ABI (poses are returned in the laser frame)
     double q[4];
-    quat_from_rot(odom, q);
+    quat_from_rot(rotation_of(odom, prm.pose_rotation_mode), q);
     pose_out[0] = q[0]; pose_out[1] = q[1]; pose_out[2] = q[2]; pose_out[3] = q[3];
     pose_out[4] = odom.m[3]; pose_out[5] = odom.m[7]; pose_out[6] = odom.m[11];
   }
@@ -1247,24 +1318,24 @@ void orc_odom_set_laser_to_base(void* h, const double* T12) {
   for (int k = 0; k < 12; k++) o->laser_to_base.m[k] = T12[k];
 }
 // the override alone (unit tests): T12 in, T12 out
-void orc_imu_override(const double* T12, const double* imu_q, const double* l2b12, double* out12) {
+void orc_imu_override(const double* T12, const double* imu_q, const double* l2b12, double* out12, int rotation_mode) {
   Iso T, L;
   for (int k = 0; k < 12; k++) { T.m[k] = T12[k]; L.m[k] = l2b12[k]; }
-  const Iso R = imu_override(T, imu_q, L);
+  const Iso R = imu_override(T, imu_q, L, rotation_mode);
   for (int k = 0; k < 12; k++) out12[k] = R.m[k];
 }
 // LaserOdometer::publishOdom (src/laser_odometry.cc:395-436): the nav_msgs/Odometry numbers.
 // out[0..3] orientation x y z w, out[4..6] position, out[7..9] twist.linear, out[10..12] twist.angular
-void orc_publish_odom(const double* prev12, const double* cur12, const double* l2b12, double delta_time, double* out) {
+void orc_publish_odom(const double* prev12, const double* cur12, const double* l2b12, double delta_time, double* out, int rotation_mode) {
   Iso P, T, L;
   for (int k = 0; k < 12; k++) { P.m[k] = prev12[k]; T.m[k] = cur12[k]; L.m[k] = l2b12[k]; }
   const Iso odom_base_link = iso_mul(T, L);                                   // :403
-  quat_from_rot(odom_base_link, out);                                         // :404
+  quat_from_rot(rotation_of(odom_base_link, rotation_mode), out);             // :403 q_current(odom_base_link.rotation())
   out[4] = odom_base_link.m[3]; out[5] = odom_base_link.m[7]; out[6] = odom_base_link.m[11];   // :405
   const Iso delta_odom = iso_mul(iso_inverse(iso_mul(P, L)), odom_base_link); // :416
   out[7] = delta_odom.m[3] / delta_time; out[8] = delta_odom.m[7] / delta_time; out[9] = delta_odom.m[11] / delta_time;  // :417-420
   double qd[4], roll, pitch, yaw;
-  quat_from_rot(delta_odom, qd);                                              // :421
+  quat_from_rot(rotation_of(delta_odom, rotation_mode), qd);                  // :420 q_delta(delta_odom.rotation())
   tf_get_rpy(tf_matrix_from_quat(qd), &roll, &pitch, &yaw);                   // :423-426
   out[10] = roll / delta_time; out[11] = pitch / delta_time; out[12] = yaw / delta_time;       // :427-429
 }
@@ -1388,6 +1459,13 @@ void orc_transform(const double* T12, const float* in, int64_t n, float* out) {
   const P4* pi = reinterpret_cast<const P4*>(in);
   P4* po = reinterpret_cast<P4*>(out);
   for (int64_t i = 0; i < n; i++) po[i] = transform_point(T, pi[i]);
+}
+void orc_debug_fail_linear_solves(int n) { g_fail_linear_solves = n; }
+// Transform::rotation() alone (unit tests): T12 in -> T12 out
+void orc_rotation_of(const double* T12, int mode, double* out12) {
+  Iso T; for (int k = 0; k < 12; k++) T.m[k] = T12[k];
+  const Iso R = rotation_of(T, mode);
+  for (int k = 0; k < 12; k++) out12[k] = R.m[k];
 }
 void orc_pose_ops(const double* q_in, const double* t_in, double* T12, double* q_back) {
   Iso T = iso_from_qt(q_in, t_in);

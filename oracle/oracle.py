@@ -28,6 +28,8 @@ class OrcParams(C.Structure):
         ("mapping", C.c_int32),
         ("lm_apply_step_on_ftol", C.c_int32),
         ("knn_mode", C.c_int32),
+        ("pose_rotation_mode", C.c_int32),
+        ("pad_", C.c_int32),
     ]
 
 
@@ -72,8 +74,9 @@ def lib():
         L.orc_odom_destroy.argtypes = [C.c_void_p]
         L.orc_odom_set_imu.argtypes = [C.c_void_p, C.c_int, dp]
         L.orc_odom_set_laser_to_base.argtypes = [C.c_void_p, dp]
-        L.orc_imu_override.argtypes = [dp, dp, dp, dp]
-        L.orc_publish_odom.argtypes = [dp, dp, dp, C.c_double, dp]
+        L.orc_imu_override.argtypes = [dp, dp, dp, dp, C.c_int]
+        L.orc_publish_odom.argtypes = [dp, dp, dp, C.c_double, dp, C.c_int]
+        L.orc_rotation_of.argtypes = [dp, C.c_int, dp]
         L.orc_odom_step.restype = C.c_int
         L.orc_odom_step.argtypes = [C.c_void_p, fp, C.c_int, dp, C.POINTER(StepInfo)]
         L.orc_odom_last_corr.restype = C.c_int
@@ -131,8 +134,10 @@ def _ip(a):
 
 def make_params(min_range=3.0, max_range=75.0, lidar_type=0, scan_lines=64, scan_regions=8,
                 edges_per_region=10, prev_frames=5, filter_local_map=False, mapping=False,
-                lm_apply_step_on_ftol=0, knn_mode=0):
-    """Defaults follow src/params.cc:40-109."""
+                lm_apply_step_on_ftol=0, knn_mode=0, pose_rotation_mode=1):
+    """Defaults follow src/params.cc:40-109.  pose_rotation_mode: what Eigen's Transform::rotation()
+    returns (laser_odometry.cc:164,186,403,420): 1 = Eigen 3.3.x polar factor (default: the README's
+    platform ships Eigen 3.3.7), 0 = Eigen >= 3.4 alias of linear()."""
     p = OrcParams()
     p.min_range, p.max_range = min_range, max_range
     p.lidar_type, p.scan_lines = lidar_type, scan_lines
@@ -142,6 +147,7 @@ def make_params(min_range=3.0, max_range=75.0, lidar_type=0, scan_lines=64, scan
     # mapping: True / 1 = with the synchronous replay of the mapping node, 2 = ~map only via set_received_map
     p.filter_local_map, p.mapping = int(filter_local_map), int(mapping)
     p.lm_apply_step_on_ftol, p.knn_mode = lm_apply_step_on_ftol, knn_mode
+    p.pose_rotation_mode = int(pose_rotation_mode)
     return p
 
 
@@ -276,24 +282,32 @@ class Map:
         return lib().orc_map_num_cells(self.h)
 
 
-def imu_override(T34, imu_q, l2b34=None):
+def imu_override(T34, imu_q, l2b34=None, rotation_mode=1):
     """laser_odometry.cc:152-183 on one pose."""
     T = np.ascontiguousarray(T34, dtype=np.float64).reshape(12)
     q = np.ascontiguousarray(imu_q, dtype=np.float64)
     L = np.ascontiguousarray(np.eye(4)[:3] if l2b34 is None else l2b34, dtype=np.float64).reshape(12)
     out = np.zeros(12)
-    lib().orc_imu_override(_dp(T), _dp(q), _dp(L), _dp(out))
+    lib().orc_imu_override(_dp(T), _dp(q), _dp(L), _dp(out), int(rotation_mode))
     return out.reshape(3, 4)
 
 
-def publish_odom(prev34, cur34, dt, l2b34=None):
+def publish_odom(prev34, cur34, dt, l2b34=None, rotation_mode=1):
     """publishOdom (laser_odometry.cc:395-436): orientation[4], position[3], linear[3], angular[3]."""
     P = np.ascontiguousarray(prev34, dtype=np.float64).reshape(12)
     T = np.ascontiguousarray(cur34, dtype=np.float64).reshape(12)
     L = np.ascontiguousarray(np.eye(4)[:3] if l2b34 is None else l2b34, dtype=np.float64).reshape(12)
     out = np.zeros(13)
-    lib().orc_publish_odom(_dp(P), _dp(T), _dp(L), float(dt), _dp(out))
+    lib().orc_publish_odom(_dp(P), _dp(T), _dp(L), float(dt), _dp(out), int(rotation_mode))
     return out
+
+
+def rotation_of(T34, mode=1):
+    """Eigen::Transform::rotation() of a 3 x 4 pose (mode 1: Eigen 3.3 polar factor, 0: linear())."""
+    T = np.ascontiguousarray(T34, dtype=np.float64).reshape(12)
+    out = np.zeros(12)
+    lib().orc_rotation_of(_dp(T), int(mode), _dp(out))
+    return out.reshape(3, 4)
 
 
 def knn5(map_xyzi, q_xyzi, mode=0):

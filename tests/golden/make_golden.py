@@ -7,7 +7,8 @@ tests a committed answer that does not depend on the oracle being rebuilt identi
 
 Inputs are regenerated from the seeds (liodom_amd/synth); only outputs are stored: per scan the edge
 (ring, index-in-ring) lists, the pose [qx qy qz qw tx ty tz], the match counts and the LM iteration
-counts; for the map: Map::getMap after the replayed updates (float32 bits)."""
+counts; for the map: Map::getMap after the replayed updates (float32 bits, or their SHA-256 for big maps)."""
+import hashlib
 import os
 import sys
 
@@ -19,11 +20,15 @@ from liodom_amd import synth          # noqa: E402
 from oracle import oracle as orc      # noqa: E402
 
 CASES = {
-    # name: (H, W, lidar_type, R, epr, P, stream, scans)
-    "stream_16x900": (16, 900, 0, 6, 10, 5, 0, 10),
-    "stream_64x1800": (64, 1800, 0, 8, 10, 20, 3, 4),
+    # name: (H, W, lidar_type, R, epr, P, stream, scans) — the four single-GPU BASELINE.json configs at
+    # full size, each with more than P + 5 scans so that the window fills and evicts
+    "stream_16x900": (16, 900, 0, 6, 10, 5, 0, 12),                # configs[0]
+    "stream_vlp16_16x1800": (16, 1800, 0, 8, 20, 10, 2, 16),      # configs[1]
+    "stream_64x1800": (64, 1800, 0, 8, 10, 20, 3, 26),            # configs[2] (headline)
+    "stream_ouster_128x2048": (128, 2048, 1, 8, 10, 30, 1, 36),   # configs[3]
     "stream_ouster_32x512": (32, 512, 1, 8, 10, 6, 1, 8),
 }
+MAP_BITS_MAX_POINTS = 20000      # larger maps are pinned by their SHA-256 only
 
 
 def generate(name):
@@ -53,7 +58,11 @@ def generate(name):
     out["poses"] = np.array(poses, dtype=np.float64)
     out["matches"] = np.array(matches, dtype=np.int32)
     out["lm_iterations"] = np.array(iters, dtype=np.int32)
-    out["map_all_bits"] = mp.all().view(np.uint32)
+    m = mp.all().view(np.uint32)
+    out["map_points"] = np.array([m.shape[0]], dtype=np.int64)
+    out["map_all_sha256"] = np.frombuffer(hashlib.sha256(np.ascontiguousarray(m).tobytes()).digest(), dtype=np.uint8)
+    if m.shape[0] <= MAP_BITS_MAX_POINTS:
+        out["map_all_bits"] = m
     return out
 
 
@@ -62,4 +71,4 @@ if __name__ == "__main__":
     for name in CASES:
         d = generate(name)
         np.savez_compressed(os.path.join(here, name + ".npz"), **d)
-        print(name, "edges/scan", d["n_edges"].tolist(), "map points", d["map_all_bits"].shape[0])
+        print(name, "edges/scan", d["n_edges"].tolist(), "map points", int(d["map_points"][0]))

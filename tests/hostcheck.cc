@@ -28,9 +28,10 @@ void hc_pose_ops(const double* q, const double* t, double* T12, double* qback) {
   iso_from_qt(q, t, T12);
   quat_from_rot(T12, qback);
 }
-void hc_imu_override(const double* T12, const double* imu_q, const double* l2b, double* out12) { imu_override(T12, imu_q, l2b, out12); }
-void hc_odom_message(const double* prev12, const double* cur12, const double* l2b, double dt, double* out13) {
-  odom_message(prev12, cur12, l2b, dt, out13);
+void hc_imu_override(const double* T12, const double* imu_q, const double* l2b, double* out12, int rotation_mode) { imu_override(T12, imu_q, l2b, rotation_mode, out12); }
+void hc_rotation_of(const double* T12, int mode, double* out12) { rotation_of(T12, mode, out12); }
+void hc_odom_message(const double* prev12, const double* cur12, const double* l2b, double dt, double* out13, int rotation_mode) {
+  odom_message(prev12, cur12, l2b, dt, rotation_mode, out13);
 }
 void hc_predict(const double* odom, const double* prev, double* pred) {
   double inv[12], rel[12];
@@ -60,6 +61,24 @@ int hc_lm_solve(const double* blocks9, int n, double* q, double* t, double min_d
   for (int k = 0; k < 4; k++) q[k] = st.q[k];
   for (int k = 0; k < 3; k++) t[k] = st.t[k];
   *iterations = st.iter; *accepted = st.accepted; *initial_cost = st.initial_cost; *final_cost = st.cost;
+  return st.termination;
+}
+// The controller alone on a caller-supplied accumulator (same one for every evaluation): lets a test
+// force TrustRegionMinimizer's invalid-step path (non-finite / non-positive-definite normal
+// equations) and read the radius sequence.  radius_out[k] = radius after the k-th lm_* call.
+int hc_lm_controller(const double* acc29, int n_blocks, const double* q, const double* t, double* radius_out, int cap,
+                     int* iterations, int* n_calls) {
+  LmState st;
+  int k = 0;
+  int flag = lm_begin(st, q, t, acc29, n_blocks, 0);
+  if (k < cap) radius_out[k] = st.radius;
+  k++;
+  while (flag == LM_NEED_EVAL && k < 16) {
+    flag = lm_update(st, acc29);
+    if (k < cap) radius_out[k] = st.radius;
+    k++;
+  }
+  *iterations = st.iter; *n_calls = k;
   return st.termination;
 }
 float hc_sqdist(const float* a, const float* b) { return sqdist_f(a[0], a[1], a[2], b[0], b[1], b[2]); }

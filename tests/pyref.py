@@ -72,25 +72,29 @@ def extract(xyzi, height, width, lidar_type=0, scan_lines=64, scan_regions=8, ed
         n = len(src)
         if n < min_points:                                     # feature_extractor.cc:188
             continue
-        P = xyzi[src, :3].astype(np.float64)                   # float -> double promotion
+        # The operands are pcl::PointXYZI floats and `10 * x` is int * float: the eleven-term sum
+        # is evaluated in float32, left to right, and only then widened to double (:196-228).
+        P = xyzi[src, :3].astype(np.float32)
+        ten = np.float32(10)
         smooth = {}
         picked = [False] * n
         for j in range(5, n - 5):                              # :195-232, left-to-right sums
             d = [0.0, 0.0, 0.0]
             for ax in range(3):
-                s = P[j - 5, ax]
+                s = P[j - 5, ax]                               # np.float32 scalars: every op rounds to float32
                 s = s + P[j - 4, ax]
                 s = s + P[j - 3, ax]
                 s = s + P[j - 2, ax]
                 s = s + P[j - 1, ax]
-                s = s - 10 * P[j, ax]
+                s = s - ten * P[j, ax]
                 s = s + P[j + 1, ax]
                 s = s + P[j + 2, ax]
                 s = s + P[j + 3, ax]
                 s = s + P[j + 4, ax]
                 s = s + P[j + 5, ax]
-                d[ax] = s
-            smooth[j] = float(d[0] * d[0] + d[1] * d[1] + d[2] * d[2])
+                assert s.dtype == np.float32
+                d[ax] = float(s)                               # double diff_x = <float expression>
+            smooth[j] = float(d[0] * d[0] + d[1] * d[1] + d[2] * d[2])   # :229 in double
         total = n - 10
         sector = total // scan_regions
         for reg in range(scan_regions):                        # :240-252
@@ -109,12 +113,12 @@ def extract(xyzi, height, width, lidar_type=0, scan_lines=64, scan_regions=8, ed
                 npick += 1
                 picked[pi] = True
                 for l in range(1, 6):
-                    dd = P[pi + l] - P[pi + l - 1]
+                    dd = (P[pi + l] - P[pi + l - 1]).astype(np.float64)   # float32 difference, then double (:281-286)
                     if dd[0] * dd[0] + dd[1] * dd[1] + dd[2] * dd[2] > 0.05:
                         break
                     picked[pi + l] = True
                 for l in range(-1, -6, -1):
-                    dd = P[pi + l] - P[pi + l + 1]
+                    dd = (P[pi + l] - P[pi + l + 1]).astype(np.float64)   # :297-302
                     if dd[0] * dd[0] + dd[1] * dd[1] + dd[2] * dd[2] > 0.05:
                         break
                     picked[pi + l] = True

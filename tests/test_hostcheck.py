@@ -33,8 +33,11 @@ def hc():
     L.hc_transform.argtypes = [dp, fp, C.c_int, fp]
     L.hc_pose_ops.argtypes = [dp, dp, dp, dp]
     L.hc_predict.argtypes = [dp, dp, dp]
-    L.hc_imu_override.argtypes = [dp, dp, dp, dp]
-    L.hc_odom_message.argtypes = [dp, dp, dp, C.c_double, dp]
+    L.hc_imu_override.argtypes = [dp, dp, dp, dp, C.c_int]
+    L.hc_odom_message.argtypes = [dp, dp, dp, C.c_double, dp, C.c_int]
+    L.hc_rotation_of.argtypes = [dp, C.c_int, dp]
+    L.hc_lm_controller.restype = C.c_int
+    L.hc_lm_controller.argtypes = [dp, C.c_int, dp, dp, dp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.hc_accumulate.argtypes = [dp, C.c_int, dp, dp, C.c_double, C.c_double, dp]
     L.hc_lm_solve.restype = C.c_int
     L.hc_lm_solve.argtypes = [dp, C.c_int, dp, dp, C.c_double, C.c_double, C.c_int,
@@ -189,19 +192,84 @@ def test_imu_override_and_odom_message(hc, orc):
             return T
         T, L = rand_iso(3.0 if trial % 2 else 0.4, 40.0), rand_iso(0.3, 1.0)
         q = Rsc.from_euler("xyz", rng.uniform(-0.7, 0.7, 3)).as_quat()
+        mode = trial % 2          # both Transform::rotation() semantics
         got = np.zeros(12)
-        hc.hc_imu_override(_dp(T.reshape(12).copy()), _dp(q.copy()), _dp(L.reshape(12).copy()), _dp(got))
-        assert np.allclose(got.reshape(3, 4), orc.imu_override(T, q, L), atol=1e-13)
+        hc.hc_imu_override(_dp(T.reshape(12).copy()), _dp(q.copy()), _dp(L.reshape(12).copy()), _dp(got), mode)
+        assert np.allclose(got.reshape(3, 4), orc.imu_override(T, q, L, rotation_mode=mode), atol=1e-13)
         # publishOdom: previous pose -> current pose = previous * known motion
         step = rand_iso(0.05, 0.3)
         T4, S4 = np.vstack([T, [0, 0, 0, 1]]), np.vstack([step, [0, 0, 0, 1]])
         cur = (T4 @ S4)[:3]
         msg = np.zeros(13)
-        hc.hc_odom_message(_dp(T.reshape(12).copy()), _dp(cur.reshape(12).copy()), _dp(L.reshape(12).copy()), 0.1, _dp(msg))
-        assert np.allclose(msg, orc.publish_odom(T, cur, 0.1, L), atol=1e-12)
+        hc.hc_odom_message(_dp(T.reshape(12).copy()), _dp(cur.reshape(12).copy()), _dp(L.reshape(12).copy()), 0.1, _dp(msg), mode)
+        assert np.allclose(msg, orc.publish_odom(T, cur, 0.1, L, rotation_mode=mode), atol=1e-12)
     # identity mounting: twist = motion / dt, orientation = pose quaternion
     I = np.eye(4)[:3]
     step = np.zeros((3, 4)); step[:, :3] = Rsc.from_euler("xyz", [0.01, -0.02, 0.03]).as_matrix(); step[:, 3] = [0.1, 0.02, -0.01]
     msg = orc.publish_odom(I, step, 0.1)
     assert np.allclose(msg[7:10], step[:, 3] / 0.1) and np.allclose(msg[10:13], np.array([0.01, -0.02, 0.03]) / 0.1, atol=1e-12)
     assert np.allclose(msg[:4], Rsc.from_matrix(step[:, :3]).as_quat(), atol=1e-12)
+
+
+def test_rotation_of_is_the_polar_factor(hc, orc):
+    """Eigen 3.3 Transform::rotation() = U V^T of linear() (computeRotationScaling).  The oracle gets it
+    from a one-sided Jacobi SVD, the product from Newton's iteration; both against numpy's SVD, on
+    slightly non-orthonormal poses (what toRotationMatrix of a non-unit quaternion produces) and on
+    badly scaled ones.  Mode 0 (Eigen >= 3.4) returns linear() untouched."""
+    from scipy.spatial.transform import Rotation as Rsc
+    rng = np.random.default_rng(11)
+    for trial in range(200):
+        R = Rsc.from_euler("xyz", rng.uniform(-3, 3, 3)).as_matrix()
+        eps = [1e-15, 1e-9, 1e-4, 0.3][trial % 4]
+        A = R @ (np.eye(3) + eps * rng.standard_normal((3, 3)))
+        if trial % 16 == 15:
+            A *= rng.uniform(0.2, 5.0)
+        T = np.zeros((3, 4)); T[:, :3] = A; T[:, 3] = rng.uniform(-50, 50, 3)
+        U, _, Vt = np.linalg.svd(A)
+        want = U @ Vt
+        assert np.linalg.det(want) > 0
+        o = orc.rotation_of(T, 1)
+        g = np.zeros(12)
+        hc.hc_rotation_of(_dp(T.reshape(12).copy()), 1, _dp(g))
+        g = g.reshape(3, 4)
+        assert np.allclose(o[:, :3], want, atol=5e-15) and np.allclose(g[:, :3], want, atol=5e-15)
+        assert np.array_equal(o[:, 3], T[:, 3]) and np.array_equal(g[:, 3], T[:, 3])
+        assert np.allclose(g[:, :3].T @ g[:, :3], np.eye(3), atol=5e-15)
+        g0 = np.zeros(12)
+        hc.hc_rotation_of(_dp(T.reshape(12).copy()), 0, _dp(g0))
+        assert np.array_equal(g0.reshape(3, 4), T) and np.array_equal(orc.rotation_of(T, 0), T)
+
+
+def test_invalid_step_halves_the_radius(hc, orc):
+    """TrustRegionMinimizer::HandleInvalidStep -> LevenbergMarquardtStrategy::StepIsInvalid():
+    radius *= 0.5 (not StepRejected's radius /= decrease_factor; decrease_factor *= 2), every invalid
+    step counts as an iteration, 4 iterations (src/laser_odometry.cc:214) end the solve.  Forced with
+    normal equations whose Cholesky fails (a non-finite diagonal entry): model_cost_change <= 0."""
+    acc = np.zeros(29)
+    acc[0] = 1.0                        # cost
+    acc[1:7] = [1.0, -2.0, 0.5, 0.1, 0.2, -0.3]     # gradient (above the 1e-10 gradient tolerance)
+    diag = [7, 13, 18, 22, 25, 27]
+    for i, d in enumerate(diag):
+        acc[d] = 4.0 + i
+    acc[7 + 1] = np.inf                 # H01 = inf: pivot 1 of the Cholesky becomes -inf / NaN -> step invalid
+    radius = np.zeros(16)
+    it, calls = C.c_int(), C.c_int()
+    q, t = np.array([0, 0, 0, 1.0]), np.zeros(3)
+    term = hc.hc_lm_controller(_dp(acc), 3, _dp(q), _dp(t), _dp(radius), 16, C.byref(it), C.byref(calls))
+    # four invalid steps inside lm_begin's first proposal loop: 1e4 -> 5e3 -> 2.5e3 -> 1.25e3 -> 625, then max-iter
+    assert term == 0 and it.value == 4 and calls.value == 1
+    assert radius[0] == 1e4 * 0.5 ** 4
+    # the oracle's solver with its linear solver made to fail (fault injection): same radius sequence
+    from test_oracle_odometry import _make_problem as mk
+    blocks = mk(np.random.default_rng(3), 60)[0]
+    q0, t0 = np.array([0, 0, 0, 1.0]), np.zeros(3)
+    orc.lib().orc_debug_fail_linear_solves(4)
+    qo, to, tr = orc.lm_solve(blocks, q0, t0)
+    orc.lib().orc_debug_fail_linear_solves(0)
+    assert tr.termination == 0 and tr.iterations == 4 and tr.accepted == 0
+    assert [tr.radius[i] for i in range(1, 5)] == [1e4, 5e3, 2.5e3, 1.25e3]
+    assert np.array_equal(qo, q0) and np.array_equal(to, t0)
+    # one failure, then normal steps: the radius of the first real step is the halved one
+    orc.lib().orc_debug_fail_linear_solves(1)
+    qo, to, tr = orc.lm_solve(blocks, q0, t0)
+    assert tr.radius[1] == 1e4 and tr.radius[2] == 5e3 and tr.iterations >= 2

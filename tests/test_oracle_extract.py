@@ -174,20 +174,30 @@ def test_short_ring_skipped(orc):
 
 
 def test_curvature_values(orc):
-    # smoothness is the FP64 11-tap stencil, evaluated left to right (feature_extractor.cc:196-229)
+    # smoothness: the 11-tap stencil is a FLOAT expression (pcl::PointXYZI floats, `10 * x` is
+    # int * float) evaluated left to right and only then widened; squares and their sum are double
+    # (feature_extractor.cc:196-229).  A float64 evaluation of the same sum differs in the last bits.
     x = _jagged_ring(200, seed=3)
     p = orc.make_params(scan_lines=16, scan_regions=2, edges_per_region=2)
     e = orc.extract(p, x, 16, 0, want_curv=True)
-    P = x[:, :3].astype(np.float64)
-    j = 57
-    d = np.zeros(3)
-    for ax in range(3):
-        s = P[j - 5, ax]
-        for k in (-4, -3, -2, -1):
-            s = s + P[j + k, ax]
-        s = s - 10 * P[j, ax]
-        for k in (1, 2, 3, 4, 5):
-            s = s + P[j + k, ax]
-        d[ax] = s
-    assert e["curv"][j] == d[0] * d[0] + d[1] * d[1] + d[2] * d[2]
+    P = x[:, :3].astype(np.float32)
+    ten = np.float32(10)
+    n_diff64 = 0
+    for j in range(5, 195):
+        d = np.zeros(3)
+        d64 = np.zeros(3)
+        for ax in range(3):
+            s = P[j - 5, ax]
+            for k in (-4, -3, -2, -1):
+                s = s + P[j + k, ax]
+            s = s - ten * P[j, ax]
+            for k in (1, 2, 3, 4, 5):
+                s = s + P[j + k, ax]
+            assert s.dtype == np.float32
+            d[ax] = float(s)
+            Q = P.astype(np.float64)
+            d64[ax] = Q[j - 5:j, ax].sum() - 10 * Q[j, ax] + Q[j + 1:j + 6, ax].sum()
+        assert e["curv"][j] == d[0] * d[0] + d[1] * d[1] + d[2] * d[2]
+        n_diff64 += e["curv"][j] != d64[0] * d64[0] + d64[1] * d64[1] + d64[2] * d64[2]
+    assert n_diff64 > 0          # the distinction is observable on this ring
     assert np.isnan(e["curv"][:5]).all() and np.isnan(e["curv"][195:200]).all()

@@ -303,3 +303,31 @@ def test_odometer_with_imu_keeps_roll_and_pitch(orc, synth):
         pose, info = od.step(orc.extract(po, x, H, W)["edges"])
     assert info.matches[1] > 30
     assert np.linalg.norm(pose[4:] - (gt[4:] - gt0[4:])) < 0.2
+
+
+def test_rotation_mode_soak(orc, synth):
+    """Eigen::Transform::rotation() (laser_odometry.cc:186): with Eigen 3.3's polar factor
+    (pose_rotation_mode 1, the default) the pose recursion T <- T (T_prev^-1 T), quaternion <- matrix
+    <- quaternion stays normalised through any accumulated rotation; with the Eigen >= 3.4 alias of
+    linear() (mode 0) the quaternion norm error grows once the sensor has turned ~90 deg and tracking
+    is lost.  1 deg/scan, 16 x 900, 150 scans."""
+    H, W, R, epr, P = 16, 900, 6, 10, 5
+    cfg = synth.make_cfg(H, W, 0, yaw_rate_deg=1.0)
+    res = {}
+    for mode in (0, 1):
+        po = orc.make_params(scan_lines=H, scan_regions=R, edges_per_region=epr, prev_frames=P, knn_mode=1,
+                             pose_rotation_mode=mode)
+        od = orc.Odometer(po)
+        errs, qn = [], []
+        for k in range(150):
+            x, gt = synth.scan(cfg, 0, k)
+            pose, _ = od.step(orc.extract(po, x, H, W)["edges"])
+            errs.append(np.linalg.norm(pose[4:] - gt[4:]))
+            qn.append(abs(np.linalg.norm(pose[:4]) - 1.0))
+        od.close()
+        res[mode] = (np.array(errs), np.array(qn))
+    # both modes agree while the accumulated rotation is small ...
+    assert np.allclose(res[0][0][:60], res[1][0][:60], atol=1e-6)
+    # ... the polar mode keeps a unit quaternion and keeps tracking; the alias mode does neither
+    assert res[1][1].max() < 1e-14 and res[1][0].max() < 1.0
+    assert res[0][1][100:].max() > 1e-8 and res[0][0][-1] > 10.0
