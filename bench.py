@@ -1,19 +1,22 @@
 #!/usr/bin/env python3
 """bench.py — LiODOM hot path on MI355X: scans/sec on the BASELINE.json headline workload.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload hdl64|vlp16|ouster128]
 
-A "step" is one pass of the hot path over one batch of synthetic input: one 64x1800 scan of one
-HDL-64-shape stream per GPU (edge extraction -> 2 x [correspondences + pose solve] -> window
-update), with the pose read back every scan as the ROS node publishes it.  All scans are resident
-in HBM before the timed region.  The path does not shard (each scan depends on the previous pose
-and window), so N > 1 GPUs run N independent replayed streams ("replicas only", no collective on
-the data path); torch.distributed (gloo) is used only for the barrier / max-over-ranks timing.
+A "step" is one pass of the hot path over one batch of synthetic input: one scan of one stream per
+GPU (edge extraction -> 2 x [correspondences + pose solve] -> window update), with the pose read back
+every scan as the ROS node publishes it.  All scans are resident in HBM before the timed region, and
+the sliding window is pre-filled to prev_frames frames (untimed, before the W warm-up steps), so every
+timed step runs in the steady state whatever K and W are.  The path does not shard (each scan depends
+on the previous pose and window), so N > 1 GPUs run N independent replayed streams ("replicas only",
+no collective on the data path); torch.distributed (gloo) is used only for the barrier / max-over-ranks
+timing and for collecting each replica's parity.
 
 Output: ONE JSON line on rank 0 with metric/value/... plus
   roofline      dominant kernel of the timed workload: algorithmic bytes / HIP-event duration
-  cpu_baseline  the CPU oracle ("port", 1 thread) on the same scans, timed on this host
-  parity        GPU-vs-oracle pose difference over the same stream (not timed)
+  cpu_baseline  the CPU oracle ("port") on a bounded sample of the same scans, timed on this host:
+                1 thread, and the reference's own thread policy
+  parity        GPU-vs-oracle pose difference, per replica (worst over ranks)
   batched       lock-step multi-stream run on one GPU (throughput mode) with its own roofline
 """
 import argparse
@@ -22,7 +25,8 @@ import os
 import sys
 import time
 
-os.environ.setdefault("OMP_WAIT_POLICY", "passive")   # generator threads must not spin during timing
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")   # OpenMP threads (generator, CPU baseline) must not spin during GPU timing
+os.environ.setdefault("OMP_PROC_BIND", "false")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -36,6 +40,12 @@ WORKLOADS = {
     # BASELINE.json configs[2] (headline): HDL-64-shape 64x1800, scan_regions=8, prev_frames=20
     "hdl64": dict(H=64, W=1800, lidar_type=0, R=8, epr=10, P=20,
                   name="HDL-64-shape 64x1800 synthetic stream, scan_regions=8, edges_per_region=10, prev_frames=20"),
+    # configs[1]: VLP-16-shape 16x1800, scan_regions=8, edges_per_region=20, prev_frames=10
+    "vlp16": dict(H=16, W=1800, lidar_type=0, R=8, epr=20, P=10,
+                  name="VLP-16-shape 16x1800 synthetic stream, scan_regions=8, edges_per_region=20, prev_frames=10"),
+    # configs[3]: Ouster-128-shape 128x2048 (liodom_ouster.launch: lidar_type=1, R=8, epr=10), prev_frames=30
+    "ouster128": dict(H=128, W=2048, lidar_type=1, R=8, epr=10, P=30,
+                      name="Ouster-128-shape 128x2048 synthetic stream (liodom_ouster.launch params), prev_frames=30"),
 }
 
 
@@ -51,7 +61,7 @@ def algorithmic_bytes(kernel, N, E, M, C, evals):
         return 16.0 * (M + E) + 28.0 * E      # one kNN pass: map + queries read, (a, b, flag) written
     if kernel == "k_lm_solve":
         return (36.0 * C + 224.0) * max(evals, 1.0)   # per residual/Jacobian evaluation
-    if kernel in ("k_window_insert", "k_hash_scatter", "k_hash_alloc", "k_hash_clear"):
+    if kernel in ("k_window_insert", "k_hash_scatter", "k_hash_alloc", "k_hash_clear", "k_hash_build"):
         return 32.0 * M                       # window / hash rebuild
     if kernel == "k_compact_edges":
         return 32.0 * E
@@ -83,21 +93,54 @@ def measured_traffic(kernel, n_streams):
 
 def roofline_from_stats(stats, n_streams, N, E, M, C, evals):
     """stats: {kernel: (launches, total_ms)} from HIP events on the handle's stream."""
+    stats = {k: v for k, v in stats.items() if v[0]}
     tot = sum(ms for _, ms in stats.values()) or 1.0
     name, (launches, ms) = max(stats.items(), key=lambda kv: kv[1][1])
     avg_s = ms / max(launches, 1) * 1e-3
     by = algorithmic_bytes(name, N, E, M, C, evals) * n_streams
     achieved = by / avg_s / 1e9 if avg_s > 0 else 0.0
+    per_scan_bytes = sum(algorithmic_bytes(k, N, E, M, C, evals) * v[0] for k, v in stats.items())   # all launches
+    scans = max(1, stats.get("k_classify", (1, 0))[0])
     return {
         "bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": measured_traffic(name, n_streams),
         "avg_kernel_us": round(avg_s * 1e6, 2), "algorithmic_bytes_per_launch": int(by),
         "share_of_gpu_time": round(ms / tot, 3),
-        "per_kernel_us": {k: round(v[1] / max(v[0], 1) * 1e3, 2) for k, v in stats.items() if v[0]},
+        "per_kernel_us": {k: round(v[1] / max(v[0], 1) * 1e3, 2) for k, v in stats.items()},
         # every kernel against the same roof: algorithmic GB/s and fraction of the 8 TB/s peak
         "per_kernel_frac": {k: round(algorithmic_bytes(k, N, E, M, C, evals) * n_streams / (v[1] / v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
-                            for k, v in stats.items() if v[0] and v[1] > 0 and algorithmic_bytes(k, N, E, M, C, evals) > 0},
+                            for k, v in stats.items() if v[1] > 0 and algorithmic_bytes(k, N, E, M, C, evals) > 0},
+        # all kernels of a step together: algorithmic bytes of one step / summed kernel time of one step
+        "end_to_end_frac_of_kernel_time": round(per_scan_bytes / scans * n_streams / (tot / scans * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
     }
+
+
+def pose_errors(poses_a, poses_b):
+    dt = np.linalg.norm(poses_a[:, 4:] - poses_b[:, 4:], axis=1)
+    dots = np.abs(np.sum(poses_a[:, :4] * poses_b[:, :4], axis=1))
+    dr = 2.0 * np.arccos(np.minimum(1.0, dots))
+    return dt, dr
+
+
+def run_oracle(orc, wl, scans, threads=(1, 1), time_from=0):
+    """The CPU oracle on `scans`; returns (poses, seconds spent on scans[time_from:])."""
+    po = orc.make_params(lidar_type=wl["lidar_type"], scan_lines=wl["H"], scan_regions=wl["R"], edges_per_region=wl["epr"],
+                         prev_frames=wl["P"], knn_mode=1)
+    orc.set_threads(*threads)
+    od = orc.Odometer(po)
+    poses = np.zeros((len(scans), 7))
+    tc = 0.0
+    for k, x in enumerate(scans):
+        ts = time.perf_counter()
+        e = orc.extract(po, x, wl["H"], wl["W"])
+        pose, _ = od.step(e["edges"])
+        te = time.perf_counter()
+        if k >= time_from:
+            tc += te - ts
+        poses[k] = pose
+    od.close()
+    orc.set_threads(1, 1)
+    return poses, tc
 
 
 def main():
@@ -106,8 +149,11 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="hdl64", choices=sorted(WORKLOADS))
-    ap.add_argument("--batched-streams", type=int, default=64, help="lock-step streams of the throughput leg (0 = skip)")
+    ap.add_argument("--batched-streams", type=int, default=256, help="lock-step streams of the throughput leg (0 = skip)")
+    ap.add_argument("--batched-data-streams", type=int, default=8, help="distinct synthetic streams replayed by the batched leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=100, help="timed scans of the CPU baseline sample (bounded)")
+    ap.add_argument("--parity-scans", type=int, default=0, help="scans compared with the oracle per replica (0 = prefill + warm-up + min(steps, 100))")
     args = ap.parse_args()
 
     # The HIP library is loaded before torch so that libamdhip64 resolves to /opt/rocm's copy.
@@ -117,17 +163,24 @@ def main():
     la.load()
     rep = Replicas()          # one process per GPU; gloo rendezvous only when WORLD_SIZE > 1
     rank, local_rank, world = rep.rank, rep.local_rank, rep.world
-    if world > 1:
-        args.gpus = world
+    if args.gpus != world:
+        # `--gpus N` without the N-rank launcher would report N x the throughput of one process
+        if rank == 0:
+            sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE is %d: launch with `python -m torch.distributed.run "
+                             "--nnodes=1 --nproc-per-node %d ... bench.py --gpus %d`\n" % (args.gpus, world, args.gpus, args.gpus))
+        rep.close()
+        sys.exit(2)
     ndev = la.device_count()
     if ndev > 0 and local_rank >= ndev:      # more ranks than GPUs (smoke runs): share devices
         local_rank = local_rank % ndev
+    rep.pin_cpus(local_rank)                 # host thread near the GPU's NUMA node (busy-polls the result record)
 
     wl = WORKLOADS[args.workload]
     H, W, R, epr, P = wl["H"], wl["W"], wl["R"], wl["epr"], wl["P"]
     N = H * W
     K, Wm = args.steps, args.warmup
-    total = K + Wm
+    F = P                                    # untimed pre-fill: the window holds P frames before the warm-up starts
+    total = F + Wm + K
 
     # ---- synthetic stream (stream id = global rank), generated before anything is timed ----
     cfg = synth.make_cfg(H, W, wl["lidar_type"])
@@ -148,46 +201,53 @@ def main():
         for k in range(first, first + count):
             g.process_resident(k, N, H, W, readback=readback, next_slot=(k + 1 if (pipelined and k < last) else -1))
 
-    # ---- timed region: W warm-up steps, then exactly K steps ----
-    run(0, Wm)
+    # ---- timed region: untimed pre-fill + W warm-up steps, then exactly K steps ----
+    run(0, F)
+    run(F, Wm)
     g.sync()
     rep.barrier()
     t0 = time.perf_counter()
-    run(Wm, K)
+    run(F + Wm, K)
     g.sync()
     rep.barrier()
     elapsed = rep.max_over_ranks(time.perf_counter() - t0)
     poses_gpu, infos = g.pose_log(0, 0, total)
-    value = args.gpus * K / elapsed
+    status_bits = 0
+    for i in infos:
+        status_bits |= int(i.status)
+    if status_bits:
+        raise SystemExit("bench.py: the device raised status bits 0x%x (ring / edge / hash overflow): results invalid" % status_bits)
+    value = world * K / elapsed
+    timed = infos[F + Wm:]
 
     # ---- roofline leg: same K steps again with HIP events around every kernel launch ----
     g.reset()
-    run(0, Wm)
+    run(0, F + Wm)
     g.sync()
     g.reset_kernel_stats()
     g.set_profiling(True)
-    run(Wm, K)
+    run(F + Wm, K)
     stats = g.kernel_stats()
     g.set_profiling(False)
-    meanE = float(np.mean([i.n_edges for i in infos[Wm:]]))
-    meanM = float(np.mean([i.map_points for i in infos[Wm:]]))
-    meanC = float(np.mean([(i.matches[0] + i.matches[1]) / 2.0 for i in infos[Wm:]]))
-    mean_evals = float(np.mean([(i.lm[0].iterations + i.lm[1].iterations + 2) / 2.0 for i in infos[Wm:]]))
+    meanE = float(np.mean([i.n_edges for i in timed]))
+    meanM = float(np.mean([i.map_points for i in timed]))
+    meanC = float(np.mean([(i.matches[0] + i.matches[1]) / 2.0 for i in timed]))
+    mean_evals = float(np.mean([(i.lm[0].iterations + i.lm[1].iterations + 2) / 2.0 for i in timed]))
     roofline = roofline_from_stats(stats, 1, N, meanE, meanM, meanC, mean_evals)
     # asynchronous replay (no per-scan readback) for reference
     g.reset()
-    run(0, Wm, readback=False)
+    run(0, F + Wm, readback=False)
     g.sync()
     t1 = time.perf_counter()
-    run(Wm, K, readback=False)
+    run(F + Wm, K, readback=False)
     g.sync()
     async_rate = K / (time.perf_counter() - t1)
     # strictly serial scans (no overlap between extraction and odometry) for reference
     g.reset()
-    run(0, Wm, pipelined=False)
+    run(0, F + Wm, pipelined=False)
     g.sync()
     t1 = time.perf_counter()
-    run(Wm, K, pipelined=False)
+    run(F + Wm, K, pipelined=False)
     g.sync()
     serial_rate = K / (time.perf_counter() - t1)
     dev_name, cus = g.device_info()
@@ -196,59 +256,76 @@ def main():
     out = None
     if rank == 0:
         out = {
-            "metric": "scans/sec (64x1800 cloud, prev_frames=20) at 1 GPU; pose RMSE vs CPU ref",
-            "value": round(value, 2), "unit": "scans/s", "n_gpus": args.gpus, "steps": K, "warmup": Wm,
+            "metric": "scans/sec (64×1800 cloud, prev_frames=20) at 1 GPU; pose RMSE vs CPU ref",
+            "value": round(value, 2), "unit": "scans/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": round(elapsed / K * 1e3, 5), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl["name"], "streams_per_gpu": 1, "points_per_scan": N,
                        "mode": "per-scan synchronous (pose read back every scan), scans resident in HBM, "
                                "extraction of scan k+1 overlapped with odometry of scan k on a second HIP stream",
-                       "parallelism": "replicas only" if args.gpus > 1 else "single stream",
+                       "prefill_scans": F,
+                       "parallelism": "replicas only" if world > 1 else "single stream",
                        "mean_edges": round(meanE, 1), "mean_map_points": round(meanM, 1), "mean_matches": round(meanC, 1),
-                       "mean_lm_evals_per_solve": round(mean_evals, 2), "device": dev_name, "compute_units": cus},
+                       "mean_lm_evals_per_solve": round(mean_evals, 2), "device": dev_name, "compute_units": cus,
+                       "library_source_hash": la.api.build_info().get("source_hash") or la.api.built_hash()},
             "async_replay_scans_per_s": round(async_rate, 2),
             "serial_scans_per_s": round(serial_rate, 2),
             "roofline": roofline,
         }
+        if args.workload != "hdl64":
+            out["metric"] = "scans/sec (%dx%d cloud, prev_frames=%d) at 1 GPU; pose RMSE vs CPU ref" % (H, W, P)
 
-    # ---- CPU baseline + parity (rank 0, N = 1 only): the oracle on the same scans ----
-    if rank == 0 and not args.no_cpu_baseline and args.gpus == 1:
-        from oracle import oracle as orc
-        po = orc.make_params(lidar_type=wl["lidar_type"], scan_lines=H, scan_regions=R, edges_per_region=epr,
-                             prev_frames=P, knn_mode=1)
-        od = orc.Odometer(po)
-        poses_cpu = np.zeros((total, 7))
-        tc = 0.0
-        for k in range(total):
-            ts = time.perf_counter()
-            e = orc.extract(po, scans[k], H, W)
-            pose, _ = od.step(e["edges"])
-            te = time.perf_counter()
-            if k >= Wm:
-                tc += te - ts
-            poses_cpu[k] = pose
-        od.close()
-        dt = np.linalg.norm(poses_gpu[:, 4:] - poses_cpu[:, 4:], axis=1)
-        dots = np.abs(np.sum(poses_gpu[:, :4] * poses_cpu[:, :4], axis=1))
-        dr = 2.0 * np.arccos(np.minimum(1.0, dots))
-        out["cpu_baseline"] = {
-            "value": round(K / tc, 3), "unit": "scans/s", "cores": 1, "kind": "port",
-            "sample": "the same %d scans (%d warm-up + %d timed), CPU oracle (oracle/liodom_oracle.cc, kd-tree kNN), 1 thread of %d"
-                      % (total, Wm, K, os.cpu_count()),
-            "gpu_over_cpu": round(value / (K / tc), 1),
-        }
+    # ---- parity, every replica on its own stream (the oracle on the host cores of that rank) ----
+    from oracle import oracle as orc
+    n_par = args.parity_scans if args.parity_scans > 0 else F + Wm + min(K, 100)
+    n_par = min(n_par, total)
+    want_baseline = rank == 0 and world == 1 and not args.no_cpu_baseline
+    n_cpu = min(K, max(1, args.cpu_sample))
+    n_run = max(n_par, F + Wm + n_cpu) if want_baseline else n_par
+    poses_cpu, tc = run_oracle(orc, wl, scans[:n_run], (1, 1), time_from=F + Wm)
+    dt, dr = pose_errors(poses_gpu[:n_par], poses_cpu[:n_par])
+    worst_t = rep.max_over_ranks(float(dt.max()))
+    worst_r = rep.max_over_ranks(float(dr.max()))
+    if rank == 0:
         out["parity"] = {
             "pose_trans_rmse_m": float(np.sqrt(np.mean(dt ** 2))), "pose_trans_max_m": float(dt.max()),
             "pose_rot_rmse_rad": float(np.sqrt(np.mean(dr ** 2))), "pose_rot_max_rad": float(dr.max()),
-            "tolerance": "1e-4 m / 1e-4 rad per scan", "scans_compared": int(total),
+            "worst_replica_trans_max_m": worst_t, "worst_replica_rot_max_rad": worst_r, "replicas_checked": world,
+            "tolerance": "1e-4 m / 1e-4 rad per scan", "scans_compared": int(n_par),
+            "pass": bool(worst_t <= 1e-4 and worst_r <= 1e-4),
+        }
+
+    # ---- CPU baseline (rank 0, N = 1 only): bounded sample, 1 thread and the reference's thread policy ----
+    if want_baseline:
+        n_timed = n_run - (F + Wm)
+        nproc = os.cpu_count() or 1
+        st_threads, ev_threads = max(2, nproc - 5), nproc      # feature_extractor.cc:29-34, laser_odometry.cc:216
+        _, tc_ref = run_oracle(orc, wl, scans[:n_run], (st_threads, ev_threads), time_from=F + Wm)
+        try:
+            cpu_model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+        except Exception:
+            cpu_model = "unknown"
+        out["cpu_baseline"] = {
+            "value": round(n_timed / tc, 3), "unit": "scans/s", "cores": 1, "kind": "port",
+            "sample": "scans %d..%d of the same stream (%d timed after %d untimed pre-fill + warm-up scans), CPU oracle "
+                      "(oracle/liodom_oracle.cc, kd-tree kNN rebuilt twice per scan), 1 thread of %d" % (F + Wm, n_run - 1, n_timed, F + Wm, nproc),
+            "gpu_over_cpu": round(value / (n_timed / tc), 1),
+            "reference_policy": {
+                "value": round(n_timed / tc_ref, 3), "unit": "scans/s", "cores": nproc,
+                "stencil_threads": st_threads, "residual_eval_threads": ev_threads,
+                "policy": "stencil loop omp num_threads = max(2, nproc - 5) (feature_extractor.cc:29-34,194); residual blocks "
+                          "evaluated by nproc threads (laser_odometry.cc:216); everything else serial as in the reference",
+                "OMP_WAIT_POLICY": os.environ.get("OMP_WAIT_POLICY"), "OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND"),
+            },
+            "nproc": nproc, "cpu_model": cpu_model,
         }
 
     # ---- batched leg: lock-step streams on one GPU (throughput mode; separately labelled) ----
-    if rank == 0 and args.batched_streams > 0 and args.gpus == 1:
+    if rank == 0 and args.batched_streams > 0 and world == 1:
         S = args.batched_streams
-        Kb, Wb = min(K, 40), min(Wm, 20)
+        Kb, Wb = min(K, 20), F + min(Wm, 4)      # pre-fill + a few warm-up steps, then Kb timed steps
         tb = Kb + Wb
-        n_data = 2                      # distinct synthetic streams; stream s replays data stream s % 2
+        n_data = max(1, min(args.batched_data_streams, S))   # distinct synthetic streams; stream s replays data stream s % n_data
         data = [scans[:tb]] + [[synth.scan(cfg, 1000 + d, k)[0] for k in range(tb)] for d in range(1, n_data)]
         gb = la.Liodom(params, la.make_config(device=local_rank, n_streams=S, max_points=N, max_width=W, pose_log_capacity=tb + 8))
         gb.alloc_resident(tb)
@@ -265,7 +342,13 @@ def main():
             gb.process_resident(k, N, H, W, readback=True, next_slot=(k + 1 if k + 1 < tb else -1))
         gb.sync()
         eb = time.perf_counter() - t2
-        _, binfos = gb.pose_log(0, 0, tb)
+        bposes, binfos = gb.pose_log(0, 0, tb)
+        bstatus = 0
+        for s in range(0, S, max(1, S // 8)):
+            for i in gb.pose_log(s, 0, tb)[1]:
+                bstatus |= int(i.status)
+        # lock-step stream 0 replays the headline data stream: same poses as the single-stream handle
+        bdt, bdr = pose_errors(bposes[:min(tb, n_par)], poses_gpu[:min(tb, n_par)])
         gb.reset()
         for k in range(Wb):
             gb.process_resident(k, N, H, W, readback=True)
@@ -276,14 +359,17 @@ def main():
         bstats = gb.kernel_stats()
         gb.set_profiling(False)
         gb.close()
-        bE = float(np.mean([i.n_edges for i in binfos[Wb:]]))
-        bM = float(np.mean([i.map_points for i in binfos[Wb:]]))
-        bC = float(np.mean([(i.matches[0] + i.matches[1]) / 2.0 for i in binfos[Wb:]]))
-        bev = float(np.mean([(i.lm[0].iterations + i.lm[1].iterations + 2) / 2.0 for i in binfos[Wb:]]))
+        bt = binfos[Wb:]
+        bE = float(np.mean([i.n_edges for i in bt]))
+        bM = float(np.mean([i.map_points for i in bt]))
+        bC = float(np.mean([(i.matches[0] + i.matches[1]) / 2.0 for i in bt]))
+        bev = float(np.mean([(i.lm[0].iterations + i.lm[1].iterations + 2) / 2.0 for i in bt]))
         out["batched"] = {
             "streams": S, "steps": Kb, "warmup": Wb, "value": round(S * Kb / eb, 1), "unit": "scans/s (aggregate, 1 GPU)",
-            "ms_per_step": round(eb / Kb * 1e3, 4),
-            "note": "lock-step streams in one launch per kernel, per-step synchronous, extraction of step k+1 overlapped; %d distinct synthetic streams replayed" % n_data,
+            "ms_per_step": round(eb / Kb * 1e3, 4), "distinct_data_streams": n_data, "status_bits": bstatus,
+            "stream0_vs_single_stream_max_m": float(bdt.max()), "stream0_vs_single_stream_max_rad": float(bdr.max()),
+            "note": "lock-step streams in one launch per kernel, per-step synchronous, extraction of step k+1 overlapped; "
+                    "%d distinct synthetic streams replayed round-robin" % n_data,
             "roofline": roofline_from_stats(bstats, S, N, bE, bM, bC, bev),
         }
 

@@ -14,8 +14,18 @@
  *
  * One handle drives one GPU and `n_streams` independent LiDAR streams that advance in
  * lock-step (every kernel is launched once over all streams).  n_streams = 1 is the drop-in
- * case for liodom_node; n_streams > 1 serves replay / multi-sensor batches.  A handle is not
- * thread-safe.
+ * case for liodom_node; n_streams > 1 serves replay / multi-sensor batches.
+ *
+ * Threading.  The reference runs a FeatureExtractor thread and a LaserOdometer thread side by side
+ * (src/liodom_node.cc:89-91) and hands edge clouds over through a queue (src/shared_data.cc:64-89).
+ * The handle mirrors that with two sides: liodom_extract_edges works on the extraction side (its own
+ * HIP stream, scratch and edge buffer), liodom_odometry_step on the odometry side (window, local-map
+ * hash, pose state, result records).  One thread may call liodom_extract_edges while another calls
+ * liodom_odometry_step on the same handle: extraction of scan k+1 then overlaps the odometry of scan
+ * k on the GPU, and the poses are bit-identical to the serial order (tests/test_gpu_threads.py).
+ * Each side serialises its own callers with a mutex; every other entry point takes both mutexes,
+ * i.e. is safe to call from any thread but does not overlap with anything.  While per-kernel
+ * profiling is enabled (liodom_set_profiling) all entry points are serialised.
  */
 #ifndef LIODOM_HIP_H
 #define LIODOM_HIP_H
@@ -114,7 +124,7 @@ void liodom_destroy(liodom_handle_t* h);
 const char* liodom_last_error(void);
 
 /* FeatureExtractor::splitPointCloud + extractFeatures (src/feature_extractor.cc:104-254) for one
- * cloud of stream `stream`.  xyzi: n points (host).  For lidar_type 1, height*width == n and
+ * cloud of stream `stream`.  Extraction side: may run concurrently with liodom_odometry_step.  xyzi: n points (host).  For lidar_type 1, height*width == n and
  * the cloud is row-major organised.  Outputs (host, capacity `cap` edges): edges in the
  * reference's output order (ring-major, region-major, pick order); edge_ring / edge_idx /
  * edge_src (each optional) = ring id, index inside the compacted ring, index into xyzi. */
@@ -123,7 +133,7 @@ int liodom_extract_edges(liodom_handle_t* h, int stream, const float* xyzi, int6
                          int32_t* edge_idx, int32_t* edge_src, int cap, int* n_edges);
 
 /* One iteration of LaserOdometer::operator() (src/laser_odometry.cc:107-267) on an edge cloud
- * (sensor frame, host memory): first call initialises the window, later calls predict, run
+ * (sensor frame, host memory; odometry side: may run concurrently with liodom_extract_edges): first call initialises the window, later calls predict, run
  * 2 x [addEdgeConstraints + solve], and append the transformed edges to the sliding window. */
 int liodom_odometry_step(liodom_handle_t* h, int stream, const float* edges_xyzi, int n_edges,
                          double stamp, double* pose_out, liodom_step_info_t* info);
@@ -191,7 +201,7 @@ int liodom_get_curvature(liodom_handle_t* h, int stream, double* curv, int64_t c
 /* ---- measurement ---- */
 /* When enabled every kernel launch is bracketed by HIP events on the handle's stream. */
 int liodom_set_profiling(liodom_handle_t* h, int enable);
-#define LIODOM_NUM_KERNELS 11
+#define LIODOM_NUM_KERNELS 12
 typedef struct liodom_kernel_stat_t {
   char name[32];
   int64_t launches;
@@ -202,6 +212,9 @@ int liodom_get_kernel_stats(liodom_handle_t* h, liodom_kernel_stat_t* stats /*LI
 int liodom_reset_kernel_stats(liodom_handle_t* h);
 /* Number of HIP devices visible to this process (0 without a GPU). */
 int liodom_device_count(int* count);
+/* PCI bus id ("0000:c1:00.0") of HIP device `device`: lets a launcher place the host thread that
+ * polls the result records on the GPU's NUMA node (/sys/bus/pci/devices/<id>/local_cpulist). */
+int liodom_device_pci_bus_id(int device, char* bus_id, int cap);
 /* Device name and compute-unit count of the handle's GPU. */
 int liodom_device_info(liodom_handle_t* h, char* name, int name_cap, int* compute_units);
 

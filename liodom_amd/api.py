@@ -1,4 +1,5 @@
 import ctypes as C
+import hashlib
 import os
 import subprocess
 
@@ -7,6 +8,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 _LIB = os.path.join(_HERE, "lib", "libliodom_hip.so")
+_HASH = _LIB + ".srchash"
+_BUILD_INFO = {"rebuilt": None, "source_hash": None}
 _SRC = [os.path.join(_HERE, "csrc", f) for f in ("liodom_hip.hip", "liodom_kernels.h", "liodom_math.h", "wave_ops.h",
                                                   "liodom_map.h", "liodom_map_host.h")] + [
     os.path.join(_ROOT, "include", "liodom_hip.h")]
@@ -23,18 +26,61 @@ def lib_path():
     return _LIB
 
 
+def source_hash():
+    """SHA-256 over the compile flags and every source the library is built from."""
+    h = hashlib.sha256()
+    h.update(" ".join(HIPCC_FLAGS).encode())
+    for p in _SRC:
+        with open(p, "rb") as f:
+            h.update(b"\0" + os.path.basename(p).encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
+def built_hash():
+    """Source hash recorded beside the library when it was built ('' if none)."""
+    try:
+        with open(_HASH) as f:
+            return f.read().strip()
+    except OSError:
+        return ""
+
+
+def is_stale():
+    return not os.path.exists(_LIB) or built_hash() != source_hash()
+
+
 def build(force=False, verbose=False):
-    """Compile the HIP library for gfx950 (hipcc cross-compiles without a GPU)."""
+    """Compile the HIP library for gfx950 (hipcc cross-compiles without a GPU).  The library is
+    rebuilt whenever the hash of its sources + flags differs from the one recorded at its last build
+    (mtimes do not survive a copy to another box), so a stale binary is never tested against newer
+    sources.  Returns the library path; build_info() tells whether this call compiled anything."""
+    import fcntl
     os.makedirs(os.path.dirname(_LIB), exist_ok=True)
-    newest = max(os.path.getmtime(p) for p in _SRC)
-    if not force and os.path.exists(_LIB) and os.path.getmtime(_LIB) >= newest:
-        return _LIB
-    hipcc = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else "hipcc"
-    cmd = [hipcc] + HIPCC_FLAGS + ["-o", _LIB, _SRC[0]]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    with open(_LIB + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)           # several ranks may arrive here at once
+        want = source_hash()
+        if not force and os.path.exists(_LIB) and built_hash() == want:
+            _BUILD_INFO.update(rebuilt=False, source_hash=want)
+            return _LIB
+        hipcc = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else "hipcc"
+        tmp = _LIB + ".tmp.%d" % os.getpid()
+        cmd = [hipcc] + HIPCC_FLAGS + ["-o", tmp, _SRC[0]]
+        if verbose:
+            print(" ".join(cmd))
+        try:
+            subprocess.check_call(cmd)
+            os.replace(tmp, _LIB)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
+        with open(_HASH, "w") as f:
+            f.write(want + "\n")
+        _BUILD_INFO.update(rebuilt=True, source_hash=want)
     return _LIB
+
+
+def build_info():
+    return dict(_BUILD_INFO)
 
 
 class Params(C.Structure):
@@ -70,7 +116,7 @@ class StepInfo(C.Structure):
                 ("status", C.c_uint32), ("scan_index", C.c_int32)]
 
 
-NUM_KERNELS = 11
+NUM_KERNELS = 12
 
 
 class MapConfig(C.Structure):
@@ -93,9 +139,15 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(_LIB):
-        raise LiodomError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
-                          "(the HIP extension is required; there is no CPU fallback)" % _LIB)
+    if is_stale():
+        # missing, or built from other sources than the ones present: rebuild (hipcc is part of the
+        # image on the build box and on the GPU box); never load a binary that does not match the tree
+        try:
+            build()
+        except Exception as ex:
+            raise LiodomError("%s is missing or stale and could not be rebuilt (%s): run `python -c 'import "
+                              "__graft_entry__ as g; g.build()'` (the HIP extension is required; there is no "
+                              "CPU fallback)" % (_LIB, ex))
     L = C.CDLL(_LIB, mode=C.RTLD_GLOBAL)
     fp, dp, ip = C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int32)
     vp = C.c_void_p
@@ -145,6 +197,8 @@ def load():
     L.liodom_reset_kernel_stats.argtypes = [vp]
     L.liodom_device_count.restype = C.c_int
     L.liodom_device_count.argtypes = [ip]
+    L.liodom_device_pci_bus_id.restype = C.c_int
+    L.liodom_device_pci_bus_id.argtypes = [C.c_int, C.c_char_p, C.c_int]
     L.liodom_device_info.restype = C.c_int
     L.liodom_device_info.argtypes = [vp, C.c_char_p, C.c_int, ip]
     i64p = C.POINTER(C.c_int64)
@@ -180,7 +234,7 @@ EXPORTED_SYMBOLS = [
     "liodom_alloc_resident", "liodom_upload_scan", "liodom_process_resident", "liodom_process_resident_pipelined", "liodom_sync", "liodom_get_pose_log",
     "liodom_reset", "liodom_get_edges", "liodom_get_window", "liodom_get_local_map", "liodom_get_correspondences", "liodom_get_curvature",
     "liodom_set_profiling", "liodom_get_kernel_stats", "liodom_reset_kernel_stats", "liodom_device_info",
-    "liodom_device_count",
+    "liodom_device_count", "liodom_device_pci_bus_id",
     "liodom_map_config_default", "liodom_map_create", "liodom_map_destroy", "liodom_map_update", "liodom_map_get_local",
     "liodom_map_get_all", "liodom_map_num_cells", "liodom_map_status", "liodom_get_received_map", "liodom_attach_mapper",
     "liodom_set_imu_orientation", "liodom_set_laser_to_base",
@@ -191,6 +245,13 @@ def device_count():
     n = C.c_int32()
     load().liodom_device_count(C.byref(n))
     return n.value
+
+
+def device_pci_bus_id(device):
+    buf = C.create_string_buffer(64)
+    if load().liodom_device_pci_bus_id(int(device), buf, 64) != 0:
+        return None
+    return buf.value.decode()
 
 
 def make_params(**kw):

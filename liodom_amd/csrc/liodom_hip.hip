@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -34,11 +35,11 @@ thread_local std::string g_last_error;
 
 enum KernelId {
   KID_CLASSIFY = 0, KID_RING_EXTRACT, KID_COMPACT, KID_KNN, KID_LM, KID_HASH_CLEAR,
-  KID_WINDOW_INSERT, KID_HASH_ALLOC, KID_HASH_SCATTER, KID_RING_SCATTER, KID_OTHER
+  KID_WINDOW_INSERT, KID_HASH_ALLOC, KID_HASH_SCATTER, KID_RING_SCATTER, KID_HASH_BUILD, KID_OTHER
 };
 const char* kKernelNames[LIODOM_NUM_KERNELS] = {
     "k_classify", "k_ring_extract", "k_compact_edges", "k_knn", "k_lm_solve",
-    "k_hash_clear", "k_window_insert", "k_hash_alloc", "k_hash_scatter", "k_ring_scatter", "other"};
+    "k_hash_clear", "k_window_insert", "k_hash_alloc", "k_hash_scatter", "k_ring_scatter", "k_hash_build", "other"};
 
 struct EventPair { hipEvent_t a, b; int kid; };
 
@@ -51,14 +52,21 @@ struct liodom_handle {
   liodom_config_t config;
   DevView v{};
   DevView* d_view = nullptr;         // device copy: kernels take a pointer (8-byte kernarg)
-  hipStream_t stream = nullptr;      // odometry (and every non-pipelined call)
-  hipStream_t stream_x = nullptr;    // extraction of the next scan in the pipelined replay
+  // Two sides, as in the reference's liodom_node (src/liodom_node.cc:89-91: one FeatureExtractor thread,
+  // one LaserOdometer thread).  The EXTRACTION side owns stream_x, the ring-split scratch, stage_in and
+  // edge buffer kEdgeBufX; the ODOMETRY side owns `stream`, edge buffers 0 / 1, the window, the hash and
+  // the result records.  mx_x / mx_o serialise callers of each side; an entry point that needs both
+  // (process_scan, the resident replay, reset, ...) takes mx_o first, then mx_x.  liodom_extract_edges
+  // (mx_x only) and liodom_odometry_step (mx_o only) can therefore run concurrently from two threads.
+  std::mutex mx_x, mx_o;
+  hipStream_t stream = nullptr;      // odometry side
+  hipStream_t stream_x = nullptr;    // extraction side (liodom_extract_edges, and the next scan's extraction in the pipelined replay)
   hipEvent_t ev_edges[2] = {nullptr, nullptr};   // edge buffer b written
   hipEvent_t ev_free[2] = {nullptr, nullptr};    // odometry finished reading edge buffer b
   bool ev_free_valid[2] = {false, false};
   int parity = 0;                    // edge buffer of the next scan to enter odometry
   int pf_slot = -1;                  // resident slot whose extraction has been issued ahead
-  int last_eb = 0;                   // edge buffer of the most recent scan (inspection)
+  int last_eb = 0;                   // edge buffer of the most recent scan that entered odometry (inspection)
   hipEvent_t pose_event = nullptr;
   int S = 1, H = 0, P = 0;
   size_t ring_lds_bytes = 0;
@@ -198,7 +206,7 @@ int launch_odometry(liodom_handle* h, int eb, int s0, int count) {
     }
   }
   if (h->lds_hash_build) {
-    ProfScope ps(h, KID_WINDOW_INSERT);     // window append + LDS-built cell hash, one workgroup per stream
+    ProfScope ps(h, KID_HASH_BUILD);        // window append + LDS-built cell hash, one workgroup per stream
     hipLaunchKernelGGL(k_hash_build, dim3(count), dim3(kBuildThreads), hash_build_lds_bytes(), h->stream, v, s0, eb);
   } else {
     {
@@ -237,11 +245,36 @@ int launch_odometry(liodom_handle* h, int eb, int s0, int count) {
   return LIODOM_OK;
 }
 
-int check_stream(liodom_handle* h, int stream) {
+// Every entry point starts here: the calling thread's current device becomes the handle's (other
+// handles / maps of the process may live on other GPUs, and HIP's current device is per thread).
+int enter(liodom_handle* h) {
   if (!h) return LIODOM_ERR_INVALID_ARG;
+  HIP_TRY(hipSetDevice(h->config.device));
+  return LIODOM_OK;
+}
+int check_stream(liodom_handle* h, int stream) {
+  int rc = enter(h);
+  if (rc) return rc;
   if (stream < 0 || stream >= h->S) { g_last_error = "stream index out of range"; return LIODOM_ERR_INVALID_ARG; }
   return LIODOM_OK;
 }
+// Lock guards of the two sides.  While per-kernel profiling is on, extraction runs on the odometry
+// stream (so that HIP-event durations are not inflated by the other side's kernels) and shares the
+// event pool: then every entry point takes both locks and the two sides are serialised.
+struct SideLocks {
+  std::unique_lock<std::mutex> lo, lx;
+  SideLocks(liodom_handle* h, bool odo, bool ext) {
+    if (odo || h->profiling) lo = std::unique_lock<std::mutex>(h->mx_o);
+    if (ext || h->profiling) lx = std::unique_lock<std::mutex>(h->mx_x);
+    // profiling was switched on between the test above and the locks (set_profiling holds both): take the rest
+    if (h->profiling && !(lo.owns_lock() && lx.owns_lock())) {
+      if (lx.owns_lock()) lx.unlock();
+      if (!lo.owns_lock()) lo = std::unique_lock<std::mutex>(h->mx_o);
+      lx = std::unique_lock<std::mutex>(h->mx_x);
+    }
+  }
+};
+hipStream_t extract_queue(liodom_handle* h) { return h->profiling ? h->stream : h->stream_x; }
 
 int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
@@ -260,7 +293,7 @@ int drain_pipeline(liodom_handle* h) {
 int issue_extract(liodom_handle* h, int slot, int eb, int n, int height, int width) {
   // while per-kernel profiling is on, everything runs on one stream so that the HIP-event
   // durations are not inflated by kernels of the other stream sharing the GPU
-  hipStream_t q = h->profiling ? h->stream : h->stream_x;
+  hipStream_t q = extract_queue(h);
   if (h->ev_free_valid[eb]) HIP_TRY(hipStreamWaitEvent(q, h->ev_free[eb], 0));
   const float4* in = h->resident + (size_t)slot * h->S * (size_t)h->v.max_points;
   int rc = launch_extract(h, q, eb, 0, h->S, in, (size_t)h->v.max_points, n, height, width);
@@ -270,6 +303,10 @@ int issue_extract(liodom_handle* h, int slot, int eb, int n, int height, int wid
 }
 
 int reset_state(liodom_handle* h) {
+  // nothing of an earlier scan may still be in flight: its finalize would publish into the records
+  // zeroed below, and an extraction issued ahead would write into scratch that is being reset
+  if (h->stream_x) HIP_TRY(hipStreamSynchronize(h->stream_x));
+  HIP_TRY(hipStreamSynchronize(h->stream));
   std::vector<StreamState> init((size_t)h->S);
   for (auto& st : init) {
     std::memset(&st, 0, sizeof(st));
@@ -288,7 +325,6 @@ int reset_state(liodom_handle* h) {
     hipLaunchKernelGGL(k_init_cells, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, h->v);
     HIP_TRY(hipGetLastError());
   }
-  if (h->stream_x) HIP_TRY(hipStreamSynchronize(h->stream_x));
   h->pf_slot = -1; h->parity = 0; h->last_eb = 0; h->ev_free_valid[0] = h->ev_free_valid[1] = false;
   HIP_TRY(hipMemsetAsync(h->v.lm_xch, 0, sizeof(unsigned long long) * (size_t)h->S * 2 * kLmGroupsMax * 64, h->stream));
   std::memset(h->host_out, 0, sizeof(HostOut) * (size_t)h->S);
@@ -429,8 +465,8 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   ALLOC(v.ring_nedges, S * h->H, 0);
   ALLOC(v.ring_npoints, S * h->H, 0);
   if (v.debug) ALLOC(v.curv_dbg, S * h->H * v.ring_cap, 0); else v.curv_dbg = nullptr;
-  ALLOC(v.edges, 2 * S * v.edge_cap, 0);
-  ALLOC(v.edges_meta, 2 * S * v.edge_cap, 0);
+  ALLOC(v.edges, kEdgeBufs * S * v.edge_cap, 0);
+  ALLOC(v.edges_meta, kEdgeBufs * S * v.edge_cap, 0);
   ALLOC(v.corr_a, S * v.edge_cap, 0);
   ALLOC(v.corr_b, S * v.edge_cap, 0);
   ALLOC(v.corr_idx, S * 2 * v.edge_cap, 0xFF);
@@ -523,28 +559,28 @@ void liodom_destroy(liodom_handle_t* h) {
 }
 
 int liodom_reset(liodom_handle_t* h) {
-  if (!h) return LIODOM_ERR_INVALID_ARG;
+  int rc = enter(h);
+  if (rc) return rc;
+  SideLocks lk(h, true, true);
   return reset_state(h);
 }
 
-static int copy_edges_out(liodom_handle_t* h, int stream, float* edges_xyzi, int32_t* edge_ring,
+static int copy_edges_out(liodom_handle_t* h, int stream, int eb, hipStream_t q, float* edges_xyzi, int32_t* edge_ring,
                           int32_t* edge_idx, int32_t* edge_src, int cap, int* n_edges) {
-  StreamState st;
-  HIP_TRY(hipMemcpyAsync(&st, h->v.state + stream, sizeof(st), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  const int eb = h->last_eb;
-  const int E = st.n_edges_buf[eb];
+  int E = 0;
+  HIP_TRY(hipMemcpyAsync(&E, &h->v.state[stream].n_edges_buf[eb], sizeof(int), hipMemcpyDeviceToHost, q));
+  HIP_TRY(hipStreamSynchronize(q));
   if (n_edges) *n_edges = E;
   if (E > cap) { g_last_error = "edge buffer too small"; return LIODOM_ERR_CAPACITY; }
   if (E == 0) return LIODOM_OK;
   if (edges_xyzi)
-    HIP_TRY(hipMemcpyAsync(edges_xyzi, h->v.edges + ((size_t)eb * h->S + stream) * h->v.edge_cap, sizeof(float4) * (size_t)E, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(edges_xyzi, h->v.edges + ((size_t)eb * h->S + stream) * h->v.edge_cap, sizeof(float4) * (size_t)E, hipMemcpyDeviceToHost, q));
   std::vector<int4> meta;
   if (edge_ring || edge_idx || edge_src) {
     meta.resize((size_t)E);
-    HIP_TRY(hipMemcpyAsync(meta.data(), h->v.edges_meta + ((size_t)eb * h->S + stream) * h->v.edge_cap, sizeof(int4) * (size_t)E, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(meta.data(), h->v.edges_meta + ((size_t)eb * h->S + stream) * h->v.edge_cap, sizeof(int4) * (size_t)E, hipMemcpyDeviceToHost, q));
   }
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipStreamSynchronize(q));
   for (int i = 0; i < E && !meta.empty(); i++) {
     if (edge_ring) edge_ring[i] = meta[i].x;
     if (edge_idx) edge_idx[i] = meta[i].y;
@@ -559,21 +595,24 @@ int liodom_extract_edges(liodom_handle_t* h, int stream, const float* xyzi, int6
   int rc = check_stream(h, stream);
   if (rc) return rc;
   if (n < 0 || n > h->v.max_points || (n > 0 && !xyzi)) { g_last_error = "bad point count"; return LIODOM_ERR_CAPACITY; }
+  // Extraction side only (mx_x, stream_x, edge buffer kEdgeBufX): safe beside a concurrent
+  // liodom_odometry_step of another thread.  An extraction the pipelined replay issued ahead is on the
+  // same HIP stream, so the shared ring-split scratch is used in stream order.
+  SideLocks lk(h, false, true);
+  hipStream_t q = extract_queue(h);
   float4* in = h->stage_in + (size_t)stream * h->v.max_points;
-  if (n) HIP_TRY(hipMemcpyAsync(in, xyzi, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, h->stream));
-  rc = drain_pipeline(h);
+  if (n) HIP_TRY(hipMemcpyAsync(in, xyzi, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, q));
+  rc = launch_extract(h, q, kEdgeBufX, stream, 1, in, 0, (int)n, height, width);
   if (rc) return rc;
-  rc = launch_extract(h, h->stream, 0, stream, 1, in, 0, (int)n, height, width);
-  if (rc) return rc;
-  h->last_eb = 0;
-  return copy_edges_out(h, stream, edges_xyzi, edge_ring, edge_idx, edge_src, cap, n_edges);
+  return copy_edges_out(h, stream, kEdgeBufX, q, edges_xyzi, edge_ring, edge_idx, edge_src, cap, n_edges);
 }
 
 int liodom_get_edges(liodom_handle_t* h, int stream, float* edges_xyzi, int32_t* edge_ring,
                      int32_t* edge_idx, int32_t* edge_src, int cap, int* n_edges) {
   int rc = check_stream(h, stream);
   if (rc) return rc;
-  return copy_edges_out(h, stream, edges_xyzi, edge_ring, edge_idx, edge_src, cap, n_edges);
+  SideLocks lk(h, true, false);
+  return copy_edges_out(h, stream, h->last_eb, h->stream, edges_xyzi, edge_ring, edge_idx, edge_src, cap, n_edges);
 }
 
 static int wait_pose(liodom_handle_t* h, int s0, int count, double* pose_out, liodom_step_info_t* info) {
@@ -603,6 +642,8 @@ int liodom_odometry_step(liodom_handle_t* h, int stream, const float* edges_xyzi
   int rc = check_stream(h, stream);
   if (rc) return rc;
   if (n_edges < 0 || n_edges > h->v.edge_cap || (n_edges > 0 && !edges_xyzi)) { g_last_error = "edge count exceeds capacity"; return LIODOM_ERR_CAPACITY; }
+  // Odometry side only (mx_o, h->stream, edge buffer 0): safe beside a concurrent liodom_extract_edges.
+  SideLocks lk(h, true, false);
   rc = drain_pipeline(h);
   if (rc) return rc;
   if (n_edges)
@@ -622,10 +663,11 @@ int liodom_process_scan(liodom_handle_t* h, int stream, const float* xyzi, int64
   int rc = check_stream(h, stream);
   if (rc) return rc;
   if (n < 0 || n > h->v.max_points || (n > 0 && !xyzi)) { g_last_error = "bad point count"; return LIODOM_ERR_CAPACITY; }
+  SideLocks lk(h, true, true);        // uses the extraction scratch on the odometry stream
+  rc = drain_pipeline(h);             // nothing issued ahead on the extraction stream may still use that scratch
+  if (rc) return rc;
   float4* in = h->stage_in + (size_t)stream * h->v.max_points;
   if (n) HIP_TRY(hipMemcpyAsync(in, xyzi, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, h->stream));
-  rc = drain_pipeline(h);
-  if (rc) return rc;
   rc = launch_extract(h, h->stream, 0, stream, 1, in, 0, (int)n, height, width);
   if (rc) return rc;
   rc = launch_odometry(h, 0, stream, 1);
@@ -656,6 +698,7 @@ int liodom_set_received_map(liodom_handle_t* h, int stream, const float* xyzi, i
   if (!h->v.mapping) { g_last_error = "liodom_set_received_map: the handle was created with mapping = 0"; return LIODOM_ERR_UNSUPPORTED; }
   if (n < 0 || (n > 0 && !xyzi)) return LIODOM_ERR_INVALID_ARG;
   if (n > h->v.recv_cap) { g_last_error = "liodom_set_received_map: cloud larger than recv_capacity"; return LIODOM_ERR_CAPACITY; }
+  SideLocks lk(h, true, false);
   const int ni = (int)n;
   if (n) HIP_TRY(hipMemcpyAsync(h->v.recv_pts + (size_t)stream * h->v.recv_cap, xyzi, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipMemcpyAsync(&h->v.state[stream].n_recv, &ni, sizeof(int), hipMemcpyHostToDevice, h->stream));
@@ -669,6 +712,7 @@ int liodom_set_imu_orientation(liodom_handle_t* h, int stream, const double* q_x
   int rc = check_stream(h, stream);
   if (rc) return rc;
   if (!q_xyzw) return LIODOM_ERR_INVALID_ARG;
+  SideLocks lk(h, true, false);
   // pageable-memory async copies are staged by the runtime before the call returns
   HIP_TRY(hipMemcpyAsync(h->v.imu_q + (size_t)stream * 4, q_xyzw, sizeof(double) * 4, hipMemcpyHostToDevice, h->stream));
   return LIODOM_OK;
@@ -676,6 +720,7 @@ int liodom_set_imu_orientation(liodom_handle_t* h, int stream, const double* q_x
 
 int liodom_set_laser_to_base(liodom_handle_t* h, const double* T) {
   if (!h || !T) return LIODOM_ERR_INVALID_ARG;
+  SideLocks lk(h, true, true);
   for (int k = 0; k < 12; k++) h->v.laser_to_base[k] = T[k];      // kernels take the view by value
   return LIODOM_OK;
 }
@@ -684,6 +729,7 @@ int liodom_get_received_map(liodom_handle_t* h, int stream, float* xyzi, int64_t
   int rc = check_stream(h, stream);
   if (rc) return rc;
   if (!h->v.mapping) { if (n_points) *n_points = 0; return LIODOM_OK; }
+  SideLocks lk(h, true, false);
   HIP_TRY(hipStreamSynchronize(h->stream));
   int n = 0;
   HIP_TRY(hipMemcpy(&n, &h->v.state[stream].n_recv, sizeof(int), hipMemcpyDeviceToHost));
@@ -697,6 +743,7 @@ int liodom_attach_mapper(liodom_handle_t* h, int stream, liodom_map_t* m, int ce
   int rc = check_stream(h, stream);
   if (rc) return rc;
   if (!h->v.mapping) { g_last_error = "liodom_attach_mapper: the handle was created with mapping = 0"; return LIODOM_ERR_UNSUPPORTED; }
+  SideLocks lk(h, true, false);
   HIP_TRY(hipStreamSynchronize(h->stream));
   if (liodom_map* old = h->mappers[stream]) {       // detach: the map gets a stream of its own again
     h->mappers[stream] = nullptr;
@@ -718,7 +765,12 @@ int liodom_attach_mapper(liodom_handle_t* h, int stream, liodom_map_t* m, int ce
 
 int liodom_alloc_resident(liodom_handle_t* h, int n_slots) {
   if (!h || n_slots < 1) return LIODOM_ERR_INVALID_ARG;
+  int rc0 = enter(h);
+  if (rc0) return rc0;
+  SideLocks lk(h, true, true);
+  HIP_TRY(hipStreamSynchronize(h->stream_x));       // an extraction issued ahead may still read the old buffer
   HIP_TRY(hipStreamSynchronize(h->stream));
+  h->pf_slot = -1;
   if (h->resident) { hipFree(h->resident); h->resident = nullptr; h->n_slots = 0; }
   const size_t bytes = sizeof(float4) * (size_t)h->S * (size_t)n_slots * (size_t)h->v.max_points;
   void* raw = nullptr;
@@ -732,6 +784,7 @@ int liodom_upload_scan(liodom_handle_t* h, int stream, int slot, const float* xy
   int rc = check_stream(h, stream);
   if (rc) return rc;
   if (!h->resident || slot < 0 || slot >= h->n_slots || n < 0 || n > h->v.max_points) { g_last_error = "bad resident slot"; return LIODOM_ERR_INVALID_ARG; }
+  SideLocks lk(h, false, true);
   float4* dst = h->resident + ((size_t)slot * h->S + stream) * (size_t)h->v.max_points;
   if (n) HIP_TRY(hipMemcpy(dst, xyzi, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice));
   return LIODOM_OK;
@@ -744,7 +797,9 @@ int liodom_process_resident(liodom_handle_t* h, int slot, int64_t n, int height,
 
 int liodom_process_resident_pipelined(liodom_handle_t* h, int slot, int next_slot, int64_t n, int height,
                                       int width, double* poses_out, liodom_step_info_t* infos_out) {
-  if (!h) return LIODOM_ERR_INVALID_ARG;
+  int rc0 = enter(h);
+  if (rc0) return rc0;
+  SideLocks lk(h, true, true);
   if (!h->resident || slot < 0 || slot >= h->n_slots || next_slot >= h->n_slots || n < 0 || n > h->v.max_points) {
     g_last_error = "bad resident slot"; return LIODOM_ERR_INVALID_ARG;
   }
@@ -772,7 +827,9 @@ int liodom_process_resident_pipelined(liodom_handle_t* h, int slot, int next_slo
 }
 
 int liodom_sync(liodom_handle_t* h) {
-  if (!h) return LIODOM_ERR_INVALID_ARG;
+  int rc0 = enter(h);
+  if (rc0) return rc0;
+  SideLocks lk(h, true, true);
   HIP_TRY(hipStreamSynchronize(h->stream_x));
   HIP_TRY(hipStreamSynchronize(h->stream));
   return LIODOM_OK;
@@ -783,6 +840,7 @@ int liodom_get_pose_log(liodom_handle_t* h, int stream, int first, int count, do
   int rc = check_stream(h, stream);
   if (rc) return rc;
   if (first < 0 || count < 0 || first + count > h->v.pose_log_cap) { g_last_error = "pose log range"; return LIODOM_ERR_INVALID_ARG; }
+  SideLocks lk(h, true, false);
   HIP_TRY(hipStreamSynchronize(h->stream));
   if (poses_out && count)
     HIP_TRY(hipMemcpy(poses_out, h->v.pose_log + ((size_t)stream * h->v.pose_log_cap + first) * 7, sizeof(double) * 7 * (size_t)count, hipMemcpyDeviceToHost));
@@ -791,9 +849,7 @@ int liodom_get_pose_log(liodom_handle_t* h, int stream, int first, int count, do
   return LIODOM_OK;
 }
 
-int liodom_get_window(liodom_handle_t* h, int stream, float* xyzi, int64_t cap, int64_t* n_points, int* n_frames) {
-  int rc = check_stream(h, stream);
-  if (rc) return rc;
+static int get_window_impl(liodom_handle_t* h, int stream, float* xyzi, int64_t cap, int64_t* n_points, int* n_frames) {
   HIP_TRY(hipStreamSynchronize(h->stream));
   StreamState st;
   HIP_TRY(hipMemcpy(&st, h->v.state + stream, sizeof(st), hipMemcpyDeviceToHost));
@@ -813,9 +869,17 @@ int liodom_get_window(liodom_handle_t* h, int stream, float* xyzi, int64_t cap, 
   return LIODOM_OK;
 }
 
+int liodom_get_window(liodom_handle_t* h, int stream, float* xyzi, int64_t cap, int64_t* n_points, int* n_frames) {
+  int rc = check_stream(h, stream);
+  if (rc) return rc;
+  SideLocks lk(h, true, false);
+  return get_window_impl(h, stream, xyzi, cap, n_points, n_frames);
+}
+
 int liodom_get_local_map(liodom_handle_t* h, int stream, float* xyzi, int64_t cap, int64_t* n_points, int* filtered) {
   int rc = check_stream(h, stream);
   if (rc) return rc;
+  SideLocks lk(h, true, false);
   HIP_TRY(hipStreamSynchronize(h->stream));
   StreamState st;
   HIP_TRY(hipMemcpy(&st, h->v.state + stream, sizeof(st), hipMemcpyDeviceToHost));
@@ -823,7 +887,7 @@ int liodom_get_local_map(liodom_handle_t* h, int stream, float* xyzi, int64_t ca
   if (st.n_filt == 0) {
     int nf = 0;
     int64_t nw = 0;
-    rc = liodom_get_window(h, stream, xyzi, cap, &nw, &nf);
+    rc = get_window_impl(h, stream, xyzi, cap, &nw, &nf);
     const int nr = h->v.mapping ? st.n_recv : 0;
     if (n_points) *n_points = nw + nr;
     if (rc) return rc;
@@ -854,6 +918,7 @@ int liodom_get_correspondences(liodom_handle_t* h, int stream, int it, int32_t* 
   int rc = check_stream(h, stream);
   if (rc) return rc;
   if (it < 0 || it > 1) return LIODOM_ERR_INVALID_ARG;
+  SideLocks lk(h, true, false);
   HIP_TRY(hipStreamSynchronize(h->stream));
   StreamState st;
   HIP_TRY(hipMemcpy(&st, h->v.state + stream, sizeof(st), hipMemcpyDeviceToHost));
@@ -874,6 +939,8 @@ int liodom_get_curvature(liodom_handle_t* h, int stream, double* curv, int64_t c
   int rc = check_stream(h, stream);
   if (rc) return rc;
   if (!h->v.curv_dbg) { g_last_error = "create the handle with debug_buffers = 1"; return LIODOM_ERR_UNSUPPORTED; }
+  SideLocks lk(h, true, true);
+  HIP_TRY(hipStreamSynchronize(h->stream_x));
   HIP_TRY(hipStreamSynchronize(h->stream));
   std::vector<int> np((size_t)h->H);
   HIP_TRY(hipMemcpy(np.data(), h->v.ring_npoints + (size_t)stream * h->H, sizeof(int) * h->H, hipMemcpyDeviceToHost));
@@ -891,15 +958,20 @@ int liodom_get_curvature(liodom_handle_t* h, int stream, double* curv, int64_t c
 }
 
 int liodom_set_profiling(liodom_handle_t* h, int enable) {
-  if (!h) return LIODOM_ERR_INVALID_ARG;
-  int rc = drain_events(h);
+  int rc = enter(h);
+  if (rc) return rc;
+  std::unique_lock<std::mutex> lo(h->mx_o), lx(h->mx_x);
+  rc = drain_events(h);
   h->profiling = enable != 0;
   return rc;
 }
 
 int liodom_get_kernel_stats(liodom_handle_t* h, liodom_kernel_stat_t* stats) {
   if (!h || !stats) return LIODOM_ERR_INVALID_ARG;
-  int rc = drain_events(h);
+  int rc = enter(h);
+  if (rc) return rc;
+  SideLocks lk(h, true, true);
+  rc = drain_events(h);
   if (rc) return rc;
   for (int i = 0; i < LIODOM_NUM_KERNELS; i++) {
     std::memset(&stats[i], 0, sizeof(stats[i]));
@@ -911,8 +983,10 @@ int liodom_get_kernel_stats(liodom_handle_t* h, liodom_kernel_stat_t* stats) {
 }
 
 int liodom_reset_kernel_stats(liodom_handle_t* h) {
-  if (!h) return LIODOM_ERR_INVALID_ARG;
-  int rc = drain_events(h);
+  int rc = enter(h);
+  if (rc) return rc;
+  SideLocks lk(h, true, true);
+  rc = drain_events(h);
   for (int i = 0; i < LIODOM_NUM_KERNELS; i++) { h->k_ms[i] = 0; h->k_count[i] = 0; }
   return rc;
 }
@@ -920,6 +994,7 @@ int liodom_reset_kernel_stats(liodom_handle_t* h) {
 /* debug: raw phase timestamps (100 MHz) written by the kernels when LIODOM_ABLATE has bit 5 set */
 int liodom_debug_clocks(liodom_handle_t* h, unsigned long long* out256) {
   if (!h || !out256) return LIODOM_ERR_INVALID_ARG;
+  SideLocks lk(h, true, true);
   HIP_TRY(hipStreamSynchronize(h->stream_x));
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(hipMemcpy(out256, h->v.dbg_clk, sizeof(unsigned long long) * 256, hipMemcpyDeviceToHost));
@@ -931,6 +1006,12 @@ int liodom_device_count(int* count) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
   *count = n;
+  return LIODOM_OK;
+}
+
+int liodom_device_pci_bus_id(int device, char* bus_id, int cap) {
+  if (!bus_id || cap < 16) return LIODOM_ERR_INVALID_ARG;
+  HIP_TRY(hipDeviceGetPCIBusId(bus_id, cap, device));
   return LIODOM_OK;
 }
 

@@ -39,6 +39,8 @@ constexpr int kLmThreads = 512;
 constexpr int kLmGroupsMax = 8;
 constexpr int kKnnGroup = 32;            // lanes cooperating on one query
 constexpr int kMaxFrames = 256;          // window frames supported by the LDS prefix tables
+constexpr int kEdgeBufs = 3;             // dense edge buffers: 0 / 1 odometry side (double-buffered), 2 extraction side
+constexpr int kEdgeBufX = 2;
 
 // Per-stream device state.
 struct StreamState {
@@ -51,7 +53,8 @@ struct StreamState {
   int32_t append_raw;     // first frame: edges enter the window untransformed (:123)
   int32_t frame_count;    // frames ever appended
   int32_t n_frames;       // frames in the window (nframes_)
-  int32_t n_edges_buf[2]; // edges of the scan in edge buffer 0 / 1 (extraction of scan k+1 overlaps odometry of scan k)
+  int32_t n_edges_buf[3]; // edges in edge buffer 0 / 1 (pipelined replay: extraction of scan k+1 overlaps odometry of scan k) / 2 (liodom_extract_edges)
+  int32_t pad0_;
   int32_t n_map;          // window points covered by the voxel hash
   int32_t n_used;         // occupied hash cells (current build)
   int32_t n_used_prev;    // occupied cells of the previous build (to clear)
@@ -115,8 +118,8 @@ struct DevView {
   int* ring_nedges;         // [S][H]
   int* ring_npoints;        // [S][H]
   double* curv_dbg;         // [S][H][ring_cap] or null
-  float4* edges;            // [2][S][edge_cap] dense, double-buffered
-  int4* edges_meta;         // [2][S][edge_cap] (ring, idx_in_ring, src, 0)
+  float4* edges;            // [kEdgeBufs][S][edge_cap] dense
+  int4* edges_meta;         // [kEdgeBufs][S][edge_cap] (ring, idx_in_ring, src, 0)
   float4* corr_a;           // [S][edge_cap]  xyz of NN0, w = valid
   float4* corr_b;           // [S][edge_cap]  xyz of NN1
   int2* corr_idx;           // [S][2][edge_cap] window indices of (NN0, NN1), debug/parity

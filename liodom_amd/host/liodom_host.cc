@@ -4,6 +4,7 @@
 #include <cstring>
 #include <fstream>
 #include <stdexcept>
+#include <thread>
 
 namespace liodom {
 
@@ -69,7 +70,8 @@ liodom_params_t Params::toC() const {
 }
 
 Stats* Stats::getInstance() { static Stats inst; return &inst; }
-void Stats::addPose(const std::array<double, 12>& p) { poses_.push_back(p); }
+void Stats::addPose(const std::array<double, 12>& p) { poses_.push_back(p); n_poses_.fetch_add(1, std::memory_order_release); }
+size_t Stats::numPoses() { return n_poses_.load(std::memory_order_acquire); }
 void Stats::addFeatureExtractionTime(const Clock::time_point& s, const Clock::time_point& e) {
   feat_extr_.push_back((double)std::chrono::duration_cast<std::chrono::milliseconds>(e - s).count());   // whole ms, stats.cc:42
 }
@@ -86,7 +88,7 @@ void Stats::stopFrame(const Clock::time_point& stop) {
     frame_times_.push_back((double)std::chrono::duration_cast<std::chrono::milliseconds>(stop - start).count());
   }
 }
-void Stats::clear() { poses_.clear(); feat_extr_.clear(); laser_odom_.clear(); frame_times_.clear(); num_of_features_.clear(); }
+void Stats::clear() { n_poses_ = 0; poses_.clear(); feat_extr_.clear(); laser_odom_.clear(); frame_times_.clear(); num_of_features_.clear(); }
 
 // File formats of Stats::writeResults (stats.cc:73-132): poses.txt = KITTI rows of the top 3x4 of
 // the pose with default ostream precision; the other files one value per line.
@@ -112,6 +114,34 @@ void Stats::writeResults(const std::string& dir) {
     for (size_t x : num_of_features_) f << x << std::endl;
   }
   dump("frame_times.txt", frame_times_);
+}
+
+SharedData* SharedData::getInstance() { static SharedData inst; return &inst; }
+void SharedData::pushPointCloud(const PointCloud& pc_in, double stamp) {
+  std::lock_guard<std::mutex> lk(pc_mutex_);
+  pc_buf_.push(std::make_pair(pc_in, stamp));
+}
+bool SharedData::popPointCloud(PointCloud& pc_out, double& stamp) {
+  std::lock_guard<std::mutex> lk(pc_mutex_);
+  if (pc_buf_.empty()) return false;
+  pc_out = std::move(pc_buf_.front().first); stamp = pc_buf_.front().second;
+  pc_buf_.pop();
+  return true;
+}
+void SharedData::pushFeatures(const PointCloud& feat_in, double stamp) {
+  std::lock_guard<std::mutex> lk(feat_mutex_);
+  feat_buf_.push(std::make_pair(feat_in, stamp));
+}
+bool SharedData::popFeatures(PointCloud& feat_out, double& stamp) {
+  std::lock_guard<std::mutex> lk(feat_mutex_);
+  if (feat_buf_.empty()) return false;
+  feat_out = std::move(feat_buf_.front().first); stamp = feat_buf_.front().second;
+  feat_buf_.pop();
+  return true;
+}
+void SharedData::clear() {
+  std::lock_guard<std::mutex> a(pc_mutex_), b(feat_mutex_);
+  pc_buf_ = {}; feat_buf_ = {};
 }
 
 Engine::Engine(const Params& p, int device, int max_points, int max_width, int pose_rotation_mode) {
@@ -141,6 +171,19 @@ void FeatureExtractor::extractFeatures(const PointCloud& pc_in, PointCloud& pc_e
   if (params->save_results_) {                                        // feature_extractor.cc:65-68
     stats->addFeatureExtractionTime(start_t, Clock::now());
     stats->addNumOfFeats(pc_edges.size());
+  }
+}
+
+void FeatureExtractor::operator()(std::atomic<bool>& running) {
+  SharedData* sdata = SharedData::getInstance();
+  while (running) {                                                   // feature_extractor.cc:46
+    PointCloud pc_curr, pc_edges;
+    double stamp = 0;
+    if (sdata->popPointCloud(pc_curr, stamp)) {                       // :49
+      extractFeatures(pc_curr, pc_edges);                             // :53-59
+      sdata->pushFeatures(pc_edges, stamp);                           // :77
+    }
+    std::this_thread::sleep_for(std::chrono::milliseconds(2));        // :80
   }
 }
 
@@ -246,6 +289,21 @@ Pose LaserOdometer::process(const PointCloud& feats, double stamp, liodom_step_i
     stats->stopFrame(end_t);
   }
   return out;
+}
+
+void LaserOdometer::operator()(std::atomic<bool>& running, std::vector<OdometryMsg>* published, std::vector<Pose>* poses) {
+  SharedData* sdata = SharedData::getInstance();
+  while (running) {                                                   // laser_odometry.cc:102
+    PointCloud feats;
+    double stamp = 0;
+    if (sdata->popFeatures(feats, stamp)) {                           // :107
+      const Pose p = process(feats, stamp);                           // :108-235
+      const OdometryMsg msg = publishOdom(stamp, p);                  // :265
+      if (published) published->push_back(msg);
+      if (poses) poses->push_back(p);
+    }
+    std::this_thread::sleep_for(std::chrono::milliseconds(2));        // :270
+  }
 }
 
 Pose LaserOdometer::processScan(const PointCloud& pc_in, double stamp, liodom_step_info_t* info) {

@@ -9,10 +9,12 @@
 //   liodom::LocalMapManager   include/liodom/laser_odometry.h:62-76 (read-only view of the device window)
 //   liodom::Stats             include/liodom/stats.h:40-80, src/stats.cc (result files)
 //   liodom::Map               include/liodom/map.h:93-116, src/map.cc (mapping node's map, on the device)
+//   liodom::SharedData        include/liodom/shared_data.h:40-86, src/shared_data.cc (the two hand-over queues)
 // Like the reference the hot-path methods return void and report problems through a log hook;
 // unlike it, failures of the GPU library also raise std::runtime_error (nothing falls back to CPU).
 #pragma once
 #include <array>
+#include <atomic>
 #include <chrono>
 #include <cstdint>
 #include <memory>
@@ -77,12 +79,29 @@ class Stats {
   void stopFrame(const Clock::time_point& stop);                                                // :60
   void writeResults(const std::string& dir);                                                    // :73-132
   void clear();
+  size_t numPoses();
  private:
   std::vector<std::array<double, 12>> poses_;
+  std::atomic<size_t> n_poses_{0};
   std::vector<double> feat_extr_, laser_odom_, frame_times_;
   std::vector<size_t> num_of_features_;
   std::mutex frame_mutex_;
   std::queue<Clock::time_point> start_times_;
+};
+
+// The mutex-guarded FIFOs between the ROS callback, the extractor thread and the odometer thread
+// (src/shared_data.cc:37-89).  Headers carry only the stamp here.
+class SharedData {
+ public:
+  static SharedData* getInstance();
+  void pushPointCloud(const PointCloud& pc_in, double stamp);          // shared_data.cc:37-42
+  bool popPointCloud(PointCloud& pc_out, double& stamp);               // :44-62
+  void pushFeatures(const PointCloud& feat_in, double stamp);          // :64-69
+  bool popFeatures(PointCloud& feat_out, double& stamp);               // :71-89
+  void clear();
+ private:
+  std::mutex pc_mutex_, feat_mutex_;
+  std::queue<std::pair<PointCloud, double>> pc_buf_, feat_buf_;
 };
 
 // Owns the GPU handle shared by the extractor and the odometer of one stream.
@@ -107,6 +126,10 @@ class FeatureExtractor {
   void extractFeatures(const PointCloud& pc_in, PointCloud& pc_edges);
   // the edges of the last scan that went through LaserOdometer::processScan (the ~edges topic, :70-75)
   void lastEdges(PointCloud& pc_edges);
+  // The worker loop of the extractor thread (feature_extractor.cc:42-82): pop a cloud, extract,
+  // push the features; polls every 2 ms like the reference.  Runs on the extraction side of the
+  // handle, concurrently with LaserOdometer::operator() (liodom_node.cc:89-91).
+  void operator()(std::atomic<bool>& running);
  private:
   std::shared_ptr<Engine> eng_;
   Params* params;
@@ -167,6 +190,9 @@ class LaserOdometer {
   Pose process(const PointCloud& feats, double stamp, liodom_step_info_t* info = nullptr);
   // lidarClb -> extractor -> odometer without leaving the device (one H2D copy, one result record)
   Pose processScan(const PointCloud& pc_in, double stamp, liodom_step_info_t* info = nullptr);
+  // The worker loop of the odometer thread (laser_odometry.cc:100-272): pop features, process, publish.
+  // `published` (optional) receives every message in order.
+  void operator()(std::atomic<bool>& running, std::vector<OdometryMsg>* published = nullptr, std::vector<Pose>* poses = nullptr);
   LocalMapManager lmap_manager;
  private:
   std::shared_ptr<Engine> eng_;

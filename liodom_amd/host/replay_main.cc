@@ -6,12 +6,16 @@
 // With mapping=true the liodom_mapping node (launch/liodom.launch:41-56) is replayed on the device
 // with its launch-file parameters (voxel_xysize= voxel_zsize= resolution= cells_xy= cells_z=); the
 // final map is written to <out_dir>map.bin (float32 x y z i).
+// threads=true runs the reference's own structure instead of the fused per-scan call: the clouds are
+// pushed into SharedData (lidarClb), a FeatureExtractor thread and a LaserOdometer thread work side by
+// side on the same handle (src/liodom_node.cc:89-91) and hand edge clouds over through the queue.
 #include <algorithm>
 #include <cstdio>
 #include <dirent.h>
 #include <fstream>
 #include <iostream>
 #include <memory>
+#include <thread>
 
 #include "liodom_host.h"
 
@@ -67,8 +71,40 @@ int main(int argc, char** argv) {
       odometer.attachMapper(mapper.get(), cells_xy, cells_z);
     }
     std::ofstream odom_log(out + "odom.txt");      // stamp, orientation xyzw, position, twist linear, twist angular
-    odom_log.precision(12);
-    for (size_t i = 0; i < clouds.size(); i++) {
+    odom_log.precision(17);
+    bool threads = false;
+    for (const std::string& a : kv) if (a == "threads=true" || a == "threads=1") threads = true;
+    if (threads) {
+      liodom::FeatureExtractor extractor(eng);
+      liodom::SharedData* sdata = liodom::SharedData::getInstance();
+      std::vector<liodom::OdometryMsg> msgs;
+      std::atomic<bool> running{true};
+      std::thread feat_thread([&] { extractor(running); });                 // liodom_node.cc:89
+      std::thread odom_thread([&] { odometer(running, &msgs, nullptr); });   // liodom_node.cc:90-91
+      for (size_t i = 0; i < clouds.size(); i++) {
+        if (params->save_results_) liodom::Stats::getInstance()->startFrame(liodom::Clock::now());   // lidarClb :49-52
+        sdata->pushPointCloud(clouds[i], 0.1 * (double)i);                 // lidarClb :54
+      }
+      // (msgs is appended by the odometer thread only; its size is polled until every scan is through)
+      for (int spin = 0; spin < 60000; spin++) {
+        std::this_thread::sleep_for(std::chrono::milliseconds(5));
+        if (liodom::Stats::getInstance()->numPoses() >= clouds.size()) break;
+      }
+      running = false;
+      feat_thread.join();
+      odom_thread.join();
+      for (const liodom::OdometryMsg& msg : msgs) {
+        odom_log << msg.stamp;
+        for (double v : msg.orientation) odom_log << ' ' << v;
+        for (double v : msg.position) odom_log << ' ' << v;
+        for (double v : msg.linear) odom_log << ' ' << v;
+        for (double v : msg.angular) odom_log << ' ' << v;
+        odom_log << '\n';
+      }
+      std::printf("threads: %zu scans through the extractor / odometer threads\n", msgs.size());
+      if (msgs.size() != clouds.size()) { std::fprintf(stderr, "liodom_replay: %zu of %zu scans processed\n", msgs.size(), clouds.size()); return 1; }
+    }
+    for (size_t i = 0; i < clouds.size() && !threads; i++) {
       liodom_step_info_t info;
       liodom::Pose p = odometer.processScan(clouds[i], 0.1 * (double)i, &info);
       const liodom::OdometryMsg msg = odometer.publishOdom(0.1 * (double)i, p);      // ~odom / ~twist numbers

@@ -44,6 +44,34 @@ class Replicas:
     def device(self):
         return self.local_rank
 
+    def pin_cpus(self, device):
+        """Best effort: restrict this process to the CPUs of the NUMA node the GPU hangs off
+        (/sys/bus/pci/devices/<bus id>/local_cpulist) — the host thread busy-polls the host-mapped result
+        record of every scan, and N replicas should not share one socket's cores by accident.  Returns
+        the CPU set in use (None if nothing was changed)."""
+        self.cpus = None
+        try:
+            from . import api
+            bus = api.device_pci_bus_id(device)
+            if not bus:
+                return None
+            path = "/sys/bus/pci/devices/%s/local_cpulist" % bus.lower()
+            if not os.path.exists(path):
+                return None
+            cpus = set()
+            for part in open(path).read().strip().split(","):
+                if not part:
+                    continue
+                lo, _, hi = part.partition("-")
+                cpus.update(range(int(lo), int(hi or lo) + 1))
+            allowed = os.sched_getaffinity(0) & cpus
+            if allowed:
+                os.sched_setaffinity(0, allowed)
+                self.cpus = sorted(allowed)
+        except Exception:
+            return None
+        return self.cpus
+
     def barrier(self):
         if self.dist:
             self.dist.barrier()

@@ -60,6 +60,15 @@ struct orc_params_t {
 
 namespace {
 
+// Thread policy of the reference, for the timed CPU baseline only (results do not depend on it):
+//   stencil loop   #pragma omp parallel for num_threads(ncores_), ncores_ = max(2, omp_get_max_threads() - 5)
+//                  (src/feature_extractor.cc:29-34,194)
+//   residual eval  ceres::Solver::Options::num_threads = nproc (src/laser_odometry.cc:216): Ceres evaluates the
+//                  residual blocks in parallel; the linear solve stays serial
+// 1 / 1 = everything serial (default).
+int g_stencil_threads = 1;
+int g_eval_threads = 1;
+
 struct P4 { float x, y, z, i; };
 
 // ------------------------------------------------------------------------------------------
@@ -194,6 +203,7 @@ void extract_features(const orc_params_t& p, const P4* pc,
     std::vector<SmoothnessItem> smooths_aux(n);                                        // :193
     std::vector<uint8_t> picked(n, 0);  // picked_ is reset only for j in [5, n-5) (:230);
                                         // entries outside are written but never read.
+#pragma omp parallel for num_threads(g_stencil_threads) if (g_stencil_threads > 1)           // :194
     for (int64_t j = 5; j < n - 5; j++) {                                              // :195
       // The operands are pcl::PointXYZI floats and `10 * x` is int * float, so each sum is a
       // FLOAT expression evaluated left to right (x86-64 SSE, FLT_EVAL_METHOD 0) and only the
@@ -797,15 +807,20 @@ void lm_solve(const std::vector<Corr>& blocks, double q[4], double t[3], double 
   const int m = 3 * C;
   std::vector<double> r(m), J((size_t)m * 6);
   double xq[4] = {q[0], q[1], q[2], q[3]}, xt[3] = {t[0], t[1], t[2]};
+  std::vector<double> blk_cost(C), blk_r((size_t)3 * C), blk_J((size_t)18 * C);
+  std::vector<char> blk_ok(C);
   auto evaluate = [&](const double* eq, const double* et, bool jac, double* cost, std::vector<double>& rr, std::vector<double>& JJ) -> bool {
+    // blocks in parallel (Ceres' evaluator threads), totals summed in block order: same bits for any thread count
+#pragma omp parallel for num_threads(g_eval_threads) if (g_eval_threads > 1) schedule(static)
+    for (int i = 0; i < C; i++)
+      blk_ok[i] = eval_block(blocks[i], eq, et, min_d, max_d, jac, &blk_cost[i], &blk_r[(size_t)3 * i], &blk_J[(size_t)18 * i]) ? 1 : 0;
     double total = 0;
     for (int i = 0; i < C; i++) {
-      double c1, rb[3], Jb[18];
-      if (!eval_block(blocks[i], eq, et, min_d, max_d, jac, &c1, rb, Jb)) return false;
-      total += c1;
+      if (!blk_ok[i]) return false;
+      total += blk_cost[i];
       if (jac) {
-        for (int k = 0; k < 3; k++) rr[3 * i + k] = rb[k];
-        for (int k = 0; k < 18; k++) JJ[(size_t)(3 * i) * 6 + k] = Jb[k];
+        for (int k = 0; k < 3; k++) rr[3 * i + k] = blk_r[(size_t)3 * i + k];
+        for (int k = 0; k < 18; k++) JJ[(size_t)(3 * i) * 6 + k] = blk_J[(size_t)18 * i + k];
       }
     }
     *cost = total;
@@ -1461,6 +1476,11 @@ void orc_transform(const double* T12, const float* in, int64_t n, float* out) {
   for (int64_t i = 0; i < n; i++) po[i] = transform_point(T, pi[i]);
 }
 void orc_debug_fail_linear_solves(int n) { g_fail_linear_solves = n; }
+// CPU-baseline thread policy (see g_stencil_threads): 0 keeps the current value.
+void orc_set_threads(int stencil_threads, int eval_threads) {
+  if (stencil_threads > 0) g_stencil_threads = stencil_threads;
+  if (eval_threads > 0) g_eval_threads = eval_threads;
+}
 // Transform::rotation() alone (unit tests): T12 in -> T12 out
 void orc_rotation_of(const double* T12, int mode, double* out12) {
   Iso T; for (int k = 0; k < 12; k++) T.m[k] = T12[k];

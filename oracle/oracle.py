@@ -46,10 +46,29 @@ class StepInfo(C.Structure):
     _fields_ = [("n_edges", C.c_int32), ("map_points", C.c_int32), ("matches", C.c_int32 * 2), ("lm", LmTrace * 2)]
 
 
+def _src_hash():
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("liodom_oracle.cc", "Makefile"):
+        with open(os.path.join(_HERE, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def build(force=False):
-    src = os.path.join(_HERE, "liodom_oracle.cc")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    """(Re)builds the oracle library when its source hash differs from the one recorded at its last
+    build (mtimes do not survive the copy to the GPU box)."""
+    import fcntl
+    os.makedirs(os.path.join(_HERE, "_build"), exist_ok=True)
+    stamp = _LIB_PATH + ".srchash"
+    with open(_LIB_PATH + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        want = _src_hash()
+        have = open(stamp).read().strip() if os.path.exists(stamp) else ""
+        if force or not os.path.exists(_LIB_PATH) or have != want:
+            subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+            with open(stamp, "w") as f:
+                f.write(want + "\n")
     return _LIB_PATH
 
 
@@ -59,8 +78,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_LIB_PATH):
-            build()
+        build()
         L = C.CDLL(_LIB_PATH)
         fp = C.POINTER(C.c_float)
         dp = C.POINTER(C.c_double)
@@ -77,6 +95,7 @@ def lib():
         L.orc_imu_override.argtypes = [dp, dp, dp, dp, C.c_int]
         L.orc_publish_odom.argtypes = [dp, dp, dp, C.c_double, dp, C.c_int]
         L.orc_rotation_of.argtypes = [dp, C.c_int, dp]
+        L.orc_set_threads.argtypes = [C.c_int, C.c_int]
         L.orc_odom_step.restype = C.c_int
         L.orc_odom_step.argtypes = [C.c_void_p, fp, C.c_int, dp, C.POINTER(StepInfo)]
         L.orc_odom_last_corr.restype = C.c_int
@@ -300,6 +319,12 @@ def publish_odom(prev34, cur34, dt, l2b34=None, rotation_mode=1):
     out = np.zeros(13)
     lib().orc_publish_odom(_dp(P), _dp(T), _dp(L), float(dt), _dp(out), int(rotation_mode))
     return out
+
+
+def set_threads(stencil_threads=1, eval_threads=1):
+    """Thread policy of the timed CPU baseline (results are identical for any setting).  The reference's:
+    stencil = max(2, omp_get_max_threads() - 5) (feature_extractor.cc:29-34), eval = nproc (laser_odometry.cc:216)."""
+    lib().orc_set_threads(int(stencil_threads), int(eval_threads))
 
 
 def rotation_of(T34, mode=1):

@@ -1,0 +1,138 @@
+"""The reference's two-thread pipeline through the C-ABI: a FeatureExtractor thread one (or more)
+scans ahead of a LaserOdometer thread on the SAME handle (src/liodom_node.cc:89-91; hand-over queue
+src/shared_data.cc:64-89).  liodom_extract_edges works on the handle's extraction side,
+liodom_odometry_step on its odometry side; run concurrently they must give the same bits as the
+serial order extract(k) -> odometry(k) -> extract(k+1) -> ..."""
+import os
+import queue
+import subprocess
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = {
+    # BASELINE.json configs[0] and configs[2]
+    "cfg1_16x900": dict(H=16, W=900, lt=0, R=6, epr=10, P=5, K=30),
+    "cfg3_64x1800": dict(H=64, W=1800, lt=0, R=8, epr=10, P=20, K=30),
+}
+
+
+def _handle(c):
+    import liodom_amd as la
+    return la.Liodom(la.make_params(lidar_type=c["lt"], scan_lines=c["H"], scan_regions=c["R"], edges_per_region=c["epr"],
+                                    prev_frames=c["P"]),
+                     la.make_config(max_points=c["H"] * c["W"], max_width=c["W"]))
+
+
+@pytest.mark.parametrize("name", sorted(CONFIGS))
+def test_extractor_thread_ahead_of_odometer_thread(synth, name):
+    c = CONFIGS[name]
+    H, W, K = c["H"], c["W"], c["K"]
+    cfg = synth.make_cfg(H, W, c["lt"])
+    scans = [synth.scan(cfg, 4, k)[0] for k in range(K)]
+
+    # serial order on one thread
+    g = _handle(c)
+    serial_edges, serial_poses, serial_info = [], [], []
+    for k in range(K):
+        e = g.extract_edges(scans[k], H, W)
+        pose, info = g.odometry_step(e["edges"], stamp=0.1 * k)
+        serial_edges.append(e)
+        serial_poses.append(pose)
+        serial_info.append((info.n_edges, tuple(info.matches), info.lm[0].iterations, info.lm[1].iterations, info.status))
+    g.close()
+
+    # two threads, unbounded queue (the reference has no back-pressure either): the extractor runs ahead
+    g = _handle(c)
+    feats = queue.Queue()
+    poses, infos, edges_t, errors = [], [], [], []
+    ahead = []                       # how many scans the extractor was ahead whenever the odometer took one
+    t_ext, t_odo = [], []            # (start, end) of every call, to show that the two sides really overlap
+    done = threading.Event()
+    import time
+
+    def extractor():
+        try:
+            for k in range(K):
+                t0 = time.perf_counter()
+                e = g.extract_edges(scans[k], H, W)      # ctypes releases the GIL inside the call
+                t_ext.append((t0, time.perf_counter()))
+                edges_t.append(e)
+                feats.put((k, e["edges"]))
+        except Exception as ex:       # pragma: no cover
+            errors.append(ex)
+        finally:
+            done.set()
+            feats.put(None)
+
+    def odometer():
+        try:
+            while True:
+                item = feats.get()
+                if item is None:
+                    break
+                k, ed = item
+                # stay one scan behind: scan k enters odometry once the extractor has finished scan k + 1
+                # (or everything), so extract(k + 2) runs while odometry(k) does
+                while len(edges_t) < k + 2 and not done.is_set():
+                    time.sleep(0.0002)
+                ahead.append(len(edges_t) - 1 - k)
+                t0 = time.perf_counter()
+                pose, info = g.odometry_step(ed, stamp=0.1 * k)
+                t_odo.append((t0, time.perf_counter()))
+                poses.append(pose)
+                infos.append((info.n_edges, tuple(info.matches), info.lm[0].iterations, info.lm[1].iterations, info.status))
+        except Exception as ex:       # pragma: no cover
+            errors.append(ex)
+
+    ta, tb = threading.Thread(target=extractor), threading.Thread(target=odometer)
+    ta.start(); tb.start()
+    ta.join(timeout=300); tb.join(timeout=300)
+    assert not errors, errors
+    assert len(poses) == K
+    for k in range(K):
+        for key in ("edges", "ring", "idx_in_ring", "src"):
+            assert np.array_equal(edges_t[k][key].view(np.uint32) if key == "edges" else edges_t[k][key],
+                                  serial_edges[k][key].view(np.uint32) if key == "edges" else serial_edges[k][key]), (k, key)
+        assert np.array_equal(poses[k].view(np.uint64), serial_poses[k].view(np.uint64)), k      # bit-equal poses
+        assert infos[k] == serial_info[k], k
+        assert infos[k][4] == 0                                                                  # no overflow status
+    assert min(ahead[:K - 1]) >= 1, "the extractor was not ahead of the odometer"
+    overlaps = sum(1 for (a0, a1) in t_ext for (b0, b1) in t_odo if a0 < b1 and b0 < a1)
+    assert overlaps >= K // 4, "extract_edges and odometry_step calls of the two threads never overlapped in time"
+    # the inspection calls still work after the threaded run
+    w, nf = g.window()
+    assert nf == min(K, c["P"])
+    g.close()
+
+
+def test_threaded_replay_harness_equals_fused_replay(synth, tmp_path):
+    """liodom_amd/host: the C++ mirror's FeatureExtractor::operator() / LaserOdometer::operator() worker
+    loops on two std::threads (liodom_replay threads=true) against the fused per-scan call."""
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "liodom_amd", "host", "liodom_replay")
+    if not os.path.exists(exe):
+        pytest.skip("liodom_replay not built (run __graft_entry__.build())")
+    H, W, K = 16, 900, 30
+    cfg = synth.make_cfg(H, W, 0)
+    scan_dir = tmp_path / "scans"
+    scan_dir.mkdir()
+    for k in range(K):
+        synth.scan(cfg, 0, k)[0].astype(np.float32).tofile(str(scan_dir / ("%06d.bin" % k)))
+    outs = {}
+    for mode in ("fused", "threads"):
+        out_dir = tmp_path / mode
+        out_dir.mkdir()
+        args = [exe, str(scan_dir), str(out_dir) + "/", "scan_lines=16", "scan_regions=6", "edges_per_region=10", "prev_frames=5"]
+        if mode == "threads":
+            args.append("threads=true")
+        r = subprocess.run(args, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr + r.stdout
+        outs[mode] = np.loadtxt(str(out_dir / "odom.txt")).reshape(K, -1)
+        assert np.loadtxt(str(out_dir / "poses.txt")).reshape(-1, 12).shape == (K, 12)
+        assert len(np.loadtxt(str(out_dir / "nfeats.txt"))) == K
+    a, b = outs["fused"], outs["threads"]
+    assert np.array_equal(a[:, :8], b[:, :8])                 # stamp, orientation, position: identical digits
+    assert np.allclose(a[1:, 8:], b[1:, 8:], rtol=0, atol=1e-9)   # twist (first row is 0/0 = NaN in both, :125,136)

@@ -9,8 +9,19 @@ OUT=$R/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd $R
-timeout 900 python -m pytest tests -m gpu -q > $OUT/${TAG}_pytest_gpu.log 2>&1
-timeout 600 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.stderr
+if [ "${SKIP_PYTEST:-0}" != "1" ]; then timeout 1200 python -m pytest tests -m gpu -q > $OUT/${TAG}_pytest_gpu.log 2>&1; fi
+timeout 900 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.stderr
+if [ "${OTHER_WORKLOADS:-1}" = "1" ]; then
+  for WLD in vlp16 ouster128; do
+    timeout 600 python bench.py --workload $WLD --batched-streams 0 > $OUT/${TAG}_bench_${WLD}.json 2> $OUT/${TAG}_bench_${WLD}.stderr
+    ( cd /tmp; rm -rf $OUT/prof_kt_$WLD
+      timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_kt_$WLD -- python3 $R/bench.py --workload $WLD --steps 100 --warmup 20 --batched-streams 0 --no-cpu-baseline > /dev/null 2> $OUT/kt_$WLD.stderr
+      DBW=$(find $OUT/prof_kt_$WLD -name "*.db" | head -1)
+      { echo "# $TAG: rocprofv3 --kernel-trace --stats -- python3 bench.py --workload $WLD --steps 100 --warmup 20 --batched-streams 0 --no-cpu-baseline";
+        python3 $R/tools/rocprof_summary.py $DBW; } > $OUT/${TAG}_bench_${WLD}_kernel_trace.txt
+      rm -rf $OUT/prof_kt_$WLD )
+  done
+fi
 cd /tmp
 rm -rf $OUT/prof_kt $OUT/prof_fetch $OUT/prof_write
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_kt -- python3 $R/bench.py --steps 100 --warmup 20 --batched-streams 0 --no-cpu-baseline > $OUT/${TAG}_kt_bench.json 2> $OUT/kt.stderr
@@ -26,4 +37,4 @@ WD=$(dirname $(find $OUT/prof_write -name "*.db" | head -1))
   echo "# small grid = 1 stream (headline), large grid = 16 lock-step streams. Per-launch averages.";
   python3 $R/tools/pmc_summary.py $FD $WD $OUT/${TAG}_pmc_traffic.json; } > $OUT/${TAG}_pmc_traffic.txt
 rm -rf $OUT/prof_kt $OUT/prof_fetch $OUT/prof_write
-tail -3 $OUT/${TAG}_pytest_gpu.log; cat $OUT/${TAG}_bench.json | head -c 600; echo; head -14 $OUT/${TAG}_bench_kernel_trace.txt; head -30 $OUT/${TAG}_pmc_traffic.txt
+tail -3 $OUT/${TAG}_pytest_gpu.log 2>/dev/null; cat $OUT/${TAG}_bench.json | head -c 600; echo; head -14 $OUT/${TAG}_bench_kernel_trace.txt; head -30 $OUT/${TAG}_pmc_traffic.txt
