@@ -44,7 +44,7 @@ extern "C" {
 #define LIODOM_ERR_NO_DEVICE (-5)
 
 /* Sticky per-stream status bits reported in liodom_step_info_t.status */
-#define LIODOM_STATUS_RING_OVERFLOW 1u  /* a ring had more points than max_ring_points; it was skipped */
+#define LIODOM_STATUS_RING_OVERFLOW 1u  /* (no longer raised: rings of any length are processed) */
 #define LIODOM_STATUS_EDGE_OVERFLOW 2u
 #define LIODOM_STATUS_HASH_FULL 4u
 #define LIODOM_STATUS_LM_SYNC_TIMEOUT 8u  /* cooperating LM workgroups did not all arrive (result invalid) */
@@ -76,8 +76,8 @@ typedef struct liodom_config_t {
   int32_t device;            /* HIP device ordinal */
   int32_t n_streams;         /* independent streams advanced in lock-step (>= 1) */
   int32_t max_points;        /* capacity: points per scan (H*W) */
-  int32_t max_width;         /* expected points per ring; sizes the per-ring LDS tile */
-  int32_t max_ring_points;   /* 0 = derive from max_width (round_up(w + w/8, 256)); <= 6144 */
+  int32_t max_width;         /* expected points per ring (informational: no per-ring capacity exists any more) */
+  int32_t max_ring_points;   /* unused (kept for layout compatibility) */
   int32_t lm_apply_step_on_ftol; /* 0 = Ceres >= 1.12 behaviour (LM section) */
   int32_t pose_log_capacity; /* scans kept in the device-side pose log (resident replay) */
   int32_t debug_buffers;     /* 1 = keep per-ring smoothness dumps for liodom_get_curvature */

@@ -155,7 +155,9 @@ int launch_extract(liodom_handle* h, hipStream_t q, int eb, int s0, int count, c
   }
   {
     ProfScope ps(h, KID_RING_EXTRACT, q);
-    hipLaunchKernelGGL(k_ring_extract, dim3(h->H, count), dim3(kExThreads), h->ring_lds_bytes, q, v, s0);
+    const int ext = ring_extract_threads(v.scan_regions);
+    if (ext <= 256) hipLaunchKernelGGL(k_ring_extract<256>, dim3(h->H, count), dim3(ext), h->ring_lds_bytes, q, v, s0);
+    else hipLaunchKernelGGL(k_ring_extract<1024>, dim3(h->H, count), dim3(ext), h->ring_lds_bytes, q, v, s0);
   }
   {
     ProfScope ps(h, KID_COMPACT, q);
@@ -429,14 +431,12 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   v.vox_inv = 1.0f / 0.4f;                                                          // setLeafSize(0.4) :290
   v.n_streams = h->S;
   v.max_points = config->max_points;
-  int width = config->max_width > 0 ? config->max_width : std::max(1, config->max_points / params->scan_lines);
-  int ring_cap = config->max_ring_points > 0 ? config->max_ring_points : round_up(width + width / 8, 256);
-  ring_cap = round_up(std::max(ring_cap, 256), 16);
-  if (ring_cap > 6144) { g_last_error = "max_ring_points exceeds the 160 KiB LDS tile (6144 points)"; return fail(LIODOM_ERR_CAPACITY); }
-  v.ring_cap = ring_cap;
+  // (max_width / max_ring_points are kept in the config for compatibility: k_ring_extract stages nothing per
+  // point in LDS any more, so there is no per-ring capacity — a ring may hold up to max_points points)
+  v.ring_cap = config->max_points;
   v.slots_per_ring = params->scan_regions * (params->edges_per_region + 1);
-  h->ring_lds_bytes = ring_extract_lds_bytes(ring_cap, v.slots_per_ring, params->scan_regions);
-  if (h->ring_lds_bytes > 160 * 1024) { g_last_error = "ring tile + pick lists exceed 160 KiB of LDS"; return fail(LIODOM_ERR_CAPACITY); }
+  h->ring_lds_bytes = ring_extract_lds_bytes(v.slots_per_ring, params->scan_regions);
+  if (h->ring_lds_bytes > 160 * 1024) { g_last_error = "pick lists (scan_regions * (edges_per_region + 1)) exceed 160 KiB of LDS"; return fail(LIODOM_ERR_CAPACITY); }
   v.edge_cap = round_up(std::max(1, h->H * v.slots_per_ring), 64);
   v.use_imu = params->use_imu ? 1 : 0;
   iso_identity(v.laser_to_base);
@@ -457,14 +457,15 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   ALLOC(v.ring_id, S * v.ring_id_stride, 0xFF);
   v.tile_cap = std::max(1, cdiv(config->max_points, kTilePts));
   ALLOC(v.tile_hist, S * (size_t)v.tile_cap * h->H, 0);
-  ALLOC(v.ring_pts, S * (size_t)config->max_points, 0);
+  ALLOC(v.ring_pts, S * (size_t)config->max_points + 64, 0);     // + padding: k_ring_extract reads up to 26 points past a ring's end
   ALLOC(v.ring_src, S * (size_t)config->max_points, 0);
   ALLOC(v.ring_start, S * (size_t)(h->H + 1), 0);
   ALLOC(v.edges_pad, S * h->H * v.slots_per_ring, 0);
   ALLOC(v.edges_pad_meta, S * h->H * v.slots_per_ring, 0);
   ALLOC(v.ring_nedges, S * h->H, 0);
   ALLOC(v.ring_npoints, S * h->H, 0);
-  if (v.debug) ALLOC(v.curv_dbg, S * h->H * v.ring_cap, 0); else v.curv_dbg = nullptr;
+  ALLOC(v.ring_c, S * (size_t)config->max_points, 0);
+  ALLOC(v.ring_picked, S * (size_t)config->max_points, 0);
   ALLOC(v.edges, kEdgeBufs * S * v.edge_cap, 0);
   ALLOC(v.edges_meta, kEdgeBufs * S * v.edge_cap, 0);
   ALLOC(v.corr_a, S * v.edge_cap, 0);
@@ -524,7 +525,9 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
     g_last_error = "hipFuncSetAttribute(max dynamic LDS) failed"; return fail(LIODOM_ERR_HIP);
   }
   if (h->ring_lds_bytes > 48 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ring_extract), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ring_extract<256>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)h->ring_lds_bytes) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ring_extract<1024>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)h->ring_lds_bytes) != hipSuccess) {
       g_last_error = "hipFuncSetAttribute(max dynamic LDS) failed"; return fail(LIODOM_ERR_HIP);
     }
@@ -938,21 +941,17 @@ int liodom_get_correspondences(liodom_handle_t* h, int stream, int it, int32_t* 
 int liodom_get_curvature(liodom_handle_t* h, int stream, double* curv, int64_t cap, int32_t* ring_offsets) {
   int rc = check_stream(h, stream);
   if (rc) return rc;
-  if (!h->v.curv_dbg) { g_last_error = "create the handle with debug_buffers = 1"; return LIODOM_ERR_UNSUPPORTED; }
+  if (!(h->v.debug & 1)) { g_last_error = "create the handle with debug_buffers = 1"; return LIODOM_ERR_UNSUPPORTED; }
   SideLocks lk(h, true, true);
   HIP_TRY(hipStreamSynchronize(h->stream_x));
   HIP_TRY(hipStreamSynchronize(h->stream));
-  std::vector<int> np((size_t)h->H);
-  HIP_TRY(hipMemcpy(np.data(), h->v.ring_npoints + (size_t)stream * h->H, sizeof(int) * h->H, hipMemcpyDeviceToHost));
-  int64_t off = 0;
-  for (int r = 0; r < h->H; r++) {
-    if (ring_offsets) ring_offsets[r] = (int32_t)off;
-    const int cnt = std::min(np[r], h->v.ring_cap);
-    if (off + cnt > cap) { g_last_error = "curvature buffer too small"; return LIODOM_ERR_CAPACITY; }
-    if (cnt && curv)
-      HIP_TRY(hipMemcpy(curv + off, h->v.curv_dbg + ((size_t)stream * h->H + r) * h->v.ring_cap, sizeof(double) * (size_t)cnt, hipMemcpyDeviceToHost));
-    off += cnt;
-  }
+  std::vector<int> rs((size_t)h->H + 1);
+  HIP_TRY(hipMemcpy(rs.data(), h->v.ring_start + (size_t)stream * (h->H + 1), sizeof(int) * (h->H + 1), hipMemcpyDeviceToHost));
+  const int64_t off = rs[h->H];
+  for (int r = 0; r < h->H && ring_offsets; r++) ring_offsets[r] = rs[r];
+  if (off > cap) { g_last_error = "curvature buffer too small"; return LIODOM_ERR_CAPACITY; }
+  if (off && curv)      // ring-major over the compacted rings = the layout of the ring-sorted copy
+    HIP_TRY(hipMemcpy(curv, h->v.ring_c + (size_t)stream * h->v.max_points, sizeof(double) * (size_t)off, hipMemcpyDeviceToHost));
   if (ring_offsets) ring_offsets[h->H] = (int32_t)off;
   return LIODOM_OK;
 }

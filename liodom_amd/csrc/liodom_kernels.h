@@ -3,7 +3,7 @@
 // Kernel map (one launch covers all streams: blockIdx.y = stream):
 //   k_classify        A1/A2  isValidPoint + ring id per point, per-tile ring histogram (feature_extractor.cc:84-179)
 //   k_ring_scatter    A2     stable counting sort of the scan by ring (input order kept per ring)
-//   k_ring_extract    A3-A5  ring -> LDS tile -> FP64 curvature stencil ->
+//   k_ring_extract    A3-A5  11-tap curvature stencil in registers (float sums, double squares) ->
 //                            greedy per-region selection with +-5 suppression (:181-313)
 //   k_compact_edges          ring-padded edges -> dense edge cloud (output order of :186-252)
 //   k_knn             A9     edges -> world, 27-cell voxel-hash 5-NN, FP64 line gate
@@ -117,7 +117,8 @@ struct DevView {
   int2* edges_pad_meta;     // (idx_in_ring, src)
   int* ring_nedges;         // [S][H]
   int* ring_npoints;        // [S][H]
-  double* curv_dbg;         // [S][H][ring_cap] or null
+  double* ring_c;           // [S][max_points] smoothness per ring-sorted point: debug dump (debug & 1) and generic-path scratch
+  unsigned char* ring_picked;  // [S][max_points] picked_ marks of the generic path
   float4* edges;            // [kEdgeBufs][S][edge_cap] dense
   int4* edges_meta;         // [kEdgeBufs][S][edge_cap] (ring, idx_in_ring, src, 0)
   float4* corr_a;           // [S][edge_cap]  xyz of NN0, w = valid
@@ -349,54 +350,218 @@ __global__ __launch_bounds__(kTileThreads) void k_ring_scatter(DevView v, int s0
 }
 
 // =============================================================================================
-// k_ring_extract: one 512-thread workgroup per (ring, stream).
-//   phase 1  coalesced load of the ring (contiguous in the ring-sorted copy) into an SoA LDS tile
-//   phase 2  FP64 11-tap curvature stencil out of LDS
-//   phase 3  selection.  Per region: repeat { wavefront argmax of smoothness over not-picked
-//            items (DPP / permlane-swap butterfly, lowest index on ties); stop below 0.1 or after
-//            epr+1 picks; suppress +-5 neighbours while consecutive gaps <= 0.05 (ballot) }.
-//            The reference walks regions in order because suppression carries across region
-//            boundaries.  Here the 8 waves run the regions speculatively
-//            in parallel (candidates register-resident, 4 or 8 per lane) assuming no carry; each
-//            region then checks whether one of its picks was suppressed by the forward spill of
-//            an earlier region.  No conflict (the common case): all results are final.  Otherwise
-//            wave 0 replays the regions in order, re-running only conflicting ones (exact:
-//            marking an item the speculative run never picked cannot change that run).
-//   phase 4  all threads write the picks in region order.
-// LDS: c[cap] f64 | px py pz [cap] f32 | picked[cap] u8 | pick_idx[slots] i32 |
-//      pick_nfnb[slots] u8 | region_cnt[R] i32 | scratch
+// k_ring_extract: one workgroup per (ring, stream), ONE 16-LANE DPP ROW PER REGION (four regions per
+// wave, ceil(R / 4) waves per workgroup: 128 threads for the default 8 regions).  Nothing per point is
+// staged in LDS.
+//   keys     lane l of a row owns the 16 consecutive items 16 l .. 16 l + 15 of its region (regions of up
+//            to 256 items) and loads their 26 points straight from the ring-sorted copy (contiguous,
+//            L1/L2 resident).  Smoothness in registers exactly as the reference evaluates it (float 11-tap
+//            sums, squares in double, feature_extractor.cc:196-229), kept as ONE 32-bit key per item: the
+//            float image of the double (monotone: float(c1) > float(c2) implies c1 > c2), 0 for items
+//            below the 0.1 threshold (they can never be picked: the sorted walk breaks at the first of
+//            them, :270).  From the same registers: the "continuity" bit of every owned point (squared gap
+//            to its predecessor <= 0.05, :281-291,297-307), OR-ed into an LDS bit array (1 bit per
+//            point), so the +-5 suppression extent of any pick is a bit scan.
+//   select   per region: repeat { row argmax of the keys (4 DPP steps; lowest ring index on ties by a second
+//            row reduction); stop when nothing is left or after epr + 1 picks; zero the keys of the pick's
+//            +-5 neighbourhood as far as the continuity bits reach }.  Only when two items of a region
+//            share the maximal float image are their doubles recomputed and compared exactly, so the pick
+//            is always the reference's: largest double, lowest index on ties.  The four rows of a wave run
+//            their regions side by side: a pick costs ~1/4 of the wave instructions of a 64-lane argmax,
+//            which is what bounds the kernel on lock-step batches (VALU issue).
+//   carry    the reference walks regions in order because suppression carries across region boundaries
+//            (SURVEY.md §0 fact 4).  Here all regions run speculatively assuming no carry; the in-order walk
+//            is the fixed point of "region r = select(region r | forward spill of region r-1)", and a spill
+//            reaches at most the first 5 items of the next region (a 5-bit mask), so every region whose
+//            incoming mask changed AND hits one of its picks is re-run with that mask until no mask changes
+//            (marking an item a run never picked cannot change that run).  Region 0 is final after the
+//            speculative pass, region r after at most r more rounds; typically none or one.
+//   emit     all threads write the picks in region order.
+// Rings / parameter sets outside this shape (regions longer than 256 items or shorter than a spill, more
+// than 64 regions, rings longer than kGapBitsCap) take the generic path: curvature and marks in global
+// scratch, regions walked in order by one wave — any ring length, no capacity flag.
 // =============================================================================================
-constexpr int kExThreads = 512;
-constexpr int kExWaves = kExThreads / 64;
+constexpr int kExLPR = 16;               // lanes per region (one DPP row)
+constexpr int kExIPL = 16;               // items per lane -> regions of up to 256 items
+constexpr int kGapBitsCap = 16384;       // points per ring covered by the LDS continuity bits (2 KB)
+constexpr int kExMaxRegions = 64;
 
-__host__ __device__ __forceinline__ size_t ring_extract_lds_bytes(int cap, int slots, int regions) {
-  size_t b = (size_t)cap * (8 + 12 + 1);
-  b += (size_t)slots * 4;
-  b += (size_t)((slots + 15) / 16 * 16);
-  b += (size_t)regions * 4 + 16 * 8 * 4 + 64;
+__host__ __device__ __forceinline__ int ring_extract_threads(int regions) {
+  const int waves = (regions + 3) / 4;
+  return 64 * (waves < 1 ? 1 : (waves > 16 ? 16 : waves));
+}
+__host__ __device__ __forceinline__ size_t ring_extract_lds_bytes(int slots, int regions) {
+  size_t b = (size_t)(kGapBitsCap / 32 + 4) * 4;          // continuity bits + pad words
+  b += (size_t)slots * 4;                                 // pick_idx
+  b += (size_t)((slots + 15) / 16 * 16);                  // pick_nfnb
+  b += (size_t)regions * 4 + 2 * kExMaxRegions * 4 + 64;  // region_cnt, masks, flags
   return (b + 15) / 16 * 16;
 }
 
-// Suppression test around pick j (feature_extractor.cc:280-310): lanes 0-4 test the forward
-// gaps l = 1..5, lanes 8-12 the backward gaps.  Returns nf | nb << 4 (neighbours marked).
-__device__ __forceinline__ int suppression_extent(const float* px, const float* py, const float* pz,
-                                                  int j, int lane) {
-  bool brk = false;
-  const int l = (lane & 7) + 1;
-  if (lane < 5) brk = gap_sq(px, py, pz, j + l, j + l - 1) > 0.05;
-  else if (lane >= 8 && lane < 13) brk = gap_sq(px, py, pz, j - l, j - l + 1) > 0.05;
-  const unsigned long long bal = __ballot(brk);
-  const unsigned int bf = (unsigned int)(bal & 0x1Fu), bb = (unsigned int)((bal >> 8) & 0x1Fu);
-  const int nf = bf ? (__ffs(bf) - 1) : 5;
-  const int nb = bb ? (__ffs(bb) - 1) : 5;
+__device__ __forceinline__ unsigned int row_max_u32(unsigned int v) {
+  unsigned int o;
+  o = (unsigned int)dpp_i32<DPP_XOR1>((int)v); v = o > v ? o : v;
+  o = (unsigned int)dpp_i32<DPP_XOR2>((int)v); v = o > v ? o : v;
+  o = (unsigned int)dpp_i32<DPP_HALF_MIRROR>((int)v); v = o > v ? o : v;
+  o = (unsigned int)dpp_i32<DPP_MIRROR>((int)v); v = o > v ? o : v;
+  return v;   // uniform over the 16-lane row
+}
+__device__ __forceinline__ int row_min_i32(int v) {
+  int o;
+  o = dpp_i32<DPP_XOR1>(v); v = o < v ? o : v;
+  o = dpp_i32<DPP_XOR2>(v); v = o < v ? o : v;
+  o = dpp_i32<DPP_HALF_MIRROR>(v); v = o < v ? o : v;
+  o = dpp_i32<DPP_MIRROR>(v); v = o < v ? o : v;
+  return v;
+}
+// the 16 ballot bits of this lane's row, != 0 iff `p` holds on any lane of the row
+__device__ __forceinline__ bool row_any(bool p, int lane) {
+  return ((__ballot(p) >> (lane & 48)) & 0xFFFFull) != 0ull;
+}
+
+// +-5 suppression extent of pick j from the continuity bits (bit k: gap(k-1, k) <= 0.05):
+// forward marks l = 1..5 stop at the first k = j + l whose bit is clear (:280-294), backward marks at the
+// first k = j - l + 1 whose bit is clear (:296-310).  Returns nf | nb << 4.
+__device__ __forceinline__ int suppression_extent_bits(const unsigned int* gb, int j) {
+  const int k0 = j - 4;                                   // >= 1 for any pick (j >= 5)
+  const int w = k0 >> 5, sh = k0 & 31;
+  const unsigned long long win = ((((unsigned long long)gb[w + 1]) << 32) | gb[w]) >> sh;   // bit i <-> k = k0 + i
+  const unsigned int back = (unsigned int)win & 31u;      // k = j-4 .. j   (i = 0..4)
+  const unsigned int fwd = (unsigned int)(win >> 5) & 31u;   // k = j+1 .. j+5
+  const unsigned int invf = ~fwd & 31u, invb = ~back & 31u;
+  const int nf = invf ? (__ffs(invf) - 1) : 5;
+  const int nb = invb ? (4 - (31 - __clz(invb))) : 5;     // highest clear bit p: k = j-4+p breaks, nb = 4 - p
+  return nf | (nb << 4);
+}
+// The same test on the points themselves (generic path).
+__device__ __forceinline__ int suppression_extent_pts(const float4* rp, int j) {
+  int nf = 5, nb = 5;
+  for (int l = 1; l <= 5; l++) {
+    const float4 a = rp[j + l], b = rp[j + l - 1];
+    if (gap_sq3(a.x, a.y, a.z, b.x, b.y, b.z) > 0.05) { nf = l - 1; break; }
+  }
+  for (int l = 1; l <= 5; l++) {
+    const float4 a = rp[j - l], b = rp[j - l + 1];
+    if (gap_sq3(a.x, a.y, a.z, b.x, b.y, b.z) > 0.05) { nb = l - 1; break; }
+  }
   return nf | (nb << 4);
 }
 
-// Generic region selection on the shared picked[] array (any region length).  Writes its own
-// suppression marks into picked[].  One wave.  Returns the number of picks.
-__device__ int select_region_lds(const double* c, const float* px, const float* py, const float* pz,
-                                 volatile unsigned char* vpicked, int rs, int re, int epr, int lane,
-                                 int* out_idx, unsigned char* out_nfnb) {
+// Smoothness of ring point j from 11 consecutive points q[0..10] = ring points j-5 .. j+5 (:196-229).
+__device__ __forceinline__ double curvature_pts(const float4* q) {
+  const double dx = stencil_sum(q[0].x, q[1].x, q[2].x, q[3].x, q[4].x, q[5].x, q[6].x, q[7].x, q[8].x, q[9].x, q[10].x);
+  const double dy = stencil_sum(q[0].y, q[1].y, q[2].y, q[3].y, q[4].y, q[5].y, q[6].y, q[7].y, q[8].y, q[9].y, q[10].y);
+  const double dz = stencil_sum(q[0].z, q[1].z, q[2].z, q[3].z, q[4].z, q[5].z, q[6].z, q[7].z, q[8].z, q[9].z, q[10].z);
+  return dx * dx + dy * dy + dz * dz;
+}
+__device__ __forceinline__ double curvature_at(const float4* __restrict__ rp, int j) {
+  float4 q[11];
+#pragma unroll
+  for (int i = 0; i < 11; i++) q[i] = rp[j - 5 + i];
+  return curvature_pts(q);
+}
+
+// Keys of the 16 items owned by this lane (region-array indices k0 .. k0 + 15, ring indices + 5): float image
+// of the smoothness, 0 = unavailable (outside the region, below 0.1, picked or suppressed).  Also returns the
+// continuity bits of the owned points k = k0 + 5 + i (bit i).  Loads are unconditional (no branch per load, all
+// in flight together, one base address + immediate offsets): two batches of 18 points for 8 items each.
+typedef float f3v __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ double curvature_f3(const f3v* q) {
+  const double dx = stencil_sum(q[0].x, q[1].x, q[2].x, q[3].x, q[4].x, q[5].x, q[6].x, q[7].x, q[8].x, q[9].x, q[10].x);
+  const double dy = stencil_sum(q[0].y, q[1].y, q[2].y, q[3].y, q[4].y, q[5].y, q[6].y, q[7].y, q[8].y, q[9].y, q[10].y);
+  const double dz = stencil_sum(q[0].z, q[1].z, q[2].z, q[3].z, q[4].z, q[5].z, q[6].z, q[7].z, q[8].z, q[9].z, q[10].z);
+  return dx * dx + dy * dy + dz * dz;
+}
+__device__ __forceinline__ unsigned int region_keys_load(unsigned int (&kf)[kExIPL], const float4* __restrict__ rp, int nr, int k0,
+                                                         int n_own, double* curv_out) {
+  unsigned int gbits = 0;
+  (void)nr;
+#pragma unroll
+  for (int c0 = 0; c0 < kExIPL; c0 += 8) {
+    f3v q[18];                                              // x y z only: 12-byte loads, 54 registers per batch
+#pragma unroll
+    for (int i = 0; i < 18; i++) {
+      // ring index k0 + c0 + i; item c0 + t uses q[t .. t + 10].  Lanes at the end of the ring read up to 26
+      // points past it (the next ring, or the padding the allocation carries): those items are not owned.
+      q[i] = *reinterpret_cast<const f3v*>(rp + k0 + c0 + i);
+    }
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+      const bool own = c0 + t < n_own;
+      const double c = curvature_f3(q + t);
+      kf[c0 + t] = (own && !(c < 0.1)) ? (unsigned int)__float_as_int((float)c) : 0u;      // :270 threshold folded in
+      if (curv_out && own) curv_out[k0 + 5 + c0 + t] = c;
+      const bool ok = !(gap_sq3(q[t + 5].x, q[t + 5].y, q[t + 5].z, q[t + 4].x, q[t + 4].y, q[t + 4].z) > 0.05);
+      gbits |= (own && ok) ? (1u << (c0 + t)) : 0u;
+    }
+    if (c0 + 8 < kExIPL) { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }   // second batch of loads after the first batch's arithmetic
+  }
+  return gbits;
+}
+
+// Greedy selection of one region per 16-lane row; rows whose `active` is false idle.  Keys are consumed
+// (picked / suppressed items zeroed).  premask: bit o set = item rs + o (o < 5) was suppressed by the previous
+// region's picks.  Returns the number of picks (uniform over the row).
+__device__ __forceinline__ int select_region_row(unsigned int (&kf)[kExIPL], const float4* __restrict__ rp, const unsigned int* gb,
+                                                 bool active, int rs, int k0, int epr, int lane, int premask, int* out_idx,
+                                                 unsigned char* out_nfnb) {
+  const int j0 = k0 + 5;
+  const int rl = lane & (kExLPR - 1);
+  if (premask) {
+#pragma unroll
+    for (int i = 0; i < kExIPL; i++) {
+      const int o = k0 + i - rs;
+      if (o < 5 && ((premask >> o) & 1)) kf[i] = 0;
+    }
+  }
+  int picks = 0;
+  while (__ballot(active) != 0ull) {
+    unsigned int bf = 0;
+#pragma unroll
+    for (int i = 0; i < kExIPL; i++) bf = kf[i] > bf ? kf[i] : bf;
+    const unsigned int m32 = row_max_u32(active ? bf : 0u);
+    active = active && m32 != 0u && picks <= epr;                  // nothing left above 0.1, or epr + 1 picks made (:270)
+    unsigned int eqm = 0;                                          // bit i: item i carries the maximal float image
+#pragma unroll
+    for (int i = 0; i < kExIPL; i++) eqm |= (kf[i] == m32) ? (1u << i) : 0u;
+    const bool has = active && eqm != 0u;
+    const int first = __ffs(eqm) - 1;
+    int j = row_min_i32(has ? j0 + first : 0x7fffffff);            // lowest ring index among the maximal float images
+    const bool tie = row_any(has && ((eqm & (eqm - 1u)) != 0u || j0 + first != j), lane);
+    if (__ballot(tie) != 0ull) {
+      // several items share the maximal float image: their exact doubles decide (recomputed from the points)
+      unsigned long long bk = 0;
+      int bj = 0x7fffffff;
+      unsigned int rem = (tie && has) ? eqm : 0u;
+#pragma unroll 1
+      while (rem) {
+        const int i = __ffs(rem) - 1;                              // ascending i: the lowest index wins among equals
+        rem &= rem - 1u;
+        const unsigned long long ck = (unsigned long long)__double_as_longlong(curvature_at(rp, j0 + i));
+        if (ck > bk) { bk = ck; bj = j0 + i; }
+      }
+      const unsigned long long m64 = row_max_u64(bk);
+      const int jt = row_min_i32((tie && has && bk == m64) ? bj : 0x7fffffff);
+      j = tie ? jt : j;
+    }
+    int ext = 0;
+    if (active) ext = suppression_extent_bits(gb, j);
+    const int nf = ext & 15, nb = ext >> 4;
+    if (active && rl == 0) { out_idx[picks] = j; out_nfnb[picks] = (unsigned char)ext; }
+    const unsigned int span = (unsigned int)(nf + nb);
+    const int lo = j - nb - j0;
+#pragma unroll
+    for (int i = 0; i < kExIPL; i++) {
+      if (active && (unsigned int)(i - lo) <= span) kf[i] = 0;     // the pick and its marked neighbours (:277,293,309)
+    }
+    picks += active ? 1 : 0;
+  }
+  return picks;
+}
+
+// Generic in-order selection of one region on global scratch (any region length).  One wave.
+__device__ int select_region_generic(const double* c, const float4* rp, volatile unsigned char* vpicked, int rs, int re,
+                                     int epr, int lane, int* out_idx, unsigned char* out_nfnb) {
   int picks = 0;
   while (true) {
     unsigned long long bkey = 0;
@@ -414,282 +579,174 @@ __device__ int select_region_lds(const double* c, const float* px, const float* 
     const double best = __longlong_as_double((long long)m);
     if (best < 0.1 || picks > epr) break;                          // :270
     const int j = wave_min_i32((bidx != 0x7fffffff && bkey == m) ? bidx : 0x7fffffff);   // ties: lowest index
-    const int ext = suppression_extent(px, py, pz, j, lane);
+    const int ext = suppression_extent_pts(rp, j);
     const int nf = ext & 15, nb = ext >> 4;
     if (lane == 0) { out_idx[picks] = j; out_nfnb[picks] = (unsigned char)ext; vpicked[j] = 1; }   // :275-277
     if (lane >= 1 && lane <= nf) vpicked[j + lane] = 1;            // :293
     if (lane >= 9 && lane <= 8 + nb) vpicked[j - (lane - 8)] = 1;  // :309
     picks++;                                                       // :276
+    __threadfence_block();
     __builtin_amdgcn_wave_barrier();
   }
   return picks;
 }
 
-// Speculative region selection with register-resident candidates: lane owns IPL consecutive
-// items; no access to picked[] (assumes nothing was suppressed by earlier regions).
-template <int IPL>
-__device__ int select_region_spec(const double* c, const float* px, const float* py, const float* pz,
-                                  int rs, int re, int epr, int lane, int* out_idx, unsigned char* out_nfnb,
-                                  const volatile unsigned char* premarks = nullptr) {
-  unsigned long long ck[IPL];
-  unsigned int pm = 0;                       // bit i set: item i unavailable
-  const int j0 = rs + lane * IPL + 5;        // ring index of this lane's first item
-#pragma unroll
-  for (int i = 0; i < IPL; i++) {
-    const int k = rs + lane * IPL + i;
-    if (k < re) {
-      ck[i] = (unsigned long long)__double_as_longlong(c[k + 5]);
-      if (premarks && premarks[k + 5]) pm |= 1u << i;   // suppressed by an earlier region's picks
-    } else { ck[i] = 0; pm |= 1u << i; }
-  }
-  int picks = 0;
-  while (true) {
-    unsigned long long bk = 0;
-    int bi = -1;
-#pragma unroll
-    for (int i = 0; i < IPL; i++) {
-      if (!((pm >> i) & 1u) && (bi < 0 || ck[i] > bk)) { bk = ck[i]; bi = i; }
-    }
-    const unsigned long long m = wave_max_u64(bi >= 0 ? bk : 0ull);
-    const double best = __longlong_as_double((long long)m);
-    // no candidate anywhere -> m == 0 -> best = 0.0 < 0.1 -> stop (same as the reference's
-    // loop running out of items)
-    if (best < 0.1 || picks > epr) break;                          // :270
-    const unsigned long long win = __ballot(bi >= 0 && bk == m);
-    const int wl = __ffsll((long long)win) - 1;                    // lowest lane = lowest index
-    const int j = readlane_i32(j0 + bi, wl);
-    const int ext = suppression_extent(px, py, pz, j, lane);
-    const int nf = ext & 15, nb = ext >> 4;
-    if (lane == 0) { out_idx[picks] = j; out_nfnb[picks] = (unsigned char)ext; }
-#pragma unroll
-    for (int i = 0; i < IPL; i++) {
-      const int idx = j0 + i;
-      if (idx >= j - nb && idx <= j + nf) pm |= 1u << i;
-    }
-    picks++;
-  }
-  return picks;
-}
-
-__global__ __launch_bounds__(kExThreads) void k_ring_extract(DevView v, int s0) {
+template <int kMaxThreads>
+__global__ __launch_bounds__(kMaxThreads) void k_ring_extract(DevView v, int s0) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int ring = blockIdx.x;
   const int s = s0 + blockIdx.y;
-  const int cap = v.ring_cap;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
   const int R = v.scan_regions, epr = v.edges_per_region, slots = v.slots_per_ring;
-  double* c = reinterpret_cast<double*>(smem);
-  float* px = reinterpret_cast<float*>(c + cap);
-  float* py = px + cap;
-  float* pz = py + cap;
-  unsigned char* picked = reinterpret_cast<unsigned char*>(pz + cap);
-  int* pick_idx = reinterpret_cast<int*>(picked + cap);                 // [R][epr+1]
+  unsigned int* gb = reinterpret_cast<unsigned int*>(smem);                          // [kGapBitsCap / 32 + 4]
+  int* pick_idx = reinterpret_cast<int*>(gb + kGapBitsCap / 32 + 4);                 // [R][epr+1]
   unsigned char* pick_nfnb = reinterpret_cast<unsigned char*>(pick_idx + slots);
-  int* region_cnt = reinterpret_cast<int*>(pick_nfnb + (slots + 15) / 16 * 16);   // [R]
-  int* wtot = region_cnt + R;                                            // [16 * kExWaves] scan scratch
+  int* region_cnt = reinterpret_cast<int*>(pick_nfnb + (slots + 15) / 16 * 16);     // [R]
+  int* used_mask = region_cnt + R;          // [kExMaxRegions] pre-marks of the run that produced the current picks
+  int* new_mask = used_mask + kExMaxRegions;   // [kExMaxRegions] spill of the predecessor's current picks
+  int* flags = new_mask + kExMaxRegions;    // [4]
 
   const int H = v.scan_lines;
   int* nedges_out = v.ring_nedges + (size_t)s * H + ring;
   int* npoints_out = v.ring_npoints + (size_t)s * H + ring;
-
-  const bool dbgb = (ring == 40 % H) && (s == 0) && (tid == 0);
   const unsigned long long t_begin = (v.debug & 32) ? wall_clock64() : 0ull;
+  const bool dbgb = (ring == (((v.debug >> 8) & 0xFF) ? ((v.debug >> 8) & 0xFF) : 40) % H) && (s == 0) && (tid == 0);
   DBG_STAMP(v, dbgb, 0, 0);
+  int dbg_rounds = 0;
   // ---- the ring's points are contiguous in the ring-sorted copy written by k_ring_scatter ----
   const int rbeg = v.ring_start[(size_t)s * (H + 1) + ring];
   const int nr = v.ring_start[(size_t)s * (H + 1) + ring + 1] - rbeg;
   const float4* rpts = v.ring_pts + (size_t)s * v.max_points + rbeg;
   const int* rsrc = v.ring_src + (size_t)s * v.max_points + rbeg;
+  double* rc = v.ring_c + (size_t)s * v.max_points + rbeg;                // debug dump / generic-path scratch
+  const bool dump = (v.debug & 1) != 0;
   if (tid == 0) *npoints_out = nr;
-  if (nr > cap) {   // ring does not fit the LDS tile: flagged, ring skipped
-    if (tid == 0) { atomicOr(&v.state[s].status, LIODOM_STATUS_RING_OVERFLOW); *nedges_out = 0; }
-    return;
-  }
   // rings below min_points_per_scan are skipped (feature_extractor.cc:188)
   if ((long long)nr < v.min_points_per_scan || nr < 11) {
     if (tid == 0) *nedges_out = 0;
-    if (v.debug && v.curv_dbg) {
-      double* dbg = v.curv_dbg + ((size_t)s * H + ring) * cap;
-      for (int j = tid; j < nr; j += kExThreads) dbg[j] = __longlong_as_double(0x7ff8000000000000ll);
-    }
+    if (dump) for (int j = tid; j < nr; j += nthreads) rc[j] = __longlong_as_double(0x7ff8000000000000ll);
     return;
   }
-  __syncthreads();
-  DBG_STAMP(v, dbgb, 0, 2);
-  // ---- phase 1: load the ring into the SoA LDS tile ----
-  for (int k0 = tid; k0 < nr; k0 += 4 * kExThreads) {    // 4 coalesced loads in flight per thread
-    float4 p[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) { const int k = k0 + u * kExThreads; if (k < nr) p[u] = rpts[k]; }
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int k = k0 + u * kExThreads;
-      if (k < nr) { px[k] = p[u].x; py[k] = p[u].y; pz[k] = p[u].z; picked[k] = 0; }
-    }
-  }
-  __syncthreads();
-  DBG_STAMP(v, dbgb, 0, 3);
-  // ---- phase 2: curvature ----
-  for (int j = 5 + tid; j < nr - 5; j += kExThreads) c[j] = curvature(px, py, pz, j);
-  __syncthreads();
-  if (v.debug && v.curv_dbg) {
-    double* dbg = v.curv_dbg + ((size_t)s * H + ring) * cap;
-    for (int j = tid; j < nr; j += kExThreads)
-      dbg[j] = (j >= 5 && j < nr - 5) ? c[j] : __longlong_as_double(0x7ff8000000000000ll);
-  }
-
-  DBG_STAMP(v, dbgb, 0, 4);
-  // ---- phase 3: selection ----
   const int total = nr - 10;                            // :238
   const int sector = total / R;                         // :239
   const int last_len = total - sector * (R - 1);
   const int max_len = sector > last_len ? sector : last_len;
   const int ppr = epr + 1;                              // picks per region (:270)
-  volatile unsigned char* vpicked = picked;
-  if (v.debug & 16) {
-    if (tid < R) region_cnt[tid] = 0;
-  } else if (max_len <= 512) {
-    for (int reg = wave; reg < R; reg += kExWaves) {
-      const int rs = sector * reg;
-      const int re = (reg == R - 1) ? total : sector * (reg + 1);   // :242-247
-      int cntp;
-      if (max_len <= 256) cntp = select_region_spec<4>(c, px, py, pz, rs, re, epr, lane, pick_idx + reg * ppr, pick_nfnb + reg * ppr);
-      else cntp = select_region_spec<8>(c, px, py, pz, rs, re, epr, lane, pick_idx + reg * ppr, pick_nfnb + reg * ppr);
-      if (lane == 0) region_cnt[reg] = cntp;
+  const bool fast = max_len <= kExLPR * kExIPL && sector >= 5 && R <= kExMaxRegions && R <= 4 * (nthreads >> 6) && nr <= kGapBitsCap;
+  if (dump) {
+    for (int j = tid; j < 5; j += nthreads) { rc[j] = __longlong_as_double(0x7ff8000000000000ll); rc[nr - 1 - j] = rc[j]; }
+  }
+  if (fast) {
+    const int row = lane >> 4, rl = lane & 15;
+    const int reg = wave * 4 + row;                     // this row's region
+    const bool rvalid = reg < R;
+    const int rs = sector * (rvalid ? reg : 0);
+    const int re = !rvalid ? rs : ((reg == R - 1) ? total : sector * (reg + 1));   // :242-247
+    const int k0 = rs + rl * kExIPL;                    // region-array index of this lane's first item (ring index + 5)
+    const int n_own = re - k0;                          // owned items inside the region (<= 0: none)
+    for (int w = tid; w < ((nr + 31) >> 5) + 3; w += nthreads) gb[w] = 0u;
+    if (tid < R) { used_mask[tid] = 0; new_mask[tid] = 0; }
+    unsigned int kf[kExIPL];
+    unsigned int gbits = region_keys_load(kf, rpts, nr, k0, n_own, dump ? rc : nullptr);
+    // the ring's first / last points are owned by no item: their continuity bits (k = 1..4, nr-5..nr-1) separately
+    unsigned int edge_bit = 0;
+    int edge_k = 0;
+    if (tid < 9) {
+      edge_k = tid < 4 ? tid + 1 : nr - 9 + tid;
+      const float4 a = rpts[edge_k], b = rpts[edge_k - 1];
+      edge_bit = !(gap_sq3(a.x, a.y, a.z, b.x, b.y, b.z) > 0.05) ? 1u : 0u;
     }
-    // Forward spill of every region's speculative picks into the following regions.
-    for (int reg = wave; reg < R; reg += kExWaves) {
-      const int end_j = ((reg == R - 1) ? total : sector * (reg + 1)) + 5;   // first ring index after the region
-      const int cntp = region_cnt[reg];
-      for (int k = lane; k < cntp; k += 64) {
-        const int j = pick_idx[reg * ppr + k];
-        const int nf = pick_nfnb[reg * ppr + k] & 15;
-        for (int l = 1; l <= nf; l++) if (j + l >= end_j) vpicked[j + l] = 1;
-      }
+    __syncthreads();                                    // bit array zeroed
+    if (gbits) {
+      const int kb = k0 + 5;                            // ring index of bit 0
+      const unsigned long long sh = (unsigned long long)gbits << (kb & 31);
+      atomicOr(&gb[kb >> 5], (unsigned int)sh);
+      if ((unsigned int)(sh >> 32)) atomicOr(&gb[(kb >> 5) + 1], (unsigned int)(sh >> 32));
     }
-    if (tid == 0) wtot[0] = 0;
+    if (edge_bit) atomicOr(&gb[edge_k >> 5], 1u << (edge_k & 31));
+    __syncthreads();
+    DBG_STAMP(v, dbgb, 0, 2);
+    // ---- speculative selection, all regions side by side ----
+    {
+      const int cntp = select_region_row(kf, rpts, gb, rvalid && re > rs, rs, k0, epr, lane, 0, pick_idx + (rvalid ? reg : 0) * ppr,
+                                         pick_nfnb + (rvalid ? reg : 0) * ppr);
+      if (rvalid && rl == 0) region_cnt[reg] = cntp;
+    }
     __syncthreads();
     DBG_STAMP(v, dbgb, 0, 5);
-    // A region's speculative result is final unless one of its picks was suppressed by an
-    // earlier region.  No conflict anywhere (the common case) -> all regions are final.
-    for (int reg = wave; reg < R; reg += kExWaves) {
-      const int cntp = region_cnt[reg];
-      bool conflict = false;
-      for (int k = lane; k < cntp; k += 64) conflict = conflict || (vpicked[pick_idx[reg * ppr + k]] != 0);
-      if (__ballot(conflict) && lane == 0) wtot[0] = 1;
-    }
-    __syncthreads();
-    if (wtot[0] != 0 && sector >= 5 && 2 * R <= 96) {
-      // Some region had a pick suppressed by its predecessor.  The reference's in-order walk is a
-      // fixed point of "region r = select(region r | forward spill of region r-1)", and a spill
-      // reaches at most the first 5 items of the next region (a 5-bit mask).  So: iterate in
-      // parallel — every region whose incoming mask changed is re-run (one wave per region) with
-      // that mask as pre-marks — until no mask changes.  Region 0 is final after the speculative
-      // pass, region r after at most r more rounds; typically one or two rounds instead of a
-      // sequential replay of all regions by one wave (noisy ground rings: 35 -> ~15 us).
-      // A region whose picks came from an unmarked run is not re-run if the mask does not hit any
-      // of its picks (marking an item that a run never picked cannot change that run).
-      int* used_mask = wtot + 16;          // [R] pre-marks of the run that produced the current picks
-      int* new_mask = wtot + 16 + R;       // [R] spill of the predecessor's current picks
-      for (int k = tid; k < nr; k += kExThreads) picked[k] = 0;
-      if (tid < R) { used_mask[tid] = 0; new_mask[tid] = 0; }
-      __syncthreads();
-      for (int round = 0; round <= R; round++) {
-        for (int reg = wave; reg + 1 < R; reg += kExWaves) {       // spill of region reg into region reg + 1
-          const int end_j = sector * (reg + 1) + 5;
-          const int cntp = region_cnt[reg];
-          int m = 0;
-          for (int k = lane; k < cntp; k += 64) {
-            const int j = pick_idx[reg * ppr + k];
-            const int nf = pick_nfnb[reg * ppr + k] & 15;
-            for (int l = 1; l <= nf; l++) if (j + l >= end_j) m |= 1 << (j + l - end_j);
-          }
-          {
-            int r5 = 0;
-#pragma unroll
-            for (int b = 0; b < 5; b++) if (__ballot((m >> b) & 1)) r5 |= 1 << b;
-            m = r5;
-          }
-          if (lane == 0) new_mask[reg + 1] = m;
+    // ---- carry resolution: fixed point over the 5-bit spill masks ----
+    for (int round = 0; round <= R; round++) {
+      if (rvalid && reg + 1 < R) {                       // spill of region reg into region reg + 1
+        const int end_j = sector * (reg + 1) + 5;        // first ring index of region reg + 1
+        const int cntp = region_cnt[reg];
+        int m = 0;
+        for (int k = rl; k < cntp; k += kExLPR) {
+          const int j = pick_idx[reg * ppr + k];
+          const int nf = pick_nfnb[reg * ppr + k] & 15;
+          for (int l = 1; l <= nf; l++) if (j + l >= end_j) m |= 1 << (j + l - end_j);
         }
-        if (tid == 0) wtot[1] = 0;
-        __syncthreads();
-        for (int reg = wave; reg < R; reg += kExWaves) {
-          const int m = new_mask[reg], um = used_mask[reg];
-          if (m == um) continue;
-          const int rs = sector * reg;
-          const int re = (reg == R - 1) ? total : sector * (reg + 1);
-          int cntp = region_cnt[reg];
-          bool need = true;
-          if (um == 0) {
+        m |= dpp_i32<DPP_XOR1>(m); m |= dpp_i32<DPP_XOR2>(m); m |= dpp_i32<DPP_HALF_MIRROR>(m); m |= dpp_i32<DPP_MIRROR>(m);
+        if (rl == 0) new_mask[reg + 1] = m;
+      }
+      if (tid == 0) flags[0] = 0;
+      __syncthreads();
+      bool need = false;
+      int m = 0;
+      if (rvalid) {
+        m = new_mask[reg];
+        const int um = used_mask[reg];
+        if (m != um) {
+          need = true;
+          if (um == 0) {      // picks of an unmarked run stay valid unless the mask hits one of them
+            const int cntp = region_cnt[reg];
             bool hit = false;
-            for (int k = lane; k < cntp; k += 64) {
+            for (int k = rl; k < cntp; k += kExLPR) {
               const int o = pick_idx[reg * ppr + k] - (rs + 5);
               hit = hit || (o < 5 && ((m >> o) & 1));
             }
-            need = __ballot(hit) != 0ull;
-          }
-          if (need) {
-            if (lane < 5) vpicked[rs + 5 + lane] = (unsigned char)((m >> lane) & 1);
-            __builtin_amdgcn_wave_barrier();
-            if (max_len <= 256) cntp = select_region_spec<4>(c, px, py, pz, rs, re, epr, lane, pick_idx + reg * ppr, pick_nfnb + reg * ppr, vpicked);
-            else cntp = select_region_spec<8>(c, px, py, pz, rs, re, epr, lane, pick_idx + reg * ppr, pick_nfnb + reg * ppr, vpicked);
-            if (lane == 0) { region_cnt[reg] = cntp; used_mask[reg] = m; wtot[1] = 1; }
-          } else if (lane == 0) {
-            used_mask[reg] = 0;          // still the unmarked run's picks, valid for this mask too
+            need = row_any(hit, lane);
+            if (!need && rl == 0) used_mask[reg] = 0;    // still the unmarked run's picks, valid for this mask too
           }
         }
-        __syncthreads();
-        if (wtot[1] == 0) break;
-        __syncthreads();
       }
-    } else if (wtot[0] != 0) {
-      // (regions shorter than a spill, or too many of them for the scratch: replay in region order)
-      // picked[] is rebuilt to hold only the forward spill of *final* picks; a conflicting
-      // region is re-run with the same register-resident routine, seeded with those marks.
-      for (int k = tid; k < nr; k += kExThreads) picked[k] = 0;
+      if (__ballot(need) != 0ull) {                      // (wave-uniform) some row of this wave re-runs its region
+        if (need) (void)region_keys_load(kf, rpts, nr, k0, n_own, nullptr);
+        const int cntp = select_region_row(kf, rpts, gb, need, rs, k0, epr, lane, m, pick_idx + (rvalid ? reg : 0) * ppr,
+                                           pick_nfnb + (rvalid ? reg : 0) * ppr);
+        if (need && rl == 0) { region_cnt[reg] = cntp; used_mask[reg] = m; flags[0] = 1; }
+      }
       __syncthreads();
-      if (wave == 0) {
-        for (int reg = 0; reg < R; reg++) {
-          const int rs = sector * reg;
-          const int re = (reg == R - 1) ? total : sector * (reg + 1);
-          int cntp = region_cnt[reg];
-          bool conflict = false;
-          for (int k = lane; k < cntp; k += 64) conflict = conflict || (vpicked[pick_idx[reg * ppr + k]] != 0);
-          if (__ballot(conflict)) {
-            if (max_len <= 256) cntp = select_region_spec<4>(c, px, py, pz, rs, re, epr, lane, pick_idx + reg * ppr, pick_nfnb + reg * ppr, vpicked);
-            else cntp = select_region_spec<8>(c, px, py, pz, rs, re, epr, lane, pick_idx + reg * ppr, pick_nfnb + reg * ppr, vpicked);
-            if (lane == 0) region_cnt[reg] = cntp;
-            __builtin_amdgcn_wave_barrier();
-          }
-          const int end_j = re + 5;
-          for (int k = lane; k < cntp; k += 64) {
-            const int j = pick_idx[reg * ppr + k];
-            const int nf = pick_nfnb[reg * ppr + k] & 15;
-            for (int l = 1; l <= nf; l++) if (j + l >= end_j) vpicked[j + l] = 1;
-          }
-          __builtin_amdgcn_wave_barrier();
-        }
+      if (flags[0] == 0) break;
+      dbg_rounds++;
+      __syncthreads();
+    }
+    DBG_STAMP(v, dbgb, 0, 6);
+  } else {
+    // ---- generic path: curvature + marks in global scratch, regions in order on one wave ----
+    unsigned char* picked = v.ring_picked + (size_t)s * v.max_points + rbeg;
+    for (int j = 5 + tid; j < nr - 5; j += nthreads) {
+      rc[j] = curvature_at(rpts, j);
+      picked[j] = 0;                                                // :230
+    }
+    __threadfence();
+    __syncthreads();
+    if (wave == 0) {
+      for (int reg = 0; reg < R; reg++) {
+        const int rs = sector * reg;
+        const int re = (reg == R - 1) ? total : sector * (reg + 1);
+        int cntp = 0;
+        if (re > rs) cntp = select_region_generic(rc, rpts, picked, rs, re, epr, lane, pick_idx + reg * ppr, pick_nfnb + reg * ppr);
+        if (lane == 0) region_cnt[reg] = cntp;
       }
     }
-  } else if (wave == 0) {
-    // very long regions: plain in-order selection on the shared picked[] array
-    for (int reg = 0; reg < R; reg++) {
-      const int rs = sector * reg;
-      const int re = (reg == R - 1) ? total : sector * (reg + 1);
-      const int cntp = select_region_lds(c, px, py, pz, vpicked, rs, re, epr, lane, pick_idx + reg * ppr, pick_nfnb + reg * ppr);
-      if (lane == 0) region_cnt[reg] = cntp;
-    }
+    __syncthreads();
   }
-  __syncthreads();
-  DBG_STAMP(v, dbgb, 0, 6);
-  // ---- phase 4: emit in region order, pick order (:275) ----
+  // ---- emit in region order, pick order (:275) ----
   float4* eout = v.edges_pad + ((size_t)s * H + ring) * slots;
   int2* mout = v.edges_pad_meta + ((size_t)s * H + ring) * slots;
   // one flat pass over all pick slots (region-major): slot (reg, k) goes to position
   // sum of the earlier regions' counts + k — one round of loads instead of one per region
-  int total_picks = 0;
-  for (int q = tid; q < R * ppr; q += kExThreads) {
+  for (int q = tid; q < R * ppr; q += nthreads) {
     const int reg = q / ppr, k = q - reg * ppr;
     if (k < region_cnt[reg]) {
       int base = 0;
@@ -700,11 +757,12 @@ __global__ __launch_bounds__(kExThreads) void k_ring_extract(DevView v, int s0) 
     }
   }
   if (tid == 0) {
+    int total_picks = 0;
     for (int r2 = 0; r2 < R; r2++) total_picks += region_cnt[r2];
     *nedges_out = total_picks;
   }
   DBG_STAMP(v, dbgb, 0, 7);
-  if ((v.debug & 32) && s == 0 && tid == 0 && ring < 128) v.dbg_clk[128 + ring] = wall_clock64() - t_begin;
+  if ((v.debug & 32) && s == 0 && tid == 0 && ring < 64) { v.dbg_clk[128 + ring] = wall_clock64() - t_begin; v.dbg_clk[96 + (ring & 31)] = (unsigned long long)dbg_rounds | ((unsigned long long)*nedges_out << 8); }
 }
 
 // =============================================================================================

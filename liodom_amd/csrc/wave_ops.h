@@ -89,6 +89,16 @@ __device__ __forceinline__ unsigned int half_min_u32(unsigned int v) {
   o = (unsigned int)xor16_i32((int)v); v = o < v ? o : v;
   return v;   // uniform over each 32-lane half
 }
+__device__ __forceinline__ unsigned int wave_max_u32(unsigned int v) {
+  unsigned int o;
+  o = (unsigned int)dpp_i32<DPP_XOR1>((int)v); v = o > v ? o : v;
+  o = (unsigned int)dpp_i32<DPP_XOR2>((int)v); v = o > v ? o : v;
+  o = (unsigned int)dpp_i32<DPP_HALF_MIRROR>((int)v); v = o > v ? o : v;
+  o = (unsigned int)dpp_i32<DPP_MIRROR>((int)v); v = o > v ? o : v;
+  o = (unsigned int)xor16_i32((int)v); v = o > v ? o : v;
+  o = (unsigned int)xor32_i32((int)v); v = o > v ? o : v;
+  return v;   // uniform over the wave
+}
 __device__ __forceinline__ int wave_min_i32(int v) {
   int o;
   o = dpp_i32<DPP_XOR1>(v); v = o < v ? o : v;

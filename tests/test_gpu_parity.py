@@ -100,17 +100,23 @@ def test_suppression_carry_across_regions(orc):
     g.close()
 
 
-def test_ring_overflow_is_reported(orc, synth):
-    # a ring with more points than the configured LDS tile is skipped and flagged, not corrupted
+def test_rings_of_any_length_are_processed(orc, synth):
+    """The reference has no per-ring capacity (std::vector per ring, feature_extractor.cc:115-175): a ring far
+    longer than the expected width — real HDL-64 clouds put well over W points into some elevation bins —
+    must be extracted like any other, never dropped.  One ring holding the whole cloud: 700 points (register
+    path), 5 000 points with 8 regions (regions longer than 512 items: generic path) and 20 000 points
+    (longer than the LDS continuity-bit array: generic path)."""
     from test_oracle_extract import _jagged_ring
-    po, g = mk(orc, 16, 256, 0, 8, 10, max_ring_points=512)
-    x = _jagged_ring(700)
-    e = g.extract_edges(x, 16, 0)
-    assert len(e["ring"]) == 0
-    pose, info = g.process_scan(x, 16, 0)
-    assert info.status & 1
-    g.close()
-
+    for n, R in ((700, 8), (5000, 8), (5000, 16), (20000, 40)):
+        po, g = mk(orc, 16, (n + 15) // 16, 0, R, 10)      # capacity: max_points = 16 * W >= n
+        x = _jagged_ring(n)
+        o = orc.extract(po, x, 16, 0)
+        e = g.extract_edges(x, 16, 0)
+        assert len(o["ring"]) > 0
+        assert_edges_equal(e, o)
+        pose, info = g.process_scan(x, 16, 0)
+        assert info.status == 0
+        g.close()
 
 def test_max_ring_size(orc):
     # largest supported ring (6144 points in one 160 KiB LDS tile)

@@ -199,9 +199,10 @@ def sec_clocks(H=64, W=1800, R=8, epr=10, P=20, K=40):
     g.L.liodom_debug_clocks(g.h, buf)
     allv = np.array(list(buf), dtype=np.int64)
     print('k_ring_extract per-ring workgroup durations (us), rings 0..63:', np.round(allv[128:192] / 100.0, 1).tolist())
+    print('k_ring_extract (carry re-run rounds, edges) of the rings written last (ring & 31):', [(int(x) & 255, int(x) >> 8) for x in allv[96:128]])
     print('k_knn workgroup-duration histogram (1 us bins, all scans):', allv[192:256].tolist())
-    a = allv[:128].reshape(4, 32)
-    names = {0: ["start", "", "ring loaded", "(unused)", "stencil", "spec select", "carry check", "emitted"],
+    a = allv[:128].reshape(4, 32).copy()
+    names = {0: ["start", "", "gap bits", "", "", "spec select", "carry resolved", "emitted"],
              1: ["start", "query ready", "hash probed", "centre streamed", "merge1", "phase2 done", "nn fetched", "gate done"],
              2: ["start", "pose ready", "eval0", "begin", "eval1", "upd1", "eval2", "upd2", "eval3", "upd3", "eval4", "upd4", "", "", "", "", "", "", "", "", "loop end", "pose written", "finalized"]}
     for k, kn in ((0, "k_ring_extract (ring 40)"), (1, "k_knn (block 20, it 0)"), (2, "k_lm_solve (it 1)")):
