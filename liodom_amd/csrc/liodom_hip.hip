@@ -497,6 +497,11 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   ALLOC(h->stage_in, S * (size_t)config->max_points, 0);
   ALLOC(v.dbg_clk, 8 * 32, 0);
   ALLOC(v.lm_xch, S * 2 * kLmGroupsMax * 64, 0);
+  v.knn_queries = config->n_streams >= 16 ? 4 : 8;          // must match the k_knn instance launch_odometry picks
+  v.knn_partials = config->n_streams >= 16 ? 0 : 1;         // measured: +37 % on the VALU-bound 256-stream kNN pass, -2 us per solve on one stream
+  v.knn_blocks = round_up(cdiv(v.edge_cap, v.knn_queries), 4);
+  ALLOC(v.knn_part, S * 2 * (size_t)v.knn_blocks * 32, 0);
+  ALLOC(v.corr_mask, S * 2 * (size_t)v.knn_blocks, 0);
   {
     void* hp = nullptr;
     if (hipHostMalloc(&hp, sizeof(HostOut) * S, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { g_last_error = "hipHostMalloc failed"; return fail(LIODOM_ERR_HIP); }

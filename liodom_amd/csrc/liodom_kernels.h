@@ -35,7 +35,9 @@ namespace liodom_dev {
 
 constexpr int kWave = 64;
 constexpr uint64_t kEmptyKey = 0xFFFFFFFFFFFFFFFFull;
-constexpr int kLmThreads = 512;
+constexpr int kLmThreads = 512;           // k_lm_solve: 8 waves, two per SIMD, all evaluate residual blocks
+constexpr int kLmEvalThreads = kLmThreads;
+constexpr int kLmCtl = kLmThreads - 64;   // lane 0 of the last wave also runs the trust-region logic; waves 0..6 prepare (compaction, register cache) meanwhile
 constexpr int kLmGroupsMax = 8;
 constexpr int kKnnGroup = 32;            // lanes cooperating on one query
 constexpr int kMaxFrames = 256;          // window frames supported by the LDS prefix tables
@@ -153,6 +155,11 @@ struct DevView {
   int* vox_pts;             // [S][map_cap] window indices grouped by voxel, ascending inside a voxel
   float4* filt_pts;         // [S][map_cap] centroid xyz + voxel-index bits
   float* filt_int;          // [S][map_cap] centroid intensity
+  double* knn_part;         // [S][2][knn_blocks][32] per-k_knn-workgroup sums of the 29-entry normal-equation accumulator at the pose the pass searched with (= the solve's first evaluation)
+  unsigned char* corr_mask; // [S][2][knn_blocks] bit q: query q of that k_knn workgroup has an accepted correspondence
+  int knn_partials;         // k_knn also evaluates every accepted block at the solve's start pose and leaves per-workgroup sums (handles with < 16 streams)
+  int knn_queries;          // queries per k_knn workgroup (8, or 4 for handles with >= 16 streams)
+  int knn_blocks;           // k_knn workgroups per stream = ceil(edge_cap / knn_queries), rounded up to a multiple of 4
   unsigned long long* lm_xch;   // [S][2][kLmGroupsMax][64] tagged granules: partial sums exchanged between the LM workgroups
   unsigned long long* dbg_clk;  // [8][32] phase timestamps (100 MHz), debug bit 5 only
 };
@@ -995,11 +1002,16 @@ __global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int oute
   __shared__ int s_adj[kKnnQueries][kKnnGroup];    // cell start - exclusive prefix
   __shared__ float s_nn[kKnnQueries][16];          // the five neighbours of every query (xyz)
   __shared__ int s_res[kKnnQueries][4];            // distance gate passed, window index of NN0, NN1
+  __shared__ double s_part[kKnnQueries][32];       // normal-equation terms of every query's residual block at the solve's start pose
+  __shared__ double s_blk[kKnnQueries][24];        // that block's J[18], rho' r [3], rho, rho', validity (0 none, 1 valid, 2 non-finite)
   const int s = s0 + blockIdx.y;
   StreamState& st = v.state[s];
   if (!st.initialized) return;                     // uniform over the workgroup
   const int E = st.n_edges_buf[eb];
-  if ((int)(blockIdx.x * kKnnQueries) >= E) return;
+  if ((int)(blockIdx.x * kKnnQueries) >= E) {      // no query here: an empty validity byte for the solve's compaction
+    if (threadIdx.x == 0) v.corr_mask[((size_t)s * 2 + outer_it) * v.knn_blocks + blockIdx.x] = 0;
+    return;
+  }
   const int grp = threadIdx.x / kKnnGroup;
   const int e = blockIdx.x * kKnnQueries + grp;
   const int hl = threadIdx.x & (kKnnGroup - 1);
@@ -1174,8 +1186,55 @@ __global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int oute
         *ca = make_float4(0, 0, 0, 0); *cb = make_float4(0, 0, 0, 0); *cidx = make_int2(-1, -1);
       }
     }
-    const int nvalid = __popcll(__ballot(valid));
-    if (q == 0 && nvalid) atomicAdd(&st.info.matches[outer_it], nvalid);   // :346
+    const unsigned long long vb = __ballot(valid);
+    const int nvalid = __popcll(vb);
+    if (q == 0) {
+      if (nvalid) atomicAdd(&st.info.matches[outer_it], nvalid);   // :346
+      v.corr_mask[((size_t)s * 2 + outer_it) * v.knn_blocks + blockIdx.x] = (unsigned char)vb;   // bit q = query q accepted
+    }
+    // The solve that follows starts at (param_q, param_t) — Ceres evaluates the residuals with the quaternion,
+    // not with the matrix the neighbours were searched with (:186-195,205-206) — which is already known here.
+    // So the residual block of every accepted correspondence is evaluated right away (one lane per query, the
+    // block's inputs are in registers) and summed per workgroup: k_lm_solve's first evaluation becomes a
+    // reduction of these partial sums instead of a pass over all correspondences.
+    double flag = 0.0;
+    if (valid && v.knn_partials) {
+      double Rm[12], pq[4], pt[3];
+#pragma unroll
+      for (int i = 0; i < 4; i++) pq[i] = st.param_q[i];
+#pragma unroll
+      for (int i = 0; i < 3; i++) pt[i] = st.param_t[i];
+      iso_from_qt(pq, pt, Rm);
+      const float4 pe = v.edges[((size_t)eb * v.n_streams + s) * v.edge_cap + eq];
+      const double p[3] = {(double)pe.x, (double)pe.y, (double)pe.z};       // :347-349 sensor frame
+      const double a[3] = {(double)nx[0], (double)ny[0], (double)nz[0]};
+      const double b[3] = {(double)nx[1], (double)ny[1], (double)nz[1]};
+      double J[18], rs[3], rho0, rho1;
+      const bool ok = residual_block(Rm, p, a, b, v.min_range, v.max_range, J, rs, &rho0, &rho1);
+#pragma unroll
+      for (int i = 0; i < 18; i++) s_blk[q][i] = J[i];
+      s_blk[q][18] = rs[0]; s_blk[q][19] = rs[1]; s_blk[q][20] = rs[2]; s_blk[q][21] = rho0; s_blk[q][22] = rho1;
+      flag = ok ? 1.0 : 2.0;
+    }
+    s_blk[q][23] = flag;
+  }
+  if (!v.knn_partials) return;                           // (uniform) lock-step batches: the solve evaluates everything itself
+  __syncthreads();
+  // entry hl of the block's contribution by lane hl of the query's own 32-lane group (J is read from LDS, so
+  // the 29-entry accumulator never occupies registers in this kernel)
+  if (hl < kAccN) {
+    const double flag = s_blk[grp][23];
+    double x = 0.0;
+    if (flag == 1.0) x = residual_entry(s_blk[grp], s_blk[grp] + 18, s_blk[grp][21], s_blk[grp][22], hl);
+    else if (flag == 2.0 && hl == 28) x = 1.0;            // non-finite block: counted, contributes nothing else
+    s_part[grp][hl] = x;
+  }
+  __syncthreads();
+  if (threadIdx.x < kAccN) {
+    double x = 0.0;
+#pragma unroll
+    for (int q = 0; q < kKnnQueries; q++) x += s_part[q][threadIdx.x];      // fixed order: deterministic
+    v.knn_part[(((size_t)s * 2 + outer_it) * v.knn_blocks + blockIdx.x) * 32 + threadIdx.x] = x;
   }
   DBG_STAMP(v, dbgb, 1, 7);
   if ((v.debug & 32) && s == 0 && threadIdx.x == 0) {      // histogram of workgroup durations, 1 us bins
@@ -1199,83 +1258,88 @@ __global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int oute
 // dynamic LDS of k_lm_solve: index list + reduction scratch (full transposed matrix if it fits the
 // 160 KB of a CU next to ~3 KB of static LDS, else one partial per 16-lane row)
 __host__ __device__ __forceinline__ bool lm_lds_reduce_fits(int edge_cap) {
-  return (size_t)((edge_cap + 3) & ~3) * sizeof(int) + (size_t)kAccN * kLmThreads * sizeof(double) + 4096 <= 160 * 1024;
+  return (size_t)((edge_cap + 3) & ~3) * sizeof(int) + (size_t)kAccN * kLmEvalThreads * sizeof(double) + 8192 <= 160 * 1024;
 }
 __host__ __device__ __forceinline__ size_t lm_lds_bytes(int edge_cap) {
   return (size_t)((edge_cap + 3) & ~3) * sizeof(int) +
-         (lm_lds_reduce_fits(edge_cap) ? (size_t)kAccN * kLmThreads : (size_t)(kLmThreads / 16) * kAccN) * sizeof(double);
+         (lm_lds_reduce_fits(edge_cap) ? (size_t)kAccN * kLmEvalThreads : (size_t)(kLmThreads / 16) * kAccN) * sizeof(double);
 }
 
-__device__ int lm_compact(const DevView& v, int s, int e_begin, int E, int* idx /*LDS [edge_cap]*/, int* wtot /*LDS [4 * 8]*/) {
-  const float4* ca = v.corr_a + (size_t)s * v.edge_cap;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  constexpr int NW = kLmThreads / 64;
+
+// Compaction of the accepted correspondences from the validity bytes k_knn left (bit q of byte b = query q of
+// k_knn workgroup b): edge indices in ascending order into idx[].  Called by every evaluator wave on its own —
+// each writes the same values, so no cross-wave synchronisation is needed before a wave reads its entries.
+__device__ int lm_compact_bits(const DevView& v, int s, int outer_it, int E, int* idx /*LDS [edge_cap]*/) {
+  const int lane = threadIdx.x & 63;
+  const int Q = v.knn_queries;
+  const int nb = (E + Q - 1) / Q;                          // k_knn workgroups that had queries
+  const int nwords = (nb + 3) >> 2;
+  const unsigned int* mw = reinterpret_cast<const unsigned int*>(v.corr_mask + ((size_t)s * 2 + outer_it) * v.knn_blocks);
   int run = 0;
-  for (int base = e_begin; base < E; base += 4 * kLmThreads) {     // 4 chunks per barrier
-    int f[4], incl[4];
-#pragma unroll
-    for (int b = 0; b < 4; b++) {
-      const int e = base + b * kLmThreads + threadIdx.x;
-      f[b] = (e < E && ca[e].w != 0.0f) ? 1 : 0;
+  for (int w0 = 0; w0 < nwords; w0 += 64) {
+    const int w = w0 + lane;
+    unsigned int word = (w < nwords) ? mw[w] : 0u;
+    const int pop = __popc(word);
+    const int incl = wave_incl_scan_i32(pop);
+    int o = run + incl - pop;
+    while (word) {
+      const int b = __ffs(word) - 1;
+      word &= word - 1u;
+      const int bit = w * 32 + b;
+      idx[o++] = (bit >> 3) * Q + (bit & 7);
     }
-#pragma unroll
-    for (int b = 0; b < 4; b++) {
-      incl[b] = wave_incl_scan_i32(f[b]);
-      if (lane == 63) wtot[b * NW + wave] = incl[b];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int b = 0; b < 4; b++) {
-      int pre = 0, tot = 0;
-#pragma unroll
-      for (int w = 0; w < NW; w++) { const int t = wtot[b * NW + w]; if (w < wave) pre += t; tot += t; }
-      if (f[b]) idx[run + pre + incl[b] - 1] = base + b * kLmThreads + threadIdx.x;
-      run += tot;
-    }
-    __syncthreads();
+    run += readlane_i32(incl, 63);
   }
   return run;
 }
 
-// The correspondences of a solve do not change between its evaluations: every thread keeps its
+// The correspondences of a solve do not change between its evaluations: every evaluator thread keeps its
 // first kLmCached triples (p, a, b) in registers (loaded once by lm_cache_load), so an evaluation
-// of up to kLmCached * kLmThreads blocks touches no memory before the reduction.
+// of up to kLmCached * kLmEvalThreads blocks touches no memory before the reduction.
 constexpr int kLmCached = 1;
 struct LmCache { float4 P[kLmCached], A[kLmCached], B[kLmCached]; };
-__device__ __forceinline__ void lm_cache_load(const DevView& v, int s, int eb, int C, const int* idx, LmCache& k) {
+__device__ __forceinline__ void lm_cache_load(const DevView& v, int s, int eb, int c_lo, int c_hi, const int* idx, LmCache& k) {
   const float4* ed = v.edges + ((size_t)eb * v.n_streams + s) * v.edge_cap;
   const float4* ca = v.corr_a + (size_t)s * v.edge_cap;
   const float4* cb = v.corr_b + (size_t)s * v.edge_cap;
+  const int et = (int)threadIdx.x;
 #pragma unroll
   for (int j = 0; j < kLmCached; j++) {
-    const int c = threadIdx.x + j * kLmThreads;
-    if (c < C) { const int e = idx[c]; k.A[j] = ca[e]; k.B[j] = cb[e]; k.P[j] = ed[e]; }
+    const int c = c_lo + et + j * kLmEvalThreads;
+    // (the controller's wave fetches its blocks inside every evaluation)
+    if (et < kLmCtl && c < c_hi) { const int e = idx[c]; k.A[j] = ca[e]; k.B[j] = cb[e]; k.P[j] = ed[e]; }
   }
 }
 
-__device__ __forceinline__ void lm_eval(const DevView& v, int s, int eb, int C, const int* idx, const double* Rm_sh,
-                                        double* part /*[kAccN][kLmThreads] or [kLmThreads/16][kAccN]*/, double* acc_out /*[kAccN]*/,
-                                        const LmCache& k) {
-  double Rm[12];
-#pragma unroll
-  for (int i = 0; i < 12; i++) Rm[i] = Rm_sh[i];
+// Evaluation of the blocks c_lo .. c_hi of the compacted list by the evaluator waves, then the reduction by
+// everybody.  part: [kAccN][kLmEvalThreads] or [kLmThreads/16][kAccN].
+__device__ __forceinline__ void lm_eval(const DevView& v, int s, int eb, int c_lo, int c_hi, const int* idx, const double* Rm_sh,
+                                        double* part, double* acc_out /*[kAccN]*/, const LmCache& k) {
+  const int et = (int)threadIdx.x;
+  const bool cached = et < kLmCtl;
   double acc[kAccN];
 #pragma unroll
   for (int i = 0; i < kAccN; i++) acc[i] = 0.0;
+  {
+    double Rm[12];
 #pragma unroll
-  for (int j = 0; j < kLmCached; j++) {
-    if ((int)threadIdx.x + j * kLmThreads < C) {
-      const double p[3] = {(double)k.P[j].x, (double)k.P[j].y, (double)k.P[j].z};     // :347-349 sensor frame
-      const double a[3] = {(double)k.A[j].x, (double)k.A[j].y, (double)k.A[j].z};
-      const double b[3] = {(double)k.B[j].x, (double)k.B[j].y, (double)k.B[j].z};
-      residual_accumulate(Rm, p, a, b, v.min_range, v.max_range, acc);
-    }
-  }
-  if (C > kLmCached * kLmThreads) {
+    for (int i = 0; i < 12; i++) Rm[i] = Rm_sh[i];
     const float4* ed = v.edges + ((size_t)eb * v.n_streams + s) * v.edge_cap;
     const float4* ca = v.corr_a + (size_t)s * v.edge_cap;
     const float4* cb = v.corr_b + (size_t)s * v.edge_cap;
-    for (int c = threadIdx.x + kLmCached * kLmThreads; c < C; c += kLmThreads) {
+    int c = c_lo + et;
+    if (cached) {
+#pragma unroll
+      for (int j = 0; j < kLmCached; j++, c += kLmEvalThreads) {
+        if (c < c_hi) {
+          const double p[3] = {(double)k.P[j].x, (double)k.P[j].y, (double)k.P[j].z};     // :347-349 sensor frame
+          const double a[3] = {(double)k.A[j].x, (double)k.A[j].y, (double)k.A[j].z};
+          const double b[3] = {(double)k.B[j].x, (double)k.B[j].y, (double)k.B[j].z};
+          residual_accumulate(Rm, p, a, b, v.min_range, v.max_range, acc);
+        }
+      }
+    }
+    for (; c < c_hi; c += kLmEvalThreads) {
       const int e = idx[c];
       const float4 A = ca[e];
       const float4 B = cb[e];
@@ -1287,27 +1351,26 @@ __device__ __forceinline__ void lm_eval(const DevView& v, int s, int eb, int C, 
     }
   }
   if (v.lm_lds_reduce) {
-    // Reduction through LDS, transposed: every thread stores its 29 partial sums as column t of
-    // red[29][kLmThreads] (conflict-free 8-byte stores); then thread (v, r) = (t / 16, t % 16) sums
-    // the elements r, r + 16, r + 32, ... of row v (conflict-free loads, 32 adds), a 4-step DPP row
-    // sum finishes row v.  Fixed order -> deterministic, no atomics.  Replaces 29 x 4 DPP steps per
-    // wave (8 waves' worth of 64-bit DPP moves serialised on 4 SIMDs).
+    // Reduction through LDS, transposed: every evaluator stores its 29 partial sums as column et of
+    // red[29][kLmEvalThreads] (conflict-free 8-byte stores); then thread (v, r) = (t / 16, t % 16) sums
+    // the elements r, r + 16, r + 32, ... of row v (conflict-free loads, 28 adds), a 4-step DPP row
+    // sum finishes row v.  Fixed order -> deterministic, no atomics.
 #pragma unroll
-    for (int i = 0; i < kAccN; i++) part[i * kLmThreads + threadIdx.x] = acc[i];
+    for (int i = 0; i < kAccN; i++) part[i * kLmEvalThreads + et] = acc[i];
     __syncthreads();
     const int vrow = threadIdx.x >> 4, r = threadIdx.x & 15;
     double x = 0.0;
     if (vrow < kAccN) {
-      const double* rowp = part + vrow * kLmThreads + r;
+      const double* rowp = part + vrow * kLmEvalThreads + r;
 #pragma unroll 8
-      for (int k = 0; k < kLmThreads / 16; k++) x += rowp[k * 16];
+      for (int kk = 0; kk < kLmEvalThreads / 16; kk++) x += rowp[kk * 16];
     }
     x = row_sum_f64(x);
     if (vrow < kAccN && r == 0) acc_out[vrow] = x;
     __syncthreads();
     return;
   }
-  // Large edge capacities (the 118 KB matrix no longer fits beside the index list): DPP butterfly
+  // Large edge capacities (the matrix no longer fits beside the index list): DPP butterfly
   // inside each 16-lane row, one partial per row into LDS, then a fixed-order sum of the partials.
 #pragma unroll
   for (int i = 0; i < kAccN; i++) acc[i] = row_sum_f64(acc[i]);
@@ -1346,9 +1409,9 @@ __device__ void hash_clear_used(const DevView& v, int s, int nup, int t, int nt)
 }
 
 // Called by the whole workgroup.  sh_cnt: LDS scratch of kMaxFrames + 1 ints.
-// Thread 64 publishes the result (pose log, host-mapped record) while thread 0 computes the
-// prediction and the window bookkeeping; the remaining threads fetch the frame sizes.
-__device__ void finalize_scan(const DevView& v, int s, StreamState& st, int* sh_cnt, int eb, bool clear_hash) {
+// Thread 64 publishes the result (pose log, host-mapped record) while thread `ctl` (the one that wrote st.odom)
+// computes the prediction and the window bookkeeping; the remaining threads fetch the frame sizes.
+__device__ void finalize_scan(const DevView& v, int s, StreamState& st, int* sh_cnt, int eb, bool clear_hash, int ctl) {
   const int P = v.prev_frames;
   const int tid = threadIdx.x;
   // LocalMapManager::addPointCloud (:34-60) on a ring of P frame slots: the new frame goes
@@ -1361,7 +1424,7 @@ __device__ void finalize_scan(const DevView& v, int s, StreamState& st, int* sh_
   int* ws = v.win_slot + (size_t)s * P;
   const int n_edges = st.n_edges_buf[eb];
   const int nup = st.n_used;      // cells of the build that this scan searched (cleared below)
-  if (tid == 0) { for (int i = 0; i < 12; i++) st.final_odom[i] = st.odom[i]; }
+  if (tid == ctl) { for (int i = 0; i < 12; i++) st.final_odom[i] = st.odom[i]; }   // (ctl wrote st.odom itself)
   __syncthreads();
   for (int j = tid; j < nf; j += blockDim.x) {
     const int sl = (fc_new - nf + j) % P;
@@ -1394,7 +1457,7 @@ __device__ void finalize_scan(const DevView& v, int s, StreamState& st, int* sh_
     }
     st.info.matches[0] = 0; st.info.matches[1] = 0;   // counters of the next scan's two kNN passes
   }
-  if (tid == 0) {
+  if (tid == ctl) {
     // prediction for the next scan: odom * (prev^-1 * odom)   (:148-150)
     double inv[12], rel[12], pred[12];
     iso_inverse(st.prev_odom, inv);
@@ -1485,14 +1548,18 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
   __shared__ double sh_acc[kAccN];
   __shared__ LmState lm;
   __shared__ int sh_flag;
+  __shared__ int sh_C;
   const int s = s0 + blockIdx.y;
   const int g = blockIdx.x, G = gridDim.x;      // G cooperating workgroups per stream
   StreamState& st = v.state[s];
   __shared__ int sh_cnt[kMaxFrames + 1];
   __shared__ double sh_loc[kAccN];
+  __shared__ double sh_red[16][32];
   extern __shared__ __attribute__((aligned(16))) int sh_idx[];   // [edge_cap] compacted correspondence indices, then the reduction matrix
-  double* sh_part = reinterpret_cast<double*>(sh_idx + ((v.edge_cap + 3) & ~3));   // [kAccN][kLmThreads]
-  if (outer_it == 0 && threadIdx.x == 0 && g == 0) {     // per-scan diagnostics (matches are counted by k_knn)
+  double* sh_part = reinterpret_cast<double*>(sh_idx + ((v.edge_cap + 3) & ~3));   // [kAccN][kLmEvalThreads]
+  const int tid = threadIdx.x;
+  const bool prep = tid < kLmCtl;               // waves 0..6: compaction + register cache while the controller lane works
+  if (outer_it == 0 && tid == 0 && g == 0) {     // per-scan diagnostics (matches are counted by k_knn)
     st.info.n_edges = st.n_edges_buf[eb];
     st.info.map_points = st.n_search;
     for (int k = 0; k < 2; k++) {
@@ -1503,88 +1570,120 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
   if (!st.initialized) {
     // first frame (:108-136): no solve; pose stays identity, edges enter the window raw
     if (outer_it == 1 && g == 0) {
-      if (threadIdx.x == 0) st.append_raw = 1;
-      finalize_scan(v, s, st, sh_cnt, eb, true);
-      if (threadIdx.x == 0) st.initialized = 1;
+      if (tid == 0) st.append_raw = 1;
+      finalize_scan(v, s, st, sh_cnt, eb, true, 0);
+      if (tid == 0) st.initialized = 1;
     }
     return;
   }
-  // (finalising solve) slots of the cell hash to reset later, 8 per thread of waves 1..: loads only
-  int clr[8];
-  int clr_n = 0;
-#pragma unroll
-  for (int k = 0; k < 8; k++) clr[k] = -1;
-  if (outer_it == 1 && g == 0 && threadIdx.x >= 64) {
-    clr_n = st.n_used;
-    const int nt = (int)blockDim.x - 64, t0 = (int)threadIdx.x - 64;
-    const int* used = v.used_cells + (size_t)s * v.map_cap;
-#pragma unroll
-    for (int k = 0; k < 8; k++) { const int u = t0 + k * nt; if (u < clr_n) clr[k] = used[u]; }
-  }
-  const bool dbgb = (s == 0) && (g == 0) && (threadIdx.x == 0) && (outer_it == 1);
+  // The second kNN pass of this scan has completed when the finalising solve starts, so the cell hash it
+  // searched is no longer needed: waves 0..6 reset its occupied slots while the controller lane works on its
+  // first update step (they would idle at the barrier otherwise).
+  bool clr_pending = outer_it == 1 && g == 0 && prep;
+  auto clear_hash_slots = [&]() {
+    hash_clear_used(v, s, st.n_used, tid, kLmCtl);
+    clr_pending = false;
+  };
+  const bool dbgb = (s == 0) && (g == 0) && (tid == kLmCtl) && (outer_it == 1);
+  const bool dbge = (s == 0) && (g == 0) && (tid == 0) && (outer_it == 1);
   DBG_STAMP(v, dbgb, 2, 0);
   const int E = st.n_edges_buf[eb];
   const int nblocks = st.info.matches[outer_it];
-  if (threadIdx.x == 0) iso_from_qt(st.param_q, st.param_t, sh_pose);
-  // this workgroup's contiguous share of the edges
-  const int chunk = (E + G - 1) / G;
-  const int e_lo = g * chunk < E ? g * chunk : E;
-  const int e_hi = (g + 1) * chunk < E ? (g + 1) * chunk : E;
   const unsigned int epoch0 = ((unsigned int)(st.scan_counter + 1) << 6) | ((unsigned int)outer_it << 5);
   unsigned int n_eval = 0;
-  const int C = lm_compact(v, s, e_lo, e_hi, sh_idx, sh_cnt);   // (ends with a barrier; sh_cnt doubles as scratch)
-  __syncthreads();
   LmCache cache;
-  lm_cache_load(v, s, eb, C, sh_idx, cache);
-  DBG_STAMP(v, dbgb, 2, 1);
-  if (G > 1) { lm_eval(v, s, eb, C, sh_idx, sh_pose, sh_part, sh_loc, cache); lm_exchange(v, s, g, G, epoch0 | ++n_eval, sh_loc, sh_acc, &st.status); }
-  else lm_eval(v, s, eb, C, sh_idx, sh_pose, sh_part, sh_acc, cache);
-  DBG_STAMP(v, dbgb, 2, 2);
-  if (threadIdx.x == 0) {
-    sh_flag = lm_begin(lm, st.param_q, st.param_t, sh_acc, nblocks, v.apply_on_ftol);
-    if (sh_flag == LM_NEED_EVAL) iso_from_qt(lm.cand_q, lm.cand_t, sh_pose);
-  } else if (outer_it == 1 && g == 0 && threadIdx.x >= 64) {
-    // The second kNN pass of this scan has completed, the cell hash it searched is no longer needed:
-    // waves 1.. reset its occupied slots while lane 0 of wave 0 runs the first controller step
-    // (they would idle at the barrier otherwise; at the end of the kernel this cost 4.5 us).  The slot
-    // indices were fetched at kernel start, so only stores are issued here.
-    CellSlot empty; empty.key = kEmptyKey; empty.start = 0; empty.cnt = 0;
+  int c_lo = 0, c_hi = 0;
+  auto my_share = [&](int C) {                           // this workgroup's contiguous share of the compacted blocks
+    const int chunk = (C + G - 1) / G;
+    c_lo = g * chunk < C ? g * chunk : C;
+    c_hi = (g + 1) * chunk < C ? (g + 1) * chunk : C;
+  };
+  if (v.knn_partials) {
+    // ---- first evaluation = sum of the partial normal equations the k_knn workgroups left, in workgroup order ----
+    {
+      const int Q = v.knn_queries;
+      const int nb = (E + Q - 1) / Q;
+      const double* part = v.knn_part + ((size_t)s * 2 + outer_it) * v.knn_blocks * 32;
+      const int i = tid & 31, r0 = tid >> 5;               // 16 row classes x 32 columns (29 used)
+      double x0 = 0.0, x1 = 0.0;
+      if (i < kAccN) {
+        // 16 independent loads in flight per pass (one memory round trip for up to 256 k_knn workgroups)
+        for (int rb = r0; rb < nb; rb += 256) {
+          double xs[16];
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-      if (clr[k] >= 0) {
-        const size_t ti = (size_t)s * v.table_size + clr[k];
-        v.cells[ti] = empty;
-        v.cell_bits[ti >> 5] = 0u;   // every set bit of that word belongs to a slot of the list being cleared
+          for (int u = 0; u < 16; u++) { const int r = rb + 16 * u; xs[u] = (r < nb) ? part[(size_t)r * 32 + i] : 0.0; }
+#pragma unroll
+          for (int u = 0; u < 16; u += 2) { x0 += xs[u]; x1 += xs[u + 1]; }
+        }
       }
-    }
-    if (clr_n > 8 * ((int)blockDim.x - 64)) {      // longer lists: the rest the ordinary way
-      const int nt = (int)blockDim.x - 64, t0 = (int)threadIdx.x - 64;
-      const int* used = v.used_cells + (size_t)s * v.map_cap;
-      for (int u = 8 * nt + t0; u < clr_n; u += nt) {
-        const size_t ti = (size_t)s * v.table_size + used[u];
-        v.cells[ti] = empty;
-        v.cell_bits[ti >> 5] = 0u;
+      sh_red[r0][i] = x0 + x1;
+      __syncthreads();
+      if (tid < kAccN) {
+        double x = 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; r++) x += sh_red[r][tid];
+        sh_acc[tid] = x;
       }
+      __syncthreads();
     }
+    DBG_STAMP(v, dbgb, 2, 2);
+    // ---- controller: first step; meanwhile every evaluator wave compacts the accepted correspondences
+    // (validity bytes -> index list) and fetches its triples into registers ----
+    if (tid == kLmCtl) {
+      sh_flag = lm_begin(lm, st.param_q, st.param_t, sh_acc, nblocks, v.apply_on_ftol);
+      if (sh_flag == LM_NEED_EVAL) iso_from_qt(lm.cand_q, lm.cand_t, sh_pose);
+      DBG_STAMP(v, dbgb, 2, 23);
+    } else if (prep) {
+      DBG_STAMP(v, dbge, 2, 24);
+      const int C = lm_compact_bits(v, s, outer_it, E, sh_idx);
+      if (tid == 0) sh_C = C;
+      DBG_STAMP(v, dbge, 2, 25);
+      my_share(C);
+      lm_cache_load(v, s, eb, c_lo, c_hi, sh_idx, cache);
+    }
+    __syncthreads();
+    if (!prep) my_share(sh_C);
+  } else {
+    // ---- lock-step batches: k_knn leaves only the validity bytes; compaction, then an ordinary first evaluation ----
+    if (prep) {
+      const int C = lm_compact_bits(v, s, outer_it, E, sh_idx);
+      if (tid == 0) sh_C = C;
+    } else if (tid == kLmCtl) {
+      iso_from_qt(st.param_q, st.param_t, sh_pose);
+    }
+    __syncthreads();
+    my_share(sh_C);
+    lm_cache_load(v, s, eb, c_lo, c_hi, sh_idx, cache);
+    if (G > 1) { lm_eval(v, s, eb, c_lo, c_hi, sh_idx, sh_pose, sh_part, sh_loc, cache); lm_exchange(v, s, g, G, epoch0 | ++n_eval, sh_loc, sh_acc, &st.status); }
+    else lm_eval(v, s, eb, c_lo, c_hi, sh_idx, sh_pose, sh_part, sh_acc, cache);
+    if (tid == kLmCtl) {
+      sh_flag = lm_begin(lm, st.param_q, st.param_t, sh_acc, nblocks, v.apply_on_ftol);
+      if (sh_flag == LM_NEED_EVAL) iso_from_qt(lm.cand_q, lm.cand_t, sh_pose);
+    } else if (clr_pending) {
+      clear_hash_slots();
+    }
+    __syncthreads();
   }
-  __syncthreads();
   DBG_STAMP(v, dbgb, 2, 3);
   int dbg_it = 0;
   while (sh_flag == LM_NEED_EVAL && !(v.debug & 8)) {
-    if (G > 1) { lm_eval(v, s, eb, C, sh_idx, sh_pose, sh_part, sh_loc, cache); lm_exchange(v, s, g, G, epoch0 | ++n_eval, sh_loc, sh_acc, &st.status); }
-    else lm_eval(v, s, eb, C, sh_idx, sh_pose, sh_part, sh_acc, cache);
+    if (G > 1) { lm_eval(v, s, eb, c_lo, c_hi, sh_idx, sh_pose, sh_part, sh_loc, cache); lm_exchange(v, s, g, G, epoch0 | ++n_eval, sh_loc, sh_acc, &st.status); }
+    else lm_eval(v, s, eb, c_lo, c_hi, sh_idx, sh_pose, sh_part, sh_acc, cache);
     DBG_STAMP(v, dbgb && dbg_it < 5, 2, 4 + 2 * dbg_it);
-    if (threadIdx.x == 0) {
+    if (tid == kLmCtl) {
       sh_flag = lm_update(lm, sh_acc);
       if (sh_flag == LM_NEED_EVAL) iso_from_qt(lm.cand_q, lm.cand_t, sh_pose);
+    } else if (clr_pending) {
+      clear_hash_slots();                                // beside the controller's first update step
     }
     __syncthreads();
     DBG_STAMP(v, dbgb && dbg_it < 5, 2, 5 + 2 * dbg_it);
     dbg_it++;
   }
+  if (clr_pending) clear_hash_slots();                   // (the solve ended at its first step)
   DBG_STAMP(v, dbgb, 2, 20);
   if (g != 0) return;        // every workgroup reached the same result; workgroup 0 records it
-  if (threadIdx.x == 0) {
+  if (tid == kLmCtl) {
     for (int k = 0; k < 4; k++) st.param_q[k] = lm.q[k];
     for (int k = 0; k < 3; k++) st.param_t[k] = lm.t[k];
     iso_from_qt(st.param_q, st.param_t, st.odom);                  // :222-227
@@ -1595,7 +1694,7 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
   }
   DBG_STAMP(v, dbgb, 2, 21);
   if (outer_it == 1) {
-    finalize_scan(v, s, st, sh_cnt, eb, false);
+    finalize_scan(v, s, st, sh_cnt, eb, false, kLmCtl);
   }
   DBG_STAMP(v, dbgb, 2, 22);
 }

@@ -440,8 +440,12 @@ LD_HD int h_idx(int i, int j) {  // upper-triangle index, i <= j
 }
 LD_HD double h_at(const double* H, int i, int j) { return i <= j ? H[h_idx(i, j)] : H[h_idx(j, i)]; }
 
-LD_HD void residual_accumulate(const double* Rm /*3x4*/, const double* p, const double* a,
-                               const double* b, double min_d, double max_d, double* acc) {
+// One block: the loss-corrected quantities the normal equations are built from.
+//   J[18]  3 x 6 tangent Jacobian (row-major: residual r, column c at J[6 r + c]), NOT yet scaled by sqrt(rho')
+//   rs[3]  rho' * residual,  rho0 = rho(|r|^2),  rho1 = rho'
+// Returns false if anything is non-finite (ceres IsEvaluationValid).
+LD_HD bool residual_block(const double* Rm /*3x4*/, const double* p, const double* a, const double* b,
+                          double min_d, double max_d, double* J, double* rs, double* rho0_out, double* rho1_out) {
   LD_FP_CONTRACT_FAST
   const double tx = Rm[3], ty = Rm[7], tz = Rm[11];
   const double Rp0 = Rm[0] * p[0] + Rm[1] * p[1] + Rm[2] * p[2];
@@ -466,7 +470,6 @@ LD_HD void residual_accumulate(const double* Rm /*3x4*/, const double* p, const 
   // Jq = (2w/L) [de]x [Rp]x ; [de]x[Rp]x = Rp de^T - (de.Rp) I
   const double dot = de0 * Rp0 + de1 * Rp1 + de2 * Rp2;
   const double k2 = 2.0 * wl;
-  double J[18];
   J[0]  = k2 * (Rp0 * de0 - dot); J[1]  = k2 * (Rp0 * de1);       J[2]  = k2 * (Rp0 * de2);
   J[6]  = k2 * (Rp1 * de0);       J[7]  = k2 * (Rp1 * de1 - dot); J[8]  = k2 * (Rp1 * de2);
   J[12] = k2 * (Rp2 * de0);       J[13] = k2 * (Rp2 * de1);       J[14] = k2 * (Rp2 * de2 - dot);
@@ -492,12 +495,32 @@ LD_HD void residual_accumulate(const double* Rm /*3x4*/, const double* p, const 
   double z = s * 0.0;
   LD_UNROLL
   for (int i = 0; i < 18; i++) z += J[i] * 0.0;
-  if (!(z == 0.0)) { acc[28] += 1.0; return; }
+  *rho0_out = rho0; *rho1_out = rho1;
+  rs[0] = rho1 * r0; rs[1] = rho1 * r1; rs[2] = rho1 * r2;
+  return z == 0.0;
+}
+// Entry e of the 29-entry accumulator contributed by one valid block (see residual_accumulate for the layout).
+LD_HD double residual_entry(const double* J, const double* rs, double rho0, double rho1, int e) {
+  LD_FP_CONTRACT_FAST
+  if (e == 0) return 0.5 * rho0;
+  if (e <= 6) { const int i = e - 1; return J[i] * rs[0] + J[6 + i] * rs[1] + J[12 + i] * rs[2]; }
+  if (e >= 28) return 0.0;
+  int k = e - 7, i = 0;                       // upper-triangle index -> (i, j)
+  while (k >= 6 - i) { k -= 6 - i; i++; }
+  const int j = i + k;
+  const double a0 = rho1 * J[i], a1 = rho1 * J[6 + i], a2 = rho1 * J[12 + i];
+  return a0 * J[j] + a1 * J[6 + j] + a2 * J[12 + j];
+}
+
+LD_HD void residual_accumulate(const double* Rm /*3x4*/, const double* p, const double* a,
+                               const double* b, double min_d, double max_d, double* acc) {
+  LD_FP_CONTRACT_FAST
+  double J[18], rs[3], rho0, rho1;
+  if (!residual_block(Rm, p, a, b, min_d, max_d, J, rs, &rho0, &rho1)) { acc[28] += 1.0; return; }
   acc[0] += 0.5 * rho0;
-  const double rs0 = rho1 * r0, rs1 = rho1 * r1, rs2 = rho1 * r2;
   LD_UNROLL
   for (int i = 0; i < 6; i++) {
-    acc[1 + i] += J[i] * rs0 + J[6 + i] * rs1 + J[12 + i] * rs2;
+    acc[1 + i] += J[i] * rs[0] + J[6 + i] * rs[1] + J[12 + i] * rs[2];
     const double a0 = rho1 * J[i], a1 = rho1 * J[6 + i], a2 = rho1 * J[12 + i];
     LD_UNROLL
     for (int j = i; j < 6; j++) acc[7 + h_idx(i, j)] += a0 * J[j] + a1 * J[6 + j] + a2 * J[12 + j];
