@@ -1600,49 +1600,30 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
   };
   if (v.knn_partials) {
     // ---- first evaluation = sum of the partial normal equations the k_knn workgroups left, in workgroup order ----
-    {
-      const int Q = v.knn_queries;
-      const int nb = (E + Q - 1) / Q;
-      const double* part = v.knn_part + ((size_t)s * 2 + outer_it) * v.knn_blocks * 32;
-      const int i = tid & 31, r0 = tid >> 5;               // 16 row classes x 32 columns (29 used)
-      double x0 = 0.0, x1 = 0.0;
-      if (i < kAccN) {
-        // 16 independent loads in flight per pass (one memory round trip for up to 256 k_knn workgroups)
-        for (int rb = r0; rb < nb; rb += 256) {
-          double xs[16];
+    const int Q = v.knn_queries;
+    const int nb = (E + Q - 1) / Q;
+    const double* part = v.knn_part + ((size_t)s * 2 + outer_it) * v.knn_blocks * 32;
+    const int i = tid & 31, r0 = tid >> 5;               // 16 row classes x 32 columns (29 used)
+    double x0 = 0.0, x1 = 0.0;
+    if (i < kAccN) {
+      // 16 independent loads in flight per pass (one memory round trip for up to 256 k_knn workgroups)
+      for (int rb = r0; rb < nb; rb += 256) {
+        double xs[16];
 #pragma unroll
-          for (int u = 0; u < 16; u++) { const int r = rb + 16 * u; xs[u] = (r < nb) ? part[(size_t)r * 32 + i] : 0.0; }
+        for (int u = 0; u < 16; u++) { const int r = rb + 16 * u; xs[u] = (r < nb) ? part[(size_t)r * 32 + i] : 0.0; }
 #pragma unroll
-          for (int u = 0; u < 16; u += 2) { x0 += xs[u]; x1 += xs[u + 1]; }
-        }
+        for (int u = 0; u < 16; u += 2) { x0 += xs[u]; x1 += xs[u + 1]; }
       }
-      sh_red[r0][i] = x0 + x1;
-      __syncthreads();
-      if (tid < kAccN) {
-        double x = 0.0;
-#pragma unroll
-        for (int r = 0; r < 16; r++) x += sh_red[r][tid];
-        sh_acc[tid] = x;
-      }
-      __syncthreads();
     }
-    DBG_STAMP(v, dbgb, 2, 2);
-    // ---- controller: first step; meanwhile every evaluator wave compacts the accepted correspondences
-    // (validity bytes -> index list) and fetches its triples into registers ----
-    if (tid == kLmCtl) {
-      sh_flag = lm_begin(lm, st.param_q, st.param_t, sh_acc, nblocks, v.apply_on_ftol);
-      if (sh_flag == LM_NEED_EVAL) iso_from_qt(lm.cand_q, lm.cand_t, sh_pose);
-      DBG_STAMP(v, dbgb, 2, 23);
-    } else if (prep) {
-      DBG_STAMP(v, dbge, 2, 24);
-      const int C = lm_compact_bits(v, s, outer_it, E, sh_idx);
-      if (tid == 0) sh_C = C;
-      DBG_STAMP(v, dbge, 2, 25);
-      my_share(C);
-      lm_cache_load(v, s, eb, c_lo, c_hi, sh_idx, cache);
+    sh_red[r0][i] = x0 + x1;
+    __syncthreads();
+    if (tid < kAccN) {
+      double x = 0.0;
+#pragma unroll
+      for (int r = 0; r < 16; r++) x += sh_red[r][tid];
+      sh_acc[tid] = x;
     }
     __syncthreads();
-    if (!prep) my_share(sh_C);
   } else {
     // ---- lock-step batches: k_knn leaves only the validity bytes; compaction, then an ordinary first evaluation ----
     if (prep) {
@@ -1656,29 +1637,40 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
     lm_cache_load(v, s, eb, c_lo, c_hi, sh_idx, cache);
     if (G > 1) { lm_eval(v, s, eb, c_lo, c_hi, sh_idx, sh_pose, sh_part, sh_loc, cache); lm_exchange(v, s, g, G, epoch0 | ++n_eval, sh_loc, sh_acc, &st.status); }
     else lm_eval(v, s, eb, c_lo, c_hi, sh_idx, sh_pose, sh_part, sh_acc, cache);
+  }
+  DBG_STAMP(v, dbgb, 2, 2);
+  // ---- trust-region loop.  Controller step on lane 0 of the last wave; beside it waves 0..6 prepare the
+  // evaluations (step 0: validity bytes -> index list, triples into registers) or reset the hash slots of the
+  // build this scan searched (step 1 of the finalising solve) ----
+  int dbg_it = 0;
+  for (int step = 0; !(v.debug & 8) || step == 0; step++) {
     if (tid == kLmCtl) {
-      sh_flag = lm_begin(lm, st.param_q, st.param_t, sh_acc, nblocks, v.apply_on_ftol);
-      if (sh_flag == LM_NEED_EVAL) iso_from_qt(lm.cand_q, lm.cand_t, sh_pose);
+      // (a wave-parallel controller — lane 8 r + c holding entry (r, c) of the 6 x 6 matrices, Cholesky columns
+      // broadcast through LDS, solves on readlane'd entries — was measured slower than this single lane:
+      // 3.9-5.9 us per step against 3.1)
+      const int f = step == 0 ? lm_begin(lm, st.param_q, st.param_t, sh_acc, nblocks, v.apply_on_ftol) : lm_update(lm, sh_acc);
+      sh_flag = f;
+      if (f == LM_NEED_EVAL) iso_from_qt(lm.cand_q, lm.cand_t, sh_pose);
+      if (step == 0) DBG_STAMP(v, dbgb, 2, 23);
+    } else if (!prep) {
+      // (the other lanes of the controller's wave wait at the barrier)
+    } else if (step == 0 && v.knn_partials) {
+      DBG_STAMP(v, dbge, 2, 24);
+      const int C = lm_compact_bits(v, s, outer_it, E, sh_idx);
+      if (tid == 0) sh_C = C;
+      DBG_STAMP(v, dbge, 2, 25);
+      my_share(C);
+      lm_cache_load(v, s, eb, c_lo, c_hi, sh_idx, cache);
     } else if (clr_pending) {
       clear_hash_slots();
     }
     __syncthreads();
-  }
-  DBG_STAMP(v, dbgb, 2, 3);
-  int dbg_it = 0;
-  while (sh_flag == LM_NEED_EVAL && !(v.debug & 8)) {
+    if (step == 0) { if (v.knn_partials && !prep) my_share(sh_C); DBG_STAMP(v, dbgb, 2, 3); }
+    else { DBG_STAMP(v, dbgb && dbg_it < 5, 2, 5 + 2 * dbg_it); dbg_it++; }
+    if (sh_flag != LM_NEED_EVAL) break;
     if (G > 1) { lm_eval(v, s, eb, c_lo, c_hi, sh_idx, sh_pose, sh_part, sh_loc, cache); lm_exchange(v, s, g, G, epoch0 | ++n_eval, sh_loc, sh_acc, &st.status); }
     else lm_eval(v, s, eb, c_lo, c_hi, sh_idx, sh_pose, sh_part, sh_acc, cache);
     DBG_STAMP(v, dbgb && dbg_it < 5, 2, 4 + 2 * dbg_it);
-    if (tid == kLmCtl) {
-      sh_flag = lm_update(lm, sh_acc);
-      if (sh_flag == LM_NEED_EVAL) iso_from_qt(lm.cand_q, lm.cand_t, sh_pose);
-    } else if (clr_pending) {
-      clear_hash_slots();                                // beside the controller's first update step
-    }
-    __syncthreads();
-    DBG_STAMP(v, dbgb && dbg_it < 5, 2, 5 + 2 * dbg_it);
-    dbg_it++;
   }
   if (clr_pending) clear_hash_slots();                   // (the solve ended at its first step)
   DBG_STAMP(v, dbgb, 2, 20);
