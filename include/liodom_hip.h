@@ -193,6 +193,11 @@ int liodom_get_local_map(liodom_handle_t* h, int stream, float* xyzi, int64_t ca
  * line points per edge. */
 int liodom_get_correspondences(liodom_handle_t* h, int stream, int it, int32_t* valid,
                                int32_t* idx_a, int32_t* idx_b, int cap, int* n);
+/* World-frame float queries (edges transformed by the pose entering outer iteration `it`,
+ * src/laser_odometry.cc:307-308) of the last step: n x float[4] (x y z 0).  debug_buffers = 1 only.
+ * Together with liodom_get_local_map (taken before the step) they are the exact inputs of the 5-NN +
+ * line-gate kernel, so that its output can be compared bit for bit with the oracle on identical inputs. */
+int liodom_get_knn_queries(liodom_handle_t* h, int stream, int it, float* xyz0, int cap, int* n);
 /* Smoothness values of the last extracted scan, ring-major over the compacted rings; also the
  * ring offsets (scan_lines + 1 entries).  NaN where the stencil is undefined. */
 int liodom_get_curvature(liodom_handle_t* h, int stream, double* curv, int64_t cap,

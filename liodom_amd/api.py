@@ -187,6 +187,8 @@ def load():
     L.liodom_get_local_map.argtypes = [vp, C.c_int, fp, C.c_int64, C.POINTER(C.c_int64), ip]
     L.liodom_get_correspondences.restype = C.c_int
     L.liodom_get_correspondences.argtypes = [vp, C.c_int, C.c_int, ip, ip, ip, C.c_int, ip]
+    L.liodom_get_knn_queries.restype = C.c_int
+    L.liodom_get_knn_queries.argtypes = [vp, C.c_int, C.c_int, fp, C.c_int, ip]
     L.liodom_get_curvature.restype = C.c_int
     L.liodom_get_curvature.argtypes = [vp, C.c_int, dp, C.c_int64, ip]
     L.liodom_set_profiling.restype = C.c_int
@@ -232,7 +234,7 @@ EXPORTED_SYMBOLS = [
     "liodom_params_default", "liodom_config_default", "liodom_create", "liodom_destroy", "liodom_last_error",
     "liodom_extract_edges", "liodom_odometry_step", "liodom_process_scan", "liodom_set_received_map",
     "liodom_alloc_resident", "liodom_upload_scan", "liodom_process_resident", "liodom_process_resident_pipelined", "liodom_sync", "liodom_get_pose_log",
-    "liodom_reset", "liodom_get_edges", "liodom_get_window", "liodom_get_local_map", "liodom_get_correspondences", "liodom_get_curvature",
+    "liodom_reset", "liodom_get_edges", "liodom_get_window", "liodom_get_local_map", "liodom_get_correspondences", "liodom_get_curvature", "liodom_get_knn_queries",
     "liodom_set_profiling", "liodom_get_kernel_stats", "liodom_reset_kernel_stats", "liodom_device_info",
     "liodom_device_count", "liodom_device_pci_bus_id",
     "liodom_map_config_default", "liodom_map_create", "liodom_map_destroy", "liodom_map_update", "liodom_map_get_local",
@@ -436,6 +438,14 @@ class Liodom:
         self._check(self.L.liodom_get_correspondences(self.h, stream, it, _ip(v), _ip(a), _ip(b), cap, C.byref(n)))
         k = n.value
         return v[:k].copy(), a[:k].copy(), b[:k].copy()
+
+    def knn_queries(self, it, stream=0):
+        """World-frame float queries of outer iteration `it` of the last step (debug_buffers = 1)."""
+        cap = self.edge_cap
+        q = np.zeros((cap, 4), np.float32)
+        n = C.c_int32()
+        self._check(self.L.liodom_get_knn_queries(self.h, stream, it, _fp(q), cap, C.byref(n)))
+        return q[:n.value, :3].copy()
 
     def curvature(self, stream=0):
         cap = int(self.config.max_points) + 16

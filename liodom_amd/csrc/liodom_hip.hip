@@ -471,6 +471,7 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   ALLOC(v.corr_a, S * v.edge_cap, 0);
   ALLOC(v.corr_b, S * v.edge_cap, 0);
   ALLOC(v.corr_idx, S * 2 * v.edge_cap, 0xFF);
+  if (v.debug & 1) ALLOC(v.knn_q, S * 2 * v.edge_cap, 0); else v.knn_q = nullptr;
   ALLOC(v.win_pts, S * h->P * v.edge_cap, 0);
   ALLOC(v.win_n, S * h->P, 0);
   ALLOC(v.win_base, S * (h->P + 1), 0);
@@ -940,6 +941,21 @@ int liodom_get_correspondences(liodom_handle_t* h, int stream, int it, int32_t* 
     if (idx_a) idx_a[i] = ci[i].x;
     if (idx_b) idx_b[i] = ci[i].y;
   }
+  return LIODOM_OK;
+}
+
+int liodom_get_knn_queries(liodom_handle_t* h, int stream, int it, float* xyz0, int cap, int* n) {
+  int rc = check_stream(h, stream);
+  if (rc) return rc;
+  if (it < 0 || it > 1) return LIODOM_ERR_INVALID_ARG;
+  if (!h->v.knn_q) { g_last_error = "create the handle with debug_buffers = 1"; return LIODOM_ERR_UNSUPPORTED; }
+  SideLocks lk(h, true, false);
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  int E = 0;
+  HIP_TRY(hipMemcpy(&E, &h->v.state[stream].n_edges_buf[h->last_eb], sizeof(int), hipMemcpyDeviceToHost));
+  if (n) *n = E;
+  if (E > cap) { g_last_error = "query buffer too small"; return LIODOM_ERR_CAPACITY; }
+  if (E && xyz0) HIP_TRY(hipMemcpy(xyz0, h->v.knn_q + ((size_t)stream * 2 + it) * h->v.edge_cap, sizeof(float4) * (size_t)E, hipMemcpyDeviceToHost));
   return LIODOM_OK;
 }
 

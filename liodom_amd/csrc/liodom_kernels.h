@@ -126,6 +126,7 @@ struct DevView {
   float4* corr_a;           // [S][edge_cap]  xyz of NN0, w = valid
   float4* corr_b;           // [S][edge_cap]  xyz of NN1
   int2* corr_idx;           // [S][2][edge_cap] window indices of (NN0, NN1), debug/parity
+  float4* knn_q;            // [S][2][edge_cap] world-frame float query of every edge and pass (debug_buffers only, else null)
   float4* win_pts;          // [S][P][edge_cap]
   int* win_n;               // [S][P]
   int* win_base;            // [S][P+1] logical prefix (oldest first)
@@ -1027,6 +1028,7 @@ __global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int oute
 #pragma unroll
     for (int i = 0; i < 12; i++) T[i] = st.odom[i];
     transform_point(T, p.x, p.y, p.z, &qx, &qy, &qz);          // :307-308
+    if (v.knn_q && hl == 0) v.knn_q[((size_t)s * 2 + outer_it) * v.edge_cap + e] = make_float4(qx, qy, qz, 0.f);
     active = ld_isfinite((double)qx) && ld_isfinite((double)qy) && ld_isfinite((double)qz) &&
              fabsf(qx) < 1.0e9f && fabsf(qy) < 1.0e9f && fabsf(qz) < 1.0e9f;
   }

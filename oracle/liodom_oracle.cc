@@ -1116,9 +1116,36 @@ struct Odometer {
   int cells_xy = 2, cells_z = 1;
   // debug capture of the last step
   std::vector<int32_t> corr_valid[2], corr_a[2], corr_b[2];
+  std::vector<P4> queries[2];                         // world-frame float queries of the last step (:307-308)
   StepInfo info{};
 
   explicit Odometer(const orc_params_t& p) : prm(p) { lmap.max_nframes = (size_t)p.local_map_size; }
+
+  // One edge of addEdgeConstraints' loop (:323-357): 5-NN, distance gate, line gate; the line points are NN0 / NN1.
+  bool match_edge(const std::vector<P4>& local_map, KdTree& tree, const P4& q, int* ia, int* ib) const {
+    Knn5 nn;
+    if (prm.knn_mode == 1) tree.search(q, nn); else knn5_brute(local_map, q, nn);      // :323
+    if (nn.n < 5) return false;                  // reference would read sq_dist[4] out of bounds (UB)
+    if (!(nn.d[4] < 1.0)) return false;                                                // :324
+    double center[3] = {0, 0, 0};
+    double nc[5][3];
+    for (int j = 0; j < 5; j++) {                                                      // :327-333
+      nc[j][0] = local_map[nn.idx[j]].x; nc[j][1] = local_map[nn.idx[j]].y; nc[j][2] = local_map[nn.idx[j]].z;
+      center[0] = center[0] + nc[j][0]; center[1] = center[1] + nc[j][1]; center[2] = center[2] + nc[j][2];
+    }
+    center[0] = center[0] / 5.0; center[1] = center[1] / 5.0; center[2] = center[2] / 5.0;  // :334
+    double cov[6] = {0, 0, 0, 0, 0, 0};                                                // :336
+    for (int j = 0; j < 5; j++) {                                                      // :337-340
+      double zx = nc[j][0] - center[0], zy = nc[j][1] - center[1], zz = nc[j][2] - center[2];
+      cov[0] = cov[0] + zx * zx; cov[1] = cov[1] + zx * zy; cov[2] = cov[2] + zx * zz;
+      cov[3] = cov[3] + zy * zy; cov[4] = cov[4] + zy * zz; cov[5] = cov[5] + zz * zz;
+    }
+    double ev[3];
+    eig3_sym(cov, ev);                                                                 // :342
+    if (!(ev[2] > 3 * ev[1])) return false;                                            // :344
+    *ia = nn.idx[0]; *ib = nn.idx[1];                                                  // :351-357
+    return true;
+  }
 
   // A9 addEdgeConstraints (:300-366)
   void add_edge_constraints(const std::vector<P4>& edges, const std::vector<P4>& local_map_gen,
@@ -1133,35 +1160,17 @@ struct Odometer {
     corr_a[it].assign(edges.size(), -1);
     corr_b[it].assign(edges.size(), -1);
     int correct = 0;
+    queries[it] = edges_map;
     for (size_t i = 0; i < edges_map.size(); i++) {                                    // :320
-      Knn5 nn;
-      if (prm.knn_mode == 1) tree.search(edges_map[i], nn); else knn5_brute(local_map, edges_map[i], nn);  // :323
-      if (nn.n < 5) continue;                    // reference would read sq_dist[4] out of bounds (UB)
-      if (nn.d[4] < 1.0) {                                                             // :324
-        double center[3] = {0, 0, 0};
-        double nc[5][3];
-        for (int j = 0; j < 5; j++) {                                                  // :327-333
-          nc[j][0] = local_map[nn.idx[j]].x; nc[j][1] = local_map[nn.idx[j]].y; nc[j][2] = local_map[nn.idx[j]].z;
-          center[0] = center[0] + nc[j][0]; center[1] = center[1] + nc[j][1]; center[2] = center[2] + nc[j][2];
-        }
-        center[0] = center[0] / 5.0; center[1] = center[1] / 5.0; center[2] = center[2] / 5.0;  // :334
-        double cov[6] = {0, 0, 0, 0, 0, 0};                                            // :336
-        for (int j = 0; j < 5; j++) {                                                  // :337-340
-          double zx = nc[j][0] - center[0], zy = nc[j][1] - center[1], zz = nc[j][2] - center[2];
-          cov[0] = cov[0] + zx * zx; cov[1] = cov[1] + zx * zy; cov[2] = cov[2] + zx * zz;
-          cov[3] = cov[3] + zy * zy; cov[4] = cov[4] + zy * zz; cov[5] = cov[5] + zz * zz;
-        }
-        double ev[3];
-        eig3_sym(cov, ev);                                                             // :342
-        if (ev[2] > 3 * ev[1]) {                                                       // :344
-          correct++;
-          Corr c;
-          c.p[0] = edges[i].x; c.p[1] = edges[i].y; c.p[2] = edges[i].z;               // :347-349
-          c.a[0] = local_map[nn.idx[0]].x; c.a[1] = local_map[nn.idx[0]].y; c.a[2] = local_map[nn.idx[0]].z;  // :351-353
-          c.b[0] = local_map[nn.idx[1]].x; c.b[1] = local_map[nn.idx[1]].y; c.b[2] = local_map[nn.idx[1]].z;  // :355-357
-          blocks.push_back(c);                                                         // :359-360
-          corr_valid[it][i] = 1; corr_a[it][i] = nn.idx[0]; corr_b[it][i] = nn.idx[1];
-        }
+      int ia = -1, ib = -1;
+      if (match_edge(local_map, tree, edges_map[i], &ia, &ib)) {
+        correct++;
+        Corr c;
+        c.p[0] = edges[i].x; c.p[1] = edges[i].y; c.p[2] = edges[i].z;               // :347-349
+        c.a[0] = local_map[ia].x; c.a[1] = local_map[ia].y; c.a[2] = local_map[ia].z;  // :351-353
+        c.b[0] = local_map[ib].x; c.b[1] = local_map[ib].y; c.b[2] = local_map[ib].z;  // :355-357
+        blocks.push_back(c);                                                         // :359-360
+        corr_valid[it][i] = 1; corr_a[it][i] = ia; corr_b[it][i] = ib;
       }
     }
     info.matches[it] = correct;
@@ -1314,6 +1323,30 @@ int orc_odom_last_corr(void* h, int it, int32_t* valid, int32_t* ia, int32_t* ib
   return n;
 }
 
+// World-frame float queries of the last step, outer iteration `it` (xyzi, n_edges rows).
+int orc_odom_last_queries(void* h, int it, float* xyzi, int cap) {
+  Odometer* o = static_cast<Odometer*>(h);
+  const int n = (int)o->queries[it].size();
+  if (n > cap) return -n;
+  if (n) std::memcpy(xyzi, o->queries[it].data(), sizeof(P4) * (size_t)n);
+  return n;
+}
+// addEdgeConstraints' per-edge loop (:320-361) on explicit inputs: a local-map cloud and world-frame float
+// queries.  valid / ia / ib per query.  mode 0 brute force, 1 kd-tree.
+void orc_match_edges(const orc_params_t* p, const float* map_xyzi, int64_t m, const float* q_xyzi, int64_t nq,
+                     int32_t* valid, int32_t* ia, int32_t* ib) {
+  Odometer od(*p);
+  std::vector<P4> map((size_t)m);
+  if (m) std::memcpy(map.data(), map_xyzi, sizeof(P4) * (size_t)m);
+  KdTree tree;
+  if (p->knn_mode == 1) tree.build(map);
+  const P4* q = reinterpret_cast<const P4*>(q_xyzi);
+  for (int64_t i = 0; i < nq; i++) {
+    int a = -1, b = -1;
+    const bool ok = od.match_edge(map, tree, q[i], &a, &b);
+    valid[i] = ok ? 1 : 0; ia[i] = ok ? a : -1; ib[i] = ok ? b : -1;
+  }
+}
 int64_t orc_odom_window_size(void* h) { return (int64_t)static_cast<Odometer*>(h)->lmap.total_points.size(); }
 int orc_odom_window_frames(void* h) { return (int)static_cast<Odometer*>(h)->lmap.nframes; }
 int64_t orc_odom_get_window(void* h, float* xyzi, int64_t cap) {

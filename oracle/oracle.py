@@ -100,6 +100,9 @@ def lib():
         L.orc_odom_step.argtypes = [C.c_void_p, fp, C.c_int, dp, C.POINTER(StepInfo)]
         L.orc_odom_last_corr.restype = C.c_int
         L.orc_odom_last_corr.argtypes = [C.c_void_p, C.c_int, ip, ip, ip, C.c_int]
+        L.orc_odom_last_queries.restype = C.c_int
+        L.orc_odom_last_queries.argtypes = [C.c_void_p, C.c_int, fp, C.c_int]
+        L.orc_match_edges.argtypes = [C.POINTER(OrcParams), fp, C.c_int64, fp, C.c_int64, ip, ip, ip]
         L.orc_odom_window_size.restype = C.c_int64
         L.orc_odom_window_size.argtypes = [C.c_void_p]
         L.orc_odom_window_frames.restype = C.c_int
@@ -231,6 +234,13 @@ class Odometer:
         m = max(m, 0)
         return v[:m], a[:m], b[:m]
 
+    def last_queries(self, it):
+        """World-frame float queries (edges x pose entering outer iteration `it`) of the last step."""
+        n = self.last_n
+        q = np.zeros((max(n, 1), 4), dtype=np.float32)
+        m = max(lib().orc_odom_last_queries(self.h, it, _fp(q), max(n, 1)), 0)
+        return q[:m, :3].copy()
+
     def window(self):
         n = lib().orc_odom_window_size(self.h)
         w = np.zeros((max(n, 1), 4), dtype=np.float32)
@@ -319,6 +329,18 @@ def publish_odom(prev34, cur34, dt, l2b34=None, rotation_mode=1):
     out = np.zeros(13)
     lib().orc_publish_odom(_dp(P), _dp(T), _dp(L), float(dt), _dp(out), int(rotation_mode))
     return out
+
+
+def match_edges(p, map_xyzi, queries_xyz):
+    """addEdgeConstraints' per-edge loop (laser_odometry.cc:320-361) on explicit inputs: (valid, ia, ib)."""
+    m = np.ascontiguousarray(map_xyzi, dtype=np.float32).reshape(-1, 4)
+    q3 = np.ascontiguousarray(queries_xyz, dtype=np.float32).reshape(-1, 3)
+    q = np.zeros((q3.shape[0], 4), dtype=np.float32)
+    q[:, :3] = q3
+    n = q.shape[0]
+    v, a, b = (np.zeros(max(n, 1), dtype=np.int32) for _ in range(3))
+    lib().orc_match_edges(C.byref(p), _fp(m), m.shape[0], _fp(q), n, _ip(v), _ip(a), _ip(b))
+    return v[:n], a[:n], b[:n]
 
 
 def set_threads(stencil_threads=1, eval_threads=1):

@@ -128,13 +128,24 @@ def test_max_ring_size(orc):
 
 
 def _run_stream(orc, synth, H, W, lt, R, epr, P, nscans, stream=0, use_pipeline=True):
+    """GPU vs oracle over a stream.  Two levels of correspondence parity:
+    (1) kernel level, identical inputs: the GPU's own float queries and the local map it searched go through the
+        oracle's addEdgeConstraints loop — valid flags and both line-point indices must be EXACTLY equal, every
+        scan, both passes;
+    (2) end to end: the oracle's own run.  The poses of the two implementations differ in the last bits (different
+        reduction orders), so a query or a window point may round to a neighbouring float; every edge whose
+        correspondence differs must be explained by such an input difference, and the second scan — whose
+        prediction is the identity in both — must agree exactly."""
     cfg = synth.make_cfg(H, W, lt)
-    po, g = mk(orc, H, W, lt, R, epr, P)
+    po, g = mk(orc, H, W, lt, R, epr, P, debug=1)
     od = orc.Odometer(po)
     worst_t, worst_r = 0.0, 0.0
+    n_e2e_diff = 0
     for k in range(nscans):
         x, _ = synth.scan(cfg, stream, k)
         o = orc.extract(po, x, H, W)
+        map_g, _ = g.local_map()                 # the cloud this scan's kNN passes search (window before the step)
+        map_o = od.window()
         pose_o, info_o = od.step(o["edges"])
         if use_pipeline:
             pose_g, info_g = g.process_scan(x, H, W)
@@ -146,17 +157,35 @@ def _run_stream(orc, synth, H, W, lt, R, epr, P, nscans, stream=0, use_pipeline=
         worst_t, worst_r = max(worst_t, dt), max(worst_r, dr)
         assert dt <= POSE_TOL_T and dr <= POSE_TOL_R, "scan %d: dt=%g dr=%g" % (k, dt, dr)
         assert info_g.n_edges == info_o.n_edges
+        assert info_g.status == 0
         if k > 0:
             assert info_g.map_points == info_o.map_points
+            win_differs = np.any(map_g.view(np.uint32) != map_o.view(np.uint32), axis=1) if map_g.shape == map_o.shape else None
             for it in (0, 1):
-                vo, ao, bo = od.last_corr(it)
                 vg, ag, bg = g.correspondences(it)
-                # identical correspondence sets unless a 1-ulp pose difference flipped a float cast
-                same = np.array_equal(vo, vg) and np.array_equal(ao[vo == 1], ag[vg == 1]) and np.array_equal(bo[vo == 1], bg[vg == 1])
-                if not same:
-                    diff = int((vo != vg).sum()) + int(((ao != ag) & (vo == 1) & (vg == 1)).sum())
-                    assert diff <= 3, "scan %d it %d: %d correspondences differ" % (k, it, diff)
-                assert abs(info_g.matches[it] - info_o.matches[it]) <= 3
+                # (1) identical inputs -> identical outputs
+                qg = g.knn_queries(it)
+                vk, ak, bk = orc.match_edges(po, map_g, qg)
+                assert np.array_equal(vk, vg) and np.array_equal(ak, ag) and np.array_equal(bk, bg), \
+                    "scan %d pass %d: kNN / line gate differ from the oracle on identical inputs at edges %s" % (
+                        k, it, np.nonzero((vk != vg) | (ak != ag) | (bk != bg))[0][:10])
+                assert info_g.matches[it] == int(vk.sum())
+                # (2) end to end
+                vo, ao, bo = od.last_corr(it)
+                qo = od.last_queries(it)
+                differ = (vo != vg) | (ao != ag) | (bo != bg)
+                if k == 1 and it == 0:
+                    assert not differ.any(), "scan 1, pass 0 (identity prediction in both): %d correspondences differ" % differ.sum()
+                for e in np.nonzero(differ)[0]:
+                    explained = bool(np.any(qg[e].view(np.uint32) != qo[e].view(np.uint32)))
+                    if not explained and win_differs is not None:
+                        for idx in (ao[e], bo[e], ag[e], bg[e]):
+                            explained = explained or (idx >= 0 and bool(win_differs[idx]))
+                        # a neighbour that only one side ranks among the five may be a point that differs, too
+                        explained = explained or bool(win_differs[np.linalg.norm(map_g[:, :3] - qg[e], axis=1) < 1.0].any())
+                    assert explained, "scan %d pass %d edge %d: correspondence differs although the query and all nearby window points are bit-equal" % (k, it, e)
+                n_e2e_diff += int(differ.sum())
+                assert int(differ.sum()) <= 6, "scan %d pass %d: %d correspondences differ" % (k, it, int(differ.sum()))
                 assert info_g.lm[it].iterations == info_o.lm[it].iterations
                 assert info_g.lm[it].termination == info_o.lm[it].termination
         # sliding window: same frames, same points (float rounding of the FP64 transform)

@@ -331,3 +331,26 @@ def test_rotation_mode_soak(orc, synth):
     # ... the polar mode keeps a unit quaternion and keeps tracking; the alias mode does neither
     assert res[1][1].max() < 1e-14 and res[1][0].max() < 1.0
     assert res[0][1][100:].max() > 1e-8 and res[0][0][-1] > 10.0
+
+
+def test_match_edges_equals_the_odometers_own_loop(orc, synth):
+    """orc.match_edges (addEdgeConstraints' per-edge loop on explicit inputs, used by the GPU tests to check the
+    kNN + line-gate kernel on identical inputs) against the correspondences the Odometer recorded itself."""
+    H, W = 16, 900
+    cfg = synth.make_cfg(H, W, 0)
+    po = orc.make_params(scan_lines=H, scan_regions=6, edges_per_region=10, prev_frames=5, knn_mode=1)
+    od = orc.Odometer(po)
+    for k in range(4):
+        x, _ = synth.scan(cfg, 0, k)
+        e = orc.extract(po, x, H, W)
+        win = od.window()
+        od.step(e["edges"])
+        if k == 0:
+            continue
+        for it in (0, 1):
+            v, a, b = od.last_corr(it)
+            q = od.last_queries(it)
+            v2, a2, b2 = orc.match_edges(po, win, q)
+            assert np.array_equal(v, v2) and np.array_equal(a, a2) and np.array_equal(b, b2)
+            assert v.sum() > 10
+    od.close()
