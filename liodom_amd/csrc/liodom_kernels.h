@@ -175,6 +175,21 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
 // debug-only phase stamps: kernel slot k, stamp index i (constant 100 MHz wall clock)
 #define DBG_STAMP(v, cond, k, i) do { if (((v).debug & 32) && (cond)) (v).dbg_clk[(k) * 32 + (i)] = wall_clock64(); } while (0)
 
+// XCD-aware workgroup placement for lock-step launches (grid = blocks x streams).  Workgroups are dispatched
+// round-robin over the 8 XCDs by linear id, and each XCD has its own 4 MB L2: with the natural mapping every
+// XCD sees the data of ALL streams (256 x 0.7 MB for k_knn: nothing stays resident, 5.5 x the algorithmic
+// traffic in round 1).  Remapped, the workgroups an XCD receives belong to one stream after the other
+// (stream = 8 * (slot / blocks) + xcd), so its L2 holds one or two streams' cell-sorted points and tables at a
+// time.  Identity unless the stream count is a multiple of 8.
+__device__ __forceinline__ void xcd_remap(int& bx, int& by) {
+  const int nbx = (int)gridDim.x, nby = (int)gridDim.y;
+  if (nby < 8 || (nby & 7)) return;
+  const int lin = bx + nbx * by;
+  const int xcd = lin & 7, slot = lin >> 3;
+  by = (slot / nbx) * 8 + xcd;
+  bx = slot - (slot / nbx) * nbx;
+}
+
 __device__ __forceinline__ unsigned long long pack_cell(int cx, int cy, int cz) {
   const unsigned long long m = 0x1FFFFFull;  // 21 bits per axis; aliasing only adds far candidates
   return ((unsigned long long)(cx & m) << 42) | ((unsigned long long)(cy & m) << 21) |
@@ -1005,19 +1020,21 @@ __global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int oute
   __shared__ int s_res[kKnnQueries][4];            // distance gate passed, window index of NN0, NN1
   __shared__ double s_part[kKnnQueries][32];       // normal-equation terms of every query's residual block at the solve's start pose
   __shared__ double s_blk[kKnnQueries][24];        // that block's J[18], rho' r [3], rho, rho', validity (0 none, 1 valid, 2 non-finite)
-  const int s = s0 + blockIdx.y;
+  int bxi = (int)blockIdx.x, byi = (int)blockIdx.y;
+  xcd_remap(bxi, byi);
+  const int s = s0 + byi;
   StreamState& st = v.state[s];
   if (!st.initialized) return;                     // uniform over the workgroup
   const int E = st.n_edges_buf[eb];
-  if ((int)(blockIdx.x * kKnnQueries) >= E) {      // no query here: an empty validity byte for the solve's compaction
-    if (threadIdx.x == 0) v.corr_mask[((size_t)s * 2 + outer_it) * v.knn_blocks + blockIdx.x] = 0;
+  if ((int)(bxi * kKnnQueries) >= E) {      // no query here: an empty validity byte for the solve's compaction
+    if (threadIdx.x == 0) v.corr_mask[((size_t)s * 2 + outer_it) * v.knn_blocks + bxi] = 0;
     return;
   }
   const int grp = threadIdx.x / kKnnGroup;
-  const int e = blockIdx.x * kKnnQueries + grp;
+  const int e = bxi * kKnnQueries + grp;
   const int hl = threadIdx.x & (kKnnGroup - 1);
   const int half_shift = (threadIdx.x & 32);     // 0 or 32: which half of the wave
-  const bool dbgb = (blockIdx.x == 5) && (s == 0) && (threadIdx.x == 0) && (outer_it == 0);
+  const bool dbgb = (bxi == 5) && (s == 0) && (threadIdx.x == 0) && (outer_it == 0);
   const unsigned long long t_blk = (v.debug & 32) ? wall_clock64() : 0ull;
   DBG_STAMP(v, dbgb, 1, 0);
   bool active = e < E;
@@ -1170,7 +1187,7 @@ __global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int oute
   // queries instead of once per query.
   if (threadIdx.x < kKnnQueries) {
     const int q = threadIdx.x;
-    const int eq = blockIdx.x * kKnnQueries + q;
+    const int eq = bxi * kKnnQueries + q;
     bool valid = (eq < E) && (s_res[q][0] != 0);
     float nx[5], ny[5], nz[5];
 #pragma unroll
@@ -1192,7 +1209,7 @@ __global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int oute
     const int nvalid = __popcll(vb);
     if (q == 0) {
       if (nvalid) atomicAdd(&st.info.matches[outer_it], nvalid);   // :346
-      v.corr_mask[((size_t)s * 2 + outer_it) * v.knn_blocks + blockIdx.x] = (unsigned char)vb;   // bit q = query q accepted
+      v.corr_mask[((size_t)s * 2 + outer_it) * v.knn_blocks + bxi] = (unsigned char)vb;   // bit q = query q accepted
     }
     // The solve that follows starts at (param_q, param_t) — Ceres evaluates the residuals with the quaternion,
     // not with the matrix the neighbours were searched with (:186-195,205-206) — which is already known here.
@@ -1236,7 +1253,7 @@ __global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int oute
     double x = 0.0;
 #pragma unroll
     for (int q = 0; q < kKnnQueries; q++) x += s_part[q][threadIdx.x];      // fixed order: deterministic
-    v.knn_part[(((size_t)s * 2 + outer_it) * v.knn_blocks + blockIdx.x) * 32 + threadIdx.x] = x;
+    v.knn_part[(((size_t)s * 2 + outer_it) * v.knn_blocks + bxi) * 32 + threadIdx.x] = x;
   }
   DBG_STAMP(v, dbgb, 1, 7);
   if ((v.debug & 32) && s == 0 && threadIdx.x == 0) {      // histogram of workgroup durations, 1 us bins

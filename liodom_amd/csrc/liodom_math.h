@@ -315,6 +315,7 @@ LD_HD void odom_message(const double* prev_odom, const double* odom, const doubl
 }
 // ceres::EigenQuaternionParameterization::Plus, x = [x y z w]
 LD_HD void quat_plus(const double* x, const double* delta, double* out) {
+  LD_FP_CONTRACT_FAST
   const double nd = sqrt(delta[0] * delta[0] + delta[1] * delta[1] + delta[2] * delta[2]);
   if (nd > 0.0) {
     // sin(nd)/nd and cos(nd).  LM steps are small rotations: below 0.5 rad the Taylor series in
@@ -562,7 +563,8 @@ struct LmState {
 
 
 // Cholesky solve of the 6x6 SPD system A y = b.  Returns false if not positive definite.
-LD_HD bool chol_solve6(const double* A /*6x6 row-major, symmetric*/, const double* b, double* y) {
+LD_HD bool chol_solve6(const double* A /*6x6 row-major, symmetric (lower triangle read)*/, const double* b, double* y) {
+  LD_FP_CONTRACT_FAST
   double Lm[36];
   double inv[6];             // reciprocals of the diagonal: one division per column
   LD_UNROLL
@@ -606,22 +608,27 @@ LD_HD bool chol_solve6(const double* A /*6x6 row-major, symmetric*/, const doubl
 }
 
 LD_HD double norm7(const double* q, const double* t) {
+  LD_FP_CONTRACT_FAST
   return sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3] + t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
 }
 
 // Computes the next valid trust-region step and the candidate point.  Invalid steps shrink the
 // radius and consume an iteration each (TrustRegionMinimizer::HandleInvalidStep).
 LD_HD int lm_propose(LmState& st) {
+  // The controller is not on the bit-exact path (pose tolerance 1e-4, and the oracle solves the step by QR anyway):
+  // FMA contraction is allowed here, and only the lower triangle of the symmetric matrices is formed.  It runs on a
+  // single lane 3-4 times per solve, so its instruction count is on the scan's critical path.
+  LD_FP_CONTRACT_FAST
   while (true) {
     if (st.iter >= kLmMaxIterations) { st.termination = LM_TERM_MAX_ITER; return LM_DONE; }
     if (st.radius < 1e-32) { st.termination = LM_TERM_RADIUS; return LM_DONE; }
     st.iter++;
-    double Hs[36], gs[6];
+    double Hs[36], gs[6];            // Hs: lower triangle (j <= i) only
     LD_UNROLL
     for (int i = 0; i < 6; i++) {
       gs[i] = st.scale[i] * st.g[i];
       LD_UNROLL
-      for (int j = 0; j < 6; j++) Hs[i * 6 + j] = st.scale[i] * st.scale[j] * h_at(st.H, i, j);
+      for (int j = 0; j <= i; j++) Hs[i * 6 + j] = st.scale[i] * st.scale[j] * st.H[h_idx(j, i)];
     }
     if (!st.reuse_diagonal) {
       LD_UNROLL
@@ -634,7 +641,10 @@ LD_HD int lm_propose(LmState& st) {
     }
     double A[36];
     LD_UNROLL
-    for (int i = 0; i < 36; i++) A[i] = Hs[i];
+    for (int i = 0; i < 6; i++) {
+      LD_UNROLL
+      for (int j = 0; j <= i; j++) A[i * 6 + j] = Hs[i * 6 + j];
+    }
     const double inv_radius = 1.0 / st.radius;
     LD_UNROLL
     for (int j = 0; j < 6; j++) A[j * 6 + j] += st.diag[j] * inv_radius;
@@ -650,10 +660,11 @@ LD_HD int lm_propose(LmState& st) {
       LD_UNROLL
       for (int i = 0; i < 6; i++) {
         sg += step[i] * gs[i];
+        // step^T Hs step from the lower triangle: diagonal once, off-diagonal entries twice
         double row = 0.0;
         LD_UNROLL
-        for (int j = 0; j < 6; j++) row += Hs[i * 6 + j] * step[j];
-        shs += step[i] * row;
+        for (int j = 0; j < i; j++) row += Hs[i * 6 + j] * step[j];
+        shs += step[i] * (2.0 * row + Hs[i * 6 + i] * step[i]);
       }
       mcc = -sg - 0.5 * shs;
     }
@@ -709,6 +720,7 @@ LD_HD int lm_begin(LmState& st, const double* q0, const double* t0, const double
 
 // acc = accumulator evaluated at the candidate (cost + normal equations).
 LD_HD int lm_update(LmState& st, const double* acc) {
+  LD_FP_CONTRACT_FAST
   const double cand_cost = (acc[28] != 0.0) ? DBL_MAX : acc[0];
   double dq[4], dt[3];
   LD_UNROLL
