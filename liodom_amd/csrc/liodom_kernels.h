@@ -1211,13 +1211,18 @@ __global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int oute
       if (nvalid) atomicAdd(&st.info.matches[outer_it], nvalid);   // :346
       v.corr_mask[((size_t)s * 2 + outer_it) * v.knn_blocks + bxi] = (unsigned char)vb;   // bit q = query q accepted
     }
+    s_res[q][3] = valid ? 1 : 0;
+  } else if (kKnnThreads > 64 && v.knn_partials && threadIdx.x >= 64 && threadIdx.x < 64 + kKnnQueries) {
     // The solve that follows starts at (param_q, param_t) — Ceres evaluates the residuals with the quaternion,
     // not with the matrix the neighbours were searched with (:186-195,205-206) — which is already known here.
-    // So the residual block of every accepted correspondence is evaluated right away (one lane per query, the
-    // block's inputs are in registers) and summed per workgroup: k_lm_solve's first evaluation becomes a
-    // reduction of these partial sums instead of a pass over all correspondences.
+    // So the residual block of every query that found five neighbours is evaluated right away and the accepted
+    // ones are summed per workgroup: k_lm_solve's first evaluation becomes a reduction of these partial sums
+    // instead of a pass over all correspondences.  One lane per query on the SECOND wave, beside the line gates
+    // of the first (the block does not depend on the gate's verdict; it is simply dropped if the gate says no).
+    const int q = threadIdx.x - 64;
+    const int eq = bxi * kKnnQueries + q;
     double flag = 0.0;
-    if (valid && v.knn_partials) {
+    if (eq < E && s_res[q][0] != 0) {
       double Rm[12], pq[4], pt[3];
 #pragma unroll
       for (int i = 0; i < 4; i++) pq[i] = st.param_q[i];
@@ -1226,8 +1231,8 @@ __global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int oute
       iso_from_qt(pq, pt, Rm);
       const float4 pe = v.edges[((size_t)eb * v.n_streams + s) * v.edge_cap + eq];
       const double p[3] = {(double)pe.x, (double)pe.y, (double)pe.z};       // :347-349 sensor frame
-      const double a[3] = {(double)nx[0], (double)ny[0], (double)nz[0]};
-      const double b[3] = {(double)nx[1], (double)ny[1], (double)nz[1]};
+      const double a[3] = {(double)s_nn[q][0], (double)s_nn[q][1], (double)s_nn[q][2]};
+      const double b[3] = {(double)s_nn[q][3], (double)s_nn[q][4], (double)s_nn[q][5]};
       double J[18], rs[3], rho0, rho1;
       const bool ok = residual_block(Rm, p, a, b, v.min_range, v.max_range, J, rs, &rho0, &rho1);
 #pragma unroll
@@ -1242,7 +1247,7 @@ __global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int oute
   // entry hl of the block's contribution by lane hl of the query's own 32-lane group (J is read from LDS, so
   // the 29-entry accumulator never occupies registers in this kernel)
   if (hl < kAccN) {
-    const double flag = s_blk[grp][23];
+    const double flag = s_res[grp][3] ? s_blk[grp][23] : 0.0;     // (gate's verdict, block's finiteness)
     double x = 0.0;
     if (flag == 1.0) x = residual_entry(s_blk[grp], s_blk[grp] + 18, s_blk[grp][21], s_blk[grp][22], hl);
     else if (flag == 2.0 && hl == 28) x = 1.0;            // non-finite block: counted, contributes nothing else
