@@ -82,6 +82,15 @@ struct liodom_handle {
   std::vector<liodom_map*> mappers;   // per stream: attached device map (mapping replay) or null
   std::vector<int> mapper_cells_xy, mapper_cells_z;
   bool lds_hash_build = false;  // k_hash_build (one workgroup per stream, LDS) instead of the 3 global-atomic kernels
+  // The odometry chain of one scan (2 x [k_knn, k_lm_solve] + the window / hash rebuild: 7 launches) captured once
+  // per (edge buffer, first stream, stream count) into a hipGraph and replayed with one hipGraphLaunch.
+  // Off by default (LIODOM_GRAPH=1 turns it on): measured on MI355X / ROCm 7.2 the graph launch is slower than the
+  // seven eager launches on the headline path (7 735 vs 8 042 scans/s per-scan synchronous, 7 674 vs 7 881
+  // asynchronous; only the strictly serial replay gains, 6 376 vs 6 308) — the chain is bound by its kernels'
+  // durations, the host enqueue (4.5 us per launch) is hidden behind them, and hipGraphLaunch adds start latency.
+  struct OdoGraph { int eb, s0, count; hipGraphExec_t exec; };
+  std::vector<OdoGraph> odo_graphs;
+  bool use_graph = false;
   std::vector<EventPair> ev_pool;
   size_t ev_used = 0;
   double k_ms[LIODOM_NUM_KERNELS] = {0};
@@ -156,8 +165,18 @@ int launch_extract(liodom_handle* h, hipStream_t q, int eb, int s0, int count, c
   {
     ProfScope ps(h, KID_RING_EXTRACT, q);
     const int ext = ring_extract_threads(v.scan_regions);
-    if (ext <= 256) hipLaunchKernelGGL(k_ring_extract<256>, dim3(h->H, count), dim3(ext), h->ring_lds_bytes, q, v, s0);
-    else hipLaunchKernelGGL(k_ring_extract<1024>, dim3(h->H, count), dim3(ext), h->ring_lds_bytes, q, v, s0);
+    // instance by the longest region the expected ring width gives (the last region takes the split's remainder)
+    const int w = h->config.max_width > 0 ? h->config.max_width : std::max(1, h->config.max_points / std::max(1, h->H));
+    const int total = std::max(0, w - 10), sector = total / std::max(1, v.scan_regions);
+    const bool big = total - sector * (v.scan_regions - 1) > kExLPR * kExIPL;
+    const dim3 grid(h->H, count), block(ext);
+    if (ext <= 256) {
+      if (big) hipLaunchKernelGGL((k_ring_extract<256, kExIPLBig>), grid, block, h->ring_lds_bytes, q, v, s0);
+      else hipLaunchKernelGGL((k_ring_extract<256, kExIPL>), grid, block, h->ring_lds_bytes, q, v, s0);
+    } else {
+      if (big) hipLaunchKernelGGL((k_ring_extract<1024, kExIPLBig>), grid, block, h->ring_lds_bytes, q, v, s0);
+      else hipLaunchKernelGGL((k_ring_extract<1024, kExIPL>), grid, block, h->ring_lds_bytes, q, v, s0);
+    }
   }
   {
     ProfScope ps(h, KID_COMPACT, q);
@@ -170,7 +189,43 @@ int launch_extract(liodom_handle* h, hipStream_t q, int eb, int s0, int count, c
 // Odometry on the dense edges already on the device.  If pose_dst != nullptr the poses + infos
 // of the streams are copied to pinned memory right after the solve and pose_event is recorded,
 // so the host can pick them up while the window / hash rebuild still runs.
+int enqueue_odometry(liodom_handle* h, int eb, int s0, int count);
+
+void drop_graphs(liodom_handle* h) {
+  for (auto& g : h->odo_graphs) (void)hipGraphExecDestroy(g.exec);
+  h->odo_graphs.clear();
+}
+
 int launch_odometry(liodom_handle* h, int eb, int s0, int count) {
+  int rc = LIODOM_OK;
+  // eager launches while profiling (an event pair around every kernel) and in mapping mode (the attached map's
+  // update enqueues host-dependent work); otherwise one graph launch
+  if (h->use_graph && !h->profiling && !h->v.mapping) {
+    hipGraphExec_t exec = nullptr;
+    for (auto& g : h->odo_graphs) if (g.eb == eb && g.s0 == s0 && g.count == count) { exec = g.exec; break; }
+    if (!exec) {
+      hipGraph_t graph = nullptr;
+      HIP_TRY(hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed));
+      rc = enqueue_odometry(h, eb, s0, count);
+      const hipError_t ce = hipStreamEndCapture(h->stream, &graph);
+      if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+      if (ce != hipSuccess || !graph) { g_last_error = std::string("hipStreamEndCapture failed: ") + hipGetErrorString(ce); return LIODOM_ERR_HIP; }
+      const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(graph);
+      if (ie != hipSuccess) { g_last_error = std::string("hipGraphInstantiate failed: ") + hipGetErrorString(ie); return LIODOM_ERR_HIP; }
+      h->odo_graphs.push_back({eb, s0, count, exec});
+    }
+    HIP_TRY(hipGraphLaunch(exec, h->stream));
+  } else {
+    rc = enqueue_odometry(h, eb, s0, count);
+    if (rc) return rc;
+  }
+  h->last_eb = eb;       // results are published by k_lm_solve into host-mapped memory (HostOut)
+  for (int i = 0; i < count; i++) h->scans_enqueued[s0 + i]++;
+  return LIODOM_OK;
+}
+
+int enqueue_odometry(liodom_handle* h, int eb, int s0, int count) {
   const DevView& v = h->v;
   const bool knn_small = h->S >= 16;            // many streams: 4 queries per workgroup, else 8
   const int knn_blocks = cdiv(h->v.edge_cap, knn_small ? 4 : 8);
@@ -189,8 +244,6 @@ int launch_odometry(liodom_handle* h, int eb, int s0, int count) {
       hipLaunchKernelGGL(k_lm_solve, dim3(h->v.lm_groups, count), dim3(kLmThreads), lm_lds_bytes(h->v.edge_cap), h->stream, v, s0, it, eb);
     }
   }
-  h->last_eb = eb;       // results are published by k_lm_solve into host-mapped memory (HostOut)
-  for (int i = 0; i < count; i++) h->scans_enqueued[s0 + i]++;
   const int map_blocks = cdiv(h->v.map_cap, 256);
   if (v.mapping) {
     // synchronous replay of the mapping node for the streams with an attached map: updateMap(edges_k,
@@ -423,6 +476,7 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   // global-atomic kernels (many workgroups) but needs 86 us as a single LDS workgroup; 64 lock-step
   // streams need 247 us (L2-atomic bound) against 103 us with one LDS workgroup each.
   h->lds_hash_build = config->n_streams >= 16;
+  if (const char* e = std::getenv("LIODOM_GRAPH")) h->use_graph = std::atoi(e) != 0;
   if (const char* e = std::getenv("LIODOM_HASH_BUILD")) h->lds_hash_build = std::strcmp(e, "global") != 0;
   v.lds_cells_max = kLdsCellsMax;
   if (const char* e = std::getenv("LIODOM_LDS_CELLS_MAX")) v.lds_cells_max = std::max(1, std::min(kLdsCellsMax, std::atoi(e)));
@@ -531,10 +585,10 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
     g_last_error = "hipFuncSetAttribute(max dynamic LDS) failed"; return fail(LIODOM_ERR_HIP);
   }
   if (h->ring_lds_bytes > 48 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ring_extract<256>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)h->ring_lds_bytes) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ring_extract<1024>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)h->ring_lds_bytes) != hipSuccess) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ring_extract<256, kExIPL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->ring_lds_bytes) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ring_extract<256, kExIPLBig>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->ring_lds_bytes) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ring_extract<1024, kExIPL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->ring_lds_bytes) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ring_extract<1024, kExIPLBig>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->ring_lds_bytes) != hipSuccess) {
       g_last_error = "hipFuncSetAttribute(max dynamic LDS) failed"; return fail(LIODOM_ERR_HIP);
     }
   }
@@ -551,6 +605,7 @@ void liodom_destroy(liodom_handle_t* h) {
   if (!h) return;
   if (h->stream_x) hipStreamSynchronize(h->stream_x);
   if (h->stream) hipStreamSynchronize(h->stream);
+  drop_graphs(h);
   for (liodom_map* mp : h->mappers) {          // attached maps outlive the handle: give them a stream of their own again
     if (!mp) continue;
     mp->stream = nullptr; mp->own_stream = false;
@@ -731,6 +786,7 @@ int liodom_set_laser_to_base(liodom_handle_t* h, const double* T) {
   if (!h || !T) return LIODOM_ERR_INVALID_ARG;
   SideLocks lk(h, true, true);
   for (int k = 0; k < 12; k++) h->v.laser_to_base[k] = T[k];      // kernels take the view by value
+  drop_graphs(h);                                                   // (captured launches carry the old view)
   return LIODOM_OK;
 }
 

@@ -405,7 +405,9 @@ __global__ __launch_bounds__(kTileThreads) void k_ring_scatter(DevView v, int s0
 // scratch, regions walked in order by one wave — any ring length, no capacity flag.
 // =============================================================================================
 constexpr int kExLPR = 16;               // lanes per region (one DPP row)
-constexpr int kExIPL = 16;               // items per lane -> regions of up to 256 items
+constexpr int kExIPL = 16;               // items per lane -> regions of up to 256 items ...
+constexpr int kExIPLBig = 24;            // ... or 384 (the last region takes the remainder of the split: Ouster 2048 / 8 -> 260); the host
+                                         // picks the instance from the expected ring width, longer regions take the generic path
 constexpr int kGapBitsCap = 16384;       // points per ring covered by the LDS continuity bits (2 KB)
 constexpr int kExMaxRegions = 64;
 
@@ -495,12 +497,13 @@ __device__ __forceinline__ double curvature_f3(const f3v* q) {
   const double dz = stencil_sum(q[0].z, q[1].z, q[2].z, q[3].z, q[4].z, q[5].z, q[6].z, q[7].z, q[8].z, q[9].z, q[10].z);
   return dx * dx + dy * dy + dz * dz;
 }
-__device__ __forceinline__ unsigned int region_keys_load(unsigned int (&kf)[kExIPL], const float4* __restrict__ rp, int nr, int k0,
+template <int IPL>
+__device__ __forceinline__ unsigned int region_keys_load(unsigned int (&kf)[IPL], const float4* __restrict__ rp, int nr, int k0,
                                                          int n_own, double* curv_out) {
   unsigned int gbits = 0;
   (void)nr;
 #pragma unroll
-  for (int c0 = 0; c0 < kExIPL; c0 += 8) {
+  for (int c0 = 0; c0 < IPL; c0 += 8) {
     f3v q[18];                                              // x y z only: 12-byte loads, 54 registers per batch
 #pragma unroll
     for (int i = 0; i < 18; i++) {
@@ -517,7 +520,7 @@ __device__ __forceinline__ unsigned int region_keys_load(unsigned int (&kf)[kExI
       const bool ok = !(gap_sq3(q[t + 5].x, q[t + 5].y, q[t + 5].z, q[t + 4].x, q[t + 4].y, q[t + 4].z) > 0.05);
       gbits |= (own && ok) ? (1u << (c0 + t)) : 0u;
     }
-    if (c0 + 8 < kExIPL) { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }   // second batch of loads after the first batch's arithmetic
+    if (c0 + 8 < IPL) { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }   // second batch of loads after the first batch's arithmetic
   }
   return gbits;
 }
@@ -525,14 +528,15 @@ __device__ __forceinline__ unsigned int region_keys_load(unsigned int (&kf)[kExI
 // Greedy selection of one region per 16-lane row; rows whose `active` is false idle.  Keys are consumed
 // (picked / suppressed items zeroed).  premask: bit o set = item rs + o (o < 5) was suppressed by the previous
 // region's picks.  Returns the number of picks (uniform over the row).
-__device__ __forceinline__ int select_region_row(unsigned int (&kf)[kExIPL], const float4* __restrict__ rp, const unsigned int* gb,
+template <int IPL>
+__device__ __forceinline__ int select_region_row(unsigned int (&kf)[IPL], const float4* __restrict__ rp, const unsigned int* gb,
                                                  bool active, int rs, int k0, int epr, int lane, int premask, int* out_idx,
                                                  unsigned char* out_nfnb) {
   const int j0 = k0 + 5;
   const int rl = lane & (kExLPR - 1);
   if (premask) {
 #pragma unroll
-    for (int i = 0; i < kExIPL; i++) {
+    for (int i = 0; i < IPL; i++) {
       const int o = k0 + i - rs;
       if (o < 5 && ((premask >> o) & 1)) kf[i] = 0;
     }
@@ -541,12 +545,12 @@ __device__ __forceinline__ int select_region_row(unsigned int (&kf)[kExIPL], con
   while (__ballot(active) != 0ull) {
     unsigned int bf = 0;
 #pragma unroll
-    for (int i = 0; i < kExIPL; i++) bf = kf[i] > bf ? kf[i] : bf;
+    for (int i = 0; i < IPL; i++) bf = kf[i] > bf ? kf[i] : bf;
     const unsigned int m32 = row_max_u32(active ? bf : 0u);
     active = active && m32 != 0u && picks <= epr;                  // nothing left above 0.1, or epr + 1 picks made (:270)
     unsigned int eqm = 0;                                          // bit i: item i carries the maximal float image
 #pragma unroll
-    for (int i = 0; i < kExIPL; i++) eqm |= (kf[i] == m32) ? (1u << i) : 0u;
+    for (int i = 0; i < IPL; i++) eqm |= (kf[i] == m32) ? (1u << i) : 0u;
     const bool has = active && eqm != 0u;
     const int first = __ffs(eqm) - 1;
     int j = row_min_i32(has ? j0 + first : 0x7fffffff);            // lowest ring index among the maximal float images
@@ -574,7 +578,7 @@ __device__ __forceinline__ int select_region_row(unsigned int (&kf)[kExIPL], con
     const unsigned int span = (unsigned int)(nf + nb);
     const int lo = j - nb - j0;
 #pragma unroll
-    for (int i = 0; i < kExIPL; i++) {
+    for (int i = 0; i < IPL; i++) {
       if (active && (unsigned int)(i - lo) <= span) kf[i] = 0;     // the pick and its marked neighbours (:277,293,309)
     }
     picks += active ? 1 : 0;
@@ -614,63 +618,25 @@ __device__ int select_region_generic(const double* c, const float4* rp, volatile
   return picks;
 }
 
-template <int kMaxThreads>
-__global__ __launch_bounds__(kMaxThreads) void k_ring_extract(DevView v, int s0) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int ring = blockIdx.x;
-  const int s = s0 + blockIdx.y;
+// The register path of k_ring_extract for one ring (keys, continuity bits, speculative selection, carry fixed
+// point); IPL items per lane.
+template <int IPL>
+__device__ __forceinline__ void ring_select_rows(const DevView& v, const float4* __restrict__ rpts, double* rc, bool dump, int nr,
+                                                 int total, int sector, int R, int epr, int ppr, unsigned int* gb, int* pick_idx,
+                                                 unsigned char* pick_nfnb, int* region_cnt, int* used_mask, int* new_mask, int* flags,
+                                                 bool dbgb, int& dbg_rounds) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
-  const int R = v.scan_regions, epr = v.edges_per_region, slots = v.slots_per_ring;
-  unsigned int* gb = reinterpret_cast<unsigned int*>(smem);                          // [kGapBitsCap / 32 + 4]
-  int* pick_idx = reinterpret_cast<int*>(gb + kGapBitsCap / 32 + 4);                 // [R][epr+1]
-  unsigned char* pick_nfnb = reinterpret_cast<unsigned char*>(pick_idx + slots);
-  int* region_cnt = reinterpret_cast<int*>(pick_nfnb + (slots + 15) / 16 * 16);     // [R]
-  int* used_mask = region_cnt + R;          // [kExMaxRegions] pre-marks of the run that produced the current picks
-  int* new_mask = used_mask + kExMaxRegions;   // [kExMaxRegions] spill of the predecessor's current picks
-  int* flags = new_mask + kExMaxRegions;    // [4]
-
-  const int H = v.scan_lines;
-  int* nedges_out = v.ring_nedges + (size_t)s * H + ring;
-  int* npoints_out = v.ring_npoints + (size_t)s * H + ring;
-  const unsigned long long t_begin = (v.debug & 32) ? wall_clock64() : 0ull;
-  const bool dbgb = (ring == (((v.debug >> 8) & 0xFF) ? ((v.debug >> 8) & 0xFF) : 40) % H) && (s == 0) && (tid == 0);
-  DBG_STAMP(v, dbgb, 0, 0);
-  int dbg_rounds = 0;
-  // ---- the ring's points are contiguous in the ring-sorted copy written by k_ring_scatter ----
-  const int rbeg = v.ring_start[(size_t)s * (H + 1) + ring];
-  const int nr = v.ring_start[(size_t)s * (H + 1) + ring + 1] - rbeg;
-  const float4* rpts = v.ring_pts + (size_t)s * v.max_points + rbeg;
-  const int* rsrc = v.ring_src + (size_t)s * v.max_points + rbeg;
-  double* rc = v.ring_c + (size_t)s * v.max_points + rbeg;                // debug dump / generic-path scratch
-  const bool dump = (v.debug & 1) != 0;
-  if (tid == 0) *npoints_out = nr;
-  // rings below min_points_per_scan are skipped (feature_extractor.cc:188)
-  if ((long long)nr < v.min_points_per_scan || nr < 11) {
-    if (tid == 0) *nedges_out = 0;
-    if (dump) for (int j = tid; j < nr; j += nthreads) rc[j] = __longlong_as_double(0x7ff8000000000000ll);
-    return;
-  }
-  const int total = nr - 10;                            // :238
-  const int sector = total / R;                         // :239
-  const int last_len = total - sector * (R - 1);
-  const int max_len = sector > last_len ? sector : last_len;
-  const int ppr = epr + 1;                              // picks per region (:270)
-  const bool fast = max_len <= kExLPR * kExIPL && sector >= 5 && R <= kExMaxRegions && R <= 4 * (nthreads >> 6) && nr <= kGapBitsCap;
-  if (dump) {
-    for (int j = tid; j < 5; j += nthreads) { rc[j] = __longlong_as_double(0x7ff8000000000000ll); rc[nr - 1 - j] = rc[j]; }
-  }
-  if (fast) {
     const int row = lane >> 4, rl = lane & 15;
     const int reg = wave * 4 + row;                     // this row's region
     const bool rvalid = reg < R;
     const int rs = sector * (rvalid ? reg : 0);
     const int re = !rvalid ? rs : ((reg == R - 1) ? total : sector * (reg + 1));   // :242-247
-    const int k0 = rs + rl * kExIPL;                    // region-array index of this lane's first item (ring index + 5)
+    const int k0 = rs + rl * IPL;                    // region-array index of this lane's first item (ring index + 5)
     const int n_own = re - k0;                          // owned items inside the region (<= 0: none)
     for (int w = tid; w < ((nr + 31) >> 5) + 3; w += nthreads) gb[w] = 0u;
     if (tid < R) { used_mask[tid] = 0; new_mask[tid] = 0; }
-    unsigned int kf[kExIPL];
-    unsigned int gbits = region_keys_load(kf, rpts, nr, k0, n_own, dump ? rc : nullptr);
+    unsigned int kf[IPL];
+    unsigned int gbits = region_keys_load<IPL>(kf, rpts, nr, k0, n_own, dump ? rc : nullptr);
     // the ring's first / last points are owned by no item: their continuity bits (k = 1..4, nr-5..nr-1) separately
     unsigned int edge_bit = 0;
     int edge_k = 0;
@@ -691,7 +657,7 @@ __global__ __launch_bounds__(kMaxThreads) void k_ring_extract(DevView v, int s0)
     DBG_STAMP(v, dbgb, 0, 2);
     // ---- speculative selection, all regions side by side ----
     {
-      const int cntp = select_region_row(kf, rpts, gb, rvalid && re > rs, rs, k0, epr, lane, 0, pick_idx + (rvalid ? reg : 0) * ppr,
+      const int cntp = select_region_row<IPL>(kf, rpts, gb, rvalid && re > rs, rs, k0, epr, lane, 0, pick_idx + (rvalid ? reg : 0) * ppr,
                                          pick_nfnb + (rvalid ? reg : 0) * ppr);
       if (rvalid && rl == 0) region_cnt[reg] = cntp;
     }
@@ -733,8 +699,8 @@ __global__ __launch_bounds__(kMaxThreads) void k_ring_extract(DevView v, int s0)
         }
       }
       if (__ballot(need) != 0ull) {                      // (wave-uniform) some row of this wave re-runs its region
-        if (need) (void)region_keys_load(kf, rpts, nr, k0, n_own, nullptr);
-        const int cntp = select_region_row(kf, rpts, gb, need, rs, k0, epr, lane, m, pick_idx + (rvalid ? reg : 0) * ppr,
+        if (need) (void)region_keys_load<IPL>(kf, rpts, nr, k0, n_own, nullptr);
+        const int cntp = select_region_row<IPL>(kf, rpts, gb, need, rs, k0, epr, lane, m, pick_idx + (rvalid ? reg : 0) * ppr,
                                            pick_nfnb + (rvalid ? reg : 0) * ppr);
         if (need && rl == 0) { region_cnt[reg] = cntp; used_mask[reg] = m; flags[0] = 1; }
       }
@@ -744,6 +710,55 @@ __global__ __launch_bounds__(kMaxThreads) void k_ring_extract(DevView v, int s0)
       __syncthreads();
     }
     DBG_STAMP(v, dbgb, 0, 6);
+}
+
+template <int kMaxThreads, int IPL>
+__global__ __launch_bounds__(kMaxThreads) void k_ring_extract(DevView v, int s0) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int ring = blockIdx.x;
+  const int s = s0 + blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
+  const int R = v.scan_regions, epr = v.edges_per_region, slots = v.slots_per_ring;
+  unsigned int* gb = reinterpret_cast<unsigned int*>(smem);                          // [kGapBitsCap / 32 + 4]
+  int* pick_idx = reinterpret_cast<int*>(gb + kGapBitsCap / 32 + 4);                 // [R][epr+1]
+  unsigned char* pick_nfnb = reinterpret_cast<unsigned char*>(pick_idx + slots);
+  int* region_cnt = reinterpret_cast<int*>(pick_nfnb + (slots + 15) / 16 * 16);     // [R]
+  int* used_mask = region_cnt + R;          // [kExMaxRegions] pre-marks of the run that produced the current picks
+  int* new_mask = used_mask + kExMaxRegions;   // [kExMaxRegions] spill of the predecessor's current picks
+  int* flags = new_mask + kExMaxRegions;    // [4]
+
+  const int H = v.scan_lines;
+  int* nedges_out = v.ring_nedges + (size_t)s * H + ring;
+  int* npoints_out = v.ring_npoints + (size_t)s * H + ring;
+  const unsigned long long t_begin = (v.debug & 32) ? wall_clock64() : 0ull;
+  const bool dbgb = (ring == (((v.debug >> 8) & 0xFF) ? ((v.debug >> 8) & 0xFF) : 40) % H) && (s == 0) && (tid == 0);
+  DBG_STAMP(v, dbgb, 0, 0);
+  int dbg_rounds = 0;
+  // ---- the ring's points are contiguous in the ring-sorted copy written by k_ring_scatter ----
+  const int rbeg = v.ring_start[(size_t)s * (H + 1) + ring];
+  const int nr = v.ring_start[(size_t)s * (H + 1) + ring + 1] - rbeg;
+  const float4* rpts = v.ring_pts + (size_t)s * v.max_points + rbeg;
+  const int* rsrc = v.ring_src + (size_t)s * v.max_points + rbeg;
+  double* rc = v.ring_c + (size_t)s * v.max_points + rbeg;                // debug dump / generic-path scratch
+  const bool dump = (v.debug & 1) != 0;
+  if (tid == 0) *npoints_out = nr;
+  // rings below min_points_per_scan are skipped (feature_extractor.cc:188)
+  if ((long long)nr < v.min_points_per_scan || nr < 11) {
+    if (tid == 0) *nedges_out = 0;
+    if (dump) for (int j = tid; j < nr; j += nthreads) rc[j] = __longlong_as_double(0x7ff8000000000000ll);
+    return;
+  }
+  const int total = nr - 10;                            // :238
+  const int sector = total / R;                         // :239
+  const int last_len = total - sector * (R - 1);
+  const int max_len = sector > last_len ? sector : last_len;
+  const int ppr = epr + 1;                              // picks per region (:270)
+  const bool fast = max_len <= kExLPR * IPL && sector >= 5 && R <= kExMaxRegions && R <= 4 * (nthreads >> 6) && nr <= kGapBitsCap;
+  if (dump) {
+    for (int j = tid; j < 5; j += nthreads) { rc[j] = __longlong_as_double(0x7ff8000000000000ll); rc[nr - 1 - j] = rc[j]; }
+  }
+  if (fast) {
+    ring_select_rows<IPL>(v, rpts, rc, dump, nr, total, sector, R, epr, ppr, gb, pick_idx, pick_nfnb, region_cnt, used_mask, new_mask, flags, dbgb, dbg_rounds);
   } else {
     // ---- generic path: curvature + marks in global scratch, regions in order on one wave ----
     unsigned char* picked = v.ring_picked + (size_t)s * v.max_points + rbeg;
