@@ -195,9 +195,14 @@ __device__ __forceinline__ unsigned long long pack_cell(int cx, int cy, int cz) 
   return ((unsigned long long)(cx & m) << 42) | ((unsigned long long)(cy & m) << 21) |
          (unsigned long long)(cz & m);
 }
+// 32-bit hash of the three 21-bit cell coordinates (spatial-hash primes + murmur3's 32-bit finaliser): a dozen
+// VALU instructions; the 64-bit finaliser used before cost ~30 (64-bit multiplies are emulated) in every probe of
+// k_knn, which is VALU-issue bound on lock-step batches.
 __device__ __forceinline__ unsigned int hash_cell(unsigned long long k, unsigned int mask) {
-  k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
-  return (unsigned int)k & mask;
+  const unsigned int x = (unsigned int)(k >> 42), y = (unsigned int)(k >> 21) & 0x1FFFFFu, z = (unsigned int)k & 0x1FFFFFu;
+  unsigned int h = (x * 73856093u) ^ (y * 19349663u) ^ (z * 83492791u);
+  h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+  return h & mask;
 }
 
 // =============================================================================================
@@ -1082,17 +1087,18 @@ __global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int oute
         h = (h + 1) & tmask;
       }
     };
-    // box distance (FP64) to the cell [c, c + 0.5)^3, shrunk by 1e-5 so that float rounding of the
-    // candidate distances can never make a pruned point look closer than the bound
-    auto box_lb = [&](int dx, int dy, int dz) -> double {
-      const double lx = (double)(cx + dx) * kCellSize, ly = (double)(cy + dy) * kCellSize, lz = (double)(cz + dz) * kCellSize;
-      const double ex = (double)qx < lx ? lx - (double)qx : ((double)qx > lx + kCellSize ? (double)qx - (lx + kCellSize) : 0.0);
-      const double ey = (double)qy < ly ? ly - (double)qy : ((double)qy > ly + kCellSize ? (double)qy - (ly + kCellSize) : 0.0);
-      const double ez = (double)qz < lz ? lz - (double)qz : ((double)qz > lz + kCellSize ? (double)qz - (lz + kCellSize) : 0.0);
-      return (ex * ex + ey * ey + ez * ez) * (1.0 - 1e-5);
+    // box distance to the cell, shrunk by 1e-5 so that rounding of the candidate distances (float, ~3e-7 relative)
+    // or of this bound itself (float, ~3e-7) can never make a pruned point look closer than the bound
+    auto box_lb = [&](int dx, int dy, int dz) -> float {
+      const float cs = (float)kCellSize;
+      const float lx = (float)(cx + dx) * cs, ly = (float)(cy + dy) * cs, lz = (float)(cz + dz) * cs;
+      const float ex = qx < lx ? lx - qx : (qx > lx + cs ? qx - (lx + cs) : 0.0f);
+      const float ey = qy < ly ? ly - qy : (qy > ly + cs ? qy - (ly + cs) : 0.0f);
+      const float ez = qz < lz ? lz - qz : (qz > lz + cs ? qz - (lz + cs) : 0.0f);
+      return (ex * ex + ey * ey + ez * ez) * (1.0f - 1e-5f);
     };
     unsigned int start = 0, cnt = 0;
-    double lb = 0.0;     // lower bound of the float squared distance from q to any point of the cell
+    float lb = 0.0f;     // lower bound of the float squared distance from q to any point of the cell
     if (hl < 27) {       // inner shell: the query's cell and its 26 neighbours
       const int dx = hl % 3 - 1, dy = (hl / 3) % 3 - 1, dz = hl / 9 - 1;
       probe(dx, dy, dz, start, cnt);
@@ -1129,10 +1135,10 @@ __global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int oute
       bound_f = b < bound_f ? b : bound_f;
     };
     bool pending = (hl < 27) && (cnt > 0);
-    const double thr[4] = {0.0, 0.04, 0.25, 4.0};
+    const float thr[4] = {0.0f, 0.04f, 0.25f, 4.0f};
 #pragma unroll
     for (int round = 0; round < 4; round++) {
-      pending = pending && !(lb > (double)bound_f);              // pruned for good
+      pending = pending && !(lb > bound_f);                      // pruned for good
       // few candidates left (<= 8 per lane): one pass over all of them is cheaper than the
       // remaining rounds with their bound refreshes
       bool all_now = false;

@@ -400,11 +400,14 @@ LD_HD bool line_gate(const float* nx, const float* ny, const float* nz) {
     cov[0] = cov[0] + zx * zx; cov[1] = cov[1] + zx * zy; cov[2] = cov[2] + zx * zz;
     cov[3] = cov[3] + zy * zy; cov[4] = cov[4] + zy * zz; cov[5] = cov[5] + zz * zz;
   }
-  // The gate needs a decision, not eigenvalues: the closed-form (trigonometric) eigenvalues of a
-  // symmetric 3 x 3 matrix cost ~60 flops + acos + 2 cos on the one lane that evaluates the gate,
-  // the iterative solver ~4 us of dependent FP64 latency.  Their absolute error is a few ulp of
-  // the largest eigenvalue, so the closed form decides whenever lambda2 - 3*lambda1 is not within
-  // 1e-9 * lambda2 of zero; the (rare) rest goes through the iterative solver as before.
+  // The gate needs a decision, not eigenvalues.  The closed-form (trigonometric) eigenvalues of a symmetric
+  // 3 x 3 matrix decide unless lambda2 - 3*lambda1 is too close to zero for their accuracy; the (rare) rest goes
+  // through the iterative solver (the oracle's algorithm).  Two stages, because the gate runs on one lane per
+  // query while the rest of its wave waits, so its instruction count is paid by the whole wave:
+  //   (1) float trigonometry (atan2f / cosf: ~110 instructions): the angle is formed from sqrt((1-r)(1+r)) and r,
+  //       which is well conditioned near |r| = 1 (the line-like case), so the eigenvalues are good to ~1e-6
+  //       relative; decides unless |diff| <= 1e-4 * lambda_max;
+  //   (2) double trigonometry (acos / cos: ~330 instructions): decides unless |diff| <= 1e-9 * lambda_max.
   const double p1 = cov[1] * cov[1] + cov[2] * cov[2] + cov[4] * cov[4];
   const double q = (cov[0] + cov[3] + cov[5]) / 3.0;
   const double d0 = cov[0] - q, d1 = cov[3] - q, d2 = cov[5] - q;
@@ -415,6 +418,16 @@ LD_HD bool line_gate(const float* nx, const float* ny, const float* nz) {
     const double b00 = d0 * ip, b11 = d1 * ip, b22 = d2 * ip, b01 = cov[1] * ip, b02 = cov[2] * ip, b12 = cov[4] * ip;
     double r = 0.5 * (b00 * (b11 * b22 - b12 * b12) - b01 * (b01 * b22 - b12 * b02) + b02 * (b01 * b12 - b11 * b02));
     r = r < -1.0 ? -1.0 : (r > 1.0 ? 1.0 : r);
+    {
+      const float s2 = (float)((1.0 - r) * (1.0 + r));
+      const float phi = atan2f(sqrtf(s2 > 0.f ? s2 : 0.f), (float)r) * (1.0f / 3.0f);
+      const double c_max = (double)cosf(phi), c_min = (double)cosf(phi + 2.0943951f);
+      const double e_max = q + 2.0 * pp * c_max;
+      const double e_min = q + 2.0 * pp * c_min;
+      const double e_mid = 3.0 * q - e_max - e_min;
+      const double diff = e_max - 3.0 * e_mid;
+      if (fabs(diff) > 1e-4 * e_max) return diff > 0.0;
+    }
     const double phi = acos(r) / 3.0;
     const double e_max = q + 2.0 * pp * cos(phi);
     const double e_min = q + 2.0 * pp * cos(phi + 2.0943951023931954923);   // + 2 pi / 3

@@ -93,6 +93,40 @@ def test_eig_and_gate_bitwise(hc, orc):
         assert hc.hc_line_gate(_fp(nx), _fp(ny), _fp(nz)) == int(ev_o[2] > 3 * ev_o[1])
 
 
+def test_line_gate_decision_near_the_threshold(hc, orc):
+    """The two-stage closed-form gate (float trigonometry, then double, then the oracle's iterative solver) must
+    take the oracle's decision lambda_max > 3 lambda_mid everywhere, also when the ratio is within 1e-3 ... 1e-9
+    of 3 (where the cheaper stages must hand over) and for degenerate neighbourhoods."""
+    rng = np.random.default_rng(42)
+    n_near = 0
+    for trial in range(6000):
+        jitter = 10.0 ** rng.uniform(-10, -2)
+        ratio = 3.0 * (1.0 + rng.choice([-1.0, 1.0]) * jitter) if trial % 2 else rng.uniform(1.0, 9.0)
+        # five points with a scatter matrix of eigenvalues ~ (ratio, 1, eps) in a random frame
+        base = rng.normal(size=(5, 3))
+        base -= base.mean(0)
+        u, sv, vt = np.linalg.svd(base, full_matrices=False)
+        target = np.sqrt(np.array([ratio, 1.0, rng.uniform(0, 0.5)]))
+        pts = (u * target) @ vt * rng.uniform(0.01, 0.5) + rng.uniform(-50, 50, 3)
+        if trial % 50 == 0:
+            pts[:] = pts[0]                                   # degenerate: five coincident points
+        pts = pts.astype(np.float32)
+        c = pts.astype(np.float64)
+        cen = np.zeros(3)
+        for j in range(5):
+            cen = cen + c[j]
+        cen = cen / 5.0
+        cov = np.zeros(6)
+        for j in range(5):
+            z = c[j] - cen
+            cov = cov + np.array([z[0] * z[0], z[0] * z[1], z[0] * z[2], z[1] * z[1], z[1] * z[2], z[2] * z[2]])
+        ev_o = orc.eig3(cov)
+        nx, ny, nz = [np.ascontiguousarray(pts[:, k]) for k in range(3)]
+        assert hc.hc_line_gate(_fp(nx), _fp(ny), _fp(nz)) == int(ev_o[2] > 3 * ev_o[1]), (trial, ev_o)
+        n_near += abs(ev_o[2] - 3 * ev_o[1]) < 1e-4 * ev_o[2]
+    assert n_near > 200          # the hand-over bands were exercised
+
+
 def test_transform_pose_bitwise(hc, orc):
     rng = np.random.default_rng(1)
     q = rng.normal(size=4)
