@@ -526,6 +526,10 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   ALLOC(v.corr_b, S * v.edge_cap, 0);
   ALLOC(v.corr_idx, S * 2 * v.edge_cap, 0xFF);
   if (v.debug & 1) ALLOC(v.knn_q, S * 2 * v.edge_cap, 0); else v.knn_q = nullptr;
+  if (std::getenv("LIODOM_KNN_REUSE") == nullptr || std::atoi(std::getenv("LIODOM_KNN_REUSE")) != 0) {
+    ALLOC(v.knn_save_pos, S * (size_t)v.edge_cap * kKnnGroup * 5, 0xFF);
+    ALLOC(v.knn_save_q, S * (size_t)v.edge_cap, 0);
+  } else { v.knn_save_pos = nullptr; v.knn_save_q = nullptr; }
   ALLOC(v.win_pts, S * h->P * v.edge_cap, 0);
   ALLOC(v.win_n, S * h->P, 0);
   ALLOC(v.win_base, S * (h->P + 1), 0);

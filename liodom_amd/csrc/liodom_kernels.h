@@ -126,6 +126,8 @@ struct DevView {
   float4* corr_a;           // [S][edge_cap]  xyz of NN0, w = valid
   float4* corr_b;           // [S][edge_cap]  xyz of NN1
   int2* corr_idx;           // [S][2][edge_cap] window indices of (NN0, NN1), debug/parity
+  int* knn_save_pos;        // [S][edge_cap][32][5] pass 0: every lane's top-5 candidate positions (second pass re-ranks them)
+  float4* knn_save_q;       // [S][edge_cap] pass 0: the query (xyz) and the guard distance below which no unsaved point lies (0 = nothing saved)
   float4* knn_q;            // [S][2][edge_cap] world-frame float query of every edge and pass (debug_buffers only, else null)
   float4* win_pts;          // [S][P][edge_cap]
   int* win_n;               // [S][P]
@@ -924,6 +926,7 @@ __device__ __forceinline__ void top5_insert(Top5& t, float d, int wi, int pos) {
 // list -> 32 lanes stride over it, four independent 16-B loads in flight per lane.
 // Measured (threshold, loads in flight) on one stream / 64 streams, us per scan step: none 132.8 / 714;
 // (96, 4) 130.8 / 822; (64, 2) 128.4 / 711; (32, 2) 127.9 / 708; (16, 2) 128.2 / 703; (64, 3) 129.4 / 759.
+constexpr float kReuseMargin = 0.05f;    // metres added to the pruning radius of the first kNN pass (see the second pass)
 constexpr int kKnnBigCell = 32;        // cells with at least this many points are streamed cell-major
 __device__ __forceinline__ void knn_stream_cells(Top5& t, const float4* sp, int* s_incl, int* s_adj,
                                                  unsigned int start, unsigned int cnt, int hl,
@@ -1071,6 +1074,7 @@ __global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int oute
   }
   DBG_STAMP(v, dbgb, 1, 1);
   if (hl == 0) { s_res[grp][0] = 0; s_res[grp][1] = -1; s_res[grp][2] = -1; }
+  if (!active && outer_it == 0 && v.knn_save_pos && e < E && hl == 0) v.knn_save_q[(size_t)s * v.edge_cap + e] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (active) {                                    // uniform over each 32-lane half
     const int cx = (int)floorf(qx * kCellInv), cy = (int)floorf(qy * kCellInv), cz = (int)floorf(qz * kCellInv);
     const unsigned int tmask = st.table_mask;
@@ -1097,101 +1101,162 @@ __global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int oute
       const float ez = qz < lz ? lz - qz : (qz > lz + cs ? qz - (lz + cs) : 0.0f);
       return (ex * ex + ey * ey + ez * ez) * (1.0f - 1e-5f);
     };
-    unsigned int start = 0, cnt = 0;
-    float lb = 0.0f;     // lower bound of the float squared distance from q to any point of the cell
-    if (hl < 27) {       // inner shell: the query's cell and its 26 neighbours
-      const int dx = hl % 3 - 1, dy = (hl / 3) % 3 - 1, dz = hl / 9 - 1;
-      probe(dx, dy, dz, start, cnt);
-      lb = box_lb(dx, dy, dz);
-    }
-    DBG_STAMP(v, dbgb, 1, 2);
-    if (v.debug & 4) cnt = 0;
     const float4* sp = v.sorted_pts + (size_t)s * v.map_cap;
     Top5 t, g;
     top5_clear(t);
-    // Cells are streamed in rounds of increasing box distance (own cell; within 0.2 m; within
-    // 0.5 m; the rest of the inner shell; then, only if still needed, the outer shell).  After
-    // every round the pruning bound is refreshed: an upper bound of the final 5th-best distance =
-    // the 5th smallest of the lanes' best distances (five distinct points are at least that close)
-    // or any single lane's own 5th entry, never above the 1.0 gate (points at >= 1.0 cannot be part
-    // of a match, :324).  A cell is skipped only if its box distance exceeds the bound, so the
-    // result is exact; a typical query ends after its own cell.
-    float bound_f = 1.0f;
-    auto refresh_bound = [&]() {
-      unsigned int bnd = 0x7f800000u;   // +inf
-      bool taken = false;
-      const unsigned int mine = (unsigned int)(t.k0 >> 32);   // non-negative floats order as uints
+    // ---- second pass of a scan: re-rank what the first pass kept.  The first solve moves the pose by millimetres, so
+    // almost every query has the same neighbours as before.  Pass 0 saved, per query, every lane's five best
+    // candidates (up to 160 positions: a superset of the five nearest) and a guard g: no map point outside that set was
+    // closer to the old query than sqrt(g) (the lanes' 5th-best distances, the box distances of the pruned cells, the
+    // distance to the border of the 27-cell block).  With d = |q_new - q_old| every unsaved point is now at least sqrt(g) - d away; if the 5th best of the
+    // re-ranked set is strictly closer than that (rounding margins included), it is the exact answer — otherwise the
+    // query takes the full search below.  Exact by construction, never approximate. ----
+    bool need_full = true;
+    if (outer_it == 1 && v.knn_save_pos) {
+      const float4 sq = v.knn_save_q[(size_t)s * v.edge_cap + e];
+      if (sq.w > 0.f) {                                          // (uniform over the half-wave)
+        const int* sv = v.knn_save_pos + (((size_t)s * v.edge_cap + e) * kKnnGroup + hl) * 5;
+        int pos[5];
 #pragma unroll
-      for (int r = 0; r < 5; r++) {
-        const unsigned int cur = taken ? 0x7f800000u : mine;
-        const unsigned int mn = half_min_u32(cur);
-        if (r == 4) bnd = mn;
-        const unsigned int win = (unsigned int)((__ballot(!taken && cur == mn) >> half_shift) & 0xFFFFFFFFull);
-        if (hl == __ffs(win) - 1) taken = true;
-      }
-      const unsigned int own5 = half_min_u32((unsigned int)(t.k4 >> 32));
-      bnd = own5 < bnd ? own5 : bnd;
-      const float b = __int_as_float((int)bnd);
-      bound_f = b < bound_f ? b : bound_f;
-    };
-    bool pending = (hl < 27) && (cnt > 0);
-    const float thr[4] = {0.0f, 0.04f, 0.25f, 4.0f};
+        for (int k = 0; k < 5; k++) pos[k] = sv[k];
+        float4 m[5];
 #pragma unroll
-    for (int round = 0; round < 4; round++) {
-      pending = pending && !(lb > bound_f);                      // pruned for good
-      // few candidates left (<= 8 per lane): one pass over all of them is cheaper than the
-      // remaining rounds with their bound refreshes
-      bool all_now = false;
-      if (round == 1 || round == 2) {
-        const int left = __shfl(half_incl_scan_i32(pending ? (int)cnt : 0), kKnnGroup - 1, kKnnGroup);
-        all_now = left <= 8 * kKnnGroup;
+        for (int k = 0; k < 5; k++) m[k] = sp[pos[k] >= 0 ? pos[k] : 0];
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+          if (pos[k] >= 0) top5_insert(t, sqdist_f(qx, qy, qz, m[k].x, m[k].y, m[k].z), __float_as_int(m[k].w), pos[k]);
+        knn_merge(t, g, hl, half_shift);
+        const double ddx = (double)qx - (double)sq.x, ddy = (double)qy - (double)sq.y, ddz = (double)qz - (double)sq.z;
+        const double delta = sqrt(ddx * ddx + ddy * ddy + ddz * ddz) * (1.0 + 1e-12);
+        const double r = sqrt((double)sq.w) * (1.0 - 2e-7) - delta;       // every unsaved point is at least this far now
+        const double limit = r > 0.0 ? r * r * (1.0 - 1e-6) : 0.0;          // (float rounding of the new distances included)
+        need_full = !((double)top5_dist(g.k4) < limit || limit > 1.0);      // beyond the 1.0 gate nothing unsaved can matter
+        if (need_full) top5_clear(t);
+        if ((v.debug & 32) && hl == 0) atomicAdd(&v.dbg_clk[2 * 32 + (need_full ? 30 : 31)], 1ull);   // (debug) second-pass fallbacks / re-ranks
       }
-      const bool now = pending && (all_now || lb <= thr[round]);
-      if ((__ballot(now) >> half_shift) & 0xFFFFFFFFull) {
-        knn_stream_cells(t, sp, s_incl[grp], s_adj[grp], start, now ? cnt : 0u, hl, qx, qy, qz);
-        pending = pending && !now;
-        if (round < 3 && ((__ballot(pending) >> half_shift) & 0xFFFFFFFFull)) refresh_bound();
-      }
-      if (round == 0) DBG_STAMP(v, dbgb, 1, 3);
-      if (round == 1) DBG_STAMP(v, dbgb, 1, 4);
     }
-    // Outer shell for 0.5 m cells only (max |d| = 2, 98 cells, up to four per lane): every one of
-    // them is at least 0.5 m from the query, so it matters only while the bound is still above 0.25.
-    if (kCellSize < 1.0 && bound_f > 0.2499f) refresh_bound();      // (uniform over the half-wave)
-    if (kCellSize < 1.0 && bound_f > 0.2499f) {
-      unsigned int ostart[4], ocnt[4];
-      double olb[4];
-      bool opend[4];
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int j = k * 32 + hl;
-        ostart[k] = 0; ocnt[k] = 0; olb[k] = 1.0e30; opend[k] = false;
-        if (j < 98) {
-          const int c = kKnnOuterCells[j];
-          const int dx = c % 5 - 2, dy = (c / 5) % 5 - 2, dz = c / 25 - 2;
-          olb[k] = box_lb(dx, dy, dz);
-          if (!(olb[k] > (double)bound_f)) { probe(dx, dy, dz, ostart[k], ocnt[k]); opend[k] = ocnt[k] > 0; }
-        }
+    if (need_full) {                                             // (uniform over the half-wave)
+      unsigned int start = 0, cnt = 0;
+      float lb = 0.0f;     // lower bound of the float squared distance from q to any point of the cell
+      if (hl < 27) {       // inner shell: the query's cell and its 26 neighbours
+        const int dx = hl % 3 - 1, dy = (hl / 3) % 3 - 1, dz = hl / 9 - 1;
+        probe(dx, dy, dz, start, cnt);
+        lb = box_lb(dx, dy, dz);
       }
-      if (v.debug & 4) { for (int k = 0; k < 4; k++) opend[k] = false; }
-#pragma unroll
-      for (int round = 0; round < 2; round++) {
-        bool streamed = false;
-#pragma unroll
+      DBG_STAMP(v, dbgb, 1, 2);
+      if (v.debug & 4) cnt = 0;
+      // Cells are streamed in rounds of increasing box distance (own cell; within 0.2 m; within
+      // 0.5 m; the rest of the inner shell; then, only if still needed, the outer shell).  After
+      // every round the pruning bound is refreshed: an upper bound of the final 5th-best distance =
+      // the 5th smallest of the lanes' best distances (five distinct points are at least that close)
+      // or any single lane's own 5th entry, never above the 1.0 gate (points at >= 1.0 cannot be part
+      // of a match, :324).  A cell is skipped only if its box distance exceeds the bound, so the
+      // result is exact; a typical query ends after its own cell.
+      float bound_f = 1.0f;
+      // first pass: cells are pruned against a bound padded by kReuseMargin, so that the guard handed to the second
+      // pass leaves room for the pose correction of the first solve (more cells streamed here, fewer fallbacks there)
+      const bool pad = outer_it == 0 && v.knn_save_pos != nullptr;
+      float prune_f = pad ? (1.0f + kReuseMargin) * (1.0f + kReuseMargin) : 1.0f;
+      auto refresh_bound = [&]() {
+        unsigned int bnd = 0x7f800000u;   // +inf
+        bool taken = false;
+        const unsigned int mine = (unsigned int)(t.k0 >> 32);   // non-negative floats order as uints
+  #pragma unroll
+        for (int r = 0; r < 5; r++) {
+          const unsigned int cur = taken ? 0x7f800000u : mine;
+          const unsigned int mn = half_min_u32(cur);
+          if (r == 4) bnd = mn;
+          const unsigned int win = (unsigned int)((__ballot(!taken && cur == mn) >> half_shift) & 0xFFFFFFFFull);
+          if (hl == __ffs(win) - 1) taken = true;
+        }
+        const unsigned int own5 = half_min_u32((unsigned int)(t.k4 >> 32));
+        bnd = own5 < bnd ? own5 : bnd;
+        const float b = __int_as_float((int)bnd);
+        bound_f = b < bound_f ? b : bound_f;
+        if (pad) { const float rb = sqrtf(bound_f) + kReuseMargin; prune_f = rb * rb; } else prune_f = bound_f;
+      };
+      bool pending = (hl < 27) && (cnt > 0);
+      bool mine_streamed = false;                  // this lane's cell went through the lists (else: pruned, or empty)
+      const float thr[4] = {0.0f, 0.04f, 0.25f, 4.0f};
+  #pragma unroll
+      for (int round = 0; round < 4; round++) {
+        pending = pending && !(lb > prune_f);                      // pruned for good
+        // few candidates left (<= 8 per lane): one pass over all of them is cheaper than the
+        // remaining rounds with their bound refreshes
+        bool all_now = false;
+        if (round == 1 || round == 2) {
+          const int left = __shfl(half_incl_scan_i32(pending ? (int)cnt : 0), kKnnGroup - 1, kKnnGroup);
+          all_now = left <= 8 * kKnnGroup;
+        }
+        const bool now = pending && (all_now || lb <= thr[round]);
+        if ((__ballot(now) >> half_shift) & 0xFFFFFFFFull) {
+          knn_stream_cells(t, sp, s_incl[grp], s_adj[grp], start, now ? cnt : 0u, hl, qx, qy, qz);
+          pending = pending && !now;
+          mine_streamed = mine_streamed || now;
+          if (round < 3 && ((__ballot(pending) >> half_shift) & 0xFFFFFFFFull)) refresh_bound();
+        }
+        if (round == 0) DBG_STAMP(v, dbgb, 1, 3);
+        if (round == 1) DBG_STAMP(v, dbgb, 1, 4);
+      }
+      // Outer shell for 0.5 m cells only (max |d| = 2, 98 cells, up to four per lane): every one of
+      // them is at least 0.5 m from the query, so it matters only while the bound is still above 0.25.
+      if (kCellSize < 1.0 && bound_f > 0.2499f) refresh_bound();      // (uniform over the half-wave)
+      if (kCellSize < 1.0 && bound_f > 0.2499f) {
+        unsigned int ostart[4], ocnt[4];
+        double olb[4];
+        bool opend[4];
+  #pragma unroll
         for (int k = 0; k < 4; k++) {
-          opend[k] = opend[k] && !(olb[k] > (double)bound_f);
-          const bool now = opend[k] && (round == 1 || olb[k] <= 0.5);
-          if ((__ballot(now) >> half_shift) & 0xFFFFFFFFull) {
-            knn_stream_cells(t, sp, s_incl[grp], s_adj[grp], ostart[k], now ? ocnt[k] : 0u, hl, qx, qy, qz);
-            opend[k] = opend[k] && !now;
-            streamed = true;
+          const int j = k * 32 + hl;
+          ostart[k] = 0; ocnt[k] = 0; olb[k] = 1.0e30; opend[k] = false;
+          if (j < 98) {
+            const int c = kKnnOuterCells[j];
+            const int dx = c % 5 - 2, dy = (c / 5) % 5 - 2, dz = c / 25 - 2;
+            olb[k] = box_lb(dx, dy, dz);
+            if (!(olb[k] > (double)bound_f)) { probe(dx, dy, dz, ostart[k], ocnt[k]); opend[k] = ocnt[k] > 0; }
           }
         }
-        const bool left = opend[0] || opend[1] || opend[2] || opend[3];
-        if (round == 0 && streamed && ((__ballot(left) >> half_shift) & 0xFFFFFFFFull)) refresh_bound();
+        if (v.debug & 4) { for (int k = 0; k < 4; k++) opend[k] = false; }
+  #pragma unroll
+        for (int round = 0; round < 2; round++) {
+          bool streamed = false;
+  #pragma unroll
+          for (int k = 0; k < 4; k++) {
+            opend[k] = opend[k] && !(olb[k] > (double)bound_f);
+            const bool now = opend[k] && (round == 1 || olb[k] <= 0.5);
+            if ((__ballot(now) >> half_shift) & 0xFFFFFFFFull) {
+              knn_stream_cells(t, sp, s_incl[grp], s_adj[grp], ostart[k], now ? ocnt[k] : 0u, hl, qx, qy, qz);
+              opend[k] = opend[k] && !now;
+              streamed = true;
+            }
+          }
+          const bool left = opend[0] || opend[1] || opend[2] || opend[3];
+          if (round == 0 && streamed && ((__ballot(left) >> half_shift) & 0xFFFFFFFFull)) refresh_bound();
+        }
       }
+      if (outer_it == 0 && v.knn_save_pos) {
+        // what the second pass needs: the lanes' lists and the guard (see above)
+        const float sk = (hl < 27 && cnt > 0 && !mine_streamed) ? lb : __int_as_float(0x7f800000);
+        unsigned int gd = half_min_u32((unsigned int)__float_as_int(sk));
+        const unsigned int k4m = half_min_u32((unsigned int)(t.k4 >> 32));
+        gd = k4m < gd ? k4m : gd;
+        float guard = __int_as_float((int)gd);
+        // points outside the 27 cells: at least 1 + (distance of q to the nearest face of its own cell) away, so a
+        // query without five neighbours inside the 1.0 gate can usually be certified as still having none
+        {
+          const float cs = (float)kCellSize;
+          const float fx = qx - (float)cx * cs, fy = qy - (float)cy * cs, fz = qz - (float)cz * cs;
+          float edge = fminf(fminf(fminf(fx, cs - fx), fminf(fy, cs - fy)), fminf(fz, cs - fz));
+          edge = edge > 0.f ? edge : 0.f;
+          const float outer = (cs + edge) * (cs + edge) * (1.0f - 1e-6f);
+          guard = guard < outer ? guard : outer;
+        }
+        int* sv = v.knn_save_pos + (((size_t)s * v.edge_cap + e) * kKnnGroup + hl) * 5;
+        sv[0] = t.p0; sv[1] = t.p1; sv[2] = t.p2; sv[3] = t.p3; sv[4] = t.p4;
+        if (hl == 0) v.knn_save_q[(size_t)s * v.edge_cap + e] = make_float4(qx, qy, qz, guard);
+      }
+      knn_merge(t, g, hl, half_shift);
     }
-    knn_merge(t, g, hl, half_shift);
     DBG_STAMP(v, dbgb, 1, 5);
     if (top5_dist(g.k4) < 1.0f) {                                // :324 (inf when < 5 candidates)
       const int mypos = hl == 0 ? g.p0 : hl == 1 ? g.p1 : hl == 2 ? g.p2 : hl == 3 ? g.p3 : g.p4;

@@ -589,3 +589,30 @@ def test_graph_replay_equals_eager(orc, synth, monkeypatch):
         res[mode] = np.array(poses)
         g.close()
     assert np.array_equal(res["0"].view(np.uint64), res["1"].view(np.uint64))
+
+
+def test_second_knn_pass_reuse_equals_full_search(orc, synth, monkeypatch):
+    """The second kNN pass of a scan re-ranks the candidates the first pass kept and accepts the result only when a
+    guard distance proves that no other map point can be among the five nearest (else it searches from scratch).
+    LIODOM_KNN_REUSE=0 disables the shortcut: poses, match counts and correspondence indices must be bit-identical,
+    also on a trajectory with large pose corrections between the passes (fast motion: many fallbacks)."""
+    H, W, R, epr, P, K = 16, 900, 6, 10, 5, 14
+    for yaw, speed in ((0.5, 0.1), (3.0, 0.6)):
+        cfg = synth.make_cfg(H, W, 0, yaw_rate_deg=yaw, speed=speed)
+        scans = [synth.scan(cfg, 6, k)[0] for k in range(K)]
+        res = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("LIODOM_KNN_REUSE", mode)
+            po, g = mk(orc, H, W, 0, R, epr, P)
+            out = []
+            for k in range(K):
+                pose, info = g.process_scan(scans[k], H, W)
+                v1, a1, b1 = g.correspondences(1)
+                out.append((pose.copy(), tuple(info.matches), v1.copy(), a1.copy(), b1.copy()))
+            res[mode] = out
+            g.close()
+        for k in range(K):
+            p0, m0, v0, a0, b0 = res["0"][k]
+            p1, m1, v1, a1, b1 = res["1"][k]
+            assert np.array_equal(p0.view(np.uint64), p1.view(np.uint64)), (yaw, k)
+            assert m0 == m1 and np.array_equal(v0, v1) and np.array_equal(a0, a1) and np.array_equal(b0, b1), (yaw, k)

@@ -200,6 +200,7 @@ def sec_clocks(H=64, W=1800, R=8, epr=10, P=20, K=40):
     allv = np.array(list(buf), dtype=np.int64)
     print('k_ring_extract per-ring workgroup durations (us), rings 0..63:', np.round(allv[128:192] / 100.0, 1).tolist())
     print('k_ring_extract (carry re-run rounds, edges) of the rings written last (ring & 31):', [(int(x) & 255, int(x) >> 8) for x in allv[96:128]])
+    print('k_knn second pass: %d queries re-ranked from the saved lists, %d fell back to the full search' % (int(allv[95]), int(allv[94])))
     print('k_knn workgroup-duration histogram (1 us bins, all scans):', allv[192:256].tolist())
     a = allv[:128].reshape(4, 32).copy()
     names = {0: ["start", "", "gap bits", "", "", "spec select", "carry resolved", "emitted"],
