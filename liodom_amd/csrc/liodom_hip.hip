@@ -233,6 +233,10 @@ int enqueue_odometry(liodom_handle* h, int eb, int s0, int count) {
     ProfScope ps(h, KID_OTHER);
     hipLaunchKernelGGL(k_imu_override, dim3(cdiv(count, 64)), dim3(64), 0, h->stream, v, s0, count);
   }
+  // early rebuild: the finalising k_lm_solve launch carries extra workgroups that count the frames that stay in the
+  // window into the second cell hash while the solve runs; k_window_insert then adds the new frame only
+  const int map_blocks = cdiv(h->v.map_cap, 256);
+  const bool early = v.early_rebuild != 0;
   for (int it = 0; it < 2; it++) {
     {
       ProfScope ps(h, KID_KNN);
@@ -241,10 +245,10 @@ int enqueue_odometry(liodom_handle* h, int eb, int s0, int count) {
     }
     {
       ProfScope ps(h, KID_LM);
-      hipLaunchKernelGGL(k_lm_solve, dim3(h->v.lm_groups, count), dim3(kLmThreads), lm_lds_bytes(h->v.edge_cap), h->stream, v, s0, it, eb);
+      const int extra = (early && it == 1) ? cdiv(h->v.edge_cap * std::max(0, h->P - 1), kLmThreads) : 0;
+      hipLaunchKernelGGL(k_lm_solve, dim3(h->v.lm_groups + extra, count), dim3(kLmThreads), lm_lds_bytes(h->v.edge_cap), h->stream, v, s0, it, eb);
     }
   }
-  const int map_blocks = cdiv(h->v.map_cap, 256);
   if (v.mapping) {
     // synchronous replay of the mapping node for the streams with an attached map: updateMap(edges_k,
     // pose_k), then getLocalMap(pose_k) straight into the stream's received-map buffer
@@ -266,7 +270,7 @@ int enqueue_odometry(liodom_handle* h, int eb, int s0, int count) {
   } else {
     {
       ProfScope ps(h, KID_WINDOW_INSERT);   // window append + cell hash in global memory, map_blocks workgroups per stream
-      hipLaunchKernelGGL(k_window_insert, dim3(map_blocks, count), dim3(256), 0, h->stream, v, s0, eb);
+      hipLaunchKernelGGL(k_window_insert, dim3(early ? cdiv(h->v.edge_cap, 256) : map_blocks, count), dim3(256), 0, h->stream, v, s0, eb);
     }
     {
       ProfScope ps(h, KID_HASH_ALLOC);
@@ -376,7 +380,7 @@ int reset_state(liodom_handle* h) {
     HIP_TRY(hipMemcpy(h->v.imu_q, qid.data(), sizeof(double) * qid.size(), hipMemcpyHostToDevice));
   }
   {
-    const size_t total = (size_t)h->S * h->v.table_size;
+    const size_t total = (size_t)h->S * h->v.table_size * (h->v.early_rebuild ? 2 : 1);
     hipLaunchKernelGGL(k_init_cells, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, h->v);
     HIP_TRY(hipGetLastError());
   }
@@ -481,7 +485,8 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   v.lds_cells_max = kLdsCellsMax;
   if (const char* e = std::getenv("LIODOM_LDS_CELLS_MAX")) v.lds_cells_max = std::max(1, std::min(kLdsCellsMax, std::atoi(e)));
   v.lm_groups = config->lm_workgroups == 0 ? ((config->n_streams <= 4 && params->scan_lines * params->scan_regions * (params->edges_per_region + 1) >= 8192) ? kLmGroupsMax : 1)
-                                           : (config->lm_workgroups >= kLmGroupsMax ? kLmGroupsMax : 1);
+                                           : (config->lm_workgroups >= kLmGroupsMax ? kLmGroupsMax : (config->lm_workgroups < 1 ? 1 : config->lm_workgroups));
+  if (const char* e = getenv("LIODOM_LM_GROUPS")) { const int gq = atoi(e); if (gq >= 1 && gq <= kLmGroupsMax) v.lm_groups = gq; }
   v.vox_inv = 1.0f / 0.4f;                                                          // setLeafSize(0.4) :290
   v.n_streams = h->S;
   v.max_points = config->max_points;
@@ -495,6 +500,9 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   v.use_imu = params->use_imu ? 1 : 0;
   iso_identity(v.laser_to_base);
   v.mapping = params->mapping ? 1 : 0;
+  // (after lds_hash_build and filter_local_map are known)
+  v.early_rebuild = (!h->lds_hash_build && !v.filter_local_map && !params->mapping) ? 1 : 0;
+  if (const char* e = std::getenv("LIODOM_EARLY_REBUILD")) { if (std::atoi(e) == 0) v.early_rebuild = 0; }
   v.recv_cap = v.mapping ? (config->recv_capacity > 0 ? config->recv_capacity : 262144) : 0;
   v.map_cap = v.edge_cap * h->P + v.recv_cap;
   int ts = 1024;
@@ -534,10 +542,11 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   ALLOC(v.win_n, S * h->P, 0);
   ALLOC(v.win_base, S * (h->P + 1), 0);
   ALLOC(v.win_slot, S * h->P, 0);
-  ALLOC(v.cells, S * v.table_size, 0);
+  const size_t ntab = v.early_rebuild ? 2 : 1;     // early_rebuild: two cell hashes per stream (index s + parity * S)
+  ALLOC(v.cells, ntab * S * v.table_size, 0);
   ALLOC(v.pt_rank, S * v.map_cap, 0);
-  ALLOC(v.cell_bits, S * (size_t)(v.table_size / 32), 0);
-  ALLOC(v.used_cells, S * v.map_cap, 0);
+  ALLOC(v.cell_bits, ntab * S * (size_t)(v.table_size / 32), 0);
+  ALLOC(v.used_cells, ntab * S * v.map_cap, 0);
   ALLOC(v.pt_cell, S * v.map_cap, 0xFF);
   if (v.recv_cap) ALLOC(v.recv_pts, S * v.recv_cap, 0);
   ALLOC(v.imu_q, S * 4, 0);

@@ -56,10 +56,10 @@ struct StreamState {
   int32_t frame_count;    // frames ever appended
   int32_t n_frames;       // frames in the window (nframes_)
   int32_t n_edges_buf[3]; // edges in edge buffer 0 / 1 (pipelined replay: extraction of scan k+1 overlaps odometry of scan k) / 2 (liodom_extract_edges)
-  int32_t pad0_;
+  int32_t reb_frame_count; // frame_count as of the scan's first solve: what the early rebuild (k_window_count_old) derives the kept frames from
   int32_t n_map;          // window points covered by the voxel hash
-  int32_t n_used;         // occupied hash cells (current build)
-  int32_t n_used_prev;    // occupied cells of the previous build (to clear)
+  int32_t n_used_tab[2];  // occupied slots of the cell hash (list used_cells); with early_rebuild one per table (the table searched
+                          // while frame_count = F is table F & 1, the next build goes into the other), else only [0] is used
   int32_t cursor;         // allocation cursor into the cell-sorted point array
   int32_t scan_counter;
   uint32_t status;
@@ -81,6 +81,10 @@ struct __attribute__((aligned(16))) CellSlot {
   unsigned int start;       // first point of the cell in sorted_pts
   unsigned int cnt;         // points in the cell
 };
+
+// early_rebuild keeps two cell hashes per stream: arrays indexed by stream (cells, cell_bits, used_cells) are indexed by
+// s + parity * n_streams instead.
+#define LD_TAB_PARITY(v, frame_count) ((v).early_rebuild ? ((frame_count) & 1) : 0)
 
 // Per-stream result record in host-mapped memory.  seq is written last (system-scope release)
 // with the number of scans completed; the host spins on it instead of using events / memcpy.
@@ -162,6 +166,8 @@ struct DevView {
   unsigned char* corr_mask; // [S][2][knn_blocks] bit q: query q of that k_knn workgroup has an accepted correspondence
   int knn_partials;         // k_knn also evaluates every accepted block at the solve's start pose and leaves per-workgroup sums (handles with < 16 streams)
   int knn_queries;          // queries per k_knn workgroup (8, or 4 for handles with >= 16 streams)
+  int early_rebuild;        // the frames that stay in the window are counted into the next cell hash beside the scan's finalising solve
+                            // (k_hash_clear + k_window_count_old on a side stream); k_window_insert then adds the new frame only
   int knn_blocks;           // k_knn workgroups per stream = ceil(edge_cap / knn_queries), rounded up to a multiple of 4
   unsigned long long* lm_xch;   // [S][2][kLmGroupsMax][64] tagged granules: partial sums exchanged between the LM workgroups
   unsigned long long* dbg_clk;  // [8][32] phase timestamps (100 MHz), debug bit 5 only
@@ -1078,8 +1084,9 @@ __global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int oute
   if (active) {                                    // uniform over each 32-lane half
     const int cx = (int)floorf(qx * kCellInv), cy = (int)floorf(qy * kCellInv), cz = (int)floorf(qz * kCellInv);
     const unsigned int tmask = st.table_mask;
-    const CellSlot* cells = v.cells + (size_t)s * v.table_size;
-    const unsigned int* bits = v.cell_bits + (size_t)s * (v.table_size >> 5);
+    const int stab = s + LD_TAB_PARITY(v, st.frame_count) * v.n_streams;
+    const CellSlot* cells = v.cells + (size_t)stab * v.table_size;
+    const unsigned int* bits = v.cell_bits + (size_t)stab * (v.table_size >> 5);
     auto probe = [&](int dx, int dy, int dz, unsigned int& start, unsigned int& cnt) {
       const unsigned long long key = pack_cell(cx + dx, cy + dy, cz + dz);
       unsigned int h = hash_cell(key, tmask);
@@ -1500,7 +1507,7 @@ __device__ __forceinline__ void lm_eval(const DevView& v, int s, int eb, int c_l
 
 // Resets the hash slots occupied by the build that this scan searched (list used_cells[0 .. nup));
 // the last kNN pass of the scan has completed before the finalising k_lm_solve launch starts.
-__device__ void hash_clear_used(const DevView& v, int s, int nup, int t, int nt) {
+__device__ void hash_clear_used(const DevView& v, int s /*table: stream + parity * n_streams*/, int nup, int t, int nt) {
   CellSlot empty; empty.key = kEmptyKey; empty.start = 0; empty.cnt = 0;
   const int* used = v.used_cells + (size_t)s * v.map_cap;
   for (int u0 = t; u0 < nup; u0 += 8 * nt) {   // 8 index loads in flight per thread
@@ -1533,7 +1540,7 @@ __device__ void finalize_scan(const DevView& v, int s, StreamState& st, int* sh_
   int* wb = v.win_base + (size_t)s * (P + 1);
   int* ws = v.win_slot + (size_t)s * P;
   const int n_edges = st.n_edges_buf[eb];
-  const int nup = st.n_used;      // cells of the build that this scan searched (cleared below)
+  const int nup = st.n_used_tab[0];      // cells of the build that this scan searched (cleared below)
   if (tid == ctl) { for (int i = 0; i < 12; i++) st.final_odom[i] = st.odom[i]; }   // (ctl wrote st.odom itself)
   __syncthreads();
   for (int j = tid; j < nf; j += blockDim.x) {
@@ -1583,15 +1590,14 @@ __device__ void finalize_scan(const DevView& v, int s, StreamState& st, int* sh_
     for (int j = 0; j < nf; j++) { const int c = sh_cnt[j]; sh_cnt[j] = acc; acc += c; }
     sh_cnt[nf] = acc;
     st.n_map = acc;
-    st.n_used_prev = st.n_used;
-    st.n_used = 0;
+    if (!v.early_rebuild) st.n_used_tab[0] = 0;
     st.cursor = 0;
   }
   __syncthreads();
   for (int j = tid; j <= nf; j += blockDim.x) wb[j] = sh_cnt[j];
   // (first frame only; in steady state the finalising solve clears the table beside its first
   // controller step instead of extending the kernel by ~4.5 us here)
-  if (clear_hash) hash_clear_used(v, s, nup, tid, (int)blockDim.x);
+  if (clear_hash && !v.early_rebuild) hash_clear_used(v, s, nup, tid, (int)blockDim.x);
 }
 
 // All-to-all exchange of the 29 partial sums between the G workgroups of a stream, inside the
@@ -1653,6 +1659,8 @@ __global__ void k_imu_override(DevView v, int s0, int count) {
   st.param_t[0] = out[3]; st.param_t[1] = out[7]; st.param_t[2] = out[11];         // :192-195
 }
 
+__device__ void count_kept_frames(const DevView& v, int s, StreamState& st, int block, int* sbase, int* sslot);
+
 __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int outer_it, int eb) {
   __shared__ double sh_pose[12];
   __shared__ double sh_acc[kAccN];
@@ -1660,9 +1668,15 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
   __shared__ int sh_flag;
   __shared__ int sh_C;
   const int s = s0 + blockIdx.y;
-  const int g = blockIdx.x, G = gridDim.x;      // G cooperating workgroups per stream
+  const int g = blockIdx.x, G = v.lm_groups;    // G cooperating workgroups per stream
   StreamState& st = v.state[s];
   __shared__ int sh_cnt[kMaxFrames + 1];
+  if (g >= G) {
+    // early_rebuild, finalising launch: the workgroups behind the solve count the kept window frames into the next cell hash
+    __shared__ int sh_slot[kMaxFrames];
+    count_kept_frames(v, s, st, g - G, sh_cnt, sh_slot);
+    return;
+  }
   __shared__ double sh_loc[kAccN];
   __shared__ double sh_red[16][32];
   extern __shared__ __attribute__((aligned(16))) int sh_idx[];   // [edge_cap] compacted correspondence indices, then the reduction matrix
@@ -1670,6 +1684,11 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
   const int tid = threadIdx.x;
   const bool prep = tid < kLmCtl;               // waves 0..6: compaction + register cache while the controller lane works
   if (outer_it == 0 && tid == 0 && g == 0) {     // per-scan diagnostics (matches are counted by k_knn)
+    if (v.early_rebuild) {
+      // the next build goes into the other table (cleared by the previous scan's k_hash_scatter): start its list of occupied
+      // slots; frame_count is snapshotted because the finalising solve advances it beside the counting workgroups
+      st.reb_frame_count = st.frame_count; st.n_used_tab[(st.frame_count + 1) & 1] = 0;
+    }
     st.info.n_edges = st.n_edges_buf[eb];
     st.info.map_points = st.n_search;
     for (int k = 0; k < 2; k++) {
@@ -1689,9 +1708,9 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
   // The second kNN pass of this scan has completed when the finalising solve starts, so the cell hash it
   // searched is no longer needed: waves 0..6 reset its occupied slots while the controller lane works on its
   // first update step (they would idle at the barrier otherwise).
-  bool clr_pending = outer_it == 1 && g == 0 && prep;
+  bool clr_pending = outer_it == 1 && g == 0 && prep && !v.early_rebuild;
   auto clear_hash_slots = [&]() {
-    hash_clear_used(v, s, st.n_used, tid, kLmCtl);
+    hash_clear_used(v, s, st.n_used_tab[0], tid, kLmCtl);
     clr_pending = false;
   };
   const bool dbgb = (s == 0) && (g == 0) && (tid == kLmCtl) && (outer_it == 1);
@@ -1807,18 +1826,66 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
 // (re)initialise every slot of the voxel hash (handle creation / reset)
 __global__ __launch_bounds__(256) void k_init_cells(DevView v) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  const size_t total = (size_t)v.n_streams * v.table_size;
+  const size_t per = (size_t)v.n_streams * v.table_size;
+  const size_t total = per * (v.early_rebuild ? 2 : 1);          // early_rebuild: two cell hashes per stream
   if (i >= total) return;
   CellSlot empty; empty.key = kEmptyKey; empty.start = 0; empty.cnt = 0;
   v.cells[i] = empty;
   if ((i & 31) == 0) v.cell_bits[i >> 5] = 0u;
-  if (v.vox_cells) { v.vox_cells[i] = empty; v.vox_fill[i] = 0; }
+  if (v.vox_cells && i < per) { v.vox_cells[i] = empty; v.vox_fill[i] = 0; }
 }
 
-// One thread per window point (oldest frame first).  Points of the newest frame are produced
-// here: edges transformed by the solved pose in FP64 and rounded to float
-// (laser_odometry.cc:231-232), then stored in the window slot (:235).  Every point is counted
-// into its 1 m cell (atomicCAS insert + atomicAdd count).
+// Counts window point m (position pt) into its 1 m cell of the build in progress: atomicCAS insert of the cell key,
+// atomicAdd of the cell's count.  The value the count had before is the point's rank inside the cell, so the scatter
+// pass needs no second atomic (and no per-cell fill counter to keep clean).  Called by whole waves (inactive lanes
+// pass live = false): the slots a wave creates are appended to the list of occupied slots with one atomic.
+__device__ __forceinline__ void hash_count_point(const DevView& v, int s, int par /*table*/, StreamState& st, int m, float4 pt, bool live) {
+  int* pc = v.pt_cell + (size_t)s * v.map_cap + m;
+  const bool fin = live && ld_isfinite((double)pt.x) && ld_isfinite((double)pt.y) && ld_isfinite((double)pt.z) &&
+                   fabsf(pt.x) < 1.0e9f && fabsf(pt.y) < 1.0e9f && fabsf(pt.z) < 1.0e9f;
+  const unsigned int tmask = (unsigned int)v.table_size - 1u;
+  const int sp = s + par * v.n_streams;
+  CellSlot* cells = v.cells + (size_t)sp * v.table_size;
+  unsigned int h = 0;
+  int found = -1;
+  bool created = false;
+  if (fin) {
+    const unsigned long long key = pack_cell((int)floorf(pt.x * kCellInv), (int)floorf(pt.y * kCellInv), (int)floorf(pt.z * kCellInv));
+    h = hash_cell(key, tmask);
+    for (int probe = 0; probe < v.table_size; probe++) {
+      const unsigned long long prev = atomicCAS(&cells[h].key, kEmptyKey, key);
+      if (prev == kEmptyKey) {
+        atomicOr(&v.cell_bits[((size_t)sp * v.table_size + h) >> 5], 1u << (h & 31));
+        found = (int)h;
+        created = true;
+        break;
+      }
+      if (prev == key) { found = (int)h; break; }
+      h = (h + 1) & tmask;
+    }
+  }
+  // list of occupied slots: one atomic per wave for all the slots its lanes created
+  {
+    const unsigned long long cm = __ballot(created);
+    if (cm) {
+      const int lane = threadIdx.x & 63;
+      int base = 0;
+      if (lane == (int)__builtin_ctzll(cm)) base = atomicAdd(&st.n_used_tab[par], (int)__popcll(cm));
+      base = __shfl(base, (int)__builtin_ctzll(cm));
+      if (created) v.used_cells[(size_t)sp * v.map_cap + base + (int)__popcll(cm & ((1ull << lane) - 1ull))] = (int)h;
+    }
+  }
+  if (!live) return;
+  if (!fin) { *pc = -1; return; }
+  if (found < 0) { atomicOr(&st.status, LIODOM_STATUS_HASH_FULL); *pc = -1; return; }
+  v.pt_rank[(size_t)s * v.map_cap + m] = (int)atomicAdd(&cells[found].cnt, 1u);
+  *pc = found;
+}
+
+// The new frame's edges (dense edge buffer eb, sensor frame) are transformed with the solved pose
+// (laser_odometry.cc:231-232), then stored in the window slot (:235).  Every point of the window is counted
+// into its 1 m cell (hash_count_point).  With early_rebuild the frames that stay were counted by count_kept_frames
+// beside the finalising solve and only the new frame is left (eb < 0 — rebuild without a new frame — counts everything).
 __global__ __launch_bounds__(256) void k_window_insert(DevView v, int s0, int eb) {
   __shared__ int sbase[kMaxFrames + 1];
   __shared__ int sslot[kMaxFrames];
@@ -1826,15 +1893,18 @@ __global__ __launch_bounds__(256) void k_window_insert(DevView v, int s0, int eb
   StreamState& st = v.state[s];
   const int M = st.n_map;
   const int MT = M + (v.mapping ? st.n_recv : 0);      // window ++ received map (:310-314)
-  if ((int)(blockIdx.x * 256) >= MT) return;
   const int P = v.prev_frames, nf = st.n_frames;
+  const bool new_only = v.early_rebuild && eb >= 0;
+  const int m_first = new_only ? v.win_base[(size_t)s * (P + 1) + (nf > 0 ? nf - 1 : 0)] : 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && !filter_active(v, st)) { st.n_search = MT; st.n_filt = 0; }
+  if (m_first + (int)(blockIdx.x * 256) >= MT) return;
   for (int j = threadIdx.x; j <= nf; j += 256) sbase[j] = v.win_base[(size_t)s * (P + 1) + j];
   for (int j = threadIdx.x; j < nf; j += 256) sslot[j] = v.win_slot[(size_t)s * P + j];
   __syncthreads();
-  const int m = blockIdx.x * 256 + threadIdx.x;
-  if (m >= MT) return;
-  float4 pt;
-  if (m < M) {
+  const int m = m_first + blockIdx.x * 256 + threadIdx.x;
+  const bool live = m < MT;
+  float4 pt = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (live && m < M) {
     int lo = 0, hi = nf;             // largest j with sbase[j] <= m
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (sbase[mid] <= m) lo = mid; else hi = mid; }
     const int j = lo, idx = m - sbase[j], slot = sslot[j];
@@ -1854,48 +1924,47 @@ __global__ __launch_bounds__(256) void k_window_insert(DevView v, int s0, int eb
     } else {
       pt = *wp;
     }
-  } else {
+  } else if (live) {
     pt = v.recv_pts[(size_t)s * v.recv_cap + (m - M)];
   }
   if (filter_active(v, st)) return;     // the kNN structure is built from the filtered cloud instead
-  if (m == 0) { st.n_search = MT; st.n_filt = 0; }
-  int* pc = v.pt_cell + (size_t)s * v.map_cap + m;
-  const bool fin = ld_isfinite((double)pt.x) && ld_isfinite((double)pt.y) && ld_isfinite((double)pt.z) &&
-                   fabsf(pt.x) < 1.0e9f && fabsf(pt.y) < 1.0e9f && fabsf(pt.z) < 1.0e9f;
-  if (!fin) { *pc = -1; return; }
-  const unsigned long long key = pack_cell((int)floorf(pt.x * kCellInv), (int)floorf(pt.y * kCellInv), (int)floorf(pt.z * kCellInv));
-  const unsigned int tmask = (unsigned int)v.table_size - 1u;
-  CellSlot* cells = v.cells + (size_t)s * v.table_size;
-  unsigned int h = hash_cell(key, tmask);
-  int found = -1;
-  bool created = false;
-  for (int probe = 0; probe < v.table_size; probe++) {
-    const unsigned long long prev = atomicCAS(&cells[h].key, kEmptyKey, key);
-    if (prev == kEmptyKey) {
-      atomicOr(&v.cell_bits[((size_t)s * v.table_size + h) >> 5], 1u << (h & 31));
-      found = (int)h;
-      created = true;
-      break;
-    }
-    if (prev == key) { found = (int)h; break; }
-    h = (h + 1) & tmask;
+  hash_count_point(v, s, LD_TAB_PARITY(v, st.frame_count), st, m, pt, live);
+}
+
+// early_rebuild: the frames that stay in the window (all but the oldest once the window is full,
+// LocalMapManager::addPointCloud :34-60) are counted into the next build — under the indices they will have after the
+// append — by extra workgroups of the finalising k_lm_solve launch, beside the solve.  Uses only state the solve does
+// not write: the frame_count snapshot and the sizes of the kept slots.  sbase / sslot: LDS, kMaxFrames + 1 ints each.
+__device__ void count_kept_frames(const DevView& v, int s, StreamState& st, int block, int* sbase, int* sslot) {
+  const int P = v.prev_frames, fc = st.reb_frame_count;
+  const int nf_old = fc < P ? fc : P;
+  const int drop = nf_old == P ? 1 : 0;
+  const int nk = nf_old - drop;                       // kept frames, chronological
+  if (nk <= 0) return;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int j = tid; j < nk; j += nt) {
+    const int sl = (fc - nf_old + drop + j) % P;
+    sslot[j] = sl;
+    sbase[j + 1] = v.win_n[(size_t)s * P + sl];
   }
-  // list of occupied slots: one atomic per wave for all the slots its lanes created
-  {
-    const unsigned long long cm = __ballot(created);
-    if (cm) {
-      const int lane = threadIdx.x & 63;
-      int base = 0;
-      if (lane == (int)__builtin_ctzll(cm)) base = atomicAdd(&st.n_used, (int)__popcll(cm));
-      base = __shfl(base, (int)__builtin_ctzll(cm));
-      if (created) v.used_cells[(size_t)s * v.map_cap + base + (int)__popcll(cm & ((1ull << lane) - 1ull))] = (int)h;
-    }
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int j = 0; j < nk; j++) { const int c = sbase[j + 1]; sbase[j] = acc; acc += c; }
+    sbase[nk] = acc;
   }
-  if (found < 0) { atomicOr(&st.status, LIODOM_STATUS_HASH_FULL); *pc = -1; return; }
-  // the value the count had before this point is its rank inside the cell: the scatter pass
-  // needs no second atomic (and no per-cell fill counter to keep clean)
-  v.pt_rank[(size_t)s * v.map_cap + m] = (int)atomicAdd(&cells[found].cnt, 1u);
-  *pc = found;
+  __syncthreads();
+  const int Mk = sbase[nk];
+  if (block * nt >= Mk) return;
+  const int m = block * nt + tid;
+  const bool live = m < Mk;
+  float4 pt = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (live) {
+    int lo = 0, hi = nk;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (sbase[mid] <= m) lo = mid; else hi = mid; }
+    pt = v.win_pts[((size_t)s * P + sslot[lo]) * v.edge_cap + (m - sbase[lo])];
+  }
+  hash_count_point(v, s, (fc + 1) & 1, st, m, pt, live);
 }
 
 // Start offsets of the occupied cells (any order: only contiguity per cell matters).  One atomic
@@ -1904,13 +1973,14 @@ __global__ __launch_bounds__(256) void k_window_insert(DevView v, int s0, int eb
 __global__ __launch_bounds__(256) void k_hash_alloc(DevView v, int s0) {
   const int s = s0 + blockIdx.y;
   StreamState& st = v.state[s];
-  const int nu = st.n_used;
+  const int par = LD_TAB_PARITY(v, st.frame_count), sp = s + par * v.n_streams;
+  const int nu = st.n_used_tab[par];
   if ((int)(blockIdx.x * 256) >= nu) return;
   const int u = blockIdx.x * 256 + threadIdx.x;
   CellSlot* slot = nullptr;
   int cnt = 0;
   if (u < nu) {
-    slot = v.cells + (size_t)s * v.table_size + v.used_cells[(size_t)s * v.map_cap + u];
+    slot = v.cells + (size_t)sp * v.table_size + v.used_cells[(size_t)sp * v.map_cap + u];
     cnt = (int)slot->cnt;
   }
   const int incl = wave_incl_scan_i32(cnt);
@@ -1928,6 +1998,10 @@ __global__ __launch_bounds__(256) void k_hash_scatter(DevView v, int s0) {
   const StreamState& st = v.state[s];
   const int M = st.n_map;
   const int MT = M + (v.mapping ? st.n_recv : 0);
+  const int par = LD_TAB_PARITY(v, st.frame_count), sp = s + par * v.n_streams;
+  // early_rebuild: the table the scan searched is dead now; reset its occupied slots for the build after this one
+  // (its counter is zeroed by the next scan's first k_lm_solve, after every workgroup here has read it)
+  if (v.early_rebuild) hash_clear_used(v, s + (1 - par) * v.n_streams, st.n_used_tab[1 - par], blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
   if ((int)(blockIdx.x * 256) >= MT || filter_active(v, st)) return;
   const int P = v.prev_frames, nf = st.n_frames;
   for (int j = threadIdx.x; j <= nf; j += 256) sbase[j] = v.win_base[(size_t)s * (P + 1) + j];
@@ -1945,7 +2019,7 @@ __global__ __launch_bounds__(256) void k_hash_scatter(DevView v, int s0) {
   } else {
     pt = v.recv_pts[(size_t)s * v.recv_cap + (m - M)];
   }
-  const size_t ti = (size_t)s * v.table_size + h;
+  const size_t ti = (size_t)sp * v.table_size + h;
   const unsigned int pos = v.cells[ti].start + (unsigned int)v.pt_rank[(size_t)s * v.map_cap + m];
   v.sorted_pts[(size_t)s * v.map_cap + pos] = make_float4(pt.x, pt.y, pt.z, __int_as_float(m));
 }
@@ -1954,7 +2028,7 @@ __global__ __launch_bounds__(256) void k_hash_scatter(DevView v, int s0) {
 // (liodom_set_received_map: the kNN cloud changed between two scans).
 __global__ __launch_bounds__(256) void k_hash_reset(DevView v, int s) {
   StreamState& st = v.state[s];
-  const int nup = st.n_used;
+  const int nup = st.n_used_tab[0];
   hash_clear_used(v, s, nup, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
   if (st.table_mask != (unsigned int)v.table_size - 1u) {      // LDS-built table: slots [0, kLdsSlotsC)
     CellSlot empty; empty.key = kEmptyKey; empty.start = 0; empty.cnt = 0;
@@ -1966,7 +2040,7 @@ __global__ __launch_bounds__(256) void k_hash_reset(DevView v, int s) {
 }
 __global__ void k_hash_reset_done(DevView v, int s) {
   StreamState& st = v.state[s];
-  st.n_used = 0; st.cursor = 0; st.table_mask = (unsigned int)v.table_size - 1u;
+  st.n_used_tab[0] = 0; st.cursor = 0; st.table_mask = (unsigned int)v.table_size - 1u;
 }
 
 // =============================================================================================
@@ -2063,7 +2137,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_hash_build(DevView v, int s0,
       for (int i = tid; i < kLdsSlots; i += kBuildThreads) { cells[i] = empty; }
       for (int i = tid; i < kLdsSlots / 32; i += kBuildThreads) bits[i] = 0u;
       __syncthreads();
-      if (tid == 0) { st.table_mask = (unsigned int)v.table_size - 1u; st.n_used = 0; }
+      if (tid == 0) { st.table_mask = (unsigned int)v.table_size - 1u; st.n_used_tab[0] = 0; }
     }
     return;
   }
@@ -2106,7 +2180,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_hash_build(DevView v, int s0,
       for (int i = tid; i < kLdsSlots / 32; i += kBuildThreads) bits[i] = 0u;
     }
     __syncthreads();
-    if (tid == 0) { st.table_mask = (unsigned int)v.table_size - 1u; st.n_used = 0; st.cursor = 0; st.n_search = M; st.n_filt = 0; }
+    if (tid == 0) { st.table_mask = (unsigned int)v.table_size - 1u; st.n_used_tab[0] = 0; st.cursor = 0; st.n_search = M; st.n_filt = 0; }
     __syncthreads();
     const unsigned int gmask = (unsigned int)v.table_size - 1u;
     for (int m = tid; m < M; m += kBuildThreads) {
@@ -2118,7 +2192,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_hash_build(DevView v, int s0,
         for (int probe = 0; probe < v.table_size; probe++) {
           const unsigned long long prev = atomicCAS(&cells[h].key, kEmptyKey, key);
           if (prev == kEmptyKey) {
-            const int u = atomicAdd(&st.n_used, 1);
+            const int u = atomicAdd(&st.n_used_tab[0], 1);
             v.used_cells[(size_t)s * v.map_cap + u] = (int)h;
             atomicOr(&bits[h >> 5], 1u << (h & 31));
             found = (int)h;
@@ -2134,7 +2208,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_hash_build(DevView v, int s0,
     }
     __threadfence();
     __syncthreads();
-    const int nu = *(volatile int*)&st.n_used;
+    const int nu = *(volatile int*)&st.n_used_tab[0];
     for (int u = tid; u < nu; u += kBuildThreads) {
       CellSlot* slot = cells + v.used_cells[(size_t)s * v.map_cap + u];
       slot->start = (unsigned int)atomicAdd(&st.cursor, (int)*(volatile unsigned int*)&slot->cnt);
@@ -2196,7 +2270,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_hash_build(DevView v, int s0,
     for (int b = 0; b < 32; b++) word |= (lkey[i * 32 + b] != kEmptyKey) ? (1u << b) : 0u;
     bits[i] = word;
   }
-  if (tid == 0) { st.table_mask = lmask; st.n_used = 0; st.cursor = 0; st.n_search = M; st.n_filt = 0; }
+  if (tid == 0) { st.table_mask = lmask; st.n_used_tab[0] = 0; st.cursor = 0; st.n_search = M; st.n_filt = 0; }
 }
 
 // =============================================================================================
@@ -2410,7 +2484,7 @@ __global__ __launch_bounds__(256) void k_filt_insert(DevView v, int s0) {
   for (int probe = 0; probe < v.table_size; probe++) {
     const unsigned long long prev = atomicCAS(&cells[h].key, kEmptyKey, key);
     if (prev == kEmptyKey) {
-      const int k = atomicAdd(&st.n_used, 1);
+      const int k = atomicAdd(&st.n_used_tab[0], 1);
       v.used_cells[(size_t)s * v.map_cap + k] = (int)h;
       atomicOr(&v.cell_bits[((size_t)s * v.table_size + h) >> 5], 1u << (h & 31));
       found = (int)h;
@@ -2429,7 +2503,7 @@ __global__ __launch_bounds__(256) void k_filt_alloc(DevView v, int s0) {
   StreamState& st = v.state[s];
   if (!filter_active(v, st)) return;
   const int u = blockIdx.x * 256 + threadIdx.x;
-  if (u >= st.n_used) return;
+  if (u >= st.n_used_tab[0]) return;
   CellSlot* slot = v.cells + (size_t)s * v.table_size + v.used_cells[(size_t)s * v.map_cap + u];
   slot->start = (unsigned int)atomicAdd(&st.cursor, (int)slot->cnt);
 }
