@@ -245,7 +245,7 @@ int enqueue_odometry(liodom_handle* h, int eb, int s0, int count) {
     }
     {
       ProfScope ps(h, KID_LM);
-      const int extra = (early && it == 1) ? cdiv(h->v.edge_cap * std::max(0, h->P - 1), kLmThreads) : 0;
+      const int extra = (early && it == 1) ? cdiv(h->v.edge_cap * std::max(1, h->P - 1), kLmThreads) : 0;   // (>= the new frame's share)
       hipLaunchKernelGGL(k_lm_solve, dim3(h->v.lm_groups + extra, count), dim3(kLmThreads), lm_lds_bytes(h->v.edge_cap), h->stream, v, s0, it, eb);
     }
   }
@@ -268,9 +268,9 @@ int enqueue_odometry(liodom_handle* h, int eb, int s0, int count) {
     ProfScope ps(h, KID_HASH_BUILD);        // window append + LDS-built cell hash, one workgroup per stream
     hipLaunchKernelGGL(k_hash_build, dim3(count), dim3(kBuildThreads), hash_build_lds_bytes(), h->stream, v, s0, eb);
   } else {
-    {
+    if (!early) {   // (early rebuild: the solving workgroup appended and counted the new frame itself)
       ProfScope ps(h, KID_WINDOW_INSERT);   // window append + cell hash in global memory, map_blocks workgroups per stream
-      hipLaunchKernelGGL(k_window_insert, dim3(early ? cdiv(h->v.edge_cap, 256) : map_blocks, count), dim3(256), 0, h->stream, v, s0, eb);
+      hipLaunchKernelGGL(k_window_insert, dim3(map_blocks, count), dim3(256), 0, h->stream, v, s0, eb);
     }
     {
       ProfScope ps(h, KID_HASH_ALLOC);
@@ -386,6 +386,7 @@ int reset_state(liodom_handle* h) {
   }
   h->pf_slot = -1; h->parity = 0; h->last_eb = 0; h->ev_free_valid[0] = h->ev_free_valid[1] = false;
   HIP_TRY(hipMemsetAsync(h->v.lm_xch, 0, sizeof(unsigned long long) * (size_t)h->S * 2 * kLmGroupsMax * 64, h->stream));
+  HIP_TRY(hipMemsetAsync(h->v.pose_xch, 0, sizeof(unsigned long long) * (size_t)h->S * 32, h->stream));
   std::memset(h->host_out, 0, sizeof(HostOut) * (size_t)h->S);
   std::fill(h->scans_enqueued.begin(), h->scans_enqueued.end(), 0);
   HIP_TRY(hipMemsetAsync(h->v.win_n, 0, sizeof(int) * (size_t)h->S * h->P, h->stream));
@@ -565,6 +566,7 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   ALLOC(h->stage_in, S * (size_t)config->max_points, 0);
   ALLOC(v.dbg_clk, 8 * 32, 0);
   ALLOC(v.lm_xch, S * 2 * kLmGroupsMax * 64, 0);
+  ALLOC(v.pose_xch, S * 32, 0);
   v.knn_queries = config->n_streams >= 16 ? 4 : 8;          // must match the k_knn instance launch_odometry picks
   v.knn_partials = config->n_streams >= 16 ? 0 : 1;         // measured: +37 % on the VALU-bound 256-stream kNN pass, -2 us per solve on one stream
   v.knn_blocks = round_up(cdiv(v.edge_cap, v.knn_queries), 4);
@@ -592,7 +594,7 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
     g_last_error = "hipFuncSetAttribute(max dynamic LDS) failed"; return fail(LIODOM_ERR_HIP);
   }
   v.lm_lds_reduce = lm_lds_reduce_fits(v.edge_cap) ? 1 : 0;
-  if (lm_lds_bytes(v.edge_cap) + 4096 > 160 * 1024) { g_last_error = "liodom_create: edge capacity too large for the solve's LDS tile"; return fail(LIODOM_ERR_INVALID_ARG); }
+  if (lm_lds_bytes(v.edge_cap) + 8192 > 160 * 1024) { g_last_error = "liodom_create: edge capacity too large for the solve's LDS tile"; return fail(LIODOM_ERR_INVALID_ARG); }
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lm_solve), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)lm_lds_bytes(h->v.edge_cap)) != hipSuccess) {
     g_last_error = "hipFuncSetAttribute(max dynamic LDS) failed"; return fail(LIODOM_ERR_HIP);

@@ -166,6 +166,7 @@ struct DevView {
   unsigned char* corr_mask; // [S][2][knn_blocks] bit q: query q of that k_knn workgroup has an accepted correspondence
   int knn_partials;         // k_knn also evaluates every accepted block at the solve's start pose and leaves per-workgroup sums (handles with < 16 streams)
   int knn_queries;          // queries per k_knn workgroup (8, or 4 for handles with >= 16 streams)
+  unsigned long long* pose_xch;   // [S][32] early_rebuild: solved pose handed to the workgroups that append the new frame (tagged 8-byte granules)
   int early_rebuild;        // the frames that stay in the window are counted into the next cell hash beside the scan's finalising solve
                             // (k_hash_clear + k_window_count_old on a side stream); k_window_insert then adds the new frame only
   int knn_blocks;           // k_knn workgroups per stream = ceil(edge_cap / knn_queries), rounded up to a multiple of 4
@@ -1525,6 +1526,8 @@ __device__ void hash_clear_used(const DevView& v, int s /*table: stream + parity
   }
 }
 
+__device__ __forceinline__ void publish_final_pose(const DevView& v, int s, const double* T, int raw, unsigned int tag, int lane);
+
 // Called by the whole workgroup.  sh_cnt: LDS scratch of kMaxFrames + 1 ints.
 // Thread 64 publishes the result (pose log, host-mapped record) while thread `ctl` (the one that wrote st.odom)
 // computes the prediction and the window bookkeeping; the remaining threads fetch the frame sizes.
@@ -1543,6 +1546,8 @@ __device__ void finalize_scan(const DevView& v, int s, StreamState& st, int* sh_
   const int nup = st.n_used_tab[0];      // cells of the build that this scan searched (cleared below)
   if (tid == ctl) { for (int i = 0; i < 12; i++) st.final_odom[i] = st.odom[i]; }   // (ctl wrote st.odom itself)
   __syncthreads();
+  // early_rebuild: hand the pose to the workgroups that append the new frame (they have been waiting for it)
+  if (v.early_rebuild && tid < 25) publish_final_pose(v, s, st.final_odom, st.append_raw, (unsigned int)st.reb_frame_count + 1u, tid);
   for (int j = tid; j < nf; j += blockDim.x) {
     const int sl = (fc_new - nf + j) % P;
     sh_cnt[j] = (sl == new_slot) ? n_edges : wn[sl];     // independent loads, one round trip
@@ -1591,6 +1596,7 @@ __device__ void finalize_scan(const DevView& v, int s, StreamState& st, int* sh_
     sh_cnt[nf] = acc;
     st.n_map = acc;
     if (!v.early_rebuild) st.n_used_tab[0] = 0;
+    else { st.n_search = acc; st.n_filt = 0; }        // (k_window_insert's job otherwise)
     st.cursor = 0;
   }
   __syncthreads();
@@ -1640,6 +1646,21 @@ __device__ void lm_exchange(const DevView& v, int s, int g, int G, unsigned int 
   __syncthreads();
 }
 
+// early_rebuild: the solved pose travels from the solving workgroup to the workgroups that append the new frame inside
+// the same launch (MI355X guide, G16 form R2: the data is the flag): 12 doubles as 24 granules {tag, 32 data bits} + one
+// granule of flags, relaxed agent-scope stores, one granule per lane (a single thread storing all 25 took 4.7 us);
+// tag = frames appended so far + 1 (never 0, the reset value).
+__device__ __forceinline__ void publish_final_pose(const DevView& v, int s, const double* T, int raw, unsigned int tag, int lane /*0..24*/) {
+  typedef __attribute__((address_space(1))) unsigned long long gu64;
+  unsigned long long* base = v.pose_xch + (size_t)s * 32;
+  unsigned int word = (unsigned int)raw;
+  if (lane < 24) {
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(T[lane >> 1]);
+    word = (lane & 1) ? (unsigned int)(bits >> 32) : (unsigned int)bits;
+  }
+  __hip_atomic_store((gu64*)(base + lane), ((unsigned long long)tag << 32) | word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // use_imu (laser_odometry.cc:152-183): the prediction (made when the previous scan finished) gets
 // the roll and pitch of the latest IMU orientation before the first kNN pass; one thread per stream.
 __global__ void k_imu_override(DevView v, int s0, int count) {
@@ -1659,7 +1680,7 @@ __global__ void k_imu_override(DevView v, int s0, int count) {
   st.param_t[0] = out[3]; st.param_t[1] = out[7]; st.param_t[2] = out[11];         // :192-195
 }
 
-__device__ void count_kept_frames(const DevView& v, int s, StreamState& st, int block, int* sbase, int* sslot);
+__device__ void count_window_frames(const DevView& v, int s, StreamState& st, int eb, int block, int* sbase, int* sslot);
 
 __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int outer_it, int eb) {
   __shared__ double sh_pose[12];
@@ -1672,9 +1693,10 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
   StreamState& st = v.state[s];
   __shared__ int sh_cnt[kMaxFrames + 1];
   if (g >= G) {
-    // early_rebuild, finalising launch: the workgroups behind the solve count the kept window frames into the next cell hash
+    // early_rebuild, finalising launch: the workgroups behind the solve count the window (kept frames right away, the new
+    // frame as soon as the solve hands over the pose) into the next cell hash
     __shared__ int sh_slot[kMaxFrames];
-    count_kept_frames(v, s, st, g - G, sh_cnt, sh_slot);
+    count_window_frames(v, s, st, eb, g - G, sh_cnt, sh_slot);
     return;
   }
   __shared__ double sh_loc[kAccN];
@@ -1816,8 +1838,9 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
   DBG_STAMP(v, dbgb, 2, 21);
   if (outer_it == 1) {
     finalize_scan(v, s, st, sh_cnt, eb, false, kLmCtl);
+    DBG_STAMP(v, dbgb, 2, 22);
   }
-  DBG_STAMP(v, dbgb, 2, 22);
+  DBG_STAMP(v, dbgb, 2, 28);
 }
 
 // =============================================================================================
@@ -1931,40 +1954,96 @@ __global__ __launch_bounds__(256) void k_window_insert(DevView v, int s0, int eb
   hash_count_point(v, s, LD_TAB_PARITY(v, st.frame_count), st, m, pt, live);
 }
 
-// early_rebuild: the frames that stay in the window (all but the oldest once the window is full,
-// LocalMapManager::addPointCloud :34-60) are counted into the next build — under the indices they will have after the
-// append — by extra workgroups of the finalising k_lm_solve launch, beside the solve.  Uses only state the solve does
-// not write: the frame_count snapshot and the sizes of the kept slots.  sbase / sslot: LDS, kMaxFrames + 1 ints each.
-__device__ void count_kept_frames(const DevView& v, int s, StreamState& st, int block, int* sbase, int* sslot) {
+// early_rebuild: the window of the next build is counted into the second cell hash by extra workgroups of the
+// finalising k_lm_solve launch, beside the solve.  The frames that stay (all but the oldest once the window is full,
+// LocalMapManager::addPointCloud :34-60) are counted right away under the indices they will have after the append;
+// the first workgroups then wait for the solved pose (publish_final_pose), transform the scan's edges with it
+// (laser_odometry.cc:231-232), store them in the new frame's window slot (:235) and count them too.  Uses only state
+// the solve does not write: the frame_count snapshot, the sizes of the kept slots, the edge count.
+// sbase / sslot: LDS, kMaxFrames + 1 ints each.  (A waiting workgroup depends only on the solving workgroup of its
+// own stream, which has a lower block index and so was dispatched before it.)
+__device__ void count_window_frames(const DevView& v, int s, StreamState& st, int eb, int block, int* sbase, int* sslot) {
+  __shared__ double sh_T[12];
+  __shared__ int sh_hand;
   const int P = v.prev_frames, fc = st.reb_frame_count;
   const int nf_old = fc < P ? fc : P;
   const int drop = nf_old == P ? 1 : 0;
   const int nk = nf_old - drop;                       // kept frames, chronological
-  if (nk <= 0) return;
   const int tid = threadIdx.x, nt = blockDim.x;
-  for (int j = tid; j < nk; j += nt) {
-    const int sl = (fc - nf_old + drop + j) % P;
-    sslot[j] = sl;
-    sbase[j + 1] = v.win_n[(size_t)s * P + sl];
+  const int par = (fc + 1) & 1;
+  const int n_new = st.n_edges_buf[eb];
+  const bool appender = block * nt < n_new;           // this workgroup also handles a share of the new frame
+  float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (appender) {                                     // (loaded before the wait)
+    const int idx = block * nt + tid;
+    e = v.edges[((size_t)eb * v.n_streams + s) * v.edge_cap + (idx < n_new ? idx : 0)];
+  }
+  int Mk = 0;
+  if (nk > 0) {
+    for (int j = tid; j < nk; j += nt) {
+      const int sl = (fc - nf_old + drop + j) % P;
+      sslot[j] = sl;
+      sbase[j + 1] = v.win_n[(size_t)s * P + sl];
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int acc = 0;
+      for (int j = 0; j < nk; j++) { const int c = sbase[j + 1]; sbase[j] = acc; acc += c; }
+      sbase[nk] = acc;
+    }
+    __syncthreads();
+    Mk = sbase[nk];
+    if (block * nt < Mk) {
+      const int m = block * nt + tid;
+      const bool live = m < Mk;
+      float4 pt = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (live) {
+        int lo = 0, hi = nk;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (sbase[mid] <= m) lo = mid; else hi = mid; }
+        pt = v.win_pts[((size_t)s * P + sslot[lo]) * v.edge_cap + (m - sbase[lo])];
+      }
+      hash_count_point(v, s, par, st, m, pt, live);
+    }
+  }
+  if (!appender) return;
+  // ---- the new frame ----
+  if (tid < 64) {
+    typedef __attribute__((address_space(1))) unsigned long long gu64;
+    const unsigned long long* base = v.pose_xch + (size_t)s * 32;
+    const unsigned int tag = (unsigned int)fc + 1u;
+    unsigned long long g = 0;
+    unsigned int spins = 0;
+    bool ok;
+    while (true) {
+      if (tid < 25) g = __hip_atomic_load((gu64*)(base + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ok = tid >= 25 || (unsigned int)(g >> 32) == tag;
+      if (__all(ok)) break;
+      if (++spins > 4000000u) break;
+      __builtin_amdgcn_s_sleep(2);
+    }
+    const bool all_ok = __all(ok);
+    const unsigned long long gflags = __shfl(g, 24);                 // flags granule: low word = append_raw
+    if (tid == 0) sh_hand = all_ok ? (int)(unsigned int)gflags + 1 : 0;   // 0: timed out, else raw + 1
+    const unsigned long long lo = __shfl(g, 2 * (tid % 12)), hi = __shfl(g, 2 * (tid % 12) + 1);
+    if (tid < 12) sh_T[tid] = __longlong_as_double((long long)((hi << 32) | (lo & 0xFFFFFFFFull)));
+    if (!all_ok && tid == 0) atomicOr(&st.status, LIODOM_STATUS_LM_SYNC_TIMEOUT);
   }
   __syncthreads();
-  if (tid == 0) {
-    int acc = 0;
-    for (int j = 0; j < nk; j++) { const int c = sbase[j + 1]; sbase[j] = acc; acc += c; }
-    sbase[nk] = acc;
+  if (sh_hand == 0) return;
+  const int idx = block * nt + tid;
+  const bool live = idx < n_new;
+  float4 pt;
+  if (sh_hand == 2) {
+    pt = e;
+  } else {
+    double T[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) T[i] = sh_T[i];
+    transform_point(T, e.x, e.y, e.z, &pt.x, &pt.y, &pt.z);
+    pt.w = e.w;
   }
-  __syncthreads();
-  const int Mk = sbase[nk];
-  if (block * nt >= Mk) return;
-  const int m = block * nt + tid;
-  const bool live = m < Mk;
-  float4 pt = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (live) {
-    int lo = 0, hi = nk;
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (sbase[mid] <= m) lo = mid; else hi = mid; }
-    pt = v.win_pts[((size_t)s * P + sslot[lo]) * v.edge_cap + (m - sbase[lo])];
-  }
-  hash_count_point(v, s, (fc + 1) & 1, st, m, pt, live);
+  if (live) v.win_pts[((size_t)s * P + (fc % P)) * v.edge_cap + idx] = pt;
+  hash_count_point(v, s, par, st, Mk + idx, pt, live);
 }
 
 // Start offsets of the occupied cells (any order: only contiguity per cell matters).  One atomic

@@ -616,3 +616,39 @@ def test_second_knn_pass_reuse_equals_full_search(orc, synth, monkeypatch):
             p1, m1, v1, a1, b1 = res["1"][k]
             assert np.array_equal(p0.view(np.uint64), p1.view(np.uint64)), (yaw, k)
             assert m0 == m1 and np.array_equal(v0, v1) and np.array_equal(a0, a1) and np.array_equal(b0, b1), (yaw, k)
+
+
+def test_early_rebuild_equals_three_kernel_rebuild(orc, synth, monkeypatch):
+    """Default for handles with < 16 streams: the window of the next cell hash is counted by extra workgroups of the
+    finalising k_lm_solve launch (kept frames beside the solve, the new frame once the solve hands over the pose, into
+    the second table).  LIODOM_EARLY_REBUILD=0 restores k_window_insert after the solve on one table.  Poses, window
+    contents and correspondences must be bit-identical, on a 3-stream handle (every stream's appending workgroups wait
+    for their own solve) through the filling and the evicting phase of the window."""
+    H, W, R, epr, P, S, K = 16, 900, 6, 10, 4, 3, 11
+    cfg = synth.make_cfg(H, W, 0)
+    scans = [[synth.scan(cfg, s, k)[0] for k in range(K)] for s in range(S)]
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("LIODOM_EARLY_REBUILD", mode)
+        po, g = mk(orc, H, W, 0, R, epr, P, S=S)
+        g.alloc_resident(K)
+        for s in range(S):
+            for k in range(K):
+                g.upload_scan(s, k, scans[s][k])
+        out = []
+        for k in range(K):
+            poses, infos = g.process_resident(k, H * W, H, W, readback=True)
+            assert all(i.status == 0 for i in infos)
+            corr = [tuple(a.copy() for a in g.correspondences(1, stream=s)) for s in range(S)]
+            wins = [g.window(s) for s in range(S)]
+            out.append((poses.copy(), [tuple(i.matches) for i in infos], corr, wins))
+        res[mode] = out
+        g.close()
+    for k in range(K):
+        p0, m0, c0, w0 = res["0"][k]
+        p1, m1, c1, w1 = res["1"][k]
+        assert np.array_equal(p0.view(np.uint64), p1.view(np.uint64)), k
+        assert m0 == m1, k
+        for s in range(S):
+            assert all(np.array_equal(a, b) for a, b in zip(c0[s], c1[s])), (k, s)
+            assert w0[s][1] == w1[s][1] and np.array_equal(w0[s][0].view(np.uint32), w1[s][0].view(np.uint32)), (k, s)
