@@ -171,6 +171,15 @@ int liodom_process_resident(liodom_handle_t* h, int slot, int64_t n, int height,
  * then name that slot. */
 int liodom_process_resident_pipelined(liodom_handle_t* h, int slot, int next_slot, int64_t n, int height,
                                       int width, double* poses_out, liodom_step_info_t* infos_out);
+/* The consumer loop of the pipelined replay, in C: resident slots first_slot .. first_slot + count - 1 in order, every
+ * scan exactly as liodom_process_resident_pipelined (the extraction of scan k+1 is issued beside the odometry of scan k;
+ * the pose of scan k is read back before the odometry of scan k+1 is submitted — per-scan synchronous, like the
+ * LaserOdometer thread that publishes ~odom per scan, src/liodom_node.cc:89-91 / laser_odometry.cc:403-430).  `ahead`
+ * != 0 also issues the extraction of slot first_slot + count at the end (the next call must start there).
+ * poses_out: count * n_streams * 7 doubles; infos_out: count * n_streams records (either may be NULL: then the poses
+ * are only waited for). */
+int liodom_replay_resident(liodom_handle_t* h, int first_slot, int count, int ahead, int64_t n, int height, int width,
+                           double* poses_out, liodom_step_info_t* infos_out);
 int liodom_sync(liodom_handle_t* h);
 int liodom_get_pose_log(liodom_handle_t* h, int stream, int first, int count, double* poses_out,
                         liodom_step_info_t* infos_out);

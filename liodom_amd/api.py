@@ -172,6 +172,8 @@ def load():
     L.liodom_process_resident.restype = C.c_int
     L.liodom_process_resident.argtypes = [vp, C.c_int, C.c_int64, C.c_int, C.c_int, dp, C.POINTER(StepInfo)]
     L.liodom_process_resident_pipelined.restype = C.c_int
+    L.liodom_replay_resident.restype = C.c_int
+    L.liodom_replay_resident.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, dp, C.POINTER(StepInfo)]
     L.liodom_process_resident_pipelined.argtypes = [vp, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, dp, C.POINTER(StepInfo)]
     L.liodom_sync.restype = C.c_int
     L.liodom_sync.argtypes = [vp]
@@ -233,7 +235,7 @@ def load():
 EXPORTED_SYMBOLS = [
     "liodom_params_default", "liodom_config_default", "liodom_create", "liodom_destroy", "liodom_last_error",
     "liodom_extract_edges", "liodom_odometry_step", "liodom_process_scan", "liodom_set_received_map",
-    "liodom_alloc_resident", "liodom_upload_scan", "liodom_process_resident", "liodom_process_resident_pipelined", "liodom_sync", "liodom_get_pose_log",
+    "liodom_alloc_resident", "liodom_upload_scan", "liodom_process_resident", "liodom_process_resident_pipelined", "liodom_replay_resident", "liodom_sync", "liodom_get_pose_log",
     "liodom_reset", "liodom_get_edges", "liodom_get_window", "liodom_get_local_map", "liodom_get_correspondences", "liodom_get_curvature", "liodom_get_knn_queries",
     "liodom_set_profiling", "liodom_get_kernel_stats", "liodom_reset_kernel_stats", "liodom_device_info",
     "liodom_device_count", "liodom_device_pci_bus_id",
@@ -373,6 +375,15 @@ class Liodom:
             return poses, infos
         self._check(self.L.liodom_process_resident_pipelined(self.h, slot, next_slot, n, height, width, None, None))
         return None, None
+
+    def replay_resident(self, first_slot, count, n, height, width, ahead=False):
+        """The pipelined per-scan synchronous loop over resident slots first_slot .. first_slot + count - 1, in C
+        (liodom_replay_resident).  Returns poses [count, n_streams, 7] and the step infos [count * n_streams]."""
+        S = self.config.n_streams
+        poses = np.zeros((count, S, 7))
+        infos = (StepInfo * (count * S))()
+        self._check(self.L.liodom_replay_resident(self.h, first_slot, count, 1 if ahead else 0, n, height, width, _dp(poses), infos))
+        return poses, infos
 
     def sync(self):
         self._check(self.L.liodom_sync(self.h))

@@ -875,11 +875,36 @@ int liodom_process_resident(liodom_handle_t* h, int slot, int64_t n, int height,
   return liodom_process_resident_pipelined(h, slot, -1, n, height, width, poses_out, infos_out);
 }
 
+// One scan of the pipelined replay (both sides locked by the caller).  wait: read the poses back before returning.
+static int replay_one(liodom_handle_t* h, int slot, int next_slot, int64_t n, int height, int width, bool wait,
+                      double* poses_out, liodom_step_info_t* infos_out);
+
 int liodom_process_resident_pipelined(liodom_handle_t* h, int slot, int next_slot, int64_t n, int height,
                                       int width, double* poses_out, liodom_step_info_t* infos_out) {
   int rc0 = enter(h);
   if (rc0) return rc0;
   SideLocks lk(h, true, true);
+  return replay_one(h, slot, next_slot, n, height, width, poses_out != nullptr || infos_out != nullptr, poses_out, infos_out);
+}
+
+int liodom_replay_resident(liodom_handle_t* h, int first_slot, int count, int ahead, int64_t n, int height, int width,
+                           double* poses_out, liodom_step_info_t* infos_out) {
+  int rc0 = enter(h);
+  if (rc0) return rc0;
+  if (count < 0 || first_slot < 0) { g_last_error = "bad resident range"; return LIODOM_ERR_INVALID_ARG; }
+  SideLocks lk(h, true, true);
+  for (int i = 0; i < count; i++) {
+    const int slot = first_slot + i;
+    const int next = (i + 1 < count || ahead) ? slot + 1 : -1;
+    const int rc = replay_one(h, slot, next, n, height, width, true, poses_out ? poses_out + (size_t)i * h->S * 7 : nullptr,
+                              infos_out ? infos_out + (size_t)i * h->S : nullptr);
+    if (rc) return rc;
+  }
+  return LIODOM_OK;
+}
+
+static int replay_one(liodom_handle_t* h, int slot, int next_slot, int64_t n, int height, int width, bool wait,
+                      double* poses_out, liodom_step_info_t* infos_out) {
   if (!h->resident || slot < 0 || slot >= h->n_slots || next_slot >= h->n_slots || n < 0 || n > h->v.max_points) {
     g_last_error = "bad resident slot"; return LIODOM_ERR_INVALID_ARG;
   }
@@ -902,7 +927,7 @@ int liodom_process_resident_pipelined(liodom_handle_t* h, int slot, int next_slo
     if (rc) return rc;
     h->pf_slot = next_slot;
   }
-  if (poses_out != nullptr || infos_out != nullptr) return wait_pose(h, 0, h->S, poses_out, infos_out);
+  if (wait) return wait_pose(h, 0, h->S, poses_out, infos_out);
   return LIODOM_OK;
 }
 

@@ -652,3 +652,24 @@ def test_early_rebuild_equals_three_kernel_rebuild(orc, synth, monkeypatch):
         for s in range(S):
             assert all(np.array_equal(a, b) for a, b in zip(c0[s], c1[s])), (k, s)
             assert w0[s][1] == w1[s][1] and np.array_equal(w0[s][0].view(np.uint32), w1[s][0].view(np.uint32)), (k, s)
+
+
+def test_replay_resident_loop_equals_per_call_replay(orc, synth):
+    # liodom_replay_resident: the consumer loop in C gives exactly what one liodom_process_resident_pipelined call per scan gives
+    H, W, R, epr, P, K = 16, 900, 6, 10, 5, 10
+    cfg = synth.make_cfg(H, W, 0)
+    po, g = mk(orc, H, W, 0, R, epr, P)
+    g.alloc_resident(K)
+    for k in range(K):
+        g.upload_scan(0, k, synth.scan(cfg, 2, k)[0])
+    ref = []
+    for k in range(K):
+        poses, _ = g.process_resident(k, H * W, H, W, readback=True, next_slot=(k + 1 if k + 1 < K else -1))
+        ref.append(poses.copy())
+    g.reset()
+    p1, i1 = g.replay_resident(0, 4, H * W, H, W, ahead=True)       # two calls: the second starts on the slot issued ahead
+    p2, i2 = g.replay_resident(4, K - 4, H * W, H, W)
+    got = np.concatenate([p1, p2])
+    assert np.array_equal(got.view(np.uint64), np.array(ref).view(np.uint64))
+    assert [i.scan_index for i in list(i1) + list(i2)] == list(range(K))
+    g.close()
