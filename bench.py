@@ -198,6 +198,11 @@ def main():
         # pipelined: the extraction of scan k+1 is issued on a second HIP stream while scan k's
         # odometry runs (the reference's own two-thread pipeline); never across the region's ends
         last = first + count - 1
+        if readback and pipelined:
+            # the consumer loop in C (liodom_replay_resident): the same per-scan synchronous discipline — pose k is read
+            # back before the odometry of scan k+1 is submitted — without a Python call per scan
+            g.replay_resident(first, count, N, H, W)
+            return
         for k in range(first, first + count):
             g.process_resident(k, N, H, W, readback=readback, next_slot=(k + 1 if (pipelined and k < last) else -1))
 
@@ -262,7 +267,8 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl["name"], "streams_per_gpu": 1, "points_per_scan": N,
                        "mode": "per-scan synchronous (pose read back every scan), scans resident in HBM, "
-                               "extraction of scan k+1 overlapped with odometry of scan k on a second HIP stream",
+                               "extraction of scan k+1 overlapped with odometry of scan k on a second HIP stream; "
+                               "consumer loop in C (liodom_replay_resident)",
                        "prefill_scans": F,
                        "parallelism": "replicas only" if world > 1 else "single stream",
                        "mean_edges": round(meanE, 1), "mean_map_points": round(meanM, 1), "mean_matches": round(meanC, 1),

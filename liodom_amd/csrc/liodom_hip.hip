@@ -233,19 +233,22 @@ int enqueue_odometry(liodom_handle* h, int eb, int s0, int count) {
     ProfScope ps(h, KID_OTHER);
     hipLaunchKernelGGL(k_imu_override, dim3(cdiv(count, 64)), dim3(64), 0, h->stream, v, s0, count);
   }
-  // early rebuild: the finalising k_lm_solve launch carries extra workgroups that count the frames that stay in the
-  // window into the second cell hash while the solve runs; k_window_insert then adds the new frame only
+  // early rebuild ("streamed rebuild", liodom_kernels.h): the four launches of a scan carry extra workgroups that build
+  // the next scan's cell hash in the second table; nothing follows the finalising solve
   const int map_blocks = cdiv(h->v.map_cap, 256);
   const bool early = v.early_rebuild != 0;
+  const int nC = cdiv(h->v.edge_cap * std::max(1, h->P - 1), kLmThreads), nP = cdiv(h->v.edge_cap, kLmThreads);
   for (int it = 0; it < 2; it++) {
     {
       ProfScope ps(h, KID_KNN);
-      if (knn_small) hipLaunchKernelGGL(k_knn<128>, dim3(knn_blocks, count), dim3(128), 0, h->stream, v, s0, it, eb);
-      else hipLaunchKernelGGL(k_knn<256>, dim3(knn_blocks, count), dim3(256), 0, h->stream, v, s0, it, eb);
+      const int kx = knn_blocks + ((early && it == 1) ? kRebuildAuxBlocks : 0);     // it 1: + ALLOC
+      if (knn_small) hipLaunchKernelGGL(k_knn<128>, dim3(kx, count), dim3(128), 0, h->stream, v, s0, it, eb);
+      else hipLaunchKernelGGL(k_knn<256>, dim3(kx, count), dim3(256), 0, h->stream, v, s0, it, eb);
     }
     {
       ProfScope ps(h, KID_LM);
-      const int extra = (early && it == 1) ? cdiv(h->v.edge_cap * std::max(1, h->P - 1), kLmThreads) : 0;   // (>= the new frame's share)
+      // it 0: + COUNT, PAD; it 1: + APPEND, CLEAR, SCATTER
+      const int extra = !early ? 0 : (it == 0 ? nC + nP : nP + kRebuildAuxBlocks + nC);
       hipLaunchKernelGGL(k_lm_solve, dim3(h->v.lm_groups + extra, count), dim3(kLmThreads), lm_lds_bytes(h->v.edge_cap), h->stream, v, s0, it, eb);
     }
   }
@@ -264,11 +267,13 @@ int enqueue_odometry(liodom_handle* h, int eb, int s0, int count) {
       if (rc) return rc;
     }
   }
-  if (h->lds_hash_build) {
+  if (early) {
+    // (nothing: the next cell hash is complete when the finalising solve launch ends)
+  } else if (h->lds_hash_build) {
     ProfScope ps(h, KID_HASH_BUILD);        // window append + LDS-built cell hash, one workgroup per stream
     hipLaunchKernelGGL(k_hash_build, dim3(count), dim3(kBuildThreads), hash_build_lds_bytes(), h->stream, v, s0, eb);
   } else {
-    if (!early) {   // (early rebuild: the solving workgroup appended and counted the new frame itself)
+    {
       ProfScope ps(h, KID_WINDOW_INSERT);   // window append + cell hash in global memory, map_blocks workgroups per stream
       hipLaunchKernelGGL(k_window_insert, dim3(map_blocks, count), dim3(256), 0, h->stream, v, s0, eb);
     }
@@ -369,7 +374,7 @@ int reset_state(liodom_handle* h) {
   std::vector<StreamState> init((size_t)h->S);
   for (auto& st : init) {
     std::memset(&st, 0, sizeof(st));
-    iso_identity(st.odom); iso_identity(st.prev_odom); iso_identity(st.final_odom);
+    iso_identity(st.odom); iso_identity(st.prev_odom); iso_identity(st.final_odom); iso_identity(st.pred_odom);
     st.param_q[3] = 1.0;
     st.table_mask = (uint32_t)h->v.table_size - 1u;
   }
@@ -507,7 +512,7 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   v.recv_cap = v.mapping ? (config->recv_capacity > 0 ? config->recv_capacity : 262144) : 0;
   v.map_cap = v.edge_cap * h->P + v.recv_cap;
   int ts = 1024;
-  while (ts < 2 * v.map_cap) ts <<= 1;
+  while (ts < 2 * (v.map_cap + (v.early_rebuild ? 8 * v.edge_cap : 0))) ts <<= 1;    // (early rebuild: cells that only the padding touches)
   v.table_size = ts;
   v.pose_log_cap = std::max(1, config->pose_log_capacity);
   v.debug = config->debug_buffers & 1;
@@ -547,11 +552,17 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   ALLOC(v.cells, ntab * S * v.table_size, 0);
   ALLOC(v.pt_rank, S * v.map_cap, 0);
   ALLOC(v.cell_bits, ntab * S * (size_t)(v.table_size / 32), 0);
-  ALLOC(v.used_cells, ntab * S * v.map_cap, 0);
+  v.used_cap = v.early_rebuild ? v.map_cap + 8 * v.edge_cap : v.map_cap;
+  ALLOC(v.used_cells, ntab * S * (size_t)v.used_cap, 0);
   ALLOC(v.pt_cell, S * v.map_cap, 0xFF);
   if (v.recv_cap) ALLOC(v.recv_pts, S * v.recv_cap, 0);
   ALLOC(v.imu_q, S * 4, 0);
-  ALLOC(v.sorted_pts, S * v.map_cap, 0);
+  v.ovf_base = v.early_rebuild ? v.map_cap + 8 * v.edge_cap : v.map_cap;
+  v.sorted_cap = v.early_rebuild ? v.ovf_base + v.edge_cap : v.map_cap;
+  ALLOC(v.sorted_pts, (v.early_rebuild ? 2 : 1) * S * (size_t)v.sorted_cap, 0);
+  if (v.early_rebuild) ALLOC(v.cell_pad, 2 * S * (size_t)v.table_size, 0); else v.cell_pad = nullptr;
+  v.rebuild_delta = 0.25f;
+  if (const char* e = std::getenv("LIODOM_REBUILD_DELTA")) { const float d = (float)std::atof(e); if (d > 0.0f && d <= 0.45f) v.rebuild_delta = d; }
   if (v.filter_local_map) {
     ALLOC(v.vox_cells, S * v.table_size, 0);
     ALLOC(v.vox_fill, S * v.table_size, 0);

@@ -72,6 +72,8 @@ struct StreamState {
   int32_t vox_minb[3];    // PCL VoxelGrid min_b_ and div_b_
   int32_t vox_divb[3];
   int32_t n_recv;         // points of the received ~map cloud (mapping mode, SharedData::setLocalMap)
+  int32_t n_ovf[2];       // early_rebuild: new-frame points kept in the overflow list of table 0 / 1 (sorted_pts[ovf_base ...])
+  double pred_odom[12];   // early_rebuild: the prediction the scan started from (st.odom moves on with the solves)
   liodom_step_info_t info;
 };
 
@@ -166,6 +168,11 @@ struct DevView {
   unsigned char* corr_mask; // [S][2][knn_blocks] bit q: query q of that k_knn workgroup has an accepted correspondence
   int knn_partials;         // k_knn also evaluates every accepted block at the solve's start pose and leaves per-workgroup sums (handles with < 16 streams)
   int knn_queries;          // queries per k_knn workgroup (8, or 4 for handles with >= 16 streams)
+  unsigned int* cell_pad;   // [2 S][table_size] early_rebuild: room reserved in the cell for points of the new frame; after the allocation: end of the cell's range
+  int used_cap;             // used_cells entries per table (map_cap; early_rebuild: + 8 edge_cap for cells only the padding touches)
+  int sorted_cap;           // sorted_pts entries per table (early_rebuild: map_cap + 8 edge_cap of padding + edge_cap of overflow list; else map_cap)
+  int ovf_base;             // first entry of the overflow list inside a table's sorted_pts
+  float rebuild_delta;      // early_rebuild: a new-frame point may move this far (per axis) between the prediction and the solved pose and still land in a padded cell
   unsigned long long* pose_xch;   // [S][32] early_rebuild: solved pose handed to the workgroups that append the new frame (tagged 8-byte granules)
   int early_rebuild;        // the frames that stay in the window are counted into the next cell hash beside the scan's finalising solve
                             // (k_hash_clear + k_window_count_old on a side stream); k_window_insert then adds the new frame only
@@ -1041,6 +1048,8 @@ __device__ __forceinline__ void top5_clear(Top5& t) {
 // 31.5 -> 29.7 us on one.  Later (cheaper insertion, cell-major lists) 128 threads beat 256 on many
 // streams (scan step 686 vs 707 us on 64) and lose slightly on one (129.2 vs 127.6 us): two instances,
 // chosen by the host from the stream count.
+__device__ void rebuild_alloc(const DevView& v, int s, StreamState& st, int block, int nblocks);
+
 template <int kKnnThreads>
 __global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int outer_it, int eb) {
   constexpr int kKnnQueries = kKnnThreads / kKnnGroup;
@@ -1054,6 +1063,12 @@ __global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int oute
   xcd_remap(bxi, byi);
   const int s = s0 + byi;
   StreamState& st = v.state[s];
+  if (v.early_rebuild) {
+    if (bxi >= v.knn_blocks) { if (outer_it == 1) rebuild_alloc(v, s, st, bxi - v.knn_blocks, (int)gridDim.x - v.knn_blocks); return; }
+    // streamed rebuild, bookkeeping before the first builders start (next launch): the frame count the build refers to
+    // (the finalising solve advances it beside them) and an empty list of occupied slots for the table being built
+    if (outer_it == 0 && bxi == 0 && threadIdx.x == 0) { st.reb_frame_count = st.frame_count; st.n_used_tab[(st.frame_count + 1) & 1] = 0; }
+  }
   if (!st.initialized) return;                     // uniform over the workgroup
   const int E = st.n_edges_buf[eb];
   if ((int)(bxi * kKnnQueries) >= E) {      // no query here: an empty validity byte for the solve's compaction
@@ -1109,7 +1124,7 @@ __global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int oute
       const float ez = qz < lz ? lz - qz : (qz > lz + cs ? qz - (lz + cs) : 0.0f);
       return (ex * ex + ey * ey + ez * ez) * (1.0f - 1e-5f);
     };
-    const float4* sp = v.sorted_pts + (size_t)s * v.map_cap;
+    const float4* sp = v.sorted_pts + (size_t)stab * v.sorted_cap;
     Top5 t, g;
     top5_clear(t);
     // ---- second pass of a scan: re-rank what the first pass kept.  The first solve moves the pose by millimetres, so
@@ -1240,6 +1255,16 @@ __global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int oute
           }
           const bool left = opend[0] || opend[1] || opend[2] || opend[3];
           if (round == 0 && streamed && ((__ballot(left) >> half_shift) & 0xFFFFFFFFull)) refresh_bound();
+        }
+      }
+      if (v.early_rebuild) {
+        // streamed rebuild: points of the newest frame that moved out of their padded cells wait in an overflow list
+        // (empty unless the solve corrected the prediction by more than rebuild_delta); they are candidates of every query
+        const int novf = st.n_ovf[LD_TAB_PARITY(v, st.frame_count)];
+        for (int i = hl; i < novf; i += kKnnGroup) {
+          const float4 m = sp[v.ovf_base + i];
+          const float d = sqdist_f(qx, qy, qz, m.x, m.y, m.z);
+          if (d <= top5_dist(t.k4)) top5_insert(t, d, __float_as_int(m.w), v.ovf_base + i);
         }
       }
       if (outer_it == 0 && v.knn_save_pos) {
@@ -1510,7 +1535,7 @@ __device__ __forceinline__ void lm_eval(const DevView& v, int s, int eb, int c_l
 // the last kNN pass of the scan has completed before the finalising k_lm_solve launch starts.
 __device__ void hash_clear_used(const DevView& v, int s /*table: stream + parity * n_streams*/, int nup, int t, int nt) {
   CellSlot empty; empty.key = kEmptyKey; empty.start = 0; empty.cnt = 0;
-  const int* used = v.used_cells + (size_t)s * v.map_cap;
+  const int* used = v.used_cells + (size_t)s * v.used_cap;
   for (int u0 = t; u0 < nup; u0 += 8 * nt) {   // 8 index loads in flight per thread
     int hh[8];
 #pragma unroll
@@ -1521,6 +1546,7 @@ __device__ void hash_clear_used(const DevView& v, int s /*table: stream + parity
         const size_t ti = (size_t)s * v.table_size + hh[k];
         v.cells[ti] = empty;
         v.cell_bits[ti >> 5] = 0u;   // every set bit of that word belongs to a slot of this list
+        if (v.cell_pad) v.cell_pad[ti] = 0u;
       }
     }
   }
@@ -1585,7 +1611,7 @@ __device__ void finalize_scan(const DevView& v, int s, StreamState& st, int* sh_
     iso_inverse(st.prev_odom, inv);
     iso_mul(inv, st.final_odom, rel);
     iso_mul(st.final_odom, rel, pred);
-    for (int i = 0; i < 12; i++) { st.prev_odom[i] = st.final_odom[i]; st.odom[i] = pred[i]; }
+    for (int i = 0; i < 12; i++) { st.prev_odom[i] = st.final_odom[i]; st.odom[i] = pred[i]; st.pred_odom[i] = pred[i]; }
     quat_from_pose(pred, v.rotation_mode, st.param_q);               // :186-190 q_curr(odom_.rotation())
     st.param_t[0] = pred[3]; st.param_t[1] = pred[7]; st.param_t[2] = pred[11];   // :192-195
     wn[new_slot] = n_edges;
@@ -1675,12 +1701,12 @@ __global__ void k_imu_override(DevView v, int s0, int count) {
   for (int k = 0; k < 4; k++) q[k] = v.imu_q[(size_t)(s0 + i) * 4 + k];
   imu_override(odom, q, l2b, v.rotation_mode, out);
 #pragma unroll
-  for (int k = 0; k < 12; k++) st.odom[k] = out[k];
+  for (int k = 0; k < 12; k++) { st.odom[k] = out[k]; st.pred_odom[k] = out[k]; }
   quat_from_pose(out, v.rotation_mode, st.param_q);                                // :186-190
   st.param_t[0] = out[3]; st.param_t[1] = out[7]; st.param_t[2] = out[11];         // :192-195
 }
 
-__device__ void count_window_frames(const DevView& v, int s, StreamState& st, int eb, int block, int* sbase, int* sslot);
+__device__ void rebuild_beside_solve(const DevView& v, int s, StreamState& st, int eb, int outer_it, int block, int* sbase, int* sslot);
 
 __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int outer_it, int eb) {
   __shared__ double sh_pose[12];
@@ -1693,10 +1719,9 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
   StreamState& st = v.state[s];
   __shared__ int sh_cnt[kMaxFrames + 1];
   if (g >= G) {
-    // early_rebuild, finalising launch: the workgroups behind the solve count the window (kept frames right away, the new
-    // frame as soon as the solve hands over the pose) into the next cell hash
+    // early_rebuild: the workgroups behind the solve build the next cell hash (see "streamed rebuild" below)
     __shared__ int sh_slot[kMaxFrames];
-    count_window_frames(v, s, st, eb, g - G, sh_cnt, sh_slot);
+    rebuild_beside_solve(v, s, st, eb, outer_it, g - G, sh_cnt, sh_slot);
     return;
   }
   __shared__ double sh_loc[kAccN];
@@ -1706,11 +1731,6 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
   const int tid = threadIdx.x;
   const bool prep = tid < kLmCtl;               // waves 0..6: compaction + register cache while the controller lane works
   if (outer_it == 0 && tid == 0 && g == 0) {     // per-scan diagnostics (matches are counted by k_knn)
-    if (v.early_rebuild) {
-      // the next build goes into the other table (cleared by the previous scan's k_hash_scatter): start its list of occupied
-      // slots; frame_count is snapshotted because the finalising solve advances it beside the counting workgroups
-      st.reb_frame_count = st.frame_count; st.n_used_tab[(st.frame_count + 1) & 1] = 0;
-    }
     st.info.n_edges = st.n_edges_buf[eb];
     st.info.map_points = st.n_search;
     for (int k = 0; k < 2; k++) {
@@ -1855,6 +1875,7 @@ __global__ __launch_bounds__(256) void k_init_cells(DevView v) {
   CellSlot empty; empty.key = kEmptyKey; empty.start = 0; empty.cnt = 0;
   v.cells[i] = empty;
   if ((i & 31) == 0) v.cell_bits[i >> 5] = 0u;
+  if (v.cell_pad) v.cell_pad[i] = 0u;
   if (v.vox_cells && i < per) { v.vox_cells[i] = empty; v.vox_fill[i] = 0; }
 }
 
@@ -1895,7 +1916,7 @@ __device__ __forceinline__ void hash_count_point(const DevView& v, int s, int pa
       int base = 0;
       if (lane == (int)__builtin_ctzll(cm)) base = atomicAdd(&st.n_used_tab[par], (int)__popcll(cm));
       base = __shfl(base, (int)__builtin_ctzll(cm));
-      if (created) v.used_cells[(size_t)sp * v.map_cap + base + (int)__popcll(cm & ((1ull << lane) - 1ull))] = (int)h;
+      if (created) v.used_cells[(size_t)sp * v.used_cap + base + (int)__popcll(cm & ((1ull << lane) - 1ull))] = (int)h;
     }
   }
   if (!live) return;
@@ -1907,8 +1928,7 @@ __device__ __forceinline__ void hash_count_point(const DevView& v, int s, int pa
 
 // The new frame's edges (dense edge buffer eb, sensor frame) are transformed with the solved pose
 // (laser_odometry.cc:231-232), then stored in the window slot (:235).  Every point of the window is counted
-// into its 1 m cell (hash_count_point).  With early_rebuild the frames that stay were counted by count_kept_frames
-// beside the finalising solve and only the new frame is left (eb < 0 — rebuild without a new frame — counts everything).
+// into its 1 m cell (hash_count_point).  (Not launched by handles with early_rebuild: see "streamed rebuild".)
 __global__ __launch_bounds__(256) void k_window_insert(DevView v, int s0, int eb) {
   __shared__ int sbase[kMaxFrames + 1];
   __shared__ int sslot[kMaxFrames];
@@ -1917,8 +1937,7 @@ __global__ __launch_bounds__(256) void k_window_insert(DevView v, int s0, int eb
   const int M = st.n_map;
   const int MT = M + (v.mapping ? st.n_recv : 0);      // window ++ received map (:310-314)
   const int P = v.prev_frames, nf = st.n_frames;
-  const bool new_only = v.early_rebuild && eb >= 0;
-  const int m_first = new_only ? v.win_base[(size_t)s * (P + 1) + (nf > 0 ? nf - 1 : 0)] : 0;
+  const int m_first = 0;
   if (blockIdx.x == 0 && threadIdx.x == 0 && !filter_active(v, st)) { st.n_search = MT; st.n_filt = 0; }
   if (m_first + (int)(blockIdx.x * 256) >= MT) return;
   for (int j = threadIdx.x; j <= nf; j += 256) sbase[j] = v.win_base[(size_t)s * (P + 1) + j];
@@ -1954,59 +1973,193 @@ __global__ __launch_bounds__(256) void k_window_insert(DevView v, int s0, int eb
   hash_count_point(v, s, LD_TAB_PARITY(v, st.frame_count), st, m, pt, live);
 }
 
-// early_rebuild: the window of the next build is counted into the second cell hash by extra workgroups of the
-// finalising k_lm_solve launch, beside the solve.  The frames that stay (all but the oldest once the window is full,
-// LocalMapManager::addPointCloud :34-60) are counted right away under the indices they will have after the append;
-// the first workgroups then wait for the solved pose (publish_final_pose), transform the scan's edges with it
-// (laser_odometry.cc:231-232), store them in the new frame's window slot (:235) and count them too.  Uses only state
-// the solve does not write: the frame_count snapshot, the sizes of the kept slots, the edge count.
-// sbase / sslot: LDS, kMaxFrames + 1 ints each.  (A waiting workgroup depends only on the solving workgroup of its
-// own stream, which has a lower block index and so was dispatched before it.)
-__device__ void count_window_frames(const DevView& v, int s, StreamState& st, int eb, int block, int* sbase, int* sslot) {
-  __shared__ double sh_T[12];
-  __shared__ int sh_hand;
+// =============================================================================================
+// Streamed rebuild (early_rebuild; handles with < 16 streams, no mapping / filtered map).
+// The cell hash of the NEXT scan is built while the current scan is solved, by extra workgroups riding on the four
+// launches of the scan; nothing is left between the finalising solve and the next scan's first kNN pass.  Two tables
+// per stream: scan F (frame_count = F when it starts) searches table F & 1 and builds table (F + 1) & 1.
+//   k_knn      it 0   bookkeeping (frame_count snapshot, empty slot list for the table being built)
+//   k_lm_solve it 0   COUNT the frames that stay in the window (all but the oldest once it is full,
+//                     LocalMapManager::addPointCloud :34-60) into their cells, under the window indices they will have
+//                     after the append; PAD: every edge of the new scan, transformed with the PREDICTED pose, reserves
+//                     one place in each cell it can reach if the solve moves it by less than rebuild_delta per axis
+//   k_knn      it 1   ALLOC: start of every occupied cell; room = counted + padded
+//   k_lm_solve it 1   SCATTER the kept points to start + rank; APPEND: the first workgroups wait for the solved pose
+//                     (publish_final_pose), transform the scan's edges (laser_odometry.cc:231-232), store them in the new
+//                     frame's window slot (:235) and put every point into its cell at start + count++ — the place its
+//                     padding reserved.  A point that moved further than rebuild_delta (or whose cell is missing) goes
+//                     to the table's overflow list instead, which every kNN query of the next scan also scans: exact in
+//                     every case, and empty unless the solve corrected the prediction by decimetres.
+//                     CLEAR the table this scan searched (dead since the second kNN pass) for the scan after the next.
+// Builders use only state the solves do not write: the frame_count snapshot, the sizes of the kept slots, the edge count,
+// the saved prediction.  (A waiting workgroup depends only on the solving workgroup of its own stream, which has a
+// lower block index and so was dispatched before it.)
+// =============================================================================================
+constexpr int kRebuildAuxBlocks = 8;      // workgroups for ALLOC (k_knn) and for CLEAR (k_lm_solve)
+
+// Prefix table of the kept frames (chronological): sbase[0 .. nk], sslot[0 .. nk).  Returns nk; whole workgroup.
+__device__ __forceinline__ int kept_frames_table(const DevView& v, int s, const StreamState& st, int* sbase, int* sslot) {
   const int P = v.prev_frames, fc = st.reb_frame_count;
   const int nf_old = fc < P ? fc : P;
   const int drop = nf_old == P ? 1 : 0;
-  const int nk = nf_old - drop;                       // kept frames, chronological
+  const int nk = nf_old - drop;
   const int tid = threadIdx.x, nt = blockDim.x;
-  const int par = (fc + 1) & 1;
+  for (int j = tid; j < nk; j += nt) {
+    const int sl = (fc - nf_old + drop + j) % P;
+    sslot[j] = sl;
+    sbase[j + 1] = v.win_n[(size_t)s * P + sl];
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int j = 0; j < nk; j++) { const int c = sbase[j + 1]; sbase[j] = acc; acc += c; }
+    sbase[nk] = acc;
+  }
+  __syncthreads();
+  return nk;
+}
+__device__ __forceinline__ float4 kept_point(const DevView& v, int s, int m, int nk, const int* sbase, const int* sslot) {
+  int lo = 0, hi = nk;
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (sbase[mid] <= m) lo = mid; else hi = mid; }
+  return v.win_pts[((size_t)s * v.prev_frames + sslot[lo]) * v.edge_cap + (m - sbase[lo])];
+}
+__device__ __forceinline__ bool point_finite(const float4& pt) {
+  return ld_isfinite((double)pt.x) && ld_isfinite((double)pt.y) && ld_isfinite((double)pt.z) &&
+         fabsf(pt.x) < 1.0e9f && fabsf(pt.y) < 1.0e9f && fabsf(pt.z) < 1.0e9f;
+}
+// the scan's edge idx at the pose the scan started from (the first frame enters the window untransformed, :123)
+__device__ __forceinline__ float4 predicted_point(const StreamState& st, const float4& e) {
+  if (!st.initialized) return e;
+  double T[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) T[i] = st.pred_odom[i];
+  float4 q;
+  transform_point(T, e.x, e.y, e.z, &q.x, &q.y, &q.z);
+  q.w = e.w;
+  return q;
+}
+
+// COUNT (block < nC) and PAD (the nP blocks behind them)
+__device__ void rebuild_count_and_pad(const DevView& v, int s, StreamState& st, int eb, int block, int* sbase, int* sslot) {
+  const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63;
+  const int par = (st.reb_frame_count + 1) & 1;
+  const int nC = (v.edge_cap * (v.prev_frames > 1 ? v.prev_frames - 1 : 1) + nt - 1) / nt;
+  if (block < nC) {
+    const int nk = kept_frames_table(v, s, st, sbase, sslot);
+    const int Mk = nk > 0 ? sbase[nk] : 0;
+    if (block * nt >= Mk) return;
+    const int m = block * nt + tid;
+    const bool live = m < Mk;
+    float4 pt = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) pt = kept_point(v, s, m, nk, sbase, sslot);
+    hash_count_point(v, s, par, st, m, pt, live);
+    return;
+  }
   const int n_new = st.n_edges_buf[eb];
-  const bool appender = block * nt < n_new;           // this workgroup also handles a share of the new frame
-  float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (appender) {                                     // (loaded before the wait)
-    const int idx = block * nt + tid;
-    e = v.edges[((size_t)eb * v.n_streams + s) * v.edge_cap + (idx < n_new ? idx : 0)];
-  }
-  int Mk = 0;
-  if (nk > 0) {
-    for (int j = tid; j < nk; j += nt) {
-      const int sl = (fc - nf_old + drop + j) % P;
-      sslot[j] = sl;
-      sbase[j + 1] = v.win_n[(size_t)s * P + sl];
-    }
-    __syncthreads();
-    if (tid == 0) {
-      int acc = 0;
-      for (int j = 0; j < nk; j++) { const int c = sbase[j + 1]; sbase[j] = acc; acc += c; }
-      sbase[nk] = acc;
-    }
-    __syncthreads();
-    Mk = sbase[nk];
-    if (block * nt < Mk) {
-      const int m = block * nt + tid;
-      const bool live = m < Mk;
-      float4 pt = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (live) {
-        int lo = 0, hi = nk;
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (sbase[mid] <= m) lo = mid; else hi = mid; }
-        pt = v.win_pts[((size_t)s * P + sslot[lo]) * v.edge_cap + (m - sbase[lo])];
+  const int idx = (block - nC) * nt + tid;
+  if ((block - nC) * nt >= n_new) return;
+  const bool live = idx < n_new;
+  const float4 q = predicted_point(st, v.edges[((size_t)eb * v.n_streams + s) * v.edge_cap + (live ? idx : 0)]);
+  const bool fin = live && point_finite(q);
+  const float d = v.rebuild_delta;
+  const int lx = (int)floorf((q.x - d) * kCellInv), hx = (int)floorf((q.x + d) * kCellInv);
+  const int ly = (int)floorf((q.y - d) * kCellInv), hy = (int)floorf((q.y + d) * kCellInv);
+  const int lz = (int)floorf((q.z - d) * kCellInv), hz = (int)floorf((q.z + d) * kCellInv);
+  const int sp = s + par * v.n_streams;
+  const unsigned int tmask = (unsigned int)v.table_size - 1u;
+  CellSlot* cells = v.cells + (size_t)sp * v.table_size;
+#pragma unroll 1
+  for (int c = 0; c < 8; c++) {        // rebuild_delta < half a cell: at most two cells per axis
+    const int cx = (c & 1) ? hx : lx, cy = (c & 2) ? hy : ly, cz = (c & 4) ? hz : lz;
+    const bool act = fin && !((c & 1) && hx == lx) && !((c & 2) && hy == ly) && !((c & 4) && hz == lz);
+    unsigned int h = 0;
+    bool created = false, found = false;
+    if (act) {
+      const unsigned long long key = pack_cell(cx, cy, cz);
+      h = hash_cell(key, tmask);
+      for (int probe = 0; probe < v.table_size; probe++) {
+        const unsigned long long prev = atomicCAS(&cells[h].key, kEmptyKey, key);
+        if (prev == kEmptyKey) { atomicOr(&v.cell_bits[((size_t)sp * v.table_size + h) >> 5], 1u << (h & 31)); created = found = true; break; }
+        if (prev == key) { found = true; break; }
+        h = (h + 1) & tmask;
       }
-      hash_count_point(v, s, par, st, m, pt, live);
+      if (found) atomicAdd(&v.cell_pad[(size_t)sp * v.table_size + h], 1u);
+      else atomicOr(&st.status, LIODOM_STATUS_HASH_FULL);
+    }
+    const unsigned long long cm = __ballot(created);   // list of occupied slots: one atomic per wave
+    if (cm) {
+      int base = 0;
+      if (lane == (int)__builtin_ctzll(cm)) base = atomicAdd(&st.n_used_tab[par], (int)__popcll(cm));
+      base = __shfl(base, (int)__builtin_ctzll(cm));
+      if (created) v.used_cells[(size_t)sp * v.used_cap + base + (int)__popcll(cm & ((1ull << lane) - 1ull))] = (int)h;
     }
   }
-  if (!appender) return;
-  // ---- the new frame ----
+}
+
+// ALLOC, by the extra workgroups of the scan's second k_knn launch: start offsets of the occupied cells (any order:
+// only contiguity per cell matters), room = points counted + places padded; cell_pad becomes the end of the range.
+__device__ void rebuild_alloc(const DevView& v, int s, StreamState& st, int block, int nblocks) {
+  const int par = (st.reb_frame_count + 1) & 1, sp = s + par * v.n_streams;
+  const int nu = st.n_used_tab[par];
+  const int nt = blockDim.x;
+  for (int u0 = block * nt; u0 < nu; u0 += nblocks * nt) {
+    const int u = u0 + (int)threadIdx.x;
+    size_t ti = 0;
+    int room = 0;
+    if (u < nu) {
+      ti = (size_t)sp * v.table_size + v.used_cells[(size_t)sp * v.used_cap + u];
+      room = (int)v.cells[ti].cnt + (int)v.cell_pad[ti];
+    }
+    const int incl = wave_incl_scan_i32(room);
+    const int total = readlane_i32(incl, 63);
+    int base = 0;
+    if ((threadIdx.x & 63) == 0 && total > 0) base = atomicAdd(&st.cursor, total);
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (u < nu) {
+      const int start = base + incl - room;
+      v.cells[ti].start = (unsigned int)start;
+      v.cell_pad[ti] = (unsigned int)(start + room);
+    }
+  }
+}
+
+// SCATTER / APPEND / CLEAR, beside the finalising solve
+__device__ void rebuild_finish(const DevView& v, int s, StreamState& st, int eb, int block, int* sbase, int* sslot) {
+  __shared__ double sh_T[12];
+  __shared__ int sh_hand;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int P = v.prev_frames, fc = st.reb_frame_count;
+  const int par = (fc + 1) & 1, sp = s + par * v.n_streams;
+  const int nP = (v.edge_cap + nt - 1) / nt;
+  float4* sorted = v.sorted_pts + (size_t)sp * v.sorted_cap;
+  CellSlot* cells = v.cells + (size_t)sp * v.table_size;
+  if (block >= nP && block < nP + kRebuildAuxBlocks) {
+    // CLEAR: the table this scan searched, its padding and its overflow list
+    const int dead = s + (1 - par) * v.n_streams;
+    hash_clear_used(v, dead, st.n_used_tab[1 - par], (block - nP) * nt + tid, kRebuildAuxBlocks * nt);
+    if (block == nP && tid == 0) st.n_ovf[1 - par] = 0;
+    return;
+  }
+  const int nk = kept_frames_table(v, s, st, sbase, sslot);
+  const int Mk = nk > 0 ? sbase[nk] : 0;
+  if (block >= nP) {
+    // SCATTER the kept points
+    const int m = (block - nP - kRebuildAuxBlocks) * nt + tid;
+    if (m >= Mk) return;
+    const int h = v.pt_cell[(size_t)s * v.map_cap + m];
+    if (h < 0) return;
+    const float4 pt = kept_point(v, s, m, nk, sbase, sslot);
+    const unsigned int pos = cells[h].start + (unsigned int)v.pt_rank[(size_t)s * v.map_cap + m];
+    sorted[pos] = make_float4(pt.x, pt.y, pt.z, __int_as_float(m));
+    return;
+  }
+  // APPEND the new frame
+  const int n_new = st.n_edges_buf[eb];
+  if (block * nt >= n_new) return;
+  const int idx = block * nt + tid;
+  const bool live = idx < n_new;
+  const float4 e = v.edges[((size_t)eb * v.n_streams + s) * v.edge_cap + (live ? idx : 0)];     // (loaded before the wait)
+  const float4 q = predicted_point(st, e);
   if (tid < 64) {
     typedef __attribute__((address_space(1))) unsigned long long gu64;
     const unsigned long long* base = v.pose_xch + (size_t)s * 32;
@@ -2029,9 +2182,7 @@ __device__ void count_window_frames(const DevView& v, int s, StreamState& st, in
     if (!all_ok && tid == 0) atomicOr(&st.status, LIODOM_STATUS_LM_SYNC_TIMEOUT);
   }
   __syncthreads();
-  if (sh_hand == 0) return;
-  const int idx = block * nt + tid;
-  const bool live = idx < n_new;
+  if (sh_hand == 0 || !live) return;
   float4 pt;
   if (sh_hand == 2) {
     pt = e;
@@ -2042,8 +2193,38 @@ __device__ void count_window_frames(const DevView& v, int s, StreamState& st, in
     transform_point(T, e.x, e.y, e.z, &pt.x, &pt.y, &pt.z);
     pt.w = e.w;
   }
-  if (live) v.win_pts[((size_t)s * P + (fc % P)) * v.edge_cap + idx] = pt;
-  hash_count_point(v, s, par, st, Mk + idx, pt, live);
+  v.win_pts[((size_t)s * P + (fc % P)) * v.edge_cap + idx] = pt;
+  if (!point_finite(pt)) return;                       // (never part of the map, as in k_window_insert)
+  const int m = Mk + idx;
+  // inside the padded cells for certain?  (1e-3 covers the float rounding of the two transforms and of q -+ delta)
+  const float dc = v.rebuild_delta - 1.0e-3f;
+  bool placed = false;
+  if (point_finite(q) && fabsf(pt.x - q.x) < dc && fabsf(pt.y - q.y) < dc && fabsf(pt.z - q.z) < dc) {
+    const unsigned long long key = pack_cell((int)floorf(pt.x * kCellInv), (int)floorf(pt.y * kCellInv), (int)floorf(pt.z * kCellInv));
+    const unsigned int tmask = (unsigned int)v.table_size - 1u;
+    unsigned int h = hash_cell(key, tmask);
+    for (int probe = 0; probe < v.table_size; probe++) {
+      const unsigned long long k = cells[h].key;
+      if (k == key) {
+        const unsigned int pos = cells[h].start + atomicAdd(&cells[h].cnt, 1u);
+        if (pos < v.cell_pad[(size_t)sp * v.table_size + h]) sorted[pos] = make_float4(pt.x, pt.y, pt.z, __int_as_float(m));
+        else atomicOr(&st.status, LIODOM_STATUS_HASH_FULL);        // (cannot happen: the padding reserved the place)
+        placed = true;
+        break;
+      }
+      if (k == kEmptyKey) break;
+      h = (h + 1) & tmask;
+    }
+  }
+  if (!placed) {
+    const int i = atomicAdd(&st.n_ovf[par], 1);
+    sorted[v.ovf_base + i] = make_float4(pt.x, pt.y, pt.z, __int_as_float(m));
+  }
+}
+
+__device__ void rebuild_beside_solve(const DevView& v, int s, StreamState& st, int eb, int outer_it, int block, int* sbase, int* sslot) {
+  if (outer_it == 0) rebuild_count_and_pad(v, s, st, eb, block, sbase, sslot);
+  else rebuild_finish(v, s, st, eb, block, sbase, sslot);
 }
 
 // Start offsets of the occupied cells (any order: only contiguity per cell matters).  One atomic
@@ -2059,7 +2240,7 @@ __global__ __launch_bounds__(256) void k_hash_alloc(DevView v, int s0) {
   CellSlot* slot = nullptr;
   int cnt = 0;
   if (u < nu) {
-    slot = v.cells + (size_t)sp * v.table_size + v.used_cells[(size_t)sp * v.map_cap + u];
+    slot = v.cells + (size_t)sp * v.table_size + v.used_cells[(size_t)sp * v.used_cap + u];
     cnt = (int)slot->cnt;
   }
   const int incl = wave_incl_scan_i32(cnt);
@@ -2078,9 +2259,6 @@ __global__ __launch_bounds__(256) void k_hash_scatter(DevView v, int s0) {
   const int M = st.n_map;
   const int MT = M + (v.mapping ? st.n_recv : 0);
   const int par = LD_TAB_PARITY(v, st.frame_count), sp = s + par * v.n_streams;
-  // early_rebuild: the table the scan searched is dead now; reset its occupied slots for the build after this one
-  // (its counter is zeroed by the next scan's first k_lm_solve, after every workgroup here has read it)
-  if (v.early_rebuild) hash_clear_used(v, s + (1 - par) * v.n_streams, st.n_used_tab[1 - par], blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
   if ((int)(blockIdx.x * 256) >= MT || filter_active(v, st)) return;
   const int P = v.prev_frames, nf = st.n_frames;
   for (int j = threadIdx.x; j <= nf; j += 256) sbase[j] = v.win_base[(size_t)s * (P + 1) + j];
@@ -2100,7 +2278,7 @@ __global__ __launch_bounds__(256) void k_hash_scatter(DevView v, int s0) {
   }
   const size_t ti = (size_t)sp * v.table_size + h;
   const unsigned int pos = v.cells[ti].start + (unsigned int)v.pt_rank[(size_t)s * v.map_cap + m];
-  v.sorted_pts[(size_t)s * v.map_cap + pos] = make_float4(pt.x, pt.y, pt.z, __int_as_float(m));
+  v.sorted_pts[(size_t)sp * v.sorted_cap + pos] = make_float4(pt.x, pt.y, pt.z, __int_as_float(m));
 }
 
 // Clears the cell hash of the current build so that it can be rebuilt without a new frame
@@ -2272,7 +2450,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_hash_build(DevView v, int s0,
           const unsigned long long prev = atomicCAS(&cells[h].key, kEmptyKey, key);
           if (prev == kEmptyKey) {
             const int u = atomicAdd(&st.n_used_tab[0], 1);
-            v.used_cells[(size_t)s * v.map_cap + u] = (int)h;
+            v.used_cells[(size_t)s * v.used_cap + u] = (int)h;
             atomicOr(&bits[h >> 5], 1u << (h & 31));
             found = (int)h;
             break;
@@ -2289,7 +2467,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_hash_build(DevView v, int s0,
     __syncthreads();
     const int nu = *(volatile int*)&st.n_used_tab[0];
     for (int u = tid; u < nu; u += kBuildThreads) {
-      CellSlot* slot = cells + v.used_cells[(size_t)s * v.map_cap + u];
+      CellSlot* slot = cells + v.used_cells[(size_t)s * v.used_cap + u];
       slot->start = (unsigned int)atomicAdd(&st.cursor, (int)*(volatile unsigned int*)&slot->cnt);
     }
     __threadfence();
@@ -2564,7 +2742,7 @@ __global__ __launch_bounds__(256) void k_filt_insert(DevView v, int s0) {
     const unsigned long long prev = atomicCAS(&cells[h].key, kEmptyKey, key);
     if (prev == kEmptyKey) {
       const int k = atomicAdd(&st.n_used_tab[0], 1);
-      v.used_cells[(size_t)s * v.map_cap + k] = (int)h;
+      v.used_cells[(size_t)s * v.used_cap + k] = (int)h;
       atomicOr(&v.cell_bits[((size_t)s * v.table_size + h) >> 5], 1u << (h & 31));
       found = (int)h;
       break;
@@ -2583,7 +2761,7 @@ __global__ __launch_bounds__(256) void k_filt_alloc(DevView v, int s0) {
   if (!filter_active(v, st)) return;
   const int u = blockIdx.x * 256 + threadIdx.x;
   if (u >= st.n_used_tab[0]) return;
-  CellSlot* slot = v.cells + (size_t)s * v.table_size + v.used_cells[(size_t)s * v.map_cap + u];
+  CellSlot* slot = v.cells + (size_t)s * v.table_size + v.used_cells[(size_t)s * v.used_cap + u];
   slot->start = (unsigned int)atomicAdd(&st.cursor, (int)slot->cnt);
 }
 

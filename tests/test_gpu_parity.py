@@ -673,3 +673,33 @@ def test_replay_resident_loop_equals_per_call_replay(orc, synth):
     assert np.array_equal(got.view(np.uint64), np.array(ref).view(np.uint64))
     assert [i.scan_index for i in list(i1) + list(i2)] == list(range(K))
     g.close()
+
+
+def test_streamed_rebuild_overflow_list_is_exact(orc, synth, monkeypatch):
+    """Streamed rebuild: a point of the new frame that the solve moved further than rebuild_delta away from where the
+    prediction put it cannot use the place its padding reserved and waits in the table's overflow list, which every kNN
+    query of the next scan scans as well.  With rebuild_delta = 2 mm most new points take that route: poses, match counts
+    and correspondences must not change by a bit (also against the three-kernel rebuild)."""
+    H, W, R, epr, P, K = 16, 900, 6, 10, 4, 10
+    cfg = synth.make_cfg(H, W, 0, yaw_rate_deg=2.0, speed=0.5)
+    scans = [synth.scan(cfg, 4, k)[0] for k in range(K)]
+    res = {}
+    for name, env in (("default", {}), ("tiny", {"LIODOM_REBUILD_DELTA": "0.002"}), ("three", {"LIODOM_EARLY_REBUILD": "0"})):
+        monkeypatch.delenv("LIODOM_REBUILD_DELTA", raising=False)
+        monkeypatch.delenv("LIODOM_EARLY_REBUILD", raising=False)
+        for kk, vv in env.items():
+            monkeypatch.setenv(kk, vv)
+        po, g = mk(orc, H, W, 0, R, epr, P)
+        out = []
+        for k in range(K):
+            pose, info = g.process_scan(scans[k], H, W)
+            assert info.status == 0
+            out.append((pose.copy(), tuple(info.matches)) + tuple(a.copy() for a in g.correspondences(1)))
+        res[name] = out
+        g.close()
+    for name in ("tiny", "three"):
+        for k in range(K):
+            a, b = res["default"][k], res[name][k]
+            assert np.array_equal(a[0].view(np.uint64), b[0].view(np.uint64)), (name, k)
+            assert a[1] == b[1] and all(np.array_equal(x, y) for x, y in zip(a[2:], b[2:])), (name, k)
+    assert sum(m[1][1] for m in res["default"]) > 100      # (the trajectory does produce matches)
