@@ -81,7 +81,7 @@ typedef struct liodom_config_t {
   int32_t lm_apply_step_on_ftol; /* 0 = Ceres >= 1.12 behaviour (LM section) */
   int32_t pose_log_capacity; /* scans kept in the device-side pose log (resident replay) */
   int32_t debug_buffers;     /* 1 = keep per-ring smoothness dumps for liodom_get_curvature */
-  int32_t lm_workgroups;     /* workgroups (CUs) per stream for the pose solve: 0 = auto (8 for <= 4 streams of >= 8192 possible edges, else 1), 1 or 8 */
+  int32_t lm_workgroups;     /* workgroups (CUs) per stream for the pose solve: 0 = auto (<= 4 streams: 8 for >= 8192 possible edges, 4 for >= 4096; else 1), or 1 .. 8 */
   int32_t recv_capacity;     /* mapping = 1: points of the received ~map cloud the kNN structure can take (0 = 262144) */
   int32_t pose_rotation_mode; /* what Eigen::Transform::rotation() returns at src/laser_odometry.cc:164,186,403,420:
                                  1 (default) = Eigen 3.3.x, the README's platform: orthonormal polar factor of linear()

@@ -1656,11 +1656,20 @@ __device__ void lm_exchange(const DevView& v, int s, int g, int G, unsigned int 
       bool ok = true;
       tot = 0.0;
       if (tid < kAccN) {
-        for (int gg = 0; gg < G; gg++) {
-          const unsigned long long lo = __hip_atomic_load((gu64*)(base + gg * 64 + 2 * tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const unsigned long long hi = __hip_atomic_load((gu64*)(base + gg * 64 + 2 * tid + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          ok = ok && ((unsigned int)(lo >> 32) == epoch) && ((unsigned int)(hi >> 32) == epoch);
-          tot += __longlong_as_double((long long)((hi << 32) | (lo & 0xFFFFFFFFull)));
+        // all 2 G loads in flight at once (a loop over the runtime G waits for every pair: G round trips per poll)
+        unsigned long long lo[kLmGroupsMax], hi[kLmGroupsMax];
+#pragma unroll
+        for (int gg = 0; gg < kLmGroupsMax; gg++) {
+          const int gq = gg < G ? gg : 0;
+          lo[gg] = __hip_atomic_load((gu64*)(base + gq * 64 + 2 * tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          hi[gg] = __hip_atomic_load((gu64*)(base + gq * 64 + 2 * tid + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int gg = 0; gg < kLmGroupsMax; gg++) {
+          if (gg < G) {
+            ok = ok && ((unsigned int)(lo[gg] >> 32) == epoch) && ((unsigned int)(hi[gg] >> 32) == epoch);
+            tot += __longlong_as_double((long long)((hi[gg] << 32) | (lo[gg] & 0xFFFFFFFFull)));
+          }
         }
       }
       if (__all(ok)) break;
@@ -2182,6 +2191,8 @@ __device__ void rebuild_finish(const DevView& v, int s, StreamState& st, int eb,
     if (!all_ok && tid == 0) atomicOr(&st.status, LIODOM_STATUS_LM_SYNC_TIMEOUT);
   }
   __syncthreads();
+  const bool dbga = (s == 0) && (block == 0) && (tid == 0);
+  DBG_STAMP(v, dbga, 2, 29);
   if (sh_hand == 0 || !live) return;
   float4 pt;
   if (sh_hand == 2) {
@@ -2220,6 +2231,7 @@ __device__ void rebuild_finish(const DevView& v, int s, StreamState& st, int eb,
     const int i = atomicAdd(&st.n_ovf[par], 1);
     sorted[v.ovf_base + i] = make_float4(pt.x, pt.y, pt.z, __int_as_float(m));
   }
+  DBG_STAMP(v, dbga, 2, 30);
 }
 
 __device__ void rebuild_beside_solve(const DevView& v, int s, StreamState& st, int eb, int outer_it, int block, int* sbase, int* sslot) {
