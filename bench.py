@@ -49,8 +49,10 @@ WORKLOADS = {
 }
 
 
-def algorithmic_bytes(kernel, N, E, M, C, evals):
-    """SURVEY.md §8(d) per-scan figures, per launch of `kernel` for one stream."""
+def algorithmic_bytes(kernel, N, E, M, C, evals, streamed=False):
+    """SURVEY.md §8(d) per-scan figures, per launch of `kernel` for one stream.  streamed: handles with < 16 streams
+    build the next cell hash with extra workgroups of the two k_lm_solve launches of a scan (32 B per window point per
+    scan, half on each launch) instead of k_window_insert / k_hash_alloc / k_hash_scatter."""
     if kernel == "k_classify":
         return 17.0 * N                       # 16 B/point read, 1 id byte written
     if kernel == "k_ring_scatter":
@@ -60,7 +62,7 @@ def algorithmic_bytes(kernel, N, E, M, C, evals):
     if kernel == "k_knn":
         return 16.0 * (M + E) + 28.0 * E      # one kNN pass: map + queries read, (a, b, flag) written
     if kernel == "k_lm_solve":
-        return (36.0 * C + 224.0) * max(evals, 1.0)   # per residual/Jacobian evaluation
+        return (36.0 * C + 224.0) * max(evals, 1.0) + (16.0 * M if streamed else 0.0)   # per residual/Jacobian evaluation (+ half of the streamed rebuild)
     if kernel in ("k_window_insert", "k_hash_scatter", "k_hash_alloc", "k_hash_clear", "k_hash_build"):
         return 32.0 * M                       # window / hash rebuild
     if kernel == "k_compact_edges":
@@ -94,12 +96,13 @@ def measured_traffic(kernel, n_streams):
 def roofline_from_stats(stats, n_streams, N, E, M, C, evals):
     """stats: {kernel: (launches, total_ms)} from HIP events on the handle's stream."""
     stats = {k: v for k, v in stats.items() if v[0]}
+    streamed = n_streams < 16 and "k_window_insert" not in stats and "k_hash_build" not in stats
     tot = sum(ms for _, ms in stats.values()) or 1.0
     name, (launches, ms) = max(stats.items(), key=lambda kv: kv[1][1])
     avg_s = ms / max(launches, 1) * 1e-3
-    by = algorithmic_bytes(name, N, E, M, C, evals) * n_streams
+    by = algorithmic_bytes(name, N, E, M, C, evals, streamed) * n_streams
     achieved = by / avg_s / 1e9 if avg_s > 0 else 0.0
-    per_scan_bytes = sum(algorithmic_bytes(k, N, E, M, C, evals) * v[0] for k, v in stats.items())   # all launches
+    per_scan_bytes = sum(algorithmic_bytes(k, N, E, M, C, evals, streamed) * v[0] for k, v in stats.items())   # all launches
     scans = max(1, stats.get("k_classify", (1, 0))[0])
     return {
         "bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -108,8 +111,8 @@ def roofline_from_stats(stats, n_streams, N, E, M, C, evals):
         "share_of_gpu_time": round(ms / tot, 3),
         "per_kernel_us": {k: round(v[1] / max(v[0], 1) * 1e3, 2) for k, v in stats.items()},
         # every kernel against the same roof: algorithmic GB/s and fraction of the 8 TB/s peak
-        "per_kernel_frac": {k: round(algorithmic_bytes(k, N, E, M, C, evals) * n_streams / (v[1] / v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
-                            for k, v in stats.items() if v[1] > 0 and algorithmic_bytes(k, N, E, M, C, evals) > 0},
+        "per_kernel_frac": {k: round(algorithmic_bytes(k, N, E, M, C, evals, streamed) * n_streams / (v[1] / v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+                            for k, v in stats.items() if v[1] > 0 and algorithmic_bytes(k, N, E, M, C, evals, streamed) > 0},
         # all kernels of a step together: algorithmic bytes of one step / summed kernel time of one step
         "end_to_end_frac_of_kernel_time": round(per_scan_bytes / scans * n_streams / (tot / scans * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
     }
