@@ -1571,15 +1571,14 @@ __device__ void finalize_scan(const DevView& v, int s, StreamState& st, int* sh_
   const int n_edges = st.n_edges_buf[eb];
   const int nup = st.n_used_tab[0];      // cells of the build that this scan searched (cleared below)
   if (tid == ctl) { for (int i = 0; i < 12; i++) st.final_odom[i] = st.odom[i]; }   // (ctl wrote st.odom itself)
-  __syncthreads();
-  // early_rebuild: hand the pose to the workgroups that append the new frame (they have been waiting for it)
-  if (v.early_rebuild && tid < 25) publish_final_pose(v, s, st.final_odom, st.append_raw, (unsigned int)st.reb_frame_count + 1u, tid);
-  for (int j = tid; j < nf; j += blockDim.x) {
+  for (int j = tid; j < nf; j += blockDim.x) {           // frame sizes of the new window (nothing here depends on the pose)
     const int sl = (fc_new - nf + j) % P;
     sh_cnt[j] = (sl == new_slot) ? n_edges : wn[sl];     // independent loads, one round trip
     ws[j] = sl;
   }
   __syncthreads();
+  // early_rebuild: hand the pose to the workgroups that append the new frame (they have been waiting for it)
+  if (v.early_rebuild && tid < 25) publish_final_pose(v, s, st.final_odom, st.append_raw, (unsigned int)st.reb_frame_count + 1u, tid);
   if (tid == 64) {
     // pose as published (laser_odometry.cc:403-412 with identity laser_to_base)
     double q[4];
@@ -2169,6 +2168,21 @@ __device__ void rebuild_finish(const DevView& v, int s, StreamState& st, int eb,
   const bool live = idx < n_new;
   const float4 e = v.edges[((size_t)eb * v.n_streams + s) * v.edge_cap + (live ? idx : 0)];     // (loaded before the wait)
   const float4 q = predicted_point(st, e);
+  // the cell the prediction puts the point into is where it ends up almost always: look its slot up before the wait
+  const unsigned int tmask = (unsigned int)v.table_size - 1u;
+  const bool q_fin = point_finite(q);
+  const unsigned long long key_pred = q_fin ? pack_cell((int)floorf(q.x * kCellInv), (int)floorf(q.y * kCellInv), (int)floorf(q.z * kCellInv)) : kEmptyKey;
+  int h_pred = -1;
+  unsigned int start_pred = 0, end_pred = 0;
+  if (live && q_fin) {
+    unsigned int h = hash_cell(key_pred, tmask);
+    for (int probe = 0; probe < v.table_size; probe++) {
+      const unsigned long long k = cells[h].key;
+      if (k == key_pred) { h_pred = (int)h; start_pred = cells[h].start; end_pred = v.cell_pad[(size_t)sp * v.table_size + h]; break; }
+      if (k == kEmptyKey) break;
+      h = (h + 1) & tmask;
+    }
+  }
   if (tid < 64) {
     typedef __attribute__((address_space(1))) unsigned long long gu64;
     const unsigned long long* base = v.pose_xch + (size_t)s * 32;
@@ -2210,21 +2224,26 @@ __device__ void rebuild_finish(const DevView& v, int s, StreamState& st, int eb,
   // inside the padded cells for certain?  (1e-3 covers the float rounding of the two transforms and of q -+ delta)
   const float dc = v.rebuild_delta - 1.0e-3f;
   bool placed = false;
-  if (point_finite(q) && fabsf(pt.x - q.x) < dc && fabsf(pt.y - q.y) < dc && fabsf(pt.z - q.z) < dc) {
+  if (q_fin && fabsf(pt.x - q.x) < dc && fabsf(pt.y - q.y) < dc && fabsf(pt.z - q.z) < dc) {
     const unsigned long long key = pack_cell((int)floorf(pt.x * kCellInv), (int)floorf(pt.y * kCellInv), (int)floorf(pt.z * kCellInv));
-    const unsigned int tmask = (unsigned int)v.table_size - 1u;
-    unsigned int h = hash_cell(key, tmask);
-    for (int probe = 0; probe < v.table_size; probe++) {
-      const unsigned long long k = cells[h].key;
-      if (k == key) {
-        const unsigned int pos = cells[h].start + atomicAdd(&cells[h].cnt, 1u);
-        if (pos < v.cell_pad[(size_t)sp * v.table_size + h]) sorted[pos] = make_float4(pt.x, pt.y, pt.z, __int_as_float(m));
-        else atomicOr(&st.status, LIODOM_STATUS_HASH_FULL);        // (cannot happen: the padding reserved the place)
-        placed = true;
-        break;
+    int hf = -1;
+    unsigned int start = 0, end = 0;
+    if (key == key_pred) {
+      hf = h_pred; start = start_pred; end = end_pred;
+    } else {                                             // crossed into a neighbour cell (also padded)
+      unsigned int h = hash_cell(key, tmask);
+      for (int probe = 0; probe < v.table_size; probe++) {
+        const unsigned long long k = cells[h].key;
+        if (k == key) { hf = (int)h; start = cells[h].start; end = v.cell_pad[(size_t)sp * v.table_size + h]; break; }
+        if (k == kEmptyKey) break;
+        h = (h + 1) & tmask;
       }
-      if (k == kEmptyKey) break;
-      h = (h + 1) & tmask;
+    }
+    if (hf >= 0) {
+      const unsigned int pos = start + atomicAdd(&cells[hf].cnt, 1u);
+      if (pos < end) sorted[pos] = make_float4(pt.x, pt.y, pt.z, __int_as_float(m));
+      else atomicOr(&st.status, LIODOM_STATUS_HASH_FULL);        // (cannot happen: the padding reserved the place)
+      placed = true;
     }
   }
   if (!placed) {
