@@ -12,9 +12,11 @@
 //                            whole Ceres-style LM solve in one workgroup per stream; second call
 //                            also finalises the scan (pose log, prediction :148-150, window
 //                            bookkeeping :34-60)
+//   streamed rebuild  A6     (handles with < 16 streams) extra workgroups of the four launches above append the
+//                            transformed edges to the sliding window (:231-235) and build the voxel hash the next
+//                            scan's kNN searches, in a second table, while the scan is solved
 //   k_window_insert / k_hash_alloc / k_hash_scatter
-//                     A6     append transformed edges to the sliding window (:231-235) and
-//                            rebuild the flat voxel hash the next scan's kNN searches
+//                     A6     the same after the solve, three launches (mapping / filtered-map handles)
 //   k_hash_build      A6     the same as ONE workgroup per stream with LDS atomics (handles with
 //                            >= 16 streams)
 //   k_voxel_* / k_filt_*  A7 filter_local_map: VoxelGrid(0.4) of the full window (:286-292)
@@ -174,8 +176,8 @@ struct DevView {
   int ovf_base;             // first entry of the overflow list inside a table's sorted_pts
   float rebuild_delta;      // early_rebuild: a new-frame point may move this far (per axis) between the prediction and the solved pose and still land in a padded cell
   unsigned long long* pose_xch;   // [S][32] early_rebuild: solved pose handed to the workgroups that append the new frame (tagged 8-byte granules)
-  int early_rebuild;        // the frames that stay in the window are counted into the next cell hash beside the scan's finalising solve
-                            // (k_hash_clear + k_window_count_old on a side stream); k_window_insert then adds the new frame only
+  int early_rebuild;        // streamed rebuild: extra workgroups of the scan's four launches build the next scan's cell hash in the
+                            // second table ("Streamed rebuild" below); no k_window_insert / k_hash_alloc / k_hash_scatter launches
   int knn_blocks;           // k_knn workgroups per stream = ceil(edge_cap / knn_queries), rounded up to a multiple of 4
   unsigned long long* lm_xch;   // [S][2][kLmGroupsMax][64] tagged granules: partial sums exchanged between the LM workgroups
   unsigned long long* dbg_clk;  // [8][32] phase timestamps (100 MHz), debug bit 5 only
