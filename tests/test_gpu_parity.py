@@ -703,3 +703,28 @@ def test_streamed_rebuild_overflow_list_is_exact(orc, synth, monkeypatch):
             assert np.array_equal(a[0].view(np.uint64), b[0].view(np.uint64)), (name, k)
             assert a[1] == b[1] and all(np.array_equal(x, y) for x, y in zip(a[2:], b[2:])), (name, k)
     assert sum(m[1][1] for m in res["default"]) > 100      # (the trajectory does produce matches)
+
+
+@pytest.mark.parametrize("P", [1, 2])
+def test_streamed_rebuild_tiny_windows(orc, synth, monkeypatch, P):
+    # prev_frames = 1: no frame is ever kept (the window is the previous scan alone); 2: one kept frame
+    H, W, R, epr, K = 16, 900, 6, 10, 7
+    cfg = synth.make_cfg(H, W, 0)
+    scans = [synth.scan(cfg, 5, k)[0] for k in range(K)]
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("LIODOM_EARLY_REBUILD", mode)
+        po, g = mk(orc, H, W, 0, R, epr, P)
+        out = []
+        for k in range(K):
+            pose, info = g.process_scan(scans[k], H, W)
+            assert info.status == 0
+            w, nf = g.window(0)
+            out.append((pose.copy(), tuple(info.matches), w.copy(), nf) + tuple(a.copy() for a in g.correspondences(1)))
+        res[mode] = out
+        g.close()
+    for k in range(K):
+        a, b = res["0"][k], res["1"][k]
+        assert np.array_equal(a[0].view(np.uint64), b[0].view(np.uint64)) and a[1] == b[1] and a[3] == b[3], (P, k)
+        assert np.array_equal(a[2].view(np.uint32), b[2].view(np.uint32)), (P, k)
+        assert all(np.array_equal(x, y) for x, y in zip(a[4:], b[4:])), (P, k)
