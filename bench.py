@@ -50,7 +50,7 @@ WORKLOADS = {
 
 
 def algorithmic_bytes(kernel, N, E, M, C, evals, streamed=False):
-    """SURVEY.md §8(d) per-scan figures, per launch of `kernel` for one stream.  streamed: handles with < 16 streams
+    """SURVEY.md §8(d) per-scan figures, per launch of `kernel` for one stream.  streamed: handles with <= 4 streams
     build the next cell hash with extra workgroups of the two k_lm_solve launches of a scan (32 B per window point per
     scan, half on each launch) instead of k_window_insert / k_hash_alloc / k_hash_scatter."""
     if kernel == "k_classify":
@@ -96,7 +96,7 @@ def measured_traffic(kernel, n_streams):
 def roofline_from_stats(stats, n_streams, N, E, M, C, evals):
     """stats: {kernel: (launches, total_ms)} from HIP events on the handle's stream."""
     stats = {k: v for k, v in stats.items() if v[0]}
-    streamed = n_streams < 16 and "k_window_insert" not in stats and "k_hash_build" not in stats
+    streamed = n_streams <= 4 and "k_window_insert" not in stats and "k_hash_build" not in stats
     tot = sum(ms for _, ms in stats.values()) or 1.0
     name, (launches, ms) = max(stats.items(), key=lambda kv: kv[1][1])
     avg_s = ms / max(launches, 1) * 1e-3

@@ -12,7 +12,7 @@
 //                            whole Ceres-style LM solve in one workgroup per stream; second call
 //                            also finalises the scan (pose log, prediction :148-150, window
 //                            bookkeeping :34-60)
-//   streamed rebuild  A6     (handles with < 16 streams) extra workgroups of the four launches above append the
+//   streamed rebuild  A6     (handles with <= 4 streams) extra workgroups of the four launches above append the
 //                            transformed edges to the sliding window (:231-235) and build the voxel hash the next
 //                            scan's kNN searches, in a second table, while the scan is solved
 //   k_window_insert / k_hash_alloc / k_hash_scatter
@@ -1984,7 +1984,7 @@ __global__ __launch_bounds__(256) void k_window_insert(DevView v, int s0, int eb
 }
 
 // =============================================================================================
-// Streamed rebuild (early_rebuild; handles with < 16 streams, no mapping / filtered map).
+// Streamed rebuild (early_rebuild; handles with <= 4 streams, no mapping / filtered map).
 // The cell hash of the NEXT scan is built while the current scan is solved, by extra workgroups riding on the four
 // launches of the scan; nothing is left between the finalising solve and the next scan's first kNN pass.  Two tables
 // per stream: scan F (frame_count = F when it starts) searches table F & 1 and builds table (F + 1) & 1.

@@ -619,7 +619,7 @@ def test_second_knn_pass_reuse_equals_full_search(orc, synth, monkeypatch):
 
 
 def test_early_rebuild_equals_three_kernel_rebuild(orc, synth, monkeypatch):
-    """Default for handles with < 16 streams: the window of the next cell hash is counted by extra workgroups of the
+    """Default for handles with <= 4 streams: the window of the next cell hash is counted by extra workgroups of the
     finalising k_lm_solve launch (kept frames beside the solve, the new frame once the solve hands over the pose, into
     the second table).  LIODOM_EARLY_REBUILD=0 restores k_window_insert after the solve on one table.  Poses, window
     contents and correspondences must be bit-identical, on a 3-stream handle (every stream's appending workgroups wait
