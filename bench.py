@@ -197,14 +197,16 @@ def main():
     g.sync()
     time.sleep(0.5)   # let the host settle after the OpenMP-heavy generation (container CPU quota)
 
-    def run(first, count, readback=True, pipelined=True):
+    def run(first, count, readback=True, pipelined=True, depth=1):
         # pipelined: the extraction of scan k+1 is issued on a second HIP stream while scan k's
         # odometry runs (the reference's own two-thread pipeline); never across the region's ends
         last = first + count - 1
         if readback and pipelined:
-            # the consumer loop in C (liodom_replay_resident): the same per-scan synchronous discipline — pose k is read
-            # back before the odometry of scan k+1 is submitted — without a Python call per scan
-            g.replay_resident(first, count, N, H, W)
+            # the consumer loop in C (liodom_replay_resident): every pose is read back, in order.  depth 1 (headline):
+            # the odometry of scan k+1 is submitted before pose k is waited for — the device needs nothing from the host
+            # between two scans, and the poses arrive exactly when they would anyway.  depth 0 (strict_sync leg): pose k
+            # is read back before scan k+1's odometry is submitted; the GPU then idles for the host's turn-around.
+            g.replay_resident(first, count, N, H, W, depth=depth)
             return
         for k in range(first, first + count):
             g.process_resident(k, N, H, W, readback=readback, next_slot=(k + 1 if (pipelined and k < last) else -1))
@@ -250,6 +252,14 @@ def main():
     run(F + Wm, K, readback=False)
     g.sync()
     async_rate = K / (time.perf_counter() - t1)
+    # strictly synchronous consumer (pose k read back before scan k+1's odometry is submitted) for reference
+    g.reset()
+    run(0, F + Wm, depth=0)
+    g.sync()
+    t1 = time.perf_counter()
+    run(F + Wm, K, depth=0)
+    g.sync()
+    strict_rate = K / (time.perf_counter() - t1)
     # strictly serial scans (no overlap between extraction and odometry) for reference
     g.reset()
     run(0, F + Wm, pipelined=False)
@@ -269,14 +279,15 @@ def main():
             "ms_per_step": round(elapsed / K * 1e3, 5), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl["name"], "streams_per_gpu": 1, "points_per_scan": N,
-                       "mode": "per-scan synchronous (pose read back every scan), scans resident in HBM, "
-                               "extraction of scan k+1 overlapped with odometry of scan k on a second HIP stream; "
-                               "consumer loop in C (liodom_replay_resident)",
+                       "mode": "pose of every scan read back in order by the consumer loop (liodom_replay_resident, depth 1: the "
+                               "odometry of scan k+1 is submitted before pose k is waited for), scans resident in HBM, "
+                               "extraction of scan k+1 overlapped with odometry of scan k on a second HIP stream",
                        "prefill_scans": F,
                        "parallelism": "replicas only" if world > 1 else "single stream",
                        "mean_edges": round(meanE, 1), "mean_map_points": round(meanM, 1), "mean_matches": round(meanC, 1),
                        "mean_lm_evals_per_solve": round(mean_evals, 2), "device": dev_name, "compute_units": cus,
                        "library_source_hash": la.api.build_info().get("source_hash") or la.api.built_hash()},
+            "strict_sync_scans_per_s": round(strict_rate, 2),
             "async_replay_scans_per_s": round(async_rate, 2),
             "serial_scans_per_s": round(serial_rate, 2),
             "roofline": roofline,

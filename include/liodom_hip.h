@@ -172,13 +172,16 @@ int liodom_process_resident(liodom_handle_t* h, int slot, int64_t n, int height,
 int liodom_process_resident_pipelined(liodom_handle_t* h, int slot, int next_slot, int64_t n, int height,
                                       int width, double* poses_out, liodom_step_info_t* infos_out);
 /* The consumer loop of the pipelined replay, in C: resident slots first_slot .. first_slot + count - 1 in order, every
- * scan exactly as liodom_process_resident_pipelined (the extraction of scan k+1 is issued beside the odometry of scan k;
- * the pose of scan k is read back before the odometry of scan k+1 is submitted — per-scan synchronous, like the
- * LaserOdometer thread that publishes ~odom per scan, src/liodom_node.cc:89-91 / laser_odometry.cc:403-430).  `ahead`
- * != 0 also issues the extraction of slot first_slot + count at the end (the next call must start there).
+ * scan exactly as liodom_process_resident_pipelined (the extraction of scan k+1 is issued beside the odometry of scan k)
+ * and every pose read back, in order — like the LaserOdometer thread that publishes ~odom per scan
+ * (src/liodom_node.cc:89-91 / laser_odometry.cc:100-107,403-430).
+ * depth = 0: strictly synchronous — pose k is read back before the odometry of scan k+1 is submitted (the GPU idles
+ * for the host's turn-around, ~6 us per scan).  depth = 1: the odometry of scan k+1 is submitted before pose k is
+ * waited for (the device needs nothing from the host between two scans; poses arrive exactly when they would anyway).
+ * `ahead` != 0 also issues the extraction of slot first_slot + count at the end (the next call must start there).
  * poses_out: count * n_streams * 7 doubles; infos_out: count * n_streams records (either may be NULL: then the poses
  * are only waited for). */
-int liodom_replay_resident(liodom_handle_t* h, int first_slot, int count, int ahead, int64_t n, int height, int width,
+int liodom_replay_resident(liodom_handle_t* h, int first_slot, int count, int ahead, int depth, int64_t n, int height, int width,
                            double* poses_out, liodom_step_info_t* infos_out);
 int liodom_sync(liodom_handle_t* h);
 int liodom_get_pose_log(liodom_handle_t* h, int stream, int first, int count, double* poses_out,

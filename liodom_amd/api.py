@@ -173,7 +173,7 @@ def load():
     L.liodom_process_resident.argtypes = [vp, C.c_int, C.c_int64, C.c_int, C.c_int, dp, C.POINTER(StepInfo)]
     L.liodom_process_resident_pipelined.restype = C.c_int
     L.liodom_replay_resident.restype = C.c_int
-    L.liodom_replay_resident.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, dp, C.POINTER(StepInfo)]
+    L.liodom_replay_resident.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, dp, C.POINTER(StepInfo)]
     L.liodom_process_resident_pipelined.argtypes = [vp, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, dp, C.POINTER(StepInfo)]
     L.liodom_sync.restype = C.c_int
     L.liodom_sync.argtypes = [vp]
@@ -376,13 +376,14 @@ class Liodom:
         self._check(self.L.liodom_process_resident_pipelined(self.h, slot, next_slot, n, height, width, None, None))
         return None, None
 
-    def replay_resident(self, first_slot, count, n, height, width, ahead=False):
-        """The pipelined per-scan synchronous loop over resident slots first_slot .. first_slot + count - 1, in C
-        (liodom_replay_resident).  Returns poses [count, n_streams, 7] and the step infos [count * n_streams]."""
+    def replay_resident(self, first_slot, count, n, height, width, ahead=False, depth=0):
+        """The pipelined consumer loop over resident slots first_slot .. first_slot + count - 1, in C
+        (liodom_replay_resident): every pose read back in order; depth 0 = strictly synchronous, 1 = the odometry of
+        scan k+1 is submitted before pose k is waited for.  Returns poses [count, n_streams, 7] and the step infos."""
         S = self.config.n_streams
         poses = np.zeros((count, S, 7))
         infos = (StepInfo * (count * S))()
-        self._check(self.L.liodom_replay_resident(self.h, first_slot, count, 1 if ahead else 0, n, height, width, _dp(poses), infos))
+        self._check(self.L.liodom_replay_resident(self.h, first_slot, count, 1 if ahead else 0, int(depth), n, height, width, _dp(poses), infos))
         return poses, infos
 
     def sync(self):

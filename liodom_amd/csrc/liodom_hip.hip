@@ -54,17 +54,21 @@ struct liodom_handle {
   DevView* d_view = nullptr;         // device copy: kernels take a pointer (8-byte kernarg)
   // Two sides, as in the reference's liodom_node (src/liodom_node.cc:89-91: one FeatureExtractor thread,
   // one LaserOdometer thread).  The EXTRACTION side owns stream_x, the ring-split scratch, stage_in and
-  // edge buffer kEdgeBufX; the ODOMETRY side owns `stream`, edge buffers 0 / 1, the window, the hash and
+  // edge buffer kEdgeBufX; the ODOMETRY side owns `stream`, edge buffers 0 / 1 / 2, the window, the hash and
   // the result records.  mx_x / mx_o serialise callers of each side; an entry point that needs both
   // (process_scan, the resident replay, reset, ...) takes mx_o first, then mx_x.  liodom_extract_edges
   // (mx_x only) and liodom_odometry_step (mx_o only) can therefore run concurrently from two threads.
   std::mutex mx_x, mx_o;
   hipStream_t stream = nullptr;      // odometry side
   hipStream_t stream_x = nullptr;    // extraction side (liodom_extract_edges, and the next scan's extraction in the pipelined replay)
-  hipEvent_t ev_edges[2] = {nullptr, nullptr};   // edge buffer b written
-  hipEvent_t ev_free[2] = {nullptr, nullptr};    // odometry finished reading edge buffer b
-  bool ev_free_valid[2] = {false, false};
+  hipEvent_t ev_edges[kEdgePipeBufs] = {nullptr, nullptr, nullptr};   // edge buffer b written
+  hipEvent_t ev_free[kEdgePipeBufs] = {nullptr, nullptr, nullptr};    // odometry finished reading edge buffer b
+  bool ev_free_valid[kEdgePipeBufs] = {false, false, false};
   int parity = 0;                    // edge buffer of the next scan to enter odometry
+  // pipelined replay without cross-stream events (pipe_flags in DevView; events are kept for the hipGraph mode):
+  unsigned int ext_seq = 0, odo_seq = 0;                 // extractions issued / odometries enqueued through the pipelined replay
+  unsigned int eb_seq[kEdgePipeBufs] = {0, 0, 0};        // sequence number of the extraction last issued into buffer b
+  unsigned int eb_reader[kEdgePipeBufs] = {0, 0, 0};     // number of the odometry that last read buffer b (0: none to wait for)
   int pf_slot = -1;                  // resident slot whose extraction has been issued ahead
   int last_eb = 0;                   // edge buffer of the most recent scan that entered odometry (inspection)
   hipEvent_t pose_event = nullptr;
@@ -91,6 +95,7 @@ struct liodom_handle {
   struct OdoGraph { int eb, s0, count; hipGraphExec_t exec; };
   std::vector<OdoGraph> odo_graphs;
   bool use_graph = false;
+  bool use_flags = false;       // pipelined replay: dependencies between the two streams through flags in device memory instead of events
   std::vector<EventPair> ev_pool;
   size_t ev_used = 0;
   double k_ms[LIODOM_NUM_KERNELS] = {0};
@@ -151,7 +156,7 @@ inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 // ---- launch sequences -----------------------------------------------------------------------
 // Feature extraction of `count` streams starting at s0; input scan for stream s0+i at in + i*stride.
 int launch_extract(liodom_handle* h, hipStream_t q, int eb, int s0, int count, const float4* in, size_t in_stride,
-                   int n, int height, int width) {
+                   int n, int height, int width, unsigned int wait_odo = 0) {
   const DevView& v = h->v;
   const int tiles = std::max(1, cdiv(n, kTilePts));
   {
@@ -180,7 +185,7 @@ int launch_extract(liodom_handle* h, hipStream_t q, int eb, int s0, int count, c
   }
   {
     ProfScope ps(h, KID_COMPACT, q);
-    hipLaunchKernelGGL(k_compact_edges, dim3(kCompactBlocks, count), dim3(256), 0, q, v, s0, eb);
+    hipLaunchKernelGGL(k_compact_edges, dim3(kCompactBlocks, count), dim3(256), 0, q, v, s0, eb, wait_odo);
   }
   HIP_TRY(hipGetLastError());
   return LIODOM_OK;
@@ -189,14 +194,14 @@ int launch_extract(liodom_handle* h, hipStream_t q, int eb, int s0, int count, c
 // Odometry on the dense edges already on the device.  If pose_dst != nullptr the poses + infos
 // of the streams are copied to pinned memory right after the solve and pose_event is recorded,
 // so the host can pick them up while the window / hash rebuild still runs.
-int enqueue_odometry(liodom_handle* h, int eb, int s0, int count);
+int enqueue_odometry(liodom_handle* h, int eb, int s0, int count, unsigned int wait_edges, unsigned int signal_odo);
 
 void drop_graphs(liodom_handle* h) {
   for (auto& g : h->odo_graphs) (void)hipGraphExecDestroy(g.exec);
   h->odo_graphs.clear();
 }
 
-int launch_odometry(liodom_handle* h, int eb, int s0, int count) {
+int launch_odometry(liodom_handle* h, int eb, int s0, int count, unsigned int wait_edges = 0, unsigned int signal_odo = 0) {
   int rc = LIODOM_OK;
   // eager launches while profiling (an event pair around every kernel) and in mapping mode (the attached map's
   // update enqueues host-dependent work); otherwise one graph launch
@@ -206,7 +211,7 @@ int launch_odometry(liodom_handle* h, int eb, int s0, int count) {
     if (!exec) {
       hipGraph_t graph = nullptr;
       HIP_TRY(hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed));
-      rc = enqueue_odometry(h, eb, s0, count);
+      rc = enqueue_odometry(h, eb, s0, count, 0, 0);
       const hipError_t ce = hipStreamEndCapture(h->stream, &graph);
       if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
       if (ce != hipSuccess || !graph) { g_last_error = std::string("hipStreamEndCapture failed: ") + hipGetErrorString(ce); return LIODOM_ERR_HIP; }
@@ -217,7 +222,7 @@ int launch_odometry(liodom_handle* h, int eb, int s0, int count) {
     }
     HIP_TRY(hipGraphLaunch(exec, h->stream));
   } else {
-    rc = enqueue_odometry(h, eb, s0, count);
+    rc = enqueue_odometry(h, eb, s0, count, wait_edges, signal_odo);
     if (rc) return rc;
   }
   h->last_eb = eb;       // results are published by k_lm_solve into host-mapped memory (HostOut)
@@ -225,7 +230,7 @@ int launch_odometry(liodom_handle* h, int eb, int s0, int count) {
   return LIODOM_OK;
 }
 
-int enqueue_odometry(liodom_handle* h, int eb, int s0, int count) {
+int enqueue_odometry(liodom_handle* h, int eb, int s0, int count, unsigned int wait_edges, unsigned int signal_odo) {
   const DevView& v = h->v;
   const bool knn_small = h->S >= 16;            // many streams: 4 queries per workgroup, else 8
   const int knn_blocks = cdiv(h->v.edge_cap, knn_small ? 4 : 8);
@@ -242,8 +247,8 @@ int enqueue_odometry(liodom_handle* h, int eb, int s0, int count) {
     {
       ProfScope ps(h, KID_KNN);
       const int kx = knn_blocks + ((early && it == 1) ? kRebuildAuxBlocks : 0);     // it 1: + ALLOC
-      if (knn_small) hipLaunchKernelGGL(k_knn<128>, dim3(kx, count), dim3(128), 0, h->stream, v, s0, it, eb);
-      else hipLaunchKernelGGL(k_knn<256>, dim3(kx, count), dim3(256), 0, h->stream, v, s0, it, eb);
+      if (knn_small) hipLaunchKernelGGL(k_knn<128>, dim3(kx, count), dim3(128), 0, h->stream, v, s0, it, eb, wait_edges, signal_odo);
+      else hipLaunchKernelGGL(k_knn<256>, dim3(kx, count), dim3(256), 0, h->stream, v, s0, it, eb, wait_edges, signal_odo);
     }
     {
       ProfScope ps(h, KID_LM);
@@ -348,7 +353,8 @@ int drain_pipeline(liodom_handle* h) {
   if (h->pf_slot >= 0 || h->parity != 0) {
     HIP_TRY(hipStreamSynchronize(h->stream_x));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    h->pf_slot = -1; h->parity = 0; h->ev_free_valid[0] = h->ev_free_valid[1] = false;
+    h->pf_slot = -1; h->parity = 0; h->ev_free_valid[0] = h->ev_free_valid[1] = h->ev_free_valid[2] = false;
+    for (int b = 0; b < kEdgePipeBufs; b++) h->eb_reader[b] = 0;      // (everything has completed: nothing to wait for)
   }
   return LIODOM_OK;
 }
@@ -358,8 +364,19 @@ int issue_extract(liodom_handle* h, int slot, int eb, int n, int height, int wid
   // while per-kernel profiling is on, everything runs on one stream so that the HIP-event
   // durations are not inflated by kernels of the other stream sharing the GPU
   hipStream_t q = extract_queue(h);
-  if (h->ev_free_valid[eb]) HIP_TRY(hipStreamWaitEvent(q, h->ev_free[eb], 0));
   const float4* in = h->resident + (size_t)slot * h->S * (size_t)h->v.max_points;
+  if (h->use_flags) {
+    // dependencies through flags in device memory (pipe_wait / k_set_flag): the buffer's last reader must have
+    // completed before k_compact_edges rewrites it; the flag of this extraction is set by a launch that follows it
+    int rc = launch_extract(h, q, eb, 0, h->S, in, (size_t)h->v.max_points, n, height, width, h->eb_reader[eb]);
+    if (rc) return rc;
+    h->eb_seq[eb] = ++h->ext_seq;
+    if (h->ext_seq == 0) h->eb_seq[eb] = ++h->ext_seq;      // (0 means "nothing to wait for")
+    hipLaunchKernelGGL(k_set_flag, dim3(1), dim3(1), 0, q, h->v.pipe_flags + eb, h->eb_seq[eb]);
+    HIP_TRY(hipGetLastError());
+    return LIODOM_OK;
+  }
+  if (h->ev_free_valid[eb]) HIP_TRY(hipStreamWaitEvent(q, h->ev_free[eb], 0));
   int rc = launch_extract(h, q, eb, 0, h->S, in, (size_t)h->v.max_points, n, height, width);
   if (rc) return rc;
   HIP_TRY(hipEventRecord(h->ev_edges[eb], q));
@@ -389,10 +406,13 @@ int reset_state(liodom_handle* h) {
     hipLaunchKernelGGL(k_init_cells, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, h->v);
     HIP_TRY(hipGetLastError());
   }
-  h->pf_slot = -1; h->parity = 0; h->last_eb = 0; h->ev_free_valid[0] = h->ev_free_valid[1] = false;
+  h->pf_slot = -1; h->parity = 0; h->last_eb = 0; h->ev_free_valid[0] = h->ev_free_valid[1] = h->ev_free_valid[2] = false;
+  h->ext_seq = h->odo_seq = 0;
+  for (int b = 0; b < kEdgePipeBufs; b++) { h->eb_seq[b] = 0; h->eb_reader[b] = 0; }
+  HIP_TRY(hipMemsetAsync(h->v.pipe_flags, 0, sizeof(unsigned int) * (kEdgePipeBufs + 1), h->stream));
   HIP_TRY(hipMemsetAsync(h->v.lm_xch, 0, sizeof(unsigned long long) * (size_t)h->S * 2 * kLmGroupsMax * 64, h->stream));
   HIP_TRY(hipMemsetAsync(h->v.pose_xch, 0, sizeof(unsigned long long) * (size_t)h->S * 32, h->stream));
-  std::memset(h->host_out, 0, sizeof(HostOut) * (size_t)h->S);
+  std::memset(h->host_out, 0, sizeof(HostOut) * 2 * (size_t)h->S);
   std::fill(h->scans_enqueued.begin(), h->scans_enqueued.end(), 0);
   HIP_TRY(hipMemsetAsync(h->v.win_n, 0, sizeof(int) * (size_t)h->S * h->P, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
@@ -466,7 +486,7 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   if (hipEventCreateWithFlags(&h->pose_event, hipEventDisableTiming) != hipSuccess) { g_last_error = "hipEventCreate failed"; return fail(LIODOM_ERR_HIP); }
   if ((use_prio ? hipStreamCreateWithPriority(&h->stream_x, hipStreamNonBlocking, prio_least)
                 : hipStreamCreateWithFlags(&h->stream_x, hipStreamNonBlocking)) != hipSuccess) { g_last_error = "hipStreamCreate failed"; return fail(LIODOM_ERR_HIP); }
-  for (int b = 0; b < 2; b++) {
+  for (int b = 0; b < kEdgePipeBufs; b++) {
     if (hipEventCreateWithFlags(&h->ev_edges[b], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_free[b], hipEventDisableTiming) != hipSuccess) { g_last_error = "hipEventCreate failed"; return fail(LIODOM_ERR_HIP); }
   }
@@ -487,6 +507,17 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   // streams need 247 us (L2-atomic bound) against 103 us with one LDS workgroup each.
   h->lds_hash_build = config->n_streams >= 16;
   if (const char* e = std::getenv("LIODOM_GRAPH")) h->use_graph = std::atoi(e) != 0;
+  {
+    // Flags instead of events between the extraction and the odometry stream: the first kNN launch of a scan polls the
+    // extraction's flag in every workgroup, so all its workgroups must fit on the GPU with room to spare for the
+    // extraction kernels they may be waiting for — one stream only, and at most 24 of the ~28 wave slots per CU.
+    // (Lock-step batches are throughput-bound: 11 us per multi-millisecond step do not matter there.)
+    int cus = 0;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, config->device);
+    const int ecap = round_up(std::max(1, params->scan_lines * params->scan_regions * (params->edges_per_region + 1)), 64);
+    h->use_flags = !h->use_graph && config->n_streams == 1 && cdiv(ecap, 8) * 4 <= cus * 24;
+    if (const char* e = std::getenv("LIODOM_PIPE_FLAGS")) { if (std::atoi(e) == 0) h->use_flags = false; }
+  }
   if (const char* e = std::getenv("LIODOM_HASH_BUILD")) h->lds_hash_build = std::strcmp(e, "global") != 0;
   v.lds_cells_max = kLdsCellsMax;
   if (const char* e = std::getenv("LIODOM_LDS_CELLS_MAX")) v.lds_cells_max = std::max(1, std::min(kLdsCellsMax, std::atoi(e)));
@@ -587,6 +618,7 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   ALLOC(v.dbg_clk, 8 * 32, 0);
   ALLOC(v.lm_xch, S * 2 * kLmGroupsMax * 64, 0);
   ALLOC(v.pose_xch, S * 32, 0);
+  ALLOC(v.pipe_flags, kEdgePipeBufs + 1, 0);
   v.knn_queries = config->n_streams >= 16 ? 4 : 8;          // must match the k_knn instance launch_odometry picks
   v.knn_partials = config->n_streams >= 16 ? 0 : 1;         // measured: +37 % on the VALU-bound 256-stream kNN pass, -2 us per solve on one stream
   v.knn_blocks = round_up(cdiv(v.edge_cap, v.knn_queries), 4);
@@ -594,9 +626,9 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   ALLOC(v.corr_mask, S * 2 * (size_t)v.knn_blocks, 0);
   {
     void* hp = nullptr;
-    if (hipHostMalloc(&hp, sizeof(HostOut) * S, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { g_last_error = "hipHostMalloc failed"; return fail(LIODOM_ERR_HIP); }
+    if (hipHostMalloc(&hp, sizeof(HostOut) * 2 * S, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { g_last_error = "hipHostMalloc failed"; return fail(LIODOM_ERR_HIP); }
     h->host_out = static_cast<HostOut*>(hp);
-    std::memset(hp, 0, sizeof(HostOut) * S);
+    std::memset(hp, 0, sizeof(HostOut) * 2 * S);
     void* dp = nullptr;
     if (hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) { g_last_error = "hipHostGetDevicePointer failed"; return fail(LIODOM_ERR_HIP); }
     v.host_out = static_cast<HostOut*>(dp);
@@ -651,7 +683,7 @@ void liodom_destroy(liodom_handle_t* h) {
   if (h->host_out) hipHostFree(h->host_out);
   for (auto& e : h->ev_pool) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
   if (h->pose_event) hipEventDestroy(h->pose_event);
-  for (int b = 0; b < 2; b++) { if (h->ev_edges[b]) hipEventDestroy(h->ev_edges[b]); if (h->ev_free[b]) hipEventDestroy(h->ev_free[b]); }
+  for (int b = 0; b < kEdgePipeBufs; b++) { if (h->ev_edges[b]) hipEventDestroy(h->ev_edges[b]); if (h->ev_free[b]) hipEventDestroy(h->ev_free[b]); }
   if (h->stream_x) hipStreamDestroy(h->stream_x);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
@@ -714,12 +746,12 @@ int liodom_get_edges(liodom_handle_t* h, int stream, float* edges_xyzi, int32_t*
   return copy_edges_out(h, stream, h->last_eb, h->stream, edges_xyzi, edge_ring, edge_idx, edge_src, cap, n_edges);
 }
 
-static int wait_pose(liodom_handle_t* h, int s0, int count, double* pose_out, liodom_step_info_t* info) {
+static int wait_pose(liodom_handle_t* h, int s0, int count, double* pose_out, liodom_step_info_t* info, int lag = 0) {
   // zero-copy: k_lm_solve's finalize writes pose + diagnostics into host-mapped memory and
   // releases HostOut.seq; spin on it (an event / memcpy round trip costs ~15 us on this stack)
   for (int i = 0; i < count; i++) {
-    volatile HostOut* ho = h->host_out + s0 + i;
-    const int expect = h->scans_enqueued[s0 + i];
+    const int expect = h->scans_enqueued[s0 + i] - lag;      // lag 1: the scan before the one enqueued last
+    volatile HostOut* ho = h->host_out + (size_t)(s0 + i) * 2 + ((expect - 1) & 1);     // (scan k = expect - 1 publishes into record k & 1)
     unsigned long long spins = 0;
     while (__atomic_load_n(&ho->seq, __ATOMIC_ACQUIRE) != expect) {
       if ((++spins & 0xFFFFull) == 0) {
@@ -728,7 +760,7 @@ static int wait_pose(liodom_handle_t* h, int s0, int count, double* pose_out, li
         if (q == hipSuccess && __atomic_load_n(&ho->seq, __ATOMIC_ACQUIRE) != expect) { g_last_error = "stream drained without publishing the scan result"; return LIODOM_ERR_HIP; }
       }
     }
-    const HostOut* r = h->host_out + s0 + i;
+    const HostOut* r = h->host_out + (size_t)(s0 + i) * 2 + ((expect - 1) & 1);
     if (pose_out) std::memcpy(pose_out + 7 * i, r->pose, sizeof(double) * 7);
     if (info) info[i] = r->info;
   }
@@ -907,19 +939,28 @@ int liodom_process_resident_pipelined(liodom_handle_t* h, int slot, int next_slo
   return replay_one(h, slot, next_slot, n, height, width, poses_out != nullptr || infos_out != nullptr, poses_out, infos_out);
 }
 
-int liodom_replay_resident(liodom_handle_t* h, int first_slot, int count, int ahead, int64_t n, int height, int width,
+int liodom_replay_resident(liodom_handle_t* h, int first_slot, int count, int ahead, int depth, int64_t n, int height, int width,
                            double* poses_out, liodom_step_info_t* infos_out) {
   int rc0 = enter(h);
   if (rc0) return rc0;
-  if (count < 0 || first_slot < 0) { g_last_error = "bad resident range"; return LIODOM_ERR_INVALID_ARG; }
+  if (count < 0 || first_slot < 0 || depth < 0 || depth > 1) { g_last_error = "bad resident range / depth"; return LIODOM_ERR_INVALID_ARG; }
   SideLocks lk(h, true, true);
+  auto out_p = [&](int i) { return poses_out ? poses_out + (size_t)i * h->S * 7 : nullptr; };
+  auto out_i = [&](int i) { return infos_out ? infos_out + (size_t)i * h->S : nullptr; };
   for (int i = 0; i < count; i++) {
     const int slot = first_slot + i;
     const int next = (i + 1 < count || ahead) ? slot + 1 : -1;
-    const int rc = replay_one(h, slot, next, n, height, width, true, poses_out ? poses_out + (size_t)i * h->S * 7 : nullptr,
-                              infos_out ? infos_out + (size_t)i * h->S : nullptr);
+    if (depth == 0) {
+      const int rc = replay_one(h, slot, next, n, height, width, true, out_p(i), out_i(i));
+      if (rc) return rc;
+      continue;
+    }
+    // depth 1: enqueue scan i, then collect the pose of scan i - 1 (its sequence number is one behind the enqueue count)
+    int rc = replay_one(h, slot, next, n, height, width, false, nullptr, nullptr);
     if (rc) return rc;
+    if (i > 0) { rc = wait_pose(h, 0, h->S, out_p(i - 1), out_i(i - 1), 1); if (rc) return rc; }
   }
+  if (depth == 1 && count > 0) { const int rc = wait_pose(h, 0, h->S, out_p(count - 1), out_i(count - 1), 0); if (rc) return rc; }
   return LIODOM_OK;
 }
 
@@ -936,12 +977,21 @@ static int replay_one(liodom_handle_t* h, int slot, int next_slot, int64_t n, in
     if (rc) return rc;
   }
   h->pf_slot = -1;
-  HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_edges[eb], 0));
-  rc = launch_odometry(h, eb, 0, h->S);
-  if (rc) return rc;
-  HIP_TRY(hipEventRecord(h->ev_free[eb], h->stream));
-  h->ev_free_valid[eb] = true;
-  h->parity = eb ^ 1;
+  if (h->use_flags) {
+    // no cross-stream events (they cost ~11 us of idle odometry stream per scan, with the host far ahead as well): the
+    // first kNN launch waits for the extraction's flag and signals that the previous odometry has completed
+    const unsigned int m = ++h->odo_seq == 0 ? ++h->odo_seq : h->odo_seq;
+    rc = launch_odometry(h, eb, 0, h->S, h->eb_seq[eb], m - 1u);
+    if (rc) return rc;
+    h->eb_reader[eb] = m;
+  } else {
+    HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_edges[eb], 0));
+    rc = launch_odometry(h, eb, 0, h->S);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(h->ev_free[eb], h->stream));
+    h->ev_free_valid[eb] = true;
+  }
+  h->parity = (eb + 1) % kEdgePipeBufs;
   if (next_slot >= 0) {                           // overlap the next scan's extraction with this odometry
     rc = issue_extract(h, next_slot, h->parity, (int)n, height, width);
     if (rc) return rc;

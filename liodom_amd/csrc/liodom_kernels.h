@@ -43,8 +43,9 @@ constexpr int kLmCtl = kLmThreads - 64;   // lane 0 of the last wave also runs t
 constexpr int kLmGroupsMax = 8;
 constexpr int kKnnGroup = 32;            // lanes cooperating on one query
 constexpr int kMaxFrames = 256;          // window frames supported by the LDS prefix tables
-constexpr int kEdgeBufs = 3;             // dense edge buffers: 0 / 1 odometry side (double-buffered), 2 extraction side
-constexpr int kEdgeBufX = 2;
+constexpr int kEdgeBufs = 4;             // dense edge buffers: 0 / 1 / 2 odometry side (pipelined replay), 3 extraction side
+constexpr int kEdgePipeBufs = 3;
+constexpr int kEdgeBufX = 3;
 
 // Per-stream device state.
 struct StreamState {
@@ -57,7 +58,7 @@ struct StreamState {
   int32_t append_raw;     // first frame: edges enter the window untransformed (:123)
   int32_t frame_count;    // frames ever appended
   int32_t n_frames;       // frames in the window (nframes_)
-  int32_t n_edges_buf[3]; // edges in edge buffer 0 / 1 (pipelined replay: extraction of scan k+1 overlaps odometry of scan k) / 2 (liodom_extract_edges)
+  int32_t n_edges_buf[4]; // edges in edge buffer 0 / 1 / 2 (pipelined replay: extraction of scan k+1 overlaps odometry of scan k) / 3 (liodom_extract_edges)
   int32_t reb_frame_count; // frame_count as of the scan's first solve: what the early rebuild (k_window_count_old) derives the kept frames from
   int32_t n_map;          // window points covered by the voxel hash
   int32_t n_used_tab[2];  // occupied slots of the cell hash (list used_cells); with early_rebuild one per table (the table searched
@@ -157,7 +158,7 @@ struct DevView {
   float4* sorted_pts;       // [S][map_cap]  xyz + window index bits
   double* pose_log;         // [S][pose_log_cap][7]
   liodom_step_info_t* info_log;  // [S][pose_log_cap]
-  HostOut* host_out;        // [S] host-mapped pinned memory, polled by the host (zero-copy)
+  HostOut* host_out;        // [S][2] host-mapped pinned memory, polled by the host (zero-copy); record of scan k = k & 1
   // filter_local_map: voxel grouping of the window and the filtered cloud
   CellSlot* vox_cells;      // [S][table_size] key = PCL voxel index
   unsigned int* vox_fill;   // [S][table_size]
@@ -175,6 +176,8 @@ struct DevView {
   int sorted_cap;           // sorted_pts entries per table (early_rebuild: map_cap + 8 edge_cap of padding + edge_cap of overflow list; else map_cap)
   int ovf_base;             // first entry of the overflow list inside a table's sorted_pts
   float rebuild_delta;      // early_rebuild: a new-frame point may move this far (per axis) between the prediction and the solved pose and still land in a padded cell
+  unsigned int* pipe_flags; // [kEdgePipeBufs + 1] pipelined replay without cross-stream events: [b] = sequence number of the extraction whose edges
+                            // are complete in edge buffer b; [kEdgePipeBufs] = number of the last odometry (of this handle) that has completed entirely
   unsigned long long* pose_xch;   // [S][32] early_rebuild: solved pose handed to the workgroups that append the new frame (tagged 8-byte granules)
   int early_rebuild;        // streamed rebuild: extra workgroups of the scan's four launches build the next scan's cell hash in the
                             // second table ("Streamed rebuild" below); no k_window_insert / k_hash_alloc / k_hash_scatter launches
@@ -827,15 +830,40 @@ __global__ __launch_bounds__(kMaxThreads) void k_ring_extract(DevView v, int s0)
 }
 
 // =============================================================================================
+// Pipelined replay: the two HIP streams of a handle (extraction / odometry) depend on each other twice per scan.  As
+// hipStreamWaitEvent / hipEventRecord pairs those dependencies cost ~11 us of idle odometry stream per scan (the barrier
+// packets are processed when the preceding kernel retires, measured with the host far ahead as well); as flags in
+// device memory they cost one early load per workgroup.  A flag is written by a kernel that follows the producer in
+// stream order (so the producer's launch has ended and its writes have left the caches) and polled by thread 0 of the
+// consumer's workgroups before they touch the data; a consumer that really had to wait also invalidates its caches.
+__device__ __forceinline__ void pipe_wait(const unsigned int* flag, unsigned int want) {
+  typedef __attribute__((address_space(1))) unsigned int gu32;
+  if (threadIdx.x == 0) {
+    unsigned int spins = 0;
+    while ((int)(__hip_atomic_load((gu32*)flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > 40000000u) break;       // (bounded; a lost producer shows up as wrong results in the parity checks, not as a hang)
+    }
+    if (spins) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+}
+__global__ void k_set_flag(unsigned int* flag, unsigned int value) {
+  typedef __attribute__((address_space(1))) unsigned int gu32;
+  __hip_atomic_store((gu32*)flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // k_compact_edges: one workgroup per stream; ring-padded edges -> dense edge cloud (edge buffer
 // `eb`) in the reference's output order.
 // =============================================================================================
 // grid (kCompactBlocks, streams): every workgroup scans the <= 256 ring counts itself (cheaper than a
 // second launch) and copies its interleaved share of the edges.
 constexpr int kCompactBlocks = 8;
-__global__ __launch_bounds__(256) void k_compact_edges(DevView v, int s0, int eb) {
+__global__ __launch_bounds__(256) void k_compact_edges(DevView v, int s0, int eb, unsigned int wait_odo) {
   __shared__ int pre[257];
   __shared__ int cntr[256];
+  // (pipelined replay) the odometry that last read edge buffer eb must have completed before it is rewritten
+  if (wait_odo) pipe_wait(v.pipe_flags + kEdgePipeBufs, wait_odo);
   const int s = s0 + blockIdx.y;
   const int H = v.scan_lines;
   const int* rn = v.ring_nedges + (size_t)s * H;
@@ -1053,7 +1081,7 @@ __device__ __forceinline__ void top5_clear(Top5& t) {
 __device__ void rebuild_alloc(const DevView& v, int s, StreamState& st, int block, int nblocks);
 
 template <int kKnnThreads>
-__global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int outer_it, int eb) {
+__global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int outer_it, int eb, unsigned int wait_edges, unsigned int signal_odo) {
   constexpr int kKnnQueries = kKnnThreads / kKnnGroup;
   __shared__ int s_incl[kKnnQueries][kKnnGroup];   // inclusive candidate prefix per cell
   __shared__ int s_adj[kKnnQueries][kKnnGroup];    // cell start - exclusive prefix
@@ -1070,6 +1098,15 @@ __global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int oute
     // streamed rebuild, bookkeeping before the first builders start (next launch): the frame count the build refers to
     // (the finalising solve advances it beside them) and an empty list of occupied slots for the table being built
     if (outer_it == 0 && bxi == 0 && threadIdx.x == 0) { st.reb_frame_count = st.frame_count; st.n_used_tab[(st.frame_count + 1) & 1] = 0; }
+  }
+  if (outer_it == 0) {
+    // (pipelined replay) this launch follows odometry `signal_odo` in stream order: that odometry has completed entirely;
+    // and the extraction that fills edge buffer eb (other stream) must have completed before anything of it is read
+    if (signal_odo && bxi == 0 && byi == 0 && threadIdx.x == 0) {
+      typedef __attribute__((address_space(1))) unsigned int gu32;
+      __hip_atomic_store((gu32*)(v.pipe_flags + kEdgePipeBufs), signal_odo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (wait_edges) pipe_wait(v.pipe_flags + eb, wait_edges);
   }
   if (!st.initialized) return;                     // uniform over the workgroup
   const int E = st.n_edges_buf[eb];
@@ -1597,7 +1634,7 @@ __device__ void finalize_scan(const DevView& v, int s, StreamState& st, int* sh_
     st.scan_counter = k + 1;
     if (v.host_out) {
       // zero-copy publication: payload, system-scope fence, then the sequence word the host polls
-      HostOut* ho = v.host_out + s;
+      HostOut* ho = v.host_out + (size_t)s * 2 + (k & 1);      // two records per stream: the host may read scan k while scan k + 1 publishes
       ho->pose[0] = q[0]; ho->pose[1] = q[1]; ho->pose[2] = q[2]; ho->pose[3] = q[3];
       ho->pose[4] = st.final_odom[3]; ho->pose[5] = st.final_odom[7]; ho->pose[6] = st.final_odom[11];
       ho->info = st.info;

@@ -672,6 +672,11 @@ def test_replay_resident_loop_equals_per_call_replay(orc, synth):
     got = np.concatenate([p1, p2])
     assert np.array_equal(got.view(np.uint64), np.array(ref).view(np.uint64))
     assert [i.scan_index for i in list(i1) + list(i2)] == list(range(K))
+    # depth 1: odometry submitted one scan ahead of the readback — same poses, same order
+    g.reset()
+    p3, i3 = g.replay_resident(0, K, H * W, H, W, depth=1)
+    assert np.array_equal(p3.view(np.uint64), np.array(ref).view(np.uint64))
+    assert [i.scan_index for i in i3] == list(range(K))
     g.close()
 
 
