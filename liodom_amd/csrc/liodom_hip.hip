@@ -509,13 +509,15 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   if (const char* e = std::getenv("LIODOM_GRAPH")) h->use_graph = std::atoi(e) != 0;
   {
     // Flags instead of events between the extraction and the odometry stream: the first kNN launch of a scan polls the
-    // extraction's flag in every workgroup, so all its workgroups must fit on the GPU with room to spare for the
-    // extraction kernels they may be waiting for — one stream only, and at most 24 of the ~28 wave slots per CU.
+    // extraction's flag in every workgroup, so all its workgroups must fit on the GPU with ample room left for the
+    // extraction kernels they may be waiting for (512-thread workgroups): one stream only, and at most 12 of the 24
+    // wave slots per CU the kernel's 74 VGPRs allow — HDL-64 (2 816 waves of 3 072) qualifies, Ouster-128 (5 632) does
+    // not: with 24 it starved the extraction in the non-pipelined replay until the bounded waits gave up.
     // (Lock-step batches are throughput-bound: 11 us per multi-millisecond step do not matter there.)
     int cus = 0;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, config->device);
     const int ecap = round_up(std::max(1, params->scan_lines * params->scan_regions * (params->edges_per_region + 1)), 64);
-    h->use_flags = !h->use_graph && config->n_streams == 1 && cdiv(ecap, 8) * 4 <= cus * 24;
+    h->use_flags = !h->use_graph && config->n_streams == 1 && cdiv(ecap, 8) * 4 <= cus * 12;
     if (const char* e = std::getenv("LIODOM_PIPE_FLAGS")) { if (std::atoi(e) == 0) h->use_flags = false; }
   }
   if (const char* e = std::getenv("LIODOM_HASH_BUILD")) h->lds_hash_build = std::strcmp(e, "global") != 0;

@@ -836,13 +836,15 @@ __global__ __launch_bounds__(kMaxThreads) void k_ring_extract(DevView v, int s0)
 // device memory they cost one early load per workgroup.  A flag is written by a kernel that follows the producer in
 // stream order (so the producer's launch has ended and its writes have left the caches) and polled by thread 0 of the
 // consumer's workgroups before they touch the data; a consumer that really had to wait also invalidates its caches.
-__device__ __forceinline__ void pipe_wait(const unsigned int* flag, unsigned int want) {
+// The wait is bounded (~0.3 s): a producer that cannot run beside the consumer — a profiler that serialises kernels across
+// streams, e.g. rocprofv3 --pmc: use LIODOM_PIPE_FLAGS=0 there — raises LIODOM_STATUS_LM_SYNC_TIMEOUT instead of hanging.
+__device__ __forceinline__ void pipe_wait(const unsigned int* flag, unsigned int want, unsigned int* status) {
   typedef __attribute__((address_space(1))) unsigned int gu32;
   if (threadIdx.x == 0) {
     unsigned int spins = 0;
     while ((int)(__hip_atomic_load((gu32*)flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
       __builtin_amdgcn_s_sleep(8);
-      if (++spins > 40000000u) break;       // (bounded; a lost producer shows up as wrong results in the parity checks, not as a hang)
+      if (++spins > 1500000u) { atomicOr(status, LIODOM_STATUS_LM_SYNC_TIMEOUT); break; }
     }
     if (spins) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
@@ -863,7 +865,7 @@ __global__ __launch_bounds__(256) void k_compact_edges(DevView v, int s0, int eb
   __shared__ int pre[257];
   __shared__ int cntr[256];
   // (pipelined replay) the odometry that last read edge buffer eb must have completed before it is rewritten
-  if (wait_odo) pipe_wait(v.pipe_flags + kEdgePipeBufs, wait_odo);
+  if (wait_odo) pipe_wait(v.pipe_flags + kEdgePipeBufs, wait_odo, &v.state[s0 + blockIdx.y].status);
   const int s = s0 + blockIdx.y;
   const int H = v.scan_lines;
   const int* rn = v.ring_nedges + (size_t)s * H;
@@ -1106,7 +1108,7 @@ __global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int oute
       typedef __attribute__((address_space(1))) unsigned int gu32;
       __hip_atomic_store((gu32*)(v.pipe_flags + kEdgePipeBufs), signal_odo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (wait_edges) pipe_wait(v.pipe_flags + eb, wait_edges);
+    if (wait_edges) pipe_wait(v.pipe_flags + eb, wait_edges, &st.status);
   }
   if (!st.initialized) return;                     // uniform over the workgroup
   const int E = st.n_edges_buf[eb];

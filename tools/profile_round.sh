@@ -29,12 +29,15 @@ DB=$(find $OUT/prof_kt -name "*.db" | head -1)
 { echo "# $TAG: rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 100 --warmup 20 --batched-streams 0 --no-cpu-baseline";
   echo "# 64x1800, R=8, epr=10, P=20, 1 stream; legs: timed (pipelined) + HIP-event + async + serial => 4 x 120 scans";
   python3 $R/tools/rocprof_summary.py $DB; } > $OUT/${TAG}_bench_kernel_trace.txt
-timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/prof_fetch -- python3 $R/bench.py --steps 40 --warmup 20 --batched-streams 16 --no-cpu-baseline > /dev/null 2> $OUT/fetch.stderr
-timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/prof_write -- python3 $R/bench.py --steps 40 --warmup 20 --batched-streams 16 --no-cpu-baseline > /dev/null 2> $OUT/write.stderr
+# (--pmc serialises kernels across streams: the flag-based stream dependencies cannot make progress there; use the event path)
+export LIODOM_PIPE_FLAGS=0
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/prof_fetch -- python3 $R/bench.py --steps 40 --warmup 20 --batched-streams 16 --no-cpu-baseline > /dev/null 2> $OUT/fetch.stderr
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/prof_write -- python3 $R/bench.py --steps 40 --warmup 20 --batched-streams 16 --no-cpu-baseline > /dev/null 2> $OUT/write.stderr
 FD=$(dirname $(find $OUT/prof_fetch -name "*.db" | head -1))
 WD=$(dirname $(find $OUT/prof_write -name "*.db" | head -1))
 { echo "# $TAG: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 40 --warmup 20 --batched-streams 16 --no-cpu-baseline";
   echo "# small grid = 1 stream (headline), large grid = 16 lock-step streams. Per-launch averages.";
   python3 $R/tools/pmc_summary.py $FD $WD $OUT/${TAG}_pmc_traffic.json; } > $OUT/${TAG}_pmc_traffic.txt
+unset LIODOM_PIPE_FLAGS
 rm -rf $OUT/prof_kt $OUT/prof_fetch $OUT/prof_write
 tail -3 $OUT/${TAG}_pytest_gpu.log 2>/dev/null; cat $OUT/${TAG}_bench.json | head -c 600; echo; head -14 $OUT/${TAG}_bench_kernel_trace.txt; head -30 $OUT/${TAG}_pmc_traffic.txt
