@@ -96,6 +96,7 @@ struct liodom_handle {
   std::vector<OdoGraph> odo_graphs;
   bool use_graph = false;
   bool use_flags = false;       // pipelined replay: dependencies between the two streams through flags in device memory instead of events
+  bool flag_gate = false;       // ... polled by a one-wave gate launch in front of the scan's first k_knn launch instead of by that launch itself
   std::vector<EventPair> ev_pool;
   size_t ev_used = 0;
   double k_ms[LIODOM_NUM_KERNELS] = {0};
@@ -517,7 +518,8 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
     int cus = 0;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, config->device);
     const int ecap = round_up(std::max(1, params->scan_lines * params->scan_regions * (params->edges_per_region + 1)), 64);
-    h->use_flags = !h->use_graph && config->n_streams == 1 && cdiv(ecap, 8) * 4 <= cus * 12;
+    h->use_flags = !h->use_graph && config->n_streams < 16;
+    h->flag_gate = !(config->n_streams == 1 && cdiv(ecap, 8) * 4 <= cus * 12);     // (larger launches: a one-wave gate launch polls instead)
     if (const char* e = std::getenv("LIODOM_PIPE_FLAGS")) { if (std::atoi(e) == 0) h->use_flags = false; }
   }
   if (const char* e = std::getenv("LIODOM_HASH_BUILD")) h->lds_hash_build = std::strcmp(e, "global") != 0;
@@ -983,7 +985,12 @@ static int replay_one(liodom_handle_t* h, int slot, int next_slot, int64_t n, in
     // no cross-stream events (they cost ~11 us of idle odometry stream per scan, with the host far ahead as well): the
     // first kNN launch waits for the extraction's flag and signals that the previous odometry has completed
     const unsigned int m = ++h->odo_seq == 0 ? ++h->odo_seq : h->odo_seq;
-    rc = launch_odometry(h, eb, 0, h->S, h->eb_seq[eb], m - 1u);
+    if (h->flag_gate) {
+      hipLaunchKernelGGL(k_pipe_gate, dim3(1), dim3(64), 0, h->stream, h->v, 0, eb, h->eb_seq[eb], m - 1u);
+      rc = launch_odometry(h, eb, 0, h->S);
+    } else {
+      rc = launch_odometry(h, eb, 0, h->S, h->eb_seq[eb], m - 1u);
+    }
     if (rc) return rc;
     h->eb_reader[eb] = m;
   } else {

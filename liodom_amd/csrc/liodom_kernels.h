@@ -850,6 +850,14 @@ __device__ __forceinline__ void pipe_wait(const unsigned int* flag, unsigned int
   }
   __syncthreads();
 }
+// Gate in front of a scan's first k_knn launch for handles whose launch is too large to poll the flag itself (its polling
+// workgroups would fill the GPU and starve the extraction they wait for): one wave waits for the extraction's flag and
+// publishes that the previous odometry has completed; the launches behind it start when it retires.
+__global__ void k_pipe_gate(DevView v, int s0, int eb, unsigned int wait_edges, unsigned int signal_odo) {
+  typedef __attribute__((address_space(1))) unsigned int gu32;
+  if (signal_odo && threadIdx.x == 0) __hip_atomic_store((gu32*)(v.pipe_flags + kEdgePipeBufs), signal_odo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (wait_edges) pipe_wait(v.pipe_flags + eb, wait_edges, &v.state[s0].status);
+}
 __global__ void k_set_flag(unsigned int* flag, unsigned int value) {
   typedef __attribute__((address_space(1))) unsigned int gu32;
   __hip_atomic_store((gu32*)flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
