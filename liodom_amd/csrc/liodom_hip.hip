@@ -255,7 +255,8 @@ int enqueue_odometry(liodom_handle* h, int eb, int s0, int count, unsigned int w
       ProfScope ps(h, KID_LM);
       // it 0: + COUNT, PAD; it 1: + APPEND, CLEAR, SCATTER
       const int extra = !early ? 0 : (it == 0 ? nC + nP : nP + kRebuildAuxBlocks + nC);
-      hipLaunchKernelGGL(k_lm_solve, dim3(h->v.lm_groups + extra, count), dim3(kLmThreads), lm_lds_bytes(h->v.edge_cap), h->stream, v, s0, it, eb);
+      const int gx = std::max(h->v.lm_groups + extra, (h->v.lm_groups - 1) * 8 + 1);      // solvers on blocks 0, 8, 16, ... (one XCD)
+      hipLaunchKernelGGL(k_lm_solve, dim3(gx, count), dim3(kLmThreads), lm_lds_bytes(h->v.edge_cap), h->stream, v, s0, it, eb);
     }
   }
   if (v.mapping) {

@@ -1682,49 +1682,67 @@ __device__ void finalize_scan(const DevView& v, int s, StreamState& st, int* sh_
 
 // All-to-all exchange of the 29 partial sums between the G workgroups of a stream, inside the
 // launch (MI355X guide, G16 form R2: the data is the flag).  Every double travels as two 8-byte
-// granules {epoch tag, 32 data bits} written and read with relaxed agent-scope atomics (sc1, L2
-// write-through / L1 bypass): no fences, no separate flag, placement independent.  Buffers are
+// granules {epoch tag, 32 data bits}: no fences, no separate flag.  Buffers are
 // double-buffered by epoch parity (a workgroup cannot publish epoch e+2 before it has read every
 // epoch e+1, which the others publish only after reading epoch e).  Every workgroup adds the G
 // partials in the same order and so continues with bit-identical totals.  Spins are bounded.
+// Two transports: (memory side, placement independent) relaxed agent-scope stores — sc1, write-through, the line
+// leaves the XCD's L2 — and agent-scope loads, ~2-3 us per exchange under load; (local) when the G workgroups sit on
+// ONE XCD — they are launched on block indices 0, 8, 16, ... which the dispatcher hands to the same XCD, and every
+// exchange carries the workgroups' XCC ids so that this is verified, never assumed — plain stores keep the granules in
+// that XCD's L2, where the L1-bypassing loads of the others find them.  The first exchange of a launch always takes the
+// memory-side transport and tells whether the later ones may go local.
+__device__ __forceinline__ unsigned int xcc_id() { return (unsigned int)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 0xFu; }   // HW_REG_XCC_ID[3:0]
 __device__ void lm_exchange(const DevView& v, int s, int g, int G, unsigned int epoch,
-                            const double* acc_local, double* acc_total, unsigned int* status) {
+                            const double* acc_local, double* acc_total, unsigned int* status, bool local, int* same_xcc /*LDS*/) {
   typedef __attribute__((address_space(1))) unsigned long long gu64;
   unsigned long long* base = v.lm_xch + ((size_t)s * 2 + (epoch & 1u)) * kLmGroupsMax * 64;
   const int tid = threadIdx.x;
-  if (tid < 2 * kAccN) {
-    const unsigned long long bits = (unsigned long long)__double_as_longlong(acc_local[tid >> 1]);
-    const unsigned long long half = (tid & 1) ? (bits >> 32) : (bits & 0xFFFFFFFFull);
-    __hip_atomic_store((gu64*)(base + g * 64 + tid), ((unsigned long long)epoch << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid <= 2 * kAccN) {
+    unsigned long long half;
+    if (tid < 2 * kAccN) {
+      const unsigned long long bits = (unsigned long long)__double_as_longlong(acc_local[tid >> 1]);
+      half = (tid & 1) ? (bits >> 32) : (bits & 0xFFFFFFFFull);
+    } else {
+      half = xcc_id();                                   // granule 58: where this workgroup runs
+    }
+    const unsigned long long word = ((unsigned long long)epoch << 32) | half;
+    if (local) __hip_atomic_store((gu64*)(base + g * 64 + tid), word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // plain store: stays in the XCD's L2
+    else __hip_atomic_store((gu64*)(base + g * 64 + tid), word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (tid < 64) {
     double tot = 0.0;
     unsigned int spins = 0;
+    bool same = true;
     while (true) {
       bool ok = true;
       tot = 0.0;
-      if (tid < kAccN) {
+      same = true;
+      if (tid <= kAccN) {
         // all 2 G loads in flight at once (a loop over the runtime G waits for every pair: G round trips per poll)
         unsigned long long lo[kLmGroupsMax], hi[kLmGroupsMax];
+        const int i0 = tid < kAccN ? 2 * tid : 2 * kAccN, i1 = tid < kAccN ? 2 * tid + 1 : 2 * kAccN;   // lane 29: the XCC ids
 #pragma unroll
         for (int gg = 0; gg < kLmGroupsMax; gg++) {
           const int gq = gg < G ? gg : 0;
-          lo[gg] = __hip_atomic_load((gu64*)(base + gq * 64 + 2 * tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          hi[gg] = __hip_atomic_load((gu64*)(base + gq * 64 + 2 * tid + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          lo[gg] = __hip_atomic_load((gu64*)(base + gq * 64 + i0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          hi[gg] = __hip_atomic_load((gu64*)(base + gq * 64 + i1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
 #pragma unroll
         for (int gg = 0; gg < kLmGroupsMax; gg++) {
           if (gg < G) {
             ok = ok && ((unsigned int)(lo[gg] >> 32) == epoch) && ((unsigned int)(hi[gg] >> 32) == epoch);
             tot += __longlong_as_double((long long)((hi[gg] << 32) | (lo[gg] & 0xFFFFFFFFull)));
+            same = same && ((unsigned int)lo[gg] == (unsigned int)lo[0]);
           }
         }
       }
       if (__all(ok)) break;
-      if (++spins > 4000000u) { if (tid == 0) atomicOr(status, LIODOM_STATUS_LM_SYNC_TIMEOUT); break; }
+      if (++spins > 4000000u) { if (tid == 0) atomicOr(status, LIODOM_STATUS_LM_SYNC_TIMEOUT); same = false; break; }
       __builtin_amdgcn_s_sleep(1);
     }
     if (tid < kAccN) acc_total[tid] = tot;
+    if (tid == kAccN) *same_xcc = same ? 1 : 0;
   }
   __syncthreads();
 }
@@ -1772,10 +1790,16 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
   __shared__ int sh_flag;
   __shared__ int sh_C;
   const int s = s0 + blockIdx.y;
-  const int g = blockIdx.x, G = v.lm_groups;    // G cooperating workgroups per stream
+  // G cooperating workgroups per stream, on block indices 0, 8, 16, ... when G > 1 (workgroups are handed to the XCDs
+  // round-robin by linear index, so these share an XCD — see lm_exchange); every other block is a rebuild workgroup
+  const int G = v.lm_groups, gstride = G > 1 ? 8 : 1, bxl = (int)blockIdx.x;
+  const bool is_solver = bxl < G * gstride && (bxl % gstride) == 0;
+  const int g = is_solver ? bxl / gstride : G + (bxl < G * gstride ? bxl - (bxl / gstride + 1) : bxl - G);
   StreamState& st = v.state[s];
   __shared__ int sh_cnt[kMaxFrames + 1];
+  __shared__ int sh_same_xcc;
   if (g >= G) {
+    if (!v.early_rebuild) return;                  // (filler blocks between the solvers)
     // early_rebuild: the workgroups behind the solve build the next cell hash (see "streamed rebuild" below)
     __shared__ int sh_slot[kMaxFrames];
     rebuild_beside_solve(v, s, st, eb, outer_it, g - G, sh_cnt, sh_slot);
@@ -1819,6 +1843,7 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
   const int nblocks = st.info.matches[outer_it];
   const unsigned int epoch0 = ((unsigned int)(st.scan_counter + 1) << 6) | ((unsigned int)outer_it << 5);
   unsigned int n_eval = 0;
+  bool xch_local = false;       // the G workgroups were seen on one XCD: exchanges through its L2 (lm_exchange)
   LmCache cache;
   int c_lo = 0, c_hi = 0;
   auto my_share = [&](int C) {                           // this workgroup's contiguous share of the compacted blocks
@@ -1863,7 +1888,7 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
     __syncthreads();
     my_share(sh_C);
     lm_cache_load(v, s, eb, c_lo, c_hi, sh_idx, cache);
-    if (G > 1) { lm_eval(v, s, eb, c_lo, c_hi, sh_idx, sh_pose, sh_part, sh_loc, cache); lm_exchange(v, s, g, G, epoch0 | ++n_eval, sh_loc, sh_acc, &st.status); }
+    if (G > 1) { lm_eval(v, s, eb, c_lo, c_hi, sh_idx, sh_pose, sh_part, sh_loc, cache); lm_exchange(v, s, g, G, epoch0 | ++n_eval, sh_loc, sh_acc, &st.status, xch_local, &sh_same_xcc); xch_local = sh_same_xcc != 0; }
     else lm_eval(v, s, eb, c_lo, c_hi, sh_idx, sh_pose, sh_part, sh_acc, cache);
   }
   DBG_STAMP(v, dbgb, 2, 2);
@@ -1896,12 +1921,13 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
     if (step == 0) { if (v.knn_partials && !prep) my_share(sh_C); DBG_STAMP(v, dbgb, 2, 3); }
     else { DBG_STAMP(v, dbgb && dbg_it < 5, 2, 5 + 2 * dbg_it); dbg_it++; }
     if (sh_flag != LM_NEED_EVAL) break;
-    if (G > 1) { lm_eval(v, s, eb, c_lo, c_hi, sh_idx, sh_pose, sh_part, sh_loc, cache); lm_exchange(v, s, g, G, epoch0 | ++n_eval, sh_loc, sh_acc, &st.status); }
+    if (G > 1) { lm_eval(v, s, eb, c_lo, c_hi, sh_idx, sh_pose, sh_part, sh_loc, cache); DBG_STAMP(v, dbgb && dbg_it < 4, 2, 12 + dbg_it); lm_exchange(v, s, g, G, epoch0 | ++n_eval, sh_loc, sh_acc, &st.status, xch_local, &sh_same_xcc); xch_local = sh_same_xcc != 0 && !(v.debug & 16); }
     else lm_eval(v, s, eb, c_lo, c_hi, sh_idx, sh_pose, sh_part, sh_acc, cache);
     DBG_STAMP(v, dbgb && dbg_it < 5, 2, 4 + 2 * dbg_it);
   }
   if (clr_pending) clear_hash_slots();                   // (the solve ended at its first step)
   DBG_STAMP(v, dbgb, 2, 20);
+  if ((v.debug & 32) && dbgb) v.dbg_clk[2 * 32 + 27] = (xch_local ? 100ull : 0ull) + 10ull * xcc_id() + (unsigned long long)n_eval;   // (debug) exchange transport, XCC, evaluations
   if (g != 0) return;        // every workgroup reached the same result; workgroup 0 records it
   if (tid == kLmCtl) {
     for (int k = 0; k < 4; k++) st.param_q[k] = lm.q[k];

@@ -207,6 +207,8 @@ def sec_clocks(H=64, W=1800, R=8, epr=10, P=20, K=40):
              1: ["start", "query ready", "hash probed", "centre streamed", "merge1", "phase2 done", "nn fetched", "gate done"],
              2: ["start", "pose ready", "eval0", "begin", "eval1", "upd1", "eval2", "upd2", "eval3", "upd3", "eval4", "upd4", "", "", "", "", "", "", "", "", "loop end", "pose written", "finalized", "", "", "", "", "", "(solving workgroup done)", "appender 0: pose received", "appender 0: point placed"]}
     r2 = a[2]
+    print("k_lm_solve (it 1) evaluation done / exchange done (us after kernel start):", [(round((int(allv[64 + 12 + i]) - int(allv[64])) / 100.0, 2), round((int(allv[64 + 4 + 2 * i]) - int(allv[64])) / 100.0, 2)) for i in range(1, 4)])
+    print("k_lm_solve (it 1) exchange: local transport %d, XCC %d, evaluations %d" % (int(allv[64 + 27]) // 100, (int(allv[64 + 27]) // 10) % 10, int(allv[64 + 27]) % 10))
     print("k_lm_solve begin phase: controller lm_begin done at %.2f us; evaluator wave 1: start %.2f, compacted %.2f (us after kernel start)" % tuple((r2[i] - r2[0]) / 100.0 for i in (23, 24, 25)))
     for k, kn in ((0, "k_ring_extract (ring 40)"), (1, "k_knn (block 20, it 0)"), (2, "k_lm_solve (it 1)")):
         row = a[k]
