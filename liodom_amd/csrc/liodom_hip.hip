@@ -248,8 +248,12 @@ int enqueue_odometry(liodom_handle* h, int eb, int s0, int count, unsigned int w
     {
       ProfScope ps(h, KID_KNN);
       const int kx = knn_blocks + ((early && it == 1) ? kRebuildAuxBlocks : 0);     // it 1: + ALLOC
-      if (knn_small) hipLaunchKernelGGL(k_knn<128>, dim3(kx, count), dim3(128), 0, h->stream, v, s0, it, eb, wait_edges, signal_odo);
-      else hipLaunchKernelGGL(k_knn<256>, dim3(kx, count), dim3(256), 0, h->stream, v, s0, it, eb, wait_edges, signal_odo);
+      if (knn_small) {
+        hipLaunchKernelGGL(k_knn<128>, dim3(kx, count), dim3(128), 0, h->stream, v, s0, it, eb, wait_edges, signal_odo);
+        if (v.knn_nn) hipLaunchKernelGGL(k_line_gate, dim3(cdiv(h->v.knn_blocks * h->v.knn_queries, 256), count), dim3(256), 0, h->stream, v, s0, it, eb);
+      } else {
+        hipLaunchKernelGGL(k_knn<256>, dim3(kx, count), dim3(256), 0, h->stream, v, s0, it, eb, wait_edges, signal_odo);
+      }
     }
     {
       ProfScope ps(h, KID_LM);
@@ -624,6 +628,11 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   ALLOC(v.lm_xch, S * 2 * kLmGroupsMax * 64, 0);
   ALLOC(v.pose_xch, S * 32, 0);
   ALLOC(v.pipe_flags, kEdgePipeBufs + 1, 0);
+  {
+    bool gate_kernel = config->n_streams >= 16;         // lock-step batches: line gates in their own launch (k_line_gate)
+    if (const char* e = std::getenv("LIODOM_GATE_KERNEL")) gate_kernel = gate_kernel && std::atoi(e) != 0;
+    if (gate_kernel) ALLOC(v.knn_nn, S * (size_t)v.edge_cap * 5, 0); else v.knn_nn = nullptr;
+  }
   v.knn_queries = config->n_streams >= 16 ? 4 : 8;          // must match the k_knn instance launch_odometry picks
   v.knn_partials = config->n_streams >= 16 ? 0 : 1;         // measured: +37 % on the VALU-bound 256-stream kNN pass, -2 us per solve on one stream
   v.knn_blocks = round_up(cdiv(v.edge_cap, v.knn_queries), 4);

@@ -176,6 +176,7 @@ struct DevView {
   int sorted_cap;           // sorted_pts entries per table (early_rebuild: map_cap + 8 edge_cap of padding + edge_cap of overflow list; else map_cap)
   int ovf_base;             // first entry of the overflow list inside a table's sorted_pts
   float rebuild_delta;      // early_rebuild: a new-frame point may move this far (per axis) between the prediction and the solved pose and still land in a padded cell
+  float4* knn_nn;           // [S][edge_cap][5] lock-step batches: the five neighbours of every query (w: found flag, index of NN0, NN1) for k_line_gate
   unsigned int* pipe_flags; // [kEdgePipeBufs + 1] pipelined replay without cross-stream events: [b] = sequence number of the extraction whose edges
                             // are complete in edge buffer b; [kEdgePipeBufs] = number of the last odometry (of this handle) that has completed entirely
   unsigned long long* pose_xch;   // [S][32] early_rebuild: solved pose handed to the workgroups that append the new frame (tagged 8-byte granules)
@@ -1351,6 +1352,20 @@ __global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int oute
   }
   __syncthreads();
   DBG_STAMP(v, dbgb, 1, 6);
+  if (kKnnThreads < 256 && v.knn_nn) {
+    // Lock-step batches (VALU-issue bound): the line gates of a workgroup's four queries would occupy a whole wave's
+    // instruction stream for four lanes.  The neighbours go to memory instead (80 B per query) and k_line_gate runs
+    // the gates with one query per lane on full waves.
+    if (threadIdx.x < kKnnQueries * 5) {
+      const int q = threadIdx.x / 5, j = threadIdx.x % 5;
+      const int eq = bxi * kKnnQueries + q;
+      if (eq < v.edge_cap) {
+        const int w = j == 0 ? s_res[q][0] : (j == 1 ? s_res[q][1] : (j == 2 ? s_res[q][2] : 0));
+        v.knn_nn[((size_t)s * v.edge_cap + eq) * 5 + j] = make_float4(s_nn[q][j * 3], s_nn[q][j * 3 + 1], s_nn[q][j * 3 + 2], __int_as_float(w));
+      }
+    }
+    return;
+  }
   // Line gate (:325-344): one lane per query, so the FP64 eigenvalue iteration runs once per 32
   // queries instead of once per query.
   if (threadIdx.x < kKnnQueries) {
@@ -1434,6 +1449,53 @@ __global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int oute
     const int bin = (int)(d / 100ull);
     atomicAdd(&v.dbg_clk[192 + (bin < 63 ? bin : 63)], 1ull);
   }
+}
+
+// k_line_gate (lock-step batches): the line gate of laser_odometry.cc:325-344 for the queries of one kNN pass, one query
+// per lane; writes the correspondences (:351-357), counts the matches (:346) and leaves the validity bytes the solve's
+// compaction reads (bit q of byte b = query q of k_knn workgroup b).
+__global__ __launch_bounds__(256) void k_line_gate(DevView v, int s0, int outer_it, int eb) {
+  const int s = s0 + blockIdx.y;
+  StreamState& st = v.state[s];
+  if (!st.initialized) return;
+  const int E = st.n_edges_buf[eb];
+  const int eq = blockIdx.x * 256 + threadIdx.x;
+  const int Q = v.knn_queries;
+  if (eq >= v.knn_blocks * Q) return;                   // (whole waves: knn_blocks * Q is a multiple of 16... see below)
+  float nx[5], ny[5], nz[5];
+  int found = 0, i0 = -1, i1 = -1;
+  if (eq < E) {
+    const float4* k = v.knn_nn + ((size_t)s * v.edge_cap + eq) * 5;
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+      const float4 m = k[j];
+      nx[j] = m.x; ny[j] = m.y; nz[j] = m.z;
+      if (j == 0) found = __float_as_int(m.w);
+      if (j == 1) i0 = __float_as_int(m.w);
+      if (j == 2) i1 = __float_as_int(m.w);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 5; j++) { nx[j] = 0.f; ny[j] = 0.f; nz[j] = 0.f; }
+  }
+  bool valid = (eq < E) && (found != 0);
+  if (valid && !(v.debug & 2)) valid = line_gate(nx, ny, nz);
+  if (eq < E) {
+    float4* ca = v.corr_a + (size_t)s * v.edge_cap + eq;
+    float4* cb = v.corr_b + (size_t)s * v.edge_cap + eq;
+    int2* cidx = v.corr_idx + ((size_t)s * 2 + outer_it) * v.edge_cap + eq;
+    if (valid) {
+      *ca = make_float4(nx[0], ny[0], nz[0], 1.0f);              // :351-353
+      *cb = make_float4(nx[1], ny[1], nz[1], 0.0f);              // :355-357
+      *cidx = make_int2(i0, i1);
+    } else {
+      *ca = make_float4(0, 0, 0, 0); *cb = make_float4(0, 0, 0, 0); *cidx = make_int2(-1, -1);
+    }
+  }
+  const unsigned long long vb = __ballot(valid);
+  const int lane = threadIdx.x & 63;
+  if (lane == 0) { const int nvalid = __popcll(vb); if (nvalid) atomicAdd(&st.info.matches[outer_it], nvalid); }   // :346
+  if ((lane % Q) == 0) v.corr_mask[((size_t)s * 2 + outer_it) * v.knn_blocks + eq / Q] = (unsigned char)((vb >> lane) & ((1ull << Q) - 1ull));
 }
 
 // =============================================================================================

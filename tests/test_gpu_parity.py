@@ -733,3 +733,31 @@ def test_streamed_rebuild_tiny_windows(orc, synth, monkeypatch, P):
         assert np.array_equal(a[0].view(np.uint64), b[0].view(np.uint64)) and a[1] == b[1] and a[3] == b[3], (P, k)
         assert np.array_equal(a[2].view(np.uint32), b[2].view(np.uint32)), (P, k)
         assert all(np.array_equal(x, y) for x, y in zip(a[4:], b[4:])), (P, k)
+
+
+def test_sixteen_lockstep_streams_match_single_stream(orc, synth):
+    # >= 16 streams: the batch instances (k_knn<128> + k_line_gate, k_hash_build; the solve evaluates every block itself,
+    # so its sums are ordered differently: poses agree to rounding, not to the bit) against a single-stream handle
+    H, W, R, epr, P, S, K = 16, 900, 6, 10, 5, 16, 8
+    cfg = synth.make_cfg(H, W, 0)
+    scans = [[synth.scan(cfg, s % 3, k)[0] for k in range(K)] for s in range(S)]
+    po, gb = mk(orc, H, W, 0, R, epr, P, S=S)
+    gb.alloc_resident(K)
+    for s in range(S):
+        for k in range(K):
+            gb.upload_scan(s, k, scans[s][k])
+    batch = []
+    for k in range(K):
+        poses, infos = gb.process_resident(k, H * W, H, W, readback=True, next_slot=(k + 1 if k + 1 < K else -1))
+        assert all(i.status == 0 for i in infos)
+        batch.append((poses.copy(), [tuple(i.matches) for i in infos]))
+    gb.close()
+    for s in range(3):
+        _, g1 = mk(orc, H, W, 0, R, epr, P)
+        for k in range(K):
+            pose, info = g1.process_scan(scans[s][k], H, W)
+            for s2 in range(s, S, 3):
+                assert np.max(np.abs(pose - batch[k][0][s2])) < 1e-9, (s2, k)
+                assert tuple(info.matches) == batch[k][1][s2], (s2, k)
+                assert np.array_equal(batch[k][0][s2].view(np.uint64), batch[k][0][s].view(np.uint64)), (s2, k)   # equal streams, equal bits
+        g1.close()
