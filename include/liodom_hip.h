@@ -48,6 +48,11 @@ extern "C" {
 #define LIODOM_STATUS_EDGE_OVERFLOW 2u
 #define LIODOM_STATUS_HASH_FULL 4u
 #define LIODOM_STATUS_LM_SYNC_TIMEOUT 8u  /* cooperating LM workgroups did not all arrive (result invalid) */
+#define LIODOM_STATUS_PIPE_TIMEOUT 16u    /* pipelined replay: a kernel waited ~0.3 s in vain for the other HIP stream of the handle
+                                             (kernels serialised across streams by a profiler / debugger, or a GPU saturated by
+                                             another process).  The waiting workgroups skipped their work: the scan's result is
+                                             invalid, the entry point that collects it returns LIODOM_ERR_HIP, and the handle
+                                             switches to event-based stream dependencies; liodom_reset() before reusing the stream */
 
 /* Field-for-field mirror of liodom::Params (include/liodom/params.h:33-49); defaults are
  * those of Params::readParams (src/params.cc:40-109). */

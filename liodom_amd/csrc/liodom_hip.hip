@@ -234,7 +234,6 @@ int launch_odometry(liodom_handle* h, int eb, int s0, int count, unsigned int wa
 int enqueue_odometry(liodom_handle* h, int eb, int s0, int count, unsigned int wait_edges, unsigned int signal_odo) {
   const DevView& v = h->v;
   const bool knn_small = h->S >= 16;            // many streams: 4 queries per workgroup, else 8
-  const int knn_blocks = cdiv(h->v.edge_cap, knn_small ? 4 : 8);
   if (v.use_imu) {
     ProfScope ps(h, KID_OTHER);
     hipLaunchKernelGGL(k_imu_override, dim3(cdiv(count, 64)), dim3(64), 0, h->stream, v, s0, count);
@@ -247,7 +246,7 @@ int enqueue_odometry(liodom_handle* h, int eb, int s0, int count, unsigned int w
   for (int it = 0; it < 2; it++) {
     {
       ProfScope ps(h, KID_KNN);
-      const int kx = knn_blocks + ((early && it == 1) ? kRebuildAuxBlocks : 0);     // it 1: + ALLOC
+      const int kx = v.knn_grid + ((early && it == 1) ? kRebuildAuxBlocks : 0);     // it 1: + ALLOC
       if (knn_small) {
         hipLaunchKernelGGL(k_knn<128>, dim3(kx, count), dim3(128), 0, h->stream, v, s0, it, eb, wait_edges, signal_odo);
         if (v.knn_nn) hipLaunchKernelGGL(k_line_gate, dim3(cdiv(h->v.knn_blocks * h->v.knn_queries, 256), count), dim3(256), 0, h->stream, v, s0, it, eb);
@@ -490,7 +489,9 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   if ((use_prio ? hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_greatest)
                 : hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) { g_last_error = "hipStreamCreate failed"; return fail(LIODOM_ERR_HIP); }
   if (hipEventCreateWithFlags(&h->pose_event, hipEventDisableTiming) != hipSuccess) { g_last_error = "hipEventCreate failed"; return fail(LIODOM_ERR_HIP); }
-  if ((use_prio ? hipStreamCreateWithPriority(&h->stream_x, hipStreamNonBlocking, prio_least)
+  // (extraction: one level below the odometry stream, not the lowest: kernels of the odometry stream may wait in-kernel for it)
+  const int prio_x = (prio_least - prio_greatest >= 2) ? prio_greatest + 1 : prio_least;
+  if ((use_prio ? hipStreamCreateWithPriority(&h->stream_x, hipStreamNonBlocking, prio_x)
                 : hipStreamCreateWithFlags(&h->stream_x, hipStreamNonBlocking)) != hipSuccess) { g_last_error = "hipStreamCreate failed"; return fail(LIODOM_ERR_HIP); }
   for (int b = 0; b < kEdgePipeBufs; b++) {
     if (hipEventCreateWithFlags(&h->ev_edges[b], hipEventDisableTiming) != hipSuccess ||
@@ -524,7 +525,12 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, config->device);
     const int ecap = round_up(std::max(1, params->scan_lines * params->scan_regions * (params->edges_per_region + 1)), 64);
     h->use_flags = !h->use_graph && config->n_streams < 16;
-    h->flag_gate = !(config->n_streams == 1 && cdiv(ecap, 8) * 4 <= cus * 12);     // (larger launches: a one-wave gate launch polls instead)
+    h->flag_gate = !(config->n_streams == 1 && cdiv(cdiv(ecap, 8), 2) * 4 <= cus * 12);     // (larger launches: a one-wave gate launch polls instead)
+    // kernels of different streams never run side by side under these: the in-kernel waits could only time out
+    for (const char* name : {"AMD_SERIALIZE_KERNEL", "HIP_LAUNCH_BLOCKING", "ROCPROFILER_PMC", "ROCPROF_COUNTERS"}) {
+      const char* e = std::getenv(name);
+      if (e && e[0] && std::strcmp(e, "0") != 0) h->use_flags = false;
+    }
     if (const char* e = std::getenv("LIODOM_PIPE_FLAGS")) { if (std::atoi(e) == 0) h->use_flags = false; }
   }
   if (const char* e = std::getenv("LIODOM_HASH_BUILD")) h->lds_hash_build = std::strcmp(e, "global") != 0;
@@ -562,10 +568,13 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   v.map_cap = v.edge_cap * h->P + v.recv_cap;
   int ts = 1024;
   while (ts < 2 * (v.map_cap + (v.early_rebuild ? 8 * v.edge_cap : 0))) ts <<= 1;    // (early rebuild: cells that only the padding touches)
+  if (const char* e = std::getenv("LIODOM_TABLE_SIZE")) { const int t = std::atoi(e); if (t >= 1024 && (t & (t - 1)) == 0) ts = t; }   // (experiments; a table that is too small raises LIODOM_STATUS_HASH_FULL)
   v.table_size = ts;
   v.pose_log_cap = std::max(1, config->pose_log_capacity);
   v.debug = config->debug_buffers & 1;
-  if (const char* ab = getenv("LIODOM_ABLATE")) v.debug |= (atoi(ab) & ~1);   // measurement-only ablation bits
+  // in-kernel phase timestamps (tools/gpu_debug.py clocks): they change no result.  The result-changing ablation bits
+  // of earlier rounds (LIODOM_ABLATE) are gone from the product build.
+  if (const char* e = getenv("LIODOM_DEBUG_CLOCKS")) { if (atoi(e) != 0) v.debug |= 32 | (atoi(e) & 64) | ((atoi(e) >> 8) << 8); }   // 1: stamps, 65: + histograms (shared-counter atomics: they perturb the timing)
   v.ring_id_stride = (size_t)round_up(config->max_points + 512, 256);
 
   const size_t S = (size_t)h->S;
@@ -574,7 +583,9 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   ALLOC(v.ring_id, S * v.ring_id_stride, 0xFF);
   v.tile_cap = std::max(1, cdiv(config->max_points, kTilePts));
   ALLOC(v.tile_hist, S * (size_t)v.tile_cap * h->H, 0);
-  ALLOC(v.ring_pts, S * (size_t)config->max_points + 64, 0);     // + padding: k_ring_extract reads up to 26 points past a ring's end
+  // + padding: region_keys_load reads unconditionally up to 16 * IPL + 10 points past the start of a ring's last region,
+  // i.e. up to kExLPR * kExIPLBig + 10 points past the end of the last ring of the last stream (values never used)
+  ALLOC(v.ring_pts, S * (size_t)config->max_points + kExLPR * kExIPLBig + 64, 0);
   ALLOC(v.ring_src, S * (size_t)config->max_points, 0);
   ALLOC(v.ring_start, S * (size_t)(h->H + 1), 0);
   ALLOC(v.edges_pad, S * h->H * v.slots_per_ring, 0);
@@ -589,10 +600,6 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   ALLOC(v.corr_b, S * v.edge_cap, 0);
   ALLOC(v.corr_idx, S * 2 * v.edge_cap, 0xFF);
   if (v.debug & 1) ALLOC(v.knn_q, S * 2 * v.edge_cap, 0); else v.knn_q = nullptr;
-  if (std::getenv("LIODOM_KNN_REUSE") == nullptr || std::atoi(std::getenv("LIODOM_KNN_REUSE")) != 0) {
-    ALLOC(v.knn_save_pos, S * (size_t)v.edge_cap * kKnnGroup * 5, 0xFF);
-    ALLOC(v.knn_save_q, S * (size_t)v.edge_cap, 0);
-  } else { v.knn_save_pos = nullptr; v.knn_save_q = nullptr; }
   ALLOC(v.win_pts, S * h->P * v.edge_cap, 0);
   ALLOC(v.win_n, S * h->P, 0);
   ALLOC(v.win_base, S * (h->P + 1), 0);
@@ -624,7 +631,8 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   ALLOC(v.pose_log, S * v.pose_log_cap * 7, 0);
   ALLOC(v.info_log, S * v.pose_log_cap, 0);
   ALLOC(h->stage_in, S * (size_t)config->max_points, 0);
-  ALLOC(v.dbg_clk, 8 * 32, 0);
+  ALLOC(v.dbg_clk, 16 * 32, 0);
+  if (v.debug & 32) ALLOC(v.dbg_q, 2 * (size_t)v.edge_cap * 12, 0); else v.dbg_q = nullptr;
   ALLOC(v.lm_xch, S * 2 * kLmGroupsMax * 64, 0);
   ALLOC(v.pose_xch, S * 32, 0);
   ALLOC(v.pipe_flags, kEdgePipeBufs + 1, 0);
@@ -636,6 +644,10 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   v.knn_queries = config->n_streams >= 16 ? 4 : 8;          // must match the k_knn instance launch_odometry picks
   v.knn_partials = config->n_streams >= 16 ? 0 : 1;         // measured: +37 % on the VALU-bound 256-stream kNN pass, -2 us per solve on one stream
   v.knn_blocks = round_up(cdiv(v.edge_cap, v.knn_queries), 4);
+  v.knn_grid = std::max(1, cdiv(v.knn_blocks, kKnnGridDiv));   // sized for the usual edge count (~1/3 of the capacity): a workgroup takes a second block if there are more
+  if (std::getenv("LIODOM_KNN_SAVE") == nullptr || std::atoi(std::getenv("LIODOM_KNN_SAVE")) != 0) ALLOC(v.knn_save_q, S * (size_t)v.edge_cap, 0);
+  else v.knn_save_q = nullptr;
+  if (const char* e = std::getenv("LIODOM_KNN_EXACT_ONLY")) v.knn_exact_only = std::atoi(e) != 0 ? 1 : 0;
   ALLOC(v.knn_part, S * 2 * (size_t)v.knn_blocks * 32, 0);
   ALLOC(v.corr_mask, S * 2 * (size_t)v.knn_blocks, 0);
   {
@@ -763,6 +775,7 @@ int liodom_get_edges(liodom_handle_t* h, int stream, float* edges_xyzi, int32_t*
 static int wait_pose(liodom_handle_t* h, int s0, int count, double* pose_out, liodom_step_info_t* info, int lag = 0) {
   // zero-copy: k_lm_solve's finalize writes pose + diagnostics into host-mapped memory and
   // releases HostOut.seq; spin on it (an event / memcpy round trip costs ~15 us on this stack)
+  bool timed_out = false;
   for (int i = 0; i < count; i++) {
     const int expect = h->scans_enqueued[s0 + i] - lag;      // lag 1: the scan before the one enqueued last
     volatile HostOut* ho = h->host_out + (size_t)(s0 + i) * 2 + ((expect - 1) & 1);     // (scan k = expect - 1 publishes into record k & 1)
@@ -777,6 +790,20 @@ static int wait_pose(liodom_handle_t* h, int s0, int count, double* pose_out, li
     const HostOut* r = h->host_out + (size_t)(s0 + i) * 2 + ((expect - 1) & 1);
     if (pose_out) std::memcpy(pose_out + 7 * i, r->pose, sizeof(double) * 7);
     if (info) info[i] = r->info;
+    if (r->info.status & LIODOM_STATUS_PIPE_TIMEOUT) timed_out = true;
+  }
+  if (timed_out) {
+    // A kernel of the pipelined replay gave up waiting for the handle's other HIP stream (pipe_wait): its workgroups
+    // skipped the scan, the published pose is the prediction.  Fail loudly and stop relying on co-scheduled streams.
+    (void)hipStreamSynchronize(h->stream_x);
+    (void)hipStreamSynchronize(h->stream);
+    h->use_flags = false;
+    h->pf_slot = -1;
+    for (int b = 0; b < kEdgePipeBufs; b++) { h->ev_free_valid[b] = false; h->eb_reader[b] = 0; }
+    g_last_error = "pipelined replay: a kernel timed out waiting for the handle's other HIP stream (LIODOM_STATUS_PIPE_TIMEOUT): "
+                   "kernels are serialised across streams (profiler with --pmc, AMD_SERIALIZE_KERNEL, debugger) or the GPU is saturated; "
+                   "the scan's result is invalid; the handle now uses events (LIODOM_PIPE_FLAGS=0) - liodom_reset() the stream";
+    return LIODOM_ERR_HIP;
   }
   return LIODOM_OK;
 }
@@ -1196,13 +1223,26 @@ int liodom_reset_kernel_stats(liodom_handle_t* h) {
   return rc;
 }
 
-/* debug: raw phase timestamps (100 MHz) written by the kernels when LIODOM_ABLATE has bit 5 set */
-int liodom_debug_clocks(liodom_handle_t* h, unsigned long long* out256) {
-  if (!h || !out256) return LIODOM_ERR_INVALID_ARG;
+/* debug: raw phase timestamps (100 MHz) written by the kernels when LIODOM_DEBUG_CLOCKS is set */
+int liodom_debug_clocks(liodom_handle_t* h, unsigned long long* out512) {
+  if (!h || !out512) return LIODOM_ERR_INVALID_ARG;
   SideLocks lk(h, true, true);
   HIP_TRY(hipStreamSynchronize(h->stream_x));
   HIP_TRY(hipStreamSynchronize(h->stream));
-  HIP_TRY(hipMemcpy(out256, h->v.dbg_clk, sizeof(unsigned long long) * 256, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out512, h->v.dbg_clk, sizeof(unsigned long long) * 512, hipMemcpyDeviceToHost));
+  return LIODOM_OK;
+}
+
+/* debug: per-query phase times of k_knn (stream 0, latest scan): out[2][edge_cap][8]; returns edge_cap through *cap */
+int liodom_debug_knn_times(liodom_handle_t* h, unsigned int* out, int* cap) {
+  if (!h || !cap) return LIODOM_ERR_INVALID_ARG;
+  *cap = h->v.edge_cap;
+  if (!out) return LIODOM_OK;
+  if (!h->v.dbg_q) return LIODOM_ERR_UNSUPPORTED;
+  SideLocks lk(h, true, true);
+  HIP_TRY(hipStreamSynchronize(h->stream_x));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(out, h->v.dbg_q, sizeof(unsigned int) * 2 * (size_t)h->v.edge_cap * 12, hipMemcpyDeviceToHost));
   return LIODOM_OK;
 }
 

@@ -115,7 +115,7 @@ struct DevView {
   // capacities
   int n_streams, max_points, ring_cap, slots_per_ring, edge_cap, map_cap, table_size;
   int pose_log_cap;
-  int debug;
+  int debug;                // bit 0: debug buffers (curvature dump, kNN queries); bit 5: phase timestamps (dbg_clk).  Neither changes a result.
   // per-stream arrays (stride = capacity)
   StreamState* state;
   unsigned char* ring_id;   size_t ring_id_stride;
@@ -135,8 +135,6 @@ struct DevView {
   float4* corr_a;           // [S][edge_cap]  xyz of NN0, w = valid
   float4* corr_b;           // [S][edge_cap]  xyz of NN1
   int2* corr_idx;           // [S][2][edge_cap] window indices of (NN0, NN1), debug/parity
-  int* knn_save_pos;        // [S][edge_cap][32][5] pass 0: every lane's top-5 candidate positions (second pass re-ranks them)
-  float4* knn_save_q;       // [S][edge_cap] pass 0: the query (xyz) and the guard distance below which no unsaved point lies (0 = nothing saved)
   float4* knn_q;            // [S][2][edge_cap] world-frame float query of every edge and pass (debug_buffers only, else null)
   float4* win_pts;          // [S][P][edge_cap]
   int* win_n;               // [S][P]
@@ -182,9 +180,13 @@ struct DevView {
   unsigned long long* pose_xch;   // [S][32] early_rebuild: solved pose handed to the workgroups that append the new frame (tagged 8-byte granules)
   int early_rebuild;        // streamed rebuild: extra workgroups of the scan's four launches build the next scan's cell hash in the
                             // second table ("Streamed rebuild" below); no k_window_insert / k_hash_alloc / k_hash_scatter launches
+  int knn_grid;             // k_knn workgroups launched per stream (each takes the query blocks b, b + knn_grid, ...)
+  float4* knn_save_q;       // [S][edge_cap] first kNN pass of a scan: the query (xyz) and its fifth-nearest distance (w; inf if none): the second pass prunes with it
+  int knn_exact_only;       // (test switch) every kNN query takes the exact list path instead of the Best2 fast path: same results
   int knn_blocks;           // k_knn workgroups per stream = ceil(edge_cap / knn_queries), rounded up to a multiple of 4
   unsigned long long* lm_xch;   // [S][2][kLmGroupsMax][64] tagged granules: partial sums exchanged between the LM workgroups
-  unsigned long long* dbg_clk;  // [8][32] phase timestamps (100 MHz), debug bit 5 only
+  unsigned long long* dbg_clk;  // [16][32] phase timestamps (100 MHz) and counters, debug bit 5 only
+  unsigned int* dbg_q;          // [2][edge_cap][8] per-query phase times of stream 0's latest scan (10 ns ticks since the workgroup's start), debug bit 5 only
 };
 
 // computeLocalMap's condition (laser_odometry.cc:286): filter && window full && !mapping
@@ -196,6 +198,7 @@ __device__ __forceinline__ bool filter_active(const DevView& v, const StreamStat
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
 // debug-only phase stamps: kernel slot k, stamp index i (constant 100 MHz wall clock)
 #define DBG_STAMP(v, cond, k, i) do { if (((v).debug & 32) && (cond)) (v).dbg_clk[(k) * 32 + (i)] = wall_clock64(); } while (0)
+#define DBG_QSTAMP(i) do { if ((v.debug & 32) && s == 0 && hl == 0 && e < E) v.dbg_q[((size_t)outer_it * v.edge_cap + e) * 12 + (i)] = (unsigned int)(wall_clock64() - t_blk); } while (0)
 
 // XCD-aware workgroup placement for lock-step launches (grid = blocks x streams).  Workgroups are dispatched
 // round-robin over the 8 XCDs by linear id, and each XCD has its own 4 MB L2: with the natural mapping every
@@ -838,18 +841,24 @@ __global__ __launch_bounds__(kMaxThreads) void k_ring_extract(DevView v, int s0)
 // stream order (so the producer's launch has ended and its writes have left the caches) and polled by thread 0 of the
 // consumer's workgroups before they touch the data; a consumer that really had to wait also invalidates its caches.
 // The wait is bounded (~0.3 s): a producer that cannot run beside the consumer — a profiler that serialises kernels across
-// streams, e.g. rocprofv3 --pmc: use LIODOM_PIPE_FLAGS=0 there — raises LIODOM_STATUS_LM_SYNC_TIMEOUT instead of hanging.
-__device__ __forceinline__ void pipe_wait(const unsigned int* flag, unsigned int want, unsigned int* status) {
+// streams, e.g. rocprofv3 --pmc: use LIODOM_PIPE_FLAGS=0 there — raises LIODOM_STATUS_PIPE_TIMEOUT instead of hanging; the waiting
+// workgroups then skip their work (nothing reads a half-written buffer or overwrites one still in use), the host reports the scan
+// as failed (wait_pose) and the handle falls back to events.
+__device__ __forceinline__ bool pipe_wait(const unsigned int* flag, unsigned int want, unsigned int* status) {
   typedef __attribute__((address_space(1))) unsigned int gu32;
+  __shared__ int s_pipe_ok;
   if (threadIdx.x == 0) {
     unsigned int spins = 0;
+    bool ok = true;
     while ((int)(__hip_atomic_load((gu32*)flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
       __builtin_amdgcn_s_sleep(8);
-      if (++spins > 1500000u) { atomicOr(status, LIODOM_STATUS_LM_SYNC_TIMEOUT); break; }
+      if (++spins > 1500000u) { atomicOr(status, LIODOM_STATUS_PIPE_TIMEOUT); ok = false; break; }
     }
     if (spins) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    s_pipe_ok = ok ? 1 : 0;
   }
   __syncthreads();
+  return s_pipe_ok != 0;      // false: the producer never arrived — the caller must not touch the buffer (it returns)
 }
 // Gate in front of a scan's first k_knn launch for handles whose launch is too large to poll the flag itself (its polling
 // workgroups would fill the GPU and starve the extraction they wait for): one wave waits for the extraction's flag and
@@ -857,7 +866,10 @@ __device__ __forceinline__ void pipe_wait(const unsigned int* flag, unsigned int
 __global__ void k_pipe_gate(DevView v, int s0, int eb, unsigned int wait_edges, unsigned int signal_odo) {
   typedef __attribute__((address_space(1))) unsigned int gu32;
   if (signal_odo && threadIdx.x == 0) __hip_atomic_store((gu32*)(v.pipe_flags + kEdgePipeBufs), signal_odo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (wait_edges) pipe_wait(v.pipe_flags + eb, wait_edges, &v.state[s0].status);
+  if (wait_edges && !pipe_wait(v.pipe_flags + eb, wait_edges, &v.state[s0].status)) {
+    // the launches behind the gate check the status bit of their own stream (k_knn) and skip the scan
+    for (int s = (int)threadIdx.x; s < v.n_streams; s += (int)blockDim.x) atomicOr(&v.state[s].status, LIODOM_STATUS_PIPE_TIMEOUT);
+  }
 }
 __global__ void k_set_flag(unsigned int* flag, unsigned int value) {
   typedef __attribute__((address_space(1))) unsigned int gu32;
@@ -874,7 +886,7 @@ __global__ __launch_bounds__(256) void k_compact_edges(DevView v, int s0, int eb
   __shared__ int pre[257];
   __shared__ int cntr[256];
   // (pipelined replay) the odometry that last read edge buffer eb must have completed before it is rewritten
-  if (wait_odo) pipe_wait(v.pipe_flags + kEdgePipeBufs, wait_odo, &v.state[s0 + blockIdx.y].status);
+  if (wait_odo && !pipe_wait(v.pipe_flags + kEdgePipeBufs, wait_odo, &v.state[s0 + blockIdx.y].status)) return;
   const int s = s0 + blockIdx.y;
   const int H = v.scan_lines;
   const int* rn = v.ring_nedges + (size_t)s * H;
@@ -919,27 +931,25 @@ __global__ void k_set_edges(DevView v, int s0, int n_edges, int eb) {
 }
 
 // =============================================================================================
-// k_knn: 32 lanes per edge (8 edges per 256-thread workgroup).
-//   lane c < 27 probes the voxel hash for neighbour cell c of the query's 1 m cell (one 16-B
-//   slot load per probe; a 27-cell search is exact for every edge that can pass the
-//   sq_dist[4] < 1.0 gate).  Phase 1 streams the query's own cell; phase 2 only
-//   the neighbour cells whose box distance is below the current 5th-best distance (exact
-//   pruning, typically 0-3 cells instead of 26).  Cell populations are prefix-summed over the
-//   half-wave (DPP scan) into one flat candidate list; the 32 lanes stride over it with four
-//   independent 16-B loads in flight, each lane keeping a sorted top-5 of (float distance,
-//   window index); five DPP/permlane min-reductions merge the 32 lists.  Line gate in FP64,
-//   then NN0 / NN1 are written as the line points (laser_odometry.cc:351-357).
+// k_knn: 32 lanes (one half-wave) per edge, 8 edges per 256-thread workgroup (4 per 128 threads on lock-step batches).
+//   lane c < 27 probes the voxel hash for neighbour cell c of the query's 1 m cell (occupancy bit, then one 16-B
+//   slot load; a 27-cell search is exact for every edge that can pass the sq_dist[4] < 1.0 gate);
+//   lane 27 contributes the overflow list of the streamed rebuild.  ALL candidates of the neighbourhood go through
+//   one flat pass (no pruning rounds, no bound refreshes: with ~12 VALU instructions per candidate slot the rounds
+//   cost more than the ~3x candidates they saved) in which every lane keeps only its two nearest candidates and
+//   the distance of its third ("Best2").  The five nearest of the query are then popped from the 64 kept entries
+//   with five half-wave minima — exact whenever no lane saw three candidates at or below the fifth popped distance
+//   and the six smallest kept distances are pairwise different (FLANN orders equal distances by index, which this
+//   path never looks at).  The ~1-2 % of the queries that fail either check repeat the stream with a per-lane sorted
+//   list of five (distance, window index) keys and a 64-bit merge ("Top5"): exact in every case.
+//   Line gate in FP64, then NN0 / NN1 are written as the line points (laser_odometry.cc:351-357).
+//   Round-2 design for the record: per-lane Top5 lists for every query, cells streamed in four
+//   rounds of increasing box distance with the bound refreshed in between, second pass re-ranking the first pass's
+//   saved lists: ~750 VALU wave instructions per query, 56 % of them fixed cost.
 // =============================================================================================
-// Cell edge of the kNN hash.  1 m: the 27-cell neighbourhood covers the sq_dist[4] < 1.0 gate
-// (:324) exactly.  0.5 m cells (kCellInv = 2, 125-cell neighbourhood in two shells, code below) were
-// measured and rejected: own cells shrink 8x and the slowest workgroup drops from 35 to 30 us, but
-// the typical query needs more streaming rounds (phase 2: 5.0 -> 7.3 us), the kernel gets slower
-// (27.5 -> 29.3 us on one stream, 214 -> 328 us on 64) and the 3x more cells overflow the LDS-built
-// table.
+// Cell edge of the kNN hash: 1 m, so that the 27-cell neighbourhood covers the sq_dist[4] < 1.0 gate (:324) exactly.
 constexpr float kCellInv = 1.0f;
 constexpr double kCellSize = 1.0;
-// The 98 cells of the outer shell (max |d| = 2) as indices into the 5 x 5 x 5 cube, x fastest.
-__device__ const unsigned char kKnnOuterCells[98] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 34, 35, 39, 40, 44, 45, 46, 47, 48, 49, 50, 51, 52, 53, 54, 55, 59, 60, 64, 65, 69, 70, 71, 72, 73, 74, 75, 76, 77, 78, 79, 80, 84, 85, 89, 90, 94, 95, 96, 97, 98, 99, 100, 101, 102, 103, 104, 105, 106, 107, 108, 109, 110, 111, 112, 113, 114, 115, 116, 117, 118, 119, 120, 121, 122, 123, 124};
 
 // Per-lane sorted list of the five best candidates.  Key = (float distance bits << 32) | window
 // index: distances are non-negative, so the unsigned 64-bit order is exactly "distance, then window
@@ -975,80 +985,154 @@ __device__ __forceinline__ void top5_insert(Top5& t, float d, int wi, int pos) {
   }
 }
 #undef TOP5_STAGE
+__device__ __forceinline__ void top5_clear(Top5& t) {
+  t.k0 = t.k1 = t.k2 = t.k3 = t.k4 = kTop5Empty;
+  t.p0 = t.p1 = t.p2 = t.p3 = t.p4 = -1;
+}
+struct Top5Acc {
+  Top5 t;
+  __device__ __forceinline__ void consider(bool ok, float d, int wi, int pos) { if (ok && d <= top5_dist(t.k4)) top5_insert(t, d, wi, pos); }   // cheap reject first
+};
 
-// Streams the candidates of the cells selected by (start, cnt) [one cell per lane of the
-// half-wave] through the per-lane top-5 lists: population prefix (DPP scan) -> flat candidate
-// list -> 32 lanes stride over it, four independent 16-B loads in flight per lane.
-// Measured (threshold, loads in flight) on one stream / 64 streams, us per scan step: none 132.8 / 714;
-// (96, 4) 130.8 / 822; (64, 2) 128.4 / 711; (32, 2) 127.9 / 708; (16, 2) 128.2 / 703; (64, 3) 129.4 / 759.
-constexpr float kReuseMargin = 0.05f;    // metres added to the pruning radius of the first kNN pass (see the second pass)
-constexpr int kKnnBigCell = 32;        // cells with at least this many points are streamed cell-major
-__device__ __forceinline__ void knn_stream_cells(Top5& t, const float4* sp, int* s_incl, int* s_adj,
+// Fast path: the two nearest candidates a lane has seen (distance + position) and the DISTANCE of its third nearest.
+// Straight-line code: ~9 VALU instructions per candidate next to the ~7 of the distance (the sorted list above: ~50).
+struct Best2Acc {
+  float m1, m2, m3;
+  int p1, p2;
+  __device__ __forceinline__ void clear() { m1 = m2 = m3 = __int_as_float(0x7f800000); p1 = p2 = -1; }
+  __device__ __forceinline__ void consider(bool ok, float d0, int /*wi*/, int pos) {
+    const float d = ok ? d0 : __int_as_float(0x7f800000);
+    const bool lt1 = d < m1, lt2 = d < m2;
+    m3 = __builtin_amdgcn_fmed3f(m2, m3, d);      // third smallest of {m1 <= m2 <= m3, d}
+    const int q2 = lt2 ? pos : p2;
+    p2 = lt1 ? p1 : q2;
+    m2 = __builtin_amdgcn_fmed3f(m1, m2, d);
+    p1 = lt1 ? pos : p1;
+    m1 = lt1 ? d : m1;
+  }
+};
+
+// Streams the candidates of the cells selected by (start, cnt) [one cell per lane of the half-wave] through the
+// per-lane accumulators: populous cells cell-major (all 32 lanes walk the same cell: no search for "which cell does
+// flat index i belong to"), the small ones as one flat list (population prefix by DPP scan, monotone cell cursor per
+// lane).  UB / U independent 16-B loads in flight per lane; loads are unconditional (index clamped into the segment,
+// the result masked), so that they leave together and the loop body is straight-line code.
+// Two tunings of the same code (template parameter kDeep of k_knn / knn_block):
+//   lock-step batches (k_knn<128>, VALU-issue bound, 7 waves per SIMD hide the latency): 4 loads in flight per lane, cells
+//     of >= 128 points cell-major, phase 1 of the first pass = own cell + neighbours within 6 cm;
+//   few streams (k_knn<256>, one wave per SIMD, bound by the dependent memory round trips of its slowest query): 16 / 8
+//     loads in flight per lane (a query with 1 000 candidates: 4 round trips instead of 9), cells of >= 256 points
+//     cell-major, phase 1 = own cell + neighbours within 20 cm (fewer queries need the second phase's round trip).
+template <bool kDeep> struct KnnTune {
+  static constexpr int kBigCell = kDeep ? 256 : 128;
+  static constexpr int kLoadsBig = kDeep ? 8 : 4;
+  static constexpr int kLoadsFlat = kDeep ? 8 : 4;
+  static constexpr float kNearSq = kDeep ? 0.04f : 0.0036f;
+  static constexpr bool kProbeBoth = kDeep;
+};
+constexpr int kKnnGridDiv = 2;         // k_knn grid = half of the query blocks the edge capacity allows: a workgroup takes block b and, if the scan has that many edges, b + grid
+template <class Acc, int UB, int U, int kBigCell>
+__device__ __forceinline__ void knn_stream_cells(Acc& t, const float4* sp, int* s_incl, int* s_adj,
                                                  unsigned int start, unsigned int cnt, int hl,
-                                                 float qx, float qy, float qz) {
-  // Populous cells first, one at a time: all 32 lanes walk the same cell, so there is no per-element
-  // search for "which cell does flat index i belong to" (an LDS read chain per candidate).  These
-  // cells carry the long lists (a 1 m cell holds up to ~430 points when 20 frames stack the same
-  // structure): the slowest workgroup of a pass went from 26 to 21 us.
+                                                 float qx, float qy, float qz, unsigned int* dbg = nullptr) {
+  unsigned int dbg_big = 0, dbg_bigit = 0, dbg_flatit = 0;
+  const unsigned long long dbg_t0 = dbg ? wall_clock64() : 0ull;
   {
     const int half_base = (threadIdx.x & 32);
-    unsigned int big = (unsigned int)((__ballot(cnt >= (unsigned int)kKnnBigCell) >> half_base) & 0xFFFFFFFFull);
+    unsigned int big = (unsigned int)((__ballot(cnt >= (unsigned int)kBigCell) >> half_base) & 0xFFFFFFFFull);
     while (big) {
       const int l = __ffs(big) - 1;
       big &= big - 1u;
       const int cs = __shfl((int)start, l, kKnnGroup), cc = __shfl((int)cnt, l, kKnnGroup);
-      constexpr int UB = 2;
+      const float4* cp = sp + cs;
+      dbg_big++;
       for (int i = hl; i < cc; i += UB * kKnnGroup) {
+        dbg_bigit++;
         float4 m[UB];
 #pragma unroll
-        for (int u = 0; u < UB; u++) if (i + u * kKnnGroup < cc) m[u] = sp[cs + i + u * kKnnGroup];
+        for (int u = 0; u < UB; u++) { const int iu = i + u * kKnnGroup; m[u] = cp[iu < cc ? iu : cc - 1]; }
 #pragma unroll
         for (int u = 0; u < UB; u++) {
-          if (i + u * kKnnGroup < cc) {
-            const float d = sqdist_f(qx, qy, qz, m[u].x, m[u].y, m[u].z);
-            if (d <= top5_dist(t.k4)) top5_insert(t, d, __float_as_int(m[u].w), cs + i + u * kKnnGroup);
-          }
+          const int iu = i + u * kKnnGroup;
+          t.consider(iu < cc, sqdist_f(qx, qy, qz, m[u].x, m[u].y, m[u].z), __float_as_int(m[u].w), cs + iu);
         }
       }
     }
-    if (cnt >= (unsigned int)kKnnBigCell) cnt = 0;       // done; the flat pass below takes the small cells
+    if (cnt >= (unsigned int)kBigCell) cnt = 0;       // done; the flat pass below takes the small cells
   }
+  const unsigned int dbg_nseg = dbg ? (unsigned int)__popc((unsigned int)(__ballot(cnt > 0) >> (threadIdx.x & 32))) : 0u;
   const int incl = half_incl_scan_i32((int)cnt);
   s_incl[hl] = incl;
   s_adj[hl] = (int)start - (incl - (int)cnt);
   __builtin_amdgcn_wave_barrier();
   const int T = s_incl[kKnnGroup - 1];
-  int c = 0;   // cell cursor (monotone: the flat index only grows)
-  // independent 16-B loads in flight per lane.  Measured 1 / 2 / 4 / 8 / 16: 27.6 / 26.1 / 27.3 / 28.0 / 28.8 us on one
-  // stream, 176 / 183 / 209 / 284 / 528 us on 64: the kernel is VALU-issue bound (PMC: SQ_INSTS_VALU x 4 cycles =
-  // 63 % of the SIMD cycles), wider unrolls only add predicated-off work.
-  constexpr int U = 2;
+  const unsigned long long dbg_t1 = dbg ? wall_clock64() : 0ull;
   for (int i = hl; i < T; i += U * kKnnGroup) {
+    dbg_flatit++;
+    // owner segment of flat index iu = number of segments whose inclusive prefix is <= iu: a 5-step binary search over
+    // the 32 prefixes in LDS, the U searches of a lane side by side (a per-lane cursor loop — dependent LDS reads behind
+    // divergent branches — cost 2-3 us per round on a single stream)
     int a[U];
-    bool ok[U];
+    int c[U];
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-      const int iu = i + u * kKnnGroup;
-      ok[u] = iu < T;
-      a[u] = 0;
-      if (ok[u]) {
-        while (s_incl[c] <= iu) c++;
-        a[u] = s_adj[c] + iu;
-      }
+    for (int u = 0; u < U; u++) { const int iu = i + u * kKnnGroup; a[u] = iu < T ? iu : T - 1; c[u] = 0; }
+#pragma unroll
+    for (int step = kKnnGroup / 2; step >= 1; step >>= 1) {
+      int pv[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) pv[u] = s_incl[c[u] + step - 1];
+#pragma unroll
+      for (int u = 0; u < U; u++) c[u] += pv[u] <= a[u] ? step : 0;
     }
+    int adj[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) adj[u] = s_adj[c[u]];
+#pragma unroll
+    for (int u = 0; u < U; u++) a[u] += adj[u];
     float4 m[U];
 #pragma unroll
-    for (int u = 0; u < U; u++) if (ok[u]) m[u] = sp[a[u]];
+    for (int u = 0; u < U; u++) m[u] = sp[a[u]];
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-      if (ok[u]) {
-        const float d = sqdist_f(qx, qy, qz, m[u].x, m[u].y, m[u].z);
-        if (d <= top5_dist(t.k4)) top5_insert(t, d, __float_as_int(m[u].w), a[u]);   // cheap reject first
-      }
-    }
+    for (int u = 0; u < U; u++)
+      t.consider(i + u * kKnnGroup < T, sqdist_f(qx, qy, qz, m[u].x, m[u].y, m[u].z), __float_as_int(m[u].w), a[u]);
   }
   __builtin_amdgcn_wave_barrier();
+  if (dbg && hl == 0) {
+    dbg[0] = (unsigned int)(dbg_t1 - dbg_t0);                      // big-cell part, 10 ns ticks
+    dbg[1] = (unsigned int)(wall_clock64() - dbg_t1);              // flat part
+    dbg[2] = dbg_big | (dbg_bigit << 8) | (dbg_flatit << 16) | ((unsigned int)T << 20);
+    dbg[3] = dbg_nseg;
+  }
 }
+
+// Pops the five nearest of the half-wave's query from the lanes' Best2 entries (position of the r-th nearest ->
+// pos[r], fifth distance -> d5).  Returns true when that result is certain:
+//   d5 <  1.0: the six smallest kept distances are pairwise different (no index tie-break needed) and every lane's
+//              third-nearest distance lies above d5 (so every candidate at or below d5 is among the kept entries);
+//   d5 >= 1.0: no lane's third nearest is below 1.0, i.e. fewer than five candidates exist inside the 1.0 gate (:324).
+__device__ __forceinline__ bool best2_select(const Best2Acc& t, int hl, int half_shift, float& d5, int (&pos)[5]) {
+  unsigned int v = (unsigned int)__float_as_int(t.m1), w = (unsigned int)__float_as_int(t.m2);
+  int ph = t.p1, pn = t.p2;
+  unsigned int g[6];
+#pragma unroll
+  for (int r = 0; r < 5; r++) {
+    g[r] = half_min_u32(v);                        // non-negative floats order as unsigned ints
+    const unsigned int win = (unsigned int)((__ballot(v == g[r]) >> half_shift) & 0xFFFFFFFFull);
+    const int l = __ffs(win) - 1;
+    pos[r] = __shfl(ph, l, kKnnGroup);
+    const bool mine = hl == l;
+    v = mine ? w : v;
+    w = mine ? 0x7f800000u : w;
+    ph = mine ? pn : ph;
+  }
+  g[5] = half_min_u32(v);
+  const unsigned int s3 = half_min_u32((unsigned int)__float_as_int(t.m3));
+  const unsigned int one = 0x3f800000u;
+  d5 = __int_as_float((int)g[4]);
+  if (g[4] < one) return g[0] < g[1] && g[1] < g[2] && g[2] < g[3] && g[3] < g[4] && g[4] < g[5] && g[4] < s3;
+  return s3 >= one;
+}
+
 
 // Merges the 32 per-lane lists of a half-wave: afterwards every lane holds the global top-5
 // (ascending by distance, ties by window index) in g.
@@ -1079,57 +1163,47 @@ __device__ __forceinline__ void knn_merge(Top5& t, Top5& g, int hl, int half_shi
   g.k0 = gk[0]; g.k1 = gk[1]; g.k2 = gk[2]; g.k3 = gk[3]; g.k4 = gk[4];
   g.p0 = gp[0]; g.p1 = gp[1]; g.p2 = gp[2]; g.p3 = gp[3]; g.p4 = gp[4];
 }
-__device__ __forceinline__ void top5_clear(Top5& t) {
-  t.k0 = t.k1 = t.k2 = t.k3 = t.k4 = kTop5Empty;
-  t.p0 = t.p1 = t.p2 = t.p3 = t.p4 = -1;
-}
 
-// Workgroup size = 32 lanes x queries.  A workgroup lasts as long as its slowest query, so few queries
-// per workgroup win: measured 1024 -> 256 threads: 332 -> 242 us per pass on 64 lock-step streams,
-// 31.5 -> 29.7 us on one.  Later (cheaper insertion, cell-major lists) 128 threads beat 256 on many
-// streams (scan step 686 vs 707 us on 64) and lose slightly on one (129.2 vs 127.6 us): two instances,
-// chosen by the host from the stream count.
+// Workgroup size = 32 lanes x queries.  A workgroup lasts as long as its slowest query, so few queries per workgroup
+// win: 8 (256 threads) on handles with few streams, 4 (128 threads) on lock-step batches; two instances, chosen by
+// the host from the stream count.
 __device__ void rebuild_alloc(const DevView& v, int s, StreamState& st, int block, int nblocks);
 
+// LDS of one k_knn workgroup (kQ queries)
+template <int kQ>
+struct KnnShared {
+  int incl[kQ][kKnnGroup];       // inclusive candidate prefix per cell
+  int adj[kQ][kKnnGroup];        // cell start - exclusive prefix
+  float nn[kQ][16];              // the five neighbours of every query (xyz)
+  int res[kQ][4];                // distance gate passed, window index of NN0, NN1, line gate passed
+  double part[kQ][32];           // normal-equation terms of every query's residual block at the solve's start pose
+  double blk[kQ][24];            // that block's J[18], rho' r [3], rho, rho', validity (0 none, 1 valid, 2 non-finite)
+};
+
+// Upper bound of the half-wave query's fifth-nearest distance from the entries kept so far: the smallest of a
+// ladder of thresholds at or below which at least five kept entries lie (1.0, the gate of :324, if none does).
+__device__ __forceinline__ float best2_bound(const Best2Acc& t, int half_shift) {
+  float B = 1.0f;
+  const float thr[4] = {0.36f, 0.09f, 0.0225f, 0.0036f};      // (0.6 m, 0.3 m, 0.15 m, 0.06 m) squared, descending
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int c = __popc((unsigned int)(__ballot(t.m1 <= thr[k]) >> half_shift)) + __popc((unsigned int)(__ballot(t.m2 <= thr[k]) >> half_shift));
+    B = c >= 5 ? thr[k] : B;
+  }
+  return B;
+}
+
+// One block of kKnnThreads / 32 queries (virtual block index bv).  Whole workgroup; returns are workgroup-uniform.
 template <int kKnnThreads>
-__global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int outer_it, int eb, unsigned int wait_edges, unsigned int signal_odo) {
+__device__ __forceinline__ void knn_block(const DevView& v, int s, StreamState& st, int outer_it, int eb, int bv, int E,
+                                          KnnShared<kKnnThreads / kKnnGroup>& sh) {
   constexpr int kKnnQueries = kKnnThreads / kKnnGroup;
-  __shared__ int s_incl[kKnnQueries][kKnnGroup];   // inclusive candidate prefix per cell
-  __shared__ int s_adj[kKnnQueries][kKnnGroup];    // cell start - exclusive prefix
-  __shared__ float s_nn[kKnnQueries][16];          // the five neighbours of every query (xyz)
-  __shared__ int s_res[kKnnQueries][4];            // distance gate passed, window index of NN0, NN1
-  __shared__ double s_part[kKnnQueries][32];       // normal-equation terms of every query's residual block at the solve's start pose
-  __shared__ double s_blk[kKnnQueries][24];        // that block's J[18], rho' r [3], rho, rho', validity (0 none, 1 valid, 2 non-finite)
-  int bxi = (int)blockIdx.x, byi = (int)blockIdx.y;
-  xcd_remap(bxi, byi);
-  const int s = s0 + byi;
-  StreamState& st = v.state[s];
-  if (v.early_rebuild) {
-    if (bxi >= v.knn_blocks) { if (outer_it == 1) rebuild_alloc(v, s, st, bxi - v.knn_blocks, (int)gridDim.x - v.knn_blocks); return; }
-    // streamed rebuild, bookkeeping before the first builders start (next launch): the frame count the build refers to
-    // (the finalising solve advances it beside them) and an empty list of occupied slots for the table being built
-    if (outer_it == 0 && bxi == 0 && threadIdx.x == 0) { st.reb_frame_count = st.frame_count; st.n_used_tab[(st.frame_count + 1) & 1] = 0; }
-  }
-  if (outer_it == 0) {
-    // (pipelined replay) this launch follows odometry `signal_odo` in stream order: that odometry has completed entirely;
-    // and the extraction that fills edge buffer eb (other stream) must have completed before anything of it is read
-    if (signal_odo && bxi == 0 && byi == 0 && threadIdx.x == 0) {
-      typedef __attribute__((address_space(1))) unsigned int gu32;
-      __hip_atomic_store((gu32*)(v.pipe_flags + kEdgePipeBufs), signal_odo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (wait_edges) pipe_wait(v.pipe_flags + eb, wait_edges, &st.status);
-  }
-  if (!st.initialized) return;                     // uniform over the workgroup
-  const int E = st.n_edges_buf[eb];
-  if ((int)(bxi * kKnnQueries) >= E) {      // no query here: an empty validity byte for the solve's compaction
-    if (threadIdx.x == 0) v.corr_mask[((size_t)s * 2 + outer_it) * v.knn_blocks + bxi] = 0;
-    return;
-  }
+  typedef KnnTune<(kKnnThreads >= 256)> Tune;
   const int grp = threadIdx.x / kKnnGroup;
-  const int e = bxi * kKnnQueries + grp;
+  const int e = bv * kKnnQueries + grp;
   const int hl = threadIdx.x & (kKnnGroup - 1);
   const int half_shift = (threadIdx.x & 32);     // 0 or 32: which half of the wave
-  const bool dbgb = (bxi == 5) && (s == 0) && (threadIdx.x == 0) && (outer_it == 0);
+  const bool dbgb = (bv == 5) && (s == 0) && (threadIdx.x == 0) && (outer_it == 0);
   const unsigned long long t_blk = (v.debug & 32) ? wall_clock64() : 0ull;
   DBG_STAMP(v, dbgb, 1, 0);
   bool active = e < E;
@@ -1144,224 +1218,167 @@ __global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int oute
     active = ld_isfinite((double)qx) && ld_isfinite((double)qy) && ld_isfinite((double)qz) &&
              fabsf(qx) < 1.0e9f && fabsf(qy) < 1.0e9f && fabsf(qz) < 1.0e9f;
   }
-  DBG_STAMP(v, dbgb, 1, 1);
-  if (hl == 0) { s_res[grp][0] = 0; s_res[grp][1] = -1; s_res[grp][2] = -1; }
-  if (!active && outer_it == 0 && v.knn_save_pos && e < E && hl == 0) v.knn_save_q[(size_t)s * v.edge_cap + e] = make_float4(0.f, 0.f, 0.f, 0.f);
+  DBG_STAMP(v, dbgb, 1, 1); DBG_QSTAMP(1);
+  if (hl == 0) { sh.res[grp][0] = 0; sh.res[grp][1] = -1; sh.res[grp][2] = -1; }
+  float d5 = __int_as_float(0x7f800000);
   if (active) {                                    // uniform over each 32-lane half
     const int cx = (int)floorf(qx * kCellInv), cy = (int)floorf(qy * kCellInv), cz = (int)floorf(qz * kCellInv);
     const unsigned int tmask = st.table_mask;
     const int stab = s + LD_TAB_PARITY(v, st.frame_count) * v.n_streams;
     const CellSlot* cells = v.cells + (size_t)stab * v.table_size;
     const unsigned int* bits = v.cell_bits + (size_t)stab * (v.table_size >> 5);
-    auto probe = [&](int dx, int dy, int dz, unsigned int& start, unsigned int& cnt) {
+    const float4* sp = v.sorted_pts + (size_t)stab * v.sorted_cap;
+    // One segment of candidates per lane: the query's cell and its 26 neighbours (lanes 0..26; the own cell is lane 13),
+    // and on lane 27 the overflow list of the streamed rebuild (points of the newest frame that moved out of their
+    // padded cells: empty unless the solve corrected the prediction by more than rebuild_delta).  lb = lower bound of
+    // the float squared distance from q to any point of the segment: the box distance of the cell, shrunk by 1e-5 so
+    // that rounding of the candidate distances (float, ~3e-7 relative) or of the bound itself can never make a
+    // pruned point look closer than the bound.
+    unsigned int start = 0, cnt = 0;
+    float lb = 0.0f;
+    if (hl < 27) {
+      const int dx = hl % 3 - 1, dy = (hl / 3) % 3 - 1, dz = hl / 9 - 1;
       const unsigned long long key = pack_cell(cx + dx, cy + dy, cz + dz);
       unsigned int h = hash_cell(key, tmask);
-      for (int pr = 0; pr < v.table_size; pr++) {
-        if (!((bits[h >> 5] >> (h & 31)) & 1u)) break;           // empty slot: cell not in the map
+      if (Tune::kProbeBoth) {
+        // (few streams: latency counts) occupancy bit and slot of the first probe leave together — one round trip instead of
+        // two; the slots of empty cells (most of the 27) are loaded for nothing, 16 B each
+        const unsigned int word = bits[h >> 5];
         const uint4 raw = *reinterpret_cast<const uint4*>(cells + h);
         const unsigned long long k = ((unsigned long long)raw.y << 32) | raw.x;
-        if (k == key) { start = raw.z; cnt = raw.w; break; }
-        h = (h + 1) & tmask;
+        bool more = ((word >> (h & 31)) & 1u) != 0u;
+        if (more && k == key) { start = raw.z; cnt = raw.w; more = false; }
+        for (int pr = 1; more && pr < v.table_size; pr++) {       // (collision chain: rare)
+          h = (h + 1) & tmask;
+          if (!((bits[h >> 5] >> (h & 31)) & 1u)) break;
+          const uint4 r2 = *reinterpret_cast<const uint4*>(cells + h);
+          if ((((unsigned long long)r2.y << 32) | r2.x) == key) { start = r2.z; cnt = r2.w; break; }
+        }
+      } else {
+        for (int pr = 0; pr < v.table_size; pr++) {
+          if (!((bits[h >> 5] >> (h & 31)) & 1u)) break;           // empty slot: cell not in the map
+          const uint4 raw = *reinterpret_cast<const uint4*>(cells + h);
+          const unsigned long long k = ((unsigned long long)raw.y << 32) | raw.x;
+          if (k == key) { start = raw.z; cnt = raw.w; break; }
+          h = (h + 1) & tmask;
+        }
       }
-    };
-    // box distance to the cell, shrunk by 1e-5 so that rounding of the candidate distances (float, ~3e-7 relative)
-    // or of this bound itself (float, ~3e-7) can never make a pruned point look closer than the bound
-    auto box_lb = [&](int dx, int dy, int dz) -> float {
       const float cs = (float)kCellSize;
       const float lx = (float)(cx + dx) * cs, ly = (float)(cy + dy) * cs, lz = (float)(cz + dz) * cs;
       const float ex = qx < lx ? lx - qx : (qx > lx + cs ? qx - (lx + cs) : 0.0f);
       const float ey = qy < ly ? ly - qy : (qy > ly + cs ? qy - (ly + cs) : 0.0f);
       const float ez = qz < lz ? lz - qz : (qz > lz + cs ? qz - (lz + cs) : 0.0f);
-      return (ex * ex + ey * ey + ez * ez) * (1.0f - 1e-5f);
-    };
-    const float4* sp = v.sorted_pts + (size_t)stab * v.sorted_cap;
-    Top5 t, g;
-    top5_clear(t);
-    // ---- second pass of a scan: re-rank what the first pass kept.  The first solve moves the pose by millimetres, so
-    // almost every query has the same neighbours as before.  Pass 0 saved, per query, every lane's five best
-    // candidates (up to 160 positions: a superset of the five nearest) and a guard g: no map point outside that set was
-    // closer to the old query than sqrt(g) (the lanes' 5th-best distances, the box distances of the pruned cells, the
-    // distance to the border of the 27-cell block).  With d = |q_new - q_old| every unsaved point is now at least sqrt(g) - d away; if the 5th best of the
-    // re-ranked set is strictly closer than that (rounding margins included), it is the exact answer — otherwise the
-    // query takes the full search below.  Exact by construction, never approximate. ----
-    bool need_full = true;
-    if (outer_it == 1 && v.knn_save_pos) {
+      lb = (ex * ex + ey * ey + ez * ez) * (1.0f - 1e-5f);
+    } else if (hl == 27 && v.early_rebuild) {
+      start = (unsigned int)v.ovf_base;
+      cnt = (unsigned int)st.n_ovf[LD_TAB_PARITY(v, st.frame_count)];
+    }
+    DBG_STAMP(v, dbgb, 1, 2); DBG_QSTAMP(2);
+    // Pruning bound B: an upper bound of the query's fifth-nearest distance (never above the 1.0 gate: points at
+    // >= 1.0 cannot be part of a match, :324); a segment is skipped only if lb > B, so the result is exact.
+    //   second pass of a scan: the map has not changed and the first solve moved the query by delta (millimetres), so
+    //   the five neighbours the first pass found are now within sqrt(d5_first) + delta: B is known before anything is
+    //   streamed, one phase.
+    //   first pass: phase 1 streams the own cell (+ the neighbours within Tune::kNearSq of q, + the overflow list), B
+    //   comes from the entries kept so far (best2_bound), phase 2 streams what B leaves of the other cells.
+    float B = 1.0f;
+    bool have_b = false;
+    if (outer_it == 1 && v.knn_save_q) {
       const float4 sq = v.knn_save_q[(size_t)s * v.edge_cap + e];
-      if (sq.w > 0.f) {                                          // (uniform over the half-wave)
-        const int* sv = v.knn_save_pos + (((size_t)s * v.edge_cap + e) * kKnnGroup + hl) * 5;
-        int pos[5];
-#pragma unroll
-        for (int k = 0; k < 5; k++) pos[k] = sv[k];
-        float4 m[5];
-#pragma unroll
-        for (int k = 0; k < 5; k++) m[k] = sp[pos[k] >= 0 ? pos[k] : 0];
-#pragma unroll
-        for (int k = 0; k < 5; k++)
-          if (pos[k] >= 0) top5_insert(t, sqdist_f(qx, qy, qz, m[k].x, m[k].y, m[k].z), __float_as_int(m[k].w), pos[k]);
-        knn_merge(t, g, hl, half_shift);
-        const double ddx = (double)qx - (double)sq.x, ddy = (double)qy - (double)sq.y, ddz = (double)qz - (double)sq.z;
-        const double delta = sqrt(ddx * ddx + ddy * ddy + ddz * ddz) * (1.0 + 1e-12);
-        const double r = sqrt((double)sq.w) * (1.0 - 2e-7) - delta;       // every unsaved point is at least this far now
-        const double limit = r > 0.0 ? r * r * (1.0 - 1e-6) : 0.0;          // (float rounding of the new distances included)
-        need_full = !((double)top5_dist(g.k4) < limit || limit > 1.0);      // beyond the 1.0 gate nothing unsaved can matter
-        if (need_full) top5_clear(t);
-        if ((v.debug & 32) && hl == 0) atomicAdd(&v.dbg_clk[2 * 32 + (need_full ? 30 : 31)], 1ull);   // (debug) second-pass fallbacks / re-ranks
+      if (sq.w < 1.0f) {                                         // (uniform over the half-wave; inf / >= 1: nothing to gain)
+        const float ddx = qx - sq.x, ddy = qy - sq.y, ddz = qz - sq.z;
+        const float delta = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
+        const float r = sqrtf(sq.w) * (1.0f + 1e-6f) + delta * (1.0f + 1e-6f) + 1e-7f;
+        B = fminf(1.0f, r * r * (1.0f + 1e-5f));
+        have_b = true;
       }
     }
-    if (need_full) {                                             // (uniform over the half-wave)
-      unsigned int start = 0, cnt = 0;
-      float lb = 0.0f;     // lower bound of the float squared distance from q to any point of the cell
-      if (hl < 27) {       // inner shell: the query's cell and its 26 neighbours
-        const int dx = hl % 3 - 1, dy = (hl / 3) % 3 - 1, dz = hl / 9 - 1;
-        probe(dx, dy, dz, start, cnt);
-        lb = box_lb(dx, dy, dz);
-      }
-      DBG_STAMP(v, dbgb, 1, 2);
-      if (v.debug & 4) cnt = 0;
-      // Cells are streamed in rounds of increasing box distance (own cell; within 0.2 m; within
-      // 0.5 m; the rest of the inner shell; then, only if still needed, the outer shell).  After
-      // every round the pruning bound is refreshed: an upper bound of the final 5th-best distance =
-      // the 5th smallest of the lanes' best distances (five distinct points are at least that close)
-      // or any single lane's own 5th entry, never above the 1.0 gate (points at >= 1.0 cannot be part
-      // of a match, :324).  A cell is skipped only if its box distance exceeds the bound, so the
-      // result is exact; a typical query ends after its own cell.
-      float bound_f = 1.0f;
-      // first pass: cells are pruned against a bound padded by kReuseMargin, so that the guard handed to the second
-      // pass leaves room for the pose correction of the first solve (more cells streamed here, fewer fallbacks there)
-      const bool pad = outer_it == 0 && v.knn_save_pos != nullptr;
-      float prune_f = pad ? (1.0f + kReuseMargin) * (1.0f + kReuseMargin) : 1.0f;
-      auto refresh_bound = [&]() {
-        unsigned int bnd = 0x7f800000u;   // +inf
-        bool taken = false;
-        const unsigned int mine = (unsigned int)(t.k0 >> 32);   // non-negative floats order as uints
-  #pragma unroll
-        for (int r = 0; r < 5; r++) {
-          const unsigned int cur = taken ? 0x7f800000u : mine;
-          const unsigned int mn = half_min_u32(cur);
-          if (r == 4) bnd = mn;
-          const unsigned int win = (unsigned int)((__ballot(!taken && cur == mn) >> half_shift) & 0xFFFFFFFFull);
-          if (hl == __ffs(win) - 1) taken = true;
-        }
-        const unsigned int own5 = half_min_u32((unsigned int)(t.k4 >> 32));
-        bnd = own5 < bnd ? own5 : bnd;
-        const float b = __int_as_float((int)bnd);
-        bound_f = b < bound_f ? b : bound_f;
-        if (pad) { const float rb = sqrtf(bound_f) + kReuseMargin; prune_f = rb * rb; } else prune_f = bound_f;
-      };
-      bool pending = (hl < 27) && (cnt > 0);
-      bool mine_streamed = false;                  // this lane's cell went through the lists (else: pruned, or empty)
-      const float thr[4] = {0.0f, 0.04f, 0.25f, 4.0f};
-  #pragma unroll
-      for (int round = 0; round < 4; round++) {
-        pending = pending && !(lb > prune_f);                      // pruned for good
-        // few candidates left (<= 8 per lane): one pass over all of them is cheaper than the
-        // remaining rounds with their bound refreshes
-        bool all_now = false;
-        if (round == 1 || round == 2) {
-          const int left = __shfl(half_incl_scan_i32(pending ? (int)cnt : 0), kKnnGroup - 1, kKnnGroup);
-          all_now = left <= 8 * kKnnGroup;
-        }
-        const bool now = pending && (all_now || lb <= thr[round]);
-        if ((__ballot(now) >> half_shift) & 0xFFFFFFFFull) {
-          knn_stream_cells(t, sp, s_incl[grp], s_adj[grp], start, now ? cnt : 0u, hl, qx, qy, qz);
-          pending = pending && !now;
-          mine_streamed = mine_streamed || now;
-          if (round < 3 && ((__ballot(pending) >> half_shift) & 0xFFFFFFFFull)) refresh_bound();
-        }
-        if (round == 0) DBG_STAMP(v, dbgb, 1, 3);
-        if (round == 1) DBG_STAMP(v, dbgb, 1, 4);
-      }
-      // Outer shell for 0.5 m cells only (max |d| = 2, 98 cells, up to four per lane): every one of
-      // them is at least 0.5 m from the query, so it matters only while the bound is still above 0.25.
-      if (kCellSize < 1.0 && bound_f > 0.2499f) refresh_bound();      // (uniform over the half-wave)
-      if (kCellSize < 1.0 && bound_f > 0.2499f) {
-        unsigned int ostart[4], ocnt[4];
-        double olb[4];
-        bool opend[4];
-  #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const int j = k * 32 + hl;
-          ostart[k] = 0; ocnt[k] = 0; olb[k] = 1.0e30; opend[k] = false;
-          if (j < 98) {
-            const int c = kKnnOuterCells[j];
-            const int dx = c % 5 - 2, dy = (c / 5) % 5 - 2, dz = c / 25 - 2;
-            olb[k] = box_lb(dx, dy, dz);
-            if (!(olb[k] > (double)bound_f)) { probe(dx, dy, dz, ostart[k], ocnt[k]); opend[k] = ocnt[k] > 0; }
-          }
-        }
-        if (v.debug & 4) { for (int k = 0; k < 4; k++) opend[k] = false; }
-  #pragma unroll
-        for (int round = 0; round < 2; round++) {
-          bool streamed = false;
-  #pragma unroll
-          for (int k = 0; k < 4; k++) {
-            opend[k] = opend[k] && !(olb[k] > (double)bound_f);
-            const bool now = opend[k] && (round == 1 || olb[k] <= 0.5);
-            if ((__ballot(now) >> half_shift) & 0xFFFFFFFFull) {
-              knn_stream_cells(t, sp, s_incl[grp], s_adj[grp], ostart[k], now ? ocnt[k] : 0u, hl, qx, qy, qz);
-              opend[k] = opend[k] && !now;
-              streamed = true;
-            }
-          }
-          const bool left = opend[0] || opend[1] || opend[2] || opend[3];
-          if (round == 0 && streamed && ((__ballot(left) >> half_shift) & 0xFFFFFFFFull)) refresh_bound();
-        }
-      }
-      if (v.early_rebuild) {
-        // streamed rebuild: points of the newest frame that moved out of their padded cells wait in an overflow list
-        // (empty unless the solve corrected the prediction by more than rebuild_delta); they are candidates of every query
-        const int novf = st.n_ovf[LD_TAB_PARITY(v, st.frame_count)];
-        for (int i = hl; i < novf; i += kKnnGroup) {
-          const float4 m = sp[v.ovf_base + i];
-          const float d = sqdist_f(qx, qy, qz, m.x, m.y, m.z);
-          if (d <= top5_dist(t.k4)) top5_insert(t, d, __float_as_int(m.w), v.ovf_base + i);
-        }
-      }
-      if (outer_it == 0 && v.knn_save_pos) {
-        // what the second pass needs: the lanes' lists and the guard (see above)
-        const float sk = (hl < 27 && cnt > 0 && !mine_streamed) ? lb : __int_as_float(0x7f800000);
-        unsigned int gd = half_min_u32((unsigned int)__float_as_int(sk));
-        const unsigned int k4m = half_min_u32((unsigned int)(t.k4 >> 32));
-        gd = k4m < gd ? k4m : gd;
-        float guard = __int_as_float((int)gd);
-        // points outside the 27 cells: at least 1 + (distance of q to the nearest face of its own cell) away, so a
-        // query without five neighbours inside the 1.0 gate can usually be certified as still having none
-        {
-          const float cs = (float)kCellSize;
-          const float fx = qx - (float)cx * cs, fy = qy - (float)cy * cs, fz = qz - (float)cz * cs;
-          float edge = fminf(fminf(fminf(fx, cs - fx), fminf(fy, cs - fy)), fminf(fz, cs - fz));
-          edge = edge > 0.f ? edge : 0.f;
-          const float outer = (cs + edge) * (cs + edge) * (1.0f - 1e-6f);
-          guard = guard < outer ? guard : outer;
-        }
-        int* sv = v.knn_save_pos + (((size_t)s * v.edge_cap + e) * kKnnGroup + hl) * 5;
-        sv[0] = t.p0; sv[1] = t.p1; sv[2] = t.p2; sv[3] = t.p3; sv[4] = t.p4;
-        if (hl == 0) v.knn_save_q[(size_t)s * v.edge_cap + e] = make_float4(qx, qy, qz, guard);
-      }
-      knn_merge(t, g, hl, half_shift);
+    bool pend = cnt > 0;
+    Best2Acc b2;
+    b2.clear();
+    int dbg_n = 0;
+    bool dbg_two_phase = false;
+    {
+      const bool now = pend && (have_b ? !(lb > B) : (hl == 13 || hl == 27 || lb <= Tune::kNearSq));
+      if (v.debug & 32) dbg_n = __shfl(half_incl_scan_i32(now ? (int)cnt : 0), kKnnGroup - 1, kKnnGroup);
+      knn_stream_cells<Best2Acc, Tune::kLoadsBig, Tune::kLoadsFlat, Tune::kBigCell>(b2, sp, sh.incl[grp], sh.adj[grp], start, now ? cnt : 0u, hl, qx, qy, qz,
+                                                                                     ((v.debug & 32) && s == 0 && e < E) ? v.dbg_q + ((size_t)outer_it * v.edge_cap + e) * 12 + 8 : nullptr);
+      pend = pend && !now;
     }
-    DBG_STAMP(v, dbgb, 1, 5);
-    if (top5_dist(g.k4) < 1.0f) {                                // :324 (inf when < 5 candidates)
-      const int mypos = hl == 0 ? g.p0 : hl == 1 ? g.p1 : hl == 2 ? g.p2 : hl == 3 ? g.p3 : g.p4;
+    DBG_STAMP(v, dbgb, 1, 3); DBG_QSTAMP(3);
+    if (!have_b && ((__ballot(pend) >> half_shift) & 0xFFFFFFFFull)) {      // (uniform over the half-wave)
+      B = best2_bound(b2, half_shift);
+      pend = pend && !(lb > B);
+      if ((__ballot(pend) >> half_shift) & 0xFFFFFFFFull) {
+        if (v.debug & 32) { dbg_n += __shfl(half_incl_scan_i32(pend ? (int)cnt : 0), kKnnGroup - 1, kKnnGroup); dbg_two_phase = true; }
+        knn_stream_cells<Best2Acc, Tune::kLoadsBig, Tune::kLoadsFlat, Tune::kBigCell>(b2, sp, sh.incl[grp], sh.adj[grp], start, pend ? cnt : 0u, hl, qx, qy, qz);
+      }
+    } else {
+      pend = false;
+    }
+    DBG_STAMP(v, dbgb, 1, 4); DBG_QSTAMP(4);
+    int pos5[5];
+    const bool certain = best2_select(b2, hl, half_shift, d5, pos5) && !v.knn_exact_only;
+    if ((v.debug & 32) && s == 0 && e < E && hl == 0) v.dbg_q[((size_t)outer_it * v.edge_cap + e) * 12] = (unsigned int)dbg_n | (dbg_two_phase ? 0x40000000u : 0u) | (certain ? 0u : 0x80000000u);
+    if ((v.debug & 64) && hl == 0) {       // (debug) fast-path results / exact-list repeats / queries with a second phase; candidates streamed
+      atomicAdd(&v.dbg_clk[256 + (certain ? 0 : 1)], 1ull);
+      if (dbg_two_phase) atomicAdd(&v.dbg_clk[258], 1ull);
+      atomicAdd(&v.dbg_clk[384 + (dbg_n / 64 < 63 ? dbg_n / 64 : 63)], 1ull);
+    }
+    if (!certain) {                                  // (uniform over the half-wave) exact path: sorted (distance, index) lists
+      // every segment the fast path streamed (its pruning was exact): lb <= B, or the phase-1 set
+      const bool all = cnt > 0 && (!(lb > B) || (!have_b && (hl == 13 || hl == 27 || lb <= Tune::kNearSq)));
+      // The fast path's fifth popped distance bounds the true fifth-nearest distance from above whenever it is finite (five
+      // kept entries lie at or below it), and nothing at or beyond the 1.0 gate can matter: the lists start filled with the
+      // sentinel (bound, INT_MAX), so only the handful of candidates at or below the bound are ever inserted — this repeat
+      // costs about as much as the fast stream (every launch has a query or two that need it, and a launch lasts as long
+      // as its slowest query).
+      Top5Acc ta;
+      Top5 g;
+      {
+        const float bnd = d5 < 1.0f ? d5 : 1.0f;
+        const unsigned long long sentinel = ((unsigned long long)(unsigned int)__float_as_int(bnd) << 32) | 0x7fffffffull;
+        ta.t.k0 = ta.t.k1 = ta.t.k2 = ta.t.k3 = ta.t.k4 = sentinel;
+        ta.t.p0 = ta.t.p1 = ta.t.p2 = ta.t.p3 = ta.t.p4 = -1;
+      }
+      knn_stream_cells<Top5Acc, 4, 4, 128>(ta, sp, sh.incl[grp], sh.adj[grp], start, all ? cnt : 0u, hl, qx, qy, qz);
+      knn_merge(ta.t, g, hl, half_shift);
+      d5 = g.p4 >= 0 ? top5_dist(g.k4) : __int_as_float(0x7f800000);       // (a sentinel among the five: fewer than five candidates inside the gate)
+      pos5[0] = g.p0; pos5[1] = g.p1; pos5[2] = g.p2; pos5[3] = g.p3; pos5[4] = g.p4;
+    }
+    DBG_STAMP(v, dbgb, 1, 5); DBG_QSTAMP(5);
+    if ((v.debug & 64) && s == 0 && hl == 0) {
+      const int bin = (int)((wall_clock64() - t_blk) / 100ull);
+      atomicAdd(&v.dbg_clk[320 + (bin < 63 ? bin : 63)], 1ull);
+      const int nb = dbg_n < 64 ? 0 : dbg_n < 128 ? 1 : dbg_n < 256 ? 2 : dbg_n < 512 ? 3 : dbg_n < 1024 ? 4 : 5;
+      atomicAdd(&v.dbg_clk[448 + (bin / 4 < 7 ? bin / 4 : 7) * 8 + nb + (dbg_two_phase ? 0 : 0)], 1ull);
+      if (!certain) atomicAdd(&v.dbg_clk[448 + (bin / 4 < 7 ? bin / 4 : 7) * 8 + 7], 1ull);
+      if (dbg_two_phase) atomicAdd(&v.dbg_clk[448 + (bin / 4 < 7 ? bin / 4 : 7) * 8 + 6], 1ull);
+    }
+    if (d5 < 1.0f) {                                 // :324 (inf when < 5 candidates)
+      const int mypos = hl == 0 ? pos5[0] : hl == 1 ? pos5[1] : hl == 2 ? pos5[2] : hl == 3 ? pos5[3] : pos5[4];
       if (hl < 5) {
         const float4 m = sp[mypos];
-        s_nn[grp][hl * 3 + 0] = m.x; s_nn[grp][hl * 3 + 1] = m.y; s_nn[grp][hl * 3 + 2] = m.z;
+        sh.nn[grp][hl * 3 + 0] = m.x; sh.nn[grp][hl * 3 + 1] = m.y; sh.nn[grp][hl * 3 + 2] = m.z;
+        if (hl < 2) sh.res[grp][1 + hl] = __float_as_int(m.w);     // window indices of NN0, NN1
       }
-      if (hl == 0) { s_res[grp][0] = 1; s_res[grp][1] = top5_index(g.k0); s_res[grp][2] = top5_index(g.k1); }
+      if (hl == 0) sh.res[grp][0] = 1;
     }
   }
+  // what the second pass prunes with: the query and its fifth-nearest distance (inf: fewer than five candidates / no query)
+  if (outer_it == 0 && v.knn_save_q && e < E && hl == 0) v.knn_save_q[(size_t)s * v.edge_cap + e] = make_float4(qx, qy, qz, d5);
   __syncthreads();
-  DBG_STAMP(v, dbgb, 1, 6);
+  DBG_STAMP(v, dbgb, 1, 6); DBG_QSTAMP(6);
   if (kKnnThreads < 256 && v.knn_nn) {
     // Lock-step batches (VALU-issue bound): the line gates of a workgroup's four queries would occupy a whole wave's
     // instruction stream for four lanes.  The neighbours go to memory instead (80 B per query) and k_line_gate runs
     // the gates with one query per lane on full waves.
     if (threadIdx.x < kKnnQueries * 5) {
       const int q = threadIdx.x / 5, j = threadIdx.x % 5;
-      const int eq = bxi * kKnnQueries + q;
+      const int eq = bv * kKnnQueries + q;
       if (eq < v.edge_cap) {
-        const int w = j == 0 ? s_res[q][0] : (j == 1 ? s_res[q][1] : (j == 2 ? s_res[q][2] : 0));
-        v.knn_nn[((size_t)s * v.edge_cap + eq) * 5 + j] = make_float4(s_nn[q][j * 3], s_nn[q][j * 3 + 1], s_nn[q][j * 3 + 2], __int_as_float(w));
+        const int w = j == 0 ? sh.res[q][0] : (j == 1 ? sh.res[q][1] : (j == 2 ? sh.res[q][2] : 0));
+        v.knn_nn[((size_t)s * v.edge_cap + eq) * 5 + j] = make_float4(sh.nn[q][j * 3], sh.nn[q][j * 3 + 1], sh.nn[q][j * 3 + 2], __int_as_float(w));
       }
     }
     return;
@@ -1370,12 +1387,12 @@ __global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int oute
   // queries instead of once per query.
   if (threadIdx.x < kKnnQueries) {
     const int q = threadIdx.x;
-    const int eq = bxi * kKnnQueries + q;
-    bool valid = (eq < E) && (s_res[q][0] != 0);
+    const int eq = bv * kKnnQueries + q;
+    bool valid = (eq < E) && (sh.res[q][0] != 0);
     float nx[5], ny[5], nz[5];
 #pragma unroll
-    for (int j = 0; j < 5; j++) { nx[j] = s_nn[q][j * 3]; ny[j] = s_nn[q][j * 3 + 1]; nz[j] = s_nn[q][j * 3 + 2]; }
-    if (valid && !(v.debug & 2)) valid = line_gate(nx, ny, nz);
+    for (int j = 0; j < 5; j++) { nx[j] = sh.nn[q][j * 3]; ny[j] = sh.nn[q][j * 3 + 1]; nz[j] = sh.nn[q][j * 3 + 2]; }
+    if (valid) valid = line_gate(nx, ny, nz);
     if (eq < E) {
       float4* ca = v.corr_a + (size_t)s * v.edge_cap + eq;
       float4* cb = v.corr_b + (size_t)s * v.edge_cap + eq;
@@ -1383,7 +1400,7 @@ __global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int oute
       if (valid) {
         *ca = make_float4(nx[0], ny[0], nz[0], 1.0f);              // :351-353
         *cb = make_float4(nx[1], ny[1], nz[1], 0.0f);              // :355-357
-        *cidx = make_int2(s_res[q][1], s_res[q][2]);
+        *cidx = make_int2(sh.res[q][1], sh.res[q][2]);
       } else {
         *ca = make_float4(0, 0, 0, 0); *cb = make_float4(0, 0, 0, 0); *cidx = make_int2(-1, -1);
       }
@@ -1391,10 +1408,12 @@ __global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int oute
     const unsigned long long vb = __ballot(valid);
     const int nvalid = __popcll(vb);
     if (q == 0) {
-      if (nvalid) atomicAdd(&st.info.matches[outer_it], nvalid);   // :346
-      v.corr_mask[((size_t)s * 2 + outer_it) * v.knn_blocks + bxi] = (unsigned char)vb;   // bit q = query q accepted
+      // :346 — with knn_partials the count travels as entry 29 of the workgroup's partial sums (no same-address atomic of
+      // every workgroup: hot-address atomics delay whatever else maps to that memory channel by microseconds)
+      if (nvalid && !v.knn_partials) atomicAdd(&st.info.matches[outer_it], nvalid);
+      v.corr_mask[((size_t)s * 2 + outer_it) * v.knn_blocks + bv] = (unsigned char)vb;   // bit q = query q accepted
     }
-    s_res[q][3] = valid ? 1 : 0;
+    sh.res[q][3] = valid ? 1 : 0;
   } else if (kKnnThreads > 64 && v.knn_partials && threadIdx.x >= 64 && threadIdx.x < 64 + kKnnQueries) {
     // The solve that follows starts at (param_q, param_t) — Ceres evaluates the residuals with the quaternion,
     // not with the matrix the neighbours were searched with (:186-195,205-206) — which is already known here.
@@ -1403,9 +1422,9 @@ __global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int oute
     // instead of a pass over all correspondences.  One lane per query on the SECOND wave, beside the line gates
     // of the first (the block does not depend on the gate's verdict; it is simply dropped if the gate says no).
     const int q = threadIdx.x - 64;
-    const int eq = bxi * kKnnQueries + q;
+    const int eq = bv * kKnnQueries + q;
     double flag = 0.0;
-    if (eq < E && s_res[q][0] != 0) {
+    if (eq < E && sh.res[q][0] != 0) {
       double Rm[12], pq[4], pt[3];
 #pragma unroll
       for (int i = 0; i < 4; i++) pq[i] = st.param_q[i];
@@ -1414,41 +1433,93 @@ __global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int oute
       iso_from_qt(pq, pt, Rm);
       const float4 pe = v.edges[((size_t)eb * v.n_streams + s) * v.edge_cap + eq];
       const double p[3] = {(double)pe.x, (double)pe.y, (double)pe.z};       // :347-349 sensor frame
-      const double a[3] = {(double)s_nn[q][0], (double)s_nn[q][1], (double)s_nn[q][2]};
-      const double b[3] = {(double)s_nn[q][3], (double)s_nn[q][4], (double)s_nn[q][5]};
+      const double a[3] = {(double)sh.nn[q][0], (double)sh.nn[q][1], (double)sh.nn[q][2]};
+      const double b[3] = {(double)sh.nn[q][3], (double)sh.nn[q][4], (double)sh.nn[q][5]};
       double J[18], rs[3], rho0, rho1;
       const bool ok = residual_block(Rm, p, a, b, v.min_range, v.max_range, J, rs, &rho0, &rho1);
 #pragma unroll
-      for (int i = 0; i < 18; i++) s_blk[q][i] = J[i];
-      s_blk[q][18] = rs[0]; s_blk[q][19] = rs[1]; s_blk[q][20] = rs[2]; s_blk[q][21] = rho0; s_blk[q][22] = rho1;
+      for (int i = 0; i < 18; i++) sh.blk[q][i] = J[i];
+      sh.blk[q][18] = rs[0]; sh.blk[q][19] = rs[1]; sh.blk[q][20] = rs[2]; sh.blk[q][21] = rho0; sh.blk[q][22] = rho1;
       flag = ok ? 1.0 : 2.0;
     }
-    s_blk[q][23] = flag;
+    sh.blk[q][23] = flag;
   }
   if (!v.knn_partials) return;                           // (uniform) lock-step batches: the solve evaluates everything itself
   __syncthreads();
   // entry hl of the block's contribution by lane hl of the query's own 32-lane group (J is read from LDS, so
   // the 29-entry accumulator never occupies registers in this kernel)
   if (hl < kAccN) {
-    const double flag = s_res[grp][3] ? s_blk[grp][23] : 0.0;     // (gate's verdict, block's finiteness)
+    const double flag = sh.res[grp][3] ? sh.blk[grp][23] : 0.0;     // (gate's verdict, block's finiteness)
     double x = 0.0;
-    if (flag == 1.0) x = residual_entry(s_blk[grp], s_blk[grp] + 18, s_blk[grp][21], s_blk[grp][22], hl);
+    if (flag == 1.0) x = residual_entry(sh.blk[grp], sh.blk[grp] + 18, sh.blk[grp][21], sh.blk[grp][22], hl);
     else if (flag == 2.0 && hl == 28) x = 1.0;            // non-finite block: counted, contributes nothing else
-    s_part[grp][hl] = x;
+    sh.part[grp][hl] = x;
+  } else if (hl == kAccN) {
+    sh.part[grp][hl] = sh.res[grp][3] ? 1.0 : 0.0;      // entry 29: accepted correspondences (:346)
   }
   __syncthreads();
-  if (threadIdx.x < kAccN) {
+  if (threadIdx.x <= kAccN) {
     double x = 0.0;
 #pragma unroll
-    for (int q = 0; q < kKnnQueries; q++) x += s_part[q][threadIdx.x];      // fixed order: deterministic
-    v.knn_part[(((size_t)s * 2 + outer_it) * v.knn_blocks + bxi) * 32 + threadIdx.x] = x;
+    for (int q = 0; q < kKnnQueries; q++) x += sh.part[q][threadIdx.x];      // fixed order: deterministic
+    v.knn_part[(((size_t)s * 2 + outer_it) * v.knn_blocks + bv) * 32 + threadIdx.x] = x;
   }
-  DBG_STAMP(v, dbgb, 1, 7);
-  if ((v.debug & 32) && s == 0 && threadIdx.x == 0) {      // histogram of workgroup durations, 1 us bins
+  DBG_STAMP(v, dbgb, 1, 7); DBG_QSTAMP(7);
+  if ((v.debug & 64) && s == 0 && threadIdx.x == 0) {      // histogram of workgroup durations, 1 us bins
     const unsigned long long d = wall_clock64() - t_blk;
     const int bin = (int)(d / 100ull);
     atomicAdd(&v.dbg_clk[192 + (bin < 63 ? bin : 63)], 1ull);
   }
+}
+
+// grid.x = v.knn_grid workgroups per stream (+ the streamed rebuild's ALLOC workgroups on the second pass): workgroup b
+// takes the query blocks b, b + knn_grid, ... below ceil(E / queries) — the grid is sized for the usual edge count
+// (half of the capacity), not for edge_cap: on lock-step batches two thirds of an edge_cap-sized grid were workgroups
+// that found nothing to do.
+template <int kKnnThreads>
+__global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int outer_it, int eb, unsigned int wait_edges, unsigned int signal_odo) {
+  constexpr int kKnnQueries = kKnnThreads / kKnnGroup;
+  __shared__ KnnShared<kKnnQueries> sh;
+  int bxi = (int)blockIdx.x, byi = (int)blockIdx.y;
+  xcd_remap(bxi, byi);
+  const int s = s0 + byi;
+  StreamState& st = v.state[s];
+  if (v.early_rebuild) {
+    if (bxi >= v.knn_grid) { if (outer_it == 1) rebuild_alloc(v, s, st, bxi - v.knn_grid, (int)gridDim.x - v.knn_grid); return; }
+    // streamed rebuild, bookkeeping before the first builders start (next launch): the frame count the build refers to
+    // (the finalising solve advances it beside them) and an empty list of occupied slots for the table being built
+    if (outer_it == 0 && bxi == 0 && threadIdx.x == 0) { st.reb_frame_count = st.frame_count; st.n_used_tab[(st.frame_count + 1) & 1] = 0; }
+  }
+  if (outer_it == 0) {
+    // (pipelined replay) this launch follows odometry `signal_odo` in stream order: that odometry has completed entirely;
+    // and the extraction that fills edge buffer eb (other stream) must have completed before anything of it is read
+    if (signal_odo && bxi == 0 && byi == 0 && threadIdx.x == 0) {
+      typedef __attribute__((address_space(1))) unsigned int gu32;
+      __hip_atomic_store((gu32*)(v.pipe_flags + kEdgePipeBufs), signal_odo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (wait_edges && !pipe_wait(v.pipe_flags + eb, wait_edges, &st.status)) return;
+  }
+  if (st.status & LIODOM_STATUS_PIPE_TIMEOUT) return;      // (uniform) a wait of this handle gave up: the edge buffer may be incomplete
+  if (!st.initialized) return;                     // uniform over the workgroup
+  const int E = st.n_edges_buf[eb];
+  // (two explicit calls, not a loop over bv: as a loop body the block needs 160 VGPRs instead of 69)
+  static_assert(kKnnGridDiv == 2, "k_knn handles exactly two query blocks per workgroup");
+  if (bxi * kKnnQueries >= E) {             // no query here: empty validity bytes for the solve's compaction
+    if (threadIdx.x == 0) {
+      v.corr_mask[((size_t)s * 2 + outer_it) * v.knn_blocks + bxi] = 0;
+      if (bxi + v.knn_grid < v.knn_blocks) v.corr_mask[((size_t)s * 2 + outer_it) * v.knn_blocks + bxi + v.knn_grid] = 0;
+    }
+    return;
+  }
+  knn_block<kKnnThreads>(v, s, st, outer_it, eb, bxi, E, sh);
+  const int bv2 = bxi + v.knn_grid;
+  if (bv2 >= v.knn_blocks) return;
+  if (bv2 * kKnnQueries >= E) {
+    if (threadIdx.x == 0) v.corr_mask[((size_t)s * 2 + outer_it) * v.knn_blocks + bv2] = 0;
+    return;
+  }
+  __syncthreads();                          // (the second block reuses the LDS)
+  knn_block<kKnnThreads>(v, s, st, outer_it, eb, bv2, E, sh);
 }
 
 // k_line_gate (lock-step batches): the line gate of laser_odometry.cc:325-344 for the queries of one kNN pass, one query
@@ -1479,7 +1550,7 @@ __global__ __launch_bounds__(256) void k_line_gate(DevView v, int s0, int outer_
     for (int j = 0; j < 5; j++) { nx[j] = 0.f; ny[j] = 0.f; nz[j] = 0.f; }
   }
   bool valid = (eq < E) && (found != 0);
-  if (valid && !(v.debug & 2)) valid = line_gate(nx, ny, nz);
+  if (valid) valid = line_gate(nx, ny, nz);
   if (eq < E) {
     float4* ca = v.corr_a + (size_t)s * v.edge_cap + eq;
     float4* cb = v.corr_b + (size_t)s * v.edge_cap + eq;
@@ -1902,7 +1973,8 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
   const bool dbge = (s == 0) && (g == 0) && (tid == 0) && (outer_it == 1);
   DBG_STAMP(v, dbgb, 2, 0);
   const int E = st.n_edges_buf[eb];
-  const int nblocks = st.info.matches[outer_it];
+  int nblocks = st.info.matches[outer_it];      // (lock-step batches: counted by k_line_gate; else from k_knn's partial sums below)
+  __shared__ int sh_nmatch;
   const unsigned int epoch0 = ((unsigned int)(st.scan_counter + 1) << 6) | ((unsigned int)outer_it << 5);
   unsigned int n_eval = 0;
   bool xch_local = false;       // the G workgroups were seen on one XCD: exchanges through its L2 (lm_exchange)
@@ -1920,7 +1992,7 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
     const double* part = v.knn_part + ((size_t)s * 2 + outer_it) * v.knn_blocks * 32;
     const int i = tid & 31, r0 = tid >> 5;               // 16 row classes x 32 columns (29 used)
     double x0 = 0.0, x1 = 0.0;
-    if (i < kAccN) {
+    if (i <= kAccN) {                                    // (entry 29: the number of accepted correspondences)
       // 16 independent loads in flight per pass (one memory round trip for up to 256 k_knn workgroups)
       for (int rb = r0; rb < nb; rb += 256) {
         double xs[16];
@@ -1932,13 +2004,15 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
     }
     sh_red[r0][i] = x0 + x1;
     __syncthreads();
-    if (tid < kAccN) {
+    if (tid <= kAccN) {
       double x = 0.0;
 #pragma unroll
       for (int r = 0; r < 16; r++) x += sh_red[r][tid];
-      sh_acc[tid] = x;
+      if (tid < kAccN) sh_acc[tid] = x;
+      else { sh_nmatch = (int)x; if (g == 0) st.info.matches[outer_it] = (int)x; }      // :346 (sum of small integers: exact)
     }
     __syncthreads();
+    nblocks = sh_nmatch;
   } else {
     // ---- lock-step batches: k_knn leaves only the validity bytes; compaction, then an ordinary first evaluation ----
     if (prep) {
@@ -1958,7 +2032,7 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
   // evaluations (step 0: validity bytes -> index list, triples into registers) or reset the hash slots of the
   // build this scan searched (step 1 of the finalising solve) ----
   int dbg_it = 0;
-  for (int step = 0; !(v.debug & 8) || step == 0; step++) {
+  for (int step = 0;; step++) {
     if (tid == kLmCtl) {
       // (a wave-parallel controller — lane 8 r + c holding entry (r, c) of the 6 x 6 matrices, Cholesky columns
       // broadcast through LDS, solves on readlane'd entries — was measured slower than this single lane:
@@ -1983,7 +2057,7 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
     if (step == 0) { if (v.knn_partials && !prep) my_share(sh_C); DBG_STAMP(v, dbgb, 2, 3); }
     else { DBG_STAMP(v, dbgb && dbg_it < 5, 2, 5 + 2 * dbg_it); dbg_it++; }
     if (sh_flag != LM_NEED_EVAL) break;
-    if (G > 1) { lm_eval(v, s, eb, c_lo, c_hi, sh_idx, sh_pose, sh_part, sh_loc, cache); DBG_STAMP(v, dbgb && dbg_it < 4, 2, 12 + dbg_it); lm_exchange(v, s, g, G, epoch0 | ++n_eval, sh_loc, sh_acc, &st.status, xch_local, &sh_same_xcc); xch_local = sh_same_xcc != 0 && !(v.debug & 16); }
+    if (G > 1) { lm_eval(v, s, eb, c_lo, c_hi, sh_idx, sh_pose, sh_part, sh_loc, cache); DBG_STAMP(v, dbgb && dbg_it < 4, 2, 12 + dbg_it); lm_exchange(v, s, g, G, epoch0 | ++n_eval, sh_loc, sh_acc, &st.status, xch_local, &sh_same_xcc); xch_local = sh_same_xcc != 0; }
     else lm_eval(v, s, eb, c_lo, c_hi, sh_idx, sh_pose, sh_part, sh_acc, cache);
     DBG_STAMP(v, dbgb && dbg_it < 5, 2, 4 + 2 * dbg_it);
   }

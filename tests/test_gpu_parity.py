@@ -177,13 +177,17 @@ def _run_stream(orc, synth, H, W, lt, R, epr, P, nscans, stream=0, use_pipeline=
                 if k == 1 and it == 0:
                     assert not differ.any(), "scan 1, pass 0 (identity prediction in both): %d correspondences differ" % differ.sum()
                 for e in np.nonzero(differ)[0]:
+                    # explained only by an input difference: the query bits, or a window point among the UNION of both
+                    # sides' five nearest neighbours (whoever ranks a differing point among its five may pick another line)
                     explained = bool(np.any(qg[e].view(np.uint32) != qo[e].view(np.uint32)))
                     if not explained and win_differs is not None:
-                        for idx in (ao[e], bo[e], ag[e], bg[e]):
-                            explained = explained or (idx >= 0 and bool(win_differs[idx]))
-                        # a neighbour that only one side ranks among the five may be a point that differs, too
-                        explained = explained or bool(win_differs[np.linalg.norm(map_g[:, :3] - qg[e], axis=1) < 1.0].any())
-                    assert explained, "scan %d pass %d edge %d: correspondence differs although the query and all nearby window points are bit-equal" % (k, it, e)
+                        q4 = np.zeros((1, 4), dtype=np.float32)
+                        q4[0, :3] = qg[e]
+                        five_g = orc.knn5(map_g, q4, 0)[0][0]
+                        q4[0, :3] = qo[e]
+                        five_o = orc.knn5(map_o, q4, 0)[0][0]
+                        explained = any(i >= 0 and bool(win_differs[i]) for i in list(five_g) + list(five_o))
+                    assert explained, "scan %d pass %d edge %d: correspondence differs although the query and the five nearest window points of both sides are bit-equal" % (k, it, e)
                 n_e2e_diff += int(differ.sum())
                 assert int(differ.sum()) <= 6, "scan %d pass %d: %d correspondences differ" % (k, it, int(differ.sum()))
                 assert info_g.lm[it].iterations == info_o.lm[it].iterations
@@ -591,31 +595,67 @@ def test_graph_replay_equals_eager(orc, synth, monkeypatch):
     assert np.array_equal(res["0"].view(np.uint64), res["1"].view(np.uint64))
 
 
-def test_second_knn_pass_reuse_equals_full_search(orc, synth, monkeypatch):
-    """The second kNN pass of a scan re-ranks the candidates the first pass kept and accepts the result only when a
-    guard distance proves that no other map point can be among the five nearest (else it searches from scratch).
-    LIODOM_KNN_REUSE=0 disables the shortcut: poses, match counts and correspondence indices must be bit-identical,
-    also on a trajectory with large pose corrections between the passes (fast motion: many fallbacks)."""
+def test_knn_fast_path_equals_exact_list_path(orc, synth, monkeypatch):
+    """k_knn keeps two candidates per lane and pops the five nearest from them; a query whose result that cannot
+    certify (three of its nearest in one lane, or equal distances that FLANN orders by index) repeats the stream
+    with sorted (distance, index) lists.  LIODOM_KNN_EXACT_ONLY=1 sends EVERY query through the list path;
+    LIODOM_KNN_SAVE=0 makes the second pass of a scan derive its pruning bound like the first one (own cell first)
+    instead of from the first pass's fifth-nearest distance.  Poses, match counts and correspondence indices must be
+    bit-identical in all three configurations, also with large pose corrections between the passes."""
     H, W, R, epr, P, K = 16, 900, 6, 10, 5, 14
+    modes = {"default": {}, "exact_only": {"LIODOM_KNN_EXACT_ONLY": "1"}, "no_saved_bound": {"LIODOM_KNN_SAVE": "0"}}
     for yaw, speed in ((0.5, 0.1), (3.0, 0.6)):
         cfg = synth.make_cfg(H, W, 0, yaw_rate_deg=yaw, speed=speed)
         scans = [synth.scan(cfg, 6, k)[0] for k in range(K)]
         res = {}
-        for mode in ("0", "1"):
-            monkeypatch.setenv("LIODOM_KNN_REUSE", mode)
+        for mode, env in modes.items():
+            for name in ("LIODOM_KNN_EXACT_ONLY", "LIODOM_KNN_SAVE"):
+                monkeypatch.delenv(name, raising=False)
+            for name, val in env.items():
+                monkeypatch.setenv(name, val)
             po, g = mk(orc, H, W, 0, R, epr, P)
             out = []
             for k in range(K):
                 pose, info = g.process_scan(scans[k], H, W)
+                v0, a0, b0 = g.correspondences(0)
                 v1, a1, b1 = g.correspondences(1)
-                out.append((pose.copy(), tuple(info.matches), v1.copy(), a1.copy(), b1.copy()))
+                out.append((pose.copy(), tuple(info.matches), v0.copy(), a0.copy(), b0.copy(), v1.copy(), a1.copy(), b1.copy()))
             res[mode] = out
             g.close()
-        for k in range(K):
-            p0, m0, v0, a0, b0 = res["0"][k]
-            p1, m1, v1, a1, b1 = res["1"][k]
-            assert np.array_equal(p0.view(np.uint64), p1.view(np.uint64)), (yaw, k)
-            assert m0 == m1 and np.array_equal(v0, v1) and np.array_equal(a0, a1) and np.array_equal(b0, b1), (yaw, k)
+        for mode in ("exact_only", "no_saved_bound"):
+            for k in range(K):
+                assert np.array_equal(res["default"][k][0].view(np.uint64), res[mode][k][0].view(np.uint64)), (mode, yaw, k)
+                assert res["default"][k][1] == res[mode][k][1], (mode, yaw, k)
+                for x, y in zip(res["default"][k][2:], res[mode][k][2:]):
+                    assert np.array_equal(x, y), (mode, yaw, k)
+
+
+def test_knn_ties_are_ordered_by_window_index(orc, synth):
+    """A sensor that does not move in a noise-free world sees the same scan again and again: the window (P = 2) holds
+    two exact copies of every edge, so the five nearest neighbours of every query come in pairs of equal float distance
+    and FLANN's result order — lower index first — decides which two points define the line.  All those queries take
+    the exact list path; valid flags and both line-point indices must equal the oracle's on the GPU's own inputs."""
+    H, W, R, epr, P, K = 16, 900, 6, 10, 2, 7
+    cfg = synth.make_cfg(H, W, 0, noise_sigma=0.0, yaw_rate_deg=0.0, speed=0.0)
+    po, g = mk(orc, H, W, 0, R, epr, P, debug=1)
+    x = synth.scan(cfg, 2, 0)[0]
+    n_tied = 0
+    for k in range(K):
+        map_g, _ = g.local_map()
+        pose, info = g.process_scan(x, H, W)
+        assert info.status == 0
+        if k == 0:
+            continue
+        for it in (0, 1):
+            vg, ag, bg = g.correspondences(it)
+            qg = g.knn_queries(it)
+            vk, ak, bk = orc.match_edges(po, map_g, qg)
+            assert np.array_equal(vk, vg) and np.array_equal(ak, ag) and np.array_equal(bk, bg), (k, it, np.nonzero((vk != vg) | (ak != ag) | (bk != bg))[0][:10])
+        if k >= 2:
+            assert len(np.unique(map_g.view(np.uint32)[:, :3], axis=0)) < len(map_g)        # the window really holds duplicates
+            n_tied += int(vg.sum())
+    assert n_tied > 0               # accepted correspondences whose NN0 / NN1 are two copies of one point
+    g.close()
 
 
 def test_early_rebuild_equals_three_kernel_rebuild(orc, synth, monkeypatch):

@@ -185,7 +185,7 @@ SECTIONS["syncprof"] = sec_syncprof
 
 def sec_clocks(H=64, W=1800, R=8, epr=10, P=20, K=40):
     import ctypes as C
-    os.environ["LIODOM_ABLATE"] = str(int(os.environ.get("LIODOM_ABLATE", "0")) | 32)
+    os.environ.setdefault("LIODOM_DEBUG_CLOCKS", "65")
     cfg = synth.make_cfg(H, W, 0)
     po, g = mk(H, W, 0, R, epr, P, pose_log_capacity=4 * K)
     g.alloc_resident(K)
@@ -194,23 +194,28 @@ def sec_clocks(H=64, W=1800, R=8, epr=10, P=20, K=40):
     for k in range(K):
         g.process_resident(k, H * W, H, W, readback=False)
     g.sync()
-    buf = (C.c_ulonglong * 256)()
+    buf = (C.c_ulonglong * 512)()
     g.L.liodom_debug_clocks.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
     g.L.liodom_debug_clocks(g.h, buf)
     allv = np.array(list(buf), dtype=np.int64)
     print('k_ring_extract per-ring workgroup durations (us), rings 0..63:', np.round(allv[128:192] / 100.0, 1).tolist())
     print('k_ring_extract (carry re-run rounds, edges) of the rings written last (ring & 31):', [(int(x) & 255, int(x) >> 8) for x in allv[96:128]])
-    print('k_knn second pass: %d queries re-ranked from the saved lists, %d fell back to the full search' % (int(allv[95]), int(allv[94])))
+    print('k_knn (both passes): %d queries answered by the Best2 fast path, %d repeated with the exact lists; %d needed a second phase' % (int(allv[256]), int(allv[257]), int(allv[258])))
+    print('k_knn query (half-wave) time to selection, 1 us bins:', allv[320:384].tolist())
+    print('k_knn candidates streamed per query, bins of 64:', allv[384:448].tolist())
+    print('k_knn time (rows: 4 us bins) x candidates (<64, <128, <256, <512, <1024, more | two-phase | exact repeat):')
+    print(allv[448:512].reshape(8, 8))
     print('k_knn workgroup-duration histogram (1 us bins, all scans):', allv[192:256].tolist())
     a = allv[:128].reshape(4, 32).copy()
+    a[2][30] = 0
     names = {0: ["start", "", "gap bits", "", "", "spec select", "carry resolved", "emitted"],
-             1: ["start", "query ready", "hash probed", "centre streamed", "merge1", "phase2 done", "nn fetched", "gate done"],
+             1: ["start", "query ready", "hash probed", "phase 1 streamed", "bound + phase 2", "five selected", "nn fetched", "gate + partial sums"],
              2: ["start", "pose ready", "eval0", "begin", "eval1", "upd1", "eval2", "upd2", "eval3", "upd3", "eval4", "upd4", "", "", "", "", "", "", "", "", "loop end", "pose written", "finalized", "", "", "", "", "", "(solving workgroup done)", "appender 0: pose received", "appender 0: point placed"]}
     r2 = a[2]
     print("k_lm_solve (it 1) evaluation done / exchange done (us after kernel start):", [(round((int(allv[64 + 12 + i]) - int(allv[64])) / 100.0, 2), round((int(allv[64 + 4 + 2 * i]) - int(allv[64])) / 100.0, 2)) for i in range(1, 4)])
     print("k_lm_solve (it 1) exchange: local transport %d, XCC %d, evaluations %d" % (int(allv[64 + 27]) // 100, (int(allv[64 + 27]) // 10) % 10, int(allv[64 + 27]) % 10))
     print("k_lm_solve begin phase: controller lm_begin done at %.2f us; evaluator wave 1: start %.2f, compacted %.2f (us after kernel start)" % tuple((r2[i] - r2[0]) / 100.0 for i in (23, 24, 25)))
-    for k, kn in ((0, "k_ring_extract (ring 40)"), (1, "k_knn (block 20, it 0)"), (2, "k_lm_solve (it 1)")):
+    for k, kn in ((0, "k_ring_extract (ring 40)"), (1, "k_knn (block 5, it 0)"), (2, "k_lm_solve (it 1)")):
         row = a[k]
         t0 = row[0]
         print(kn)
@@ -221,6 +226,59 @@ def sec_clocks(H=64, W=1800, R=8, epr=10, P=20, K=40):
             print("   %-22s +%7.2f us  (at %7.2f)" % (nm, (row[i] - prev) / 100.0, (row[i] - t0) / 100.0))
             prev = row[i]
     g.close()
+
+
+def sec_knntimes(H=64, W=1800, R=8, epr=10, P=20, K=40):
+    """Per-query phase times of k_knn for the last scan of a pipelined replay (LIODOM_DEBUG_CLOCKS)."""
+    import ctypes as C
+    os.environ.setdefault("LIODOM_DEBUG_CLOCKS", "1")
+    cfg = synth.make_cfg(H, W, 0)
+    po, g = mk(H, W, 0, R, epr, P, pose_log_capacity=4 * K)
+    g.alloc_resident(K)
+    for k in range(K):
+        g.upload_scan(0, k, synth.scan(cfg, 0, k)[0])
+    serial = os.environ.get("KNN_SERIAL", "0") != "0"      # every scan alone on the GPU (no extraction of the next scan beside it)
+    print("mode:", "serial (pose read back before the next scan is submitted)" if serial else "asynchronous replay (next scan's extraction overlaps)")
+    for k in range(K):
+        g.process_resident(k, H * W, H, W, readback=serial)
+    g.sync()
+    cap = C.c_int(0)
+    g.L.liodom_debug_knn_times.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+    g.L.liodom_debug_knn_times(g.h, None, C.byref(cap))
+    buf = np.zeros((2, cap.value, 12), dtype=np.uint32)
+    assert g.L.liodom_debug_knn_times(g.h, buf.ctypes.data_as(C.c_void_p), C.byref(cap)) == 0
+    E = int(np.count_nonzero(buf[0, :, 7] | buf[0, :, 6]))
+    names = ["query ready", "probed", "phase 1", "phase 2", "selected", "barrier", "end"]
+    for it in (0, 1):
+        t = buf[it, :E, 1:8].astype(np.float64) / 100.0
+        x = buf[it, :E, 8:]
+        n = buf[it, :E, 0] & 0x3FFFFFFF
+        two = (buf[it, :E, 0] >> 30) & 1
+        d = np.diff(np.concatenate([np.zeros((E, 1)), t], axis=1), axis=1)
+        print("pass %d: %d queries; mean phase durations (us): %s" % (it, E, ", ".join("%s %.2f" % (nm, x) for nm, x in zip(names, d.mean(axis=0)))))
+        sel = t[:, 4]
+        order = np.argsort(-sel)
+        print("  selection time percentiles (us): 50%% %.2f  90%% %.2f  99%% %.2f  max %.2f" % tuple(np.percentile(sel, [50, 90, 99, 100])))
+        for q in order[:12]:
+            print("  slow query %4d: n=%5d two-phase=%d  %s | phase-1 stream: big part %.2f us (%d cells, %d rounds), flat part %.2f us (%d rounds, T=%d)" % (
+                q, n[q], two[q], "  ".join("%s +%.2f" % (nm, xx) for nm, xx in zip(names, d[q])), x[q, 0] / 100.0, x[q, 2] & 255, (x[q, 2] >> 8) & 255, x[q, 1] / 100.0, (x[q, 2] >> 16) & 15, x[q, 2] >> 20))
+        flat_t = x[:, 1] / 100.0
+        rounds = (x[:, 2] >> 16) & 15
+        nseg = x[:, 3]
+        pair_rounds = np.maximum(rounds[0::2][:E // 2], rounds[1::2][:E // 2])
+        pair_nseg = np.maximum(nseg[0::2][:E // 2], nseg[1::2][:E // 2])
+        pair_t = flat_t[0::2][:E // 2]
+        for r in (1, 2, 3):
+            for lo, hi in ((1, 2), (3, 4), (5, 8), (9, 28)):
+                msk = (pair_rounds == r) & (pair_nseg >= lo) & (pair_nseg <= hi)
+                if msk.sum():
+                    print("   phase-1 flat part, %d round(s), %2d..%2d segments: %4d wave(s), mean %.2f us, 90%% %.2f, max %.2f" % (r, lo, hi, msk.sum(), pair_t[msk].mean(), np.percentile(pair_t[msk], 90), pair_t[msk].max()))
+        wg = sel[:E - E % 8].reshape(-1, 8)
+        print("  workgroup (8 queries) max selection time: mean %.2f us, max %.2f; mean of all queries %.2f" % (wg.max(axis=1).mean(), wg.max(), sel.mean()))
+    g.close()
+
+
+SECTIONS["knntimes"] = sec_knntimes
 
 
 SECTIONS["clocks"] = sec_clocks
