@@ -17,7 +17,13 @@ Output: ONE JSON line on rank 0 with metric/value/... plus
   cpu_baseline  the CPU oracle ("port") on a bounded sample of the same scans, timed on this host:
                 1 thread, and the reference's own thread policy
   parity        GPU-vs-oracle pose difference, per replica (worst over ranks)
+  roofline_8d   the same timed leg scored per STAGE against SURVEY.md §8(d)'s bytes (extract = 16 N + 24 E for classify +
+                scatter + extract + compact together, ...)
+  host_fed / two_thread   the drop-in-shaped rates: scans arriving in pinned HOST memory (liodom_replay_host: upload and
+                extraction of scan k+1 overlap the odometry of scan k), and an extractor thread + an odometer thread
+                through liodom_extract_edges / liodom_odometry_step as INTEGRATION.md §2 prescribes (never `value`)
   batched       lock-step multi-stream run on one GPU (throughput mode) with its own roofline
+Exit status 3 if any replica's parity check fails.
 """
 import argparse
 import json
@@ -70,30 +76,65 @@ def algorithmic_bytes(kernel, N, E, M, C, evals, streamed=False):
     return 0.0
 
 
-def measured_traffic(kernel, n_streams):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled as the
-    microarch guide prescribes for gfx950, + WRITE_SIZE; profiles/*_pmc_traffic.json, produced by
-    tools/pmc_summary.py).  PMC counters cannot be collected from inside this process; the figure
-    is scaled from the nearest profiled stream count and is null when no profile is committed."""
+def measured_traffic(kernel, n_streams, workload):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC profile of THIS workload
+    (profiles/*_pmc_traffic_<workload>.json, written by tools/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE passes;
+    FETCH_SIZE doubled as the microarch guide prescribes for gfx950).  Rows are selected by launch shape — the profile
+    keeps the single-stream run and the lock-step run (its stream count recorded) apart, launch-weighted over the grids a
+    kernel is launched with — never by "smallest grid".  PMC counters cannot be collected from inside this process; null
+    when no profile of this workload is committed."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic_%s.json" % workload)))
     if not files:
         return None
     try:
-        rows = json.load(open(files[-1])).get(kernel)
-        if not rows:
+        prof = json.load(open(files[-1]))
+        if prof.get("workload") != workload:
             return None
-        rows = sorted(rows, key=lambda r: r["grid"])
-        base = rows[0]                       # smallest grid = 1 stream
-        per_stream = base["hbm_bytes_per_launch"]
-        if n_streams > 1 and len(rows) > 1:  # larger grid = 16 lock-step streams
-            per_stream = rows[-1]["hbm_bytes_per_launch"] / max(1.0, rows[-1]["grid"] / base["grid"])
-        return int(per_stream * n_streams)
+        if n_streams == 1:
+            row = prof.get("single", {}).get(kernel)
+            return int(row["hbm_bytes_per_launch"]) if row else None
+        b = prof.get("batched", {})
+        row = b.get("kernels", {}).get(kernel)
+        if not row or not b.get("streams"):
+            return None
+        return int(row["hbm_bytes_per_launch"] / b["streams"] * n_streams)      # scaled from the profiled stream count
     except Exception:
         return None
 
 
-def roofline_from_stats(stats, n_streams, N, E, M, C, evals):
+STAGES_8D = {
+    # SURVEY.md §8(d): stage -> (kernels whose time counts, bytes per scan)
+    "extract": (("k_classify", "k_ring_scatter", "k_ring_extract", "k_compact_edges"), lambda N, E, M, C, ev: 16.0 * N + 24.0 * E),
+    "knn (2 passes)": (("k_knn",), lambda N, E, M, C, ev: 2.0 * (16.0 * (M + E) + 28.0 * E)),
+    "solve + window/hash rebuild + append": (("k_lm_solve", "k_window_insert", "k_hash_alloc", "k_hash_scatter", "k_hash_build", "k_hash_clear"),
+                                             lambda N, E, M, C, ev: 2.0 * (36.0 * C + 224.0) * max(ev, 1.0) + 32.0 * M + 32.0 * E),
+}
+
+
+def roofline_8d(stats, n_streams, N, E, M, C, evals):
+    """Stages scored against SURVEY.md §8(d)'s algorithmic bytes per scan (all streams of a step together): summed
+    HIP-event kernel time of the stage per step vs its bytes — e.g. extract = 16 N + 24 E for the three extraction
+    passes + compaction together, whatever traffic the implementation's extra passes cause."""
+    stats = {k: v for k, v in stats.items() if v[0]}
+    steps = max(1, stats.get("k_classify", (1, 0))[0])
+    out, tot_b, tot_us = {}, 0.0, 0.0
+    for name, (kernels, fn) in STAGES_8D.items():
+        us = sum(stats[k][1] for k in kernels if k in stats) / steps * 1e3
+        by = fn(N, E, M, C, evals) * n_streams
+        tot_b += by
+        tot_us += us
+        out[name] = {"us_per_step": round(us, 2), "bytes_per_step": int(by),
+                     "achieved_GBs": round(by / (us * 1e-6) / 1e9, 2) if us > 0 else 0.0,
+                     "frac": round(by / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5) if us > 0 else 0.0}
+    out["all stages"] = {"us_per_step": round(tot_us, 2), "bytes_per_step": int(tot_b),
+                         "achieved_GBs": round(tot_b / (tot_us * 1e-6) / 1e9, 2) if tot_us > 0 else 0.0,
+                         "frac": round(tot_b / (tot_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5) if tot_us > 0 else 0.0,
+                         "note": "summed kernel time (extraction overlaps odometry on a second stream in the timed leg)"}
+    return out
+
+
+def roofline_from_stats(stats, n_streams, N, E, M, C, evals, workload="hdl64"):
     """stats: {kernel: (launches, total_ms)} from HIP events on the handle's stream."""
     stats = {k: v for k, v in stats.items() if v[0]}
     streamed = n_streams <= 4 and "k_window_insert" not in stats and "k_hash_build" not in stats
@@ -106,7 +147,7 @@ def roofline_from_stats(stats, n_streams, N, E, M, C, evals):
     scans = max(1, stats.get("k_classify", (1, 0))[0])
     return {
         "bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": measured_traffic(name, n_streams),
+        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": measured_traffic(name, n_streams, workload),
         "avg_kernel_us": round(avg_s * 1e6, 2), "algorithmic_bytes_per_launch": int(by),
         "share_of_gpu_time": round(ms / tot, 3),
         "per_kernel_us": {k: round(v[1] / max(v[0], 1) * 1e3, 2) for k, v in stats.items()},
@@ -176,6 +217,7 @@ def main():
     ndev = la.device_count()
     if ndev > 0 and local_rank >= ndev:      # more ranks than GPUs (smoke runs): share devices
         local_rank = local_rank % ndev
+    orig_affinity = os.sched_getaffinity(0)
     rep.pin_cpus(local_rank)                 # host thread near the GPU's NUMA node (busy-polls the result record)
 
     wl = WORKLOADS[args.workload]
@@ -243,7 +285,8 @@ def main():
     meanM = float(np.mean([i.map_points for i in timed]))
     meanC = float(np.mean([(i.matches[0] + i.matches[1]) / 2.0 for i in timed]))
     mean_evals = float(np.mean([(i.lm[0].iterations + i.lm[1].iterations + 2) / 2.0 for i in timed]))
-    roofline = roofline_from_stats(stats, 1, N, meanE, meanM, meanC, mean_evals)
+    roofline = roofline_from_stats(stats, 1, N, meanE, meanM, meanC, mean_evals, args.workload)
+    roofline8d = roofline_8d(stats, 1, N, meanE, meanM, meanC, mean_evals)
     # asynchronous replay (no per-scan readback) for reference
     g.reset()
     run(0, F + Wm, readback=False)
@@ -268,6 +311,57 @@ def main():
     run(F + Wm, K, pipelined=False)
     g.sync()
     serial_rate = K / (time.perf_counter() - t1)
+    modes = g.modes()
+    # ---- drop-in-shaped legs (rank 0 of a 1-GPU run only; never `value`) ----
+    host_fed = two_thread = None
+    if world == 1:
+        # (a) scans arrive in HOST memory: pinned ring, upload + extraction of scan k+1 overlap the odometry of scan k, every pose read back
+        host = np.zeros((total, 1, N, 4), dtype=np.float32)
+        for k in range(total):
+            host[k, 0, :scans[k].shape[0]] = scans[k]
+        g.reset()
+        g.replay_host(host[:F + Wm], N, H, W, depth=1)
+        t1 = time.perf_counter()
+        hp, hi = g.replay_host(host[F + Wm:], N, H, W, depth=1)
+        th = time.perf_counter() - t1
+        # (continues the same trajectory: must equal the resident replay's poses)
+        hf_ok = bool(np.array_equal(hp[:, 0].view(np.uint64), poses_gpu[F + Wm:].view(np.uint64)))
+        host_fed = {"scans_per_s": round(K / th, 2), "us_per_scan": round(th / K * 1e6, 2),
+                    "mode": "liodom_replay_host, depth 1: page-locked host ring -> hipMemcpyAsync (%.2f MB per scan) on the extraction stream, "
+                            "extraction of scan k+1 beside the odometry of scan k, every pose read back in order" % (N * 16 / 1e6),
+                    "poses_bit_equal_to_resident_replay": hf_ok}
+        # (b) two threads through the C-ABI, as the reference node runs its FeatureExtractor / LaserOdometer threads (liodom_node.cc:89-91)
+        import queue
+        import threading
+        g.reset()
+        qd = queue.Queue(maxsize=2)
+        nrun = F + Wm + K
+        t_start = [0.0]
+        tt_poses = np.zeros((nrun, 7))
+
+        def extractor():
+            for k in range(nrun):
+                qd.put(g.extract_edges(scans[k], H, W)["edges"])
+            qd.put(None)
+
+        def odometer():
+            k = 0
+            while True:
+                e = qd.get()
+                if e is None:
+                    break
+                if k == F + Wm:
+                    t_start[0] = time.perf_counter()
+                tt_poses[k] = g.odometry_step(e)[0]
+                k += 1
+
+        th_x, th_o = threading.Thread(target=extractor), threading.Thread(target=odometer)
+        th_x.start(); th_o.start(); th_x.join(); th_o.join()
+        tt = time.perf_counter() - t_start[0]
+        two_thread = {"scans_per_s": round(K / tt, 2), "us_per_scan": round(tt / K * 1e6, 2),
+                      "mode": "extractor thread (liodom_extract_edges: host scan in, host edges out) + odometer thread (liodom_odometry_step: host "
+                              "edges in, pose out) on one handle, a 2-deep queue between them (Python threads; ctypes releases the GIL)",
+                      "poses_bit_equal_to_resident_replay": bool(np.array_equal(tt_poses.view(np.uint64), poses_gpu[:nrun].view(np.uint64)))}
     dev_name, cus = g.device_info()
     g.close()
 
@@ -286,12 +380,18 @@ def main():
                        "parallelism": "replicas only" if world > 1 else "single stream",
                        "mean_edges": round(meanE, 1), "mean_map_points": round(meanM, 1), "mean_matches": round(meanC, 1),
                        "mean_lm_evals_per_solve": round(mean_evals, 2), "device": dev_name, "compute_units": cus,
-                       "library_source_hash": la.api.build_info().get("source_hash") or la.api.built_hash()},
+                       "library_source_hash": la.api.build_info().get("source_hash") or la.api.built_hash(),
+                       "modes": modes,
+                       "environment": {k: v for k, v in os.environ.items() if k.startswith("LIODOM_") or k in ("HIP_FORCE_DEV_KERNARG", "AMD_SERIALIZE_KERNEL", "HIP_LAUNCH_BLOCKING")}},
             "strict_sync_scans_per_s": round(strict_rate, 2),
             "async_replay_scans_per_s": round(async_rate, 2),
             "serial_scans_per_s": round(serial_rate, 2),
             "roofline": roofline,
+            "roofline_8d": roofline8d,
         }
+        if host_fed:
+            out["host_fed"] = host_fed
+            out["two_thread"] = two_thread
         if args.workload != "hdl64":
             out["metric"] = "scans/sec (%dx%d cloud, prev_frames=%d) at 1 GPU; pose RMSE vs CPU ref" % (H, W, P)
 
@@ -320,6 +420,13 @@ def main():
         n_timed = n_run - (F + Wm)
         nproc = os.cpu_count() or 1
         st_threads, ev_threads = max(2, nproc - 5), nproc      # feature_extractor.cc:29-34, laser_odometry.cc:216
+        # the reference's thread counts come from the machine, not from this process's affinity mask: give the OpenMP
+        # threads the CPUs back that pin_cpus() took away for the GPU legs (nproc threads on one NUMA node's cores
+        # would time an oversubscribed run)
+        try:
+            os.sched_setaffinity(0, orig_affinity)
+        except Exception:
+            pass
         _, tc_ref = run_oracle(orc, wl, scans[:n_run], (st_threads, ev_threads), time_from=F + Wm)
         try:
             cpu_model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
@@ -348,6 +455,7 @@ def main():
         n_data = max(1, min(args.batched_data_streams, S))   # distinct synthetic streams; stream s replays data stream s % n_data
         data = [scans[:tb]] + [[synth.scan(cfg, 1000 + d, k)[0] for k in range(tb)] for d in range(1, n_data)]
         gb = la.Liodom(params, la.make_config(device=local_rank, n_streams=S, max_points=N, max_width=W, pose_log_capacity=tb + 8))
+        bmodes = gb.modes()
         gb.alloc_resident(tb)
         for s in range(S):
             for k in range(tb):
@@ -390,12 +498,16 @@ def main():
             "stream0_vs_single_stream_max_m": float(bdt.max()), "stream0_vs_single_stream_max_rad": float(bdr.max()),
             "note": "lock-step streams in one launch per kernel, per-step synchronous, extraction of step k+1 overlapped; "
                     "%d distinct synthetic streams replayed round-robin" % n_data,
-            "roofline": roofline_from_stats(bstats, S, N, bE, bM, bC, bev),
+            "roofline": roofline_from_stats(bstats, S, N, bE, bM, bC, bev, args.workload),
+            "roofline_8d": roofline_8d(bstats, S, N, bE, bM, bC, bev),
+            "modes": bmodes,
         }
 
     rep.close()
     if rank == 0:
         print(json.dumps(out))
+        if not out["parity"]["pass"] or (host_fed and not (host_fed["poses_bit_equal_to_resident_replay"] and two_thread["poses_bit_equal_to_resident_replay"])):
+            sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -188,6 +188,19 @@ int liodom_process_resident_pipelined(liodom_handle_t* h, int slot, int next_slo
  * are only waited for). */
 int liodom_replay_resident(liodom_handle_t* h, int first_slot, int count, int ahead, int depth, int64_t n, int height, int width,
                            double* poses_out, liodom_step_info_t* infos_out);
+
+/* Host-fed replay: the shape the patched liodom_node sees (scans arrive in HOST memory, one per PointCloud2 message,
+ * src/liodom_node.cc:40-55 -> shared_data.cc:37-42).  Scan i of stream s is read from
+ * xyzi_base + ((size_t)i * n_streams + s) * scan_stride_floats (n points of packed float4).  The upload of scan k+1
+ * (hipMemcpyAsync on the extraction stream into a ring of device staging slots) and its extraction overlap the
+ * odometry of scan k; every pose is read back, in order (depth as in liodom_replay_resident).  For the copies to be
+ * asynchronous the host buffer must be page-locked: liodom_pin_host_buffer / liodom_unpin_host_buffer register a
+ * caller-owned buffer (pageable memory works, the copies then stage through the runtime).  The handle's resident
+ * scan buffer is (re)allocated as the staging ring (liodom_alloc_resident(h, 3)) if it has fewer than 3 slots. */
+int liodom_replay_host(liodom_handle_t* h, const float* xyzi_base, int64_t scan_stride_floats, int count, int depth,
+                       int64_t n, int height, int width, double* poses_out, liodom_step_info_t* infos_out);
+int liodom_pin_host_buffer(void* p, int64_t bytes);
+int liodom_unpin_host_buffer(void* p);
 int liodom_sync(liodom_handle_t* h);
 int liodom_get_pose_log(liodom_handle_t* h, int stream, int first, int count, double* poses_out,
                         liodom_step_info_t* infos_out);
@@ -239,6 +252,10 @@ int liodom_device_count(int* count);
 int liodom_device_pci_bus_id(int device, char* bus_id, int cap);
 /* Device name and compute-unit count of the handle's GPU. */
 int liodom_device_info(liodom_handle_t* h, char* name, int name_cap, int* compute_units);
+/* The code paths this handle runs, as "key=value key=value ..." (stream-dependency mechanism, hash rebuild variant,
+ * workgroups per solve, kNN tuning, test switches picked up from the environment at liodom_create).  Every variant
+ * produces the same results (each has an equality test); measurements quote this string next to their numbers. */
+int liodom_get_modes(liodom_handle_t* h, char* buf, int cap);
 
 
 /* ---- liodom::Map on the device (mapping node, src/map.cc, src/liodom_mapping_node.cc) ---- */

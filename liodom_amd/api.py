@@ -238,7 +238,7 @@ EXPORTED_SYMBOLS = [
     "liodom_alloc_resident", "liodom_upload_scan", "liodom_process_resident", "liodom_process_resident_pipelined", "liodom_replay_resident", "liodom_sync", "liodom_get_pose_log",
     "liodom_reset", "liodom_get_edges", "liodom_get_window", "liodom_get_local_map", "liodom_get_correspondences", "liodom_get_curvature", "liodom_get_knn_queries",
     "liodom_set_profiling", "liodom_get_kernel_stats", "liodom_reset_kernel_stats", "liodom_device_info",
-    "liodom_device_count", "liodom_device_pci_bus_id",
+    "liodom_device_count", "liodom_device_pci_bus_id", "liodom_get_modes", "liodom_replay_host", "liodom_pin_host_buffer", "liodom_unpin_host_buffer",
     "liodom_map_config_default", "liodom_map_create", "liodom_map_destroy", "liodom_map_update", "liodom_map_get_local",
     "liodom_map_get_all", "liodom_map_num_cells", "liodom_map_status", "liodom_get_received_map", "liodom_attach_mapper",
     "liodom_set_imu_orientation", "liodom_set_laser_to_base",
@@ -385,6 +385,33 @@ class Liodom:
         infos = (StepInfo * (count * S))()
         self._check(self.L.liodom_replay_resident(self.h, first_slot, count, 1 if ahead else 0, int(depth), n, height, width, _dp(poses), infos))
         return poses, infos
+
+    def replay_host(self, scans, n, height, width, depth=1, pin=True):
+        """Host-fed replay (liodom_replay_host): scans = float32 array [count, n_streams, max_points, 4] in host memory
+        (page-locked for the duration of the call if pin).  Returns poses [count, n_streams, 7] and the step infos."""
+        S = self.config.n_streams
+        a = np.ascontiguousarray(scans, dtype=np.float32)
+        count = a.shape[0]
+        stride = int(a.size // max(1, count * S))
+        poses = np.zeros((count, S, 7))
+        infos = (StepInfo * (count * S))()
+        self.L.liodom_replay_host.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(StepInfo)]
+        self.L.liodom_pin_host_buffer.argtypes = [C.c_void_p, C.c_int64]
+        self.L.liodom_unpin_host_buffer.argtypes = [C.c_void_p]
+        pinned = pin and self.L.liodom_pin_host_buffer(a.ctypes.data_as(C.c_void_p), a.nbytes) == 0
+        try:
+            self._check(self.L.liodom_replay_host(self.h, _fp(a), stride, count, int(depth), n, height, width, _dp(poses), infos))
+        finally:
+            if pinned:
+                self.L.liodom_unpin_host_buffer(a.ctypes.data_as(C.c_void_p))
+        return poses, infos
+
+    def modes(self):
+        """The code paths this handle runs ("key=value ..." from liodom_get_modes) as a dict of strings."""
+        buf = C.create_string_buffer(1024)
+        self.L.liodom_get_modes.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        self._check(self.L.liodom_get_modes(self.h, buf, 1024))
+        return dict(kv.split("=", 1) for kv in buf.value.decode().split())
 
     def sync(self):
         self._check(self.L.liodom_sync(self.h))

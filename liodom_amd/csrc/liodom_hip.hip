@@ -61,6 +61,10 @@ struct liodom_handle {
   std::mutex mx_x, mx_o;
   hipStream_t stream = nullptr;      // odometry side
   hipStream_t stream_x = nullptr;    // extraction side (liodom_extract_edges, and the next scan's extraction in the pipelined replay)
+  hipStream_t stream_c = nullptr;    // host-fed replay: uploads (a copy engine works beside the extraction kernels of the previous scan)
+  hipEvent_t ev_up[3] = {nullptr, nullptr, nullptr};      // staging slot uploaded
+  hipEvent_t ev_xdone[3] = {nullptr, nullptr, nullptr};   // extraction that read the staging slot has been issued (recorded on the extraction stream)
+  bool ev_xdone_valid[3] = {false, false, false};
   hipEvent_t ev_edges[kEdgePipeBufs] = {nullptr, nullptr, nullptr};   // edge buffer b written
   hipEvent_t ev_free[kEdgePipeBufs] = {nullptr, nullptr, nullptr};    // odometry finished reading edge buffer b
   bool ev_free_valid[kEdgePipeBufs] = {false, false, false};
@@ -710,6 +714,8 @@ void liodom_destroy(liodom_handle_t* h) {
   for (auto& e : h->ev_pool) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
   if (h->pose_event) hipEventDestroy(h->pose_event);
   for (int b = 0; b < kEdgePipeBufs; b++) { if (h->ev_edges[b]) hipEventDestroy(h->ev_edges[b]); if (h->ev_free[b]) hipEventDestroy(h->ev_free[b]); }
+  if (h->stream_c) { hipStreamSynchronize(h->stream_c); hipStreamDestroy(h->stream_c); }
+  for (int b = 0; b < 3; b++) { if (h->ev_up[b]) hipEventDestroy(h->ev_up[b]); if (h->ev_xdone[b]) hipEventDestroy(h->ev_xdone[b]); }
   if (h->stream_x) hipStreamDestroy(h->stream_x);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
@@ -970,7 +976,7 @@ int liodom_process_resident(liodom_handle_t* h, int slot, int64_t n, int height,
 
 // One scan of the pipelined replay (both sides locked by the caller).  wait: read the poses back before returning.
 static int replay_one(liodom_handle_t* h, int slot, int next_slot, int64_t n, int height, int width, bool wait,
-                      double* poses_out, liodom_step_info_t* infos_out);
+                      double* poses_out, liodom_step_info_t* infos_out, const float* next_host = nullptr, int64_t host_stride = 0);
 
 int liodom_process_resident_pipelined(liodom_handle_t* h, int slot, int next_slot, int64_t n, int height,
                                       int width, double* poses_out, liodom_step_info_t* infos_out) {
@@ -1005,8 +1011,38 @@ int liodom_replay_resident(liodom_handle_t* h, int first_slot, int count, int ah
   return LIODOM_OK;
 }
 
+// Host-fed replay: the scan of every stream for resident slot `slot` is copied from host memory on the extraction stream
+// (ordered behind the extraction that last read the slot).
+static int upload_slot_async(liodom_handle_t* h, int slot, const float* host, int64_t stride, int64_t n) {
+  // copies on their own stream (copy engine) so that they run beside the extraction kernels of the previous scan; the
+  // slot is free once the extraction that last read it has completed, and its extraction waits for the upload
+  const int r = slot % 3;
+  if (!h->stream_c) {
+    HIP_TRY(hipStreamCreateWithFlags(&h->stream_c, hipStreamNonBlocking));
+    for (int b = 0; b < 3; b++) {
+      HIP_TRY(hipEventCreateWithFlags(&h->ev_up[b], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&h->ev_xdone[b], hipEventDisableTiming));
+    }
+  }
+  hipStream_t q = extract_queue(h);
+  if (h->ev_xdone_valid[r]) HIP_TRY(hipStreamWaitEvent(h->stream_c, h->ev_xdone[r], 0));
+  for (int s = 0; s < h->S && n > 0; s++) {
+    float4* dst = h->resident + ((size_t)slot * h->S + s) * (size_t)h->v.max_points;
+    HIP_TRY(hipMemcpyAsync(dst, host + (size_t)s * (size_t)stride, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, h->stream_c));
+  }
+  HIP_TRY(hipEventRecord(h->ev_up[r], h->stream_c));
+  HIP_TRY(hipStreamWaitEvent(q, h->ev_up[r], 0));
+  return LIODOM_OK;
+}
+static int upload_slot_consumed(liodom_handle_t* h, int slot) {      // call right after the slot's extraction has been issued
+  const int r = slot % 3;
+  HIP_TRY(hipEventRecord(h->ev_xdone[r], extract_queue(h)));
+  h->ev_xdone_valid[r] = true;
+  return LIODOM_OK;
+}
+
 static int replay_one(liodom_handle_t* h, int slot, int next_slot, int64_t n, int height, int width, bool wait,
-                      double* poses_out, liodom_step_info_t* infos_out) {
+                      double* poses_out, liodom_step_info_t* infos_out, const float* next_host, int64_t host_stride) {
   if (!h->resident || slot < 0 || slot >= h->n_slots || next_slot >= h->n_slots || n < 0 || n > h->v.max_points) {
     g_last_error = "bad resident slot"; return LIODOM_ERR_INVALID_ARG;
   }
@@ -1038,12 +1074,67 @@ static int replay_one(liodom_handle_t* h, int slot, int next_slot, int64_t n, in
     h->ev_free_valid[eb] = true;
   }
   h->parity = (eb + 1) % kEdgePipeBufs;
-  if (next_slot >= 0) {                           // overlap the next scan's extraction with this odometry
+  if (next_slot >= 0) {                           // overlap the next scan's (upload and) extraction with this odometry
+    if (next_host) { rc = upload_slot_async(h, next_slot, next_host, host_stride, n); if (rc) return rc; }
     rc = issue_extract(h, next_slot, h->parity, (int)n, height, width);
     if (rc) return rc;
+    if (next_host) { rc = upload_slot_consumed(h, next_slot); if (rc) return rc; }
     h->pf_slot = next_slot;
   }
   if (wait) return wait_pose(h, 0, h->S, poses_out, infos_out);
+  return LIODOM_OK;
+}
+
+int liodom_replay_host(liodom_handle_t* h, const float* xyzi_base, int64_t scan_stride_floats, int count, int depth,
+                       int64_t n, int height, int width, double* poses_out, liodom_step_info_t* infos_out) {
+  int rc0 = enter(h);
+  if (rc0) return rc0;
+  if (count < 0 || depth < 0 || depth > 1 || n < 0 || n > h->v.max_points || (count > 0 && n > 0 && !xyzi_base) || scan_stride_floats < 4 * n) {
+    g_last_error = "liodom_replay_host: bad arguments"; return LIODOM_ERR_INVALID_ARG;
+  }
+  constexpr int kRing = 3;
+  if (h->n_slots < kRing) { const int rc = liodom_alloc_resident(h, kRing); if (rc) return rc; }
+  SideLocks lk(h, true, true);
+  int rc = drain_pipeline(h);
+  if (rc) return rc;
+  auto out_p = [&](int i) { return poses_out ? poses_out + (size_t)i * h->S * 7 : nullptr; };
+  auto out_i = [&](int i) { return infos_out ? infos_out + (size_t)i * h->S : nullptr; };
+  auto src = [&](int i) { return xyzi_base + (size_t)i * (size_t)h->S * (size_t)scan_stride_floats; };
+  for (int i = 0; i < count; i++) {
+    const int slot = i % kRing, next = (i + 1 < count) ? (i + 1) % kRing : -1;
+    if (i == 0) {                                 // first scan: upload + extraction now
+      rc = upload_slot_async(h, slot, src(0), scan_stride_floats, n);
+      if (rc) return rc;
+      rc = issue_extract(h, slot, h->parity, (int)n, height, width);
+      if (rc) return rc;
+      h->pf_slot = slot;
+      rc = upload_slot_consumed(h, slot);
+      if (rc) return rc;
+    }
+    const float* nh = next >= 0 ? src(i + 1) : nullptr;
+    if (depth == 0) {
+      rc = replay_one(h, slot, next, n, height, width, true, out_p(i), out_i(i), nh, scan_stride_floats);
+      if (rc) return rc;
+      continue;
+    }
+    rc = replay_one(h, slot, next, n, height, width, false, nullptr, nullptr, nh, scan_stride_floats);
+    if (rc) return rc;
+    if (i > 0) { rc = wait_pose(h, 0, h->S, out_p(i - 1), out_i(i - 1), 1); if (rc) return rc; }
+  }
+  if (depth == 1 && count > 0) { rc = wait_pose(h, 0, h->S, out_p(count - 1), out_i(count - 1), 0); if (rc) return rc; }
+  if (h->stream_c) HIP_TRY(hipStreamSynchronize(h->stream_c));
+  for (int b = 0; b < 3; b++) h->ev_xdone_valid[b] = false;
+  return drain_pipeline(h);                       // the caller's buffer may be reused / unpinned after the return
+}
+
+int liodom_pin_host_buffer(void* p, int64_t bytes) {
+  if (!p || bytes <= 0) return LIODOM_ERR_INVALID_ARG;
+  HIP_TRY(hipHostRegister(p, (size_t)bytes, hipHostRegisterDefault));
+  return LIODOM_OK;
+}
+int liodom_unpin_host_buffer(void* p) {
+  if (!p) return LIODOM_ERR_INVALID_ARG;
+  HIP_TRY(hipHostUnregister(p));
   return LIODOM_OK;
 }
 
@@ -1243,6 +1334,20 @@ int liodom_debug_knn_times(liodom_handle_t* h, unsigned int* out, int* cap) {
   HIP_TRY(hipStreamSynchronize(h->stream_x));
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(hipMemcpy(out, h->v.dbg_q, sizeof(unsigned int) * 2 * (size_t)h->v.edge_cap * 12, hipMemcpyDeviceToHost));
+  return LIODOM_OK;
+}
+
+int liodom_get_modes(liodom_handle_t* h, char* buf, int cap) {
+  if (!h || !buf || cap < 2) return LIODOM_ERR_INVALID_ARG;
+  const DevView& v = h->v;
+  snprintf(buf, (size_t)cap,
+           "n_streams=%d early_rebuild=%d hash_build=%s pipe_flags=%d flag_gate=%d graph=%d lm_groups=%d knn_instance=%d knn_queries=%d "
+           "knn_grid=%d/%d knn_partials=%d knn_saved_bound=%d knn_exact_only=%d line_gate_kernel=%d filter_local_map=%d mapping=%d "
+           "rotation_mode=%d table_size=%d rebuild_delta=%.3f debug=%d",
+           h->S, v.early_rebuild, v.early_rebuild ? "streamed" : (h->lds_hash_build ? "lds" : "global"), h->use_flags ? 1 : 0,
+           (h->use_flags && h->flag_gate) ? 1 : 0, h->use_graph ? 1 : 0, v.lm_groups, h->S >= 16 ? 128 : 256, v.knn_queries, v.knn_grid,
+           v.knn_blocks, v.knn_partials, v.knn_save_q ? 1 : 0, v.knn_exact_only, v.knn_nn ? 1 : 0, v.filter_local_map, v.mapping,
+           v.rotation_mode, v.table_size, (double)v.rebuild_delta, v.debug);
   return LIODOM_OK;
 }
 

@@ -1018,20 +1018,30 @@ struct Best2Acc {
 // lane).  UB / U independent 16-B loads in flight per lane; loads are unconditional (index clamped into the segment,
 // the result masked), so that they leave together and the loop body is straight-line code.
 // Two tunings of the same code (template parameter kDeep of k_knn / knn_block):
-//   lock-step batches (k_knn<128>, VALU-issue bound, 7 waves per SIMD hide the latency): 4 loads in flight per lane, cells
-//     of >= 128 points cell-major, phase 1 of the first pass = own cell + neighbours within 6 cm;
+//   lock-step batches (k_knn<128>, VALU-issue bound, 7 waves per SIMD hide the latency): 2 loads in flight per lane, cells
+//     of >= 64 points cell-major, phase 1 of the first pass = own cell + neighbours within 6 cm (measured at 256 streams,
+//     us per pass: loads 4/4 + cells >= 128: 576; 2/2 + >= 64: 511; 1/1 + >= 32: 534; per-lane cursor instead of the binary
+//     search: +6 %; phase-1 radius 0 / 6 / 14 cm: 509 / 511 / 510);
 //   few streams (k_knn<256>, one wave per SIMD, bound by the dependent memory round trips of its slowest query): 16 / 8
 //     loads in flight per lane (a query with 1 000 candidates: 4 round trips instead of 9), cells of >= 256 points
 //     cell-major, phase 1 = own cell + neighbours within 20 cm (fewer queries need the second phase's round trip).
+#ifndef LIODOM_TUNE_B_BIG            // (lock-step instance; overridable for experiments: tools/variant_build.sh)
+#define LIODOM_TUNE_B_BIG 64
+#define LIODOM_TUNE_B_LOADS_BIG 2
+#define LIODOM_TUNE_B_LOADS_FLAT 2
+#define LIODOM_TUNE_B_CURSOR false
+#define LIODOM_TUNE_B_NEAR 0.0036f
+#endif
 template <bool kDeep> struct KnnTune {
-  static constexpr int kBigCell = kDeep ? 256 : 128;
-  static constexpr int kLoadsBig = kDeep ? 8 : 4;
-  static constexpr int kLoadsFlat = kDeep ? 8 : 4;
-  static constexpr float kNearSq = kDeep ? 0.04f : 0.0036f;
+  static constexpr int kBigCell = kDeep ? 256 : LIODOM_TUNE_B_BIG;
+  static constexpr int kLoadsBig = kDeep ? 8 : LIODOM_TUNE_B_LOADS_BIG;
+  static constexpr int kLoadsFlat = kDeep ? 8 : LIODOM_TUNE_B_LOADS_FLAT;
+  static constexpr float kNearSq = kDeep ? 0.04f : LIODOM_TUNE_B_NEAR;
   static constexpr bool kProbeBoth = kDeep;
+  static constexpr bool kCursor = kDeep ? false : LIODOM_TUNE_B_CURSOR;      // flat list: per-lane cursor instead of the binary search
 };
 constexpr int kKnnGridDiv = 2;         // k_knn grid = half of the query blocks the edge capacity allows: a workgroup takes block b and, if the scan has that many edges, b + grid
-template <class Acc, int UB, int U, int kBigCell>
+template <class Acc, int UB, int U, int kBigCell, bool kCursor = false>
 __device__ __forceinline__ void knn_stream_cells(Acc& t, const float4* sp, int* s_incl, int* s_adj,
                                                  unsigned int start, unsigned int cnt, int hl,
                                                  float qx, float qy, float qz, unsigned int* dbg = nullptr) {
@@ -1067,6 +1077,7 @@ __device__ __forceinline__ void knn_stream_cells(Acc& t, const float4* sp, int* 
   __builtin_amdgcn_wave_barrier();
   const int T = s_incl[kKnnGroup - 1];
   const unsigned long long dbg_t1 = dbg ? wall_clock64() : 0ull;
+  int cur = 0;
   for (int i = hl; i < T; i += U * kKnnGroup) {
     dbg_flatit++;
     // owner segment of flat index iu = number of segments whose inclusive prefix is <= iu: a 5-step binary search over
@@ -1076,13 +1087,22 @@ __device__ __forceinline__ void knn_stream_cells(Acc& t, const float4* sp, int* 
     int c[U];
 #pragma unroll
     for (int u = 0; u < U; u++) { const int iu = i + u * kKnnGroup; a[u] = iu < T ? iu : T - 1; c[u] = 0; }
+    if (kCursor) {
+      // (lock-step batches: fewer instructions) monotone per-lane cursor: the flat index only grows
 #pragma unroll
-    for (int step = kKnnGroup / 2; step >= 1; step >>= 1) {
-      int pv[U];
+      for (int u = 0; u < U; u++) {
+        while (s_incl[cur] <= a[u]) cur++;
+        c[u] = cur;
+      }
+    } else {
 #pragma unroll
-      for (int u = 0; u < U; u++) pv[u] = s_incl[c[u] + step - 1];
+      for (int step = kKnnGroup / 2; step >= 1; step >>= 1) {
+        int pv[U];
 #pragma unroll
-      for (int u = 0; u < U; u++) c[u] += pv[u] <= a[u] ? step : 0;
+        for (int u = 0; u < U; u++) pv[u] = s_incl[c[u] + step - 1];
+#pragma unroll
+        for (int u = 0; u < U; u++) c[u] += pv[u] <= a[u] ? step : 0;
+      }
     }
     int adj[U];
 #pragma unroll
@@ -1301,7 +1321,7 @@ __device__ __forceinline__ void knn_block(const DevView& v, int s, StreamState& 
     {
       const bool now = pend && (have_b ? !(lb > B) : (hl == 13 || hl == 27 || lb <= Tune::kNearSq));
       if (v.debug & 32) dbg_n = __shfl(half_incl_scan_i32(now ? (int)cnt : 0), kKnnGroup - 1, kKnnGroup);
-      knn_stream_cells<Best2Acc, Tune::kLoadsBig, Tune::kLoadsFlat, Tune::kBigCell>(b2, sp, sh.incl[grp], sh.adj[grp], start, now ? cnt : 0u, hl, qx, qy, qz,
+      knn_stream_cells<Best2Acc, Tune::kLoadsBig, Tune::kLoadsFlat, Tune::kBigCell, Tune::kCursor>(b2, sp, sh.incl[grp], sh.adj[grp], start, now ? cnt : 0u, hl, qx, qy, qz,
                                                                                      ((v.debug & 32) && s == 0 && e < E) ? v.dbg_q + ((size_t)outer_it * v.edge_cap + e) * 12 + 8 : nullptr);
       pend = pend && !now;
     }
@@ -1311,7 +1331,7 @@ __device__ __forceinline__ void knn_block(const DevView& v, int s, StreamState& 
       pend = pend && !(lb > B);
       if ((__ballot(pend) >> half_shift) & 0xFFFFFFFFull) {
         if (v.debug & 32) { dbg_n += __shfl(half_incl_scan_i32(pend ? (int)cnt : 0), kKnnGroup - 1, kKnnGroup); dbg_two_phase = true; }
-        knn_stream_cells<Best2Acc, Tune::kLoadsBig, Tune::kLoadsFlat, Tune::kBigCell>(b2, sp, sh.incl[grp], sh.adj[grp], start, pend ? cnt : 0u, hl, qx, qy, qz);
+        knn_stream_cells<Best2Acc, Tune::kLoadsBig, Tune::kLoadsFlat, Tune::kBigCell, Tune::kCursor>(b2, sp, sh.incl[grp], sh.adj[grp], start, pend ? cnt : 0u, hl, qx, qy, qz);
       }
     } else {
       pend = false;

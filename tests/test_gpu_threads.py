@@ -136,3 +136,89 @@ def test_threaded_replay_harness_equals_fused_replay(synth, tmp_path):
     a, b = outs["fused"], outs["threads"]
     assert np.array_equal(a[:, :8], b[:, :8])                 # stamp, orientation, position: identical digits
     assert np.allclose(a[1:, 8:], b[1:, 8:], rtol=0, atol=1e-9)   # twist (first row is 0/0 = NaN in both, :125,136)
+
+
+def _replay(g, K, N, H, W):
+    poses, infos = g.replay_resident(0, K, N, H, W, depth=1)
+    status = 0
+    for i in infos:
+        status |= int(i.status)
+    return poses, status
+
+
+@pytest.mark.parametrize("shape", ["two_single_stream_handles", "two_stream_handle_and_single"])
+def test_two_handles_on_one_gpu_in_pipelined_replay(synth, shape):
+    """The in-kernel cross-stream waits (pipe_wait, the streamed rebuild's pose hand-off, the multi-workgroup solve's
+    exchanges) assume that the kernels they wait for can run beside them.  Two handles on ONE GPU, each in pipelined
+    replay from its own host thread (two sensors, or two replicas sharing a device), must not disturb each other:
+    200 scans, poses bit-equal to the solo runs, no status bit (a wait that gave up would raise
+    LIODOM_STATUS_PIPE_TIMEOUT / LM_SYNC_TIMEOUT and fail the replay)."""
+    import liodom_amd as la
+    H, W, R, epr, P, K = 16, 1800, 8, 20, 10, 200
+    N = H * W
+    cfg = synth.make_cfg(H, W, 0)
+    streams = {sid: [synth.scan(cfg, sid, k)[0] for k in range(K)] for sid in (11, 12, 13)}
+    par = la.make_params(scan_lines=H, scan_regions=R, edges_per_region=epr, prev_frames=P)
+
+    def make(sids):
+        g = la.Liodom(par, la.make_config(n_streams=len(sids), max_points=N, max_width=W, pose_log_capacity=K + 8))
+        g.alloc_resident(K)
+        for s, sid in enumerate(sids):
+            for k in range(K):
+                g.upload_scan(s, k, streams[sid][k])
+        g.sync()
+        return g
+
+    layout = [(11,), (12,)] if shape == "two_single_stream_handles" else [(11, 12), (13,)]
+    solo = []
+    for sids in layout:
+        g = make(sids)
+        poses, status = _replay(g, K, N, H, W)
+        assert status == 0
+        solo.append(poses.copy())
+        g.close()
+
+    handles = [make(sids) for sids in layout]
+    out, errors = [None] * len(handles), []
+    start = threading.Barrier(len(handles))
+
+    def run(i):
+        try:
+            start.wait()
+            out[i] = _replay(handles[i], K, N, H, W)
+        except Exception as ex:          # noqa: BLE001
+            errors.append((i, ex))
+
+    threads = [threading.Thread(target=run, args=(i,)) for i in range(len(handles))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for i, g in enumerate(handles):
+        poses, status = out[i]
+        assert status == 0, "handle %d: status bits 0x%x" % (i, status)
+        assert np.array_equal(poses.view(np.uint64), solo[i].view(np.uint64)), "handle %d: poses differ from its solo run" % i
+        g.close()
+
+
+def test_host_fed_replay_equals_resident_replay(synth):
+    """liodom_replay_host (scans in page-locked host memory, upload + extraction of scan k+1 beside the odometry of scan k)
+    must give the bits of the resident replay."""
+    import liodom_amd as la
+    H, W, R, epr, P, K = 16, 900, 6, 10, 5, 40
+    N = H * W
+    cfg = synth.make_cfg(H, W, 0)
+    scans = np.stack([synth.scan(cfg, 3, k)[0] for k in range(K)])
+    par = la.make_params(scan_lines=H, scan_regions=R, edges_per_region=epr, prev_frames=P)
+    g = la.Liodom(par, la.make_config(max_points=N, max_width=W, pose_log_capacity=2 * K + 8))
+    g.alloc_resident(K)
+    for k in range(K):
+        g.upload_scan(0, k, scans[k])
+    ref, _ = g.replay_resident(0, K, N, H, W, depth=1)
+    for depth in (1, 0):
+        g.reset()
+        got, infos = g.replay_host(scans.reshape(K, 1, N, 4), N, H, W, depth=depth)
+        assert np.array_equal(got.view(np.uint64), ref.view(np.uint64)), depth
+        assert all(int(i.status) == 0 for i in infos)
+    g.close()

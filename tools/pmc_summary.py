@@ -1,9 +1,13 @@
-"""Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs (separate passes) per kernel and grid size.
-FETCH_SIZE / WRITE_SIZE are reported in KiB; per /opt/skills/guides/MI355X_MICROARCH.md (HBM section)
-FETCH_SIZE on gfx950 counts 128-B requests at 64 B, i.e. reads exactly half of a wide coalesced
-stream — `fetch_corrected` doubles it (calibration in this very trace: k_classify reads 16 B/point =
-1843 KB and reports 925 KB).  WRITE_SIZE is uncalibrated (k_classify writes 1 B/point = 113 KB and
-reports 112.75 KB, so it is taken as is)."""
+"""Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs (separate passes) into the per-workload traffic profile bench.py reads.
+
+usage: pmc_summary.py <workload> <out.json> <single_fetch_dir> <single_write_dir> [<batched_streams> <batched_fetch_dir> <batched_write_dir>]
+
+FETCH_SIZE / WRITE_SIZE are reported in KiB; per /opt/skills/guides/MI355X_MICROARCH.md (HBM section) FETCH_SIZE on
+gfx950 counts 128-B requests at 64 B, i.e. reads exactly half of a wide coalesced stream — `fetch_corrected` doubles it
+(calibration in these traces: k_classify reads 16 B/point = 1843 KB and reports ~925 KB).  WRITE_SIZE is uncalibrated
+(k_classify writes 1 B/point = 113 KB and reports ~113 KB, so it is taken as is).  A kernel launched with several grid
+sizes in one run (k_knn / k_lm_solve: first and second pass of a scan) is averaged over all its launches; the single-stream
+run and the lock-step run are kept apart, so a row is always selected by launch shape."""
 import glob
 import json
 import sqlite3
@@ -11,23 +15,42 @@ import sys
 
 
 def load(dirname, counter):
-    f = glob.glob(dirname + "/*.db")[0]
+    f = glob.glob(dirname + "/**/*.db", recursive=True)[0]
     db = sqlite3.connect(f)
     rows = db.execute("select kernel_name, grid_size, count(*), avg(value) from counters_collection "
                       "where counter_name=? group by kernel_name, grid_size", (counter,)).fetchall()
-    return {(k.split("(")[0].split("<")[0].replace("void ", "").replace("liodom_dev::", ""), g): (n, v) for k, g, n, v in rows if "liodom_dev" in k}
+    out = {}
+    for k, g, n, v in rows:
+        if "liodom_dev" not in k:
+            continue
+        name = k.split("(")[0].split("<")[0].replace("void ", "").replace("liodom_dev::", "")
+        out.setdefault(name, []).append((g, n, v))
+    return out
+
+
+def merge(fetch_dir, write_dir, title):
+    fetch, write = load(fetch_dir, "FETCH_SIZE"), load(write_dir, "WRITE_SIZE")
+    res = {}
+    print("# " + title)
+    print("%-18s %-26s %8s %14s %18s %14s %16s" % ("kernel", "grids (launches)", "launches", "FETCH_SIZE KiB", "fetch_corrected KiB", "WRITE_SIZE KiB", "HBM B / launch"))
+    for name in sorted(fetch):
+        nf = sum(n for _, n, _ in fetch[name])
+        fv = sum(n * v for _, n, v in fetch[name]) / max(nf, 1)
+        w = write.get(name, [])
+        nw = sum(n for _, n, _ in w)
+        wv = sum(n * v for _, n, v in w) / max(nw, 1)
+        grids = " ".join("%d(%d)" % (g, n) for g, n, _ in sorted(fetch[name]))
+        hbm = int((2 * fv + wv) * 1024)
+        print("%-18s %-26s %8d %14.1f %18.1f %14.1f %16d" % (name, grids[:26], nf, fv, 2 * fv, wv, hbm))
+        res[name] = {"launches": nf, "grids": sorted(g for g, _, _ in fetch[name]), "fetch_kib_raw": fv, "fetch_kib_corrected": 2 * fv,
+                     "write_kib": wv, "hbm_bytes_per_launch": hbm}
+    return res
 
 
 if __name__ == "__main__":
-    fetch = load(sys.argv[1], "FETCH_SIZE")
-    write = load(sys.argv[2], "WRITE_SIZE")
-    out = {}
-    print("%-18s %10s %8s %14s %18s %14s" % ("kernel", "grid", "launches", "FETCH_SIZE KiB", "fetch_corrected KiB", "WRITE_SIZE KiB"))
-    for key in sorted(fetch):
-        n, fv = fetch[key]
-        wv = write.get(key, (0, 0.0))[1]
-        print("%-18s %10d %8d %14.1f %18.1f %14.1f" % (key[0], key[1], n, fv, 2 * fv, wv))
-        out.setdefault(key[0], []).append({"grid": key[1], "launches": n, "fetch_kib_raw": fv, "fetch_kib_corrected": 2 * fv,
-                                           "write_kib": wv, "hbm_bytes_per_launch": int((2 * fv + wv) * 1024)})
-    if len(sys.argv) > 3:
-        json.dump(out, open(sys.argv[3], "w"), indent=1)
+    workload, out = sys.argv[1], sys.argv[2]
+    prof = {"workload": workload, "single": merge(sys.argv[3], sys.argv[4], "%s, one stream (per-launch averages)" % workload)}
+    if len(sys.argv) > 7:
+        S = int(sys.argv[5])
+        prof["batched"] = {"streams": S, "kernels": merge(sys.argv[6], sys.argv[7], "%s, %d lock-step streams (per-launch averages, whole launch)" % (workload, S))}
+    json.dump(prof, open(out, "w"), indent=1)
