@@ -164,13 +164,19 @@ int launch_extract(liodom_handle* h, hipStream_t q, int eb, int s0, int count, c
                    int n, int height, int width, unsigned int wait_odo = 0) {
   const DevView& v = h->v;
   const int tiles = std::max(1, cdiv(n, kTilePts));
-  {
-    ProfScope ps(h, KID_CLASSIFY, q);
-    hipLaunchKernelGGL(k_classify, dim3(tiles, count), dim3(kTileThreads), 0, q, v, s0, in, in_stride, n, height, width);
-  }
-  {
+  if (v.lidar_type == 1 && width > 0 && (long long)h->H * width <= (long long)v.max_points) {
+    // organised cloud: ring = row, the split is a per-row compaction (no classify / scatter passes)
     ProfScope ps(h, KID_RING_SCATTER, q);
-    hipLaunchKernelGGL(k_ring_scatter, dim3(tiles, count), dim3(kTileThreads), ring_scatter_lds_bytes(h->H), q, v, s0, in, in_stride, n);
+    hipLaunchKernelGGL(k_row_compact, dim3(h->H, count), dim3(kRowThreads), 0, q, v, s0, in, in_stride, n, height, width);
+  } else {
+    {
+      ProfScope ps(h, KID_CLASSIFY, q);
+      hipLaunchKernelGGL(k_classify, dim3(tiles, count), dim3(kTileThreads), 0, q, v, s0, in, in_stride, n, height, width);
+    }
+    {
+      ProfScope ps(h, KID_RING_SCATTER, q);
+      hipLaunchKernelGGL(k_ring_scatter, dim3(tiles, count), dim3(kTileThreads), ring_scatter_lds_bytes(h->H), q, v, s0, in, in_stride, n);
+    }
   }
   {
     ProfScope ps(h, KID_RING_EXTRACT, q);
@@ -592,6 +598,7 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   ALLOC(v.ring_pts, S * (size_t)config->max_points + kExLPR * kExIPLBig + 64, 0);
   ALLOC(v.ring_src, S * (size_t)config->max_points, 0);
   ALLOC(v.ring_start, S * (size_t)(h->H + 1), 0);
+  ALLOC(v.ring_len, S * (size_t)h->H, 0);
   ALLOC(v.edges_pad, S * h->H * v.slots_per_ring, 0);
   ALLOC(v.edges_pad_meta, S * h->H * v.slots_per_ring, 0);
   ALLOC(v.ring_nedges, S * h->H, 0);
@@ -1269,14 +1276,19 @@ int liodom_get_curvature(liodom_handle_t* h, int stream, double* curv, int64_t c
   SideLocks lk(h, true, true);
   HIP_TRY(hipStreamSynchronize(h->stream_x));
   HIP_TRY(hipStreamSynchronize(h->stream));
-  std::vector<int> rs((size_t)h->H + 1);
+  std::vector<int> rs((size_t)h->H + 1), rl((size_t)h->H);
   HIP_TRY(hipMemcpy(rs.data(), h->v.ring_start + (size_t)stream * (h->H + 1), sizeof(int) * (h->H + 1), hipMemcpyDeviceToHost));
-  const int64_t off = rs[h->H];
-  for (int r = 0; r < h->H && ring_offsets; r++) ring_offsets[r] = rs[r];
-  if (off > cap) { g_last_error = "curvature buffer too small"; return LIODOM_ERR_CAPACITY; }
-  if (off && curv)      // ring-major over the compacted rings = the layout of the ring-sorted copy
-    HIP_TRY(hipMemcpy(curv, h->v.ring_c + (size_t)stream * h->v.max_points, sizeof(double) * (size_t)off, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(rl.data(), h->v.ring_len + (size_t)stream * h->H, sizeof(int) * h->H, hipMemcpyDeviceToHost));
+  // output: the compacted rings back to back (on the device the rings of an organised cloud sit at ring * width)
+  int64_t off = 0;
+  for (int r = 0; r < h->H; r++) { if (ring_offsets) ring_offsets[r] = (int32_t)off; off += rl[r]; }
   if (ring_offsets) ring_offsets[h->H] = (int32_t)off;
+  if (off > cap) { g_last_error = "curvature buffer too small"; return LIODOM_ERR_CAPACITY; }
+  int64_t o = 0;
+  for (int r = 0; r < h->H && curv; r++) {
+    if (rl[r]) HIP_TRY(hipMemcpy(curv + o, h->v.ring_c + (size_t)stream * h->v.max_points + rs[r], sizeof(double) * (size_t)rl[r], hipMemcpyDeviceToHost));
+    o += rl[r];
+  }
   return LIODOM_OK;
 }
 

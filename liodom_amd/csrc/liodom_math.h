@@ -56,8 +56,7 @@ LD_HD bool valid_point(double x, double y, double z, double min_range, double ma
 }
 
 // Velodyne elevation binning (:127-151).  Returns -1 when the point is dropped.
-LD_HD int velodyne_ring(double z, double dist, int scan_lines) {
-  const double angle = atan(z / dist) * 180 / kPi;
+LD_HD int velodyne_ring_from_angle(double angle, int scan_lines) {
   int scan_id;
   if (scan_lines == 64) {
     if (angle >= -8.83) scan_id = int((2 - angle) * 3.0 + 0.5);
@@ -73,6 +72,10 @@ LD_HD int velodyne_ring(double z, double dist, int scan_lines) {
     return -1;
   }
   return scan_id;
+}
+LD_HD int velodyne_ring(double z, double dist, int scan_lines) {
+  const double angle = atan(z / dist) * 180 / kPi;
+  return velodyne_ring_from_angle(angle, scan_lines);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -82,6 +82,51 @@ def test_extract_edge_cases(orc):
     g.close()
 
 
+def test_ring_split_at_decision_boundaries(orc):
+    """k_classify decides in float where that is safe and falls back to the reference's FP64 expressions near a decision
+    boundary.  Points placed ON and within 1e-9 .. 1e-3 (degrees / relative range) of every boundary — elevation bin
+    edges of the 16 / 32 / 64-line formulas, the 2 / -8.83 / -24.33 degree limits, min_range and max_range — must land
+    in exactly the rings the oracle's (literal FP64) split gives: ring sizes and the per-ring smoothness bits."""
+    rng = np.random.default_rng(5)
+    for H in (16, 32, 64):
+        if H == 64:
+            edges = [2 - (k - 0.5) / 3.0 for k in range(0, 34)] + [-8.83 - (k - 0.5) / 2.0 for k in range(0, 33)] + [2.0, -8.83, -24.33]
+        elif H == 32:
+            edges = [k * 4.0 / 3.0 - 92.0 / 3.0 for k in range(-1, 34)]
+        else:
+            edges = [2.0 * (k - 0.5) - 15.0 for k in range(-1, 18)]
+        offs = [0.0] + [sgn * 10.0 ** -e for e in range(3, 10) for sgn in (1, -1)]
+        pts = []
+        W = 0
+        for az in np.linspace(-3.1, 3.1, 220):
+            col = []
+            for a in edges:
+                for o in offs:
+                    r = 10.0 + 3.0 * np.sin(7 * az) + rng.normal(0, 0.02)
+                    el = np.deg2rad(a + o)
+                    col.append((r * np.cos(el) * np.cos(az), r * np.cos(el) * np.sin(az), r * np.sin(el), 0.0))
+            # range limits (XY range): exactly on, and a hair inside / outside
+            for lim in (3.0, 75.0):
+                for o in offs:
+                    d = lim * (1.0 + o)
+                    col.append((d * np.cos(az), d * np.sin(az), -0.05 * d, 0.0))
+            W = len(col)
+            pts.extend(col)
+        x = np.array(pts, dtype=np.float32)
+        po, g = mk(orc, H, 4 * len(x) // H, 0, 8, 10, debug=1)
+        o_offs, o_order = orc.split(po, x, H, 0)
+        o = orc.extract(po, x, H, 0, want_curv=True)
+        e = g.extract_edges(x, H, 0)
+        cg, offs_g = g.curvature()
+        assert np.array_equal(offs_g, o_offs), (H, offs_g, o_offs)
+        assert_edges_equal(e, o)
+        co = o["curv"][:len(cg)]
+        m = ~np.isnan(cg)
+        assert np.array_equal(np.isnan(cg), np.isnan(co)) and np.array_equal(cg[m].view(np.uint64), co[m].view(np.uint64)), H
+        assert o_offs[-1] > 0.5 * len(x) and W > 0
+        g.close()
+
+
 def test_suppression_carry_across_regions(orc):
     # SURVEY.md §0 fact 4 — same construction as tests/test_oracle_extract.py
     n = 910
