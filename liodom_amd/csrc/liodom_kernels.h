@@ -1794,15 +1794,22 @@ __device__ __forceinline__ void lm_eval(const DevView& v, int s, int eb, int c_l
     // red[29][kLmEvalThreads] (conflict-free 8-byte stores); then thread (v, r) = (t / 16, t % 16) sums
     // the elements r, r + 16, r + 32, ... of row v (conflict-free loads, 28 adds), a 4-step DPP row
     // sum finishes row v.  Fixed order -> deterministic, no atomics.
+    // (only the columns of threads that hold a block — with several workgroups per solve about half of them — rounded up
+    //  to whole 16-lane rows: the other threads' partial sums are zero and neither written nor read)
+    const int nb_here = c_hi - c_lo;
+    const int ncol = ((nb_here < kLmEvalThreads ? nb_here : kLmEvalThreads) + 15) & ~15;
+    if (et < ncol) {
 #pragma unroll
-    for (int i = 0; i < kAccN; i++) part[i * kLmEvalThreads + et] = acc[i];
+      for (int i = 0; i < kAccN; i++) part[i * kLmEvalThreads + et] = acc[i];
+    }
     __syncthreads();
     const int vrow = threadIdx.x >> 4, r = threadIdx.x & 15;
     double x = 0.0;
     if (vrow < kAccN) {
       const double* rowp = part + vrow * kLmEvalThreads + r;
+      const int nk = ncol >> 4;
 #pragma unroll 8
-      for (int kk = 0; kk < kLmEvalThreads / 16; kk++) x += rowp[kk * 16];
+      for (int kk = 0; kk < nk; kk++) x += rowp[kk * 16];
     }
     x = row_sum_f64(x);
     if (vrow < kAccN && r == 0) acc_out[vrow] = x;
@@ -2089,6 +2096,7 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
   const int E = st.n_edges_buf[eb];
   int nblocks = st.info.matches[outer_it];      // (lock-step batches: counted by k_line_gate; else from k_knn's partial sums below)
   __shared__ int sh_nmatch;
+  __shared__ double sh_scale[8];
   const unsigned int epoch0 = ((unsigned int)(st.scan_counter + 1) << 6) | ((unsigned int)outer_it << 5);
   unsigned int n_eval = 0;
   bool xch_local = false;       // the G workgroups were seen on one XCD: exchanges through its L2 (lm_exchange)
@@ -2147,11 +2155,17 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
   // build this scan searched (step 1 of the finalising solve) ----
   int dbg_it = 0;
   for (int step = 0;; step++) {
+    if (step == 0 && tid > kLmCtl && tid <= kLmCtl + 6) {
+      // the six Jacobi scales of lm_begin (an FP64 square root and a division each) on six lanes of the controller's wave
+      const int j = tid - kLmCtl - 1;
+      sh_scale[j] = 1.0 / (1.0 + sqrt(sh_acc[7 + h_idx(j, j)]));
+    }
+    if (step == 0) __builtin_amdgcn_wave_barrier();
     if (tid == kLmCtl) {
       // (a wave-parallel controller — lane 8 r + c holding entry (r, c) of the 6 x 6 matrices, Cholesky columns
       // broadcast through LDS, solves on readlane'd entries — was measured slower than this single lane:
       // 3.9-5.9 us per step against 3.1)
-      const int f = step == 0 ? lm_begin(lm, st.param_q, st.param_t, sh_acc, nblocks, v.apply_on_ftol) : lm_update(lm, sh_acc);
+      const int f = step == 0 ? lm_begin(lm, st.param_q, st.param_t, sh_acc, nblocks, v.apply_on_ftol, sh_scale) : lm_update(lm, sh_acc);
       sh_flag = f;
       if (f == LM_NEED_EVAL) iso_from_qt(lm.cand_q, lm.cand_t, sh_pose);
       if (step == 0) DBG_STAMP(v, dbgb, 2, 23);

@@ -705,8 +705,9 @@ LD_HD int lm_propose(LmState& st) {
 }
 
 // acc = accumulator evaluated at (q0, t0); n_blocks = number of residual blocks.
+// pre_scale (optional): the six Jacobi scales 1 / (1 + sqrt(H_jj)), computed by six lanes side by side on the device
 LD_HD int lm_begin(LmState& st, const double* q0, const double* t0, const double* acc,
-                   int n_blocks, int apply_on_ftol) {
+                   int n_blocks, int apply_on_ftol, const double* pre_scale = nullptr) {
   LD_UNROLL
   for (int k = 0; k < 4; k++) st.q[k] = st.cand_q[k] = q0[k];
   LD_UNROLL
@@ -729,7 +730,7 @@ LD_HD int lm_begin(LmState& st, const double* q0, const double* t0, const double
   LD_UNROLL
   for (int j = 0; j < 21; j++) st.H[j] = acc[7 + j];
   LD_UNROLL
-  for (int j = 0; j < 6; j++) st.scale[j] = 1.0 / (1.0 + sqrt(st.H[h_idx(j, j)]));
+  for (int j = 0; j < 6; j++) st.scale[j] = pre_scale ? pre_scale[j] : 1.0 / (1.0 + sqrt(st.H[h_idx(j, j)]));
   if (gmax <= 1e-10) { st.termination = LM_TERM_GRAD_TOL; return LM_DONE; }
   return lm_propose(st);
 }
