@@ -1132,6 +1132,7 @@ template <bool kDeep> struct KnnTune {
   static constexpr int kLoadsFlat = kDeep ? 8 : LIODOM_TUNE_B_LOADS_FLAT;
   static constexpr float kNearSq = kDeep ? 0.04f : LIODOM_TUNE_B_NEAR;
   static constexpr bool kProbeBoth = kDeep;
+  static constexpr bool kHoistLoads = kDeep;
   static constexpr bool kCursor = kDeep ? false : LIODOM_TUNE_B_CURSOR;      // flat list: per-lane cursor instead of the binary search
 };
 constexpr int kKnnGridDiv = 2;         // k_knn grid = half of the query blocks the edge capacity allows: a workgroup takes block b and, if the scan has that many edges, b + grid
@@ -1139,7 +1140,6 @@ template <class Acc, int UB, int U, int kBigCell, bool kCursor = false>
 __device__ __forceinline__ void knn_stream_cells(Acc& t, const float4* sp, int* s_incl, int* s_adj,
                                                  unsigned int start, unsigned int cnt, int hl,
                                                  float qx, float qy, float qz, unsigned int* dbg = nullptr) {
-  unsigned int dbg_big = 0, dbg_bigit = 0, dbg_flatit = 0;
   const unsigned long long dbg_t0 = dbg ? wall_clock64() : 0ull;
   {
     const int half_base = (threadIdx.x & 32);
@@ -1149,9 +1149,7 @@ __device__ __forceinline__ void knn_stream_cells(Acc& t, const float4* sp, int* 
       big &= big - 1u;
       const int cs = __shfl((int)start, l, kKnnGroup), cc = __shfl((int)cnt, l, kKnnGroup);
       const float4* cp = sp + cs;
-      dbg_big++;
       for (int i = hl; i < cc; i += UB * kKnnGroup) {
-        dbg_bigit++;
         float4 m[UB];
 #pragma unroll
         for (int u = 0; u < UB; u++) { const int iu = i + u * kKnnGroup; m[u] = cp[iu < cc ? iu : cc - 1]; }
@@ -1173,7 +1171,6 @@ __device__ __forceinline__ void knn_stream_cells(Acc& t, const float4* sp, int* 
   const unsigned long long dbg_t1 = dbg ? wall_clock64() : 0ull;
   int cur = 0;
   for (int i = hl; i < T; i += U * kKnnGroup) {
-    dbg_flatit++;
     // owner segment of flat index iu = number of segments whose inclusive prefix is <= iu: a 5-step binary search over
     // the 32 prefixes in LDS, the U searches of a lane side by side (a per-lane cursor loop — dependent LDS reads behind
     // divergent branches — cost 2-3 us per round on a single stream)
@@ -1214,7 +1211,7 @@ __device__ __forceinline__ void knn_stream_cells(Acc& t, const float4* sp, int* 
   if (dbg && hl == 0) {
     dbg[0] = (unsigned int)(dbg_t1 - dbg_t0);                      // big-cell part, 10 ns ticks
     dbg[1] = (unsigned int)(wall_clock64() - dbg_t1);              // flat part
-    dbg[2] = dbg_big | (dbg_bigit << 8) | (dbg_flatit << 16) | ((unsigned int)T << 20);
+    dbg[2] = ((unsigned int)((T + U * kKnnGroup - 1) / (U * kKnnGroup)) << 16) | ((unsigned int)T << 20);   // flat rounds, flat candidates
     dbg[3] = dbg_nseg;
   }
 }
@@ -1310,7 +1307,7 @@ __device__ __forceinline__ float best2_bound(const Best2Acc& t, int half_shift) 
 // One block of kKnnThreads / 32 queries (virtual block index bv).  Whole workgroup; returns are workgroup-uniform.
 template <int kKnnThreads>
 __device__ __forceinline__ void knn_block(const DevView& v, int s, StreamState& st, int outer_it, int eb, int bv, int E,
-                                          KnnShared<kKnnThreads / kKnnGroup>& sh) {
+                                          KnnShared<kKnnThreads / kKnnGroup>& sh, const float4& p_in, const double (&T_in)[12]) {
   constexpr int kKnnQueries = kKnnThreads / kKnnGroup;
   typedef KnnTune<(kKnnThreads >= 256)> Tune;
   const int grp = threadIdx.x / kKnnGroup;
@@ -1323,10 +1320,17 @@ __device__ __forceinline__ void knn_block(const DevView& v, int s, StreamState& 
   bool active = e < E;
   float qx = 0.f, qy = 0.f, qz = 0.f;
   if (active) {
-    const float4 p = v.edges[((size_t)eb * v.n_streams + s) * v.edge_cap + e];
+    // (few streams: edge and pose were loaded by the caller, beside the stream's state words; lock-step batches load them
+    //  here — hoisted they would cost 10 VGPRs, i.e. a wave per SIMD)
+    float4 p = p_in;
     double T[12];
 #pragma unroll
-    for (int i = 0; i < 12; i++) T[i] = st.odom[i];
+    for (int i = 0; i < 12; i++) T[i] = T_in[i];
+    if (!Tune::kHoistLoads) {
+      p = v.edges[((size_t)eb * v.n_streams + s) * v.edge_cap + e];
+#pragma unroll
+      for (int i = 0; i < 12; i++) T[i] = st.odom[i];
+    }
     transform_point(T, p.x, p.y, p.z, &qx, &qy, &qz);          // :307-308
     if (v.knn_q && hl == 0) v.knn_q[((size_t)s * 2 + outer_it) * v.edge_cap + e] = make_float4(qx, qy, qz, 0.f);
     active = ld_isfinite((double)qx) && ld_isfinite((double)qy) && ld_isfinite((double)qz) &&
@@ -1455,7 +1459,7 @@ __device__ __forceinline__ void knn_block(const DevView& v, int s, StreamState& 
         ta.t.k0 = ta.t.k1 = ta.t.k2 = ta.t.k3 = ta.t.k4 = sentinel;
         ta.t.p0 = ta.t.p1 = ta.t.p2 = ta.t.p3 = ta.t.p4 = -1;
       }
-      knn_stream_cells<Top5Acc, 4, 4, 128>(ta, sp, sh.incl[grp], sh.adj[grp], start, all ? cnt : 0u, hl, qx, qy, qz);
+      knn_stream_cells<Top5Acc, 2, 2, 64>(ta, sp, sh.incl[grp], sh.adj[grp], start, all ? cnt : 0u, hl, qx, qy, qz);
       knn_merge(ta.t, g, hl, half_shift);
       d5 = g.p4 >= 0 ? top5_dist(g.k4) : __int_as_float(0x7f800000);       // (a sentinel among the five: fewer than five candidates inside the gate)
       pos5[0] = g.p0; pos5[1] = g.p1; pos5[2] = g.p2; pos5[3] = g.p3; pos5[4] = g.p4;
@@ -1613,9 +1617,23 @@ __global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int oute
     }
     if (wait_edges && !pipe_wait(v.pipe_flags + eb, wait_edges, &st.status)) return;
   }
-  if (st.status & LIODOM_STATUS_PIPE_TIMEOUT) return;      // (uniform) a wait of this handle gave up: the edge buffer may be incomplete
-  if (!st.initialized) return;                     // uniform over the workgroup
+  // The block's first loads — its edge, the pose — leave together with the stream's state words instead of behind the
+  // branches on them (one memory round trip less on the launch's critical path; the edge index is clamped, an unused
+  // edge costs nothing).
+  typedef KnnTune<(kKnnThreads >= 256)> Tune;
+  const int e_first = bxi * kKnnQueries + (int)(threadIdx.x / kKnnGroup);
+  float4 p_first = make_float4(0.f, 0.f, 0.f, 0.f);
+  double T[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (Tune::kHoistLoads) {
+    p_first = v.edges[((size_t)eb * v.n_streams + s) * v.edge_cap + (e_first < v.edge_cap ? e_first : v.edge_cap - 1)];
+#pragma unroll
+    for (int i = 0; i < 12; i++) T[i] = st.odom[i];
+  }
+  const unsigned int st_status = st.status;
+  const int st_init = st.initialized;
   const int E = st.n_edges_buf[eb];
+  if (st_status & LIODOM_STATUS_PIPE_TIMEOUT) return;      // (uniform) a wait of this handle gave up: the edge buffer may be incomplete
+  if (!st_init) return;                            // uniform over the workgroup
   // (two explicit calls, not a loop over bv: as a loop body the block needs 160 VGPRs instead of 69)
   static_assert(kKnnGridDiv == 2, "k_knn handles exactly two query blocks per workgroup");
   if (bxi * kKnnQueries >= E) {             // no query here: empty validity bytes for the solve's compaction
@@ -1625,7 +1643,7 @@ __global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int oute
     }
     return;
   }
-  knn_block<kKnnThreads>(v, s, st, outer_it, eb, bxi, E, sh);
+  knn_block<kKnnThreads>(v, s, st, outer_it, eb, bxi, E, sh, p_first, T);
   const int bv2 = bxi + v.knn_grid;
   if (bv2 >= v.knn_blocks) return;
   if (bv2 * kKnnQueries >= E) {
@@ -1633,7 +1651,16 @@ __global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int oute
     return;
   }
   __syncthreads();                          // (the second block reuses the LDS)
-  knn_block<kKnnThreads>(v, s, st, outer_it, eb, bv2, E, sh);
+  const int e_second = bv2 * kKnnQueries + (int)(threadIdx.x / kKnnGroup);
+  float4 p_second = make_float4(0.f, 0.f, 0.f, 0.f);
+  double T2[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // (reloaded: kept live across the first block the pose would cost 24 VGPRs)
+  if (Tune::kHoistLoads) {
+    p_second = v.edges[((size_t)eb * v.n_streams + s) * v.edge_cap + (e_second < v.edge_cap ? e_second : v.edge_cap - 1)];
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 12; i++) T2[i] = st.odom[i];
+  }
+  knn_block<kKnnThreads>(v, s, st, outer_it, eb, bv2, E, sh, p_second, T2);
 }
 
 // k_line_gate (lock-step batches): the line gate of laser_odometry.cc:325-344 for the queries of one kNN pass, one query
