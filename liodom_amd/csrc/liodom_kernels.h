@@ -1929,7 +1929,7 @@ __device__ void finalize_scan(const DevView& v, int s, StreamState& st, int* sh_
       ho->pose[0] = q[0]; ho->pose[1] = q[1]; ho->pose[2] = q[2]; ho->pose[3] = q[3];
       ho->pose[4] = st.final_odom[3]; ho->pose[5] = st.final_odom[7]; ho->pose[6] = st.final_odom[11];
       ho->info = st.info;
-      __threadfence_system();
+      // (the system-scope release orders this thread's payload stores before the sequence word: no separate fence)
       __hip_atomic_store(&ho->seq, k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     st.info.matches[0] = 0; st.info.matches[1] = 0;   // counters of the next scan's two kNN passes

@@ -319,19 +319,21 @@ LD_HD void odom_message(const double* prev_odom, const double* odom, const doubl
 // ceres::EigenQuaternionParameterization::Plus, x = [x y z w]
 LD_HD void quat_plus(const double* x, const double* delta, double* out) {
   LD_FP_CONTRACT_FAST
-  const double nd = sqrt(delta[0] * delta[0] + delta[1] * delta[1] + delta[2] * delta[2]);
-  if (nd > 0.0) {
+  const double u2 = delta[0] * delta[0] + delta[1] * delta[1] + delta[2] * delta[2];
+  if (u2 > 0.0) {
     // sin(nd)/nd and cos(nd).  LM steps are small rotations: below 0.5 rad the Taylor series in
     // nd^2 (9 terms, truncation error < 1e-19) replaces the two ~170-instruction library calls on
-    // the single lane that runs the controller; larger steps take the library path.
+    // the single lane that runs the controller — and needs no square root (nd only enters as nd^2);
+    // larger steps take the library path.
     double s, aw;
-    if (nd < 0.5) {
-      const double u = nd * nd;
+    if (u2 < 0.25) {
+      const double u = u2;
       s = 1.0 + u * (-1.0 / 6.0 + u * (1.0 / 120.0 + u * (-1.0 / 5040.0 + u * (1.0 / 362880.0 + u * (-1.0 / 39916800.0 +
           u * (1.0 / 6227020800.0 + u * (-1.0 / 1307674368000.0 + u * (1.0 / 355687428096000.0))))))));
       aw = 1.0 + u * (-0.5 + u * (1.0 / 24.0 + u * (-1.0 / 720.0 + u * (1.0 / 40320.0 + u * (-1.0 / 3628800.0 +
            u * (1.0 / 479001600.0 + u * (-1.0 / 87178291200.0 + u * (1.0 / 20922789888000.0))))))));
     } else {
+      const double nd = sqrt(u2);
       s = sin(nd) / nd;
       aw = cos(nd);
     }
@@ -744,8 +746,10 @@ LD_HD int lm_update(LmState& st, const double* acc) {
   for (int k = 0; k < 4; k++) dq[k] = st.q[k] - st.cand_q[k];
   LD_UNROLL
   for (int k = 0; k < 3; k++) dt[k] = st.t[k] - st.cand_t[k];
-  const double step_norm = norm7(dq, dt);
-  if (step_norm <= 1e-8 * (st.x_norm + 1e-8)) { st.termination = LM_TERM_PARAM_TOL; return LM_DONE; }
+  // parameter tolerance |step| <= 1e-8 (|x| + 1e-8), compared on the squares (one FP64 square root less on the controller's lane)
+  const double step_sq = dq[0] * dq[0] + dq[1] * dq[1] + dq[2] * dq[2] + dq[3] * dq[3] + dt[0] * dt[0] + dt[1] * dt[1] + dt[2] * dt[2];
+  const double ptol = 1e-8 * (st.x_norm + 1e-8);
+  if (step_sq <= ptol * ptol) { st.termination = LM_TERM_PARAM_TOL; return LM_DONE; }
   const double cost_change = st.cost - cand_cost;
   if (fabs(cost_change) <= 1e-6 * st.cost) {
     st.termination = LM_TERM_FUNC_TOL;
