@@ -656,8 +656,14 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   v.knn_partials = config->n_streams >= 16 ? 0 : 1;         // measured: +37 % on the VALU-bound 256-stream kNN pass, -2 us per solve on one stream
   v.knn_blocks = round_up(cdiv(v.edge_cap, v.knn_queries), 4);
   v.knn_grid = std::max(1, cdiv(v.knn_blocks, kKnnGridDiv));   // sized for the usual edge count (~1/3 of the capacity): a workgroup takes a second block if there are more
-  if (std::getenv("LIODOM_KNN_SAVE") == nullptr || std::atoi(std::getenv("LIODOM_KNN_SAVE")) != 0) ALLOC(v.knn_save_q, S * (size_t)v.edge_cap, 0);
-  else v.knn_save_q = nullptr;
+  {
+    // LIODOM_KNN_SAVE: 2 (default) second pass re-ranks the first pass's kept candidates and prunes with its fifth distance;
+    // 1: pruning bound only; 0: the second pass searches like the first (all three give the same results)
+    const int save = std::getenv("LIODOM_KNN_SAVE") ? std::atoi(std::getenv("LIODOM_KNN_SAVE")) : 2;
+    if (save >= 1) ALLOC(v.knn_save_q, S * (size_t)v.edge_cap, 0); else v.knn_save_q = nullptr;
+    if (save >= 2) { ALLOC(v.knn_save_pos, S * (size_t)v.edge_cap * kKnnGroup, 0xFF); ALLOC(v.knn_save_g, S * (size_t)v.edge_cap, 0); }
+    else { v.knn_save_pos = nullptr; v.knn_save_g = nullptr; }
+  }
   if (const char* e = std::getenv("LIODOM_KNN_EXACT_ONLY")) v.knn_exact_only = std::atoi(e) != 0 ? 1 : 0;
   ALLOC(v.knn_part, S * 2 * (size_t)v.knn_blocks * 32, 0);
   ALLOC(v.corr_mask, S * 2 * (size_t)v.knn_blocks, 0);
@@ -1358,7 +1364,7 @@ int liodom_get_modes(liodom_handle_t* h, char* buf, int cap) {
            "rotation_mode=%d table_size=%d rebuild_delta=%.3f debug=%d",
            h->S, v.early_rebuild, v.early_rebuild ? "streamed" : (h->lds_hash_build ? "lds" : "global"), h->use_flags ? 1 : 0,
            (h->use_flags && h->flag_gate) ? 1 : 0, h->use_graph ? 1 : 0, v.lm_groups, h->S >= 16 ? 128 : 256, v.knn_queries, v.knn_grid,
-           v.knn_blocks, v.knn_partials, v.knn_save_q ? 1 : 0, v.knn_exact_only, v.knn_nn ? 1 : 0, v.filter_local_map, v.mapping,
+           v.knn_blocks, v.knn_partials, v.knn_save_pos ? 2 : (v.knn_save_q ? 1 : 0), v.knn_exact_only, v.knn_nn ? 1 : 0, v.filter_local_map, v.mapping,
            v.rotation_mode, v.table_size, (double)v.rebuild_delta, v.debug);
   return LIODOM_OK;
 }

@@ -183,6 +183,8 @@ struct DevView {
                             // second table ("Streamed rebuild" below); no k_window_insert / k_hash_alloc / k_hash_scatter launches
   int knn_grid;             // k_knn workgroups launched per stream (each takes the query blocks b, b + knn_grid, ...)
   float4* knn_save_q;       // [S][edge_cap] first kNN pass of a scan: the query (xyz) and its fifth-nearest distance (w; inf if none): the second pass prunes with it
+  int2* knn_save_pos;       // [S][edge_cap][32] first kNN pass: the two candidates every lane kept (positions in the cell-sorted array; -1: none)
+  float* knn_save_g;        // [S][edge_cap] first kNN pass: guard — no map point outside the kept set was closer to that pass's query than sqrt(guard) (0: nothing saved)
   int knn_exact_only;       // (test switch) every kNN query takes the exact list path instead of the Best2 fast path: same results
   int knn_blocks;           // k_knn workgroups per stream = ceil(edge_cap / knn_queries), rounded up to a multiple of 4
   unsigned long long* lm_xch;   // [S][2][kLmGroupsMax][64] tagged granules: partial sums exchanged between the LM workgroups
@@ -1126,6 +1128,9 @@ struct Best2Acc {
 #define LIODOM_TUNE_B_CURSOR false
 #define LIODOM_TUNE_B_NEAR 0.0036f
 #endif
+#ifndef LIODOM_TUNE_B_WAVES
+#define LIODOM_TUNE_B_WAVES 7        // waves per SIMD the lock-step instance is compiled for (72 VGPRs)
+#endif
 template <bool kDeep> struct KnnTune {
   static constexpr int kBigCell = kDeep ? 256 : LIODOM_TUNE_B_BIG;
   static constexpr int kLoadsBig = kDeep ? 8 : LIODOM_TUNE_B_LOADS_BIG;
@@ -1346,6 +1351,43 @@ __device__ __forceinline__ void knn_block(const DevView& v, int s, StreamState& 
     const CellSlot* cells = v.cells + (size_t)stab * v.table_size;
     const unsigned int* bits = v.cell_bits + (size_t)stab * (v.table_size >> 5);
     const float4* sp = v.sorted_pts + (size_t)stab * v.sorted_cap;
+    float d5_r = __int_as_float(0x7f800000);
+    int pos5[5] = {-1, -1, -1, -1, -1};
+    // ---- second pass of a scan: re-rank what the first pass kept.  The first solve moves the pose by millimetres, so
+    // almost every query has the same neighbours as before.  Pass 0 saved the two candidates every lane kept (64 positions:
+    // a superset of the five nearest) and a guard g: no map point outside that set was closer to the old query than
+    // sqrt(g) (the lanes' third-nearest distances, the box distances of the pruned cells, the distance to the border of
+    // the 27-cell block).  With d = |q_new - q_old| every unsaved point is now at least sqrt(g) - d away; if the fifth of
+    // the re-ranked set is strictly closer than that (rounding margins included) — or nothing unsaved can be inside the
+    // 1.0 gate — it is the exact answer and the query needs no probe and no stream; otherwise it searches below. ----
+    bool reranked = false;
+    if (outer_it == 1 && v.knn_save_pos && !v.knn_exact_only) {
+      const float gsq = v.knn_save_g[(size_t)s * v.edge_cap + e];
+      if (gsq > 0.f) {                                           // (uniform over the half-wave)
+        const float4 sq = v.knn_save_q[(size_t)s * v.edge_cap + e];
+        const int2 sv = v.knn_save_pos[((size_t)s * v.edge_cap + e) * kKnnGroup + hl];
+        const float4 m0 = sp[sv.x >= 0 ? sv.x : 0], m1 = sp[sv.y >= 0 ? sv.y : 0];
+        Best2Acc br;
+        br.clear();
+        br.consider(sv.x >= 0, sqdist_f(qx, qy, qz, m0.x, m0.y, m0.z), 0, sv.x);
+        br.consider(sv.y >= 0, sqdist_f(qx, qy, qz, m1.x, m1.y, m1.z), 0, sv.y);
+        float d5n;
+        int p5[5];
+        const bool sel_ok = best2_select(br, hl, half_shift, d5n, p5);
+        const double ddx = (double)qx - (double)sq.x, ddy = (double)qy - (double)sq.y, ddz = (double)qz - (double)sq.z;
+        const double delta = sqrt(ddx * ddx + ddy * ddy + ddz * ddz) * (1.0 + 1e-12);
+        const double r = sqrt((double)gsq) * (1.0 - 2e-7) - delta;         // every unsaved point is at least this far now
+        const double limit = r > 0.0 ? r * r * (1.0 - 1e-6) : 0.0;         // (float rounding of the new distances included)
+        reranked = sel_ok && ((double)d5n < limit || limit > 1.0);         // beyond the 1.0 gate nothing unsaved can matter
+        if (reranked) {
+          d5_r = d5n;
+#pragma unroll
+          for (int k = 0; k < 5; k++) pos5[k] = p5[k];
+        }
+      }
+    }
+    if ((v.debug & 64) && hl == 0 && outer_it == 1) atomicAdd(&v.dbg_clk[259 + (reranked ? 0 : 1)], 1ull);
+    if (!reranked) {
     // One segment of candidates per lane: the query's cell and its 26 neighbours (lanes 0..26; the own cell is lane 13),
     // and on lane 27 the overflow list of the streamed rebuild (points of the newest frame that moved out of their
     // padded cells: empty unless the solve corrected the prediction by more than rebuild_delta).  lb = lower bound of
@@ -1435,7 +1477,6 @@ __device__ __forceinline__ void knn_block(const DevView& v, int s, StreamState& 
       pend = false;
     }
     DBG_STAMP(v, dbgb, 1, 4); DBG_QSTAMP(4);
-    int pos5[5];
     const bool certain = best2_select(b2, hl, half_shift, d5, pos5) && !v.knn_exact_only;
     if ((v.debug & 32) && s == 0 && e < E && hl == 0) v.dbg_q[((size_t)outer_it * v.edge_cap + e) * 12] = (unsigned int)dbg_n | (dbg_two_phase ? 0x40000000u : 0u) | (certain ? 0u : 0x80000000u);
     if ((v.debug & 64) && hl == 0) {       // (debug) fast-path results / exact-list repeats / queries with a second phase; candidates streamed
@@ -1464,7 +1505,25 @@ __device__ __forceinline__ void knn_block(const DevView& v, int s, StreamState& 
       d5 = g.p4 >= 0 ? top5_dist(g.k4) : __int_as_float(0x7f800000);       // (a sentinel among the five: fewer than five candidates inside the gate)
       pos5[0] = g.p0; pos5[1] = g.p1; pos5[2] = g.p2; pos5[3] = g.p3; pos5[4] = g.p4;
     }
-    DBG_STAMP(v, dbgb, 1, 5); DBG_QSTAMP(5);
+    if (outer_it == 0 && v.knn_save_pos) {
+      // what the second pass re-ranks: the lanes' kept candidates and the guard (see above)
+      const float sk = (cnt > 0 && !(!(lb > B) || (!have_b && (hl == 13 || hl == 27 || lb <= Tune::kNearSq)))) ? lb : __int_as_float(0x7f800000);   // pruned, non-empty segment
+      unsigned int gd = half_min_u32((unsigned int)__float_as_int(sk));
+      const unsigned int m3m = half_min_u32((unsigned int)__float_as_int(b2.m3));
+      gd = m3m < gd ? m3m : gd;
+      float guard = __int_as_float((int)gd);
+      {
+        // points outside the 27 cells: at least 1 + (distance of q to the nearest face of its own cell) away
+        const float cs = (float)kCellSize;
+        const float fx = qx - (float)cx * cs, fy = qy - (float)cy * cs, fz = qz - (float)cz * cs;
+        float edge = fminf(fminf(fminf(fx, cs - fx), fminf(fy, cs - fy)), fminf(fz, cs - fz));
+        edge = edge > 0.f ? edge : 0.f;
+        const float outer = (cs + edge) * (cs + edge) * (1.0f - 1e-6f);
+        guard = guard < outer ? guard : outer;
+      }
+      v.knn_save_pos[((size_t)s * v.edge_cap + e) * kKnnGroup + hl] = make_int2(b2.p1, b2.p2);
+      if (hl == 0) v.knn_save_g[(size_t)s * v.edge_cap + e] = guard < 3.0e38f ? guard : 3.0e38f;
+    }
     if ((v.debug & 64) && s == 0 && hl == 0) {
       const int bin = (int)((wall_clock64() - t_blk) / 100ull);
       atomicAdd(&v.dbg_clk[320 + (bin < 63 ? bin : 63)], 1ull);
@@ -1473,6 +1532,9 @@ __device__ __forceinline__ void knn_block(const DevView& v, int s, StreamState& 
       if (!certain) atomicAdd(&v.dbg_clk[448 + (bin / 4 < 7 ? bin / 4 : 7) * 8 + 7], 1ull);
       if (dbg_two_phase) atomicAdd(&v.dbg_clk[448 + (bin / 4 < 7 ? bin / 4 : 7) * 8 + 6], 1ull);
     }
+    }   // (!reranked)
+    else d5 = d5_r;
+    DBG_STAMP(v, dbgb, 1, 5); DBG_QSTAMP(5);
     if (d5 < 1.0f) {                                 // :324 (inf when < 5 candidates)
       const int mypos = hl == 0 ? pos5[0] : hl == 1 ? pos5[1] : hl == 2 ? pos5[2] : hl == 3 ? pos5[3] : pos5[4];
       if (hl < 5) {
@@ -1484,7 +1546,10 @@ __device__ __forceinline__ void knn_block(const DevView& v, int s, StreamState& 
     }
   }
   // what the second pass prunes with: the query and its fifth-nearest distance (inf: fewer than five candidates / no query)
-  if (outer_it == 0 && v.knn_save_q && e < E && hl == 0) v.knn_save_q[(size_t)s * v.edge_cap + e] = make_float4(qx, qy, qz, d5);
+  if (outer_it == 0 && v.knn_save_q && e < E && hl == 0) {
+    v.knn_save_q[(size_t)s * v.edge_cap + e] = make_float4(qx, qy, qz, d5);
+    if (!active && v.knn_save_g) v.knn_save_g[(size_t)s * v.edge_cap + e] = 0.f;       // (no query: nothing to re-rank)
+  }
   __syncthreads();
   DBG_STAMP(v, dbgb, 1, 6); DBG_QSTAMP(6);
   if (kKnnThreads < 256 && v.knn_nn) {
@@ -1595,7 +1660,7 @@ __device__ __forceinline__ void knn_block(const DevView& v, int s, StreamState& 
 // (half of the capacity), not for edge_cap: on lock-step batches two thirds of an edge_cap-sized grid were workgroups
 // that found nothing to do.
 template <int kKnnThreads>
-__global__ __launch_bounds__(kKnnThreads) void k_knn(DevView v, int s0, int outer_it, int eb, unsigned int wait_edges, unsigned int signal_odo) {
+__global__ __launch_bounds__(kKnnThreads, (kKnnThreads >= 256 ? 1 : LIODOM_TUNE_B_WAVES)) void k_knn(DevView v, int s0, int outer_it, int eb, unsigned int wait_edges, unsigned int signal_odo) {
   constexpr int kKnnQueries = kKnnThreads / kKnnGroup;
   __shared__ KnnShared<kKnnQueries> sh;
   int bxi = (int)blockIdx.x, byi = (int)blockIdx.y;

@@ -644,11 +644,13 @@ def test_knn_fast_path_equals_exact_list_path(orc, synth, monkeypatch):
     """k_knn keeps two candidates per lane and pops the five nearest from them; a query whose result that cannot
     certify (three of its nearest in one lane, or equal distances that FLANN orders by index) repeats the stream
     with sorted (distance, index) lists.  LIODOM_KNN_EXACT_ONLY=1 sends EVERY query through the list path;
-    LIODOM_KNN_SAVE=0 makes the second pass of a scan derive its pruning bound like the first one (own cell first)
-    instead of from the first pass's fifth-nearest distance.  Poses, match counts and correspondence indices must be
-    bit-identical in all three configurations, also with large pose corrections between the passes."""
+    the second pass of a scan by default re-ranks the candidates the first pass kept and accepts that only when a guard
+    distance proves that no other map point can be among the five nearest (LIODOM_KNN_SAVE=1: it only takes its
+    pruning bound from the first pass's fifth-nearest distance; =0: it searches like the first pass).  Poses, match
+    counts and correspondence indices must be bit-identical in all configurations, also with large pose corrections
+    between the passes (many re-rankings that cannot be certified)."""
     H, W, R, epr, P, K = 16, 900, 6, 10, 5, 14
-    modes = {"default": {}, "exact_only": {"LIODOM_KNN_EXACT_ONLY": "1"}, "no_saved_bound": {"LIODOM_KNN_SAVE": "0"}}
+    modes = {"default": {}, "exact_only": {"LIODOM_KNN_EXACT_ONLY": "1"}, "bound_only": {"LIODOM_KNN_SAVE": "1"}, "no_saved_bound": {"LIODOM_KNN_SAVE": "0"}}
     for yaw, speed in ((0.5, 0.1), (3.0, 0.6)):
         cfg = synth.make_cfg(H, W, 0, yaw_rate_deg=yaw, speed=speed)
         scans = [synth.scan(cfg, 6, k)[0] for k in range(K)]
@@ -667,7 +669,7 @@ def test_knn_fast_path_equals_exact_list_path(orc, synth, monkeypatch):
                 out.append((pose.copy(), tuple(info.matches), v0.copy(), a0.copy(), b0.copy(), v1.copy(), a1.copy(), b1.copy()))
             res[mode] = out
             g.close()
-        for mode in ("exact_only", "no_saved_bound"):
+        for mode in ("exact_only", "bound_only", "no_saved_bound"):
             for k in range(K):
                 assert np.array_equal(res["default"][k][0].view(np.uint64), res[mode][k][0].view(np.uint64)), (mode, yaw, k)
                 assert res["default"][k][1] == res[mode][k][1], (mode, yaw, k)
