@@ -551,7 +551,9 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   // VLP-16 12.2k / 12.1k / -.
   {
     const int ecap = params->scan_lines * params->scan_regions * (params->edges_per_region + 1);
-    const int auto_g = config->n_streams > 4 ? 1 : (ecap >= 8192 ? kLmGroupsMax : (ecap >= 4096 ? 4 : 1));
+    // (round 3, A/B on one box, scans/s: HDL-64 G = 2 / 4 / 8: 11.4k / 11.9k / 12.1k; VLP-16 G = 1 / 2 / 4 / 8: 13.2k / 13.5k / 14.0k / 14.0k;
+    //  16 workgroups — a build with kLmGroupsMax = 16 — lose: the exchange's fan-in grows, HDL-64 11.4k, Ouster-128 8.8k vs 9.05k)
+    const int auto_g = config->n_streams > 4 ? 1 : (ecap >= 2048 ? kLmGroupsMax : (ecap >= 512 ? 4 : 1));
     v.lm_groups = config->lm_workgroups == 0 ? auto_g
                                              : (config->lm_workgroups >= kLmGroupsMax ? kLmGroupsMax : (config->lm_workgroups < 1 ? 1 : config->lm_workgroups));
   }

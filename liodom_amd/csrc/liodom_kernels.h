@@ -40,7 +40,10 @@ constexpr uint64_t kEmptyKey = 0xFFFFFFFFFFFFFFFFull;
 constexpr int kLmThreads = 512;           // k_lm_solve: 8 waves, two per SIMD, all evaluate residual blocks
 constexpr int kLmEvalThreads = kLmThreads;
 constexpr int kLmCtl = kLmThreads - 64;   // lane 0 of the last wave also runs the trust-region logic; waves 0..6 prepare (compaction, register cache) meanwhile
-constexpr int kLmGroupsMax = 8;
+#ifndef LIODOM_LM_GROUPS_MAX
+#define LIODOM_LM_GROUPS_MAX 8
+#endif
+constexpr int kLmGroupsMax = LIODOM_LM_GROUPS_MAX;
 constexpr int kKnnGroup = 32;            // lanes cooperating on one query
 constexpr int kMaxFrames = 256;          // window frames supported by the LDS prefix tables
 constexpr int kEdgeBufs = 4;             // dense edge buffers: 0 / 1 / 2 odometry side (pipelined replay), 3 extraction side
