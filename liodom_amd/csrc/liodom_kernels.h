@@ -764,8 +764,10 @@ __device__ __forceinline__ void ring_select_rows(const DevView& v, const float4*
     const int n_own = re - k0;                          // owned items inside the region (<= 0: none)
     for (int w = tid; w < ((nr + 31) >> 5) + 3; w += nthreads) gb[w] = 0u;
     if (tid < R) { used_mask[tid] = 0; new_mask[tid] = 0; }
-    unsigned int kf[IPL];
+    unsigned int kf[IPL], kf0[IPL];                    // kf0: the keys as loaded (a carry re-run starts from them again)
     unsigned int gbits = region_keys_load<IPL>(kf, rpts, nr, k0, n_own, dump ? rc : nullptr);
+#pragma unroll
+    for (int i = 0; i < IPL; i++) kf0[i] = kf[i];
     // the ring's first / last points are owned by no item: their continuity bits (k = 1..4, nr-5..nr-1) separately
     unsigned int edge_bit = 0;
     int edge_k = 0;
@@ -828,7 +830,10 @@ __device__ __forceinline__ void ring_select_rows(const DevView& v, const float4*
         }
       }
       if (__ballot(need) != 0ull) {                      // (wave-uniform) some row of this wave re-runs its region
-        if (need) (void)region_keys_load<IPL>(kf, rpts, nr, k0, n_own, nullptr);
+        // (the keys are restored from the register copy: reloading the 26 points per lane and recomputing 16 FP64
+        //  smoothness values cost 3.7 us per round — more than the re-run itself on most rings)
+#pragma unroll
+        for (int i = 0; i < IPL; i++) kf[i] = kf0[i];
         const int cntp = select_region_row<IPL>(kf, rpts, gb, need, rs, k0, epr, lane, m, pick_idx + (rvalid ? reg : 0) * ppr,
                                            pick_nfnb + (rvalid ? reg : 0) * ppr);
         if (need && rl == 0) { region_cnt[reg] = cntp; used_mask[reg] = m; flags[0] = 1; }
@@ -1121,8 +1126,8 @@ struct Best2Acc {
 //     of >= 64 points cell-major, phase 1 of the first pass = own cell + neighbours within 6 cm (measured at 256 streams,
 //     us per pass: loads 4/4 + cells >= 128: 576; 2/2 + >= 64: 511; 1/1 + >= 32: 534; per-lane cursor instead of the binary
 //     search: +6 %; phase-1 radius 0 / 6 / 14 cm: 509 / 511 / 510);
-//   few streams (k_knn<256>, one wave per SIMD, bound by the dependent memory round trips of its slowest query): 16 / 8
-//     loads in flight per lane (a query with 1 000 candidates: 4 round trips instead of 9), cells of >= 256 points
+//   few streams (k_knn<256>, one wave per SIMD, bound by the dependent memory round trips of its slowest query): 4
+//     loads in flight per lane, cells of >= 128 points (8 loads / >= 256: no difference)
 //     cell-major, phase 1 = own cell + neighbours within 20 cm (fewer queries need the second phase's round trip).
 #ifndef LIODOM_TUNE_B_BIG            // (lock-step instance; overridable for experiments: tools/variant_build.sh)
 #define LIODOM_TUNE_B_BIG 64
@@ -1134,11 +1139,16 @@ struct Best2Acc {
 #ifndef LIODOM_TUNE_B_WAVES
 #define LIODOM_TUNE_B_WAVES 7        // waves per SIMD the lock-step instance is compiled for (72 VGPRs)
 #endif
+#ifndef LIODOM_TUNE_D_BIG            // (few-stream instance)
+#define LIODOM_TUNE_D_BIG 128
+#define LIODOM_TUNE_D_LOADS 4
+#define LIODOM_TUNE_D_NEAR 0.04f
+#endif
 template <bool kDeep> struct KnnTune {
-  static constexpr int kBigCell = kDeep ? 256 : LIODOM_TUNE_B_BIG;
-  static constexpr int kLoadsBig = kDeep ? 8 : LIODOM_TUNE_B_LOADS_BIG;
-  static constexpr int kLoadsFlat = kDeep ? 8 : LIODOM_TUNE_B_LOADS_FLAT;
-  static constexpr float kNearSq = kDeep ? 0.04f : LIODOM_TUNE_B_NEAR;
+  static constexpr int kBigCell = kDeep ? LIODOM_TUNE_D_BIG : LIODOM_TUNE_B_BIG;
+  static constexpr int kLoadsBig = kDeep ? LIODOM_TUNE_D_LOADS : LIODOM_TUNE_B_LOADS_BIG;
+  static constexpr int kLoadsFlat = kDeep ? LIODOM_TUNE_D_LOADS : LIODOM_TUNE_B_LOADS_FLAT;
+  static constexpr float kNearSq = kDeep ? LIODOM_TUNE_D_NEAR : LIODOM_TUNE_B_NEAR;
   static constexpr bool kProbeBoth = kDeep;
   static constexpr bool kHoistLoads = kDeep;
   static constexpr bool kCursor = kDeep ? false : LIODOM_TUNE_B_CURSOR;      // flat list: per-lane cursor instead of the binary search
