@@ -69,7 +69,7 @@ struct liodom_handle {
   hipEvent_t ev_free[kEdgePipeBufs] = {nullptr, nullptr, nullptr};    // odometry finished reading edge buffer b
   bool ev_free_valid[kEdgePipeBufs] = {false, false, false};
   int parity = 0;                    // edge buffer of the next scan to enter odometry
-  // pipelined replay without cross-stream events (pipe_flags in DevView; events are kept for the hipGraph mode):
+  // pipelined replay without cross-stream events (pipe_flags in DevView; events remain for handles with >= 16 streams and as the fallback):
   unsigned int ext_seq = 0, odo_seq = 0;                 // extractions issued / odometries enqueued through the pipelined replay
   unsigned int eb_seq[kEdgePipeBufs] = {0, 0, 0};        // sequence number of the extraction last issued into buffer b
   unsigned int eb_reader[kEdgePipeBufs] = {0, 0, 0};     // number of the odometry that last read buffer b (0: none to wait for)
@@ -90,15 +90,6 @@ struct liodom_handle {
   std::vector<liodom_map*> mappers;   // per stream: attached device map (mapping replay) or null
   std::vector<int> mapper_cells_xy, mapper_cells_z;
   bool lds_hash_build = false;  // k_hash_build (one workgroup per stream, LDS) instead of the 3 global-atomic kernels
-  // The odometry chain of one scan (2 x [k_knn, k_lm_solve] + the window / hash rebuild: 7 launches) captured once
-  // per (edge buffer, first stream, stream count) into a hipGraph and replayed with one hipGraphLaunch.
-  // Off by default (LIODOM_GRAPH=1 turns it on): measured on MI355X / ROCm 7.2 the graph launch is slower than the
-  // seven eager launches on the headline path (7 735 vs 8 042 scans/s per-scan synchronous, 7 674 vs 7 881
-  // asynchronous; only the strictly serial replay gains, 6 376 vs 6 308) — the chain is bound by its kernels'
-  // durations, the host enqueue (4.5 us per launch) is hidden behind them, and hipGraphLaunch adds start latency.
-  struct OdoGraph { int eb, s0, count; hipGraphExec_t exec; };
-  std::vector<OdoGraph> odo_graphs;
-  bool use_graph = false;
   bool use_flags = false;       // pipelined replay: dependencies between the two streams through flags in device memory instead of events
   bool flag_gate = false;       // ... polled by a one-wave gate launch in front of the scan's first k_knn launch instead of by that launch itself
   std::vector<EventPair> ev_pool;
@@ -207,35 +198,11 @@ int launch_extract(liodom_handle* h, hipStream_t q, int eb, int s0, int count, c
 // so the host can pick them up while the window / hash rebuild still runs.
 int enqueue_odometry(liodom_handle* h, int eb, int s0, int count, unsigned int wait_edges, unsigned int signal_odo);
 
-void drop_graphs(liodom_handle* h) {
-  for (auto& g : h->odo_graphs) (void)hipGraphExecDestroy(g.exec);
-  h->odo_graphs.clear();
-}
-
 int launch_odometry(liodom_handle* h, int eb, int s0, int count, unsigned int wait_edges = 0, unsigned int signal_odo = 0) {
-  int rc = LIODOM_OK;
-  // eager launches while profiling (an event pair around every kernel) and in mapping mode (the attached map's
-  // update enqueues host-dependent work); otherwise one graph launch
-  if (h->use_graph && !h->profiling && !h->v.mapping) {
-    hipGraphExec_t exec = nullptr;
-    for (auto& g : h->odo_graphs) if (g.eb == eb && g.s0 == s0 && g.count == count) { exec = g.exec; break; }
-    if (!exec) {
-      hipGraph_t graph = nullptr;
-      HIP_TRY(hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed));
-      rc = enqueue_odometry(h, eb, s0, count, 0, 0);
-      const hipError_t ce = hipStreamEndCapture(h->stream, &graph);
-      if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-      if (ce != hipSuccess || !graph) { g_last_error = std::string("hipStreamEndCapture failed: ") + hipGetErrorString(ce); return LIODOM_ERR_HIP; }
-      const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-      (void)hipGraphDestroy(graph);
-      if (ie != hipSuccess) { g_last_error = std::string("hipGraphInstantiate failed: ") + hipGetErrorString(ie); return LIODOM_ERR_HIP; }
-      h->odo_graphs.push_back({eb, s0, count, exec});
-    }
-    HIP_TRY(hipGraphLaunch(exec, h->stream));
-  } else {
-    rc = enqueue_odometry(h, eb, s0, count, wait_edges, signal_odo);
-    if (rc) return rc;
-  }
+  // (a hipGraph replay of this launch sequence was measured slower than the eager launches in rounds 1-2 — the chain is
+  //  bound by its kernels, the host enqueue is hidden behind them, hipGraphLaunch adds start latency — and removed in round 3)
+  const int rc = enqueue_odometry(h, eb, s0, count, wait_edges, signal_odo);
+  if (rc) return rc;
   h->last_eb = eb;       // results are published by k_lm_solve into host-mapped memory (HostOut)
   for (int i = 0; i < count; i++) h->scans_enqueued[s0 + i]++;
   return LIODOM_OK;
@@ -523,7 +490,6 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   // global-atomic kernels (many workgroups) but needs 86 us as a single LDS workgroup; 64 lock-step
   // streams need 247 us (L2-atomic bound) against 103 us with one LDS workgroup each.
   h->lds_hash_build = config->n_streams >= 16;
-  if (const char* e = std::getenv("LIODOM_GRAPH")) h->use_graph = std::atoi(e) != 0;
   {
     // Flags instead of events between the extraction and the odometry stream: the first kNN launch of a scan polls the
     // extraction's flag in every workgroup, so all its workgroups must fit on the GPU with ample room left for the
@@ -534,7 +500,7 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
     int cus = 0;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, config->device);
     const int ecap = round_up(std::max(1, params->scan_lines * params->scan_regions * (params->edges_per_region + 1)), 64);
-    h->use_flags = !h->use_graph && config->n_streams < 16;
+    h->use_flags = config->n_streams < 16;
     h->flag_gate = !(config->n_streams == 1 && cdiv(cdiv(ecap, 8), 2) * 4 <= cus * 12);     // (larger launches: a one-wave gate launch polls instead)
     // kernels of different streams never run side by side under these: the in-kernel waits could only time out
     for (const char* name : {"AMD_SERIALIZE_KERNEL", "HIP_LAUNCH_BLOCKING", "ROCPROFILER_PMC", "ROCPROF_COUNTERS"}) {
@@ -717,7 +683,6 @@ void liodom_destroy(liodom_handle_t* h) {
   if (!h) return;
   if (h->stream_x) hipStreamSynchronize(h->stream_x);
   if (h->stream) hipStreamSynchronize(h->stream);
-  drop_graphs(h);
   for (liodom_map* mp : h->mappers) {          // attached maps outlive the handle: give them a stream of their own again
     if (!mp) continue;
     mp->stream = nullptr; mp->own_stream = false;
@@ -915,7 +880,6 @@ int liodom_set_laser_to_base(liodom_handle_t* h, const double* T) {
   if (!h || !T) return LIODOM_ERR_INVALID_ARG;
   SideLocks lk(h, true, true);
   for (int k = 0; k < 12; k++) h->v.laser_to_base[k] = T[k];      // kernels take the view by value
-  drop_graphs(h);                                                   // (captured launches carry the old view)
   return LIODOM_OK;
 }
 
@@ -1361,11 +1325,11 @@ int liodom_get_modes(liodom_handle_t* h, char* buf, int cap) {
   if (!h || !buf || cap < 2) return LIODOM_ERR_INVALID_ARG;
   const DevView& v = h->v;
   snprintf(buf, (size_t)cap,
-           "n_streams=%d early_rebuild=%d hash_build=%s pipe_flags=%d flag_gate=%d graph=%d lm_groups=%d knn_instance=%d knn_queries=%d "
+           "n_streams=%d early_rebuild=%d hash_build=%s pipe_flags=%d flag_gate=%d lm_groups=%d knn_instance=%d knn_queries=%d "
            "knn_grid=%d/%d knn_partials=%d knn_saved_bound=%d knn_exact_only=%d line_gate_kernel=%d filter_local_map=%d mapping=%d "
            "rotation_mode=%d table_size=%d rebuild_delta=%.3f debug=%d",
            h->S, v.early_rebuild, v.early_rebuild ? "streamed" : (h->lds_hash_build ? "lds" : "global"), h->use_flags ? 1 : 0,
-           (h->use_flags && h->flag_gate) ? 1 : 0, h->use_graph ? 1 : 0, v.lm_groups, h->S >= 16 ? 128 : 256, v.knn_queries, v.knn_grid,
+           (h->use_flags && h->flag_gate) ? 1 : 0, v.lm_groups, h->S >= 16 ? 128 : 256, v.knn_queries, v.knn_grid,
            v.knn_blocks, v.knn_partials, v.knn_save_pos ? 2 : (v.knn_save_q ? 1 : 0), v.knn_exact_only, v.knn_nn ? 1 : 0, v.filter_local_map, v.mapping,
            v.rotation_mode, v.table_size, (double)v.rebuild_delta, v.debug);
   return LIODOM_OK;

@@ -614,32 +614,6 @@ def test_extract_region_counts(orc, synth, R, epr):
     g.close()
 
 
-def test_graph_replay_equals_eager(orc, synth, monkeypatch):
-    """LIODOM_GRAPH=1: the odometry chain replayed from a captured hipGraph (one per edge buffer) gives the
-    bits of the eager launches — per-scan synchronous and pipelined resident replay."""
-    H, W, R, epr, P, K = 16, 900, 6, 10, 5, 12
-    cfg = synth.make_cfg(H, W, 0)
-    scans = [synth.scan(cfg, 5, k)[0] for k in range(K)]
-    res = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("LIODOM_GRAPH", mode)
-        po, g = mk(orc, H, W, 0, R, epr, P, pose_log_capacity=64)
-        g.alloc_resident(K)
-        for k in range(K):
-            g.upload_scan(0, k, scans[k])
-        poses = []
-        for k in range(K):
-            p, info = g.process_resident(k, H * W, H, W, readback=True, next_slot=(k + 1 if k + 1 < K else -1))
-            assert info[0].status == 0
-            poses.append(p[0].copy())
-        g.reset()
-        for k in range(K):
-            poses.append(g.process_scan(scans[k], H, W)[0])
-        res[mode] = np.array(poses)
-        g.close()
-    assert np.array_equal(res["0"].view(np.uint64), res["1"].view(np.uint64))
-
-
 def test_knn_fast_path_equals_exact_list_path(orc, synth, monkeypatch):
     """k_knn keeps two candidates per lane and pops the five nearest from them; a query whose result that cannot
     certify (three of its nearest in one lane, or equal distances that FLANN orders by index) repeats the stream
