@@ -552,7 +552,8 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   v.debug = config->debug_buffers & 1;
   // in-kernel phase timestamps (tools/gpu_debug.py clocks): they change no result.  The result-changing ablation bits
   // of earlier rounds (LIODOM_ABLATE) are gone from the product build.
-  if (const char* e = getenv("LIODOM_DEBUG_CLOCKS")) { if (atoi(e) != 0) v.debug |= 32 | (atoi(e) & 64) | ((atoi(e) >> 8) << 8); }   // 1: stamps, 65: + histograms (shared-counter atomics: they perturb the timing)
+  // instrumented builds only (-DLIODOM_INSTRUMENT, tools/variant_build.sh): 1: stamps, 65: + histograms (shared-counter atomics: they perturb the timing)
+  if (kInstrument) { if (const char* e = getenv("LIODOM_DEBUG_CLOCKS")) { if (atoi(e) != 0) v.debug |= 32 | (atoi(e) & 64) | ((atoi(e) >> 8) << 8); } }
   v.ring_id_stride = (size_t)round_up(config->max_points + 512, 256);
 
   const size_t S = (size_t)h->S;
@@ -1301,6 +1302,7 @@ int liodom_reset_kernel_stats(liodom_handle_t* h) {
 /* debug: raw phase timestamps (100 MHz) written by the kernels when LIODOM_DEBUG_CLOCKS is set */
 int liodom_debug_clocks(liodom_handle_t* h, unsigned long long* out512) {
   if (!h || !out512) return LIODOM_ERR_INVALID_ARG;
+  if (!kInstrument) { g_last_error = "liodom_debug_clocks: the product library carries no instrumentation; build a variant with -DLIODOM_INSTRUMENT (tools/variant_build.sh)"; return LIODOM_ERR_UNSUPPORTED; }
   SideLocks lk(h, true, true);
   HIP_TRY(hipStreamSynchronize(h->stream_x));
   HIP_TRY(hipStreamSynchronize(h->stream));

@@ -202,9 +202,16 @@ __device__ __forceinline__ bool filter_active(const DevView& v, const StreamStat
 
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
-// debug-only phase stamps: kernel slot k, stamp index i (constant 100 MHz wall clock)
-#define DBG_STAMP(v, cond, k, i) do { if (((v).debug & 32) && (cond)) (v).dbg_clk[(k) * 32 + (i)] = wall_clock64(); } while (0)
-#define DBG_QSTAMP(i) do { if ((v.debug & 32) && s == 0 && hl == 0 && e < E) v.dbg_q[((size_t)outer_it * v.edge_cap + e) * 12 + (i)] = (unsigned int)(wall_clock64() - t_blk); } while (0)
+// In-kernel instrumentation (phase timestamps, per-query times, histograms; tools/gpu_debug.py) exists only in builds with
+// -DLIODOM_INSTRUMENT (tools/variant_build.sh): the product library carries none of it — no debug branches in the hot kernels.
+#if defined(LIODOM_INSTRUMENT)
+constexpr bool kInstrument = true;
+#else
+constexpr bool kInstrument = false;
+#endif
+// phase stamps: kernel slot k, stamp index i (constant 100 MHz wall clock)
+#define DBG_STAMP(v, cond, k, i) do { if (kInstrument && ((v).debug & 32) && (cond)) (v).dbg_clk[(k) * 32 + (i)] = wall_clock64(); } while (0)
+#define DBG_QSTAMP(i) do { if (kInstrument && (kInstrument && (v.debug & 32)) && s == 0 && hl == 0 && e < E) v.dbg_q[((size_t)outer_it * v.edge_cap + e) * 12 + (i)] = (unsigned int)(wall_clock64() - t_blk); } while (0)
 
 // XCD-aware workgroup placement for lock-step launches (grid = blocks x streams).  Workgroups are dispatched
 // round-robin over the 8 XCDs by linear id, and each XCD has its own 4 MB L2: with the natural mapping every
@@ -864,7 +871,7 @@ __global__ __launch_bounds__(kMaxThreads) void k_ring_extract(DevView v, int s0)
   const int H = v.scan_lines;
   int* nedges_out = v.ring_nedges + (size_t)s * H + ring;
   int* npoints_out = v.ring_npoints + (size_t)s * H + ring;
-  const unsigned long long t_begin = (v.debug & 32) ? wall_clock64() : 0ull;
+  const unsigned long long t_begin = (kInstrument && (v.debug & 32)) ? wall_clock64() : 0ull;
   const bool dbgb = (ring == (((v.debug >> 8) & 0xFF) ? ((v.debug >> 8) & 0xFF) : 40) % H) && (s == 0) && (tid == 0);
   DBG_STAMP(v, dbgb, 0, 0);
   int dbg_rounds = 0;
@@ -934,7 +941,7 @@ __global__ __launch_bounds__(kMaxThreads) void k_ring_extract(DevView v, int s0)
     *nedges_out = total_picks;
   }
   DBG_STAMP(v, dbgb, 0, 7);
-  if ((v.debug & 32) && s == 0 && tid == 0 && ring < 64) { v.dbg_clk[128 + ring] = wall_clock64() - t_begin; v.dbg_clk[96 + (ring & 31)] = (unsigned long long)dbg_rounds | ((unsigned long long)*nedges_out << 8); }
+  if ((kInstrument && (v.debug & 32)) && s == 0 && tid == 0 && ring < 64) { v.dbg_clk[128 + ring] = wall_clock64() - t_begin; v.dbg_clk[96 + (ring & 31)] = (unsigned long long)dbg_rounds | ((unsigned long long)*nedges_out << 8); }
 }
 
 // =============================================================================================
@@ -1333,7 +1340,7 @@ __device__ __forceinline__ void knn_block(const DevView& v, int s, StreamState& 
   const int hl = threadIdx.x & (kKnnGroup - 1);
   const int half_shift = (threadIdx.x & 32);     // 0 or 32: which half of the wave
   const bool dbgb = (bv == 5) && (s == 0) && (threadIdx.x == 0) && (outer_it == 0);
-  const unsigned long long t_blk = (v.debug & 32) ? wall_clock64() : 0ull;
+  const unsigned long long t_blk = (kInstrument && (v.debug & 32)) ? wall_clock64() : 0ull;
   DBG_STAMP(v, dbgb, 1, 0);
   bool active = e < E;
   float qx = 0.f, qy = 0.f, qz = 0.f;
@@ -1399,7 +1406,7 @@ __device__ __forceinline__ void knn_block(const DevView& v, int s, StreamState& 
         }
       }
     }
-    if ((v.debug & 64) && hl == 0 && outer_it == 1) atomicAdd(&v.dbg_clk[259 + (reranked ? 0 : 1)], 1ull);
+    if ((kInstrument && (v.debug & 64)) && hl == 0 && outer_it == 1) atomicAdd(&v.dbg_clk[259 + (reranked ? 0 : 1)], 1ull);
     if (!reranked) {
     // One segment of candidates per lane: the query's cell and its 26 neighbours (lanes 0..26; the own cell is lane 13),
     // and on lane 27 the overflow list of the streamed rebuild (points of the newest frame that moved out of their
@@ -1473,9 +1480,9 @@ __device__ __forceinline__ void knn_block(const DevView& v, int s, StreamState& 
     bool dbg_two_phase = false;
     {
       const bool now = pend && (have_b ? !(lb > B) : (hl == 13 || hl == 27 || lb <= Tune::kNearSq));
-      if (v.debug & 32) dbg_n = __shfl(half_incl_scan_i32(now ? (int)cnt : 0), kKnnGroup - 1, kKnnGroup);
+      if (kInstrument && (v.debug & 32)) dbg_n = __shfl(half_incl_scan_i32(now ? (int)cnt : 0), kKnnGroup - 1, kKnnGroup);
       knn_stream_cells<Best2Acc, Tune::kLoadsBig, Tune::kLoadsFlat, Tune::kBigCell, Tune::kCursor>(b2, sp, sh.incl[grp], sh.adj[grp], start, now ? cnt : 0u, hl, qx, qy, qz,
-                                                                                     ((v.debug & 32) && s == 0 && e < E) ? v.dbg_q + ((size_t)outer_it * v.edge_cap + e) * 12 + 8 : nullptr);
+                                                                                     ((kInstrument && (v.debug & 32)) && s == 0 && e < E) ? v.dbg_q + ((size_t)outer_it * v.edge_cap + e) * 12 + 8 : nullptr);
       pend = pend && !now;
     }
     DBG_STAMP(v, dbgb, 1, 3); DBG_QSTAMP(3);
@@ -1483,7 +1490,7 @@ __device__ __forceinline__ void knn_block(const DevView& v, int s, StreamState& 
       B = best2_bound(b2, half_shift);
       pend = pend && !(lb > B);
       if ((__ballot(pend) >> half_shift) & 0xFFFFFFFFull) {
-        if (v.debug & 32) { dbg_n += __shfl(half_incl_scan_i32(pend ? (int)cnt : 0), kKnnGroup - 1, kKnnGroup); dbg_two_phase = true; }
+        if (kInstrument && (v.debug & 32)) { dbg_n += __shfl(half_incl_scan_i32(pend ? (int)cnt : 0), kKnnGroup - 1, kKnnGroup); dbg_two_phase = true; }
         knn_stream_cells<Best2Acc, Tune::kLoadsBig, Tune::kLoadsFlat, Tune::kBigCell, Tune::kCursor>(b2, sp, sh.incl[grp], sh.adj[grp], start, pend ? cnt : 0u, hl, qx, qy, qz);
       }
     } else {
@@ -1491,8 +1498,8 @@ __device__ __forceinline__ void knn_block(const DevView& v, int s, StreamState& 
     }
     DBG_STAMP(v, dbgb, 1, 4); DBG_QSTAMP(4);
     const bool certain = best2_select(b2, hl, half_shift, d5, pos5) && !v.knn_exact_only;
-    if ((v.debug & 32) && s == 0 && e < E && hl == 0) v.dbg_q[((size_t)outer_it * v.edge_cap + e) * 12] = (unsigned int)dbg_n | (dbg_two_phase ? 0x40000000u : 0u) | (certain ? 0u : 0x80000000u);
-    if ((v.debug & 64) && hl == 0) {       // (debug) fast-path results / exact-list repeats / queries with a second phase; candidates streamed
+    if ((kInstrument && (v.debug & 32)) && s == 0 && e < E && hl == 0) v.dbg_q[((size_t)outer_it * v.edge_cap + e) * 12] = (unsigned int)dbg_n | (dbg_two_phase ? 0x40000000u : 0u) | (certain ? 0u : 0x80000000u);
+    if ((kInstrument && (v.debug & 64)) && hl == 0) {       // (debug) fast-path results / exact-list repeats / queries with a second phase; candidates streamed
       atomicAdd(&v.dbg_clk[256 + (certain ? 0 : 1)], 1ull);
       if (dbg_two_phase) atomicAdd(&v.dbg_clk[258], 1ull);
       atomicAdd(&v.dbg_clk[384 + (dbg_n / 64 < 63 ? dbg_n / 64 : 63)], 1ull);
@@ -1537,7 +1544,7 @@ __device__ __forceinline__ void knn_block(const DevView& v, int s, StreamState& 
       v.knn_save_pos[((size_t)s * v.edge_cap + e) * kKnnGroup + hl] = make_int2(b2.p1, b2.p2);
       if (hl == 0) v.knn_save_g[(size_t)s * v.edge_cap + e] = guard < 3.0e38f ? guard : 3.0e38f;
     }
-    if ((v.debug & 64) && s == 0 && hl == 0) {
+    if ((kInstrument && (v.debug & 64)) && s == 0 && hl == 0) {
       const int bin = (int)((wall_clock64() - t_blk) / 100ull);
       atomicAdd(&v.dbg_clk[320 + (bin < 63 ? bin : 63)], 1ull);
       const int nb = dbg_n < 64 ? 0 : dbg_n < 128 ? 1 : dbg_n < 256 ? 2 : dbg_n < 512 ? 3 : dbg_n < 1024 ? 4 : 5;
@@ -1661,7 +1668,7 @@ __device__ __forceinline__ void knn_block(const DevView& v, int s, StreamState& 
     v.knn_part[(((size_t)s * 2 + outer_it) * v.knn_blocks + bv) * 32 + threadIdx.x] = x;
   }
   DBG_STAMP(v, dbgb, 1, 7); DBG_QSTAMP(7);
-  if ((v.debug & 64) && s == 0 && threadIdx.x == 0) {      // histogram of workgroup durations, 1 us bins
+  if ((kInstrument && (v.debug & 64)) && s == 0 && threadIdx.x == 0) {      // histogram of workgroup durations, 1 us bins
     const unsigned long long d = wall_clock64() - t_blk;
     const int bin = (int)(d / 100ull);
     atomicAdd(&v.dbg_clk[192 + (bin < 63 ? bin : 63)], 1ull);
@@ -2296,7 +2303,7 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
   }
   if (clr_pending) clear_hash_slots();                   // (the solve ended at its first step)
   DBG_STAMP(v, dbgb, 2, 20);
-  if ((v.debug & 32) && dbgb) v.dbg_clk[2 * 32 + 27] = (xch_local ? 100ull : 0ull) + 10ull * xcc_id() + (unsigned long long)n_eval;   // (debug) exchange transport, XCC, evaluations
+  if ((kInstrument && (v.debug & 32)) && dbgb) v.dbg_clk[2 * 32 + 27] = (xch_local ? 100ull : 0ull) + 10ull * xcc_id() + (unsigned long long)n_eval;   // (debug) exchange transport, XCC, evaluations
   if (g != 0) return;        // every workgroup reached the same result; workgroup 0 records it
   if (tid == kLmCtl) {
     for (int k = 0; k < 4; k++) st.param_q[k] = lm.q[k];
