@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -47,6 +48,8 @@ struct EventPair { hipEvent_t a, b; int kid; };
 
 #include "liodom_map_host.h"
 
+std::atomic<int> g_live_handles{0};      // handles alive in this process (the overlapped second kNN pass is for a GPU one handle has to itself)
+
 struct liodom_handle {
   liodom_params_t params;
   liodom_config_t config;
@@ -60,6 +63,13 @@ struct liodom_handle {
   // (mx_x only) and liodom_odometry_step (mx_o only) can therefore run concurrently from two threads.
   std::mutex mx_x, mx_o;
   hipStream_t stream = nullptr;      // odometry side
+  hipStream_t stream_k = nullptr;    // overlapped second kNN pass of a scan (liodom_kernels.h "Overlapped second kNN pass"): beside the first solve
+  bool counted_live = false;         // this handle is part of g_live_handles
+  bool ov_ok = false;                // the handle qualifies for it (one stream, streamed rebuild, the pass leaves 2/3 of the wave slots free)
+  unsigned int ov_seq = 0;           // launch sequence number its flags carry
+  hipEvent_t ev_ov = nullptr;        // recorded on the odometry stream in front of the first overlapped scan after scans that were not
+  bool ov_prev = false;              // the previous scan of this handle was overlapped
+  int ov_warm = 0;                   // scans enqueued so far, up to kOvWarmScans (the first ones run every kernel of the chain for the first time)
   hipStream_t stream_x = nullptr;    // extraction side (liodom_extract_edges, and the next scan's extraction in the pipelined replay)
   hipStream_t stream_c = nullptr;    // host-fed replay: uploads (a copy engine works beside the extraction kernels of the previous scan)
   hipEvent_t ev_up[3] = {nullptr, nullptr, nullptr};      // staging slot uploaded
@@ -86,7 +96,7 @@ struct liodom_handle {
   std::vector<int> scans_enqueued;   // per stream: scans launched so far (expected HostOut.seq)
   std::vector<void*> allocs;
   // profiling
-  bool profiling = false;
+  std::atomic<bool> profiling{false};   // read without a lock by SideLocks / extract_queue, written under both mutexes
   std::vector<liodom_map*> mappers;   // per stream: attached device map (mapping replay) or null
   std::vector<int> mapper_cells_xy, mapper_cells_z;
   bool lds_hash_build = false;  // k_hash_build (one workgroup per stream, LDS) instead of the 3 global-atomic kernels
@@ -220,15 +230,42 @@ int enqueue_odometry(liodom_handle* h, int eb, int s0, int count, unsigned int w
   const int map_blocks = cdiv(h->v.map_cap, 256);
   const bool early = v.early_rebuild != 0;
   const int nC = cdiv(h->v.edge_cap * std::max(1, h->P - 1), kLmThreads), nP = cdiv(h->v.edge_cap, kLmThreads);
+  // Overlapped second kNN pass (liodom_kernels.h): the pass goes to stream_k behind the first solve's launch and waits inside
+  // the kernel; it needs kernels of different streams to run side by side (as the flags of the pipelined replay do) and the
+  // GPU mostly to itself: not while a second handle lives in this process (its waiting workgroups and ours could end up
+  // behind each other in a shared hardware queue), not under per-kernel profiling.
+  const bool overlap_ok = early && h->ov_ok && h->use_flags && !h->profiling && count == 1 && g_live_handles.load() <= 1;
+  // The first scans of a handle are not overlapped: their launches are the first of every kernel of the chain on this queue
+  // (scratch set-up, code upload), which can hold the odometry stream back for longer than a waiting kernel is willing to
+  // poll.  At a switch to overlapped scans stream_k waits (event) for the odometry stream to have drained, so that its
+  // first polling launch cannot start before everything it depends on has run once.
+  constexpr int kOvWarmScans = 2;
+  const bool overlap = overlap_ok && h->ov_warm >= kOvWarmScans;
+  if (h->ov_warm < kOvWarmScans) h->ov_warm++;
+  unsigned int seq_k = 0u;                           // (0 means "not overlapped" to the kernels)
+  if (overlap) {
+    if (++h->ov_seq == 0u) h->ov_seq = 1u;
+    seq_k = h->ov_seq;
+    if (!h->ov_prev) {
+      HIP_TRY(hipEventRecord(h->ev_ov, h->stream));
+      HIP_TRY(hipStreamWaitEvent(h->stream_k, h->ev_ov, 0));
+    }
+  }
+  h->ov_prev = overlap;
   for (int it = 0; it < 2; it++) {
     {
       ProfScope ps(h, KID_KNN);
-      const int kx = v.knn_grid + ((early && it == 1) ? kRebuildAuxBlocks : 0);     // it 1: + ALLOC
+      const int kx = v.knn_grid + ((early && it == 1 && !seq_k) ? kRebuildAuxBlocks : 0);     // it 1: + ALLOC (overlapped pass: k_rebuild_alloc below)
       if (knn_small) {
-        hipLaunchKernelGGL(k_knn<128>, dim3(kx, count), dim3(128), 0, h->stream, v, s0, it, eb, wait_edges, signal_odo);
+        hipLaunchKernelGGL(k_knn<128>, dim3(kx, count), dim3(128), 0, h->stream, v, s0, it, eb, wait_edges, signal_odo, 0u);
         if (v.knn_nn) hipLaunchKernelGGL(k_line_gate, dim3(cdiv(h->v.knn_blocks * h->v.knn_queries, 256), count), dim3(256), 0, h->stream, v, s0, it, eb);
+      } else if (it == 1 && seq_k) {
+        hipLaunchKernelGGL(k_ov_gate, dim3(1), dim3(64), 0, h->stream_k, v, s0, seq_k);
+        hipLaunchKernelGGL((k_knn<256, true>), dim3(kx, count), dim3(256), 0, h->stream_k, v, s0, it, eb, 0u, 0u, seq_k);
+        // ALLOC between the two solve launches, beside the pass's tail
+        hipLaunchKernelGGL(k_rebuild_alloc, dim3(kRebuildAllocBlocks, count), dim3(256), 0, h->stream, v, s0);
       } else {
-        hipLaunchKernelGGL(k_knn<256>, dim3(kx, count), dim3(256), 0, h->stream, v, s0, it, eb, wait_edges, signal_odo);
+        hipLaunchKernelGGL(k_knn<256>, dim3(kx, count), dim3(256), 0, h->stream, v, s0, it, eb, wait_edges, signal_odo, 0u);
       }
     }
     {
@@ -236,7 +273,7 @@ int enqueue_odometry(liodom_handle* h, int eb, int s0, int count, unsigned int w
       // it 0: + COUNT, PAD; it 1: + APPEND, CLEAR, SCATTER
       const int extra = !early ? 0 : (it == 0 ? nC + nP : nP + kRebuildAuxBlocks + nC);
       const int gx = std::max(h->v.lm_groups + extra, (h->v.lm_groups - 1) * 8 + 1);      // solvers on blocks 0, 8, 16, ... (one XCD)
-      hipLaunchKernelGGL(k_lm_solve, dim3(gx, count), dim3(kLmThreads), lm_lds_bytes(h->v.edge_cap), h->stream, v, s0, it, eb);
+      hipLaunchKernelGGL(k_lm_solve, dim3(gx, count), dim3(kLmThreads), lm_lds_bytes(h->v.edge_cap), h->stream, v, s0, it, eb, seq_k);
     }
   }
   if (v.mapping) {
@@ -465,7 +502,10 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   const bool use_prio = std::getenv("LIODOM_NO_STREAM_PRIORITY") == nullptr && prio_least != prio_greatest;
   if ((use_prio ? hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_greatest)
                 : hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) { g_last_error = "hipStreamCreate failed"; return fail(LIODOM_ERR_HIP); }
+  if (hipEventCreateWithFlags(&h->ev_ov, hipEventDisableTiming) != hipSuccess) { g_last_error = "hipEventCreate failed"; return fail(LIODOM_ERR_HIP); }
   if (hipEventCreateWithFlags(&h->pose_event, hipEventDisableTiming) != hipSuccess) { g_last_error = "hipEventCreate failed"; return fail(LIODOM_ERR_HIP); }
+  if ((use_prio ? hipStreamCreateWithPriority(&h->stream_k, hipStreamNonBlocking, prio_greatest)
+                : hipStreamCreateWithFlags(&h->stream_k, hipStreamNonBlocking)) != hipSuccess) { g_last_error = "hipStreamCreate failed"; return fail(LIODOM_ERR_HIP); }
   // (extraction: one level below the odometry stream, not the lowest: kernels of the odometry stream may wait in-kernel for it)
   const int prio_x = (prio_least - prio_greatest >= 2) ? prio_greatest + 1 : prio_least;
   if ((use_prio ? hipStreamCreateWithPriority(&h->stream_x, hipStreamNonBlocking, prio_x)
@@ -553,7 +593,7 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   // in-kernel phase timestamps (tools/gpu_debug.py clocks): they change no result.  The result-changing ablation bits
   // of earlier rounds (LIODOM_ABLATE) are gone from the product build.
   // instrumented builds only (-DLIODOM_INSTRUMENT, tools/variant_build.sh): 1: stamps, 65: + histograms (shared-counter atomics: they perturb the timing)
-  if (kInstrument) { if (const char* e = getenv("LIODOM_DEBUG_CLOCKS")) { if (atoi(e) != 0) v.debug |= 32 | (atoi(e) & 64) | ((atoi(e) >> 8) << 8); } }
+  if (kInstrument) { if (const char* e = getenv("LIODOM_DEBUG_CLOCKS")) { if (atoi(e) != 0) v.debug |= ((atoi(e) & 128) ? (atoi(e) & 32) : 32) | (atoi(e) & (64 | 128)) | ((atoi(e) >> 8) << 8); } }
   v.ring_id_stride = (size_t)round_up(config->max_points + 512, 256);
 
   const size_t S = (size_t)h->S;
@@ -635,6 +675,9 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   }
   if (const char* e = std::getenv("LIODOM_KNN_EXACT_ONLY")) v.knn_exact_only = std::atoi(e) != 0 ? 1 : 0;
   ALLOC(v.knn_part, S * 2 * (size_t)v.knn_blocks * 32, 0);
+  ALLOC(v.ov_flags, S, 0);
+  ALLOC(v.pose_xch0, S * (size_t)kOvReplicas * 512, 0);
+  ALLOC(v.knn_done, S * (size_t)v.knn_grid, 0);
   ALLOC(v.corr_mask, S * 2 * (size_t)v.knn_blocks, 0);
   {
     void* hp = nullptr;
@@ -671,10 +714,21 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
       g_last_error = "hipFuncSetAttribute(max dynamic LDS) failed"; return fail(LIODOM_ERR_HIP);
     }
   }
+  {
+    // Overlapped second kNN pass: its workgroups wait inside the kernel for the first solve, so they must leave most of the GPU
+    // to the launches they wait for (and to the next scan's extraction): one stream, at most a third of the wave slots
+    // (HDL-64: 352 workgroups x 4 waves = 1 408 of 6 144).  LIODOM_KNN_OVERLAP=0 keeps the pass on the odometry stream.
+    int cus = 0;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, config->device);
+    h->ov_ok = v.early_rebuild && S == 1 && v.knn_partials && (long long)v.knn_grid * 4 * 3 <= (long long)cus * 24;
+    if (const char* e = std::getenv("LIODOM_KNN_OVERLAP")) { if (std::atoi(e) == 0) h->ov_ok = false; }
+  }
   ALLOC(h->d_view, 1, 0);
   if (hipMemcpy(h->d_view, &h->v, sizeof(DevView), hipMemcpyHostToDevice) != hipSuccess) { g_last_error = "DevView upload failed"; return fail(LIODOM_ERR_HIP); }
   rc = reset_state(h);
   if (rc != LIODOM_OK) return fail(rc);
+  g_live_handles.fetch_add(1);
+  h->counted_live = true;
   *out = h;
   return LIODOM_OK;
 #undef ALLOC
@@ -682,8 +736,11 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
 
 void liodom_destroy(liodom_handle_t* h) {
   if (!h) return;
+  if (h->counted_live) g_live_handles.fetch_sub(1);
   if (h->stream_x) hipStreamSynchronize(h->stream_x);
   if (h->stream) hipStreamSynchronize(h->stream);
+  if (h->stream_k) { hipStreamSynchronize(h->stream_k); hipStreamDestroy(h->stream_k); }
+  if (h->ev_ov) hipEventDestroy(h->ev_ov);
   for (liodom_map* mp : h->mappers) {          // attached maps outlive the handle: give them a stream of their own again
     if (!mp) continue;
     mp->stream = nullptr; mp->own_stream = false;
@@ -784,6 +841,7 @@ static int wait_pose(liodom_handle_t* h, int s0, int count, double* pose_out, li
     // skipped the scan, the published pose is the prediction.  Fail loudly and stop relying on co-scheduled streams.
     (void)hipStreamSynchronize(h->stream_x);
     (void)hipStreamSynchronize(h->stream);
+    (void)hipStreamSynchronize(h->stream_k);
     h->use_flags = false;
     h->pf_slot = -1;
     for (int b = 0; b < kEdgePipeBufs; b++) { h->ev_free_valid[b] = false; h->eb_reader[b] = 0; }
@@ -879,6 +937,7 @@ int liodom_set_imu_orientation(liodom_handle_t* h, int stream, const double* q_x
 
 int liodom_set_laser_to_base(liodom_handle_t* h, const double* T) {
   if (!h || !T) return LIODOM_ERR_INVALID_ARG;
+  if (int rc = enter(h)) return rc;
   SideLocks lk(h, true, true);
   for (int k = 0; k < 12; k++) h->v.laser_to_base[k] = T[k];      // kernels take the view by value
   return LIODOM_OK;
@@ -1303,6 +1362,7 @@ int liodom_reset_kernel_stats(liodom_handle_t* h) {
 int liodom_debug_clocks(liodom_handle_t* h, unsigned long long* out512) {
   if (!h || !out512) return LIODOM_ERR_INVALID_ARG;
   if (!kInstrument) { g_last_error = "liodom_debug_clocks: the product library carries no instrumentation; build a variant with -DLIODOM_INSTRUMENT (tools/variant_build.sh)"; return LIODOM_ERR_UNSUPPORTED; }
+  if (int rc = enter(h)) return rc;
   SideLocks lk(h, true, true);
   HIP_TRY(hipStreamSynchronize(h->stream_x));
   HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1316,6 +1376,7 @@ int liodom_debug_knn_times(liodom_handle_t* h, unsigned int* out, int* cap) {
   *cap = h->v.edge_cap;
   if (!out) return LIODOM_OK;
   if (!h->v.dbg_q) return LIODOM_ERR_UNSUPPORTED;
+  if (int rc = enter(h)) return rc;
   SideLocks lk(h, true, true);
   HIP_TRY(hipStreamSynchronize(h->stream_x));
   HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1329,11 +1390,12 @@ int liodom_get_modes(liodom_handle_t* h, char* buf, int cap) {
   snprintf(buf, (size_t)cap,
            "n_streams=%d early_rebuild=%d hash_build=%s pipe_flags=%d flag_gate=%d lm_groups=%d knn_instance=%d knn_queries=%d "
            "knn_grid=%d/%d knn_partials=%d knn_saved_bound=%d knn_exact_only=%d line_gate_kernel=%d filter_local_map=%d mapping=%d "
-           "rotation_mode=%d table_size=%d rebuild_delta=%.3f debug=%d",
+           "rotation_mode=%d table_size=%d rebuild_delta=%.3f knn_overlap=%d debug=%d",
            h->S, v.early_rebuild, v.early_rebuild ? "streamed" : (h->lds_hash_build ? "lds" : "global"), h->use_flags ? 1 : 0,
            (h->use_flags && h->flag_gate) ? 1 : 0, v.lm_groups, h->S >= 16 ? 128 : 256, v.knn_queries, v.knn_grid,
            v.knn_blocks, v.knn_partials, v.knn_save_pos ? 2 : (v.knn_save_q ? 1 : 0), v.knn_exact_only, v.knn_nn ? 1 : 0, v.filter_local_map, v.mapping,
-           v.rotation_mode, v.table_size, (double)v.rebuild_delta, v.debug);
+           v.rotation_mode, v.table_size, (double)v.rebuild_delta,
+           (v.early_rebuild && h->ov_ok && h->use_flags && g_live_handles.load() <= 1) ? 1 : 0, v.debug);
   return LIODOM_OK;
 }
 

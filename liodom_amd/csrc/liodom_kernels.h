@@ -49,6 +49,8 @@ constexpr int kMaxFrames = 256;          // window frames supported by the LDS p
 constexpr int kEdgeBufs = 4;             // dense edge buffers: 0 / 1 / 2 odometry side (pipelined replay), 3 extraction side
 constexpr int kEdgePipeBufs = 3;
 constexpr int kEdgeBufX = 3;
+constexpr int kOvReplicas = 8;           // copies of the first solve's result, 4 KiB apart, for the polling k_knn workgroups
+constexpr int kOvGranules = 38;          // 19 doubles as {tag, 32 bits} granules
 
 // Per-stream device state.
 struct StreamState {
@@ -79,7 +81,10 @@ struct StreamState {
   int32_t vox_divb[3];
   int32_t n_recv;         // points of the received ~map cloud (mapping mode, SharedData::setLocalMap)
   int32_t n_ovf[2];       // early_rebuild: new-frame points kept in the overflow list of table 0 / 1 (sorted_pts[ovf_base ...])
-  double pred_odom[12];   // early_rebuild: the prediction the scan started from (st.odom moves on with the solves)
+  int32_t reb_initialized; // early_rebuild: `initialized` as of the scan's first kNN pass (the finalising solve sets it beside the builders)
+  int32_t reb_pad;
+  double pred_odom[12];   // early_rebuild: the prediction the scan started from, snapshot taken by the scan's first kNN launch: st.odom moves
+                          // on with the solves, and the finalising solve writes the NEXT scan's prediction while builders of this scan still run
   liodom_step_info_t info;
 };
 
@@ -191,6 +196,11 @@ struct DevView {
   int knn_exact_only;       // (test switch) every kNN query takes the exact list path instead of the Best2 fast path: same results
   int knn_blocks;           // k_knn workgroups per stream = ceil(edge_cap / knn_queries), rounded up to a multiple of 4
   unsigned long long* lm_xch;   // [S][2][kLmGroupsMax][64] tagged granules: partial sums exchanged between the LM workgroups
+  // Overlapped second kNN pass (handles with one stream, early_rebuild, flags; "Overlapped second kNN pass" below): the pass is
+  // launched on its own HIP stream beside the scan's first solve and waits inside the kernel; tags = the launch sequence number.
+  unsigned int* ov_flags;          // [S] sequence number of the latest scan whose first solve launch has started (its first kNN pass has completed)
+  unsigned long long* pose_xch0;   // [S][kOvReplicas][512] the first solve's result (odom[12], q[4], t[3]) as 38 tagged granules, replicated over memory channels
+  unsigned int* knn_done;          // [S][knn_grid] sequence number of the latest overlapped second pass workgroup b has completed
   unsigned long long* dbg_clk;  // [16][32] phase timestamps (100 MHz) and counters, debug bit 5 only
   unsigned int* dbg_q;          // [2][edge_cap][8] per-query phase times of stream 0's latest scan (10 ns ticks since the workgroup's start), debug bit 5 only
 };
@@ -211,6 +221,8 @@ constexpr bool kInstrument = false;
 #endif
 // phase stamps: kernel slot k, stamp index i (constant 100 MHz wall clock)
 #define DBG_STAMP(v, cond, k, i) do { if (kInstrument && ((v).debug & 32) && (cond)) (v).dbg_clk[(k) * 32 + (i)] = wall_clock64(); } while (0)
+// stamps of the overlapped second kNN pass (debug bit 7; entries 448.. of dbg_clk, shared with a bit-6 histogram)
+#define OV_STAMP(v, cond, i) do { if (kInstrument && ((v).debug & 128) && (cond)) (v).dbg_clk[448 + (i)] = wall_clock64(); } while (0)
 #define DBG_QSTAMP(i) do { if (kInstrument && (kInstrument && (v.debug & 32)) && s == 0 && hl == 0 && e < E) v.dbg_q[((size_t)outer_it * v.edge_cap + e) * 12 + (i)] = (unsigned int)(wall_clock64() - t_blk); } while (0)
 
 // XCD-aware workgroup placement for lock-step launches (grid = blocks x streams).  Workgroups are dispatched
@@ -343,6 +355,11 @@ __host__ __device__ __forceinline__ size_t ring_scatter_lds_bytes(int H) {
   return ring_scatter_stage_bytes(H) + (size_t)(2 * H + 2 * 16) * 4;
 }
 
+// staging-slot swizzles of k_ring_scatter (bijections on [0, 2048)): 16-byte elements have 16 bank groups (low 4 bits of
+// the slot), 4-byte elements 64 banks (low 6 bits); the XOR term is constant over an aligned run of 32 / 64 slots
+__device__ __forceinline__ int stage_swz16(int e) { return e ^ ((e >> 5) & 15); }
+__device__ __forceinline__ int stage_swz4(int e) { return e ^ ((e >> 6) & 63); }
+
 __global__ __launch_bounds__(kTileThreads) void k_ring_scatter(DevView v, int s0, const float4* __restrict__ in,
                                                                size_t in_stride, int n) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -421,13 +438,18 @@ __global__ __launch_bounds__(kTileThreads) void k_ring_scatter(DevView v, int s0
     }
   }
   __syncthreads();                  // masks / prefixes are dead: their bytes become the staging tile
+  // Bank swizzle of the staging tile.  In firing order the lanes of a wave hold consecutive rings, so their staging
+  // slots lie ~32 apart (a tile holds ~32 points of each ring): unswizzled, the 64 16-byte stores of a wave land on
+  // one group of four banks (64-way conflict; the SQ counters had 38 % of this kernel's CU cycles in LDS bank
+  // conflicts, profiles/r03_n_sq.txt).  XOR-ing the low bits of the slot with the bits above them spreads slots 32
+  // apart over all banks and keeps an aligned run of consecutive slots (the read-out below) a permutation of itself.
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     if (slot[j] >= 0) {
       const int i = tile * kTilePts + j * kTileThreads + tid;
-      spts[slot[j]] = in[(size_t)blockIdx.y * in_stride + i];       // coalesced read
-      sdst[slot[j]] = dst[j];
-      ssrc[slot[j]] = i;
+      spts[stage_swz16(slot[j])] = in[(size_t)blockIdx.y * in_stride + i];       // coalesced read
+      sdst[stage_swz4(slot[j])] = dst[j];
+      ssrc[stage_swz4(slot[j])] = i;
     }
   }
   __syncthreads();
@@ -437,9 +459,9 @@ __global__ __launch_bounds__(kTileThreads) void k_ring_scatter(DevView v, int s0
   int* osrc = v.ring_src + (size_t)s * v.max_points;
   const int nvalid = wloc[0] + wloc[1] + wloc[2] + wloc[3] + wloc[4] + wloc[5] + wloc[6] + wloc[7];
   for (int p = tid; p < nvalid; p += kTileThreads) {
-    const int d = sdst[p];
-    out[d] = spts[p];
-    osrc[d] = ssrc[p];
+    const int d = sdst[stage_swz4(p)];
+    out[d] = spts[stage_swz16(p)];
+    osrc[d] = ssrc[stage_swz4(p)];
   }
 }
 
@@ -982,6 +1004,120 @@ __global__ void k_pipe_gate(DevView v, int s0, int eb, unsigned int wait_edges, 
     for (int s = (int)threadIdx.x; s < v.n_streams; s += (int)blockDim.x) atomicOr(&v.state[s].status, LIODOM_STATUS_PIPE_TIMEOUT);
   }
 }
+// =============================================================================================
+// Overlapped second kNN pass (one-stream handles with the streamed rebuild and flags).  The odometry chain of a scan is
+// kNN, solve, kNN, solve; as four launches of one HIP stream every link costs a launch boundary (~0.7 us idle), the ramp of
+// the next launch (kernel arguments, state words, first loads: ~2 us of dependent round trips) and the tail of the previous
+// one.  The second kNN pass depends on the first solve only through the 19 doubles of its result, and everything else it
+// reads — the edge, what the first pass saved for the re-ranking, the saved candidates themselves — is known when the
+// first pass has completed.  So this pass is launched on a HIP stream of its own (stream_k) right behind the first solve's
+// launch and waits INSIDE the kernel, twice:
+//   1. for ov_flags[s] == seq, stored by the first solve's launch when it starts (it follows the first kNN pass in stream
+//      order, so that pass has completed and its writes are visible) -> the workgroups load their edges and the saved
+//      candidates (two dependent round trips) while the solve runs;
+//   2. for the solve's result, published as tagged granules (the data is the flag) in kOvReplicas copies 4 KiB apart, so
+//      that the polling workgroups do not queue on one memory channel -> transform, re-rank, gate, partial sums.
+// Every workgroup of the pass then stores seq into knn_done[s][b] (after a release fence), and the finalising solve's
+// launch — which follows the first solve in stream order and therefore starts while this pass still runs — polls those
+// flags in its solving workgroups before it reads the pass's results, and in the workgroups that clear the searched table
+// before they touch it.  All waits are bounded (LIODOM_STATUS_PIPE_TIMEOUT, as pipe_wait); workgroups that wait never
+// hold more than a third of the GPU's wave slots, and a waiting workgroup depends only on launches enqueued before its own.
+// Launch order on the host: kNN(0) [stream], solve(0) [stream], kNN(1) [stream_k], solve(1) [stream].
+// =============================================================================================
+// Stores / loads that are visible across the XCDs without cache maintenance: agent-scope relaxed atomics go through the
+// XCD's L2 to the memory side.  (The alternative — plain accesses plus release / acquire fences — costs an L2 write-back or
+// invalidate per fence on a part whose eight L2s are not coherent with each other: with one per workgroup of a 352-workgroup
+// launch the solve running beside it took 80 us instead of 24.)
+__device__ __forceinline__ void wt_store_u32(void* p, unsigned int x) {
+  typedef __attribute__((address_space(1))) unsigned int gu32;
+  __hip_atomic_store((gu32*)p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void wt_store_u64(void* p, unsigned long long x) {
+  typedef __attribute__((address_space(1))) unsigned long long gu64;
+  __hip_atomic_store((gu64*)p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void wt_store_f4(float4* p, const float4& x) {
+  wt_store_u64(p, ((unsigned long long)__float_as_uint(x.y) << 32) | __float_as_uint(x.x));
+  wt_store_u64(reinterpret_cast<char*>(p) + 8, ((unsigned long long)__float_as_uint(x.w) << 32) | __float_as_uint(x.z));
+}
+__device__ __forceinline__ void wt_store_u8(void* p, unsigned char x) {
+  typedef __attribute__((address_space(1))) unsigned char gu8;
+  __hip_atomic_store((gu8*)p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned int coh_load_u32(const void* p) {
+  typedef __attribute__((address_space(1))) unsigned int gu32;
+  return __hip_atomic_load((gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the first solve's result leaves its workgroup: vals = odom[12], q[4], t[3] in LDS; threads 0 .. kOvReplicas * kOvGranules - 1
+__device__ __forceinline__ void ov_publish_pose(const DevView& v, int s, const double* vals, unsigned int tag, int tid) {
+  typedef __attribute__((address_space(1))) unsigned long long gu64;
+  if (tid >= kOvReplicas * kOvGranules) return;
+  const int rep = tid / kOvGranules, gi = tid % kOvGranules;
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(vals[gi >> 1]);
+  const unsigned int word = (gi & 1) ? (unsigned int)(bits >> 32) : (unsigned int)bits;
+  __hip_atomic_store((gu64*)(v.pose_xch0 + ((size_t)s * kOvReplicas + rep) * 512 + gi), ((unsigned long long)tag << 32) | word,
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// whole workgroup; the first wave polls replica rep until every granule carries the tag; out19: LDS.  false: gave up.
+__device__ __forceinline__ bool ov_wait_pose(const DevView& v, int s, int rep, unsigned int tag, double* out19, unsigned int* status) {
+  typedef __attribute__((address_space(1))) unsigned long long gu64;
+  __shared__ int s_ov_ok;
+  const int tid = (int)threadIdx.x;
+  if (tid < 64) {
+    const unsigned long long* base = v.pose_xch0 + ((size_t)s * kOvReplicas + rep) * 512;
+    unsigned long long g = 0;
+    unsigned int spins = 0;
+    bool ok;
+    // One lane polls the LAST granule (the publisher's lanes store in order, it usually lands last); only then do all
+    // lanes fetch theirs — and go round again if some granule is not there yet.  (All 38 lanes of 352 workgroups polling
+    // — agent-scope loads do not coalesce and do not hit in the L2 — congested the memory fabric: the solve they were
+    // waiting for took 100 us instead of 24, the next scan's k_classify 40 instead of 7.)
+    while (true) {
+      unsigned long long last = 0;
+      if (tid == 0) last = __hip_atomic_load((gu64*)(base + kOvGranules - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last = __shfl(last, 0);
+      ok = true;
+      if ((unsigned int)(last >> 32) == tag) {
+        if (tid < kOvGranules) g = __hip_atomic_load((gu64*)(base + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = tid >= kOvGranules || (unsigned int)(g >> 32) == tag;
+        if (__all(ok)) break;
+      } else {
+        ok = false;
+      }
+      if (++spins > 2000000u) break;
+      __builtin_amdgcn_s_sleep(64);
+    }
+    const bool all_ok = __all(ok);
+    const unsigned long long lo = __shfl(g, 2 * (tid % 19)), hi = __shfl(g, 2 * (tid % 19) + 1);
+    if (tid < 19) out19[tid] = __longlong_as_double((long long)((hi << 32) | (lo & 0xFFFFFFFFull)));
+    if (tid == 0) { s_ov_ok = all_ok ? 1 : 0; if (!all_ok) atomicOr(status, LIODOM_STATUS_PIPE_TIMEOUT); }
+  }
+  __syncthreads();
+  return s_ov_ok != 0;
+}
+// whole workgroup, every exit path of an overlapped k_knn workgroup: its results are visible before the flag is
+__device__ __forceinline__ void ov_signal_knn_done(const DevView& v, int s, int b, unsigned int seq) {
+  typedef __attribute__((address_space(1))) unsigned int gu32;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the pass's results are write-through stores: acknowledged = visible to every XCD)
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store((gu32*)(v.knn_done + (size_t)s * v.knn_grid + b), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// whole workgroup (finalising solve's launch): every workgroup of the overlapped second pass has completed
+__device__ __forceinline__ void ov_wait_knn_done(const DevView& v, int s, unsigned int seq, unsigned int* status) {
+  typedef __attribute__((address_space(1))) unsigned int gu32;
+  const unsigned int* f = v.knn_done + (size_t)s * v.knn_grid;
+  for (int b = (int)threadIdx.x; b < v.knn_grid; b += (int)blockDim.x) {
+    unsigned int spins = 0;
+    while ((int)(__hip_atomic_load((gu32*)(f + b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) < 0) {
+      __builtin_amdgcn_s_sleep(32);
+      if (++spins > 3000000u) { atomicOr(status, LIODOM_STATUS_PIPE_TIMEOUT); break; }
+    }
+  }
+  // (no acquire fence — an L2 invalidate per waiting workgroup: this launch started, with clean caches, before the pass wrote
+  //  any of its results, and reads none of them before this point; the pass's stores are write-through)
+  __syncthreads();
+}
+
 __global__ void k_set_flag(unsigned int* flag, unsigned int value) {
   typedef __attribute__((address_space(1))) unsigned int gu32;
   __hip_atomic_store((gu32*)flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1329,10 +1465,37 @@ __device__ __forceinline__ float best2_bound(const Best2Acc& t, int half_shift) 
   return B;
 }
 
+// What a query of the second pass re-ranks (saved by the first pass), loaded ahead of the pose by the overlapped pass.
+struct KnnPre {
+  float gsq;        // guard (0: nothing saved)
+  float4 sq;        // the first pass's query and its fifth-nearest distance
+  int2 sv;          // this lane's two saved candidates (positions in the cell-sorted array)
+  float4 m0, m1;    // ... and the points there
+};
+__device__ __forceinline__ void knn_prefetch(const DevView& v, int s, int e, int hl, const float4* sp, KnnPre& pre) {
+  const int ec = e < v.edge_cap ? e : v.edge_cap - 1;
+  pre.gsq = 0.f;
+  pre.sq = make_float4(0.f, 0.f, 0.f, __int_as_float(0x7f800000));
+  pre.sv = make_int2(-1, -1);
+  pre.m0 = pre.m1 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (v.knn_save_q) pre.sq = v.knn_save_q[(size_t)s * v.edge_cap + ec];
+  if (v.knn_save_pos && !v.knn_exact_only) {
+    pre.gsq = v.knn_save_g[(size_t)s * v.edge_cap + ec];
+    pre.sv = v.knn_save_pos[((size_t)s * v.edge_cap + ec) * kKnnGroup + hl];
+    // (all lanes load, whatever the guard says — a branch on it would be one more dependent round trip; clamped: entries of
+    //  edges beyond the scan's count are leftovers)
+    pre.m0 = sp[(pre.sv.x >= 0 && pre.sv.x < v.sorted_cap) ? pre.sv.x : 0];
+    pre.m1 = sp[(pre.sv.y >= 0 && pre.sv.y < v.sorted_cap) ? pre.sv.y : 0];
+  }
+}
+
 // One block of kKnnThreads / 32 queries (virtual block index bv).  Whole workgroup; returns are workgroup-uniform.
-template <int kKnnThreads>
+// kPre (overlapped second pass): what the re-ranking loads is in `pre` already, and the solve's start point (q, t) comes
+// from qt (LDS) — the stream's state is still being written by the first solve's launch.
+template <int kKnnThreads, bool kPre = false>
 __device__ __forceinline__ void knn_block(const DevView& v, int s, StreamState& st, int outer_it, int eb, int bv, int E,
-                                          KnnShared<kKnnThreads / kKnnGroup>& sh, const float4& p_in, const double (&T_in)[12]) {
+                                          KnnShared<kKnnThreads / kKnnGroup>& sh, const float4& p_in, const double (&T_in)[12],
+                                          const KnnPre& pre, const double* qt) {
   constexpr int kKnnQueries = kKnnThreads / kKnnGroup;
   typedef KnnTune<(kKnnThreads >= 256)> Tune;
   const int grp = threadIdx.x / kKnnGroup;
@@ -1382,11 +1545,11 @@ __device__ __forceinline__ void knn_block(const DevView& v, int s, StreamState& 
     // 1.0 gate — it is the exact answer and the query needs no probe and no stream; otherwise it searches below. ----
     bool reranked = false;
     if (outer_it == 1 && v.knn_save_pos && !v.knn_exact_only) {
-      const float gsq = v.knn_save_g[(size_t)s * v.edge_cap + e];
+      const float gsq = kPre ? pre.gsq : v.knn_save_g[(size_t)s * v.edge_cap + e];
       if (gsq > 0.f) {                                           // (uniform over the half-wave)
-        const float4 sq = v.knn_save_q[(size_t)s * v.edge_cap + e];
-        const int2 sv = v.knn_save_pos[((size_t)s * v.edge_cap + e) * kKnnGroup + hl];
-        const float4 m0 = sp[sv.x >= 0 ? sv.x : 0], m1 = sp[sv.y >= 0 ? sv.y : 0];
+        const float4 sq = kPre ? pre.sq : v.knn_save_q[(size_t)s * v.edge_cap + e];
+        const int2 sv = kPre ? pre.sv : v.knn_save_pos[((size_t)s * v.edge_cap + e) * kKnnGroup + hl];
+        const float4 m0 = kPre ? pre.m0 : sp[sv.x >= 0 ? sv.x : 0], m1 = kPre ? pre.m1 : sp[sv.y >= 0 ? sv.y : 0];
         Best2Acc br;
         br.clear();
         br.consider(sv.x >= 0, sqdist_f(qx, qy, qz, m0.x, m0.y, m0.z), 0, sv.x);
@@ -1464,7 +1627,7 @@ __device__ __forceinline__ void knn_block(const DevView& v, int s, StreamState& 
     float B = 1.0f;
     bool have_b = false;
     if (outer_it == 1 && v.knn_save_q) {
-      const float4 sq = v.knn_save_q[(size_t)s * v.edge_cap + e];
+      const float4 sq = kPre ? pre.sq : v.knn_save_q[(size_t)s * v.edge_cap + e];
       if (sq.w < 1.0f) {                                         // (uniform over the half-wave; inf / >= 1: nothing to gain)
         const float ddx = qx - sq.x, ddy = qy - sq.y, ddz = qz - sq.z;
         const float delta = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
@@ -1600,12 +1763,15 @@ __device__ __forceinline__ void knn_block(const DevView& v, int s, StreamState& 
       float4* ca = v.corr_a + (size_t)s * v.edge_cap + eq;
       float4* cb = v.corr_b + (size_t)s * v.edge_cap + eq;
       int2* cidx = v.corr_idx + ((size_t)s * 2 + outer_it) * v.edge_cap + eq;
-      if (valid) {
-        *ca = make_float4(nx[0], ny[0], nz[0], 1.0f);              // :351-353
-        *cb = make_float4(nx[1], ny[1], nz[1], 0.0f);              // :355-357
-        *cidx = make_int2(sh.res[q][1], sh.res[q][2]);
+      const float4 oa = valid ? make_float4(nx[0], ny[0], nz[0], 1.0f) : make_float4(0, 0, 0, 0);              // :351-353
+      const float4 ob = valid ? make_float4(nx[1], ny[1], nz[1], 0.0f) : make_float4(0, 0, 0, 0);              // :355-357
+      const int2 oi = valid ? make_int2(sh.res[q][1], sh.res[q][2]) : make_int2(-1, -1);
+      if (kPre) {
+        // (overlapped pass: the finalising solve's launch is already running on other XCDs — write-through stores)
+        wt_store_f4(ca, oa); wt_store_f4(cb, ob);
+        wt_store_u64(cidx, ((unsigned long long)(unsigned int)oi.y << 32) | (unsigned int)oi.x);
       } else {
-        *ca = make_float4(0, 0, 0, 0); *cb = make_float4(0, 0, 0, 0); *cidx = make_int2(-1, -1);
+        *ca = oa; *cb = ob; *cidx = oi;
       }
     }
     const unsigned long long vb = __ballot(valid);
@@ -1614,7 +1780,8 @@ __device__ __forceinline__ void knn_block(const DevView& v, int s, StreamState& 
       // :346 — with knn_partials the count travels as entry 29 of the workgroup's partial sums (no same-address atomic of
       // every workgroup: hot-address atomics delay whatever else maps to that memory channel by microseconds)
       if (nvalid && !v.knn_partials) atomicAdd(&st.info.matches[outer_it], nvalid);
-      v.corr_mask[((size_t)s * 2 + outer_it) * v.knn_blocks + bv] = (unsigned char)vb;   // bit q = query q accepted
+      unsigned char* cm = &v.corr_mask[((size_t)s * 2 + outer_it) * v.knn_blocks + bv];   // bit q = query q accepted
+      if (kPre) wt_store_u8(cm, (unsigned char)vb); else *cm = (unsigned char)vb;
     }
     sh.res[q][3] = valid ? 1 : 0;
   } else if (kKnnThreads > 64 && v.knn_partials && threadIdx.x >= 64 && threadIdx.x < 64 + kKnnQueries) {
@@ -1630,9 +1797,9 @@ __device__ __forceinline__ void knn_block(const DevView& v, int s, StreamState& 
     if (eq < E && sh.res[q][0] != 0) {
       double Rm[12], pq[4], pt[3];
 #pragma unroll
-      for (int i = 0; i < 4; i++) pq[i] = st.param_q[i];
+      for (int i = 0; i < 4; i++) pq[i] = kPre ? qt[i] : st.param_q[i];
 #pragma unroll
-      for (int i = 0; i < 3; i++) pt[i] = st.param_t[i];
+      for (int i = 0; i < 3; i++) pt[i] = kPre ? qt[4 + i] : st.param_t[i];
       iso_from_qt(pq, pt, Rm);
       const float4 pe = v.edges[((size_t)eb * v.n_streams + s) * v.edge_cap + eq];
       const double p[3] = {(double)pe.x, (double)pe.y, (double)pe.z};       // :347-349 sensor frame
@@ -1665,7 +1832,8 @@ __device__ __forceinline__ void knn_block(const DevView& v, int s, StreamState& 
     double x = 0.0;
 #pragma unroll
     for (int q = 0; q < kKnnQueries; q++) x += sh.part[q][threadIdx.x];      // fixed order: deterministic
-    v.knn_part[(((size_t)s * 2 + outer_it) * v.knn_blocks + bv) * 32 + threadIdx.x] = x;
+    double* dst = &v.knn_part[(((size_t)s * 2 + outer_it) * v.knn_blocks + bv) * 32 + threadIdx.x];
+    if (kPre) wt_store_u64(dst, (unsigned long long)__double_as_longlong(x)); else *dst = x;
   }
   DBG_STAMP(v, dbgb, 1, 7); DBG_QSTAMP(7);
   if ((kInstrument && (v.debug & 64)) && s == 0 && threadIdx.x == 0) {      // histogram of workgroup durations, 1 us bins
@@ -1679,21 +1847,29 @@ __device__ __forceinline__ void knn_block(const DevView& v, int s, StreamState& 
 // takes the query blocks b, b + knn_grid, ... below ceil(E / queries) — the grid is sized for the usual edge count
 // (half of the capacity), not for edge_cap: on lock-step batches two thirds of an edge_cap-sized grid were workgroups
 // that found nothing to do.
-template <int kKnnThreads>
-__global__ __launch_bounds__(kKnnThreads, (kKnnThreads >= 256 ? 1 : LIODOM_TUNE_B_WAVES)) void k_knn(DevView v, int s0, int outer_it, int eb, unsigned int wait_edges, unsigned int signal_odo) {
+// kOv: the overlapped second pass (see "Overlapped second kNN pass" above; one-stream handles, the 256-thread instance):
+// launched on stream_k beside the scan's first solve, seq = the launch sequence number the flags carry.
+template <int kKnnThreads, bool kOv>
+__device__ __forceinline__ void knn_pass(const DevView& v, int s, int bxi, int byi, int outer_it, int eb, unsigned int wait_edges,
+                                         unsigned int signal_odo, unsigned int seq, KnnShared<kKnnThreads / kKnnGroup>& sh, double* sh_ov) {
   constexpr int kKnnQueries = kKnnThreads / kKnnGroup;
-  __shared__ KnnShared<kKnnQueries> sh;
-  int bxi = (int)blockIdx.x, byi = (int)blockIdx.y;
-  xcd_remap(bxi, byi);
-  const int s = s0 + byi;
   StreamState& st = v.state[s];
-  if (v.early_rebuild) {
+  if (kOv) {
+    // the scan's first solve launch has started: the first kNN pass (and everything before it) has completed
+    // (k_ov_gate in front of this launch has seen the flag already: the launch started, with clean caches, after the first pass ended)
+    if (!pipe_wait(v.ov_flags + s, seq, &st.status)) return;
+    OV_STAMP(v, threadIdx.x == 0 && bxi == 0, 9); OV_STAMP(v, threadIdx.x == 0 && bxi == v.knn_grid - 1, 13);
+  } else if (v.early_rebuild) {
     if (bxi >= v.knn_grid) { if (outer_it == 1) rebuild_alloc(v, s, st, bxi - v.knn_grid, (int)gridDim.x - v.knn_grid); return; }
     // streamed rebuild, bookkeeping before the first builders start (next launch): the frame count the build refers to
-    // (the finalising solve advances it beside them) and an empty list of occupied slots for the table being built
-    if (outer_it == 0 && bxi == 0 && threadIdx.x == 0) { st.reb_frame_count = st.frame_count; st.n_used_tab[(st.frame_count + 1) & 1] = 0; }
+    // (the finalising solve advances it beside them), an empty list of occupied slots for the table being built, and the
+    // prediction the scan starts from
+    if (outer_it == 0 && bxi == 0 && threadIdx.x == 0) {
+      st.reb_frame_count = st.frame_count; st.n_used_tab[(st.frame_count + 1) & 1] = 0; st.reb_initialized = st.initialized;
+    }
+    if (outer_it == 0 && bxi == 0 && threadIdx.x >= 64 && threadIdx.x < 76) st.pred_odom[threadIdx.x - 64] = st.odom[threadIdx.x - 64];
   }
-  if (outer_it == 0) {
+  if (!kOv && outer_it == 0) {
     // (pipelined replay) this launch follows odometry `signal_odo` in stream order: that odometry has completed entirely;
     // and the extraction that fills edge buffer eb (other stream) must have completed before anything of it is read
     if (signal_odo && bxi == 0 && byi == 0 && threadIdx.x == 0) {
@@ -1711,8 +1887,10 @@ __global__ __launch_bounds__(kKnnThreads, (kKnnThreads >= 256 ? 1 : LIODOM_TUNE_
   double T[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (Tune::kHoistLoads) {
     p_first = v.edges[((size_t)eb * v.n_streams + s) * v.edge_cap + (e_first < v.edge_cap ? e_first : v.edge_cap - 1)];
+    if (!kOv) {
 #pragma unroll
-    for (int i = 0; i < 12; i++) T[i] = st.odom[i];
+      for (int i = 0; i < 12; i++) T[i] = st.odom[i];
+    }
   }
   const unsigned int st_status = st.status;
   const int st_init = st.initialized;
@@ -1723,29 +1901,76 @@ __global__ __launch_bounds__(kKnnThreads, (kKnnThreads >= 256 ? 1 : LIODOM_TUNE_
   static_assert(kKnnGridDiv == 2, "k_knn handles exactly two query blocks per workgroup");
   if (bxi * kKnnQueries >= E) {             // no query here: empty validity bytes for the solve's compaction
     if (threadIdx.x == 0) {
-      v.corr_mask[((size_t)s * 2 + outer_it) * v.knn_blocks + bxi] = 0;
-      if (bxi + v.knn_grid < v.knn_blocks) v.corr_mask[((size_t)s * 2 + outer_it) * v.knn_blocks + bxi + v.knn_grid] = 0;
+      unsigned char* cm = &v.corr_mask[((size_t)s * 2 + outer_it) * v.knn_blocks + bxi];
+      if (kOv) wt_store_u8(cm, 0); else *cm = 0;
+      if (bxi + v.knn_grid < v.knn_blocks) { if (kOv) wt_store_u8(cm + v.knn_grid, 0); else cm[v.knn_grid] = 0; }
     }
     return;
   }
-  knn_block<kKnnThreads>(v, s, st, outer_it, eb, bxi, E, sh, p_first, T);
   const int bv2 = bxi + v.knn_grid;
+  const int e_second = bv2 * kKnnQueries + (int)(threadIdx.x / kKnnGroup);
+  const bool second = bv2 < v.knn_blocks && bv2 * kKnnQueries < E;
+  KnnPre pre1, pre2;
+  float4 p_second = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (kOv) {
+    // everything the two blocks need apart from the solve's result; then wait for that
+    const int stab = s + LD_TAB_PARITY(v, st.frame_count) * v.n_streams;
+    const float4* sp = v.sorted_pts + (size_t)stab * v.sorted_cap;
+    const int hl = threadIdx.x & (kKnnGroup - 1);
+    knn_prefetch(v, s, e_first, hl, sp, pre1);
+    if (second) {
+      p_second = v.edges[((size_t)eb * v.n_streams + s) * v.edge_cap + (e_second < v.edge_cap ? e_second : v.edge_cap - 1)];
+      knn_prefetch(v, s, e_second, hl, sp, pre2);
+    }
+    if (!ov_wait_pose(v, s, bxi % kOvReplicas, seq, sh_ov, &st.status)) return;
+    OV_STAMP(v, threadIdx.x == 0 && bxi == 0, 10); OV_STAMP(v, threadIdx.x == 0 && bxi == v.knn_grid - 1, 14);
+#pragma unroll
+    for (int i = 0; i < 12; i++) T[i] = sh_ov[i];
+  }
+  knn_block<kKnnThreads, kOv>(v, s, st, outer_it, eb, bxi, E, sh, p_first, T, pre1, kOv ? sh_ov + 12 : nullptr);
   if (bv2 >= v.knn_blocks) return;
-  if (bv2 * kKnnQueries >= E) {
-    if (threadIdx.x == 0) v.corr_mask[((size_t)s * 2 + outer_it) * v.knn_blocks + bv2] = 0;
+  if (!second) {
+    if (threadIdx.x == 0) { unsigned char* cm = &v.corr_mask[((size_t)s * 2 + outer_it) * v.knn_blocks + bv2]; if (kOv) wt_store_u8(cm, 0); else *cm = 0; }
     return;
   }
   __syncthreads();                          // (the second block reuses the LDS)
-  const int e_second = bv2 * kKnnQueries + (int)(threadIdx.x / kKnnGroup);
-  float4 p_second = make_float4(0.f, 0.f, 0.f, 0.f);
   double T2[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // (reloaded: kept live across the first block the pose would cost 24 VGPRs)
-  if (Tune::kHoistLoads) {
+  if (kOv) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) T2[i] = sh_ov[i];
+  } else if (Tune::kHoistLoads) {
     p_second = v.edges[((size_t)eb * v.n_streams + s) * v.edge_cap + (e_second < v.edge_cap ? e_second : v.edge_cap - 1)];
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int i = 0; i < 12; i++) T2[i] = st.odom[i];
   }
-  knn_block<kKnnThreads>(v, s, st, outer_it, eb, bv2, E, sh, p_second, T2);
+  knn_block<kKnnThreads, kOv>(v, s, st, outer_it, eb, bv2, E, sh, p_second, T2, pre2, kOv ? sh_ov + 12 : nullptr);
+}
+
+template <int kKnnThreads, bool kOv = false>
+__global__ __launch_bounds__(kKnnThreads, (kKnnThreads >= 256 ? 1 : LIODOM_TUNE_B_WAVES)) void k_knn(DevView v, int s0, int outer_it, int eb, unsigned int wait_edges, unsigned int signal_odo, unsigned int seq) {
+  constexpr int kKnnQueries = kKnnThreads / kKnnGroup;
+  __shared__ KnnShared<kKnnQueries> sh;
+  __shared__ double sh_ov[kOv ? 20 : 1];       // overlapped pass: the first solve's odom[12], q[4], t[3]
+  int bxi = (int)blockIdx.x, byi = (int)blockIdx.y;
+  xcd_remap(bxi, byi);
+  const int s = s0 + byi;
+  if (kOv) { OV_STAMP(v, threadIdx.x == 0 && bxi == 0, 8); OV_STAMP(v, threadIdx.x == 0 && bxi == v.knn_grid - 1, 12); }
+  else if (outer_it == 0) OV_STAMP(v, threadIdx.x == 0 && bxi == 0, 16);
+  knn_pass<kKnnThreads, kOv>(v, s, bxi, byi, outer_it, eb, wait_edges, signal_odo, seq, sh, sh_ov);
+  if (kOv) ov_signal_knn_done(v, s, bxi, seq);       // (every exit of the pass is workgroup-uniform)
+  if (kOv) { OV_STAMP(v, threadIdx.x == 0 && bxi == 0, 11); OV_STAMP(v, threadIdx.x == 0 && bxi == v.knn_grid - 1, 15); }
+  else if (outer_it == 0) OV_STAMP(v, threadIdx.x == 0 && bxi == v.knn_grid - 1, 17);
+}
+
+// One wave in front of the overlapped pass on stream_k: the pass's workgroups must not become resident before the first
+// solve's launch is (k_lm_solve needs CUs whose registers are all free — 2 waves x 256 VGPRs per SIMD — and 352 polling
+// k_knn workgroups leave none: the solve could not start, the pass would wait for it forever).  The launch behind this
+// gate starts when it retires, i.e. once the solve's workgroups are on their CUs.
+__global__ void k_ov_gate(DevView v, int s, unsigned int seq) {
+  OV_STAMP(v, threadIdx.x == 0, 6);
+  (void)pipe_wait(v.ov_flags + s, seq, &v.state[s].status);
+  OV_STAMP(v, threadIdx.x == 0, 7);
 }
 
 // k_line_gate (lock-step batches): the line gate of laser_odometry.cc:325-344 for the queries of one kNN pass, one query
@@ -2025,7 +2250,7 @@ __device__ void finalize_scan(const DevView& v, int s, StreamState& st, int* sh_
     iso_inverse(st.prev_odom, inv);
     iso_mul(inv, st.final_odom, rel);
     iso_mul(st.final_odom, rel, pred);
-    for (int i = 0; i < 12; i++) { st.prev_odom[i] = st.final_odom[i]; st.odom[i] = pred[i]; st.pred_odom[i] = pred[i]; }
+    for (int i = 0; i < 12; i++) { st.prev_odom[i] = st.final_odom[i]; st.odom[i] = pred[i]; }
     quat_from_pose(pred, v.rotation_mode, st.param_q);               // :186-190 q_curr(odom_.rotation())
     st.param_t[0] = pred[3]; st.param_t[1] = pred[7]; st.param_t[2] = pred[11];   // :192-195
     wn[new_slot] = n_edges;
@@ -2142,14 +2367,14 @@ __global__ void k_imu_override(DevView v, int s0, int count) {
   for (int k = 0; k < 4; k++) q[k] = v.imu_q[(size_t)(s0 + i) * 4 + k];
   imu_override(odom, q, l2b, v.rotation_mode, out);
 #pragma unroll
-  for (int k = 0; k < 12; k++) { st.odom[k] = out[k]; st.pred_odom[k] = out[k]; }
+  for (int k = 0; k < 12; k++) st.odom[k] = out[k];
   quat_from_pose(out, v.rotation_mode, st.param_q);                                // :186-190
   st.param_t[0] = out[3]; st.param_t[1] = out[7]; st.param_t[2] = out[11];         // :192-195
 }
 
-__device__ void rebuild_beside_solve(const DevView& v, int s, StreamState& st, int eb, int outer_it, int block, int* sbase, int* sslot);
+__device__ void rebuild_beside_solve(const DevView& v, int s, StreamState& st, int eb, int outer_it, int block, int nblocks, unsigned int seq, int* sbase, int* sslot);
 
-__global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int outer_it, int eb) {
+__global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int outer_it, int eb, unsigned int seq) {
   __shared__ double sh_pose[12];
   __shared__ double sh_acc[kAccN];
   __shared__ LmState lm;
@@ -2164,11 +2389,18 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
   StreamState& st = v.state[s];
   __shared__ int sh_cnt[kMaxFrames + 1];
   __shared__ int sh_same_xcc;
+  // seq != 0: the scan's second kNN pass runs beside this launch ("Overlapped second kNN pass"): the first solve's launch says
+  // that it has started (= the first pass has completed), the finalising one waits for the second pass where it needs it
+  OV_STAMP(v, bxl == 0 && threadIdx.x == 0, outer_it == 0 ? 0 : 3);
+  if (seq && outer_it == 0 && bxl == 0 && threadIdx.x == 0) {
+    typedef __attribute__((address_space(1))) unsigned int gu32;
+    __hip_atomic_store((gu32*)(v.ov_flags + s), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   if (g >= G) {
     if (!v.early_rebuild) return;                  // (filler blocks between the solvers)
     // early_rebuild: the workgroups behind the solve build the next cell hash (see "streamed rebuild" below)
     __shared__ int sh_slot[kMaxFrames];
-    rebuild_beside_solve(v, s, st, eb, outer_it, g - G, sh_cnt, sh_slot);
+    rebuild_beside_solve(v, s, st, eb, outer_it, g - G, (int)gridDim.x - G, seq, sh_cnt, sh_slot);
     return;
   }
   __shared__ double sh_loc[kAccN];
@@ -2219,6 +2451,9 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
     c_lo = g * chunk < C ? g * chunk : C;
     c_hi = (g + 1) * chunk < C ? (g + 1) * chunk : C;
   };
+  if (seq && outer_it == 1) ov_wait_knn_done(v, s, seq, &st.status);      // the overlapped second kNN pass has completed
+  OV_STAMP(v, g == 0 && tid == 0 && outer_it == 1, 4);
+  OV_STAMP(v, g == 0 && tid == 0 && outer_it == 0, 18);
   if (v.knn_partials) {
     // ---- first evaluation = sum of the partial normal equations the k_knn workgroups left, in workgroup order ----
     const int Q = v.knn_queries;
@@ -2305,6 +2540,22 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
   DBG_STAMP(v, dbgb, 2, 20);
   if ((kInstrument && (v.debug & 32)) && dbgb) v.dbg_clk[2 * 32 + 27] = (xch_local ? 100ull : 0ull) + 10ull * xcc_id() + (unsigned long long)n_eval;   // (debug) exchange transport, XCC, evaluations
   if (g != 0) return;        // every workgroup reached the same result; workgroup 0 records it
+  if (seq && outer_it == 0) {
+    // overlapped second kNN pass: its workgroups are waiting for exactly these 19 doubles — they leave first
+    __shared__ double sh_ov[20];
+    if (tid == kLmCtl) {
+      double q[4], t[3], T[12];
+      for (int k = 0; k < 4; k++) q[k] = lm.q[k];
+      for (int k = 0; k < 3; k++) t[k] = lm.t[k];
+      iso_from_qt(q, t, T);
+      for (int k = 0; k < 12; k++) sh_ov[k] = T[k];
+      for (int k = 0; k < 4; k++) sh_ov[12 + k] = q[k];
+      for (int k = 0; k < 3; k++) sh_ov[16 + k] = t[k];
+    }
+    __syncthreads();
+    ov_publish_pose(v, s, sh_ov, seq, tid);
+    OV_STAMP(v, tid == 0, 1);
+  }
   if (tid == kLmCtl) {
     for (int k = 0; k < 4; k++) st.param_q[k] = lm.q[k];
     for (int k = 0; k < 3; k++) st.param_t[k] = lm.t[k];
@@ -2320,6 +2571,7 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
     DBG_STAMP(v, dbgb, 2, 22);
   }
   DBG_STAMP(v, dbgb, 2, 28);
+  OV_STAMP(v, tid == 0, outer_it == 0 ? 2 : 5);
 }
 
 // =============================================================================================
@@ -2454,7 +2706,8 @@ __global__ __launch_bounds__(256) void k_window_insert(DevView v, int s0, int eb
 // the saved prediction.  (A waiting workgroup depends only on the solving workgroup of its own stream, which has a
 // lower block index and so was dispatched before it.)
 // =============================================================================================
-constexpr int kRebuildAuxBlocks = 8;      // workgroups for ALLOC (k_knn) and for CLEAR (k_lm_solve)
+constexpr int kRebuildAuxBlocks = 8;      // workgroups for ALLOC (inside k_knn) and for CLEAR (k_lm_solve)
+constexpr int kRebuildAllocBlocks = 32;   // k_rebuild_alloc: the ~8 000 occupied cells of a headline scan in one sweep (it sits between the two solve launches)
 
 // Prefix table of the kept frames (chronological): sbase[0 .. nk], sslot[0 .. nk).  Returns nk; whole workgroup.
 __device__ __forceinline__ int kept_frames_table(const DevView& v, int s, const StreamState& st, int* sbase, int* sslot) {
@@ -2488,7 +2741,7 @@ __device__ __forceinline__ bool point_finite(const float4& pt) {
 }
 // the scan's edge idx at the pose the scan started from (the first frame enters the window untransformed, :123)
 __device__ __forceinline__ float4 predicted_point(const StreamState& st, const float4& e) {
-  if (!st.initialized) return e;
+  if (!st.reb_initialized) return e;
   double T[12];
 #pragma unroll
   for (int i = 0; i < 12; i++) T[i] = st.pred_odom[i];
@@ -2555,7 +2808,9 @@ __device__ void rebuild_count_and_pad(const DevView& v, int s, StreamState& st, 
   }
 }
 
-// ALLOC, by the extra workgroups of the scan's second k_knn launch: start offsets of the occupied cells (any order:
+// ALLOC, by the extra workgroups of the scan's second k_knn launch — or, when that pass is overlapped with the first solve
+// on a stream of its own, by k_rebuild_alloc between the two solve launches (a launch boundary must separate ALLOC from
+// COUNT / PAD before it and from SCATTER / APPEND behind it) —: start offsets of the occupied cells (any order:
 // only contiguity per cell matters), room = points counted + places padded; cell_pad becomes the end of the range.
 __device__ void rebuild_alloc(const DevView& v, int s, StreamState& st, int block, int nblocks) {
   const int par = (st.reb_frame_count + 1) & 1, sp = s + par * v.n_streams;
@@ -2582,8 +2837,14 @@ __device__ void rebuild_alloc(const DevView& v, int s, StreamState& st, int bloc
   }
 }
 
+__global__ __launch_bounds__(256) void k_rebuild_alloc(DevView v, int s0) {
+  const int s = s0 + blockIdx.y;
+  StreamState& st = v.state[s];
+  rebuild_alloc(v, s, st, (int)blockIdx.x, (int)gridDim.x);
+}
+
 // SCATTER / APPEND / CLEAR, beside the finalising solve
-__device__ void rebuild_finish(const DevView& v, int s, StreamState& st, int eb, int block, int* sbase, int* sslot) {
+__device__ void rebuild_finish(const DevView& v, int s, StreamState& st, int eb, int block, unsigned int seq, int* sbase, int* sslot) {
   __shared__ double sh_T[12];
   __shared__ int sh_hand;
   const int tid = threadIdx.x, nt = blockDim.x;
@@ -2593,7 +2854,9 @@ __device__ void rebuild_finish(const DevView& v, int s, StreamState& st, int eb,
   float4* sorted = v.sorted_pts + (size_t)sp * v.sorted_cap;
   CellSlot* cells = v.cells + (size_t)sp * v.table_size;
   if (block >= nP && block < nP + kRebuildAuxBlocks) {
-    // CLEAR: the table this scan searched, its padding and its overflow list
+    // CLEAR: the table this scan searched, its padding and its overflow list (dead since the second kNN pass — which, when
+    // it runs beside this launch, has to have completed first)
+    if (seq) ov_wait_knn_done(v, s, seq, &st.status);
     const int dead = s + (1 - par) * v.n_streams;
     hash_clear_used(v, dead, st.n_used_tab[1 - par], (block - nP) * nt + tid, kRebuildAuxBlocks * nt);
     if (block == nP && tid == 0) st.n_ovf[1 - par] = 0;
@@ -2704,9 +2967,10 @@ __device__ void rebuild_finish(const DevView& v, int s, StreamState& st, int eb,
   DBG_STAMP(v, dbga, 2, 30);
 }
 
-__device__ void rebuild_beside_solve(const DevView& v, int s, StreamState& st, int eb, int outer_it, int block, int* sbase, int* sslot) {
+__device__ void rebuild_beside_solve(const DevView& v, int s, StreamState& st, int eb, int outer_it, int block, int nblocks, unsigned int seq, int* sbase, int* sslot) {
+  (void)nblocks;
   if (outer_it == 0) rebuild_count_and_pad(v, s, st, eb, block, sbase, sslot);
-  else rebuild_finish(v, s, st, eb, block, sbase, sslot);
+  else rebuild_finish(v, s, st, eb, block, seq, sbase, sslot);
 }
 
 // Start offsets of the occupied cells (any order: only contiguity per cell matters).  One atomic

@@ -244,6 +244,35 @@ def sec_clocks(H=64, W=1800, R=8, epr=10, P=20, K=40):
     g.close()
 
 
+def sec_ovclocks(H=64, W=1800, R=8, epr=10, P=20, K=40):
+    """Wall-clock stamps around the overlapped second kNN pass of the last scan (instrumented build, debug bit 7)."""
+    import ctypes as C
+    os.environ.setdefault("LIODOM_DEBUG_CLOCKS", "128")
+    cfg = synth.make_cfg(H, W, 0)
+    po, g = mk(H, W, 0, R, epr, P, pose_log_capacity=4 * K)
+    print("modes:", g.modes())
+    g.alloc_resident(K)
+    for k in range(K):
+        g.upload_scan(0, k, synth.scan(cfg, 0, k)[0])
+    serial = os.environ.get("KNN_SERIAL", "0") != "0"
+    for k in range(K):
+        g.process_resident(k, H * W, H, W, readback=serial)
+    g.sync()
+    buf = (C.c_ulonglong * 512)()
+    g.L.liodom_debug_clocks.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+    g.L.liodom_debug_clocks(g.h, buf)
+    a = np.array(list(buf), dtype=np.int64)[448:480]
+    names = ["solve0 wg0 start", "solve0 pose published", "solve0 wg0 end", "solve1 wg0 start", "solve1 wait done", "solve1 wg0 end", "gate start", "gate saw flag",
+             "knn1 wg0 start", "knn1 wg0 past flag", "knn1 wg0 pose seen", "knn1 wg0 end", "knn1 wgN start", "knn1 wgN past flag", "knn1 wgN pose seen", "knn1 wgN end",
+             "knn0 wg0 start", "knn0 wgN end", "solve0 partial sums next"]
+    t0 = a[16] if a[16] else a[0]
+    order = sorted(range(len(names)), key=lambda i: a[i])
+    for i in order:
+        if a[i]:
+            print("   %-26s %8.2f us" % (names[i], (a[i] - t0) / 100.0))
+    g.close()
+
+
 def sec_knntimes(H=64, W=1800, R=8, epr=10, P=20, K=40):
     """Per-query phase times of k_knn for the last scan of a pipelined replay (LIODOM_DEBUG_CLOCKS)."""
     import ctypes as C
@@ -295,6 +324,7 @@ def sec_knntimes(H=64, W=1800, R=8, epr=10, P=20, K=40):
 
 
 SECTIONS["knntimes"] = sec_knntimes
+SECTIONS["ovclocks"] = sec_ovclocks
 
 
 SECTIONS["clocks"] = sec_clocks
@@ -340,7 +370,7 @@ SECTIONS["long"] = sec_long
 
 if __name__ == "__main__":
     names = sys.argv[1:] or ["extract", "odom", "odom64", "timing"]
-    if any(n in ("clocks", "knntimes") for n in names):
+    if any(n in ("clocks", "knntimes", "ovclocks") for n in names):
         _use_instrumented_library()
     for n in names:
         print("=" * 20, n)
