@@ -1068,24 +1068,14 @@ __device__ __forceinline__ bool ov_wait_pose(const DevView& v, int s, int rep, u
     unsigned long long g = 0;
     unsigned int spins = 0;
     bool ok;
-    // One lane polls the LAST granule (the publisher's lanes store in order, it usually lands last); only then do all
-    // lanes fetch theirs — and go round again if some granule is not there yet.  (All 38 lanes of 352 workgroups polling
-    // — agent-scope loads do not coalesce and do not hit in the L2 — congested the memory fabric: the solve they were
-    // waiting for took 100 us instead of 24, the next scan's k_classify 40 instead of 7.)
+    // (all 38 lanes poll: one round trip after the publication instead of two; what had congested the memory fabric in the
+    //  first version of this pass were release / acquire fences — an L2 write-back / invalidate each —, not these loads)
     while (true) {
-      unsigned long long last = 0;
-      if (tid == 0) last = __hip_atomic_load((gu64*)(base + kOvGranules - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      last = __shfl(last, 0);
-      ok = true;
-      if ((unsigned int)(last >> 32) == tag) {
-        if (tid < kOvGranules) g = __hip_atomic_load((gu64*)(base + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ok = tid >= kOvGranules || (unsigned int)(g >> 32) == tag;
-        if (__all(ok)) break;
-      } else {
-        ok = false;
-      }
+      if (tid < kOvGranules) g = __hip_atomic_load((gu64*)(base + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ok = tid >= kOvGranules || (unsigned int)(g >> 32) == tag;
+      if (__all(ok)) break;
       if (++spins > 2000000u) break;
-      __builtin_amdgcn_s_sleep(64);
+      __builtin_amdgcn_s_sleep(6);
     }
     const bool all_ok = __all(ok);
     const unsigned long long lo = __shfl(g, 2 * (tid % 19)), hi = __shfl(g, 2 * (tid % 19) + 1);
@@ -1465,34 +1455,125 @@ __device__ __forceinline__ float best2_bound(const Best2Acc& t, int half_shift) 
   return B;
 }
 
-// What a query of the second pass re-ranks (saved by the first pass), loaded ahead of the pose by the overlapped pass.
+// One segment of candidates per lane of the half-wave: the cell of (cx, cy, cz) and its 26 neighbours (lanes 0..26; the own
+// cell is lane 13) and, on lane 27, the overflow list of the streamed rebuild.  lb = lower bound of the float squared
+// distance from q to any point of the segment (see knn_block).
+template <class Tune>
+__device__ __forceinline__ void knn_probe_cells(const DevView& v, const StreamState& st, int hl, int cx, int cy, int cz, float qx, float qy, float qz,
+                                                const CellSlot* cells, const unsigned int* bits, unsigned int tmask,
+                                                unsigned int& start, unsigned int& cnt, float& lb) {
+  if (hl < 27) {
+    const int dx = hl % 3 - 1, dy = (hl / 3) % 3 - 1, dz = hl / 9 - 1;
+    const unsigned long long key = pack_cell(cx + dx, cy + dy, cz + dz);
+    unsigned int h = hash_cell(key, tmask);
+    if (Tune::kProbeBoth) {
+      // (few streams: latency counts) occupancy bit and slot of the first probe leave together — one round trip instead of
+      // two; the slots of empty cells (most of the 27) are loaded for nothing, 16 B each
+      const unsigned int word = bits[h >> 5];
+      const uint4 raw = *reinterpret_cast<const uint4*>(cells + h);
+      const unsigned long long k = ((unsigned long long)raw.y << 32) | raw.x;
+      bool more = ((word >> (h & 31)) & 1u) != 0u;
+      if (more && k == key) { start = raw.z; cnt = raw.w; more = false; }
+      for (int pr = 1; more && pr < v.table_size; pr++) {       // (collision chain: rare)
+        h = (h + 1) & tmask;
+        if (!((bits[h >> 5] >> (h & 31)) & 1u)) break;
+        const uint4 r2 = *reinterpret_cast<const uint4*>(cells + h);
+        if ((((unsigned long long)r2.y << 32) | r2.x) == key) { start = r2.z; cnt = r2.w; break; }
+      }
+    } else {
+      for (int pr = 0; pr < v.table_size; pr++) {
+        if (!((bits[h >> 5] >> (h & 31)) & 1u)) break;           // empty slot: cell not in the map
+        const uint4 raw = *reinterpret_cast<const uint4*>(cells + h);
+        const unsigned long long k = ((unsigned long long)raw.y << 32) | raw.x;
+        if (k == key) { start = raw.z; cnt = raw.w; break; }
+        h = (h + 1) & tmask;
+      }
+    }
+    const float cs = (float)kCellSize;
+    const float lx = (float)(cx + dx) * cs, ly = (float)(cy + dy) * cs, lz = (float)(cz + dz) * cs;
+    const float ex = qx < lx ? lx - qx : (qx > lx + cs ? qx - (lx + cs) : 0.0f);
+    const float ey = qy < ly ? ly - qy : (qy > ly + cs ? qy - (ly + cs) : 0.0f);
+    const float ez = qz < lz ? lz - qz : (qz > lz + cs ? qz - (lz + cs) : 0.0f);
+    lb = (ex * ex + ey * ey + ez * ez) * (1.0f - 1e-5f);
+  } else if (hl == 27 && v.early_rebuild) {
+    start = (unsigned int)v.ovf_base;
+    cnt = (unsigned int)st.n_ovf[LD_TAB_PARITY(v, st.frame_count)];
+  }
+}
+
+// What a query of the OVERLAPPED second pass re-ranks, collected while the first solve still runs (knn_presearch).
 struct KnnPre {
-  float gsq;        // guard (0: nothing saved)
+  float gsq;        // guard: no map point outside the collected set is closer to the first pass's query than sqrt(gsq) (0: nothing collected)
   float4 sq;        // the first pass's query and its fifth-nearest distance
-  int2 sv;          // this lane's two saved candidates (positions in the cell-sorted array)
-  float4 m0, m1;    // ... and the points there
+  int p[5];         // this lane's collected candidates (positions in the cell-sorted array; -1: none)
+  float4 c[5];      // ... and the points there (w: window index)
 };
-__device__ __forceinline__ void knn_prefetch(const DevView& v, int s, int e, int hl, const float4* sp, KnnPre& pre) {
+// Overlapped second pass, before the first solve's result is there: an exact search around the FIRST pass's query q_old (the
+// second query will be millimetres away) that collects every map point within sqrt(d5_old) + kOvMargin of it — sorted
+// per-lane lists of five, the sentinel-initialised Top5 lists of the exact path — and loads the collected points.  With the
+// result of the solve the block only re-ranks these (knn_block, kPre): d = |q_new - q_old| is far below the margin, so the
+// re-ranked five are certified by the same guard argument as the non-overlapped re-ranking, practically always — the
+// search a non-certified query falls back to (which a launch lasts as long as) disappears from the critical path.
+constexpr float kOvMargin = 0.03f;
+template <int kKnnThreads>
+__device__ __forceinline__ void knn_presearch(const DevView& v, int s, const StreamState& st, int e, int E,
+                                              KnnShared<kKnnThreads / kKnnGroup>& sh, KnnPre& pre) {
+  typedef KnnTune<(kKnnThreads >= 256)> Tune;
+  const int grp = threadIdx.x / kKnnGroup, hl = threadIdx.x & (kKnnGroup - 1);
   const int ec = e < v.edge_cap ? e : v.edge_cap - 1;
   pre.gsq = 0.f;
   pre.sq = make_float4(0.f, 0.f, 0.f, __int_as_float(0x7f800000));
-  pre.sv = make_int2(-1, -1);
-  pre.m0 = pre.m1 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (v.knn_save_q) pre.sq = v.knn_save_q[(size_t)s * v.edge_cap + ec];
-  if (v.knn_save_pos && !v.knn_exact_only) {
-    pre.gsq = v.knn_save_g[(size_t)s * v.edge_cap + ec];
-    pre.sv = v.knn_save_pos[((size_t)s * v.edge_cap + ec) * kKnnGroup + hl];
-    // (all lanes load, whatever the guard says — a branch on it would be one more dependent round trip; clamped: entries of
-    //  edges beyond the scan's count are leftovers)
-    pre.m0 = sp[(pre.sv.x >= 0 && pre.sv.x < v.sorted_cap) ? pre.sv.x : 0];
-    pre.m1 = sp[(pre.sv.y >= 0 && pre.sv.y < v.sorted_cap) ? pre.sv.y : 0];
+#pragma unroll
+  for (int k = 0; k < 5; k++) { pre.p[k] = -1; pre.c[k] = make_float4(0.f, 0.f, 0.f, 0.f); }
+  if (!v.knn_save_q) return;
+  pre.sq = v.knn_save_q[(size_t)s * v.edge_cap + ec];
+  const float qx = pre.sq.x, qy = pre.sq.y, qz = pre.sq.z;
+  const bool act = e < E && !v.knn_exact_only && ld_isfinite((double)qx) && ld_isfinite((double)qy) && ld_isfinite((double)qz) &&
+                   fabsf(qx) < 1.0e9f && fabsf(qy) < 1.0e9f && fabsf(qz) < 1.0e9f;
+  if (!act) return;                                // (uniform over the half-wave)
+  const int cx = (int)floorf(qx * kCellInv), cy = (int)floorf(qy * kCellInv), cz = (int)floorf(qz * kCellInv);
+  const unsigned int tmask = st.table_mask;
+  const int stab = s + LD_TAB_PARITY(v, st.frame_count) * v.n_streams;
+  const CellSlot* cells = v.cells + (size_t)stab * v.table_size;
+  const unsigned int* bits = v.cell_bits + (size_t)stab * (v.table_size >> 5);
+  const float4* sp = v.sorted_pts + (size_t)stab * v.sorted_cap;
+  unsigned int start = 0, cnt = 0;
+  float lb = 0.0f;
+  knn_probe_cells<Tune>(v, st, hl, cx, cy, cz, qx, qy, qz, cells, bits, tmask, start, cnt, lb);
+  // everything within sqrt(min(d5_old, 1)) + margin of q_old (beyond the 1.0 gate nothing can matter: :324)
+  const float r = fminf(sqrtf(pre.sq.w), 1.0f) + kOvMargin;
+  const float B = r * r * (1.0f + 1e-5f);
+  Top5Acc ta;
+  {
+    const unsigned long long sentinel = ((unsigned long long)(unsigned int)__float_as_int(B) << 32) | 0x7fffffffull;
+    ta.t.k0 = ta.t.k1 = ta.t.k2 = ta.t.k3 = ta.t.k4 = sentinel;
+    ta.t.p0 = ta.t.p1 = ta.t.p2 = ta.t.p3 = ta.t.p4 = -1;
   }
+  const bool all = cnt > 0 && !(lb > B);
+  knn_stream_cells<Top5Acc, 2, 2, 64>(ta, sp, sh.incl[grp], sh.adj[grp], start, all ? cnt : 0u, hl, qx, qy, qz);
+  // guard: B itself (segments with lb > B and points beyond B were left out), the fifth entry of a lane whose list is full
+  // (it may have dropped candidates at or beyond that distance), the border of the 27-cell block
+  float gl = B;
+  if (ta.t.p4 >= 0) gl = fminf(gl, top5_dist(ta.t.k4));
+  float guard = __int_as_float((int)half_min_u32((unsigned int)__float_as_int(gl)));
+  {
+    const float cs = (float)kCellSize;
+    const float fx = qx - (float)cx * cs, fy = qy - (float)cy * cs, fz = qz - (float)cz * cs;
+    float edge = fminf(fminf(fminf(fx, cs - fx), fminf(fy, cs - fy)), fminf(fz, cs - fz));
+    edge = edge > 0.f ? edge : 0.f;
+    const float outer = (cs + edge) * (cs + edge) * (1.0f - 1e-6f);
+    guard = guard < outer ? guard : outer;
+  }
+  pre.gsq = guard;
+  pre.p[0] = ta.t.p0; pre.p[1] = ta.t.p1; pre.p[2] = ta.t.p2; pre.p[3] = ta.t.p3; pre.p[4] = ta.t.p4;
+#pragma unroll
+  for (int k = 0; k < 5; k++) pre.c[k] = sp[pre.p[k] >= 0 ? pre.p[k] : 0];
 }
 
 // One block of kKnnThreads / 32 queries (virtual block index bv).  Whole workgroup; returns are workgroup-uniform.
 // kPre (overlapped second pass): what the re-ranking loads is in `pre` already, and the solve's start point (q, t) comes
 // from qt (LDS) — the stream's state is still being written by the first solve's launch.
-template <int kKnnThreads, bool kPre = false>
+template <int kKnnThreads, bool kPre = false, bool kTail = true>
 __device__ __forceinline__ void knn_block(const DevView& v, int s, StreamState& st, int outer_it, int eb, int bv, int E,
                                           KnnShared<kKnnThreads / kKnnGroup>& sh, const float4& p_in, const double (&T_in)[12],
                                           const KnnPre& pre, const double* qt) {
@@ -1544,12 +1625,49 @@ __device__ __forceinline__ void knn_block(const DevView& v, int s, StreamState& 
     // the re-ranked set is strictly closer than that (rounding margins included) — or nothing unsaved can be inside the
     // 1.0 gate — it is the exact answer and the query needs no probe and no stream; otherwise it searches below. ----
     bool reranked = false;
+    if (kPre) {
+      // overlapped pass: re-rank what knn_presearch collected around the first pass's query (sorted lists, exact merge:
+      // ties by window index as in the exact path)
+      if (pre.gsq > 0.f) {                                       // (uniform over the half-wave)
+        Top5 t, g;
+        top5_clear(t);
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+          if (pre.p[k] >= 0) top5_insert(t, sqdist_f(qx, qy, qz, pre.c[k].x, pre.c[k].y, pre.c[k].z), __float_as_int(pre.c[k].w), pre.p[k]);
+        }
+        knn_merge(t, g, hl, half_shift);
+        const float d5n = g.p4 >= 0 ? top5_dist(g.k4) : __int_as_float(0x7f800000);
+        const double ddx = (double)qx - (double)pre.sq.x, ddy = (double)qy - (double)pre.sq.y, ddz = (double)qz - (double)pre.sq.z;
+        const double delta = sqrt(ddx * ddx + ddy * ddy + ddz * ddz) * (1.0 + 1e-12);
+        const double r = sqrt((double)pre.gsq) * (1.0 - 2e-7) - delta;     // every point outside the collected set is at least this far now
+        const double limit = r > 0.0 ? r * r * (1.0 - 1e-6) : 0.0;         // (float rounding of the new distances included)
+        reranked = (double)d5n < limit || limit > 1.0;                     // beyond the 1.0 gate nothing uncollected can matter
+        if (reranked) {
+          d5_r = d5n;
+          pos5[0] = g.p0; pos5[1] = g.p1; pos5[2] = g.p2; pos5[3] = g.p3; pos5[4] = g.p4;
+          if (d5n < 1.0f) {
+            // the five neighbours are among the points the lanes hold: whoever holds the r-th hands it over (no second fetch)
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+              if (pre.p[k] >= 0) {
+                const int r = pre.p[k] == g.p0 ? 0 : pre.p[k] == g.p1 ? 1 : pre.p[k] == g.p2 ? 2 : pre.p[k] == g.p3 ? 3 : pre.p[k] == g.p4 ? 4 : -1;
+                if (r >= 0) {
+                  sh.nn[grp][r * 3 + 0] = pre.c[k].x; sh.nn[grp][r * 3 + 1] = pre.c[k].y; sh.nn[grp][r * 3 + 2] = pre.c[k].z;
+                  if (r < 2) sh.res[grp][1 + r] = __float_as_int(pre.c[k].w);     // window indices of NN0, NN1
+                }
+              }
+            }
+            if (hl == 0) sh.res[grp][0] = 1;
+          }
+        }
+      }
+    } else
     if (outer_it == 1 && v.knn_save_pos && !v.knn_exact_only) {
-      const float gsq = kPre ? pre.gsq : v.knn_save_g[(size_t)s * v.edge_cap + e];
+      const float gsq = v.knn_save_g[(size_t)s * v.edge_cap + e];
       if (gsq > 0.f) {                                           // (uniform over the half-wave)
-        const float4 sq = kPre ? pre.sq : v.knn_save_q[(size_t)s * v.edge_cap + e];
-        const int2 sv = kPre ? pre.sv : v.knn_save_pos[((size_t)s * v.edge_cap + e) * kKnnGroup + hl];
-        const float4 m0 = kPre ? pre.m0 : sp[sv.x >= 0 ? sv.x : 0], m1 = kPre ? pre.m1 : sp[sv.y >= 0 ? sv.y : 0];
+        const float4 sq = v.knn_save_q[(size_t)s * v.edge_cap + e];
+        const int2 sv = v.knn_save_pos[((size_t)s * v.edge_cap + e) * kKnnGroup + hl];
+        const float4 m0 = sp[sv.x >= 0 ? sv.x : 0], m1 = sp[sv.y >= 0 ? sv.y : 0];
         Best2Acc br;
         br.clear();
         br.consider(sv.x >= 0, sqdist_f(qx, qy, qz, m0.x, m0.y, m0.z), 0, sv.x);
@@ -1579,43 +1697,7 @@ __device__ __forceinline__ void knn_block(const DevView& v, int s, StreamState& 
     // pruned point look closer than the bound.
     unsigned int start = 0, cnt = 0;
     float lb = 0.0f;
-    if (hl < 27) {
-      const int dx = hl % 3 - 1, dy = (hl / 3) % 3 - 1, dz = hl / 9 - 1;
-      const unsigned long long key = pack_cell(cx + dx, cy + dy, cz + dz);
-      unsigned int h = hash_cell(key, tmask);
-      if (Tune::kProbeBoth) {
-        // (few streams: latency counts) occupancy bit and slot of the first probe leave together — one round trip instead of
-        // two; the slots of empty cells (most of the 27) are loaded for nothing, 16 B each
-        const unsigned int word = bits[h >> 5];
-        const uint4 raw = *reinterpret_cast<const uint4*>(cells + h);
-        const unsigned long long k = ((unsigned long long)raw.y << 32) | raw.x;
-        bool more = ((word >> (h & 31)) & 1u) != 0u;
-        if (more && k == key) { start = raw.z; cnt = raw.w; more = false; }
-        for (int pr = 1; more && pr < v.table_size; pr++) {       // (collision chain: rare)
-          h = (h + 1) & tmask;
-          if (!((bits[h >> 5] >> (h & 31)) & 1u)) break;
-          const uint4 r2 = *reinterpret_cast<const uint4*>(cells + h);
-          if ((((unsigned long long)r2.y << 32) | r2.x) == key) { start = r2.z; cnt = r2.w; break; }
-        }
-      } else {
-        for (int pr = 0; pr < v.table_size; pr++) {
-          if (!((bits[h >> 5] >> (h & 31)) & 1u)) break;           // empty slot: cell not in the map
-          const uint4 raw = *reinterpret_cast<const uint4*>(cells + h);
-          const unsigned long long k = ((unsigned long long)raw.y << 32) | raw.x;
-          if (k == key) { start = raw.z; cnt = raw.w; break; }
-          h = (h + 1) & tmask;
-        }
-      }
-      const float cs = (float)kCellSize;
-      const float lx = (float)(cx + dx) * cs, ly = (float)(cy + dy) * cs, lz = (float)(cz + dz) * cs;
-      const float ex = qx < lx ? lx - qx : (qx > lx + cs ? qx - (lx + cs) : 0.0f);
-      const float ey = qy < ly ? ly - qy : (qy > ly + cs ? qy - (ly + cs) : 0.0f);
-      const float ez = qz < lz ? lz - qz : (qz > lz + cs ? qz - (lz + cs) : 0.0f);
-      lb = (ex * ex + ey * ey + ez * ez) * (1.0f - 1e-5f);
-    } else if (hl == 27 && v.early_rebuild) {
-      start = (unsigned int)v.ovf_base;
-      cnt = (unsigned int)st.n_ovf[LD_TAB_PARITY(v, st.frame_count)];
-    }
+    knn_probe_cells<Tune>(v, st, hl, cx, cy, cz, qx, qy, qz, cells, bits, tmask, start, cnt, lb);
     DBG_STAMP(v, dbgb, 1, 2); DBG_QSTAMP(2);
     // Pruning bound B: an upper bound of the query's fifth-nearest distance (never above the 1.0 gate: points at
     // >= 1.0 cannot be part of a match, :324); a segment is skipped only if lb > B, so the result is exact.
@@ -1718,7 +1800,7 @@ __device__ __forceinline__ void knn_block(const DevView& v, int s, StreamState& 
     }   // (!reranked)
     else d5 = d5_r;
     DBG_STAMP(v, dbgb, 1, 5); DBG_QSTAMP(5);
-    if (d5 < 1.0f) {                                 // :324 (inf when < 5 candidates)
+    if (d5 < 1.0f && !(kPre && reranked)) {          // :324 (inf when < 5 candidates)
       const int mypos = hl == 0 ? pos5[0] : hl == 1 ? pos5[1] : hl == 2 ? pos5[2] : hl == 3 ? pos5[3] : pos5[4];
       if (hl < 5) {
         const float4 m = sp[mypos];
@@ -1733,6 +1815,7 @@ __device__ __forceinline__ void knn_block(const DevView& v, int s, StreamState& 
     v.knn_save_q[(size_t)s * v.edge_cap + e] = make_float4(qx, qy, qz, d5);
     if (!active && v.knn_save_g) v.knn_save_g[(size_t)s * v.edge_cap + e] = 0.f;       // (no query: nothing to re-rank)
   }
+  if (!kTail) return;          // (overlapped pass: the line gates / partial sums of the workgroup's two blocks run side by side, knn_tail_dual)
   __syncthreads();
   DBG_STAMP(v, dbgb, 1, 6); DBG_QSTAMP(6);
   if (kKnnThreads < 256 && v.knn_nn) {
@@ -1843,6 +1926,89 @@ __device__ __forceinline__ void knn_block(const DevView& v, int s, StreamState& 
   }
 }
 
+// Overlapped second pass: line gates and partial sums of the workgroup's two query blocks side by side (the same steps as
+// the tail of knn_block, which runs them for one block: there waves 2 and 3 idle while lanes 0..7 of wave 0 run the
+// gates and lanes 0..7 of wave 1 the residual blocks; here block A uses waves 0 / 1 and block B waves 2 / 3 — after the
+// first solve's result has arrived this tail IS the launch's critical path).  Results leave as write-through stores.
+template <int kKnnThreads>
+__device__ __forceinline__ void knn_tail_dual(const DevView& v, int s, int outer_it, int eb, int bvA, int bvB, bool haveB, int E,
+                                              KnnShared<kKnnThreads / kKnnGroup>& shA, KnnShared<kKnnThreads / kKnnGroup>& shB, const double* qt) {
+  constexpr int kKnnQueries = kKnnThreads / kKnnGroup;
+  static_assert(kKnnThreads == 256, "two blocks of 8 queries on four waves");
+  const int grp = threadIdx.x / kKnnGroup, hl = threadIdx.x & (kKnnGroup - 1);
+  const int half = (int)threadIdx.x >> 7, t = (int)threadIdx.x & 127;
+  KnnShared<kKnnQueries>& sh = half ? shB : shA;
+  const int bv = half ? bvB : bvA;
+  const bool live = half ? haveB : true;
+  if (t < kKnnQueries && live) {
+    const int q = t;
+    const int eq = bv * kKnnQueries + q;
+    bool valid = (eq < E) && (sh.res[q][0] != 0);
+    float nx[5], ny[5], nz[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) { nx[j] = sh.nn[q][j * 3]; ny[j] = sh.nn[q][j * 3 + 1]; nz[j] = sh.nn[q][j * 3 + 2]; }
+    if (valid) valid = line_gate(nx, ny, nz);                                                                 // :325-344
+    if (eq < E) {
+      const float4 oa = valid ? make_float4(nx[0], ny[0], nz[0], 1.0f) : make_float4(0, 0, 0, 0);              // :351-353
+      const float4 ob = valid ? make_float4(nx[1], ny[1], nz[1], 0.0f) : make_float4(0, 0, 0, 0);              // :355-357
+      const int2 oi = valid ? make_int2(sh.res[q][1], sh.res[q][2]) : make_int2(-1, -1);
+      wt_store_f4(v.corr_a + (size_t)s * v.edge_cap + eq, oa);
+      wt_store_f4(v.corr_b + (size_t)s * v.edge_cap + eq, ob);
+      wt_store_u64(v.corr_idx + ((size_t)s * 2 + outer_it) * v.edge_cap + eq, ((unsigned long long)(unsigned int)oi.y << 32) | (unsigned int)oi.x);
+    }
+    const unsigned long long vb = __ballot(valid);
+    if (q == 0) wt_store_u8(&v.corr_mask[((size_t)s * 2 + outer_it) * v.knn_blocks + bv], (unsigned char)vb);   // bit q = query q accepted
+    sh.res[q][3] = valid ? 1 : 0;
+  } else if (t >= 64 && t < 64 + kKnnQueries && live) {
+    // the residual block of every query that found five neighbours, at the finalising solve's start point (see knn_block)
+    const int q = t - 64;
+    const int eq = bv * kKnnQueries + q;
+    double flag = 0.0;
+    if (eq < E && sh.res[q][0] != 0) {
+      double Rm[12], pq[4], pt[3];
+#pragma unroll
+      for (int i = 0; i < 4; i++) pq[i] = qt[i];
+#pragma unroll
+      for (int i = 0; i < 3; i++) pt[i] = qt[4 + i];
+      iso_from_qt(pq, pt, Rm);
+      const float4 pe = v.edges[((size_t)eb * v.n_streams + s) * v.edge_cap + eq];
+      const double p[3] = {(double)pe.x, (double)pe.y, (double)pe.z};       // :347-349 sensor frame
+      const double a[3] = {(double)sh.nn[q][0], (double)sh.nn[q][1], (double)sh.nn[q][2]};
+      const double b[3] = {(double)sh.nn[q][3], (double)sh.nn[q][4], (double)sh.nn[q][5]};
+      double J[18], rs[3], rho0, rho1;
+      const bool ok = residual_block(Rm, p, a, b, v.min_range, v.max_range, J, rs, &rho0, &rho1);
+#pragma unroll
+      for (int i = 0; i < 18; i++) sh.blk[q][i] = J[i];
+      sh.blk[q][18] = rs[0]; sh.blk[q][19] = rs[1]; sh.blk[q][20] = rs[2]; sh.blk[q][21] = rho0; sh.blk[q][22] = rho1;
+      flag = ok ? 1.0 : 2.0;
+    }
+    sh.blk[q][23] = flag;
+  }
+  __syncthreads();
+  // entry hl of every block's contribution, by lane hl of the 32-lane group with the query's number (both blocks)
+#pragma unroll
+  for (int b = 0; b < 2; b++) {
+    if (b == 1 && !haveB) break;
+    KnnShared<kKnnQueries>& shb = b ? shB : shA;
+    if (hl < kAccN) {
+      const double flag = shb.res[grp][3] ? shb.blk[grp][23] : 0.0;     // (gate's verdict, block's finiteness)
+      double x = 0.0;
+      if (flag == 1.0) x = residual_entry(shb.blk[grp], shb.blk[grp] + 18, shb.blk[grp][21], shb.blk[grp][22], hl);
+      else if (flag == 2.0 && hl == 28) x = 1.0;            // non-finite block: counted, contributes nothing else
+      shb.part[grp][hl] = x;
+    } else if (hl == kAccN) {
+      shb.part[grp][hl] = shb.res[grp][3] ? 1.0 : 0.0;      // entry 29: accepted correspondences (:346)
+    }
+  }
+  __syncthreads();
+  if (t <= kAccN && live) {
+    double x = 0.0;
+#pragma unroll
+    for (int q = 0; q < kKnnQueries; q++) x += sh.part[q][t];      // fixed order: deterministic
+    wt_store_u64(&v.knn_part[(((size_t)s * 2 + outer_it) * v.knn_blocks + bv) * 32 + t], (unsigned long long)__double_as_longlong(x));
+  }
+}
+
 // grid.x = v.knn_grid workgroups per stream (+ the streamed rebuild's ALLOC workgroups on the second pass): workgroup b
 // takes the query blocks b, b + knn_grid, ... below ceil(E / queries) — the grid is sized for the usual edge count
 // (half of the capacity), not for edge_cap: on lock-step batches two thirds of an edge_cap-sized grid were workgroups
@@ -1851,7 +2017,7 @@ __device__ __forceinline__ void knn_block(const DevView& v, int s, StreamState& 
 // launched on stream_k beside the scan's first solve, seq = the launch sequence number the flags carry.
 template <int kKnnThreads, bool kOv>
 __device__ __forceinline__ void knn_pass(const DevView& v, int s, int bxi, int byi, int outer_it, int eb, unsigned int wait_edges,
-                                         unsigned int signal_odo, unsigned int seq, KnnShared<kKnnThreads / kKnnGroup>& sh, double* sh_ov) {
+                                         unsigned int signal_odo, unsigned int seq, KnnShared<kKnnThreads / kKnnGroup>& sh, KnnShared<kKnnThreads / kKnnGroup>& sh2, double* sh_ov) {
   constexpr int kKnnQueries = kKnnThreads / kKnnGroup;
   StreamState& st = v.state[s];
   if (kOv) {
@@ -1914,20 +2080,25 @@ __device__ __forceinline__ void knn_pass(const DevView& v, int s, int bxi, int b
   float4 p_second = make_float4(0.f, 0.f, 0.f, 0.f);
   if (kOv) {
     // everything the two blocks need apart from the solve's result; then wait for that
-    const int stab = s + LD_TAB_PARITY(v, st.frame_count) * v.n_streams;
-    const float4* sp = v.sorted_pts + (size_t)stab * v.sorted_cap;
-    const int hl = threadIdx.x & (kKnnGroup - 1);
-    knn_prefetch(v, s, e_first, hl, sp, pre1);
-    if (second) {
-      p_second = v.edges[((size_t)eb * v.n_streams + s) * v.edge_cap + (e_second < v.edge_cap ? e_second : v.edge_cap - 1)];
-      knn_prefetch(v, s, e_second, hl, sp, pre2);
-    }
+    if (second) p_second = v.edges[((size_t)eb * v.n_streams + s) * v.edge_cap + (e_second < v.edge_cap ? e_second : v.edge_cap - 1)];
+    knn_presearch<kKnnThreads>(v, s, st, e_first, E, sh, pre1);
+    if (second) knn_presearch<kKnnThreads>(v, s, st, e_second, E, sh2, pre2);
+    else pre2.gsq = 0.f;
     if (!ov_wait_pose(v, s, bxi % kOvReplicas, seq, sh_ov, &st.status)) return;
     OV_STAMP(v, threadIdx.x == 0 && bxi == 0, 10); OV_STAMP(v, threadIdx.x == 0 && bxi == v.knn_grid - 1, 14);
 #pragma unroll
     for (int i = 0; i < 12; i++) T[i] = sh_ov[i];
   }
-  knn_block<kKnnThreads, kOv>(v, s, st, outer_it, eb, bxi, E, sh, p_first, T, pre1, kOv ? sh_ov + 12 : nullptr);
+  if constexpr (kOv) {
+    // both blocks' queries, then their gates and partial sums side by side
+    knn_block<kKnnThreads, true, false>(v, s, st, outer_it, eb, bxi, E, sh, p_first, T, pre1, sh_ov + 12);
+    if (second) knn_block<kKnnThreads, true, false>(v, s, st, outer_it, eb, bv2, E, sh2, p_second, T, pre2, sh_ov + 12);
+    else if (bv2 < v.knn_blocks && threadIdx.x == 0) wt_store_u8(&v.corr_mask[((size_t)s * 2 + outer_it) * v.knn_blocks + bv2], 0);
+    __syncthreads();
+    knn_tail_dual<kKnnThreads>(v, s, outer_it, eb, bxi, bv2, second, E, sh, sh2, sh_ov + 12);
+    return;
+  }
+  knn_block<kKnnThreads, false>(v, s, st, outer_it, eb, bxi, E, sh, p_first, T, pre1, nullptr);
   if (bv2 >= v.knn_blocks) return;
   if (!second) {
     if (threadIdx.x == 0) { unsigned char* cm = &v.corr_mask[((size_t)s * 2 + outer_it) * v.knn_blocks + bv2]; if (kOv) wt_store_u8(cm, 0); else *cm = 0; }
@@ -1935,29 +2106,27 @@ __device__ __forceinline__ void knn_pass(const DevView& v, int s, int bxi, int b
   }
   __syncthreads();                          // (the second block reuses the LDS)
   double T2[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // (reloaded: kept live across the first block the pose would cost 24 VGPRs)
-  if (kOv) {
-#pragma unroll
-    for (int i = 0; i < 12; i++) T2[i] = sh_ov[i];
-  } else if (Tune::kHoistLoads) {
+  if (Tune::kHoistLoads) {
     p_second = v.edges[((size_t)eb * v.n_streams + s) * v.edge_cap + (e_second < v.edge_cap ? e_second : v.edge_cap - 1)];
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int i = 0; i < 12; i++) T2[i] = st.odom[i];
   }
-  knn_block<kKnnThreads, kOv>(v, s, st, outer_it, eb, bv2, E, sh, p_second, T2, pre2, kOv ? sh_ov + 12 : nullptr);
+  knn_block<kKnnThreads, false>(v, s, st, outer_it, eb, bv2, E, sh, p_second, T2, pre2, nullptr);
 }
 
 template <int kKnnThreads, bool kOv = false>
 __global__ __launch_bounds__(kKnnThreads, (kKnnThreads >= 256 ? 1 : LIODOM_TUNE_B_WAVES)) void k_knn(DevView v, int s0, int outer_it, int eb, unsigned int wait_edges, unsigned int signal_odo, unsigned int seq) {
   constexpr int kKnnQueries = kKnnThreads / kKnnGroup;
-  __shared__ KnnShared<kKnnQueries> sh;
+  __shared__ KnnShared<kKnnQueries> shs[kOv ? 2 : 1];      // (overlapped pass: one per query block — their tails run side by side)
+  KnnShared<kKnnQueries>& sh = shs[0];
   __shared__ double sh_ov[kOv ? 20 : 1];       // overlapped pass: the first solve's odom[12], q[4], t[3]
   int bxi = (int)blockIdx.x, byi = (int)blockIdx.y;
   xcd_remap(bxi, byi);
   const int s = s0 + byi;
   if (kOv) { OV_STAMP(v, threadIdx.x == 0 && bxi == 0, 8); OV_STAMP(v, threadIdx.x == 0 && bxi == v.knn_grid - 1, 12); }
   else if (outer_it == 0) OV_STAMP(v, threadIdx.x == 0 && bxi == 0, 16);
-  knn_pass<kKnnThreads, kOv>(v, s, bxi, byi, outer_it, eb, wait_edges, signal_odo, seq, sh, sh_ov);
+  knn_pass<kKnnThreads, kOv>(v, s, bxi, byi, outer_it, eb, wait_edges, signal_odo, seq, sh, shs[kOv ? 1 : 0], sh_ov);
   if (kOv) ov_signal_knn_done(v, s, bxi, seq);       // (every exit of the pass is workgroup-uniform)
   if (kOv) { OV_STAMP(v, threadIdx.x == 0 && bxi == 0, 11); OV_STAMP(v, threadIdx.x == 0 && bxi == v.knn_grid - 1, 15); }
   else if (outer_it == 0) OV_STAMP(v, threadIdx.x == 0 && bxi == v.knn_grid - 1, 17);
@@ -2694,7 +2863,8 @@ __global__ __launch_bounds__(256) void k_window_insert(DevView v, int s0, int eb
 //                     LocalMapManager::addPointCloud :34-60) into their cells, under the window indices they will have
 //                     after the append; PAD: every edge of the new scan, transformed with the PREDICTED pose, reserves
 //                     one place in each cell it can reach if the solve moves it by less than rebuild_delta per axis
-//   k_knn      it 1   ALLOC: start of every occupied cell; room = counted + padded
+//   k_knn      it 1   ALLOC: start of every occupied cell; room = counted + padded (when that pass is overlapped with the first
+//                     solve on its own stream: k_rebuild_alloc, a launch of its own between the two solve launches)
 //   k_lm_solve it 1   SCATTER the kept points to start + rank; APPEND: the first workgroups wait for the solved pose
 //                     (publish_final_pose), transform the scan's edges (laser_odometry.cc:231-232), store them in the new
 //                     frame's window slot (:235) and put every point into its cell at start + count++ — the place its

@@ -620,21 +620,27 @@ def test_knn_fast_path_equals_exact_list_path(orc, synth, monkeypatch):
     with sorted (distance, index) lists.  LIODOM_KNN_EXACT_ONLY=1 sends EVERY query through the list path;
     the second pass of a scan by default re-ranks the candidates the first pass kept and accepts that only when a guard
     distance proves that no other map point can be among the five nearest (LIODOM_KNN_SAVE=1: it only takes its
-    pruning bound from the first pass's fifth-nearest distance; =0: it searches like the first pass).  Poses, match
+    pruning bound from the first pass's fifth-nearest distance; =0: it searches like the first pass); on one-stream handles
+    the second pass is overlapped with the first solve and re-ranks the result of an exact search around the first
+    pass's query instead (LIODOM_KNN_OVERLAP=0: not overlapped).  Poses, match
     counts and correspondence indices must be bit-identical in all configurations, also with large pose corrections
     between the passes (many re-rankings that cannot be certified)."""
     H, W, R, epr, P, K = 16, 900, 6, 10, 5, 14
-    modes = {"default": {}, "exact_only": {"LIODOM_KNN_EXACT_ONLY": "1"}, "bound_only": {"LIODOM_KNN_SAVE": "1"}, "no_saved_bound": {"LIODOM_KNN_SAVE": "0"}}
+    modes = {"default": {}, "exact_only": {"LIODOM_KNN_EXACT_ONLY": "1"}, "bound_only": {"LIODOM_KNN_SAVE": "1"}, "no_saved_bound": {"LIODOM_KNN_SAVE": "0"},
+             "no_overlap": {"LIODOM_KNN_OVERLAP": "0"}, "no_overlap_exact_only": {"LIODOM_KNN_OVERLAP": "0", "LIODOM_KNN_EXACT_ONLY": "1"}}
     for yaw, speed in ((0.5, 0.1), (3.0, 0.6)):
         cfg = synth.make_cfg(H, W, 0, yaw_rate_deg=yaw, speed=speed)
         scans = [synth.scan(cfg, 6, k)[0] for k in range(K)]
         res = {}
         for mode, env in modes.items():
-            for name in ("LIODOM_KNN_EXACT_ONLY", "LIODOM_KNN_SAVE"):
+            for name in ("LIODOM_KNN_EXACT_ONLY", "LIODOM_KNN_SAVE", "LIODOM_KNN_OVERLAP"):
                 monkeypatch.delenv(name, raising=False)
             for name, val in env.items():
                 monkeypatch.setenv(name, val)
             po, g = mk(orc, H, W, 0, R, epr, P)
+            # (by default the second pass of a scan runs beside its first solve on a HIP stream of its own and re-ranks what
+            #  an exact search around the first pass's query collected meanwhile; LIODOM_KNN_OVERLAP=0: on the odometry stream)
+            assert g.modes()["knn_overlap"] == ("0" if "LIODOM_KNN_OVERLAP" in env else "1")
             out = []
             for k in range(K):
                 pose, info = g.process_scan(scans[k], H, W)
@@ -643,7 +649,7 @@ def test_knn_fast_path_equals_exact_list_path(orc, synth, monkeypatch):
                 out.append((pose.copy(), tuple(info.matches), v0.copy(), a0.copy(), b0.copy(), v1.copy(), a1.copy(), b1.copy()))
             res[mode] = out
             g.close()
-        for mode in ("exact_only", "bound_only", "no_saved_bound"):
+        for mode in ("exact_only", "bound_only", "no_saved_bound", "no_overlap", "no_overlap_exact_only"):
             for k in range(K):
                 assert np.array_equal(res["default"][k][0].view(np.uint64), res[mode][k][0].view(np.uint64)), (mode, yaw, k)
                 assert res["default"][k][1] == res[mode][k][1], (mode, yaw, k)
