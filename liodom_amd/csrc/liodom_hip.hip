@@ -68,6 +68,8 @@ struct liodom_handle {
   bool ov_ok = false;                // the handle qualifies for it (one stream, streamed rebuild, the pass leaves 2/3 of the wave slots free)
   unsigned int ov_seq = 0;           // launch sequence number its flags carry
   hipEvent_t ev_ov = nullptr;        // recorded on the odometry stream in front of the first overlapped scan after scans that were not
+  bool stream_c_shared = false;      // stream_c is stream_k
+  bool ov_suppress = false;          // host-fed replay: the host's enqueue work per scan is the limit there, and the overlapped pass costs two more launches
   bool ov_prev = false;              // the previous scan of this handle was overlapped
   int ov_warm = 0;                   // scans enqueued so far, up to kOvWarmScans (the first ones run every kernel of the chain for the first time)
   hipStream_t stream_x = nullptr;    // extraction side (liodom_extract_edges, and the next scan's extraction in the pipelined replay)
@@ -234,7 +236,7 @@ int enqueue_odometry(liodom_handle* h, int eb, int s0, int count, unsigned int w
   // the kernel; it needs kernels of different streams to run side by side (as the flags of the pipelined replay do) and the
   // GPU mostly to itself: not while a second handle lives in this process (its waiting workgroups and ours could end up
   // behind each other in a shared hardware queue), not under per-kernel profiling.
-  const bool overlap_ok = early && h->ov_ok && h->use_flags && !h->profiling && count == 1 && g_live_handles.load() <= 1;
+  const bool overlap_ok = early && h->ov_ok && h->use_flags && !h->profiling && !h->ov_suppress && count == 1 && g_live_handles.load() <= 1;
   // The first scans of a handle are not overlapped: their launches are the first of every kernel of the chain on this queue
   // (scratch set-up, code upload), which can hold the odometry stream back for longer than a waiting kernel is willing to
   // poll.  At a switch to overlapped scans stream_k waits (event) for the odometry stream to have drained, so that its
@@ -504,8 +506,6 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
                 : hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) { g_last_error = "hipStreamCreate failed"; return fail(LIODOM_ERR_HIP); }
   if (hipEventCreateWithFlags(&h->ev_ov, hipEventDisableTiming) != hipSuccess) { g_last_error = "hipEventCreate failed"; return fail(LIODOM_ERR_HIP); }
   if (hipEventCreateWithFlags(&h->pose_event, hipEventDisableTiming) != hipSuccess) { g_last_error = "hipEventCreate failed"; return fail(LIODOM_ERR_HIP); }
-  if ((use_prio ? hipStreamCreateWithPriority(&h->stream_k, hipStreamNonBlocking, prio_greatest)
-                : hipStreamCreateWithFlags(&h->stream_k, hipStreamNonBlocking)) != hipSuccess) { g_last_error = "hipStreamCreate failed"; return fail(LIODOM_ERR_HIP); }
   // (extraction: one level below the odometry stream, not the lowest: kernels of the odometry stream may wait in-kernel for it)
   const int prio_x = (prio_least - prio_greatest >= 2) ? prio_greatest + 1 : prio_least;
   if ((use_prio ? hipStreamCreateWithPriority(&h->stream_x, hipStreamNonBlocking, prio_x)
@@ -722,6 +722,10 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, config->device);
     h->ov_ok = v.early_rebuild && S == 1 && v.knn_partials && (long long)v.knn_grid * 4 * 3 <= (long long)cus * 24;
     if (const char* e = std::getenv("LIODOM_KNN_OVERLAP")) { if (std::atoi(e) == 0) h->ov_ok = false; }
+    // (the stream exists only on handles that use it: HIP multiplexes its streams onto a few hardware queues, and one more
+    //  stream made the host-fed replay's copy stream share a queue — 11.3k -> 7.5k scans/s on every workload)
+    if (h->ov_ok && (use_prio ? hipStreamCreateWithPriority(&h->stream_k, hipStreamNonBlocking, prio_greatest)
+                              : hipStreamCreateWithFlags(&h->stream_k, hipStreamNonBlocking)) != hipSuccess) { g_last_error = "hipStreamCreate failed"; return fail(LIODOM_ERR_HIP); }
   }
   ALLOC(h->d_view, 1, 0);
   if (hipMemcpy(h->d_view, &h->v, sizeof(DevView), hipMemcpyHostToDevice) != hipSuccess) { g_last_error = "DevView upload failed"; return fail(LIODOM_ERR_HIP); }
@@ -752,7 +756,7 @@ void liodom_destroy(liodom_handle_t* h) {
   for (auto& e : h->ev_pool) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
   if (h->pose_event) hipEventDestroy(h->pose_event);
   for (int b = 0; b < kEdgePipeBufs; b++) { if (h->ev_edges[b]) hipEventDestroy(h->ev_edges[b]); if (h->ev_free[b]) hipEventDestroy(h->ev_free[b]); }
-  if (h->stream_c) { hipStreamSynchronize(h->stream_c); hipStreamDestroy(h->stream_c); }
+  if (h->stream_c && !h->stream_c_shared) { hipStreamSynchronize(h->stream_c); hipStreamDestroy(h->stream_c); }
   for (int b = 0; b < 3; b++) { if (h->ev_up[b]) hipEventDestroy(h->ev_up[b]); if (h->ev_xdone[b]) hipEventDestroy(h->ev_xdone[b]); }
   if (h->stream_x) hipStreamDestroy(h->stream_x);
   if (h->stream) hipStreamDestroy(h->stream);
@@ -841,7 +845,7 @@ static int wait_pose(liodom_handle_t* h, int s0, int count, double* pose_out, li
     // skipped the scan, the published pose is the prediction.  Fail loudly and stop relying on co-scheduled streams.
     (void)hipStreamSynchronize(h->stream_x);
     (void)hipStreamSynchronize(h->stream);
-    (void)hipStreamSynchronize(h->stream_k);
+    if (h->stream_k) (void)hipStreamSynchronize(h->stream_k);
     h->use_flags = false;
     h->pf_slot = -1;
     for (int b = 0; b < kEdgePipeBufs; b++) { h->ev_free_valid[b] = false; h->eb_reader[b] = 0; }
@@ -1057,7 +1061,12 @@ static int upload_slot_async(liodom_handle_t* h, int slot, const float* host, in
   // slot is free once the extraction that last read it has completed, and its extraction waits for the upload
   const int r = slot % 3;
   if (!h->stream_c) {
-    HIP_TRY(hipStreamCreateWithFlags(&h->stream_c, hipStreamNonBlocking));
+    // HIP multiplexes its streams onto a few hardware queues: a handle that owns stream_k (overlapped second kNN pass) has
+    // no queue left for a copy stream of its own — with one, the uploads of the host-fed replay ended up behind other
+    // streams' launches (11.3k -> 7.5k scans/s).  That replay does not overlap the pass (ov_suppress), so stream_k is
+    // idle in it and carries the uploads.
+    if (h->stream_k) { h->stream_c = h->stream_k; h->stream_c_shared = true; }
+    else HIP_TRY(hipStreamCreateWithFlags(&h->stream_c, hipStreamNonBlocking));
     for (int b = 0; b < 3; b++) {
       HIP_TRY(hipEventCreateWithFlags(&h->ev_up[b], hipEventDisableTiming));
       HIP_TRY(hipEventCreateWithFlags(&h->ev_xdone[b], hipEventDisableTiming));
@@ -1136,6 +1145,11 @@ int liodom_replay_host(liodom_handle_t* h, const float* xyzi_base, int64_t scan_
   SideLocks lk(h, true, true);
   int rc = drain_pipeline(h);
   if (rc) return rc;
+  // Measured (MI355X, HDL-64 shape): with uploads the loop is bound by the host's enqueue work (an upload, three event
+  // operations, six extraction and five odometry launches per scan: 88 us); the overlapped second kNN pass adds a gate and an
+  // ALLOC launch on a third stream and made it 133 us.  So not here.
+  struct Suppress { liodom_handle* h; ~Suppress() { h->ov_suppress = false; } } suppress{h};
+  h->ov_suppress = true;
   auto out_p = [&](int i) { return poses_out ? poses_out + (size_t)i * h->S * 7 : nullptr; };
   auto out_i = [&](int i) { return infos_out ? infos_out + (size_t)i * h->S : nullptr; };
   auto src = [&](int i) { return xyzi_base + (size_t)i * (size_t)h->S * (size_t)scan_stride_floats; };
