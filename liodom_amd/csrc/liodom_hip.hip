@@ -720,6 +720,7 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
     // (HDL-64: 352 workgroups x 4 waves = 1 408 of 6 144).  LIODOM_KNN_OVERLAP=0 keeps the pass on the odometry stream.
     int cus = 0;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, config->device);
+    // (measured with half of the slots allowed: Ouster-128, 704 workgroups = 2 816 waves, loses — 9.0k -> 8.4k scans/s)
     h->ov_ok = v.early_rebuild && S == 1 && v.knn_partials && (long long)v.knn_grid * 4 * 3 <= (long long)cus * 24;
     if (const char* e = std::getenv("LIODOM_KNN_OVERLAP")) { if (std::atoi(e) == 0) h->ov_ok = false; }
     // (the stream exists only on handles that use it: HIP multiplexes its streams onto a few hardware queues, and one more
