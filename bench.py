@@ -117,7 +117,7 @@ def roofline_8d(stats, n_streams, N, E, M, C, evals):
     HIP-event kernel time of the stage per step vs its bytes — e.g. extract = 16 N + 24 E for the three extraction
     passes + compaction together, whatever traffic the implementation's extra passes cause."""
     stats = {k: v for k, v in stats.items() if v[0]}
-    steps = max(1, stats.get("k_classify", (1, 0))[0])
+    steps = max(1, stats.get("k_ring_extract", stats.get("k_classify", (1, 0)))[0])      # (organised clouds have no k_classify launch: k_row_compact, booked as k_ring_scatter)
     out, tot_b, tot_us = {}, 0.0, 0.0
     for name, (kernels, fn) in STAGES_8D.items():
         us = sum(stats[k][1] for k in kernels if k in stats) / steps * 1e3
@@ -144,7 +144,7 @@ def roofline_from_stats(stats, n_streams, N, E, M, C, evals, workload="hdl64"):
     by = algorithmic_bytes(name, N, E, M, C, evals, streamed) * n_streams
     achieved = by / avg_s / 1e9 if avg_s > 0 else 0.0
     per_scan_bytes = sum(algorithmic_bytes(k, N, E, M, C, evals, streamed) * v[0] for k, v in stats.items())   # all launches
-    scans = max(1, stats.get("k_classify", (1, 0))[0])
+    scans = max(1, stats.get("k_ring_extract", stats.get("k_classify", (1, 0)))[0])
     return {
         "bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": measured_traffic(name, n_streams, workload),
