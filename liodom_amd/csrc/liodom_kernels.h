@@ -1099,8 +1099,8 @@ __device__ __forceinline__ void ov_wait_knn_done(const DevView& v, int s, unsign
   for (int b = (int)threadIdx.x; b < v.knn_grid; b += (int)blockDim.x) {
     unsigned int spins = 0;
     while ((int)(__hip_atomic_load((gu32*)(f + b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) < 0) {
-      __builtin_amdgcn_s_sleep(32);
-      if (++spins > 3000000u) { atomicOr(status, LIODOM_STATUS_PIPE_TIMEOUT); break; }
+      __builtin_amdgcn_s_sleep(4);
+      if (++spins > 6000000u) { atomicOr(status, LIODOM_STATUS_PIPE_TIMEOUT); break; }
     }
   }
   // (no acquire fence — an L2 invalidate per waiting workgroup: this launch started, with clean caches, before the pass wrote
