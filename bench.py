@@ -215,8 +215,11 @@ def main():
         rep.close()
         sys.exit(2)
     ndev = la.device_count()
-    if ndev > 0 and local_rank >= ndev:      # more ranks than GPUs (smoke runs): share devices
+    if ndev > 0 and world > ndev:            # more ranks than GPUs (smoke runs): share devices
         local_rank = local_rank % ndev
+        # processes that share a GPU cannot see each other's handles: the in-kernel waits of the overlapped second kNN pass
+        # are meant for a GPU one handle has to itself (the library switches it off for a second handle in ONE process)
+        os.environ.setdefault("LIODOM_KNN_OVERLAP", "0")
     orig_affinity = os.sched_getaffinity(0)
     rep.pin_cpus(local_rank)                 # host thread near the GPU's NUMA node (busy-polls the result record)
 
