@@ -3246,8 +3246,35 @@ __device__ __forceinline__ float4 win_point(const DevView& v, int s, int nf, con
   return v.win_pts[((size_t)s * v.prev_frames + w.sslot[lo]) * v.edge_cap + (m - w.sbase[lo])];
 }
 __device__ __forceinline__ bool point_ok(const float4& p) {
-  return ld_isfinite((double)p.x) && ld_isfinite((double)p.y) && ld_isfinite((double)p.z) &&
-         fabsf(p.x) < 1.0e9f && fabsf(p.y) < 1.0e9f && fabsf(p.z) < 1.0e9f;
+  // finite and below 1e9 in magnitude (NaN and inf fail the comparisons: no separate finiteness test needed)
+  return fabsf(p.x) < 1.0e9f && fabsf(p.y) < 1.0e9f && fabsf(p.z) < 1.0e9f;
+}
+
+// Runs of equal cell keys among the valid lanes of a wave (consecutive lanes hold consecutive window points, i.e.
+// neighbouring edges of a frame: ~8 points per run).  One lane per run — its head — performs the LDS atomic for the whole
+// run; the others take the head's result by a lane read.  Without this the 64 lanes of an atomic instruction queue on a
+// handful of addresses: 256 lock-step streams spent 70 us of the build's 174 in the counting pass.
+struct KeyRun {
+  bool head;        // this lane is the first of its run (valid lanes only)
+  int head_lane;    // lane of the run's head
+  int rank;         // position inside the run
+  int len;          // length of the run (meaningful on the head)
+};
+__device__ __forceinline__ KeyRun wave_key_runs(bool valid, unsigned long long key, int lane) {
+  const unsigned long long vm = __ballot(valid);
+  const unsigned int klo = (unsigned int)key, khi = (unsigned int)(key >> 32);
+  const unsigned int plo = (unsigned int)__shfl_up((int)klo, 1), phi = (unsigned int)__shfl_up((int)khi, 1);
+  const bool prev_valid = lane > 0 && ((vm >> (lane - 1)) & 1ull);
+  KeyRun r;
+  r.head = valid && (!prev_valid || plo != klo || phi != khi);
+  const unsigned long long hm = __ballot(r.head);
+  const unsigned long long upto = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);        // lanes 0 .. lane
+  const unsigned long long below = hm & upto;
+  r.head_lane = below ? 63 - __clzll((long long)below) : lane;
+  r.rank = lane - r.head_lane;
+  const unsigned long long stop = (hm | ~vm) & ~upto;                                   // next head or invalid lane above
+  r.len = (stop ? __ffsll((long long)stop) - 1 : 64) - lane;
+  return r;
 }
 
 constexpr int kLdsSlots = 8192;
@@ -3293,6 +3320,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_hash_build(DevView v, int s0,
   const int M = Mw + (v.mapping ? st.n_recv : 0);      // window ++ received map (:310-314)
   const float4* recv = v.recv_pts + (size_t)s * v.recv_cap;
   const bool filt = filter_active(v, st);
+  OV_STAMP(v, tid == 0 && s == 0, 19);
   win_index_load(v, s, nf, w, tid, kBuildThreads);
   if (tid == 0) { sh_used = 0; sh_over = 0; }
   if (!filt) for (int i = tid; i < kLdsSlots; i += kBuildThreads) { lkey[i] = kEmptyKey; lcnt[i] = 0; }
@@ -3314,24 +3342,29 @@ __global__ __launch_bounds__(kBuildThreads) void k_hash_build(DevView v, int s0,
     }
     return;
   }
+  OV_STAMP(v, tid == 0 && s == 0, 20);
   // ---- insert + count in LDS (kBuildUnroll point loads in flight per thread) ----
   const unsigned int lmask = kLdsSlots - 1;
   int jc = 0;                      // frame cursor: this thread's m only grows
-  for (int m0 = tid; m0 < M; m0 += kBuildUnroll * kBuildThreads) {
+  const int lane = tid & 63;
+  for (int m0 = tid; m0 - lane < M; m0 += kBuildUnroll * kBuildThreads) {
     float4 pt[kBuildUnroll];
 #pragma unroll
     for (int k = 0; k < kBuildUnroll; k++) {
       const int m = m0 + k * kBuildThreads;
+      pt[k] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (m < M) pt[k] = m < Mw ? window_point_produce(v, s, st, eb, w, nf, m, &jc) : recv[m - Mw];
     }
 #pragma unroll
     for (int k = 0; k < kBuildUnroll; k++) {
+      // (whole waves walk this loop together: m0 - lane is the same for all lanes, the per-lane tests are masks)
       const int m = m0 + k * kBuildThreads;
-      if (m >= M) continue;
-      int found = -1;
-      if (point_ok(pt[k])) {
-        const unsigned long long key = pack_cell((int)floorf(pt[k].x * kCellInv), (int)floorf(pt[k].y * kCellInv), (int)floorf(pt[k].z * kCellInv));
+      const bool ok = m < M && point_ok(pt[k]);
+      const unsigned long long key = pack_cell((int)floorf(pt[k].x * kCellInv), (int)floorf(pt[k].y * kCellInv), (int)floorf(pt[k].z * kCellInv));
+      const KeyRun run = wave_key_runs(ok, key, lane);
+      if (run.head) {
         unsigned int h = hash_cell(key, lmask);
+        int found = -1;
         for (int probe = 0; probe < kLdsSlots; probe++) {
           const unsigned long long prev = atomicCAS(&lkey[h], kEmptyKey, key);
           if (prev == kEmptyKey) { if (atomicAdd(&sh_used, 1) >= v.lds_cells_max) sh_over = 1; found = (int)h; break; }
@@ -3339,9 +3372,8 @@ __global__ __launch_bounds__(kBuildThreads) void k_hash_build(DevView v, int s0,
           if (*(volatile int*)&sh_over) break;      // the global-table fallback redoes everything
           h = (h + 1) & lmask;
         }
-        if (found >= 0) prank[m] = (int)atomicAdd(&lcnt[found], 1u);   // rank inside the cell
+        if (found >= 0) atomicAdd(&lcnt[found], (unsigned int)run.len);      // the whole run's count
       }
-      pcell[m] = found;
     }
   }
   __syncthreads();
@@ -3397,6 +3429,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_hash_build(DevView v, int s0,
     }
     return;
   }
+  OV_STAMP(v, tid == 0 && s == 0, 21);
   // ---- exclusive prefix of the counts over the slots (8 consecutive slots per thread) ----
   {
     constexpr int PER = kLdsSlots / kBuildThreads;   // 8
@@ -3414,27 +3447,42 @@ __global__ __launch_bounds__(kBuildThreads) void k_hash_build(DevView v, int s0,
     for (int k = 0; k < PER; k++) { lstart[tid * PER + k] = (unsigned int)run; run += (int)c[k]; }
   }
   __syncthreads();
+  OV_STAMP(v, tid == 0 && s == 0, 22);
   // ---- scatter to cell-contiguous order: position = start of the cell + rank of the point ----
+  // The cell of a point is looked up again (a read-only probe by the run's head) and its position taken from the cell's
+  // cursor — lstart[h], advanced by the run's length — instead of a (cell, rank) pair written by the counting pass and
+  // read back here: 16 B per point less traffic in a pass that is bandwidth-bound on 256 lock-step streams (3.6 TB/s).
   jc = 0;
-  for (int m0 = tid; m0 < M; m0 += kBuildUnroll * kBuildThreads) {
+  for (int m0 = tid; m0 - lane < M; m0 += kBuildUnroll * kBuildThreads) {
     float4 pt[kBuildUnroll];
-    int hc[kBuildUnroll], rk[kBuildUnroll];
 #pragma unroll
     for (int k = 0; k < kBuildUnroll; k++) {
       const int m = m0 + k * kBuildThreads;
-      hc[k] = -1;
-      if (m < M) { hc[k] = pcell[m]; rk[k] = prank[m]; pt[k] = m < Mw ? win_point(v, s, nf, w, m, &jc) : recv[m - Mw]; }
+      pt[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < M) pt[k] = m < Mw ? win_point(v, s, nf, w, m, &jc) : recv[m - Mw];
     }
 #pragma unroll
     for (int k = 0; k < kBuildUnroll; k++) {
-      if (hc[k] < 0) continue;
-      v.sorted_pts[(size_t)s * v.map_cap + lstart[hc[k]] + (unsigned int)rk[k]] =
-          make_float4(pt[k].x, pt[k].y, pt[k].z, __int_as_float(m0 + k * kBuildThreads));
+      const int m = m0 + k * kBuildThreads;
+      const bool ok = m < M && point_ok(pt[k]);
+      const unsigned long long key = pack_cell((int)floorf(pt[k].x * kCellInv), (int)floorf(pt[k].y * kCellInv), (int)floorf(pt[k].z * kCellInv));
+      const KeyRun run = wave_key_runs(ok, key, lane);
+      unsigned int pos0 = 0xFFFFFFFFu;
+      if (run.head) {
+        unsigned int h = hash_cell(key, lmask);
+        int probe = 0;
+        while (lkey[h] != key && probe < kLdsSlots) { h = (h + 1) & lmask; probe++; }      // (inserted by the counting pass)
+        if (probe < kLdsSlots) pos0 = atomicAdd(&lstart[h], (unsigned int)run.len);
+      }
+      pos0 = (unsigned int)__shfl((int)pos0, run.head_lane);
+      if (ok && pos0 != 0xFFFFFFFFu) v.sorted_pts[(size_t)s * v.map_cap + pos0 + (unsigned int)run.rank] = make_float4(pt[k].x, pt[k].y, pt[k].z, __int_as_float(m));
     }
   }
+  __syncthreads();
+  OV_STAMP(v, tid == 0 && s == 0, 23);
   // ---- publish the table: slots [0, 8192) of the stream's global table + occupancy bits ----
   for (int i = tid; i < kLdsSlots; i += kBuildThreads) {
-    CellSlot o; o.key = lkey[i]; o.cnt = lcnt[i]; o.start = lstart[i];
+    CellSlot o; o.key = lkey[i]; o.cnt = lcnt[i]; o.start = lstart[i] - lcnt[i];      // (the scatter pass advanced the cursors to the cells' ends)
     cells[i] = o;
   }
   for (int i = tid; i < kLdsSlots / 32; i += kBuildThreads) {
@@ -3444,6 +3492,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_hash_build(DevView v, int s0,
     bits[i] = word;
   }
   if (tid == 0) { st.table_mask = lmask; st.n_used_tab[0] = 0; st.cursor = 0; st.n_search = M; st.n_filt = 0; }
+  OV_STAMP(v, tid == 0 && s == 0, 24);
 }
 
 // =============================================================================================

@@ -324,6 +324,34 @@ def sec_knntimes(H=64, W=1800, R=8, epr=10, P=20, K=40):
 
 
 SECTIONS["knntimes"] = sec_knntimes
+def sec_hbclocks(H=64, W=1800, R=8, epr=10, P=20, K=36):
+    """Phase stamps of k_hash_build (stream 0's workgroup) on a lock-step batch (instrumented build, debug bit 7)."""
+    import ctypes as C
+    os.environ.setdefault("LIODOM_DEBUG_CLOCKS", "128")
+    S = int(os.environ.get("HB_STREAMS", "256"))
+    cfg = synth.make_cfg(H, W, 0)
+    import liodom_amd as la
+    g = la.Liodom(la.make_params(scan_lines=H, scan_regions=R, edges_per_region=epr, prev_frames=P),
+                  la.make_config(n_streams=S, max_points=H * W, max_width=W, pose_log_capacity=K + 8))
+    g.alloc_resident(K)
+    scans = [synth.scan(cfg, 0, k)[0] for k in range(K)]
+    for s in range(S):
+        for k in range(K):
+            g.upload_scan(s, k, scans[k])
+    for k in range(K):
+        g.process_resident(k, H * W, H, W, readback=False, next_slot=(k + 1 if k + 1 < K else -1))
+    g.sync()
+    buf = (C.c_ulonglong * 512)()
+    g.L.liodom_debug_clocks.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+    g.L.liodom_debug_clocks(g.h, buf)
+    a = np.array(list(buf), dtype=np.int64)[448 + 19:448 + 25]
+    names = ["start", "table initialised", "insert + count done", "prefix done", "scatter done (after barrier)", "table published"]
+    for i in range(1, 6):
+        print("   %-30s +%7.2f us  (at %7.2f)" % (names[i], (a[i] - a[i - 1]) / 100.0, (a[i] - a[0]) / 100.0))
+    g.close()
+
+
+SECTIONS["hbclocks"] = sec_hbclocks
 SECTIONS["ovclocks"] = sec_ovclocks
 
 
@@ -370,7 +398,7 @@ SECTIONS["long"] = sec_long
 
 if __name__ == "__main__":
     names = sys.argv[1:] or ["extract", "odom", "odom64", "timing"]
-    if any(n in ("clocks", "knntimes", "ovclocks") for n in names):
+    if any(n in ("clocks", "knntimes", "ovclocks", "hbclocks") for n in names):
         _use_instrumented_library()
     for n in names:
         print("=" * 20, n)
