@@ -206,8 +206,9 @@ def sec_clocks(H=64, W=1800, R=8, epr=10, P=20, K=40):
     g.alloc_resident(K)
     for k in range(K):
         g.upload_scan(0, k, synth.scan(cfg, 0, k)[0])
+    serial = os.environ.get("CLK_SERIAL", "0") != "0"        # every scan alone on the GPU (no odometry of the previous scan beside the extraction)
     for k in range(K):
-        g.process_resident(k, H * W, H, W, readback=False)
+        g.process_resident(k, H * W, H, W, readback=serial)
     g.sync()
     buf = (C.c_ulonglong * 512)()
     g.L.liodom_debug_clocks.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
