@@ -1,0 +1,555 @@
+// kernels_lm.h — k_lm_solve: the Ceres-style solve, scan finalisation, in-launch exchanges.
+// Part of liodom_kernels.h (included there, inside namespace liodom_dev, in this order; not a standalone header).
+// =============================================================================================
+// k_lm_solve: one 512-thread workgroup per stream runs the whole Ceres-style solve.
+//   eval: every thread accumulates the 29-entry normal-equation accumulator over its edges
+//   (fused residual + analytic Jacobian + Huber), wavefront shfl butterfly, then a fixed-order
+//   cross-wave sum through LDS (deterministic, no atomics, no MFMA: this is a 6x6 reduction).
+//   Thread 0 runs the LM controller (liodom_math.h) between evaluations.
+//   finalize (second outer iteration, or the very first frame): pose log, constant-velocity
+//   prediction for the next scan, window bookkeeping, hash-generation counters.
+// =============================================================================================
+// Indices of the edges with an accepted correspondence, in edge order (deterministic), built once
+// per solve in LDS so that every evaluation runs over C dense items instead of E sparse ones.
+// dynamic LDS of k_lm_solve: index list + reduction scratch (full transposed matrix if it fits the
+// 160 KB of a CU next to ~3 KB of static LDS, else one partial per 16-lane row)
+__host__ __device__ __forceinline__ bool lm_lds_reduce_fits(int edge_cap) {
+  return (size_t)((edge_cap + 3) & ~3) * sizeof(int) + (size_t)kAccN * kLmEvalThreads * sizeof(double) + 8192 <= 160 * 1024;
+}
+__host__ __device__ __forceinline__ size_t lm_lds_bytes(int edge_cap) {
+  return (size_t)((edge_cap + 3) & ~3) * sizeof(int) +
+         (lm_lds_reduce_fits(edge_cap) ? (size_t)kAccN * kLmEvalThreads : (size_t)(kLmThreads / 16) * kAccN) * sizeof(double);
+}
+
+
+// Compaction of the accepted correspondences from the validity bytes k_knn left (bit q of byte b = query q of
+// k_knn workgroup b): edge indices in ascending order into idx[].  Called by every evaluator wave on its own —
+// each writes the same values, so no cross-wave synchronisation is needed before a wave reads its entries.
+__device__ int lm_compact_bits(const DevView& v, int s, int outer_it, int E, int* idx /*LDS [edge_cap]*/) {
+  const int lane = threadIdx.x & 63;
+  const int Q = v.knn_queries;
+  const int nb = (E + Q - 1) / Q;                          // k_knn workgroups that had queries
+  const int nwords = (nb + 3) >> 2;
+  const unsigned int* mw = reinterpret_cast<const unsigned int*>(v.corr_mask + ((size_t)s * 2 + outer_it) * v.knn_blocks);
+  int run = 0;
+  for (int w0 = 0; w0 < nwords; w0 += 64) {
+    const int w = w0 + lane;
+    unsigned int word = (w < nwords) ? mw[w] : 0u;
+    const int pop = __popc(word);
+    const int incl = wave_incl_scan_i32(pop);
+    int o = run + incl - pop;
+    while (word) {
+      const int b = __ffs(word) - 1;
+      word &= word - 1u;
+      const int bit = w * 32 + b;
+      idx[o++] = (bit >> 3) * Q + (bit & 7);
+    }
+    run += readlane_i32(incl, 63);
+  }
+  return run;
+}
+
+// The correspondences of a solve do not change between its evaluations: every evaluator thread keeps its
+// first kLmCached triples (p, a, b) in registers (loaded once by lm_cache_load), so an evaluation
+// of up to kLmCached * kLmEvalThreads blocks touches no memory before the reduction.
+constexpr int kLmCached = 1;
+struct LmCache { float4 P[kLmCached], A[kLmCached], B[kLmCached]; };
+__device__ __forceinline__ void lm_cache_load(const DevView& v, int s, int eb, int c_lo, int c_hi, const int* idx, LmCache& k) {
+  const float4* ed = v.edges + ((size_t)eb * v.n_streams + s) * v.edge_cap;
+  const float4* ca = v.corr_a + (size_t)s * v.edge_cap;
+  const float4* cb = v.corr_b + (size_t)s * v.edge_cap;
+  const int et = (int)threadIdx.x;
+#pragma unroll
+  for (int j = 0; j < kLmCached; j++) {
+    const int c = c_lo + et + j * kLmEvalThreads;
+    // (the controller's wave fetches its blocks inside every evaluation)
+    if (et < kLmCtl && c < c_hi) { const int e = idx[c]; k.A[j] = ca[e]; k.B[j] = cb[e]; k.P[j] = ed[e]; }
+  }
+}
+
+// Evaluation of the blocks c_lo .. c_hi of the compacted list by the evaluator waves, then the reduction by
+// everybody.  part: [kAccN][kLmEvalThreads] or [kLmThreads/16][kAccN].
+__device__ __forceinline__ void lm_eval(const DevView& v, int s, int eb, int c_lo, int c_hi, const int* idx, const double* Rm_sh,
+                                        double* part, double* acc_out /*[kAccN]*/, const LmCache& k) {
+  const int et = (int)threadIdx.x;
+  const bool cached = et < kLmCtl;
+  double acc[kAccN];
+#pragma unroll
+  for (int i = 0; i < kAccN; i++) acc[i] = 0.0;
+  {
+    double Rm[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) Rm[i] = Rm_sh[i];
+    const float4* ed = v.edges + ((size_t)eb * v.n_streams + s) * v.edge_cap;
+    const float4* ca = v.corr_a + (size_t)s * v.edge_cap;
+    const float4* cb = v.corr_b + (size_t)s * v.edge_cap;
+    int c = c_lo + et;
+    if (cached) {
+#pragma unroll
+      for (int j = 0; j < kLmCached; j++, c += kLmEvalThreads) {
+        if (c < c_hi) {
+          const double p[3] = {(double)k.P[j].x, (double)k.P[j].y, (double)k.P[j].z};     // :347-349 sensor frame
+          const double a[3] = {(double)k.A[j].x, (double)k.A[j].y, (double)k.A[j].z};
+          const double b[3] = {(double)k.B[j].x, (double)k.B[j].y, (double)k.B[j].z};
+          residual_accumulate(Rm, p, a, b, v.min_range, v.max_range, acc);
+        }
+      }
+    }
+    for (; c < c_hi; c += kLmEvalThreads) {
+      const int e = idx[c];
+      const float4 A = ca[e];
+      const float4 B = cb[e];
+      const float4 P = ed[e];
+      const double p[3] = {(double)P.x, (double)P.y, (double)P.z};
+      const double a[3] = {(double)A.x, (double)A.y, (double)A.z};
+      const double b[3] = {(double)B.x, (double)B.y, (double)B.z};
+      residual_accumulate(Rm, p, a, b, v.min_range, v.max_range, acc);
+    }
+  }
+  if (v.lm_lds_reduce) {
+    // Reduction through LDS, transposed: every evaluator stores its 29 partial sums as column et of
+    // red[29][kLmEvalThreads] (conflict-free 8-byte stores); then thread (v, r) = (t / 16, t % 16) sums
+    // the elements r, r + 16, r + 32, ... of row v (conflict-free loads, 28 adds), a 4-step DPP row
+    // sum finishes row v.  Fixed order -> deterministic, no atomics.
+    // (only the columns of threads that hold a block — with several workgroups per solve about half of them — rounded up
+    //  to whole 16-lane rows: the other threads' partial sums are zero and neither written nor read)
+    const int nb_here = c_hi - c_lo;
+    const int ncol = ((nb_here < kLmEvalThreads ? nb_here : kLmEvalThreads) + 15) & ~15;
+    if (et < ncol) {
+#pragma unroll
+      for (int i = 0; i < kAccN; i++) part[i * kLmEvalThreads + et] = acc[i];
+    }
+    __syncthreads();
+    const int vrow = threadIdx.x >> 4, r = threadIdx.x & 15;
+    double x = 0.0;
+    if (vrow < kAccN) {
+      const double* rowp = part + vrow * kLmEvalThreads + r;
+      const int nk = ncol >> 4;
+#pragma unroll 8
+      for (int kk = 0; kk < nk; kk++) x += rowp[kk * 16];
+    }
+    x = row_sum_f64(x);
+    if (vrow < kAccN && r == 0) acc_out[vrow] = x;
+    __syncthreads();
+    return;
+  }
+  // Large edge capacities (the matrix no longer fits beside the index list): DPP butterfly
+  // inside each 16-lane row, one partial per row into LDS, then a fixed-order sum of the partials.
+#pragma unroll
+  for (int i = 0; i < kAccN; i++) acc[i] = row_sum_f64(acc[i]);
+  const int row = threadIdx.x >> 4;
+  if ((threadIdx.x & 15) == 0) {
+#pragma unroll
+    for (int i = 0; i < kAccN; i++) part[row * kAccN + i] = acc[i];
+  }
+  __syncthreads();
+  if (threadIdx.x < kAccN) {
+    double x = 0.0;
+    for (int w = 0; w < kLmThreads / 16; w++) x += part[w * kAccN + threadIdx.x];
+    acc_out[threadIdx.x] = x;
+  }
+  __syncthreads();
+}
+
+// Resets the hash slots occupied by the build that this scan searched (list used_cells[0 .. nup));
+// the last kNN pass of the scan has completed before the finalising k_lm_solve launch starts.
+__device__ void hash_clear_used(const DevView& v, int s /*table: stream + parity * n_streams*/, int nup, int t, int nt) {
+  CellSlot empty; empty.key = kEmptyKey; empty.start = 0; empty.cnt = 0;
+  const int* used = v.used_cells + (size_t)s * v.used_cap;
+  for (int u0 = t; u0 < nup; u0 += 8 * nt) {   // 8 index loads in flight per thread
+    int hh[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { const int u = u0 + k * nt; hh[k] = (u < nup) ? used[u] : -1; }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      if (hh[k] >= 0) {
+        const size_t ti = (size_t)s * v.table_size + hh[k];
+        v.cells[ti] = empty;
+        v.cell_bits[ti >> 5] = 0u;   // every set bit of that word belongs to a slot of this list
+        if (v.cell_pad) v.cell_pad[ti] = 0u;
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void publish_final_pose(const DevView& v, int s, const double* T, int raw, unsigned int tag, int lane);
+
+// Called by the whole workgroup.  sh_cnt: LDS scratch of kMaxFrames + 1 ints.
+// Thread 64 publishes the result (pose log, host-mapped record) while thread `ctl` (the one that wrote st.odom)
+// computes the prediction and the window bookkeeping; the remaining threads fetch the frame sizes.
+__device__ void finalize_scan(const DevView& v, int s, StreamState& st, int* sh_cnt, int eb, bool clear_hash, int ctl) {
+  const int P = v.prev_frames;
+  const int tid = threadIdx.x;
+  // LocalMapManager::addPointCloud (:34-60) on a ring of P frame slots: the new frame goes
+  // into slot frame_count % P (overwriting the oldest once the window is full)
+  const int fc_new = st.frame_count + 1;
+  const int nf = fc_new < P ? fc_new : P;
+  const int new_slot = st.frame_count % P;
+  int* wn = v.win_n + (size_t)s * P;
+  int* wb = v.win_base + (size_t)s * (P + 1);
+  int* ws = v.win_slot + (size_t)s * P;
+  const int n_edges = st.n_edges_buf[eb];
+  const int nup = st.n_used_tab[0];      // cells of the build that this scan searched (cleared below)
+  if (tid == ctl) { for (int i = 0; i < 12; i++) st.final_odom[i] = st.odom[i]; }   // (ctl wrote st.odom itself)
+  for (int j = tid; j < nf; j += blockDim.x) {           // frame sizes of the new window (nothing here depends on the pose)
+    const int sl = (fc_new - nf + j) % P;
+    sh_cnt[j] = (sl == new_slot) ? n_edges : wn[sl];     // independent loads, one round trip
+    ws[j] = sl;
+  }
+  __syncthreads();
+  // early_rebuild: hand the pose to the workgroups that append the new frame (they have been waiting for it)
+  if (v.early_rebuild && tid < 25) publish_final_pose(v, s, st.final_odom, st.append_raw, (unsigned int)st.reb_frame_count + 1u, tid);
+  if (tid == 64) {
+    // pose as published (laser_odometry.cc:403-412 with identity laser_to_base)
+    double q[4];
+    quat_from_pose(st.final_odom, v.rotation_mode, q);             // :403 q_current(odom_base_link.rotation())
+    const int k = st.scan_counter;
+    st.info.scan_index = k;
+    st.info.status = st.status;
+    if (k < v.pose_log_cap) {
+      double* pl = v.pose_log + ((size_t)s * v.pose_log_cap + k) * 7;
+      pl[0] = q[0]; pl[1] = q[1]; pl[2] = q[2]; pl[3] = q[3];
+      pl[4] = st.final_odom[3]; pl[5] = st.final_odom[7]; pl[6] = st.final_odom[11];
+      v.info_log[(size_t)s * v.pose_log_cap + k] = st.info;
+    }
+    st.scan_counter = k + 1;
+    if (v.host_out) {
+      // zero-copy publication: payload, system-scope fence, then the sequence word the host polls
+      HostOut* ho = v.host_out + (size_t)s * 2 + (k & 1);      // two records per stream: the host may read scan k while scan k + 1 publishes
+      ho->pose[0] = q[0]; ho->pose[1] = q[1]; ho->pose[2] = q[2]; ho->pose[3] = q[3];
+      ho->pose[4] = st.final_odom[3]; ho->pose[5] = st.final_odom[7]; ho->pose[6] = st.final_odom[11];
+      ho->info = st.info;
+      // (the system-scope release orders this thread's payload stores before the sequence word: no separate fence)
+      __hip_atomic_store(&ho->seq, k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    st.info.matches[0] = 0; st.info.matches[1] = 0;   // counters of the next scan's two kNN passes
+  }
+  if (tid == ctl) {
+    // prediction for the next scan: odom * (prev^-1 * odom)   (:148-150)
+    double inv[12], rel[12], pred[12];
+    iso_inverse(st.prev_odom, inv);
+    iso_mul(inv, st.final_odom, rel);
+    iso_mul(st.final_odom, rel, pred);
+    for (int i = 0; i < 12; i++) { st.prev_odom[i] = st.final_odom[i]; st.odom[i] = pred[i]; }
+    quat_from_pose(pred, v.rotation_mode, st.param_q);               // :186-190 q_curr(odom_.rotation())
+    st.param_t[0] = pred[3]; st.param_t[1] = pred[7]; st.param_t[2] = pred[11];   // :192-195
+    wn[new_slot] = n_edges;
+    st.frame_count = fc_new;
+    st.n_frames = nf;
+    int acc = 0;
+    for (int j = 0; j < nf; j++) { const int c = sh_cnt[j]; sh_cnt[j] = acc; acc += c; }
+    sh_cnt[nf] = acc;
+    st.n_map = acc;
+    if (!v.early_rebuild) st.n_used_tab[0] = 0;
+    else { st.n_search = acc; st.n_filt = 0; }        // (k_window_insert's job otherwise)
+    st.cursor = 0;
+  }
+  __syncthreads();
+  for (int j = tid; j <= nf; j += blockDim.x) wb[j] = sh_cnt[j];
+  // (first frame only; in steady state the finalising solve clears the table beside its first
+  // controller step instead of extending the kernel by ~4.5 us here)
+  if (clear_hash && !v.early_rebuild) hash_clear_used(v, s, nup, tid, (int)blockDim.x);
+}
+
+// All-to-all exchange of the 29 partial sums between the G workgroups of a stream, inside the
+// launch (MI355X guide, G16 form R2: the data is the flag).  Every double travels as two 8-byte
+// granules {epoch tag, 32 data bits}: no fences, no separate flag.  Buffers are
+// double-buffered by epoch parity (a workgroup cannot publish epoch e+2 before it has read every
+// epoch e+1, which the others publish only after reading epoch e).  Every workgroup adds the G
+// partials in the same order and so continues with bit-identical totals.  Spins are bounded.
+// Two transports: (memory side, placement independent) relaxed agent-scope stores — sc1, write-through, the line
+// leaves the XCD's L2 — and agent-scope loads, ~2-3 us per exchange under load; (local) when the G workgroups sit on
+// ONE XCD — they are launched on block indices 0, 8, 16, ... which the dispatcher hands to the same XCD, and every
+// exchange carries the workgroups' XCC ids so that this is verified, never assumed — plain stores keep the granules in
+// that XCD's L2, where the L1-bypassing loads of the others find them.  The first exchange of a launch always takes the
+// memory-side transport and tells whether the later ones may go local.
+__device__ __forceinline__ unsigned int xcc_id() { return (unsigned int)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 0xFu; }   // HW_REG_XCC_ID[3:0]
+__device__ void lm_exchange(const DevView& v, int s, int g, int G, unsigned int epoch,
+                            const double* acc_local, double* acc_total, unsigned int* status, bool local, int* same_xcc /*LDS*/) {
+  typedef __attribute__((address_space(1))) unsigned long long gu64;
+  unsigned long long* base = v.lm_xch + ((size_t)s * 2 + (epoch & 1u)) * kLmGroupsMax * 64;
+  const int tid = threadIdx.x;
+  if (tid <= 2 * kAccN) {
+    unsigned long long half;
+    if (tid < 2 * kAccN) {
+      const unsigned long long bits = (unsigned long long)__double_as_longlong(acc_local[tid >> 1]);
+      half = (tid & 1) ? (bits >> 32) : (bits & 0xFFFFFFFFull);
+    } else {
+      half = xcc_id();                                   // granule 58: where this workgroup runs
+    }
+    const unsigned long long word = ((unsigned long long)epoch << 32) | half;
+    if (local) __hip_atomic_store((gu64*)(base + g * 64 + tid), word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // plain store: stays in the XCD's L2
+    else __hip_atomic_store((gu64*)(base + g * 64 + tid), word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (tid < 64) {
+    double tot = 0.0;
+    unsigned int spins = 0;
+    bool same = true;
+    while (true) {
+      bool ok = true;
+      tot = 0.0;
+      same = true;
+      if (tid <= kAccN) {
+        // all 2 G loads in flight at once (a loop over the runtime G waits for every pair: G round trips per poll)
+        unsigned long long lo[kLmGroupsMax], hi[kLmGroupsMax];
+        const int i0 = tid < kAccN ? 2 * tid : 2 * kAccN, i1 = tid < kAccN ? 2 * tid + 1 : 2 * kAccN;   // lane 29: the XCC ids
+#pragma unroll
+        for (int gg = 0; gg < kLmGroupsMax; gg++) {
+          const int gq = gg < G ? gg : 0;
+          lo[gg] = __hip_atomic_load((gu64*)(base + gq * 64 + i0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          hi[gg] = __hip_atomic_load((gu64*)(base + gq * 64 + i1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int gg = 0; gg < kLmGroupsMax; gg++) {
+          if (gg < G) {
+            ok = ok && ((unsigned int)(lo[gg] >> 32) == epoch) && ((unsigned int)(hi[gg] >> 32) == epoch);
+            tot += __longlong_as_double((long long)((hi[gg] << 32) | (lo[gg] & 0xFFFFFFFFull)));
+            same = same && ((unsigned int)lo[gg] == (unsigned int)lo[0]);
+          }
+        }
+      }
+      if (__all(ok)) break;
+      if (++spins > 4000000u) { if (tid == 0) atomicOr(status, LIODOM_STATUS_LM_SYNC_TIMEOUT); same = false; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (tid < kAccN) acc_total[tid] = tot;
+    if (tid == kAccN) *same_xcc = same ? 1 : 0;
+  }
+  __syncthreads();
+}
+
+// early_rebuild: the solved pose travels from the solving workgroup to the workgroups that append the new frame inside
+// the same launch (MI355X guide, G16 form R2: the data is the flag): 12 doubles as 24 granules {tag, 32 data bits} + one
+// granule of flags, relaxed agent-scope stores, one granule per lane (a single thread storing all 25 took 4.7 us);
+// tag = frames appended so far + 1 (never 0, the reset value).
+__device__ __forceinline__ void publish_final_pose(const DevView& v, int s, const double* T, int raw, unsigned int tag, int lane /*0..24*/) {
+  typedef __attribute__((address_space(1))) unsigned long long gu64;
+  unsigned long long* base = v.pose_xch + (size_t)s * 32;
+  unsigned int word = (unsigned int)raw;
+  if (lane < 24) {
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(T[lane >> 1]);
+    word = (lane & 1) ? (unsigned int)(bits >> 32) : (unsigned int)bits;
+  }
+  __hip_atomic_store((gu64*)(base + lane), ((unsigned long long)tag << 32) | word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// use_imu (laser_odometry.cc:152-183): the prediction (made when the previous scan finished) gets
+// the roll and pitch of the latest IMU orientation before the first kNN pass; one thread per stream.
+__global__ void k_imu_override(DevView v, int s0, int count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  StreamState& st = v.state[s0 + i];
+  if (!st.initialized) return;
+  double odom[12], out[12], l2b[12], q[4];
+#pragma unroll
+  for (int k = 0; k < 12; k++) { odom[k] = st.odom[k]; l2b[k] = v.laser_to_base[k]; }
+#pragma unroll
+  for (int k = 0; k < 4; k++) q[k] = v.imu_q[(size_t)(s0 + i) * 4 + k];
+  imu_override(odom, q, l2b, v.rotation_mode, out);
+#pragma unroll
+  for (int k = 0; k < 12; k++) st.odom[k] = out[k];
+  quat_from_pose(out, v.rotation_mode, st.param_q);                                // :186-190
+  st.param_t[0] = out[3]; st.param_t[1] = out[7]; st.param_t[2] = out[11];         // :192-195
+}
+
+__device__ void rebuild_beside_solve(const DevView& v, int s, StreamState& st, int eb, int outer_it, int block, int nblocks, unsigned int seq, int* sbase, int* sslot);
+
+__global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int outer_it, int eb, unsigned int seq) {
+  __shared__ double sh_pose[12];
+  __shared__ double sh_acc[kAccN];
+  __shared__ LmState lm;
+  __shared__ int sh_flag;
+  __shared__ int sh_C;
+  const int s = s0 + blockIdx.y;
+  // G cooperating workgroups per stream, on block indices 0, 8, 16, ... when G > 1 (workgroups are handed to the XCDs
+  // round-robin by linear index, so these share an XCD — see lm_exchange); every other block is a rebuild workgroup
+  const int G = v.lm_groups, gstride = G > 1 ? 8 : 1, bxl = (int)blockIdx.x;
+  const bool is_solver = bxl < G * gstride && (bxl % gstride) == 0;
+  const int g = is_solver ? bxl / gstride : G + (bxl < G * gstride ? bxl - (bxl / gstride + 1) : bxl - G);
+  StreamState& st = v.state[s];
+  __shared__ int sh_cnt[kMaxFrames + 1];
+  __shared__ int sh_same_xcc;
+  // seq != 0: the scan's second kNN pass runs beside this launch ("Overlapped second kNN pass"): the first solve's launch says
+  // that it has started (= the first pass has completed), the finalising one waits for the second pass where it needs it
+  OV_STAMP(v, bxl == 0 && threadIdx.x == 0, outer_it == 0 ? 0 : 3);
+  if (seq && outer_it == 0 && bxl == 0 && threadIdx.x == 0) {
+    typedef __attribute__((address_space(1))) unsigned int gu32;
+    __hip_atomic_store((gu32*)(v.ov_flags + s), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (g >= G) {
+    if (!v.early_rebuild) return;                  // (filler blocks between the solvers)
+    // early_rebuild: the workgroups behind the solve build the next cell hash (see "streamed rebuild" below)
+    __shared__ int sh_slot[kMaxFrames];
+    rebuild_beside_solve(v, s, st, eb, outer_it, g - G, (int)gridDim.x - G, seq, sh_cnt, sh_slot);
+    return;
+  }
+  __shared__ double sh_loc[kAccN];
+  __shared__ double sh_red[16][32];
+  extern __shared__ __attribute__((aligned(16))) int sh_idx[];   // [edge_cap] compacted correspondence indices, then the reduction matrix
+  double* sh_part = reinterpret_cast<double*>(sh_idx + ((v.edge_cap + 3) & ~3));   // [kAccN][kLmEvalThreads]
+  const int tid = threadIdx.x;
+  const bool prep = tid < kLmCtl;               // waves 0..6: compaction + register cache while the controller lane works
+  if (outer_it == 0 && tid == 0 && g == 0) {     // per-scan diagnostics (matches are counted by k_knn)
+    st.info.n_edges = st.n_edges_buf[eb];
+    st.info.map_points = st.n_search;
+    for (int k = 0; k < 2; k++) {
+      st.info.lm[k].iterations = 0; st.info.lm[k].accepted = 0; st.info.lm[k].termination = LM_TERM_NO_RESIDUALS;
+      st.info.lm[k].pad = 0; st.info.lm[k].initial_cost = 0.0; st.info.lm[k].final_cost = 0.0;
+    }
+  }
+  if (!st.initialized) {
+    // first frame (:108-136): no solve; pose stays identity, edges enter the window raw
+    if (outer_it == 1 && g == 0) {
+      if (tid == 0) st.append_raw = 1;
+      finalize_scan(v, s, st, sh_cnt, eb, true, 0);
+      if (tid == 0) st.initialized = 1;
+    }
+    return;
+  }
+  // The second kNN pass of this scan has completed when the finalising solve starts, so the cell hash it
+  // searched is no longer needed: waves 0..6 reset its occupied slots while the controller lane works on its
+  // first update step (they would idle at the barrier otherwise).
+  bool clr_pending = outer_it == 1 && g == 0 && prep && !v.early_rebuild;
+  auto clear_hash_slots = [&]() {
+    hash_clear_used(v, s, st.n_used_tab[0], tid, kLmCtl);
+    clr_pending = false;
+  };
+  const bool dbgb = (s == 0) && (g == 0) && (tid == kLmCtl) && (outer_it == 1);
+  const bool dbge = (s == 0) && (g == 0) && (tid == 0) && (outer_it == 1);
+  DBG_STAMP(v, dbgb, 2, 0);
+  const int E = st.n_edges_buf[eb];
+  int nblocks = st.info.matches[outer_it];      // (lock-step batches: counted by k_line_gate; else from k_knn's partial sums below)
+  __shared__ int sh_nmatch;
+  __shared__ double sh_scale[8];
+  const unsigned int epoch0 = ((unsigned int)(st.scan_counter + 1) << 6) | ((unsigned int)outer_it << 5);
+  unsigned int n_eval = 0;
+  bool xch_local = false;       // the G workgroups were seen on one XCD: exchanges through its L2 (lm_exchange)
+  LmCache cache;
+  int c_lo = 0, c_hi = 0;
+  auto my_share = [&](int C) {                           // this workgroup's contiguous share of the compacted blocks
+    const int chunk = (C + G - 1) / G;
+    c_lo = g * chunk < C ? g * chunk : C;
+    c_hi = (g + 1) * chunk < C ? (g + 1) * chunk : C;
+  };
+  if (seq && outer_it == 1) ov_wait_knn_done(v, s, seq, &st.status);      // the overlapped second kNN pass has completed
+  OV_STAMP(v, g == 0 && tid == 0 && outer_it == 1, 4);
+  OV_STAMP(v, g == 0 && tid == 0 && outer_it == 0, 18);
+  if (v.knn_partials) {
+    // ---- first evaluation = sum of the partial normal equations the k_knn workgroups left, in workgroup order ----
+    const int Q = v.knn_queries;
+    const int nb = (E + Q - 1) / Q;
+    const double* part = v.knn_part + ((size_t)s * 2 + outer_it) * v.knn_blocks * 32;
+    const int i = tid & 31, r0 = tid >> 5;               // 16 row classes x 32 columns (29 used)
+    double x0 = 0.0, x1 = 0.0;
+    if (i <= kAccN) {                                    // (entry 29: the number of accepted correspondences)
+      // 16 independent loads in flight per pass (one memory round trip for up to 256 k_knn workgroups)
+      for (int rb = r0; rb < nb; rb += 256) {
+        double xs[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) { const int r = rb + 16 * u; xs[u] = (r < nb) ? part[(size_t)r * 32 + i] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < 16; u += 2) { x0 += xs[u]; x1 += xs[u + 1]; }
+      }
+    }
+    sh_red[r0][i] = x0 + x1;
+    __syncthreads();
+    if (tid <= kAccN) {
+      double x = 0.0;
+#pragma unroll
+      for (int r = 0; r < 16; r++) x += sh_red[r][tid];
+      if (tid < kAccN) sh_acc[tid] = x;
+      else { sh_nmatch = (int)x; if (g == 0) st.info.matches[outer_it] = (int)x; }      // :346 (sum of small integers: exact)
+    }
+    __syncthreads();
+    nblocks = sh_nmatch;
+  } else {
+    // ---- lock-step batches: k_knn leaves only the validity bytes; compaction, then an ordinary first evaluation ----
+    if (prep) {
+      const int C = lm_compact_bits(v, s, outer_it, E, sh_idx);
+      if (tid == 0) sh_C = C;
+    } else if (tid == kLmCtl) {
+      iso_from_qt(st.param_q, st.param_t, sh_pose);
+    }
+    __syncthreads();
+    my_share(sh_C);
+    lm_cache_load(v, s, eb, c_lo, c_hi, sh_idx, cache);
+    if (G > 1) { lm_eval(v, s, eb, c_lo, c_hi, sh_idx, sh_pose, sh_part, sh_loc, cache); lm_exchange(v, s, g, G, epoch0 | ++n_eval, sh_loc, sh_acc, &st.status, xch_local, &sh_same_xcc); xch_local = sh_same_xcc != 0; }
+    else lm_eval(v, s, eb, c_lo, c_hi, sh_idx, sh_pose, sh_part, sh_acc, cache);
+  }
+  DBG_STAMP(v, dbgb, 2, 2);
+  // ---- trust-region loop.  Controller step on lane 0 of the last wave; beside it waves 0..6 prepare the
+  // evaluations (step 0: validity bytes -> index list, triples into registers) or reset the hash slots of the
+  // build this scan searched (step 1 of the finalising solve) ----
+  int dbg_it = 0;
+  for (int step = 0;; step++) {
+    if (step == 0 && tid > kLmCtl && tid <= kLmCtl + 6) {
+      // the six Jacobi scales of lm_begin (an FP64 square root and a division each) on six lanes of the controller's wave
+      const int j = tid - kLmCtl - 1;
+      sh_scale[j] = 1.0 / (1.0 + sqrt(sh_acc[7 + h_idx(j, j)]));
+    }
+    if (step == 0) __builtin_amdgcn_wave_barrier();
+    if (tid == kLmCtl) {
+      // (a wave-parallel controller — lane 8 r + c holding entry (r, c) of the 6 x 6 matrices, Cholesky columns
+      // broadcast through LDS, solves on readlane'd entries — was measured slower than this single lane:
+      // 3.9-5.9 us per step against 3.1)
+      const int f = step == 0 ? lm_begin(lm, st.param_q, st.param_t, sh_acc, nblocks, v.apply_on_ftol, sh_scale) : lm_update(lm, sh_acc);
+      sh_flag = f;
+      if (f == LM_NEED_EVAL) iso_from_qt(lm.cand_q, lm.cand_t, sh_pose);
+      if (step == 0) DBG_STAMP(v, dbgb, 2, 23);
+    } else if (!prep) {
+      // (the other lanes of the controller's wave wait at the barrier)
+    } else if (step == 0 && v.knn_partials) {
+      DBG_STAMP(v, dbge, 2, 24);
+      const int C = lm_compact_bits(v, s, outer_it, E, sh_idx);
+      if (tid == 0) sh_C = C;
+      DBG_STAMP(v, dbge, 2, 25);
+      my_share(C);
+      lm_cache_load(v, s, eb, c_lo, c_hi, sh_idx, cache);
+    } else if (clr_pending) {
+      clear_hash_slots();
+    }
+    __syncthreads();
+    if (step == 0) { if (v.knn_partials && !prep) my_share(sh_C); DBG_STAMP(v, dbgb, 2, 3); }
+    else { DBG_STAMP(v, dbgb && dbg_it < 5, 2, 5 + 2 * dbg_it); dbg_it++; }
+    if (sh_flag != LM_NEED_EVAL) break;
+    if (G > 1) { lm_eval(v, s, eb, c_lo, c_hi, sh_idx, sh_pose, sh_part, sh_loc, cache); DBG_STAMP(v, dbgb && dbg_it < 4, 2, 12 + dbg_it); lm_exchange(v, s, g, G, epoch0 | ++n_eval, sh_loc, sh_acc, &st.status, xch_local, &sh_same_xcc); xch_local = sh_same_xcc != 0; }
+    else lm_eval(v, s, eb, c_lo, c_hi, sh_idx, sh_pose, sh_part, sh_acc, cache);
+    DBG_STAMP(v, dbgb && dbg_it < 5, 2, 4 + 2 * dbg_it);
+  }
+  if (clr_pending) clear_hash_slots();                   // (the solve ended at its first step)
+  DBG_STAMP(v, dbgb, 2, 20);
+  if ((kInstrument && (v.debug & 32)) && dbgb) v.dbg_clk[2 * 32 + 27] = (xch_local ? 100ull : 0ull) + 10ull * xcc_id() + (unsigned long long)n_eval;   // (debug) exchange transport, XCC, evaluations
+  if (g != 0) return;        // every workgroup reached the same result; workgroup 0 records it
+  if (seq && outer_it == 0) {
+    // overlapped second kNN pass: its workgroups are waiting for exactly these 19 doubles — they leave first
+    __shared__ double sh_ov[20];
+    if (tid == kLmCtl) {
+      double q[4], t[3], T[12];
+      for (int k = 0; k < 4; k++) q[k] = lm.q[k];
+      for (int k = 0; k < 3; k++) t[k] = lm.t[k];
+      iso_from_qt(q, t, T);
+      for (int k = 0; k < 12; k++) sh_ov[k] = T[k];
+      for (int k = 0; k < 4; k++) sh_ov[12 + k] = q[k];
+      for (int k = 0; k < 3; k++) sh_ov[16 + k] = t[k];
+    }
+    __syncthreads();
+    ov_publish_pose(v, s, sh_ov, seq, tid);
+    OV_STAMP(v, tid == 0, 1);
+  }
+  if (tid == kLmCtl) {
+    for (int k = 0; k < 4; k++) st.param_q[k] = lm.q[k];
+    for (int k = 0; k < 3; k++) st.param_t[k] = lm.t[k];
+    iso_from_qt(st.param_q, st.param_t, st.odom);                  // :222-227
+    liodom_lm_trace_t& tr = st.info.lm[outer_it];
+    tr.iterations = lm.iter; tr.accepted = lm.accepted; tr.termination = lm.termination; tr.pad = 0;
+    tr.initial_cost = lm.initial_cost; tr.final_cost = lm.cost;
+    if (outer_it == 1) st.append_raw = 0;
+  }
+  DBG_STAMP(v, dbgb, 2, 21);
+  if (outer_it == 1) {
+    finalize_scan(v, s, st, sh_cnt, eb, false, kLmCtl);
+    DBG_STAMP(v, dbgb, 2, 22);
+  }
+  DBG_STAMP(v, dbgb, 2, 28);
+  OV_STAMP(v, tid == 0, outer_it == 0 ? 2 : 5);
+}

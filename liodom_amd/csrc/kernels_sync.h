@@ -1,0 +1,148 @@
+// kernels_sync.h — dependencies between the HIP streams of a handle as flags in device memory: pipelined replay (pipe_wait, k_pipe_gate, k_set_flag) and the overlapped second kNN pass (tagged pose granules, done flags, write-through stores).
+// Part of liodom_kernels.h (included there, inside namespace liodom_dev, in this order; not a standalone header).
+// =============================================================================================
+// Pipelined replay: the two HIP streams of a handle (extraction / odometry) depend on each other twice per scan.  As
+// hipStreamWaitEvent / hipEventRecord pairs those dependencies cost ~11 us of idle odometry stream per scan (the barrier
+// packets are processed when the preceding kernel retires, measured with the host far ahead as well); as flags in
+// device memory they cost one early load per workgroup.  A flag is written by a kernel that follows the producer in
+// stream order (so the producer's launch has ended and its writes have left the caches) and polled by thread 0 of the
+// consumer's workgroups before they touch the data; a consumer that really had to wait also invalidates its caches.
+// The wait is bounded (~0.3 s): a producer that cannot run beside the consumer — a profiler that serialises kernels across
+// streams, e.g. rocprofv3 --pmc: use LIODOM_PIPE_FLAGS=0 there — raises LIODOM_STATUS_PIPE_TIMEOUT instead of hanging; the waiting
+// workgroups then skip their work (nothing reads a half-written buffer or overwrites one still in use), the host reports the scan
+// as failed (wait_pose) and the handle falls back to events.
+__device__ __forceinline__ bool pipe_wait(const unsigned int* flag, unsigned int want, unsigned int* status) {
+  typedef __attribute__((address_space(1))) unsigned int gu32;
+  __shared__ int s_pipe_ok;
+  if (threadIdx.x == 0) {
+    unsigned int spins = 0;
+    bool ok = true;
+    while ((int)(__hip_atomic_load((gu32*)flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > 1500000u) { atomicOr(status, LIODOM_STATUS_PIPE_TIMEOUT); ok = false; break; }
+    }
+    if (spins) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    s_pipe_ok = ok ? 1 : 0;
+  }
+  __syncthreads();
+  return s_pipe_ok != 0;      // false: the producer never arrived — the caller must not touch the buffer (it returns)
+}
+// Gate in front of a scan's first k_knn launch for handles whose launch is too large to poll the flag itself (its polling
+// workgroups would fill the GPU and starve the extraction they wait for): one wave waits for the extraction's flag and
+// publishes that the previous odometry has completed; the launches behind it start when it retires.
+__global__ void k_pipe_gate(DevView v, int s0, int eb, unsigned int wait_edges, unsigned int signal_odo) {
+  typedef __attribute__((address_space(1))) unsigned int gu32;
+  if (signal_odo && threadIdx.x == 0) __hip_atomic_store((gu32*)(v.pipe_flags + kEdgePipeBufs), signal_odo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (wait_edges && !pipe_wait(v.pipe_flags + eb, wait_edges, &v.state[s0].status)) {
+    // the launches behind the gate check the status bit of their own stream (k_knn) and skip the scan
+    for (int s = (int)threadIdx.x; s < v.n_streams; s += (int)blockDim.x) atomicOr(&v.state[s].status, LIODOM_STATUS_PIPE_TIMEOUT);
+  }
+}
+// =============================================================================================
+// Overlapped second kNN pass (one-stream handles with the streamed rebuild and flags).  The odometry chain of a scan is
+// kNN, solve, kNN, solve; as four launches of one HIP stream every link costs a launch boundary (~0.7 us idle), the ramp of
+// the next launch (kernel arguments, state words, first loads: ~2 us of dependent round trips) and the tail of the previous
+// one.  The second kNN pass depends on the first solve only through the 19 doubles of its result, and everything else it
+// reads — the edge, what the first pass saved for the re-ranking, the saved candidates themselves — is known when the
+// first pass has completed.  So this pass is launched on a HIP stream of its own (stream_k) right behind the first solve's
+// launch and waits INSIDE the kernel, twice:
+//   1. for ov_flags[s] == seq, stored by the first solve's launch when it starts (it follows the first kNN pass in stream
+//      order, so that pass has completed and its writes are visible) -> the workgroups load their edges and the saved
+//      candidates (two dependent round trips) while the solve runs;
+//   2. for the solve's result, published as tagged granules (the data is the flag) in kOvReplicas copies 4 KiB apart, so
+//      that the polling workgroups do not queue on one memory channel -> transform, re-rank, gate, partial sums.
+// Every workgroup of the pass then stores seq into knn_done[s][b] (after a release fence), and the finalising solve's
+// launch — which follows the first solve in stream order and therefore starts while this pass still runs — polls those
+// flags in its solving workgroups before it reads the pass's results, and in the workgroups that clear the searched table
+// before they touch it.  All waits are bounded (LIODOM_STATUS_PIPE_TIMEOUT, as pipe_wait); workgroups that wait never
+// hold more than a third of the GPU's wave slots, and a waiting workgroup depends only on launches enqueued before its own.
+// Launch order on the host: kNN(0) [stream], solve(0) [stream], kNN(1) [stream_k], solve(1) [stream].
+// =============================================================================================
+// Stores / loads that are visible across the XCDs without cache maintenance: agent-scope relaxed atomics go through the
+// XCD's L2 to the memory side.  (The alternative — plain accesses plus release / acquire fences — costs an L2 write-back or
+// invalidate per fence on a part whose eight L2s are not coherent with each other: with one per workgroup of a 352-workgroup
+// launch the solve running beside it took 80 us instead of 24.)
+__device__ __forceinline__ void wt_store_u32(void* p, unsigned int x) {
+  typedef __attribute__((address_space(1))) unsigned int gu32;
+  __hip_atomic_store((gu32*)p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void wt_store_u64(void* p, unsigned long long x) {
+  typedef __attribute__((address_space(1))) unsigned long long gu64;
+  __hip_atomic_store((gu64*)p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void wt_store_f4(float4* p, const float4& x) {
+  wt_store_u64(p, ((unsigned long long)__float_as_uint(x.y) << 32) | __float_as_uint(x.x));
+  wt_store_u64(reinterpret_cast<char*>(p) + 8, ((unsigned long long)__float_as_uint(x.w) << 32) | __float_as_uint(x.z));
+}
+__device__ __forceinline__ void wt_store_u8(void* p, unsigned char x) {
+  typedef __attribute__((address_space(1))) unsigned char gu8;
+  __hip_atomic_store((gu8*)p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned int coh_load_u32(const void* p) {
+  typedef __attribute__((address_space(1))) unsigned int gu32;
+  return __hip_atomic_load((gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the first solve's result leaves its workgroup: vals = odom[12], q[4], t[3] in LDS; threads 0 .. kOvReplicas * kOvGranules - 1
+__device__ __forceinline__ void ov_publish_pose(const DevView& v, int s, const double* vals, unsigned int tag, int tid) {
+  typedef __attribute__((address_space(1))) unsigned long long gu64;
+  if (tid >= kOvReplicas * kOvGranules) return;
+  const int rep = tid / kOvGranules, gi = tid % kOvGranules;
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(vals[gi >> 1]);
+  const unsigned int word = (gi & 1) ? (unsigned int)(bits >> 32) : (unsigned int)bits;
+  __hip_atomic_store((gu64*)(v.pose_xch0 + ((size_t)s * kOvReplicas + rep) * 512 + gi), ((unsigned long long)tag << 32) | word,
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// whole workgroup; the first wave polls replica rep until every granule carries the tag; out19: LDS.  false: gave up.
+__device__ __forceinline__ bool ov_wait_pose(const DevView& v, int s, int rep, unsigned int tag, double* out19, unsigned int* status) {
+  typedef __attribute__((address_space(1))) unsigned long long gu64;
+  __shared__ int s_ov_ok;
+  const int tid = (int)threadIdx.x;
+  if (tid < 64) {
+    const unsigned long long* base = v.pose_xch0 + ((size_t)s * kOvReplicas + rep) * 512;
+    unsigned long long g = 0;
+    unsigned int spins = 0;
+    bool ok;
+    // (all 38 lanes poll: one round trip after the publication instead of two; what had congested the memory fabric in the
+    //  first version of this pass were release / acquire fences — an L2 write-back / invalidate each —, not these loads)
+    while (true) {
+      if (tid < kOvGranules) g = __hip_atomic_load((gu64*)(base + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ok = tid >= kOvGranules || (unsigned int)(g >> 32) == tag;
+      if (__all(ok)) break;
+      if (++spins > 2000000u) break;
+      __builtin_amdgcn_s_sleep(6);
+    }
+    const bool all_ok = __all(ok);
+    const unsigned long long lo = __shfl(g, 2 * (tid % 19)), hi = __shfl(g, 2 * (tid % 19) + 1);
+    if (tid < 19) out19[tid] = __longlong_as_double((long long)((hi << 32) | (lo & 0xFFFFFFFFull)));
+    if (tid == 0) { s_ov_ok = all_ok ? 1 : 0; if (!all_ok) atomicOr(status, LIODOM_STATUS_PIPE_TIMEOUT); }
+  }
+  __syncthreads();
+  return s_ov_ok != 0;
+}
+// whole workgroup, every exit path of an overlapped k_knn workgroup: its results are visible before the flag is
+__device__ __forceinline__ void ov_signal_knn_done(const DevView& v, int s, int b, unsigned int seq) {
+  typedef __attribute__((address_space(1))) unsigned int gu32;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the pass's results are write-through stores: acknowledged = visible to every XCD)
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store((gu32*)(v.knn_done + (size_t)s * v.knn_grid + b), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// whole workgroup (finalising solve's launch): every workgroup of the overlapped second pass has completed
+__device__ __forceinline__ void ov_wait_knn_done(const DevView& v, int s, unsigned int seq, unsigned int* status) {
+  typedef __attribute__((address_space(1))) unsigned int gu32;
+  const unsigned int* f = v.knn_done + (size_t)s * v.knn_grid;
+  for (int b = (int)threadIdx.x; b < v.knn_grid; b += (int)blockDim.x) {
+    unsigned int spins = 0;
+    while ((int)(__hip_atomic_load((gu32*)(f + b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) < 0) {
+      __builtin_amdgcn_s_sleep(4);
+      if (++spins > 6000000u) { atomicOr(status, LIODOM_STATUS_PIPE_TIMEOUT); break; }
+    }
+  }
+  // (no acquire fence — an L2 invalidate per waiting workgroup: this launch started, with clean caches, before the pass wrote
+  //  any of its results, and reads none of them before this point; the pass's stores are write-through)
+  __syncthreads();
+}
+
+__global__ void k_set_flag(unsigned int* flag, unsigned int value) {
+  typedef __attribute__((address_space(1))) unsigned int gu32;
+  __hip_atomic_store((gu32*)flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}

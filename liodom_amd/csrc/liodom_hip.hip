@@ -63,7 +63,7 @@ struct liodom_handle {
   // (mx_x only) and liodom_odometry_step (mx_o only) can therefore run concurrently from two threads.
   std::mutex mx_x, mx_o;
   hipStream_t stream = nullptr;      // odometry side
-  hipStream_t stream_k = nullptr;    // overlapped second kNN pass of a scan (liodom_kernels.h "Overlapped second kNN pass"): beside the first solve
+  hipStream_t stream_k = nullptr;    // overlapped second kNN pass of a scan (kernels_sync.h "Overlapped second kNN pass"): beside the first solve
   bool counted_live = false;         // this handle is part of g_live_handles
   bool ov_ok = false;                // the handle qualifies for it (one stream, streamed rebuild, the pass leaves 2/3 of the wave slots free)
   unsigned int ov_seq = 0;           // launch sequence number its flags carry
@@ -227,12 +227,12 @@ int enqueue_odometry(liodom_handle* h, int eb, int s0, int count, unsigned int w
     ProfScope ps(h, KID_OTHER);
     hipLaunchKernelGGL(k_imu_override, dim3(cdiv(count, 64)), dim3(64), 0, h->stream, v, s0, count);
   }
-  // early rebuild ("streamed rebuild", liodom_kernels.h): the four launches of a scan carry extra workgroups that build
+  // early rebuild ("streamed rebuild", kernels_rebuild.h): the four launches of a scan carry extra workgroups that build
   // the next scan's cell hash in the second table; nothing follows the finalising solve
   const int map_blocks = cdiv(h->v.map_cap, 256);
   const bool early = v.early_rebuild != 0;
   const int nC = cdiv(h->v.edge_cap * std::max(1, h->P - 1), kLmThreads), nP = cdiv(h->v.edge_cap, kLmThreads);
-  // Overlapped second kNN pass (liodom_kernels.h): the pass goes to stream_k behind the first solve's launch and waits inside
+  // Overlapped second kNN pass (kernels_sync.h): the pass goes to stream_k behind the first solve's launch and waits inside
   // the kernel; it needs kernels of different streams to run side by side (as the flags of the pipelined replay do) and the
   // GPU mostly to itself: not while a second handle lives in this process (its waiting workgroups and ours could end up
   // behind each other in a shared hardware queue), not under per-kernel profiling.
