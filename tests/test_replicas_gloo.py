@@ -48,3 +48,28 @@ def test_single_process_is_a_noop():
         for k, v in env_backup.items():
             if v is not None:
                 os.environ[k] = v
+
+
+def test_bench_refuses_gpus_without_the_launcher():
+    """`bench.py --gpus N` must run under the N-rank launcher: one process reporting N x its own throughput would be a
+    made-up aggregate.  The check comes before anything touches a GPU (exit code 2, nothing on stdout)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, env=env, timeout=300, cwd=ROOT)
+    assert out.returncode == 2, (out.returncode, out.stderr[-500:])
+    assert out.stdout.strip() == "" and "WORLD_SIZE is 1" in out.stderr
+
+
+def test_bench_under_the_launcher_agrees_on_the_world(tmp_path):
+    """Two ranks of bench.py under torch.distributed.run on a box without GPUs: both pass the launcher check (--gpus ==
+    WORLD_SIZE) and then fail loudly at the device — the product path has no CPU fall-back — with a non-zero exit."""
+    import pytest
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("on a GPU box this is a real two-rank run: the driver's scaling bench covers it")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert out.returncode != 0
+    assert "WORLD_SIZE is" not in out.stderr          # the launcher check passed on both ranks
