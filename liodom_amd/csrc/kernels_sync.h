@@ -51,10 +51,10 @@ __global__ void k_pipe_gate(DevView v, int s0, int eb, unsigned int wait_edges, 
 //      candidates (two dependent round trips) while the solve runs;
 //   2. for the solve's result, published as tagged granules (the data is the flag) in kOvReplicas copies 4 KiB apart, so
 //      that the polling workgroups do not queue on one memory channel -> transform, re-rank, gate, partial sums.
-// Every workgroup of the pass then stores seq into knn_done[s][b] (after a release fence), and the finalising solve's
-// launch — which follows the first solve in stream order and therefore starts while this pass still runs — polls those
-// flags in its solving workgroups before it reads the pass's results, and in the workgroups that clear the searched table
-// before they touch it.  All waits are bounded (LIODOM_STATUS_PIPE_TIMEOUT, as pipe_wait); workgroups that wait never
+// Every workgroup of the pass stores its results write-through, waits for their acknowledgement (s_waitcnt — no fence:
+// see below) and then stores seq into knn_done[s][b]; the finalising solve's launch — which follows the first solve in
+// stream order and therefore starts while this pass still runs — polls those flags in its solving workgroups before it
+// reads the pass's results, and in the workgroups that clear the searched table before they touch it.  All waits are bounded (LIODOM_STATUS_PIPE_TIMEOUT, as pipe_wait); workgroups that wait never
 // hold more than a third of the GPU's wave slots, and a waiting workgroup depends only on launches enqueued before its own.
 // Launch order on the host: kNN(0) [stream], solve(0) [stream], kNN(1) [stream_k], solve(1) [stream].
 // =============================================================================================
@@ -62,10 +62,6 @@ __global__ void k_pipe_gate(DevView v, int s0, int eb, unsigned int wait_edges, 
 // XCD's L2 to the memory side.  (The alternative — plain accesses plus release / acquire fences — costs an L2 write-back or
 // invalidate per fence on a part whose eight L2s are not coherent with each other: with one per workgroup of a 352-workgroup
 // launch the solve running beside it took 80 us instead of 24.)
-__device__ __forceinline__ void wt_store_u32(void* p, unsigned int x) {
-  typedef __attribute__((address_space(1))) unsigned int gu32;
-  __hip_atomic_store((gu32*)p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 __device__ __forceinline__ void wt_store_u64(void* p, unsigned long long x) {
   typedef __attribute__((address_space(1))) unsigned long long gu64;
   __hip_atomic_store((gu64*)p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -77,10 +73,6 @@ __device__ __forceinline__ void wt_store_f4(float4* p, const float4& x) {
 __device__ __forceinline__ void wt_store_u8(void* p, unsigned char x) {
   typedef __attribute__((address_space(1))) unsigned char gu8;
   __hip_atomic_store((gu8*)p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ unsigned int coh_load_u32(const void* p) {
-  typedef __attribute__((address_space(1))) unsigned int gu32;
-  return __hip_atomic_load((gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // the first solve's result leaves its workgroup: vals = odom[12], q[4], t[3] in LDS; threads 0 .. kOvReplicas * kOvGranules - 1
 __device__ __forceinline__ void ov_publish_pose(const DevView& v, int s, const double* vals, unsigned int tag, int tid) {
