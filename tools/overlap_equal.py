@@ -1,0 +1,42 @@
+"""Pose logs of the same replay with and without the overlapped second kNN pass must be bit-identical.
+usage: python tools/overlap_equal.py [hdl64|vlp16] [scans]   (spawns itself once per mode: the switch is read at handle creation)"""
+import os, subprocess, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+shape = sys.argv[1] if len(sys.argv) > 1 else "hdl64"
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 600
+if len(sys.argv) > 3:
+    import liodom_amd as la
+    from liodom_amd import synth
+    H, W, LT, R, epr, P = {"hdl64": (64, 1800, 0, 8, 10, 20), "vlp16": (16, 1800, 0, 8, 20, 10)}[shape]
+    cfg = synth.make_cfg(H, W, LT)
+    g = la.Liodom(la.make_params(lidar_type=LT, scan_lines=H, scan_regions=R, edges_per_region=epr, prev_frames=P),
+                  la.make_config(n_streams=1, max_points=H * W, max_width=W, pose_log_capacity=K + 8))
+    slots = 60
+    g.alloc_resident(slots)
+    out = []
+    for k0 in range(0, K, slots):
+        n = min(slots, K - k0)
+        for k in range(n):
+            g.upload_scan(0, k, synth.scan(cfg, 5, k0 + k)[0])
+        g.sync()
+        poses, infos = g.replay_resident(0, n, H * W, H, W, depth=1)
+        assert all(int(i.status) == 0 for i in infos)
+        out.append(poses.copy())
+    np.save(sys.argv[3], np.concatenate(out))
+    print(g.modes()["knn_overlap"], flush=True)
+    g.close()
+    sys.exit(0)
+files = []
+for ov in ("1", "0"):
+    f = "/tmp/ov_%s_%s.npy" % (shape, ov)
+    env = dict(os.environ, LIODOM_KNN_OVERLAP=ov)
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), shape, str(K), f], env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.strip().splitlines()[-1] == ov, r.stdout
+    files.append(f)
+a, b = np.load(files[0]), np.load(files[1])
+same = np.array_equal(a.view(np.uint64), b.view(np.uint64))
+print("%s: %d scans, overlapped vs not: %s" % (shape, K, "bit-identical" if same else "DIFFERENT"))
+sys.exit(0 if same else 1)
