@@ -42,9 +42,11 @@ extern "C" {
 #define LIODOM_ERR_CAPACITY (-3)      /* caller buffer or configured capacity too small */
 #define LIODOM_ERR_HIP (-4)           /* HIP runtime failure; see liodom_last_error() */
 #define LIODOM_ERR_NO_DEVICE (-5)
+#define LIODOM_ERR_BUSY (-6)          /* device-resident hand-off: every slot holds an edge cloud that has not been consumed yet (retry
+                                         after liodom_odometry_step_device), or tickets are outstanding where none may be */
 
 /* Sticky per-stream status bits reported in liodom_step_info_t.status */
-#define LIODOM_STATUS_RING_OVERFLOW 1u  /* (no longer raised: rings of any length are processed) */
+/* (bit 1u is not used: rings of any length are processed) */
 #define LIODOM_STATUS_EDGE_OVERFLOW 2u
 #define LIODOM_STATUS_HASH_FULL 4u
 #define LIODOM_STATUS_LM_SYNC_TIMEOUT 8u  /* cooperating LM workgroups did not all arrive (result invalid) */
@@ -81,8 +83,10 @@ typedef struct liodom_config_t {
   int32_t device;            /* HIP device ordinal */
   int32_t n_streams;         /* independent streams advanced in lock-step (>= 1) */
   int32_t max_points;        /* capacity: points per scan (H*W) */
-  int32_t max_width;         /* expected points per ring (informational: no per-ring capacity exists any more) */
-  int32_t max_ring_points;   /* unused (kept for layout compatibility) */
+  int32_t max_width;         /* expected points per ring (0 = max_points / scan_lines): picks the extraction kernel instance whose
+                                register tile covers the longest region, (max_width - 10) / scan_regions + remainder items;
+                                not a capacity — longer rings are processed by the generic path of the same kernel */
+  int32_t reserved1;         /* must be 0 */
   int32_t lm_apply_step_on_ftol; /* 0 = Ceres >= 1.12 behaviour (LM section) */
   int32_t pose_log_capacity; /* scans kept in the device-side pose log (resident replay) */
   int32_t debug_buffers;     /* 1 = keep per-ring smoothness dumps for liodom_get_curvature */
@@ -143,6 +147,47 @@ int liodom_extract_edges(liodom_handle_t* h, int stream, const float* xyzi, int6
 int liodom_odometry_step(liodom_handle_t* h, int stream, const float* edges_xyzi, int n_edges,
                          double stamp, double* pose_out, liodom_step_info_t* info);
 
+/* ---- the same two entry points with the edge cloud staying on the device ----
+ * The reference hands every edge cloud from the FeatureExtractor thread to the LaserOdometer thread through a queue
+ * (src/shared_data.cc:64-89: pushFeatures / popFeatures).  With the two calls above that queue element is a host cloud: a
+ * device-to-host copy on the extraction side, a host-to-device copy on the odometry side, both synchronous, per scan.  Here the
+ * queue element is a TICKET: the edges stay in one of three device buffers, the scan's upload is asynchronous, nothing on the
+ * extraction side blocks, and the odometry's first kernel waits on the device for the extraction it needs.  One-stream handles.
+ *
+ *   liodom_extract_edges_device   FeatureExtractor::operator() body up to the hand-over (feature_extractor.cc:49-77): enqueues
+ *       upload + extraction of one cloud and returns at once.  LIODOM_ERR_BUSY when all three slots hold clouds that
+ *       liodom_odometry_step_device has not taken yet (the reference's queue is unbounded: keep the cloud and retry).
+ *       xyzi: any host memory; a buffer from liodom_scan_buffer or one registered with liodom_pin_host_buffer is read
+ *       asynchronously (no staging copy) and must then stay untouched until liodom_wait_edges or liodom_odometry_step_device of
+ *       the ticket has returned.
+ *   liodom_wait_edges             the cloud for the ~edges topic (feature_extractor.cc:70-75): waits until the extraction has
+ *       completed and copies the edges out of host-mapped memory the extraction kernel wrote (no device-to-host copy call).
+ *       Optional; any thread; before the ticket's liodom_odometry_step_device call returns or — from the extractor thread — before
+ *       the ticket is pushed into the queue.
+ *   liodom_odometry_step_device   LaserOdometer::operator() body (laser_odometry.cc:107-267) on the ticket's cloud; tickets must
+ *       be consumed in the order they were issued.  = liodom_odometry_submit_device + liodom_odometry_collect: a thread that finds
+ *       the next ticket already in its queue may submit it before it collects (and publishes) the previous pose — the device then
+ *       needs nothing from the host between two scans; at most two scans in flight (LIODOM_ERR_BUSY beyond).  A slot becomes free
+ *       for the extraction side when the pose of its scan has been collected.
+ *   liodom_scan_buffer            a page-locked buffer (capacity max_points) to assemble the next cloud in — the place of
+ *       pcl::fromROSMsg's target in lidarClb (src/liodom_node.cc:43-44); valid until the extraction it is passed to.
+ * Poses are bit-identical to liodom_process_scan on the same clouds (tests/test_gpu_threads.py). */
+typedef struct liodom_edge_ticket_t {
+  uint32_t seq;              /* sequence number of the extraction (never 0) */
+  int32_t slot;              /* device edge buffer that holds the cloud */
+  int32_t stream;
+  int32_t reserved;
+} liodom_edge_ticket_t;
+int liodom_scan_buffer(liodom_handle_t* h, int stream, float** xyzi, int64_t* capacity_points);
+int liodom_extract_edges_device(liodom_handle_t* h, int stream, const float* xyzi, int64_t n, int height, int width,
+                                liodom_edge_ticket_t* ticket);
+int liodom_wait_edges(liodom_handle_t* h, const liodom_edge_ticket_t* ticket, float* edges_xyzi, int32_t* edge_ring,
+                      int32_t* edge_idx, int32_t* edge_src, int cap, int* n_edges);
+int liodom_odometry_step_device(liodom_handle_t* h, const liodom_edge_ticket_t* ticket, double stamp, double* pose_out,
+                                liodom_step_info_t* info);
+int liodom_odometry_submit_device(liodom_handle_t* h, const liodom_edge_ticket_t* ticket, double stamp);
+int liodom_odometry_collect(liodom_handle_t* h, int stream, double* pose_out, liodom_step_info_t* info);
+
 /* lidarClb -> FeatureExtractor -> LaserOdometer for one scan without leaving the device
  * (src/liodom_node.cc:40-55 + the two worker loops).  pose_out / info / edges outputs optional. */
 int liodom_process_scan(liodom_handle_t* h, int stream, const float* xyzi, int64_t n, int height,
@@ -196,7 +241,8 @@ int liodom_replay_resident(liodom_handle_t* h, int first_slot, int count, int ah
  * odometry of scan k; every pose is read back, in order (depth as in liodom_replay_resident).  For the copies to be
  * asynchronous the host buffer must be page-locked: liodom_pin_host_buffer / liodom_unpin_host_buffer register a
  * caller-owned buffer (pageable memory works, the copies then stage through the runtime).  The handle's resident
- * scan buffer is (re)allocated as the staging ring (liodom_alloc_resident(h, 3)) if it has fewer than 3 slots. */
+ * scan buffer is (re)allocated as the staging ring (liodom_alloc_resident(h, 3)) if it has fewer than 3 slots; resident slots
+ * 0 .. 2 are overwritten by the replayed scans either way. */
 int liodom_replay_host(liodom_handle_t* h, const float* xyzi_base, int64_t scan_stride_floats, int count, int depth,
                        int64_t n, int height, int width, double* poses_out, liodom_step_info_t* infos_out);
 int liodom_pin_host_buffer(void* p, int64_t bytes);

@@ -102,7 +102,7 @@ class Params(C.Structure):
 class Config(C.Structure):
     _fields_ = [
         ("device", C.c_int32), ("n_streams", C.c_int32), ("max_points", C.c_int32), ("max_width", C.c_int32),
-        ("max_ring_points", C.c_int32), ("lm_apply_step_on_ftol", C.c_int32), ("pose_log_capacity", C.c_int32),
+        ("reserved1", C.c_int32), ("lm_apply_step_on_ftol", C.c_int32), ("pose_log_capacity", C.c_int32),
         ("debug_buffers", C.c_int32), ("lm_workgroups", C.c_int32), ("recv_capacity", C.c_int32),
         ("pose_rotation_mode", C.c_int32), ("reserved0", C.c_int32),
     ]
@@ -127,6 +127,14 @@ class MapConfig(C.Structure):
                 ("voxel_xysize", C.c_double), ("voxel_zsize", C.c_double), ("resolution", C.c_double),
                 ("cell_capacity", C.c_int32), ("max_update_points", C.c_int32), ("max_modified_cells", C.c_int32),
                 ("reserved", C.c_int32)]
+
+
+class EdgeTicket(C.Structure):
+    """liodom_edge_ticket_t: an edge cloud left on the device by liodom_extract_edges_device."""
+    _fields_ = [("seq", C.c_uint32), ("slot", C.c_int32), ("stream", C.c_int32), ("reserved", C.c_int32)]
+
+
+ERR_BUSY = -6
 
 
 class KernelStat(C.Structure):
@@ -230,8 +238,44 @@ def load():
     L.liodom_map_num_cells.argtypes = [vp, ip]
     L.liodom_map_status.restype = C.c_int
     L.liodom_map_status.argtypes = [vp, C.POINTER(C.c_uint32)]
+    tp = C.POINTER(EdgeTicket)
+    L.liodom_scan_buffer.restype = C.c_int
+    L.liodom_scan_buffer.argtypes = [vp, C.c_int, C.POINTER(fp), i64p]
+    L.liodom_extract_edges_device.restype = C.c_int
+    L.liodom_extract_edges_device.argtypes = [vp, C.c_int, fp, C.c_int64, C.c_int, C.c_int, tp]
+    L.liodom_wait_edges.restype = C.c_int
+    L.liodom_wait_edges.argtypes = [vp, tp, fp, ip, ip, ip, C.c_int, ip]
+    L.liodom_odometry_step_device.restype = C.c_int
+    L.liodom_odometry_step_device.argtypes = [vp, tp, C.c_double, dp, C.POINTER(StepInfo)]
+    L.liodom_odometry_submit_device.restype = C.c_int
+    L.liodom_odometry_submit_device.argtypes = [vp, tp, C.c_double]
+    L.liodom_odometry_collect.restype = C.c_int
+    L.liodom_odometry_collect.argtypes = [vp, C.c_int, dp, C.POINTER(StepInfo)]
+    L.liodom_pin_host_buffer.restype = C.c_int
+    L.liodom_pin_host_buffer.argtypes = [C.c_void_p, C.c_int64]
+    L.liodom_unpin_host_buffer.restype = C.c_int
+    L.liodom_unpin_host_buffer.argtypes = [C.c_void_p]
     _lib = L
     return L
+
+
+_host_lib = None
+
+
+def host_lib():
+    """libliodom_host.so: the C++ mirror of the reference's classes over the C-ABI (liodom_amd/host), built by make."""
+    global _host_lib
+    if _host_lib is None:
+        load()
+        hd = os.path.join(_HERE, "host")
+        subprocess.check_call(["make", "-C", hd, "-s"])
+        HL = C.CDLL(os.path.join(hd, "libliodom_host.so"), mode=C.RTLD_GLOBAL)
+        HL.liodom_host_two_thread_replay.restype = C.c_int
+        HL.liodom_host_two_thread_replay.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int,
+                                                     C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                                     C.POINTER(C.c_int64)]
+        _host_lib = HL
+    return _host_lib
 
 
 EXPORTED_SYMBOLS = [
@@ -244,6 +288,8 @@ EXPORTED_SYMBOLS = [
     "liodom_map_config_default", "liodom_map_create", "liodom_map_destroy", "liodom_map_update", "liodom_map_get_local",
     "liodom_map_get_all", "liodom_map_num_cells", "liodom_map_status", "liodom_get_received_map", "liodom_attach_mapper",
     "liodom_set_imu_orientation", "liodom_set_laser_to_base",
+    "liodom_scan_buffer", "liodom_extract_edges_device", "liodom_wait_edges", "liodom_odometry_step_device",
+    "liodom_odometry_submit_device", "liodom_odometry_collect",
 ]
 
 
@@ -350,6 +396,79 @@ class Liodom:
         info = StepInfo()
         self._check(self.L.liodom_odometry_step(self.h, stream, _fp(e), e.shape[0], stamp, _dp(pose), C.byref(info)))
         return pose, info
+
+    # --- the same two sides with the edge cloud staying on the device (tickets) ---
+    def scan_buffer(self, stream=0):
+        """Page-locked buffer [max_points, 4] to assemble the next cloud in (liodom_scan_buffer)."""
+        p = C.POINTER(C.c_float)()
+        cap = C.c_int64()
+        self._check(self.L.liodom_scan_buffer(self.h, stream, C.byref(p), C.byref(cap)))
+        return np.ctypeslib.as_array(p, shape=(cap.value, 4))
+
+    def extract_edges_device(self, xyzi, height, width, stream=0):
+        """Enqueues upload + extraction; returns the ticket, or None when every hand-off slot is taken (LIODOM_ERR_BUSY).
+        A page-locked `xyzi` (scan_buffer / pin) must stay untouched until wait_edges or the ticket's odometry returned."""
+        x = xyzi if (isinstance(xyzi, np.ndarray) and xyzi.dtype == np.float32 and xyzi.flags["C_CONTIGUOUS"]) else np.ascontiguousarray(xyzi, dtype=np.float32)
+        n = x.size // 4
+        t = EdgeTicket()
+        rc = self.L.liodom_extract_edges_device(self.h, stream, _fp(x), n, height, width, C.byref(t))
+        if rc == ERR_BUSY:
+            return None
+        self._check(rc)
+        t._keep = x          # the upload may still be reading it
+        return t
+
+    def wait_edges(self, ticket):
+        cap = self.edge_cap
+        e = np.zeros((cap, 4), np.float32)
+        ring, idx, src = (np.zeros(cap, np.int32) for _ in range(3))
+        n = C.c_int32()
+        self._check(self.L.liodom_wait_edges(self.h, C.byref(ticket), _fp(e), _ip(ring), _ip(idx), _ip(src), cap, C.byref(n)))
+        k = n.value
+        return dict(edges=e[:k].copy(), ring=ring[:k].copy(), idx_in_ring=idx[:k].copy(), src=src[:k].copy())
+
+    def odometry_step_device(self, ticket, stamp=0.0):
+        pose = np.zeros(7)
+        info = StepInfo()
+        self._check(self.L.liodom_odometry_step_device(self.h, C.byref(ticket), stamp, _dp(pose), C.byref(info)))
+        return pose, info
+
+    def odometry_submit_device(self, ticket, stamp=0.0):
+        """False when two scans are already in flight (LIODOM_ERR_BUSY)."""
+        rc = self.L.liodom_odometry_submit_device(self.h, C.byref(ticket), stamp)
+        if rc == ERR_BUSY:
+            return False
+        self._check(rc)
+        return True
+
+    def odometry_collect(self, stream=0):
+        pose = np.zeros(7)
+        info = StepInfo()
+        self._check(self.L.liodom_odometry_collect(self.h, stream, _dp(pose), C.byref(info)))
+        return pose, info
+
+    def two_thread_replay(self, scans, n, height, width, timed_from=0, fetch_edges=True, depth=1, pin=True):
+        """The two-thread binding driven by two C++ threads (liodom_host_two_thread_replay in libliodom_host.so: an extractor
+        thread with liodom_extract_edges_device + liodom_wait_edges, an odometer thread with liodom_odometry_submit_device /
+        liodom_odometry_collect, a ticket queue between them).  scans: float32 [count, max_points, 4] in host memory (page-locked
+        for the call if pin).  Returns (poses [count, 7], seconds from the submission of scan timed_from to the last pose,
+        total number of edges fetched)."""
+        HL = host_lib()
+        a = np.ascontiguousarray(scans, dtype=np.float32)
+        count = a.shape[0]
+        stride = int(a.size // max(1, count))
+        poses = np.zeros((count, 7))
+        secs = C.c_double()
+        tot = C.c_int64()
+        pinned = pin and self.L.liodom_pin_host_buffer(a.ctypes.data_as(C.c_void_p), a.nbytes) == 0
+        try:
+            self._check(HL.liodom_host_two_thread_replay(self.h, _fp(a), stride, count, n, height, width, int(timed_from),
+                                                         1 if fetch_edges else 0, int(depth), self.edge_cap, _dp(poses),
+                                                         C.byref(secs), C.byref(tot)))
+        finally:
+            if pinned:
+                self.L.liodom_unpin_host_buffer(a.ctypes.data_as(C.c_void_p))
+        return poses, secs.value, tot.value
 
     def process_scan(self, xyzi, height, width, stamp=0.0, stream=0):
         x = np.ascontiguousarray(xyzi, dtype=np.float32).reshape(-1, 4)

@@ -6,7 +6,7 @@
 // grid (kCompactBlocks, streams): every workgroup scans the <= 256 ring counts itself (cheaper than a
 // second launch) and copies its interleaved share of the edges.
 constexpr int kCompactBlocks = 8;
-__global__ __launch_bounds__(256) void k_compact_edges(DevView v, int s0, int eb, unsigned int wait_odo) {
+__global__ __launch_bounds__(256) void k_compact_edges(DevView v, int s0, int eb, unsigned int wait_odo, int mirror) {
   __shared__ int pre[257];
   __shared__ int cntr[256];
   // (pipelined replay) the odometry that last read edge buffer eb must have completed before it is rewritten
@@ -27,9 +27,13 @@ __global__ __launch_bounds__(256) void k_compact_edges(DevView v, int s0, int eb
     __syncthreads();
     // threads >= H contribute 0, so pre[H] already equals the total
   }
+  // mirror: the device-resident hand-off also leaves the edges in host-mapped memory (slot eb) for the thread that publishes
+  // ~edges; the stores cross PCIe while the kernel runs and are complete when it ends (k_publish_edges follows in stream order)
+  const bool to_host = mirror != 0 && v.host_edges != nullptr && eb < kEdgePipeBufs;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     const int acc = pre[256];
     v.state[s].n_edges_buf[eb] = acc > v.edge_cap ? v.edge_cap : acc;
+    if (to_host) v.host_edges_hdr[kEdgePipeBufs + eb] = (unsigned int)(acc > v.edge_cap ? v.edge_cap : acc);
   }
   const int E = pre[H] > v.edge_cap ? v.edge_cap : pre[H];
   for (int e = blockIdx.x * 256 + threadIdx.x; e < E; e += kCompactBlocks * 256) {
@@ -38,10 +42,24 @@ __global__ __launch_bounds__(256) void k_compact_edges(DevView v, int s0, int eb
     const int r = lo, k = e - pre[r];
     const size_t pi = ((size_t)s * H + r) * v.slots_per_ring + k;
     const size_t eo = ((size_t)eb * v.n_streams + s) * v.edge_cap + e;
-    v.edges[eo] = v.edges_pad[pi];
+    const float4 pt = v.edges_pad[pi];
+    v.edges[eo] = pt;
     const int2 m = v.edges_pad_meta[pi];
     v.edges_meta[eo] = make_int4(r, m.x, m.y, 0);
+    if (to_host) {
+      v.host_edges[(size_t)eb * v.edge_cap + e] = pt;
+      v.host_edges_meta[(size_t)eb * v.edge_cap + e] = make_int4(r, m.x, m.y, 0);
+    }
   }
+}
+
+// Behind k_compact_edges in stream order (that launch has ended: its stores, to HBM and to host memory, are complete):
+// the extraction's sequence number for the odometry side's kernels (dev_flag, as k_set_flag; may be null) and for the host
+// thread that waits for the edges (host_seq, system scope; may be null).
+__global__ void k_publish_edges(unsigned int* dev_flag, unsigned int* host_seq, unsigned int value) {
+  typedef __attribute__((address_space(1))) unsigned int gu32;
+  if (dev_flag) __hip_atomic_store((gu32*)dev_flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (host_seq) __hip_atomic_store(host_seq, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // For liodom_odometry_step (edges supplied by the caller): set counts and reset diagnostics.

@@ -410,8 +410,10 @@ __device__ __forceinline__ unsigned int region_keys_load(unsigned int (&kf)[IPL]
     f3v q[18];                                              // x y z only: 12-byte loads, 54 registers per batch
 #pragma unroll
     for (int i = 0; i < 18; i++) {
-      // ring index k0 + c0 + i; item c0 + t uses q[t .. t + 10].  Lanes at the end of the ring read up to 26
-      // points past it (the next ring, or the padding the allocation carries): those items are not owned.
+      // ring index k0 + c0 + i; item c0 + t uses q[t .. t + 10].  A region shorter than the 16 * IPL items of the register
+      // tile leaves lanes whose items lie beyond its end: they read up to 16 * IPL + 10 points past the START of the ring's
+      // last region, i.e. into the next ring or into the padding behind the last ring of the last stream (liodom_create
+      // allocates kExLPR * kExIPLBig + 64 points of it); those items are not owned and their values never used.
       q[i] = *reinterpret_cast<const f3v*>(rp + k0 + c0 + i);
     }
 #pragma unroll

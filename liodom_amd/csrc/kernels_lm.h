@@ -400,6 +400,9 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
   if (!st.initialized) {
     // first frame (:108-136): no solve; pose stays identity, edges enter the window raw
     if (outer_it == 1 && g == 0) {
+      // (the host never overlaps the second kNN pass of an uninitialised stream — reset_state() — but if it did, that pass must
+      //  have read `initialized` before it changes: a workgroup that saw 1 would wait for a pose this branch never publishes)
+      if (seq) ov_wait_knn_done(v, s, seq, &st.status);
       if (tid == 0) st.append_raw = 1;
       finalize_scan(v, s, st, sh_cnt, eb, true, 0);
       if (tid == 0) st.initialized = 1;

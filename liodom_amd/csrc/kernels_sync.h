@@ -134,6 +134,20 @@ __device__ __forceinline__ void ov_wait_knn_done(const DevView& v, int s, unsign
   __syncthreads();
 }
 
+// liodom_create's probe: do kernels of two HIP streams of this process run side by side?  One wave waits (bounded, ~2 ms) for a
+// flag that a launch on the other stream sets.  Under a profiler or debugger that serialises kernels across streams (rocprofv3
+// --pmc, AMD_SERIALIZE_KERNEL) the setter cannot start before the waiter has given up: result[0] = 1 seen / 2 gave up.
+__global__ void k_probe_wait(const unsigned int* flag, unsigned int* result) {
+  typedef __attribute__((address_space(1))) unsigned int gu32;
+  if (threadIdx.x != 0) return;
+  unsigned int spins = 0, seen = 2u;
+  while (spins++ < 12000u) {        // ~ 2 ms at s_sleep 8 (~0.17 us per round)
+    if (__hip_atomic_load((gu32*)flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { seen = 1u; break; }
+    __builtin_amdgcn_s_sleep(8);
+  }
+  result[0] = seen;
+}
+
 __global__ void k_set_flag(unsigned int* flag, unsigned int value) {
   typedef __attribute__((address_space(1))) unsigned int gu32;
   __hip_atomic_store((gu32*)flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -51,6 +51,9 @@ struct EventPair { hipEvent_t a, b; int kid; };
 std::atomic<int> g_live_handles{0};      // handles alive in this process (the overlapped second kNN pass is for a GPU one handle has to itself)
 
 struct liodom_handle {
+  liodom_handle() {
+    for (int b = 0; b < kEdgePipeBufs; b++) { ev_free_valid[b] = false; eb_reader[b] = 0u; tk_seq[b] = 0u; }
+  }
   liodom_params_t params;
   liodom_config_t config;
   DevView v{};
@@ -79,12 +82,29 @@ struct liodom_handle {
   bool ev_xdone_valid[3] = {false, false, false};
   hipEvent_t ev_edges[kEdgePipeBufs] = {nullptr, nullptr, nullptr};   // edge buffer b written
   hipEvent_t ev_free[kEdgePipeBufs] = {nullptr, nullptr, nullptr};    // odometry finished reading edge buffer b
-  bool ev_free_valid[kEdgePipeBufs] = {false, false, false};
+  std::atomic<bool> ev_free_valid[kEdgePipeBufs];      // (written by the odometry side, read by the extraction side)
   int parity = 0;                    // edge buffer of the next scan to enter odometry
   // pipelined replay without cross-stream events (pipe_flags in DevView; events remain for handles with >= 16 streams and as the fallback):
   unsigned int ext_seq = 0, odo_seq = 0;                 // extractions issued / odometries enqueued through the pipelined replay
   unsigned int eb_seq[kEdgePipeBufs] = {0, 0, 0};        // sequence number of the extraction last issued into buffer b
-  unsigned int eb_reader[kEdgePipeBufs] = {0, 0, 0};     // number of the odometry that last read buffer b (0: none to wait for)
+  std::atomic<unsigned int> eb_reader[kEdgePipeBufs];    // number of the odometry that last read buffer b (0: none to wait for); written by the odometry side
+  // Device-resident hand-off of the two-thread binding (liodom_extract_edges_device on the extraction side fills pipeline buffer
+  // x_next and returns a ticket; liodom_odometry_step_device on the odometry side consumes it): the element of the reference's
+  // feature queue (shared_data.cc:64-89) without the cloud leaving HBM.
+  std::atomic<unsigned int> tk_seq[kEdgePipeBufs];       // 0: slot free, else the sequence number of the extraction it holds; freed by the odometry side
+                                                         // when the pose of that scan has been collected (its odometry has completed)
+  int x_next = 0;                                        // slot of the next liodom_extract_edges_device (extraction side)
+  int odo_fifo[2] = {0, 0}, odo_pending = 0;             // odometry side: slots of the submitted, not yet collected scans (oldest first)
+  float4* host_edges = nullptr;      // host-mapped mirror of the dense edges of pipeline buffers 0..2 (one-stream handles; DevView::host_edges)
+  int4* host_edges_meta = nullptr;
+  unsigned int* host_edges_hdr = nullptr;
+  float4* pin_ring = nullptr;        // page-locked scan staging ring [kEdgePipeBufs][max_points]: liodom_scan_buffer hands slots out, pageable scans are copied through it
+  hipEvent_t ev_pin[kEdgePipeBufs] = {nullptr, nullptr, nullptr};     // the upload out of staging slot r has completed
+  bool ev_pin_valid[kEdgePipeBufs] = {false, false, false};
+  int pin_next = 0;
+  bool streams_concurrent = true;    // liodom_create's probe: kernels of two streams of this handle ran side by side
+  std::atomic<bool> pipe_active{false};        // scans went through the pipeline edge buffers by ticket since the last drain
+  std::atomic<bool> fallback_pending{false};   // a kernel of this handle gave up an in-kernel wait (LIODOM_STATUS_PIPE_TIMEOUT): liodom_reset() switches to events
   int pf_slot = -1;                  // resident slot whose extraction has been issued ahead
   int last_eb = 0;                   // edge buffer of the most recent scan that entered odometry (inspection)
   hipEvent_t pose_event = nullptr;
@@ -164,7 +184,7 @@ inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 // ---- launch sequences -----------------------------------------------------------------------
 // Feature extraction of `count` streams starting at s0; input scan for stream s0+i at in + i*stride.
 int launch_extract(liodom_handle* h, hipStream_t q, int eb, int s0, int count, const float4* in, size_t in_stride,
-                   int n, int height, int width, unsigned int wait_odo = 0) {
+                   int n, int height, int width, unsigned int wait_odo = 0, int mirror = 0) {
   const DevView& v = h->v;
   const int tiles = std::max(1, cdiv(n, kTilePts));
   if (v.lidar_type == 1 && width > 0 && (long long)h->H * width <= (long long)v.max_points) {
@@ -199,7 +219,7 @@ int launch_extract(liodom_handle* h, hipStream_t q, int eb, int s0, int count, c
   }
   {
     ProfScope ps(h, KID_COMPACT, q);
-    hipLaunchKernelGGL(k_compact_edges, dim3(kCompactBlocks, count), dim3(256), 0, q, v, s0, eb, wait_odo);
+    hipLaunchKernelGGL(k_compact_edges, dim3(kCompactBlocks, count), dim3(256), 0, q, v, s0, eb, wait_odo, mirror);
   }
   HIP_TRY(hipGetLastError());
   return LIODOM_OK;
@@ -348,6 +368,14 @@ int check_stream(liodom_handle* h, int stream) {
   if (stream < 0 || stream >= h->S) { g_last_error = "stream index out of range"; return LIODOM_ERR_INVALID_ARG; }
   return LIODOM_OK;
 }
+// entry points that enqueue scans: not after an in-kernel wait of this handle gave up (see wait_pose)
+int check_usable(liodom_handle* h) {
+  if (h->fallback_pending.load()) {
+    g_last_error = "the handle had a LIODOM_STATUS_PIPE_TIMEOUT: call liodom_reset() before processing further scans";
+    return LIODOM_ERR_HIP;
+  }
+  return LIODOM_OK;
+}
 // Lock guards of the two sides.  While per-kernel profiling is on, extraction runs on the odometry
 // stream (so that HIP-event durations are not inflated by the other side's kernels) and shares the
 // event pool: then every entry point takes both locks and the two sides are serialised.
@@ -370,12 +398,44 @@ int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 // The plain (non-pipelined) entry points run everything on h->stream with edge buffer 0; make
 // sure no extraction issued ahead by the pipelined replay is still in flight.
+int tickets_idle(liodom_handle* h) {      // the plain entry points use pipeline edge buffer 0 themselves
+  for (int b = 0; b < kEdgePipeBufs; b++) {
+    if (h->tk_seq[b].load() != 0u) { g_last_error = "edge tickets of liodom_extract_edges_device are outstanding: consume them with liodom_odometry_step_device first"; return LIODOM_ERR_BUSY; }
+  }
+  return LIODOM_OK;
+}
 int drain_pipeline(liodom_handle* h) {
-  if (h->pf_slot >= 0 || h->parity != 0) {
+  if (h->pf_slot >= 0 || h->parity != 0 || h->pipe_active.exchange(false)) {
     HIP_TRY(hipStreamSynchronize(h->stream_x));
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->pf_slot = -1; h->parity = 0; h->ev_free_valid[0] = h->ev_free_valid[1] = h->ev_free_valid[2] = false;
     for (int b = 0; b < kEdgePipeBufs; b++) h->eb_reader[b] = 0;      // (everything has completed: nothing to wait for)
+  }
+  return LIODOM_OK;
+}
+
+// The odometry of the scan in pipeline edge buffer eb behind whatever produces that buffer (extraction number wait_seq with
+// flags, ev_edges[eb] with events), as the pipelined replay and the device-resident hand-off enqueue it.  Odometry side.
+int enqueue_pipeline_odometry(liodom_handle* h, int eb, unsigned int wait_seq) {
+  int rc;
+  if (h->use_flags) {
+    // no cross-stream events (they cost ~11 us of idle odometry stream per scan, with the host far ahead as well): the
+    // first kNN launch waits for the extraction's flag and signals that the previous odometry has completed
+    const unsigned int m = ++h->odo_seq == 0 ? ++h->odo_seq : h->odo_seq;
+    if (h->flag_gate) {
+      hipLaunchKernelGGL(k_pipe_gate, dim3(1), dim3(64), 0, h->stream, h->v, 0, eb, wait_seq, m - 1u);
+      rc = launch_odometry(h, eb, 0, h->S);
+    } else {
+      rc = launch_odometry(h, eb, 0, h->S, wait_seq, m - 1u);
+    }
+    if (rc) return rc;
+    h->eb_reader[eb] = m;
+  } else {
+    HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_edges[eb], 0));
+    rc = launch_odometry(h, eb, 0, h->S);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(h->ev_free[eb], h->stream));
+    h->ev_free_valid[eb] = true;
   }
   return LIODOM_OK;
 }
@@ -429,6 +489,14 @@ int reset_state(liodom_handle* h) {
   }
   h->pf_slot = -1; h->parity = 0; h->last_eb = 0; h->ev_free_valid[0] = h->ev_free_valid[1] = h->ev_free_valid[2] = false;
   h->ext_seq = h->odo_seq = 0;
+  // the first scans after a reset are not overlapped (as after liodom_create): the first one runs with st.initialized == 0, where
+  // no first solve publishes the pose an overlapped second kNN pass would wait for
+  if (h->stream_k) HIP_TRY(hipStreamSynchronize(h->stream_k));
+  h->ov_warm = 0; h->ov_prev = false;
+  if (h->fallback_pending.exchange(false)) h->use_flags = false;      // an in-kernel wait gave up (wait_pose): events from here on
+  for (int b = 0; b < kEdgePipeBufs; b++) { h->tk_seq[b] = 0u; h->ev_pin_valid[b] = false; }      // outstanding edge tickets are void
+  h->x_next = 0; h->odo_pending = 0;
+  if (h->host_edges_hdr) std::memset(h->host_edges_hdr, 0, sizeof(unsigned int) * 2 * kEdgePipeBufs);
   for (int b = 0; b < kEdgePipeBufs; b++) { h->eb_seq[b] = 0; h->eb_reader[b] = 0; }
   HIP_TRY(hipMemsetAsync(h->v.pipe_flags, 0, sizeof(unsigned int) * (kEdgePipeBufs + 1), h->stream));
   HIP_TRY(hipMemsetAsync(h->v.lm_xch, 0, sizeof(unsigned long long) * (size_t)h->S * 2 * kLmGroupsMax * 64, h->stream));
@@ -470,7 +538,7 @@ void liodom_config_default(liodom_config_t* c) {
   if (!c) return;
   std::memset(c, 0, sizeof(*c));
   c->device = 0; c->n_streams = 1; c->max_points = 64 * 1800; c->max_width = 1800;
-  c->max_ring_points = 0; c->lm_apply_step_on_ftol = 0; c->pose_log_capacity = 1024; c->debug_buffers = 0;
+  c->reserved1 = 0; c->lm_apply_step_on_ftol = 0; c->pose_log_capacity = 1024; c->debug_buffers = 0;
   c->lm_workgroups = 0;
   c->pose_rotation_mode = 1;    // Eigen 3.3.x Transform::rotation()
 }
@@ -567,8 +635,8 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   v.vox_inv = 1.0f / 0.4f;                                                          // setLeafSize(0.4) :290
   v.n_streams = h->S;
   v.max_points = config->max_points;
-  // (max_width / max_ring_points are kept in the config for compatibility: k_ring_extract stages nothing per
-  // point in LDS any more, so there is no per-ring capacity — a ring may hold up to max_points points)
+  // (k_ring_extract stages nothing per point in LDS, so there is no per-ring capacity — a ring may hold up to max_points
+  // points; config.max_width only picks the kernel instance, launch_extract)
   v.ring_cap = config->max_points;
   v.slots_per_ring = params->scan_regions * (params->edges_per_region + 1);
   h->ring_lds_bytes = ring_extract_lds_bytes(v.slots_per_ring, params->scan_regions);
@@ -656,6 +724,42 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   ALLOC(v.lm_xch, S * 2 * kLmGroupsMax * 64, 0);
   ALLOC(v.pose_xch, S * 32, 0);
   ALLOC(v.pipe_flags, kEdgePipeBufs + 1, 0);
+  v.host_edges = nullptr; v.host_edges_meta = nullptr; v.host_edges_hdr = nullptr;
+  if (S == 1) {
+    // device-resident hand-off (liodom_extract_edges_device): host-mapped mirror of the dense edges of the three pipeline buffers
+    const size_t ne = (size_t)kEdgePipeBufs * v.edge_cap;
+    void *he = nullptr, *hm = nullptr, *hh = nullptr;
+    if (hipHostMalloc(&he, sizeof(float4) * ne, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        hipHostMalloc(&hm, sizeof(int4) * ne, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        hipHostMalloc(&hh, sizeof(unsigned int) * 2 * kEdgePipeBufs, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+      if (he) hipHostFree(he);
+      if (hm) hipHostFree(hm);
+      g_last_error = "hipHostMalloc (edge mirror) failed"; return fail(LIODOM_ERR_HIP);
+    }
+    h->host_edges = static_cast<float4*>(he); h->host_edges_meta = static_cast<int4*>(hm); h->host_edges_hdr = static_cast<unsigned int*>(hh);
+    std::memset(hh, 0, sizeof(unsigned int) * 2 * kEdgePipeBufs);
+    void *de = nullptr, *dm = nullptr, *dh = nullptr;
+    if (hipHostGetDevicePointer(&de, he, 0) != hipSuccess || hipHostGetDevicePointer(&dm, hm, 0) != hipSuccess ||
+        hipHostGetDevicePointer(&dh, hh, 0) != hipSuccess) { g_last_error = "hipHostGetDevicePointer failed"; return fail(LIODOM_ERR_HIP); }
+    v.host_edges = static_cast<float4*>(de); v.host_edges_meta = static_cast<int4*>(dm); v.host_edges_hdr = static_cast<unsigned int*>(dh);
+  }
+  if (h->use_flags) {
+    // Flags need kernels of the handle's streams to run side by side.  Known serialisers are caught by name above; this probe
+    // catches the rest (a profiler collecting counters, a debugger): one wave on the odometry stream waits up to ~10 ms for a flag
+    // that a launch on the extraction stream sets.  If it gives up, the handle uses events from the start.
+    unsigned int* probe = nullptr;
+    ALLOC(probe, 4, 0);
+    hipLaunchKernelGGL(k_set_flag, dim3(1), dim3(1), 0, h->stream, probe + 2, 1u);        // (first launches on both streams: code upload)
+    hipLaunchKernelGGL(k_set_flag, dim3(1), dim3(1), 0, h->stream_x, probe + 3, 1u);
+    if (hipStreamSynchronize(h->stream) != hipSuccess || hipStreamSynchronize(h->stream_x) != hipSuccess) { g_last_error = "stream probe failed"; return fail(LIODOM_ERR_HIP); }
+    hipLaunchKernelGGL(k_probe_wait, dim3(1), dim3(64), 0, h->stream, probe, probe + 1);
+    hipLaunchKernelGGL(k_set_flag, dim3(1), dim3(1), 0, h->stream_x, probe, 1u);
+    unsigned int res = 0;
+    if (hipStreamSynchronize(h->stream) != hipSuccess || hipStreamSynchronize(h->stream_x) != hipSuccess ||
+        hipMemcpy(&res, probe + 1, sizeof(res), hipMemcpyDeviceToHost) != hipSuccess) { g_last_error = "stream probe failed"; return fail(LIODOM_ERR_HIP); }
+    h->streams_concurrent = res == 1u;
+    if (!h->streams_concurrent) h->use_flags = false;
+  }
   {
     bool gate_kernel = config->n_streams >= 16;         // lock-step batches: line gates in their own launch (k_line_gate)
     if (const char* e = std::getenv("LIODOM_GATE_KERNEL")) gate_kernel = gate_kernel && std::atoi(e) != 0;
@@ -754,6 +858,11 @@ void liodom_destroy(liodom_handle_t* h) {
   for (void* p : h->allocs) hipFree(p);
   if (h->resident) hipFree(h->resident);
   if (h->host_out) hipHostFree(h->host_out);
+  if (h->host_edges) hipHostFree(h->host_edges);
+  if (h->host_edges_meta) hipHostFree(h->host_edges_meta);
+  if (h->host_edges_hdr) hipHostFree(h->host_edges_hdr);
+  if (h->pin_ring) hipHostFree(h->pin_ring);
+  for (int b = 0; b < kEdgePipeBufs; b++) if (h->ev_pin[b]) hipEventDestroy(h->ev_pin[b]);
   for (auto& e : h->ev_pool) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
   if (h->pose_event) hipEventDestroy(h->pose_event);
   for (int b = 0; b < kEdgePipeBufs; b++) { if (h->ev_edges[b]) hipEventDestroy(h->ev_edges[b]); if (h->ev_free[b]) hipEventDestroy(h->ev_free[b]); }
@@ -800,6 +909,7 @@ int liodom_extract_edges(liodom_handle_t* h, int stream, const float* xyzi, int6
                          int32_t* edge_src, int cap, int* n_edges) {
   int rc = check_stream(h, stream);
   if (rc) return rc;
+  if ((rc = check_usable(h))) return rc;
   if (n < 0 || n > h->v.max_points || (n > 0 && !xyzi)) { g_last_error = "bad point count"; return LIODOM_ERR_CAPACITY; }
   // Extraction side only (mx_x, stream_x, edge buffer kEdgeBufX): safe beside a concurrent
   // liodom_odometry_step of another thread.  An extraction the pipelined replay issued ahead is on the
@@ -842,17 +952,14 @@ static int wait_pose(liodom_handle_t* h, int s0, int count, double* pose_out, li
     if (r->info.status & LIODOM_STATUS_PIPE_TIMEOUT) timed_out = true;
   }
   if (timed_out) {
-    // A kernel of the pipelined replay gave up waiting for the handle's other HIP stream (pipe_wait): its workgroups
-    // skipped the scan, the published pose is the prediction.  Fail loudly and stop relying on co-scheduled streams.
-    (void)hipStreamSynchronize(h->stream_x);
-    (void)hipStreamSynchronize(h->stream);
-    if (h->stream_k) (void)hipStreamSynchronize(h->stream_k);
-    h->use_flags = false;
-    h->pf_slot = -1;
-    for (int b = 0; b < kEdgePipeBufs; b++) { h->ev_free_valid[b] = false; h->eb_reader[b] = 0; }
-    g_last_error = "pipelined replay: a kernel timed out waiting for the handle's other HIP stream (LIODOM_STATUS_PIPE_TIMEOUT): "
-                   "kernels are serialised across streams (profiler with --pmc, AMD_SERIALIZE_KERNEL, debugger) or the GPU is saturated; "
-                   "the scan's result is invalid; the handle now uses events (LIODOM_PIPE_FLAGS=0) - liodom_reset() the stream";
+    // A kernel gave up waiting for another HIP stream of the handle (pipe_wait / ov_wait_*): its workgroups skipped the scan, the
+    // published pose is the prediction.  Fail loudly; the switch to event-based dependencies needs both sides of the handle
+    // (this caller may hold the odometry side only while another thread extracts): it is applied by liodom_reset(), and every
+    // entry point that enqueues work refuses until then (check_usable).
+    h->fallback_pending.store(true);
+    g_last_error = "a kernel timed out waiting for another HIP stream of the handle (LIODOM_STATUS_PIPE_TIMEOUT): kernels are serialised "
+                   "across streams (profiler with --pmc, AMD_SERIALIZE_KERNEL, debugger) or the GPU is saturated by another process; the "
+                   "scan's result is invalid; call liodom_reset(): the handle then continues with event-based stream dependencies";
     return LIODOM_ERR_HIP;
   }
   return LIODOM_OK;
@@ -863,9 +970,11 @@ int liodom_odometry_step(liodom_handle_t* h, int stream, const float* edges_xyzi
   (void)stamp;
   int rc = check_stream(h, stream);
   if (rc) return rc;
+  if ((rc = check_usable(h))) return rc;
   if (n_edges < 0 || n_edges > h->v.edge_cap || (n_edges > 0 && !edges_xyzi)) { g_last_error = "edge count exceeds capacity"; return LIODOM_ERR_CAPACITY; }
   // Odometry side only (mx_o, h->stream, edge buffer 0): safe beside a concurrent liodom_extract_edges.
   SideLocks lk(h, true, false);
+  if ((rc = tickets_idle(h))) return rc;
   rc = drain_pipeline(h);
   if (rc) return rc;
   if (n_edges)
@@ -879,13 +988,187 @@ int liodom_odometry_step(liodom_handle_t* h, int stream, const float* edges_xyzi
   return wait_pose(h, stream, 1, pose_out, info);
 }
 
+// ---- device-resident hand-off between the two sides (the reference's feature queue without the cloud leaving HBM) ----
+static int ensure_pin_ring(liodom_handle* h) {
+  if (h->pin_ring) return LIODOM_OK;
+  void* p = nullptr;
+  HIP_TRY(hipHostMalloc(&p, sizeof(float4) * (size_t)kEdgePipeBufs * (size_t)h->v.max_points, hipHostMallocDefault));
+  h->pin_ring = static_cast<float4*>(p);
+  for (int b = 0; b < kEdgePipeBufs; b++) HIP_TRY(hipEventCreateWithFlags(&h->ev_pin[b], hipEventDisableTiming));
+  return LIODOM_OK;
+}
+
+int liodom_scan_buffer(liodom_handle_t* h, int stream, float** xyzi, int64_t* capacity_points) {
+  int rc = check_stream(h, stream);
+  if (rc) return rc;
+  if (!xyzi) return LIODOM_ERR_INVALID_ARG;
+  if (h->S != 1) { g_last_error = "liodom_scan_buffer: one-stream handles only"; return LIODOM_ERR_UNSUPPORTED; }
+  SideLocks lk(h, false, true);
+  if ((rc = ensure_pin_ring(h))) return rc;
+  const int r = h->pin_next;
+  // the upload that last read this slot (three scans ago) must have left it
+  if (h->ev_pin_valid[r]) { HIP_TRY(hipEventSynchronize(h->ev_pin[r])); h->ev_pin_valid[r] = false; }
+  *xyzi = reinterpret_cast<float*>(h->pin_ring + (size_t)r * h->v.max_points);
+  if (capacity_points) *capacity_points = h->v.max_points;
+  return LIODOM_OK;
+}
+
+int liodom_extract_edges_device(liodom_handle_t* h, int stream, const float* xyzi, int64_t n, int height, int width,
+                                liodom_edge_ticket_t* ticket) {
+  int rc = check_stream(h, stream);
+  if (rc) return rc;
+  if ((rc = check_usable(h))) return rc;
+  if (!ticket) return LIODOM_ERR_INVALID_ARG;
+  if (h->S != 1) { g_last_error = "liodom_extract_edges_device: one-stream handles only (lock-step handles advance all streams together: liodom_process_resident)"; return LIODOM_ERR_UNSUPPORTED; }
+  if (n < 0 || n > h->v.max_points || (n > 0 && !xyzi)) { g_last_error = "bad point count"; return LIODOM_ERR_CAPACITY; }
+  SideLocks lk(h, false, true);                      // extraction side only: safe beside a concurrent liodom_odometry_step_device
+  if (h->pf_slot >= 0) { g_last_error = "liodom_extract_edges_device: a pipelined replay of this handle has an extraction issued ahead"; return LIODOM_ERR_BUSY; }
+  const int eb = h->x_next;
+  if (h->tk_seq[eb].load() != 0u) {
+    g_last_error = "liodom_extract_edges_device: all hand-off slots hold edge clouds no liodom_odometry_step_device has taken yet";
+    return LIODOM_ERR_BUSY;
+  }
+  hipStream_t q = extract_queue(h);
+  float4* in = h->stage_in + (size_t)stream * h->v.max_points;
+  if (n) {
+    // The scan's upload is asynchronous when it starts from page-locked memory: a slot of the handle's own ring
+    // (liodom_scan_buffer), or a buffer the caller registered (liodom_pin_host_buffer) — which must stay untouched until
+    // liodom_wait_edges / liodom_odometry_step_device of this ticket has returned.  A pageable scan is copied through the ring.
+    if ((rc = ensure_pin_ring(h))) return rc;
+    const char* lo = reinterpret_cast<const char*>(h->pin_ring);
+    const char* hi = lo + sizeof(float4) * (size_t)kEdgePipeBufs * (size_t)h->v.max_points;
+    const char* src = reinterpret_cast<const char*>(xyzi);
+    bool own = src >= lo && src < hi, pinned = own;
+    if (!own) {
+      hipPointerAttribute_t attr;
+      if (hipPointerGetAttributes(&attr, xyzi) == hipSuccess) pinned = attr.type == hipMemoryTypeHost;
+      else (void)hipGetLastError();                  // (unregistered pageable memory: not an error)
+    }
+    const int r = own ? (int)((src - lo) / (sizeof(float4) * (size_t)h->v.max_points)) : h->pin_next;
+    if (!pinned) {
+      if (h->ev_pin_valid[r]) { HIP_TRY(hipEventSynchronize(h->ev_pin[r])); h->ev_pin_valid[r] = false; }
+      std::memcpy(h->pin_ring + (size_t)r * h->v.max_points, xyzi, sizeof(float4) * (size_t)n);
+      xyzi = reinterpret_cast<const float*>(h->pin_ring + (size_t)r * h->v.max_points);
+    }
+    HIP_TRY(hipMemcpyAsync(in, xyzi, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, q));
+    if (own || !pinned) {
+      HIP_TRY(hipEventRecord(h->ev_pin[r], q));
+      h->ev_pin_valid[r] = true;
+      h->pin_next = (r + 1) % kEdgePipeBufs;
+    }
+  }
+  unsigned int seq = ++h->ext_seq;
+  if (seq == 0u) seq = ++h->ext_seq;                 // (0 means "nothing to wait for")
+  unsigned int* host_seq = h->v.host_edges_hdr ? h->v.host_edges_hdr + eb : nullptr;
+  // (the slot is free: the odometry that last read buffer eb has been collected, i.e. has completed — no wait on the device,
+  //  which would depend on when the other thread submits its next scan)
+  if (h->use_flags) {
+    rc = launch_extract(h, q, eb, stream, 1, in, 0, (int)n, height, width, 0u, 1);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_publish_edges, dim3(1), dim3(1), 0, q, h->v.pipe_flags + eb, host_seq, seq);
+  } else {
+    rc = launch_extract(h, q, eb, stream, 1, in, 0, (int)n, height, width, 0u, 1);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_publish_edges, dim3(1), dim3(1), 0, q, (unsigned int*)nullptr, host_seq, seq);
+    HIP_TRY(hipEventRecord(h->ev_edges[eb], q));
+  }
+  HIP_TRY(hipGetLastError());
+  h->eb_seq[eb] = seq;
+  h->pipe_active.store(true);
+  h->tk_seq[eb].store(seq);
+  h->x_next = (eb + 1) % kEdgePipeBufs;
+  ticket->seq = seq; ticket->slot = eb; ticket->stream = stream; ticket->reserved = 0;
+  return LIODOM_OK;
+}
+
+int liodom_wait_edges(liodom_handle_t* h, const liodom_edge_ticket_t* ticket, float* edges_xyzi, int32_t* edge_ring,
+                      int32_t* edge_idx, int32_t* edge_src, int cap, int* n_edges) {
+  if (!h || !ticket) return LIODOM_ERR_INVALID_ARG;
+  int rc = check_stream(h, ticket->stream);
+  if (rc) return rc;
+  const int eb = ticket->slot;
+  if (eb < 0 || eb >= kEdgePipeBufs || !h->host_edges_hdr) { g_last_error = "liodom_wait_edges: bad ticket"; return LIODOM_ERR_INVALID_ARG; }
+  // No lock: the slot's mirror is rewritten only by an extraction issued after the ticket has been consumed
+  // (liodom_odometry_step_device), which the caller orders behind this call.
+  volatile unsigned int* hs = h->host_edges_hdr + eb;
+  unsigned long long spins = 0;
+  while ((int)(__atomic_load_n(hs, __ATOMIC_ACQUIRE) - ticket->seq) < 0) {
+    if ((++spins & 0xFFFFull) == 0) {
+      const hipError_t q = hipStreamQuery(extract_queue(h));
+      if (q != hipErrorNotReady && q != hipSuccess) { g_last_error = std::string("stream error while waiting for edges: ") + hipGetErrorString(q); return LIODOM_ERR_HIP; }
+      if (q == hipSuccess && (int)(__atomic_load_n(hs, __ATOMIC_ACQUIRE) - ticket->seq) < 0) { g_last_error = "extraction stream drained without publishing the ticket's edges"; return LIODOM_ERR_HIP; }
+    }
+  }
+  if (__atomic_load_n(hs, __ATOMIC_ACQUIRE) != ticket->seq) { g_last_error = "liodom_wait_edges: the ticket's slot has been reused (stale ticket)"; return LIODOM_ERR_INVALID_ARG; }
+  const int E = (int)h->host_edges_hdr[kEdgePipeBufs + eb];
+  if (n_edges) *n_edges = E;
+  if (E > cap && (edges_xyzi || edge_ring || edge_idx || edge_src)) { g_last_error = "edge buffer too small"; return LIODOM_ERR_CAPACITY; }
+  const float4* he = h->host_edges + (size_t)eb * h->v.edge_cap;
+  const int4* hm = h->host_edges_meta + (size_t)eb * h->v.edge_cap;
+  if (edges_xyzi && E) std::memcpy(edges_xyzi, he, sizeof(float4) * (size_t)E);
+  if (edge_ring || edge_idx || edge_src) {
+    for (int i = 0; i < E; i++) {
+      if (edge_ring) edge_ring[i] = hm[i].x;
+      if (edge_idx) edge_idx[i] = hm[i].y;
+      if (edge_src) edge_src[i] = hm[i].z;
+    }
+  }
+  return LIODOM_OK;
+}
+
+int liodom_odometry_submit_device(liodom_handle_t* h, const liodom_edge_ticket_t* ticket, double stamp) {
+  (void)stamp;
+  if (!h || !ticket) return LIODOM_ERR_INVALID_ARG;
+  int rc = check_stream(h, ticket->stream);
+  if (rc) return rc;
+  if ((rc = check_usable(h))) return rc;
+  const int eb = ticket->slot;
+  if (h->S != 1 || eb < 0 || eb >= kEdgePipeBufs) { g_last_error = "liodom_odometry_submit_device: bad ticket"; return LIODOM_ERR_INVALID_ARG; }
+  SideLocks lk(h, true, false);                      // odometry side only: safe beside a concurrent liodom_extract_edges_device
+  if (ticket->seq == 0u || h->tk_seq[eb].load() != ticket->seq) {
+    g_last_error = "liodom_odometry_submit_device: stale or unknown ticket (already consumed, or voided by liodom_reset)";
+    return LIODOM_ERR_INVALID_ARG;
+  }
+  for (int i = 0; i < h->odo_pending; i++) if (h->odo_fifo[i] == eb) { g_last_error = "liodom_odometry_submit_device: ticket already submitted"; return LIODOM_ERR_INVALID_ARG; }
+  if (h->odo_pending >= 2) { g_last_error = "liodom_odometry_submit_device: two scans are in flight: collect a pose first (liodom_odometry_collect)"; return LIODOM_ERR_BUSY; }
+  rc = enqueue_pipeline_odometry(h, eb, ticket->seq);
+  if (rc) return rc;
+  h->pipe_active.store(true);
+  h->odo_fifo[h->odo_pending++] = eb;
+  return LIODOM_OK;
+}
+
+int liodom_odometry_collect(liodom_handle_t* h, int stream, double* pose_out, liodom_step_info_t* info) {
+  int rc = check_stream(h, stream);
+  if (rc) return rc;
+  SideLocks lk(h, true, false);
+  if (h->odo_pending <= 0) { g_last_error = "liodom_odometry_collect: no scan has been submitted"; return LIODOM_ERR_INVALID_ARG; }
+  rc = wait_pose(h, stream, 1, pose_out, info, h->odo_pending - 1);      // the oldest of the (at most two) scans in flight
+  const int eb = h->odo_fifo[0];
+  h->odo_fifo[0] = h->odo_fifo[1];
+  h->odo_pending--;
+  h->tk_seq[eb].store(0u);                           // its odometry has completed: the slot may be refilled
+  return rc;
+}
+
+int liodom_odometry_step_device(liodom_handle_t* h, const liodom_edge_ticket_t* ticket, double stamp, double* pose_out,
+                                liodom_step_info_t* info) {
+  if (!h || !ticket) return LIODOM_ERR_INVALID_ARG;
+  if (h->odo_pending != 0) { g_last_error = "liodom_odometry_step_device: a submitted scan has not been collected (liodom_odometry_collect)"; return LIODOM_ERR_BUSY; }
+  const int rc = liodom_odometry_submit_device(h, ticket, stamp);
+  if (rc) return rc;
+  return liodom_odometry_collect(h, ticket->stream, pose_out, info);
+}
+
 int liodom_process_scan(liodom_handle_t* h, int stream, const float* xyzi, int64_t n, int height,
                         int width, double stamp, double* pose_out, liodom_step_info_t* info) {
   (void)stamp;
   int rc = check_stream(h, stream);
   if (rc) return rc;
+  if ((rc = check_usable(h))) return rc;
   if (n < 0 || n > h->v.max_points || (n > 0 && !xyzi)) { g_last_error = "bad point count"; return LIODOM_ERR_CAPACITY; }
   SideLocks lk(h, true, true);        // uses the extraction scratch on the odometry stream
+  if ((rc = tickets_idle(h))) return rc;
   rc = drain_pipeline(h);             // nothing issued ahead on the extraction stream may still use that scratch
   if (rc) return rc;
   float4* in = h->stage_in + (size_t)stream * h->v.max_points;
@@ -1026,6 +1309,7 @@ int liodom_process_resident_pipelined(liodom_handle_t* h, int slot, int next_slo
                                       int width, double* poses_out, liodom_step_info_t* infos_out) {
   int rc0 = enter(h);
   if (rc0) return rc0;
+  if ((rc0 = check_usable(h))) return rc0;
   SideLocks lk(h, true, true);
   return replay_one(h, slot, next_slot, n, height, width, poses_out != nullptr || infos_out != nullptr, poses_out, infos_out);
 }
@@ -1034,6 +1318,7 @@ int liodom_replay_resident(liodom_handle_t* h, int first_slot, int count, int ah
                            double* poses_out, liodom_step_info_t* infos_out) {
   int rc0 = enter(h);
   if (rc0) return rc0;
+  if ((rc0 = check_usable(h))) return rc0;
   if (count < 0 || first_slot < 0 || depth < 0 || depth > 1) { g_last_error = "bad resident range / depth"; return LIODOM_ERR_INVALID_ARG; }
   SideLocks lk(h, true, true);
   auto out_p = [&](int i) { return poses_out ? poses_out + (size_t)i * h->S * 7 : nullptr; };
@@ -1103,25 +1388,8 @@ static int replay_one(liodom_handle_t* h, int slot, int next_slot, int64_t n, in
     if (rc) return rc;
   }
   h->pf_slot = -1;
-  if (h->use_flags) {
-    // no cross-stream events (they cost ~11 us of idle odometry stream per scan, with the host far ahead as well): the
-    // first kNN launch waits for the extraction's flag and signals that the previous odometry has completed
-    const unsigned int m = ++h->odo_seq == 0 ? ++h->odo_seq : h->odo_seq;
-    if (h->flag_gate) {
-      hipLaunchKernelGGL(k_pipe_gate, dim3(1), dim3(64), 0, h->stream, h->v, 0, eb, h->eb_seq[eb], m - 1u);
-      rc = launch_odometry(h, eb, 0, h->S);
-    } else {
-      rc = launch_odometry(h, eb, 0, h->S, h->eb_seq[eb], m - 1u);
-    }
-    if (rc) return rc;
-    h->eb_reader[eb] = m;
-  } else {
-    HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_edges[eb], 0));
-    rc = launch_odometry(h, eb, 0, h->S);
-    if (rc) return rc;
-    HIP_TRY(hipEventRecord(h->ev_free[eb], h->stream));
-    h->ev_free_valid[eb] = true;
-  }
+  rc = enqueue_pipeline_odometry(h, eb, h->eb_seq[eb]);
+  if (rc) return rc;
   h->parity = (eb + 1) % kEdgePipeBufs;
   if (next_slot >= 0) {                           // overlap the next scan's (upload and) extraction with this odometry
     if (next_host) { rc = upload_slot_async(h, next_slot, next_host, host_stride, n); if (rc) return rc; }
@@ -1138,6 +1406,7 @@ int liodom_replay_host(liodom_handle_t* h, const float* xyzi_base, int64_t scan_
                        int64_t n, int height, int width, double* poses_out, liodom_step_info_t* infos_out) {
   int rc0 = enter(h);
   if (rc0) return rc0;
+  if ((rc0 = check_usable(h))) return rc0;
   if (count < 0 || depth < 0 || depth > 1 || n < 0 || n > h->v.max_points || (count > 0 && n > 0 && !xyzi_base) || scan_stride_floats < 4 * n) {
     g_last_error = "liodom_replay_host: bad arguments"; return LIODOM_ERR_INVALID_ARG;
   }
@@ -1405,12 +1674,12 @@ int liodom_get_modes(liodom_handle_t* h, char* buf, int cap) {
   snprintf(buf, (size_t)cap,
            "n_streams=%d early_rebuild=%d hash_build=%s pipe_flags=%d flag_gate=%d lm_groups=%d knn_instance=%d knn_queries=%d "
            "knn_grid=%d/%d knn_partials=%d knn_saved_bound=%d knn_exact_only=%d line_gate_kernel=%d filter_local_map=%d mapping=%d "
-           "rotation_mode=%d table_size=%d rebuild_delta=%.3f knn_overlap=%d debug=%d",
+           "rotation_mode=%d table_size=%d rebuild_delta=%.3f knn_overlap=%d streams_concurrent=%d debug=%d",
            h->S, v.early_rebuild, v.early_rebuild ? "streamed" : (h->lds_hash_build ? "lds" : "global"), h->use_flags ? 1 : 0,
            (h->use_flags && h->flag_gate) ? 1 : 0, v.lm_groups, h->S >= 16 ? 128 : 256, v.knn_queries, v.knn_grid,
            v.knn_blocks, v.knn_partials, v.knn_save_pos ? 2 : (v.knn_save_q ? 1 : 0), v.knn_exact_only, v.knn_nn ? 1 : 0, v.filter_local_map, v.mapping,
            v.rotation_mode, v.table_size, (double)v.rebuild_delta,
-           (v.early_rebuild && h->ov_ok && h->use_flags && g_live_handles.load() <= 1) ? 1 : 0, v.debug);
+           (v.early_rebuild && h->ov_ok && h->use_flags && g_live_handles.load() <= 1) ? 1 : 0, h->streams_concurrent ? 1 : 0, v.debug);
   return LIODOM_OK;
 }
 

@@ -201,6 +201,13 @@ struct DevView {
   unsigned int* ov_flags;          // [S] sequence number of the latest scan whose first solve launch has started (its first kNN pass has completed)
   unsigned long long* pose_xch0;   // [S][kOvReplicas][512] the first solve's result (odom[12], q[4], t[3]) as 38 tagged granules, replicated over memory channels
   unsigned int* knn_done;          // [S][knn_grid] sequence number of the latest overlapped second pass workgroup b has completed
+  // Device-resident hand-off of the two-thread binding (liodom_extract_edges_device -> liodom_odometry_step_device, one-stream
+  // handles): k_compact_edges also leaves the dense edges of pipeline buffer b in host-mapped memory, so that the extractor
+  // thread can publish ~edges (feature_extractor.cc:70-75) without a device-to-host copy call; null on other handles.
+  float4* host_edges;           // [kEdgePipeBufs][edge_cap] host-mapped
+  int4* host_edges_meta;        // [kEdgePipeBufs][edge_cap] (ring, idx_in_ring, src, 0)
+  unsigned int* host_edges_hdr; // [2][kEdgePipeBufs]: sequence number of the extraction whose edges are complete in slot b (written by
+                                // k_publish_edges, system scope); number of edges in slot b
   unsigned long long* dbg_clk;  // [16][32] phase timestamps (100 MHz) and counters, debug bit 5 only
   unsigned int* dbg_q;          // [2][edge_cap][8] per-query phase times of stream 0's latest scan (10 ns ticks since the workgroup's start), debug bit 5 only
 };

@@ -1,6 +1,7 @@
 #include "liodom_host.h"
 #include "../csrc/liodom_math.h"   // odom_message: the same header the kernels use
 
+#include <algorithm>
 #include <cstring>
 #include <fstream>
 #include <stdexcept>
@@ -129,16 +130,27 @@ bool SharedData::popPointCloud(PointCloud& pc_out, double& stamp) {
   return true;
 }
 void SharedData::pushFeatures(const PointCloud& feat_in, double stamp) {
-  std::lock_guard<std::mutex> lk(feat_mutex_);
-  feat_buf_.push(std::make_pair(feat_in, stamp));
+  Features f; f.edges = feat_in; f.stamp = stamp;
+  pushFeatures(std::move(f));
 }
 bool SharedData::popFeatures(PointCloud& feat_out, double& stamp) {
+  Features f;
+  if (!popFeatures(f)) return false;
+  feat_out = std::move(f.edges); stamp = f.stamp;
+  return true;
+}
+void SharedData::pushFeatures(Features&& f) {
+  std::lock_guard<std::mutex> lk(feat_mutex_);
+  feat_buf_.push(std::move(f));
+}
+bool SharedData::popFeatures(Features& f) {
   std::lock_guard<std::mutex> lk(feat_mutex_);
   if (feat_buf_.empty()) return false;
-  feat_out = std::move(feat_buf_.front().first); stamp = feat_buf_.front().second;
+  f = std::move(feat_buf_.front());
   feat_buf_.pop();
   return true;
 }
+size_t SharedData::numFeatures() { std::lock_guard<std::mutex> lk(feat_mutex_); return feat_buf_.size(); }
 void SharedData::clear() {
   std::lock_guard<std::mutex> a(pc_mutex_), b(feat_mutex_);
   pc_buf_ = {}; feat_buf_ = {};
@@ -174,16 +186,48 @@ void FeatureExtractor::extractFeatures(const PointCloud& pc_in, PointCloud& pc_e
   }
 }
 
+static void worker_pause(SharedData* sdata) {                          // feature_extractor.cc:80 / laser_odometry.cc:270
+  const int us = sdata->poll_us.load(std::memory_order_relaxed);
+  if (us > 0) std::this_thread::sleep_for(std::chrono::microseconds(us));
+  else std::this_thread::yield();
+}
+
 void FeatureExtractor::operator()(std::atomic<bool>& running) {
   SharedData* sdata = SharedData::getInstance();
+  PointCloud pc_curr;
+  double stamp = 0;
+  bool have = false;             // a cloud popped while every hand-off slot was taken: retried, the reference's queue is unbounded
   while (running) {                                                   // feature_extractor.cc:46
-    PointCloud pc_curr, pc_edges;
-    double stamp = 0;
-    if (sdata->popPointCloud(pc_curr, stamp)) {                       // :49
-      extractFeatures(pc_curr, pc_edges);                             // :53-59
-      sdata->pushFeatures(pc_edges, stamp);                           // :77
+    if (have || sdata->popPointCloud(pc_curr, stamp)) {               // :49
+      if (!device_handoff_) {
+        PointCloud pc_edges;
+        extractFeatures(pc_curr, pc_edges);                           // :53-59
+        sdata->pushFeatures(pc_edges, stamp);                         // :77
+        have = false;
+      } else {
+        const auto start_t = Clock::now();
+        Features f;
+        f.stamp = stamp;
+        const int rc = liodom_extract_edges_device(eng_->handle(), 0, reinterpret_cast<const float*>(pc_curr.points.data()),
+                                                   (int64_t)pc_curr.size(), (int)pc_curr.height, (int)pc_curr.width, &f.ticket);
+        if (rc == LIODOM_ERR_BUSY) { have = true; worker_pause(sdata); continue; }
+        check(rc, "liodom_extract_edges_device");
+        have = false;
+        // the cloud for ~edges (:70-75) out of the extraction's host-mapped mirror
+        f.edges.points.resize((size_t)eng_->edge_capacity());
+        int n = 0;
+        check(liodom_wait_edges(eng_->handle(), &f.ticket, reinterpret_cast<float*>(f.edges.points.data()), nullptr, nullptr, nullptr,
+                                eng_->edge_capacity(), &n), "liodom_wait_edges");
+        f.edges.points.resize((size_t)n);
+        f.edges.width = (uint32_t)n; f.edges.height = 1;
+        if (params->save_results_) {                                  // :65-68
+          stats->addFeatureExtractionTime(start_t, Clock::now());
+          stats->addNumOfFeats(f.edges.size());
+        }
+        sdata->pushFeatures(std::move(f));                            // :77
+      }
     }
-    std::this_thread::sleep_for(std::chrono::milliseconds(2));        // :80
+    worker_pause(sdata);                                              // :80
   }
 }
 
@@ -272,8 +316,34 @@ void LaserOdometer::attachMapper(Map* map, int cells_xy, int cells_z) {
   check(liodom_attach_mapper(eng_->handle(), 0, map ? map->handle() : nullptr, cells_xy, cells_z), "liodom_attach_mapper");
 }
 
+static double wall_secs() {      // ros::Time::now().toSec() of the reference (wall clock unless /use_sim_time)
+  return std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count();
+}
+
 LaserOdometer::LaserOdometer(std::shared_ptr<Engine> e)
-    : lmap_manager(e), eng_(e), params(Params::getInstance()), stats(Stats::getInstance()) {}
+    : lmap_manager(e), eng_(e), params(Params::getInstance()), stats(Stats::getInstance()) {
+  for (int i = 0; i < 5; i++) { in_freqs_[i] = 20.0; out_freqs_[i] = 20.0; }   // laser_odometry.cc:83-86 (100 / 5)
+  last_in_time_secs_ = wall_secs();                                            // :89
+  last_out_time_secs_ = last_in_time_secs_;                                    // :90
+}
+
+// laser_odometry.cc:239-256: running mean over five scans of the input rate (from the message stamps) and of the output
+// rate (from the wall clock); a warning when the odometer keeps up with less than 80 % of the input.
+void LaserOdometer::updateFrequencies(double in_stamp_secs, double now_secs) {
+  mean_in_freq_ -= in_freqs_[num_freqs_];                                                   // :240
+  in_freqs_[num_freqs_] = (1.0 / (in_stamp_secs - last_in_time_secs_)) / 5.0;               // :241
+  mean_in_freq_ += in_freqs_[num_freqs_];                                                   // :242
+  last_in_time_secs_ = in_stamp_secs;                                                       // :243
+  mean_out_freq_ -= out_freqs_[num_freqs_];                                                 // :245
+  out_freqs_[num_freqs_] = (1.0 / (now_secs - last_out_time_secs_)) / 5.0;                  // :246
+  mean_out_freq_ += out_freqs_[num_freqs_];                                                 // :247
+  last_out_time_secs_ = now_secs;                                                           // :248
+  num_freqs_ = (num_freqs_ + 1) % 5;                                                        // :250-251
+  if (mean_out_freq_ < mean_in_freq_ * 0.8) {                                               // :254-256 (ROS_WARN)
+    freq_warnings_++;
+    std::fprintf(stderr, "[ WARN] Output frequency too low: %2.2f (in: %2.2f)\n", mean_out_freq_, mean_in_freq_);
+  }
+}
 
 Pose LaserOdometer::process(const PointCloud& feats, double stamp, liodom_step_info_t* info) {
   const auto start_t = Clock::now();
@@ -282,8 +352,28 @@ Pose LaserOdometer::process(const PointCloud& feats, double stamp, liodom_step_i
                              (int)feats.size(), stamp, p, info), "liodom_odometry_step");
   Pose out;
   std::memcpy(out.q, p, sizeof(double) * 4); std::memcpy(out.t, p + 4, sizeof(double) * 3);
-  if (params->save_results_) {                                        // laser_odometry.cc:259-263
-    const auto end_t = Clock::now();
+  const auto end_t = Clock::now();                                    // laser_odometry.cc:237
+  if (init_) updateFrequencies(stamp, wall_secs());                   // :239-256 (the first frame takes the other branch, :108-136)
+  init_ = true;                                                       // :124
+  if (params->save_results_) {                                        // :259-263
+    stats->addPose(out.matrix34());
+    stats->addLaserOdometryTime(start_t, end_t);
+    stats->stopFrame(end_t);
+  }
+  return out;
+}
+
+Pose LaserOdometer::process(const Features& feats, liodom_step_info_t* info) {
+  if (feats.ticket.seq == 0u) return process(feats.edges, feats.stamp, info);
+  const auto start_t = Clock::now();
+  double p[7];
+  check(liodom_odometry_step_device(eng_->handle(), &feats.ticket, feats.stamp, p, info), "liodom_odometry_step_device");
+  Pose out;
+  std::memcpy(out.q, p, sizeof(double) * 4); std::memcpy(out.t, p + 4, sizeof(double) * 3);
+  const auto end_t = Clock::now();                                    // laser_odometry.cc:237
+  if (init_) updateFrequencies(feats.stamp, wall_secs());             // :239-256
+  init_ = true;
+  if (params->save_results_) {                                        // :259-263
     stats->addPose(out.matrix34());
     stats->addLaserOdometryTime(start_t, end_t);
     stats->stopFrame(end_t);
@@ -294,17 +384,90 @@ Pose LaserOdometer::process(const PointCloud& feats, double stamp, liodom_step_i
 void LaserOdometer::operator()(std::atomic<bool>& running, std::vector<OdometryMsg>* published, std::vector<Pose>* poses) {
   SharedData* sdata = SharedData::getInstance();
   while (running) {                                                   // laser_odometry.cc:102
-    PointCloud feats;
-    double stamp = 0;
-    if (sdata->popFeatures(feats, stamp)) {                           // :107
-      const Pose p = process(feats, stamp);                           // :108-235
-      const OdometryMsg msg = publishOdom(stamp, p);                  // :265
+    Features feats;
+    if (sdata->popFeatures(feats)) {                                  // :107
+      const Pose p = process(feats);                                  // :108-235
+      const OdometryMsg msg = publishOdom(feats.stamp, p);            // :265
       if (published) published->push_back(msg);
       if (poses) poses->push_back(p);
     }
-    std::this_thread::sleep_for(std::chrono::milliseconds(2));        // :270
+    worker_pause(sdata);                                              // :270
   }
 }
+
+}  // namespace liodom
+
+// ---- throughput of the two-thread binding, measured in C++ (bench.py's two_thread leg; liodom_replay threads=true) ----
+// An extractor thread and an odometer thread drive ONE handle through the C-ABI exactly as the patched liodom_node would
+// (INTEGRATION.md §2): liodom_extract_edges_device (+ liodom_wait_edges: the ~edges cloud) on one side, a queue of tickets,
+// liodom_odometry_submit_device / liodom_odometry_collect on the other (depth 1: the next ticket, if it is already queued, is
+// submitted before the previous pose is collected; depth 0: liodom_odometry_step_device).  No sleeps: both threads spin-yield.
+// scans: count clouds of n points (packed XYZI) `stride_floats` apart in host memory — page-locked (liodom_pin_host_buffer)
+// for asynchronous uploads.  The clock runs from the submission of scan `timed_from` to the collection of the last pose.
+extern "C" int liodom_host_two_thread_replay(liodom_handle_t* h, const float* scans, int64_t stride_floats, int count, int64_t n,
+                                             int height, int width, int timed_from, int fetch_edges, int depth, int edge_cap,
+                                             double* poses_out /*count x 7*/, double* seconds_out, int64_t* edges_total_out) {
+  if (!h || !scans || count <= 0 || !poses_out) return LIODOM_ERR_INVALID_ARG;
+  std::mutex qm;
+  std::queue<liodom_edge_ticket_t> q;
+  std::atomic<int> rc_x{0}, rc_o{0};
+  std::atomic<bool> abort_all{false};
+  int64_t edges_total = 0;
+  std::thread tx([&] {
+    std::vector<float> ebuf((size_t)std::max(1, edge_cap) * 4);
+    for (int k = 0; k < count && !abort_all; k++) {
+      liodom_edge_ticket_t t;
+      int rc;
+      while ((rc = liodom_extract_edges_device(h, 0, scans + (size_t)k * (size_t)stride_floats, n, height, width, &t)) == LIODOM_ERR_BUSY) {
+        if (abort_all) return;
+        std::this_thread::yield();
+      }
+      if (rc) { rc_x = rc; abort_all = true; return; }
+      if (fetch_edges) {
+        int ne = 0;
+        rc = liodom_wait_edges(h, &t, ebuf.data(), nullptr, nullptr, nullptr, edge_cap, &ne);
+        if (rc) { rc_x = rc; abort_all = true; return; }
+        edges_total += ne;
+      }
+      std::lock_guard<std::mutex> lk(qm);
+      q.push(t);
+    }
+  });
+  std::chrono::steady_clock::time_point t0{}, t1{};
+  std::thread to([&] {
+    int submitted = 0, collected = 0;
+    const int max_fly = depth ? 2 : 1;
+    while (collected < count && !abort_all) {
+      liodom_edge_ticket_t t;
+      bool got = false;
+      if (submitted < count && submitted - collected < max_fly) {
+        std::lock_guard<std::mutex> lk(qm);
+        if (!q.empty()) { t = q.front(); q.pop(); got = true; }
+      }
+      if (got) {                                     // a ticket is waiting: its odometry goes in behind the scan in flight
+        if (submitted == timed_from) t0 = std::chrono::steady_clock::now();
+        const int rc = liodom_odometry_submit_device(h, &t, 0.1 * submitted);
+        if (rc) { rc_o = rc; abort_all = true; return; }
+        submitted++;
+      } else if (submitted > collected) {            // nothing (more) to submit: the oldest pose in flight is collected (and would be published)
+        const int rc = liodom_odometry_collect(h, 0, poses_out + 7 * (size_t)collected, nullptr);
+        if (rc) { rc_o = rc; abort_all = true; return; }
+        collected++;
+      } else {
+        std::this_thread::yield();
+      }
+    }
+    t1 = std::chrono::steady_clock::now();
+  });
+  tx.join();
+  to.join();
+  if (seconds_out) *seconds_out = std::chrono::duration<double>(t1 - t0).count();
+  if (edges_total_out) *edges_total_out = edges_total;
+  if (rc_x) return rc_x;
+  return rc_o;
+}
+
+namespace liodom {
 
 Pose LaserOdometer::processScan(const PointCloud& pc_in, double stamp, liodom_step_info_t* info) {
   const auto start_t = Clock::now();
@@ -317,6 +480,8 @@ Pose LaserOdometer::processScan(const PointCloud& pc_in, double stamp, liodom_st
   if (info) *info = local;
   Pose out;
   std::memcpy(out.q, p, sizeof(double) * 4); std::memcpy(out.t, p + 4, sizeof(double) * 3);
+  if (init_) updateFrequencies(stamp, wall_secs());                   // laser_odometry.cc:239-256
+  init_ = true;
   if (params->save_results_) {
     const auto end_t = Clock::now();
     stats->addNumOfFeats((size_t)local.n_edges);

@@ -91,6 +91,13 @@ class Stats {
 
 // The mutex-guarded FIFOs between the ROS callback, the extractor thread and the odometer thread
 // (src/shared_data.cc:37-89).  Headers carry only the stamp here.
+// One element of the feature queue: the edge cloud as published on ~edges (host copy) and — with the device-resident
+// hand-off — the ticket of the copy that stayed in HBM (liodom_extract_edges_device); ticket.seq == 0: host cloud only.
+struct Features {
+  PointCloud edges;
+  double stamp = 0;
+  liodom_edge_ticket_t ticket{0, 0, 0, 0};
+};
 class SharedData {
  public:
   static SharedData* getInstance();
@@ -98,10 +105,17 @@ class SharedData {
   bool popPointCloud(PointCloud& pc_out, double& stamp);               // :44-62
   void pushFeatures(const PointCloud& feat_in, double stamp);          // :64-69
   bool popFeatures(PointCloud& feat_out, double& stamp);               // :71-89
+  void pushFeatures(Features&& f);                                     // the same with the device ticket
+  bool popFeatures(Features& f);
+  size_t numFeatures();
   void clear();
+  // Poll interval of the two worker loops in microseconds (the reference sleeps 2 ms, feature_extractor.cc:80 /
+  // laser_odometry.cc:270; 0 = yield only: throughput measurements)
+  std::atomic<int> poll_us{2000};
  private:
   std::mutex pc_mutex_, feat_mutex_;
-  std::queue<std::pair<PointCloud, double>> pc_buf_, feat_buf_;
+  std::queue<std::pair<PointCloud, double>> pc_buf_;
+  std::queue<Features> feat_buf_;
 };
 
 // Owns the GPU handle shared by the extractor and the odometer of one stream.
@@ -130,10 +144,15 @@ class FeatureExtractor {
   // push the features; polls every 2 ms like the reference.  Runs on the extraction side of the
   // handle, concurrently with LaserOdometer::operator() (liodom_node.cc:89-91).
   void operator()(std::atomic<bool>& running);
+  // Device-resident hand-off (default): the worker loop leaves every edge cloud on the device (liodom_extract_edges_device), takes
+  // the host copy for ~edges from the extraction's host-mapped mirror (liodom_wait_edges) and queues the ticket with it.
+  // false: liodom_extract_edges (host cloud out), as the first version of this binding did.
+  void setDeviceHandoff(bool on) { device_handoff_ = on; }
  private:
   std::shared_ptr<Engine> eng_;
   Params* params;
   Stats* stats;
+  bool device_handoff_ = true;
 };
 
 class LocalMapManager {
@@ -188,6 +207,8 @@ class LaserOdometer {
   void attachMapper(Map* map, int cells_xy = 2, int cells_z = 1);
   // One pass of the loop body of LaserOdometer::operator() (laser_odometry.cc:107-267).
   Pose process(const PointCloud& feats, double stamp, liodom_step_info_t* info = nullptr);
+  // The same on an edge cloud the extractor left on the device (Features::ticket)
+  Pose process(const Features& feats, liodom_step_info_t* info = nullptr);
   // lidarClb -> extractor -> odometer without leaving the device (one H2D copy, one result record)
   Pose processScan(const PointCloud& pc_in, double stamp, liodom_step_info_t* info = nullptr);
   // The worker loop of the odometer thread (laser_odometry.cc:100-272): pop features, process, publish.
@@ -202,6 +223,19 @@ class LaserOdometer {
   std::array<double, 12> laser_to_base_{{1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0}};  // laser_odometry.h:104
   double prev_stamp_ = 0.0;                                                     // laser_odometry.h:97
   bool published_ = false;
+  // output-rate watchdog (laser_odometry.cc:239-256; state laser_odometry.h:105-111, initial values laser_odometry.cc:83-90)
+  void updateFrequencies(double in_stamp_secs, double now_secs);
+  double in_freqs_[5], out_freqs_[5];
+  double mean_in_freq_ = 100.0, mean_out_freq_ = 100.0;
+  int num_freqs_ = 0;
+  double last_in_time_secs_ = 0.0, last_out_time_secs_ = 0.0;
+  int freq_warnings_ = 0;
+  bool init_ = false;                                                           // laser_odometry.h:94
+ public:
+  // mean input / output frequency over the last five scans and the number of "Output frequency too low" warnings so far
+  double meanInFreq() const { return mean_in_freq_; }
+  double meanOutFreq() const { return mean_out_freq_; }
+  int frequencyWarnings() const { return freq_warnings_; }
 };
 
 }  // namespace liodom

@@ -8,7 +8,9 @@
 // final map is written to <out_dir>map.bin (float32 x y z i).
 // threads=true runs the reference's own structure instead of the fused per-scan call: the clouds are
 // pushed into SharedData (lidarClb), a FeatureExtractor thread and a LaserOdometer thread work side by
-// side on the same handle (src/liodom_node.cc:89-91) and hand edge clouds over through the queue.
+// side on the same handle (src/liodom_node.cc:89-91) and hand edge clouds over through the queue — the clouds stay on the
+// device (tickets; handoff=host restores host clouds).  poll_us= sets the worker loops' sleep (2000 as the reference; 0 = yield);
+// the run prints its scans/s.
 #include <algorithm>
 #include <cstdio>
 #include <dirent.h>
@@ -72,11 +74,19 @@ int main(int argc, char** argv) {
     }
     std::ofstream odom_log(out + "odom.txt");      // stamp, orientation xyzw, position, twist linear, twist angular
     odom_log.precision(17);
-    bool threads = false;
-    for (const std::string& a : kv) if (a == "threads=true" || a == "threads=1") threads = true;
+    bool threads = false, host_handoff = false;
+    int poll_us = 2000;
+    for (const std::string& a : kv) {
+      if (a == "threads=true" || a == "threads=1") threads = true;
+      if (a == "handoff=host") host_handoff = true;
+      if (a.rfind("poll_us=", 0) == 0) poll_us = std::stoi(a.substr(8));
+    }
     if (threads) {
       liodom::FeatureExtractor extractor(eng);
+      extractor.setDeviceHandoff(!host_handoff);
       liodom::SharedData* sdata = liodom::SharedData::getInstance();
+      sdata->poll_us = poll_us;
+      const auto t_begin = std::chrono::steady_clock::now();
       std::vector<liodom::OdometryMsg> msgs;
       std::atomic<bool> running{true};
       std::thread feat_thread([&] { extractor(running); });                 // liodom_node.cc:89
@@ -86,10 +96,11 @@ int main(int argc, char** argv) {
         sdata->pushPointCloud(clouds[i], 0.1 * (double)i);                 // lidarClb :54
       }
       // (msgs is appended by the odometer thread only; its size is polled until every scan is through)
-      for (int spin = 0; spin < 60000; spin++) {
-        std::this_thread::sleep_for(std::chrono::milliseconds(5));
+      for (int spin = 0; spin < 3000000; spin++) {
+        std::this_thread::sleep_for(std::chrono::microseconds(100));
         if (liodom::Stats::getInstance()->numPoses() >= clouds.size()) break;
       }
+      const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
       running = false;
       feat_thread.join();
       odom_thread.join();
@@ -101,7 +112,8 @@ int main(int argc, char** argv) {
         for (double v : msg.angular) odom_log << ' ' << v;
         odom_log << '\n';
       }
-      std::printf("threads: %zu scans through the extractor / odometer threads\n", msgs.size());
+      std::printf("threads: %zu scans through the extractor / odometer threads in %.3f s = %.1f scans/s (handoff=%s, poll_us=%d)\n",
+                  msgs.size(), secs, (double)msgs.size() / secs, host_handoff ? "host" : "device", poll_us);
       if (msgs.size() != clouds.size()) { std::fprintf(stderr, "liodom_replay: %zu of %zu scans processed\n", msgs.size(), clouds.size()); return 1; }
     }
     for (size_t i = 0; i < clouds.size() && !threads; i++) {

@@ -164,9 +164,9 @@ def test_rings_of_any_length_are_processed(orc, synth):
         g.close()
 
 def test_max_ring_size(orc):
-    # largest supported ring (6144 points in one 160 KiB LDS tile)
+    # a 6144-point ring (regions of 766 items: beyond the register tile of either instance, generic path)
     from test_oracle_extract import _jagged_ring
-    po, g = mk(orc, 16, 6144, 0, 8, 10, max_ring_points=6144)
+    po, g = mk(orc, 16, 6144, 0, 8, 10)
     x = _jagged_ring(6144, seed=5)
     assert_edges_equal(g.extract_edges(x, 16, 0), orc.extract(po, x, 16, 0))
     g.close()

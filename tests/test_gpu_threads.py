@@ -222,3 +222,155 @@ def test_host_fed_replay_equals_resident_replay(synth):
         assert np.array_equal(got.view(np.uint64), ref.view(np.uint64)), depth
         assert all(int(i.status) == 0 for i in infos)
     g.close()
+
+
+@pytest.mark.parametrize("name", sorted(CONFIGS))
+def test_device_handoff_two_threads_equal_serial_order(synth, name):
+    """liodom_extract_edges_device / liodom_wait_edges on an extractor thread, liodom_odometry_submit_device /
+    liodom_odometry_collect on an odometer thread (src/liodom_node.cc:89-91 with the queue element of
+    src/shared_data.cc:64-89 staying in HBM): edges as liodom_extract_edges returns them, poses bit-equal to the serial
+    extract -> odometry order with host clouds."""
+    import time
+    c = CONFIGS[name]
+    H, W, K = c["H"], c["W"], c["K"]
+    cfg = synth.make_cfg(H, W, c["lt"])
+    scans = [synth.scan(cfg, 4, k)[0] for k in range(K)]
+    g = _handle(c)
+    serial_edges, serial_poses = [], []
+    for k in range(K):
+        e = g.extract_edges(scans[k], H, W)
+        pose, _ = g.odometry_step(e["edges"], stamp=0.1 * k)
+        serial_edges.append(e)
+        serial_poses.append(pose)
+    g.close()
+
+    for depth in (0, 1):
+        g = _handle(c)
+        tickets = queue.Queue()
+        edges_t, poses, infos, errors, busy = [], [], [], [], [0]
+
+        def extractor():
+            try:
+                for k in range(K):
+                    # scans 0, 3, 6, ... are assembled in the handle's page-locked buffer (asynchronous upload), the others
+                    # come from pageable memory (copied through the ring)
+                    src = scans[k]
+                    if k % 3 == 0:
+                        buf = g.scan_buffer()
+                        buf[:src.shape[0]] = src
+                        src = buf[:src.shape[0]]
+                    while True:
+                        t = g.extract_edges_device(src, H, W)
+                        if t is not None:
+                            break
+                        busy[0] += 1
+                        time.sleep(0.0001)
+                    edges_t.append(g.wait_edges(t))
+                    tickets.put(t)
+            except Exception as ex:       # pragma: no cover
+                errors.append(ex)
+            finally:
+                tickets.put(None)
+
+        def odometer():
+            try:
+                inflight, finished = 0, False
+                while not finished or inflight:
+                    t = None
+                    if not finished and inflight < (2 if depth else 1):
+                        try:
+                            t = tickets.get(timeout=0.0 if inflight else 5.0)
+                        except queue.Empty:
+                            t = None
+                        else:
+                            if t is None:
+                                finished = True
+                    if t is not None:
+                        assert g.odometry_submit_device(t, stamp=0.1 * len(poses))
+                        inflight += 1
+                        continue
+                    if inflight:
+                        pose, info = g.odometry_collect()
+                        poses.append(pose)
+                        infos.append(int(info.status))
+                        inflight -= 1
+            except Exception as ex:       # pragma: no cover
+                errors.append(ex)
+
+        ta, tb = threading.Thread(target=extractor), threading.Thread(target=odometer)
+        ta.start(); tb.start()
+        ta.join(timeout=300); tb.join(timeout=300)
+        assert not errors, errors
+        assert len(poses) == K and not any(infos)
+        for k in range(K):
+            for key in ("edges", "ring", "idx_in_ring", "src"):
+                a, b = edges_t[k][key], serial_edges[k][key]
+                assert np.array_equal(a.view(np.uint32) if key == "edges" else a, b.view(np.uint32) if key == "edges" else b), (depth, k, key)
+            assert np.array_equal(poses[k].view(np.uint64), serial_poses[k].view(np.uint64)), (depth, k)
+        w, nf = g.window()
+        assert nf == min(K, c["P"])
+        g.close()
+
+
+def test_device_handoff_back_pressure_and_stale_tickets(synth):
+    """Three hand-off slots: a fourth extraction without a consumed ticket is refused (LIODOM_ERR_BUSY, nothing enqueued);
+    a ticket is good once; the plain entry points refuse while tickets are outstanding; liodom_reset voids tickets."""
+    import liodom_amd as la
+    c = CONFIGS["cfg1_16x900"]
+    H, W = c["H"], c["W"]
+    cfg = synth.make_cfg(H, W, 0)
+    scans = [synth.scan(cfg, 2, k)[0] for k in range(8)]
+    g = _handle(c)
+    ref = _handle(c)
+    want = [ref.process_scan(scans[k], H, W)[0] for k in range(6)]
+    ref.close()
+    t = [g.extract_edges_device(scans[k], H, W) for k in range(3)]
+    assert all(x is not None for x in t)
+    assert g.extract_edges_device(scans[3], H, W) is None              # all three slots filled
+    with pytest.raises(la.LiodomError):
+        g.process_scan(scans[0], H, W)                                 # plain entry point: tickets outstanding
+    p0, _ = g.odometry_step_device(t[0])
+    assert np.array_equal(p0.view(np.uint64), want[0].view(np.uint64))
+    with pytest.raises(la.LiodomError):
+        g.odometry_step_device(t[0])                                   # consumed
+    t3 = g.extract_edges_device(scans[3], H, W)                        # slot 0 is free again
+    assert t3 is not None and t3.slot == t[0].slot
+    got = [g.odometry_step_device(x)[0] for x in (t[1], t[2], t3)]
+    for k, p in enumerate(got, start=1):
+        assert np.array_equal(p.view(np.uint64), want[k].view(np.uint64)), k
+    # two in flight at most
+    ta, tb = g.extract_edges_device(scans[4], H, W), g.extract_edges_device(scans[5], H, W)
+    assert g.odometry_submit_device(ta) and g.odometry_submit_device(tb)
+    tc = g.extract_edges_device(scans[6], H, W)
+    assert tc is not None and g.odometry_submit_device(tc) is False    # LIODOM_ERR_BUSY
+    for k in (4, 5):
+        assert np.array_equal(g.odometry_collect()[0].view(np.uint64), want[k].view(np.uint64)), k
+    g.reset()
+    with pytest.raises(la.LiodomError):
+        g.odometry_step_device(tc)                                     # voided by the reset
+    pose, info = g.process_scan(scans[0], H, W)                        # the handle is usable as before
+    assert info.status == 0 and np.array_equal(pose.view(np.uint64), want[0].view(np.uint64))
+    g.close()
+
+
+def test_cxx_two_thread_replay_equals_resident_replay(synth):
+    """liodom_host_two_thread_replay (two std::threads through the C-ABI, what bench.py's two_thread leg times) gives the
+    bits of the resident replay, at both depths, with and without fetching the ~edges clouds."""
+    import liodom_amd as la
+    H, W, R, epr, P, K = 16, 900, 6, 10, 5, 60
+    N = H * W
+    cfg = synth.make_cfg(H, W, 0)
+    scans = np.stack([synth.scan(cfg, 3, k)[0] for k in range(K)])
+    par = la.make_params(scan_lines=H, scan_regions=R, edges_per_region=epr, prev_frames=P)
+    g = la.Liodom(par, la.make_config(max_points=N, max_width=W, pose_log_capacity=2 * K + 8))
+    g.alloc_resident(K)
+    for k in range(K):
+        g.upload_scan(0, k, scans[k])
+    ref, infos = g.replay_resident(0, K, N, H, W, depth=1)
+    n_edges = sum(int(i.n_edges) for i in infos)
+    for depth, fetch, pin in ((1, True, True), (0, True, False), (1, False, True)):
+        g.reset()
+        got, secs, tot = g.two_thread_replay(scans, N, H, W, timed_from=10, fetch_edges=fetch, depth=depth, pin=pin)
+        assert np.array_equal(got.view(np.uint64), ref[:, 0].view(np.uint64)), (depth, fetch, pin)
+        assert secs > 0 and tot == (n_edges if fetch else 0)
+    g.close()
