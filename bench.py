@@ -46,6 +46,11 @@ WORKLOADS = {
     # BASELINE.json configs[2] (headline): HDL-64-shape 64x1800, scan_regions=8, prev_frames=20
     "hdl64": dict(H=64, W=1800, lidar_type=0, R=8, epr=10, P=20,
                   name="HDL-64-shape 64x1800 synthetic stream, scan_regions=8, edges_per_region=10, prev_frames=20"),
+    # the headline shape with ragged input (dropped points under load: ~25 % NaN no-returns, rings of unequal length, three rings
+    # below min_points_per_scan; liodom_amd.synth.ragged) — not a BASELINE config, a robustness leg
+    "hdl64_ragged": dict(H=64, W=1800, lidar_type=0, R=8, epr=10, P=20, ragged=True,
+                         name="HDL-64-shape 64x1800 synthetic stream with ragged returns (~25 % NaN no-returns, unequal rings, 3 rings below "
+                              "min_points_per_scan), scan_regions=8, edges_per_region=10, prev_frames=20"),
     # configs[1]: VLP-16-shape 16x1800, scan_regions=8, edges_per_region=20, prev_frames=10
     "vlp16": dict(H=16, W=1800, lidar_type=0, R=8, epr=20, P=10,
                   name="VLP-16-shape 16x1800 synthetic stream, scan_regions=8, edges_per_region=20, prev_frames=10"),
@@ -232,20 +237,23 @@ def main():
     K, Wm = args.steps, args.warmup
     F = P                                    # untimed pre-fill: the window holds P frames before the warm-up starts
     total = F + Wm + K
+    n_res = total + 1                        # (+ the scan whose extraction the last timed step issues)
 
     # ---- synthetic stream (stream id = global rank), generated before anything is timed ----
     cfg = synth.make_cfg(H, W, wl["lidar_type"])
-    scans = [synth.scan(cfg, rep.stream_id, k)[0] for k in range(total)]
+    scans = [synth.scan(cfg, rep.stream_id, k)[0] for k in range(n_res)]
+    if wl.get("ragged"):
+        scans = [synth.ragged(x, H, W, wl["lidar_type"], seed=1000 * rep.stream_id + k) for k, x in enumerate(scans)]
 
     params = la.make_params(lidar_type=wl["lidar_type"], scan_lines=H, scan_regions=R, edges_per_region=epr, prev_frames=P)
     g = la.Liodom(params, la.make_config(device=local_rank, n_streams=1, max_points=N, max_width=W, pose_log_capacity=total + 8))
-    g.alloc_resident(total)
-    for k in range(total):
+    g.alloc_resident(n_res)
+    for k in range(n_res):
         g.upload_scan(0, k, scans[k])
     g.sync()
     time.sleep(0.5)   # let the host settle after the OpenMP-heavy generation (container CPU quota)
 
-    def run(first, count, readback=True, pipelined=True, depth=1):
+    def run(first, count, readback=True, pipelined=True, depth=1, ahead=False):
         # pipelined: the extraction of scan k+1 is issued on a second HIP stream while scan k's
         # odometry runs (the reference's own two-thread pipeline); never across the region's ends
         last = first + count - 1
@@ -254,7 +262,9 @@ def main():
             # the odometry of scan k+1 is submitted before pose k is waited for — the device needs nothing from the host
             # between two scans, and the poses arrive exactly when they would anyway.  depth 0 (strict_sync leg): pose k
             # is read back before scan k+1's odometry is submitted; the GPU then idles for the host's turn-around.
-            g.replay_resident(first, count, N, H, W, depth=depth)
+            # ahead: the call also issues the extraction of the scan behind its last one, as every step inside it does for its
+            # successor — the next call starts with that extraction already running beside the previous odometry (steady state)
+            g.replay_resident(first, count, N, H, W, depth=depth, ahead=ahead)
             return
         for k in range(first, first + count):
             g.process_resident(k, N, H, W, readback=readback, next_slot=(k + 1 if (pipelined and k < last) else -1))
@@ -267,12 +277,16 @@ def main():
     for r in range(max(1, args.repeats) + 1):
         if r:
             g.reset()
+        # A step of the pipelined replay = the odometry of scan k + the extraction of scan k + 1 beside it.  The timed region
+        # is K such steps in the steady state: the warm-up's last step has issued the extraction of the first timed scan (as
+        # every step does for its successor), and the last timed step issues the extraction of the scan behind the region —
+        # K odometries and K extractions inside the region, all completed before the clock stops (g.sync()).
         run(0, F)
-        run(F, Wm)
+        run(F, Wm, ahead=True)
         g.sync()
         rep.barrier()
         t0 = time.perf_counter()
-        run(F + Wm, K)
+        run(F + Wm, K, ahead=True)
         g.sync()
         rep.barrier()
         samples.append(rep.max_over_ranks(time.perf_counter() - t0))
@@ -377,7 +391,9 @@ def main():
             "config": {"workload": wl["name"], "streams_per_gpu": 1, "points_per_scan": N,
                        "mode": "pose of every scan read back in order by the consumer loop (liodom_replay_resident, depth 1: the "
                                "odometry of scan k+1 is submitted before pose k is waited for), scans resident in HBM, "
-                               "extraction of scan k+1 overlapped with odometry of scan k on a second HIP stream",
+                               "extraction of scan k+1 overlapped with odometry of scan k on a second HIP stream; the timed region "
+                               "is K steady-state steps = K odometries + K extractions (the step before it has issued the first "
+                               "timed scan's extraction, the last timed step issues the next scan's)",
                        "prefill_scans": F,
                        "timed_region_repeats": len(kept), "timed_region_discarded": len(samples) - len(kept),
                        "value_is": "median over the repeats of the K-step timed region (same scans, same poses every repeat)",
@@ -400,7 +416,7 @@ def main():
             out["two_thread_scans_per_s"] = two_thread["scans_per_s"]      # the C-ABI as a patched liodom_node drives it
             out["host_fed"] = host_fed
             out["two_thread"] = two_thread
-        if args.workload != "hdl64":
+        if args.workload not in ("hdl64",):
             out["metric"] = "scans/sec (%dx%d cloud, prev_frames=%d) at 1 GPU; pose RMSE vs CPU ref" % (H, W, P)
 
     # ---- parity, every replica on its own stream (the oracle on the host cores of that rank) ----
@@ -462,6 +478,8 @@ def main():
         tb = Kb + Wb
         n_data = max(1, min(args.batched_data_streams, S))   # distinct synthetic streams; stream s replays data stream s % n_data
         data = [scans[:tb]] + [[synth.scan(cfg, 1000 + d, k)[0] for k in range(tb)] for d in range(1, n_data)]
+        if wl.get("ragged"):
+            data = [data[0]] + [[synth.ragged(x, H, W, wl["lidar_type"], seed=1000 * (1000 + d) + k) for k, x in enumerate(data[d])] for d in range(1, n_data)]
         gb = la.Liodom(params, la.make_config(device=local_rank, n_streams=S, max_points=N, max_width=W, pose_log_capacity=tb + 8))
         bmodes = gb.modes()
         gb.alloc_resident(tb)

@@ -61,3 +61,33 @@ def scan(cfg, stream, k):
                           pose.ctypes.data_as(C.POINTER(C.c_double)))
     assert rc == 0
     return out, pose
+
+
+def ragged(xyzi, height, width, lidar_type=0, seed=0, min_keep=0.55, dead_rings=3):
+    """A ragged copy of a synthetic scan (what real sensors deliver and SURVEY.md §8(d)'s box world never does): 20-30 % of the
+    returns become NaN no-returns (isValidPoint, feature_extractor.cc:84-102), every ring loses its own share — between 5 % and
+    1 - min_keep of its points, in bursts and singly — so that the compacted rings have unequal lengths, and `dead_rings` rings
+    keep fewer than min_points_per_scan points (skipped at feature_extractor.cc:188-190).  The ring of a point is its beam:
+    firing order is column-major for lidar_type 0 (point i = column i // height, beam i % height), row-major for lidar_type 1."""
+    rng = np.random.default_rng(1234567 + int(seed))
+    out = np.array(xyzi, dtype=np.float32, copy=True).reshape(-1, 4)
+    n = out.shape[0]
+    idx = np.arange(n)
+    beam = (idx % height) if lidar_type == 0 else (idx // width)
+    col = (idx // height) if lidar_type == 0 else (idx % width)
+    drop = np.zeros(n, dtype=bool)
+    frac = rng.uniform(0.05, 1.0 - min_keep, size=height)
+    dead = rng.choice(height, size=min(dead_rings, height), replace=False)
+    for b in range(height):
+        m = beam == b
+        if b in dead:
+            keep_cols = rng.choice(width, size=int(rng.integers(5, 60)), replace=False)
+            drop[m] = ~np.isin(col[m], keep_cols)
+            continue
+        d = rng.random(width) < 0.5 * frac[b]                    # single no-returns
+        nb = max(1, int(0.5 * frac[b] * width / 40))             # bursts of ~40 columns (sky, glass)
+        for s in rng.integers(0, width, size=nb):
+            d[s:s + int(rng.integers(10, 70))] = True
+        drop[m] = d[col[m]]
+    out[drop, :3] = np.nan
+    return out

@@ -172,7 +172,7 @@ def test_max_ring_size(orc):
     g.close()
 
 
-def _run_stream(orc, synth, H, W, lt, R, epr, P, nscans, stream=0, use_pipeline=True):
+def _run_stream(orc, synth, H, W, lt, R, epr, P, nscans, stream=0, use_pipeline=True, mutate=None):
     """GPU vs oracle over a stream.  Two levels of correspondence parity:
     (1) kernel level, identical inputs: the GPU's own float queries and the local map it searched go through the
         oracle's addEdgeConstraints loop — valid flags and both line-point indices must be EXACTLY equal, every
@@ -188,6 +188,8 @@ def _run_stream(orc, synth, H, W, lt, R, epr, P, nscans, stream=0, use_pipeline=
     n_e2e_diff = 0
     for k in range(nscans):
         x, _ = synth.scan(cfg, stream, k)
+        if mutate is not None:
+            x = mutate(x, k)
         o = orc.extract(po, x, H, W)
         map_g, _ = g.local_map()                 # the cloud this scan's kNN passes search (window before the step)
         map_o = od.window()
@@ -263,6 +265,25 @@ def test_odometry_parity_cfg2(orc, synth):
 def test_odometry_parity_headline(orc, synth):
     # BASELINE config 3 (headline): 64 x 1800, R=8, epr=10, P=20
     _run_stream(orc, synth, 64, 1800, 0, 8, 10, 20, 30)
+
+
+def test_odometry_parity_headline_ragged(orc, synth):
+    # the headline shape with ragged input: ~25 % NaN no-returns, rings of unequal length (every ring loses its own share of
+    # points, in bursts and singly), three rings below min_points_per_scan (feature_extractor.cc:84-102,188-190)
+    H, W = 64, 1800
+    seen = {}
+
+    def mutate(x, k):
+        r = synth.ragged(x, H, W, 0, seed=k)
+        seen[k] = float(np.isnan(r[:, 0]).mean())
+        return r
+
+    _run_stream(orc, synth, H, W, 0, 8, 10, 20, 26, mutate=mutate)
+    assert 0.15 < np.mean(list(seen.values())) < 0.40
+    po = orc.make_params(scan_lines=H, prev_frames=20)
+    offs, _ = orc.split(po, synth.ragged(synth.scan(synth.make_cfg(H, W, 0), 0, 3)[0], H, W, 0, seed=3), H, W)
+    lens = np.diff(offs)
+    assert (lens < 90).sum() >= 2 and lens.max() - lens[lens >= 90].min() > 400      # skipped rings, unequal lengths
 
 
 def test_odometry_parity_ouster(orc, synth):
@@ -828,3 +849,57 @@ def test_sixteen_lockstep_streams_match_single_stream(orc, synth):
                 assert tuple(info.matches) == batch[k][1][s2], (s2, k)
                 assert np.array_equal(batch[k][0][s2].view(np.uint64), batch[k][0][s].view(np.uint64)), (s2, k)   # equal streams, equal bits
         g1.close()
+
+
+def test_sixteen_streams_headline_size_against_the_oracle(orc, synth):
+    """The code that produces the batched number — k_knn<128> + k_line_gate, the one-workgroup lock-step k_lm_solve,
+    k_hash_build — on a 16-stream handle at the headline size (64 x 1800, P = 20, 26 scans: the window fills and evicts),
+    checked against the oracle DIRECTLY, per stream: correspondences of both passes exactly equal to the oracle's loop
+    (laser_odometry.cc:320-361) on that stream's own queries and local map, LM iteration counts and terminations equal to
+    the oracle's run (laser_odometry.cc:201-218), pose within 1e-4 m / 1e-4 rad.  Stream 3 replays ragged scans."""
+    H, W, R, epr, P, S, K = 64, 1800, 8, 10, 20, 16, 26
+    N = H * W
+    D = 4                                     # distinct data streams; handle stream s replays data stream s % D
+    cfg = synth.make_cfg(H, W, 0)
+    data = [[synth.scan(cfg, 20 + d, k)[0] for k in range(K)] for d in range(D)]
+    data[3] = [synth.ragged(x, H, W, 0, seed=100 + k) for k, x in enumerate(data[3])]
+    po, gb = mk(orc, H, W, 0, R, epr, P, S=S, debug=1, pose_log_capacity=K + 8)
+    modes = gb.modes()
+    assert modes["knn_instance"] == "128" and modes["line_gate_kernel"] == "1" and modes["hash_build"] == "lds"
+    gb.alloc_resident(K)
+    for s in range(S):
+        for k in range(K):
+            gb.upload_scan(s, k, data[s % D][k])
+    ods = [orc.Odometer(po) for _ in range(D)]
+    worst_t = worst_r = 0.0
+    for k in range(K):
+        maps = [gb.local_map(d)[0] for d in range(D)]          # what this step's kNN passes search, per checked stream
+        poses, infos = gb.process_resident(k, N, H, W, readback=True, next_slot=(k + 1 if k + 1 < K else -1))
+        for s in range(S):
+            assert infos[s].status == 0, (k, s)
+            assert np.array_equal(poses[s].view(np.uint64), poses[s % D].view(np.uint64)), (k, s)      # equal data, equal bits
+            assert tuple(infos[s].matches) == tuple(infos[s % D].matches), (k, s)
+        for d in range(D):
+            o = orc.extract(po, data[d][k], H, W)
+            pose_o, info_o = ods[d].step(o["edges"])
+            ig = infos[d]
+            assert ig.n_edges == info_o.n_edges, (k, d)
+            dt = np.linalg.norm(poses[d][4:] - pose_o[4:])
+            dr = rot_angle(poses[d][:4], pose_o[:4])
+            worst_t, worst_r = max(worst_t, dt), max(worst_r, dr)
+            assert dt <= POSE_TOL_T and dr <= POSE_TOL_R, "scan %d stream %d: dt=%g dr=%g" % (k, d, dt, dr)
+            if k == 0:
+                continue
+            assert ig.map_points == info_o.map_points, (k, d)
+            for it in (0, 1):
+                vg, ag, bg = gb.correspondences(it, stream=d)
+                qg = gb.knn_queries(it, stream=d)
+                vk, ak, bk = orc.match_edges(po, maps[d], qg)
+                assert np.array_equal(vk, vg) and np.array_equal(ak, ag) and np.array_equal(bk, bg), \
+                    "scan %d stream %d pass %d: kNN / line gate differ from the oracle on identical inputs at edges %s" % (
+                        k, d, it, np.nonzero((vk != vg) | (ak != ag) | (bk != bg))[0][:10])
+                assert ig.matches[it] == int(vk.sum()), (k, d, it)
+                assert ig.lm[it].iterations == info_o.lm[it].iterations, (k, d, it)
+                assert ig.lm[it].termination == info_o.lm[it].termination, (k, d, it)
+    gb.close()
+    assert worst_t < 1e-6 and worst_r < 1e-6
