@@ -919,6 +919,12 @@ __device__ __forceinline__ void knn_pass(const DevView& v, int s, int bxi, int b
     else pre2.gsq = 0.f;
     if (!ov_wait_pose(v, s, bxi % kOvReplicas, seq, sh_ov, &st.status)) return;
     OV_STAMP(v, threadIdx.x == 0 && bxi == 0, 10); OV_STAMP(v, threadIdx.x == 0 && bxi == v.knn_grid - 1, 14);
+    if (kInstrument && (v.debug & 128) && threadIdx.x == 0) {      // (debug) when this workgroup saw the pose, relative to its publication: 0.25 us bins
+      sh_ov[19] = __longlong_as_double((long long)wall_clock64());
+      const unsigned long long pub = *(volatile unsigned long long*)&v.dbg_clk[448 + 1];
+      const long long d = (long long)wall_clock64() - (long long)pub;
+      if (pub && d >= 0) atomicAdd(&v.dbg_clk[320 + (d / 25 < 63 ? d / 25 : 63)], 1ull);
+    }
 #pragma unroll
     for (int i = 0; i < 12; i++) T[i] = sh_ov[i];
   }
@@ -957,10 +963,21 @@ __global__ __launch_bounds__(kKnnThreads, (kKnnThreads >= 256 ? 1 : LIODOM_TUNE_
   int bxi = (int)blockIdx.x, byi = (int)blockIdx.y;
   xcd_remap(bxi, byi);
   const int s = s0 + byi;
+  if (kInstrument && kOv && threadIdx.x == 0) sh_ov[19] = 0.0;
   if (kOv) { OV_STAMP(v, threadIdx.x == 0 && bxi == 0, 8); OV_STAMP(v, threadIdx.x == 0 && bxi == v.knn_grid - 1, 12); }
   else if (outer_it == 0) OV_STAMP(v, threadIdx.x == 0 && bxi == 0, 16);
   knn_pass<kKnnThreads, kOv>(v, s, bxi, byi, outer_it, eb, wait_edges, signal_odo, seq, sh, shs[kOv ? 1 : 0], sh_ov);
   if (kOv) ov_signal_knn_done(v, s, bxi, seq);       // (every exit of the pass is workgroup-uniform)
+  if (kInstrument && (v.debug & 128) && threadIdx.x == 0) {
+    if (kOv) {                                         // (debug) pose seen -> flag raised, per workgroup with queries: 0.5 us bins
+      const long long t_seen = __double_as_longlong(sh_ov[19]);
+      if (bxi * kKnnQueries < v.state[s].n_edges_buf[eb] && t_seen) { const long long d = (long long)wall_clock64() - t_seen; atomicAdd(&v.dbg_clk[256 + (d / 50 < 63 ? d / 50 : 63)], 1ull); }
+    } else if (outer_it == 0) {                        // (debug) first pass: end of every workgroup relative to the start of workgroup 0: 0.5 us bins
+      const unsigned long long t0 = *(volatile unsigned long long*)&v.dbg_clk[448 + 16];
+      const long long d = (long long)wall_clock64() - (long long)t0;
+      if (t0 && d >= 0 && bxi * kKnnQueries < v.state[s].n_edges_buf[eb]) atomicAdd(&v.dbg_clk[384 + (d / 50 < 63 ? d / 50 : 63)], 1ull);
+    }
+  }
   if (kOv) { OV_STAMP(v, threadIdx.x == 0 && bxi == 0, 11); OV_STAMP(v, threadIdx.x == 0 && bxi == v.knn_grid - 1, 15); }
   else if (outer_it == 0) OV_STAMP(v, threadIdx.x == 0 && bxi == v.knn_grid - 1, 17);
 }

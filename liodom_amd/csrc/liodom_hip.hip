@@ -99,6 +99,12 @@ struct liodom_handle {
   int4* host_edges_meta = nullptr;
   unsigned int* host_edges_hdr = nullptr;
   float4* pin_ring = nullptr;        // page-locked scan staging ring [kEdgePipeBufs][max_points]: liodom_scan_buffer hands slots out, pageable scans are copied through it
+  float4* stage_ring = nullptr;      // device side of the hand-off's uploads [kEdgePipeBufs][max_points] when they run on the copy stream
+  bool tk_copy_stream = false;       // ... (LIODOM_COPY_STREAM, default on): the upload of scan k+1 runs beside the extraction of scan k
+  hipEvent_t ev_cp[kEdgePipeBufs] = {nullptr, nullptr, nullptr};      // the upload into device staging slot r has completed (copy stream)
+  hipEvent_t ev_sdone[kEdgePipeBufs] = {nullptr, nullptr, nullptr};   // the extraction that read device staging slot r has been issued (recorded on the extraction stream)
+  bool ev_sdone_valid[kEdgePipeBufs] = {false, false, false};
+  int stage_next = 0;
   hipEvent_t ev_pin[kEdgePipeBufs] = {nullptr, nullptr, nullptr};     // the upload out of staging slot r has completed
   bool ev_pin_valid[kEdgePipeBufs] = {false, false, false};
   int pin_next = 0;
@@ -494,7 +500,8 @@ int reset_state(liodom_handle* h) {
   if (h->stream_k) HIP_TRY(hipStreamSynchronize(h->stream_k));
   h->ov_warm = 0; h->ov_prev = false;
   if (h->fallback_pending.exchange(false)) h->use_flags = false;      // an in-kernel wait gave up (wait_pose): events from here on
-  for (int b = 0; b < kEdgePipeBufs; b++) { h->tk_seq[b] = 0u; h->ev_pin_valid[b] = false; }      // outstanding edge tickets are void
+  for (int b = 0; b < kEdgePipeBufs; b++) { h->tk_seq[b] = 0u; h->ev_pin_valid[b] = false; h->ev_sdone_valid[b] = false; }      // outstanding edge tickets are void
+  if (h->stream_c && !h->stream_c_shared) HIP_TRY(hipStreamSynchronize(h->stream_c));
   h->x_next = 0; h->odo_pending = 0;
   if (h->host_edges_hdr) std::memset(h->host_edges_hdr, 0, sizeof(unsigned int) * 2 * kEdgePipeBufs);
   for (int b = 0; b < kEdgePipeBufs; b++) { h->eb_seq[b] = 0; h->eb_reader[b] = 0; }
@@ -862,7 +869,7 @@ void liodom_destroy(liodom_handle_t* h) {
   if (h->host_edges_meta) hipHostFree(h->host_edges_meta);
   if (h->host_edges_hdr) hipHostFree(h->host_edges_hdr);
   if (h->pin_ring) hipHostFree(h->pin_ring);
-  for (int b = 0; b < kEdgePipeBufs; b++) if (h->ev_pin[b]) hipEventDestroy(h->ev_pin[b]);
+  for (int b = 0; b < kEdgePipeBufs; b++) { if (h->ev_pin[b]) hipEventDestroy(h->ev_pin[b]); if (h->ev_sdone[b]) hipEventDestroy(h->ev_sdone[b]); if (h->ev_cp[b]) hipEventDestroy(h->ev_cp[b]); }
   for (auto& e : h->ev_pool) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
   if (h->pose_event) hipEventDestroy(h->pose_event);
   for (int b = 0; b < kEdgePipeBufs; b++) { if (h->ev_edges[b]) hipEventDestroy(h->ev_edges[b]); if (h->ev_free[b]) hipEventDestroy(h->ev_free[b]); }
@@ -995,6 +1002,24 @@ static int ensure_pin_ring(liodom_handle* h) {
   HIP_TRY(hipHostMalloc(&p, sizeof(float4) * (size_t)kEdgePipeBufs * (size_t)h->v.max_points, hipHostMallocDefault));
   h->pin_ring = static_cast<float4*>(p);
   for (int b = 0; b < kEdgePipeBufs; b++) HIP_TRY(hipEventCreateWithFlags(&h->ev_pin[b], hipEventDisableTiming));
+  // Uploads on a copy stream of their own, into a ring of device staging slots: the DMA of scan k+1 (1.84 MB, ~37 us) then runs
+  // beside the extraction kernels of scan k instead of in front of its own on the extraction stream.  (The host-fed replay found a
+  // further stream per handle harmful when ONE host thread enqueues everything; with two threads it pays: LIODOM_COPY_STREAM=0
+  // switches it off.)
+  bool want = true;
+  if (const char* e = std::getenv("LIODOM_COPY_STREAM")) want = std::atoi(e) != 0;
+  if (want && !h->profiling) {
+    void* d = nullptr;
+    HIP_TRY(hipMalloc(&d, sizeof(float4) * (size_t)kEdgePipeBufs * (size_t)h->v.max_points));
+    h->stage_ring = static_cast<float4*>(d);
+    h->allocs.push_back(d);
+    if (!h->stream_c) HIP_TRY(hipStreamCreateWithFlags(&h->stream_c, hipStreamNonBlocking));
+    for (int b = 0; b < kEdgePipeBufs; b++) {
+      HIP_TRY(hipEventCreateWithFlags(&h->ev_sdone[b], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&h->ev_cp[b], hipEventDisableTiming));
+    }
+    h->tk_copy_stream = true;
+  }
   return LIODOM_OK;
 }
 
@@ -1050,13 +1075,28 @@ int liodom_extract_edges_device(liodom_handle_t* h, int stream, const float* xyz
       std::memcpy(h->pin_ring + (size_t)r * h->v.max_points, xyzi, sizeof(float4) * (size_t)n);
       xyzi = reinterpret_cast<const float*>(h->pin_ring + (size_t)r * h->v.max_points);
     }
-    HIP_TRY(hipMemcpyAsync(in, xyzi, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, q));
-    if (own || !pinned) {
-      HIP_TRY(hipEventRecord(h->ev_pin[r], q));
+    hipStream_t qc = q;
+    int sr = -1;
+    if (h->tk_copy_stream && !h->profiling) {
+      // device staging slot sr: free once the extraction that last read it has run (ev_sdone, recorded on the extraction stream)
+      sr = h->stage_next;
+      h->stage_next = (sr + 1) % kEdgePipeBufs;
+      qc = h->stream_c;
+      in = h->stage_ring + (size_t)sr * h->v.max_points;
+      if (h->ev_sdone_valid[sr]) HIP_TRY(hipStreamWaitEvent(qc, h->ev_sdone[sr], 0));
+    }
+    HIP_TRY(hipMemcpyAsync(in, xyzi, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, qc));
+    if (own || !pinned) {                            // the page-locked ring slot may be refilled once this upload has left it
+      HIP_TRY(hipEventRecord(h->ev_pin[r], qc));
       h->ev_pin_valid[r] = true;
       h->pin_next = (r + 1) % kEdgePipeBufs;
     }
+    if (sr >= 0) {                                   // the extraction starts when the upload into its staging slot has completed
+      HIP_TRY(hipEventRecord(h->ev_cp[sr], qc));
+      HIP_TRY(hipStreamWaitEvent(q, h->ev_cp[sr], 0));
+    }
   }
+  const bool staged_on_ring = n > 0 && h->tk_copy_stream && !h->profiling;
   unsigned int seq = ++h->ext_seq;
   if (seq == 0u) seq = ++h->ext_seq;                 // (0 means "nothing to wait for")
   unsigned int* host_seq = h->v.host_edges_hdr ? h->v.host_edges_hdr + eb : nullptr;
@@ -1073,6 +1113,11 @@ int liodom_extract_edges_device(liodom_handle_t* h, int stream, const float* xyz
     HIP_TRY(hipEventRecord(h->ev_edges[eb], q));
   }
   HIP_TRY(hipGetLastError());
+  if (staged_on_ring) {
+    const int sr = (h->stage_next + kEdgePipeBufs - 1) % kEdgePipeBufs;
+    HIP_TRY(hipEventRecord(h->ev_sdone[sr], q));
+    h->ev_sdone_valid[sr] = true;
+  }
   h->eb_seq[eb] = seq;
   h->pipe_active.store(true);
   h->tk_seq[eb].store(seq);
@@ -1353,6 +1398,8 @@ static int upload_slot_async(liodom_handle_t* h, int slot, const float* host, in
     // idle in it and carries the uploads.
     if (h->stream_k) { h->stream_c = h->stream_k; h->stream_c_shared = true; }
     else HIP_TRY(hipStreamCreateWithFlags(&h->stream_c, hipStreamNonBlocking));
+  }
+  if (!h->ev_up[0]) {
     for (int b = 0; b < 3; b++) {
       HIP_TRY(hipEventCreateWithFlags(&h->ev_up[b], hipEventDisableTiming));
       HIP_TRY(hipEventCreateWithFlags(&h->ev_xdone[b], hipEventDisableTiming));

@@ -262,7 +262,11 @@ def sec_ovclocks(H=64, W=1800, R=8, epr=10, P=20, K=40):
     buf = (C.c_ulonglong * 512)()
     g.L.liodom_debug_clocks.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
     g.L.liodom_debug_clocks(g.h, buf)
-    a = np.array(list(buf), dtype=np.int64)[448:480]
+    allv = np.array(list(buf), dtype=np.int64)
+    print("overlapped pass: pose publication -> seen by a workgroup, 0.25 us bins (all scans):", allv[320:384].tolist())
+    print("overlapped pass: pose seen -> done flag raised, per workgroup with queries, 0.5 us bins (all scans):", allv[256:320].tolist())
+    print("first pass: workgroup end relative to the start of workgroup 0, 0.5 us bins (all scans):", allv[384:448].tolist())
+    a = allv[448:480]
     names = ["solve0 wg0 start", "solve0 pose published", "solve0 wg0 end", "solve1 wg0 start", "solve1 wait done", "solve1 wg0 end", "gate start", "gate saw flag",
              "knn1 wg0 start", "knn1 wg0 past flag", "knn1 wg0 pose seen", "knn1 wg0 end", "knn1 wgN start", "knn1 wgN past flag", "knn1 wgN pose seen", "knn1 wgN end",
              "knn0 wg0 start", "knn0 wgN end", "solve0 partial sums next"]
