@@ -99,11 +99,11 @@ def measured_traffic(kernel, n_streams, workload):
         if n_streams == 1:
             row = prof.get("single", {}).get(kernel)
             return int(row["hbm_bytes_per_launch"]) if row else None
-        b = prof.get("batched", {})
-        row = b.get("kernels", {}).get(kernel)
-        if not row or not b.get("streams"):
-            return None
-        return int(row["hbm_bytes_per_launch"] / b["streams"] * n_streams)      # scaled from the profiled stream count
+        for b in prof.get("batched_groups", [prof.get("batched", {})]):
+            row = b.get("kernels", {}).get(kernel)
+            if row and b.get("streams") == n_streams:          # a measurement at THIS stream count only: nothing is scaled
+                return int(row["hbm_bytes_per_launch"])
+        return None
     except Exception:
         return None
 

@@ -1002,11 +1002,12 @@ static int ensure_pin_ring(liodom_handle* h) {
   HIP_TRY(hipHostMalloc(&p, sizeof(float4) * (size_t)kEdgePipeBufs * (size_t)h->v.max_points, hipHostMallocDefault));
   h->pin_ring = static_cast<float4*>(p);
   for (int b = 0; b < kEdgePipeBufs; b++) HIP_TRY(hipEventCreateWithFlags(&h->ev_pin[b], hipEventDisableTiming));
-  // Uploads on a copy stream of their own, into a ring of device staging slots: the DMA of scan k+1 (1.84 MB, ~37 us) then runs
-  // beside the extraction kernels of scan k instead of in front of its own on the extraction stream.  (The host-fed replay found a
-  // further stream per handle harmful when ONE host thread enqueues everything; with two threads it pays: LIODOM_COPY_STREAM=0
-  // switches it off.)
-  bool want = true;
+  // LIODOM_COPY_STREAM=1: uploads on a copy stream of their own, into a ring of device staging slots, so that the DMA of scan k+1
+  // (1.84 MB, ~37 us) runs beside the extraction kernels of scan k instead of in front of its own on the extraction stream.
+  // Measured (MI355X, HDL-64 shape, two C++ threads): 10.3k scans/s WITHOUT it, 7.5k with it, with GPU_MAX_HW_QUEUES=8 as well —
+  // the same loss the host-fed replay saw with a fourth stream per handle (the two cross-stream event edges per scan cost more
+  // than the overlap gains).  Off by default; kept for runtimes where a fourth stream is cheap.
+  bool want = false;
   if (const char* e = std::getenv("LIODOM_COPY_STREAM")) want = std::atoi(e) != 0;
   if (want && !h->profiling) {
     void* d = nullptr;

@@ -1,6 +1,11 @@
 """Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs (separate passes) into the per-workload traffic profile bench.py reads.
 
-usage: pmc_summary.py <workload> <out.json> <single_fetch_dir> <single_write_dir> [<batched_streams> <batched_fetch_dir> <batched_write_dir>]
+usage: pmc_summary.py <workload> <out.json> <skip_scans> <single_fetch_dir> <single_write_dir> [<batched_streams> <batched_fetch_dir> <batched_write_dir>]...
+
+skip_scans: the workload's pre-fill (tools/workload_run.py runs P scans into an empty window first): of every (kernel, grid)
+the first skip_scans / total_scans share of the launches — in dispatch order — is dropped, so that the averages are those of the
+steady state bench.py times.  Several batched groups may follow (e.g. 16 and 256 lock-step streams); bench.py uses the one whose
+stream count equals its own and never scales a measurement to another stream count.
 
 FETCH_SIZE / WRITE_SIZE are reported in KiB; per /opt/skills/guides/MI355X_MICROARCH.md (HBM section) FETCH_SIZE on
 gfx950 counts 128-B requests at 64 B, i.e. reads exactly half of a wide coalesced stream — `fetch_corrected` doubles it
@@ -14,17 +19,31 @@ import sqlite3
 import sys
 
 
+SKIP_FRACTION = 0.0     # share of every (kernel, grid)'s launches that belongs to the pre-fill (dispatch order)
+
+
 def load(dirname, counter):
     f = glob.glob(dirname + "/**/*.db", recursive=True)[0]
     db = sqlite3.connect(f)
-    rows = db.execute("select kernel_name, grid_size, count(*), avg(value) from counters_collection "
-                      "where counter_name=? group by kernel_name, grid_size", (counter,)).fetchall()
-    out = {}
-    for k, g, n, v in rows:
+    try:
+        rows = db.execute("select kernel_name, grid_size, dispatch_id, value from counters_collection where counter_name=? "
+                          "order by dispatch_id", (counter,)).fetchall()
+    except sqlite3.Error:
+        rows = db.execute("select kernel_name, grid_size, rowid, value from counters_collection where counter_name=? order by rowid",
+                          (counter,)).fetchall()
+    per = {}
+    for k, g, d, v in rows:
         if "liodom_dev" not in k:
             continue
         name = k.split("(")[0].split("<")[0].replace("void ", "").replace("liodom_dev::", "")
-        out.setdefault(name, []).append((g, n, v))
+        per.setdefault((name, g), {}).setdefault(d, 0.0)
+        per[(name, g)][d] += v                      # (one row per counter instance / XCC: summed per dispatch)
+    out = {}
+    for (name, g), disp in per.items():
+        vals = [disp[d] for d in sorted(disp)]
+        drop = int(round(len(vals) * SKIP_FRACTION))
+        vals = vals[drop:] if len(vals) > drop else vals
+        out.setdefault(name, []).append((g, len(vals), sum(vals) / max(len(vals), 1)))
     return out
 
 
@@ -48,9 +67,18 @@ def merge(fetch_dir, write_dir, title):
 
 
 if __name__ == "__main__":
-    workload, out = sys.argv[1], sys.argv[2]
-    prof = {"workload": workload, "single": merge(sys.argv[3], sys.argv[4], "%s, one stream (per-launch averages)" % workload)}
-    if len(sys.argv) > 7:
-        S = int(sys.argv[5])
-        prof["batched"] = {"streams": S, "kernels": merge(sys.argv[6], sys.argv[7], "%s, %d lock-step streams (per-launch averages, whole launch)" % (workload, S))}
+    workload, out, skip = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    total = skip + int(__import__("os").environ.get("PMC_STEADY_SCANS", "20"))
+    SKIP_FRACTION = skip / float(total)
+    prof = {"workload": workload, "prefill_scans_dropped": skip, "steady_scans": total - skip,
+            "single": merge(sys.argv[4], sys.argv[5], "%s, one stream, steady state (per-launch averages over the launches behind the %d pre-fill scans)" % (workload, skip))}
+    rest = sys.argv[6:]
+    groups = []
+    while len(rest) >= 3:
+        S = int(rest[0])
+        groups.append({"streams": S, "kernels": merge(rest[1], rest[2], "%s, %d lock-step streams, steady state (per-launch averages, whole launch)" % (workload, S))})
+        rest = rest[3:]
+    if groups:
+        prof["batched"] = groups[-1]               # (the largest stream count given last: what bench.py's batched leg runs)
+        prof["batched_groups"] = groups
     json.dump(prof, open(out, "w"), indent=1)

@@ -27,14 +27,18 @@ for WLD in $WLS; do
     export LIODOM_PIPE_FLAGS=0
     for C in FETCH_SIZE WRITE_SIZE; do
       rm -rf $OUT/pmc1_$C $OUT/pmc16_$C
-      timeout 300 rocprofv3 --kernel-trace --pmc $C -d $OUT/pmc1_$C -- python3 $R/tools/workload_run.py $WLD 1 46 > /dev/null 2> $OUT/pmc1_$C.err
-      if [ $WLD = hdl64 ]; then timeout 300 rocprofv3 --kernel-trace --pmc $C -d $OUT/pmc16_$C -- python3 $R/tools/workload_run.py $WLD 16 30 > /dev/null 2> $OUT/pmc16_$C.err; fi
+      timeout 300 rocprofv3 --kernel-trace --pmc $C -d $OUT/pmc1_$C -- python3 $R/tools/workload_run.py $WLD 1 20 > /dev/null 2> $OUT/pmc1_$C.err
+      if [ $WLD = hdl64 ]; then
+        timeout 300 rocprofv3 --kernel-trace --pmc $C -d $OUT/pmc16_$C -- python3 $R/tools/workload_run.py $WLD 16 20 > /dev/null 2> $OUT/pmc16_$C.err
+        timeout 600 rocprofv3 --kernel-trace --pmc $C -d $OUT/pmc256_$C -- python3 $R/tools/workload_run.py $WLD 256 20 > /dev/null 2> $OUT/pmc256_$C.err
+      fi
     done
     unset LIODOM_PIPE_FLAGS
-    { echo "# $TAG: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 tools/workload_run.py $WLD <streams> <scans>   (LIODOM_PIPE_FLAGS=0)";
-      if [ $WLD = hdl64 ]; then python3 $R/tools/pmc_summary.py $WLD $OUT/${TAG}_pmc_traffic_$WLD.json $OUT/pmc1_FETCH_SIZE $OUT/pmc1_WRITE_SIZE 16 $OUT/pmc16_FETCH_SIZE $OUT/pmc16_WRITE_SIZE;
-      else python3 $R/tools/pmc_summary.py $WLD $OUT/${TAG}_pmc_traffic_$WLD.json $OUT/pmc1_FETCH_SIZE $OUT/pmc1_WRITE_SIZE; fi; } > $OUT/${TAG}_pmc_traffic_$WLD.txt
-    rm -rf $OUT/pmc1_FETCH_SIZE $OUT/pmc1_WRITE_SIZE $OUT/pmc16_FETCH_SIZE $OUT/pmc16_WRITE_SIZE )
+    case $WLD in vlp16) PF=10;; ouster128) PF=30;; *) PF=20;; esac
+    { echo "# $TAG: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 tools/workload_run.py $WLD <streams> 20   (window pre-filled first: the $PF pre-fill scans' launches are dropped; LIODOM_PIPE_FLAGS=0)";
+      if [ $WLD = hdl64 ]; then PMC_STEADY_SCANS=20 python3 $R/tools/pmc_summary.py $WLD $OUT/${TAG}_pmc_traffic_$WLD.json $PF $OUT/pmc1_FETCH_SIZE $OUT/pmc1_WRITE_SIZE 16 $OUT/pmc16_FETCH_SIZE $OUT/pmc16_WRITE_SIZE 256 $OUT/pmc256_FETCH_SIZE $OUT/pmc256_WRITE_SIZE;
+      else PMC_STEADY_SCANS=20 python3 $R/tools/pmc_summary.py $WLD $OUT/${TAG}_pmc_traffic_$WLD.json $PF $OUT/pmc1_FETCH_SIZE $OUT/pmc1_WRITE_SIZE; fi; } > $OUT/${TAG}_pmc_traffic_$WLD.txt
+    rm -rf $OUT/pmc1_FETCH_SIZE $OUT/pmc1_WRITE_SIZE $OUT/pmc16_FETCH_SIZE $OUT/pmc16_WRITE_SIZE $OUT/pmc256_FETCH_SIZE $OUT/pmc256_WRITE_SIZE )
 done
 if [ "${SKIP_SQ:-0}" != "1" ]; then SQ_STREAMS=64 $R/tools/pmc_sq.sh $TAG > /dev/null 2>&1; fi
 cat $OUT/${TAG}_bench.json | head -c 900; echo; head -14 $OUT/${TAG}_bench_kernel_trace.txt; head -24 $OUT/${TAG}_pmc_traffic_hdl64.txt

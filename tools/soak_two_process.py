@@ -1,0 +1,129 @@
+"""Soak of the in-kernel cross-stream signalling (pipe flags, overlapped second kNN pass, in-launch exchanges) while a SECOND
+PROCESS saturates the same GPU.  The library can only see the handles of its own process (g_live_handles); nothing tells it
+that another process's kernels occupy the CUs its waiting workgroups expect to share.  Outcome required: the replay's pose log
+is bit-identical to the solo run — or the library reports a clean LIODOM_ERR_HIP (LIODOM_STATUS_PIPE_TIMEOUT), and after
+liodom_reset() (event-based dependencies from then on) the replay completes bit-identical.  Never a wrong pose.
+
+usage: python tools/soak_two_process.py [hdl64|vlp16] [scans=20000] [distinct=400] [hog=matmul|spin]
+The replay walks `distinct` synthetic scans back and forth (0 .. distinct-1, distinct-2 .. 0, ...): a continuous trajectory of
+any length from a bounded number of generated scans."""
+import os, subprocess, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+if len(sys.argv) > 1 and sys.argv[1] == "--hog":
+    # the second process: keeps every CU busy until the stop file appears
+    import torch
+    kind, stop = sys.argv[2], sys.argv[3]
+    dev = torch.device("cuda:0")
+    a = torch.randn(8192, 8192, device=dev, dtype=torch.float32)
+    b = torch.randn(8192, 8192, device=dev, dtype=torch.float32)
+    x = torch.randn(64 * 1024 * 1024, device=dev)
+    open(stop + ".ready", "w").write("1")
+    n = 0
+    while not os.path.exists(stop):
+        if kind == "matmul":
+            for _ in range(8):
+                a = (a @ b).clamp_(-1, 1)
+        else:
+            for _ in range(32):
+                x = x * 1.0001 + 0.5          # bandwidth-bound elementwise kernels, every CU
+        torch.cuda.synchronize()
+        n += 1
+    print("hog iterations", n)
+    sys.exit(0)
+
+import liodom_amd as la
+from liodom_amd import synth
+shape = sys.argv[1] if len(sys.argv) > 1 else "hdl64"
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
+D = int(sys.argv[3]) if len(sys.argv) > 3 else 400
+hog_kind = sys.argv[4] if len(sys.argv) > 4 else "matmul"
+H, W, LT, R, epr, P = {"hdl64": (64, 1800, 0, 8, 10, 20), "vlp16": (16, 1800, 0, 8, 20, 10)}[shape]
+N = H * W
+cfg = synth.make_cfg(H, W, LT)
+print("generating %d scans ..." % D, flush=True)
+scans = [synth.scan(cfg, 5, k)[0] for k in range(D)]
+order = list(range(D)) + list(range(D - 2, 0, -1))            # one period of the back-and-forth walk
+g = la.Liodom(la.make_params(lidar_type=LT, scan_lines=H, scan_regions=R, edges_per_region=epr, prev_frames=P),
+              la.make_config(n_streams=1, max_points=N, max_width=W, pose_log_capacity=1024))
+print("modes:", g.modes(), flush=True)
+g.alloc_resident(D)
+for k in range(D):
+    g.upload_scan(0, k, scans[k])
+g.sync()
+
+
+def replay(label):
+    """K scans along the walk; returns (poses or None, error text or None)."""
+    out = []
+    t0 = time.perf_counter()
+    k = 0
+    try:
+        while k < K:
+            # runs of consecutive resident slots (ascending) go through the C consumer loop; descending stretches scan by scan
+            i = k % len(order)
+            if i < D - 1:
+                n = min(D - i, K - k)
+                poses, infos = g.replay_resident(order[i], n, N, H, W, depth=1)
+                st = 0
+                for inf in infos:
+                    st |= int(inf.status)
+                if st:
+                    return None, "status bits 0x%x" % st
+                out.append(poses[:, 0].copy())
+                k += n
+            else:
+                pose, info = g.process_resident(order[i], N, H, W, readback=True)
+                if int(info[0].status):
+                    return None, "status bits 0x%x" % int(info[0].status)
+                out.append(pose.copy())
+                k += 1
+    except la.LiodomError as ex:
+        return None, str(ex)
+    dt = time.perf_counter() - t0
+    print("%s: %d scans in %.2f s = %.0f scans/s" % (label, K, dt, K / dt), flush=True)
+    return np.concatenate(out), None
+
+
+solo, err = replay("solo")
+assert err is None, err
+stop = "/tmp/liodom_soak_stop_%d" % os.getpid()
+for f in (stop, stop + ".ready"):
+    if os.path.exists(f):
+        os.remove(f)
+hog = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--hog", hog_kind, stop], stdout=subprocess.PIPE, text=True)
+t_wait = time.time()
+while not os.path.exists(stop + ".ready") and time.time() - t_wait < 180:
+    time.sleep(0.2)
+assert os.path.exists(stop + ".ready"), "the second process did not start"
+time.sleep(1.0)
+verdict = "FAIL"
+try:
+    g.reset()
+    loaded, err = replay("beside the second process (%s)" % hog_kind)
+    if err is None:
+        same = np.array_equal(loaded.view(np.uint64), solo.view(np.uint64))
+        verdict = "bit-identical to the solo run" if same else "WRONG POSES (no error reported)"
+    else:
+        print("clean error beside the second process:", err[:300], flush=True)
+        g.reset()                                   # applies the event-path fallback
+        print("modes after reset:", g.modes(), flush=True)
+        again, err2 = replay("after liodom_reset (events), still beside the second process")
+        if err2 is None and np.array_equal(again.view(np.uint64), solo.view(np.uint64)):
+            verdict = "clean LIODOM_ERR_HIP, then bit-identical on the event path"
+        else:
+            verdict = "FAIL after the fallback: %s" % (err2 or "poses differ")
+finally:
+    open(stop, "w").write("1")
+    try:
+        print(hog.communicate(timeout=120)[0].strip())
+    except Exception:
+        hog.kill()
+    for f in (stop, stop + ".ready"):
+        if os.path.exists(f):
+            os.remove(f)
+print("%s, %d scans, overlap %s: %s" % (shape, K, g.modes().get("knn_overlap"), verdict))
+g.close()
+sys.exit(0 if verdict.startswith(("bit-identical", "clean")) else 1)
