@@ -108,6 +108,7 @@ struct liodom_handle {
   hipEvent_t ev_pin[kEdgePipeBufs] = {nullptr, nullptr, nullptr};     // the upload out of staging slot r has completed
   bool ev_pin_valid[kEdgePipeBufs] = {false, false, false};
   int pin_next = 0;
+  bool safe_mode = false;            // no in-kernel waits at all: events between the streams, one workgroup per solve, three-kernel hash rebuild
   bool streams_concurrent = true;    // liodom_create's probe: kernels of two streams of this handle ran side by side
   std::atomic<bool> pipe_active{false};        // scans went through the pipeline edge buffers by ticket since the last drain
   std::atomic<bool> fallback_pending{false};   // a kernel of this handle gave up an in-kernel wait (LIODOM_STATUS_PIPE_TIMEOUT): liodom_reset() switches to events
@@ -470,11 +471,30 @@ int issue_extract(liodom_handle* h, int slot, int eb, int n, int height, int wid
   return LIODOM_OK;
 }
 
+// Safe mode: every dependency that a kernel of this handle would wait for INSIDE a kernel is replaced by one the runtime orders.
+// In-kernel waits need the producer to run beside the waiter; a GPU saturated by another process (or a tool that serialises
+// kernels) breaks that, the bounded waits give up (LIODOM_STATUS_PIPE_TIMEOUT / LM_SYNC_TIMEOUT) and the scan is lost.  Afterwards:
+//   stream dependencies   flags polled by kernels            -> hipEvent pairs
+//   second kNN pass       beside the first solve, polling     -> behind it in stream order
+//   pose solve            G workgroups exchanging partial sums in the launch -> one workgroup (sums in a different order: poses
+//                         agree with the G-workgroup solve to rounding, not to the bit)
+//   hash rebuild          workgroups inside the solve launches waiting for its pose -> k_window_insert / k_hash_alloc /
+//                         k_hash_scatter behind the solve (bit-identical: test_early_rebuild_equals_three_kernel_rebuild)
+// Entered by liodom_reset() after a timeout, or at creation with LIODOM_SAFE_MODE=1.
+void enter_safe_mode(liodom_handle* h) {
+  h->safe_mode = true;
+  h->use_flags = false;
+  h->v.lm_groups = 1;
+  h->v.early_rebuild = 0;      // (the second table, the padding and the overflow list stay allocated and unused)
+}
+
 int reset_state(liodom_handle* h) {
   // nothing of an earlier scan may still be in flight: its finalize would publish into the records
   // zeroed below, and an extraction issued ahead would write into scratch that is being reset
   if (h->stream_x) HIP_TRY(hipStreamSynchronize(h->stream_x));
   HIP_TRY(hipStreamSynchronize(h->stream));
+  if (h->stream_k) HIP_TRY(hipStreamSynchronize(h->stream_k));
+  if (h->fallback_pending.exchange(false)) enter_safe_mode(h);      // an in-kernel wait gave up (wait_pose)
   std::vector<StreamState> init((size_t)h->S);
   for (auto& st : init) {
     std::memset(&st, 0, sizeof(st));
@@ -497,9 +517,7 @@ int reset_state(liodom_handle* h) {
   h->ext_seq = h->odo_seq = 0;
   // the first scans after a reset are not overlapped (as after liodom_create): the first one runs with st.initialized == 0, where
   // no first solve publishes the pose an overlapped second kNN pass would wait for
-  if (h->stream_k) HIP_TRY(hipStreamSynchronize(h->stream_k));
   h->ov_warm = 0; h->ov_prev = false;
-  if (h->fallback_pending.exchange(false)) h->use_flags = false;      // an in-kernel wait gave up (wait_pose): events from here on
   for (int b = 0; b < kEdgePipeBufs; b++) { h->tk_seq[b] = 0u; h->ev_pin_valid[b] = false; h->ev_sdone_valid[b] = false; }      // outstanding edge tickets are void
   if (h->stream_c && !h->stream_c_shared) HIP_TRY(hipStreamSynchronize(h->stream_c));
   h->x_next = 0; h->odo_pending = 0;
@@ -657,6 +675,7 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   //  47.3k / 51.3k — with many streams the waiting workgroups of one stream hold the CUs the next stream's solve needs)
   v.early_rebuild = (!h->lds_hash_build && !v.filter_local_map && !params->mapping && config->n_streams <= 4) ? 1 : 0;
   if (const char* e = std::getenv("LIODOM_EARLY_REBUILD")) { if (std::atoi(e) == 0) v.early_rebuild = 0; }
+  if (const char* e = std::getenv("LIODOM_SAFE_MODE")) { if (std::atoi(e) != 0) enter_safe_mode(h); }
   v.recv_cap = v.mapping ? (config->recv_capacity > 0 ? config->recv_capacity : 262144) : 0;
   v.map_cap = v.edge_cap * h->P + v.recv_cap;
   int ts = 1024;
@@ -956,7 +975,7 @@ static int wait_pose(liodom_handle_t* h, int s0, int count, double* pose_out, li
     const HostOut* r = h->host_out + (size_t)(s0 + i) * 2 + ((expect - 1) & 1);
     if (pose_out) std::memcpy(pose_out + 7 * i, r->pose, sizeof(double) * 7);
     if (info) info[i] = r->info;
-    if (r->info.status & LIODOM_STATUS_PIPE_TIMEOUT) timed_out = true;
+    if (r->info.status & (LIODOM_STATUS_PIPE_TIMEOUT | LIODOM_STATUS_LM_SYNC_TIMEOUT)) timed_out = true;
   }
   if (timed_out) {
     // A kernel gave up waiting for another HIP stream of the handle (pipe_wait / ov_wait_*): its workgroups skipped the scan, the
@@ -964,9 +983,9 @@ static int wait_pose(liodom_handle_t* h, int s0, int count, double* pose_out, li
     // (this caller may hold the odometry side only while another thread extracts): it is applied by liodom_reset(), and every
     // entry point that enqueues work refuses until then (check_usable).
     h->fallback_pending.store(true);
-    g_last_error = "a kernel timed out waiting for another HIP stream of the handle (LIODOM_STATUS_PIPE_TIMEOUT): kernels are serialised "
-                   "across streams (profiler with --pmc, AMD_SERIALIZE_KERNEL, debugger) or the GPU is saturated by another process; the "
-                   "scan's result is invalid; call liodom_reset(): the handle then continues with event-based stream dependencies";
+    g_last_error = "a kernel timed out waiting for another kernel of the handle (LIODOM_STATUS_PIPE_TIMEOUT / LM_SYNC_TIMEOUT): kernels are "
+                   "serialised across streams (profiler with --pmc, AMD_SERIALIZE_KERNEL, debugger) or the GPU is saturated by another "
+                   "process; the scan's result is invalid; call liodom_reset(): the handle then continues in safe mode (no in-kernel waits)";
     return LIODOM_ERR_HIP;
   }
   return LIODOM_OK;
@@ -1722,12 +1741,12 @@ int liodom_get_modes(liodom_handle_t* h, char* buf, int cap) {
   snprintf(buf, (size_t)cap,
            "n_streams=%d early_rebuild=%d hash_build=%s pipe_flags=%d flag_gate=%d lm_groups=%d knn_instance=%d knn_queries=%d "
            "knn_grid=%d/%d knn_partials=%d knn_saved_bound=%d knn_exact_only=%d line_gate_kernel=%d filter_local_map=%d mapping=%d "
-           "rotation_mode=%d table_size=%d rebuild_delta=%.3f knn_overlap=%d streams_concurrent=%d debug=%d",
+           "rotation_mode=%d table_size=%d rebuild_delta=%.3f knn_overlap=%d streams_concurrent=%d safe_mode=%d debug=%d",
            h->S, v.early_rebuild, v.early_rebuild ? "streamed" : (h->lds_hash_build ? "lds" : "global"), h->use_flags ? 1 : 0,
            (h->use_flags && h->flag_gate) ? 1 : 0, v.lm_groups, h->S >= 16 ? 128 : 256, v.knn_queries, v.knn_grid,
            v.knn_blocks, v.knn_partials, v.knn_save_pos ? 2 : (v.knn_save_q ? 1 : 0), v.knn_exact_only, v.knn_nn ? 1 : 0, v.filter_local_map, v.mapping,
            v.rotation_mode, v.table_size, (double)v.rebuild_delta,
-           (v.early_rebuild && h->ov_ok && h->use_flags && g_live_handles.load() <= 1) ? 1 : 0, h->streams_concurrent ? 1 : 0, v.debug);
+           (v.early_rebuild && h->ov_ok && h->use_flags && g_live_handles.load() <= 1) ? 1 : 0, h->streams_concurrent ? 1 : 0, h->safe_mode ? 1 : 0, v.debug);
   return LIODOM_OK;
 }
 

@@ -374,3 +374,21 @@ def test_cxx_two_thread_replay_equals_resident_replay(synth):
         assert np.array_equal(got.view(np.uint64), ref[:, 0].view(np.uint64)), (depth, fetch, pin)
         assert secs > 0 and tot == (n_edges if fetch else 0)
     g.close()
+
+
+@pytest.mark.parametrize("hog", ["spin", "matmul"])
+def test_second_process_saturating_the_gpu_never_gives_a_wrong_pose(hog):
+    """tools/soak_two_process.py: a replay with every in-kernel wait active (pipe flags, overlapped second kNN pass, in-launch
+    exchanges) while a SECOND PROCESS keeps every CU busy.  Either bit-identical to the solo run, or a clean LIODOM_ERR_HIP and —
+    after liodom_reset(), which enters the safe mode (no in-kernel waits) — bit-identical to a solo safe-mode run."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        import torch  # noqa: F401  (the second process uses it to load the GPU)
+    except Exception:
+        pytest.skip("torch not importable: no second process to load the GPU with")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_two_process.py"), "vlp16", "3000", "150", hog],
+                       capture_output=True, text=True, timeout=900)
+    tail = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ""
+    assert r.returncode == 0, (tail, r.stderr[-1500:])
+    assert "bit-identical" in tail

@@ -46,16 +46,17 @@ cfg = synth.make_cfg(H, W, LT)
 print("generating %d scans ..." % D, flush=True)
 scans = [synth.scan(cfg, 5, k)[0] for k in range(D)]
 order = list(range(D)) + list(range(D - 2, 0, -1))            # one period of the back-and-forth walk
-g = la.Liodom(la.make_params(lidar_type=LT, scan_lines=H, scan_regions=R, edges_per_region=epr, prev_frames=P),
-              la.make_config(n_streams=1, max_points=N, max_width=W, pose_log_capacity=1024))
-print("modes:", g.modes(), flush=True)
-g.alloc_resident(D)
-for k in range(D):
-    g.upload_scan(0, k, scans[k])
-g.sync()
+def make():
+    h = la.Liodom(la.make_params(lidar_type=LT, scan_lines=H, scan_regions=R, edges_per_region=epr, prev_frames=P),
+                  la.make_config(n_streams=1, max_points=N, max_width=W, pose_log_capacity=1024))
+    h.alloc_resident(D)
+    for k in range(D):
+        h.upload_scan(0, k, scans[k])
+    h.sync()
+    return h
 
 
-def replay(label):
+def replay(g, label):
     """K scans along the walk; returns (poses or None, error text or None)."""
     out = []
     t0 = time.perf_counter()
@@ -75,7 +76,8 @@ def replay(label):
                 out.append(poses[:, 0].copy())
                 k += n
             else:
-                pose, info = g.process_resident(order[i], N, H, W, readback=True)
+                nxt = order[(i + 1) % len(order)] if k + 1 < K else -1          # (its extraction is issued beside this odometry)
+                pose, info = g.process_resident(order[i], N, H, W, readback=True, next_slot=nxt)
                 if int(info[0].status):
                     return None, "status bits 0x%x" % int(info[0].status)
                 out.append(pose.copy())
@@ -87,8 +89,21 @@ def replay(label):
     return np.concatenate(out), None
 
 
-solo, err = replay("solo")
+# reference of the safe mode (what a handle falls back to after a timeout: one workgroup per solve, so its sums — and the last
+# bits of its poses — differ from the normal mode's), from a handle created in it
+os.environ["LIODOM_SAFE_MODE"] = "1"
+gs = make()
+solo_safe, err = replay(gs, "solo, safe mode %s" % gs.modes().get("safe_mode"))
 assert err is None, err
+gs.close()
+del os.environ["LIODOM_SAFE_MODE"]
+g = make()
+print("modes:", g.modes(), flush=True)
+solo, err = replay(g, "solo")
+assert err is None, err
+dq = np.abs(solo - solo_safe).max()
+print("normal vs safe mode, solo: max |pose difference| %.3e" % dq, flush=True)
+assert dq < 1e-6
 stop = "/tmp/liodom_soak_stop_%d" % os.getpid()
 for f in (stop, stop + ".ready"):
     if os.path.exists(f):
@@ -102,7 +117,7 @@ time.sleep(1.0)
 verdict = "FAIL"
 try:
     g.reset()
-    loaded, err = replay("beside the second process (%s)" % hog_kind)
+    loaded, err = replay(g, "beside the second process (%s)" % hog_kind)
     if err is None:
         same = np.array_equal(loaded.view(np.uint64), solo.view(np.uint64))
         verdict = "bit-identical to the solo run" if same else "WRONG POSES (no error reported)"
@@ -110,9 +125,9 @@ try:
         print("clean error beside the second process:", err[:300], flush=True)
         g.reset()                                   # applies the event-path fallback
         print("modes after reset:", g.modes(), flush=True)
-        again, err2 = replay("after liodom_reset (events), still beside the second process")
-        if err2 is None and np.array_equal(again.view(np.uint64), solo.view(np.uint64)):
-            verdict = "clean LIODOM_ERR_HIP, then bit-identical on the event path"
+        again, err2 = replay(g, "after liodom_reset (safe mode), still beside the second process")
+        if err2 is None and np.array_equal(again.view(np.uint64), solo_safe.view(np.uint64)):
+            verdict = "clean LIODOM_ERR_HIP, then bit-identical to the solo safe-mode run after liodom_reset"
         else:
             verdict = "FAIL after the fallback: %s" % (err2 or "poses differ")
 finally:
