@@ -696,7 +696,7 @@ __device__ __forceinline__ void knn_block(const DevView& v, int s, StreamState& 
       // :346 — with knn_partials the count travels as entry 29 of the workgroup's partial sums (no same-address atomic of
       // every workgroup: hot-address atomics delay whatever else maps to that memory channel by microseconds)
       if (nvalid && !v.knn_partials) atomicAdd(&st.info.matches[outer_it], nvalid);
-      unsigned char* cm = &v.corr_mask[((size_t)s * 2 + outer_it) * v.knn_blocks + bv];   // bit q = query q accepted
+      unsigned char* cm = &v.corr_mask[((size_t)s * 2 + outer_it) * v.mask_stride + bv];   // bit q = query q accepted
       if (kPre) wt_store_u8(cm, (unsigned char)vb); else *cm = (unsigned char)vb;
     }
     sh.res[q][3] = valid ? 1 : 0;
@@ -790,7 +790,7 @@ __device__ __forceinline__ void knn_tail_dual(const DevView& v, int s, int outer
       wt_store_u64(v.corr_idx + ((size_t)s * 2 + outer_it) * v.edge_cap + eq, ((unsigned long long)(unsigned int)oi.y << 32) | (unsigned int)oi.x);
     }
     const unsigned long long vb = __ballot(valid);
-    if (q == 0) wt_store_u8(&v.corr_mask[((size_t)s * 2 + outer_it) * v.knn_blocks + bv], (unsigned char)vb);   // bit q = query q accepted
+    if (q == 0) wt_store_u8(&v.corr_mask[((size_t)s * 2 + outer_it) * v.mask_stride + bv], (unsigned char)vb);   // bit q = query q accepted
     sh.res[q][3] = valid ? 1 : 0;
   } else if (t >= 64 && t < 64 + kKnnQueries && live) {
     // the residual block of every query that found five neighbours, at the finalising solve's start point (see knn_block)
@@ -900,7 +900,7 @@ __device__ __forceinline__ void knn_pass(const DevView& v, int s, int bxi, int b
   static_assert(kKnnGridDiv == 2, "k_knn handles exactly two query blocks per workgroup");
   if (bxi * kKnnQueries >= E) {             // no query here: empty validity bytes for the solve's compaction
     if (threadIdx.x == 0) {
-      unsigned char* cm = &v.corr_mask[((size_t)s * 2 + outer_it) * v.knn_blocks + bxi];
+      unsigned char* cm = &v.corr_mask[((size_t)s * 2 + outer_it) * v.mask_stride + bxi];
       if (kOv) wt_store_u8(cm, 0); else *cm = 0;
       if (bxi + v.knn_grid < v.knn_blocks) { if (kOv) wt_store_u8(cm + v.knn_grid, 0); else cm[v.knn_grid] = 0; }
     }
@@ -932,7 +932,7 @@ __device__ __forceinline__ void knn_pass(const DevView& v, int s, int bxi, int b
     // both blocks' queries, then their gates and partial sums side by side
     knn_block<kKnnThreads, true, false>(v, s, st, outer_it, eb, bxi, E, sh, p_first, T, pre1, sh_ov + 12);
     if (second) knn_block<kKnnThreads, true, false>(v, s, st, outer_it, eb, bv2, E, sh2, p_second, T, pre2, sh_ov + 12);
-    else if (bv2 < v.knn_blocks && threadIdx.x == 0) wt_store_u8(&v.corr_mask[((size_t)s * 2 + outer_it) * v.knn_blocks + bv2], 0);
+    else if (bv2 < v.knn_blocks && threadIdx.x == 0) wt_store_u8(&v.corr_mask[((size_t)s * 2 + outer_it) * v.mask_stride + bv2], 0);
     __syncthreads();
     knn_tail_dual<kKnnThreads>(v, s, outer_it, eb, bxi, bv2, second, E, sh, sh2, sh_ov + 12);
     return;
@@ -940,7 +940,7 @@ __device__ __forceinline__ void knn_pass(const DevView& v, int s, int bxi, int b
   knn_block<kKnnThreads, false>(v, s, st, outer_it, eb, bxi, E, sh, p_first, T, pre1, nullptr);
   if (bv2 >= v.knn_blocks) return;
   if (!second) {
-    if (threadIdx.x == 0) { unsigned char* cm = &v.corr_mask[((size_t)s * 2 + outer_it) * v.knn_blocks + bv2]; if (kOv) wt_store_u8(cm, 0); else *cm = 0; }
+    if (threadIdx.x == 0) { unsigned char* cm = &v.corr_mask[((size_t)s * 2 + outer_it) * v.mask_stride + bv2]; if (kOv) wt_store_u8(cm, 0); else *cm = 0; }
     return;
   }
   __syncthreads();                          // (the second block reuses the LDS)
@@ -1036,5 +1036,5 @@ __global__ __launch_bounds__(256) void k_line_gate(DevView v, int s0, int outer_
   const unsigned long long vb = __ballot(valid);
   const int lane = threadIdx.x & 63;
   if (lane == 0) { const int nvalid = __popcll(vb); if (nvalid) atomicAdd(&st.info.matches[outer_it], nvalid); }   // :346
-  if ((lane % Q) == 0) v.corr_mask[((size_t)s * 2 + outer_it) * v.knn_blocks + eq / Q] = (unsigned char)((vb >> lane) & ((1ull << Q) - 1ull));
+  if ((lane % Q) == 0) v.corr_mask[((size_t)s * 2 + outer_it) * v.mask_stride + eq / Q] = (unsigned char)((vb >> lane) & ((1ull << Q) - 1ull));
 }

@@ -30,7 +30,7 @@ __device__ int lm_compact_bits(const DevView& v, int s, int outer_it, int E, int
   const int Q = v.knn_queries;
   const int nb = (E + Q - 1) / Q;                          // k_knn workgroups that had queries
   const int nwords = (nb + 3) >> 2;
-  const unsigned int* mw = reinterpret_cast<const unsigned int*>(v.corr_mask + ((size_t)s * 2 + outer_it) * v.knn_blocks);
+  const unsigned int* mw = reinterpret_cast<const unsigned int*>(v.corr_mask + ((size_t)s * 2 + outer_it) * v.mask_stride);
   int run = 0;
   for (int w0 = 0; w0 < nwords; w0 += 64) {
     const int w = w0 + lane;
@@ -120,16 +120,19 @@ __device__ __forceinline__ void lm_eval(const DevView& v, int s, int eb, int c_l
       for (int i = 0; i < kAccN; i++) part[i * kLmEvalThreads + et] = acc[i];
     }
     __syncthreads();
-    const int vrow = threadIdx.x >> 4, r = threadIdx.x & 15;
-    double x = 0.0;
-    if (vrow < kAccN) {
-      const double* rowp = part + vrow * kLmEvalThreads + r;
-      const int nk = ncol >> 4;
+    const int r = threadIdx.x & 15;
+#pragma unroll
+    for (int vrow = threadIdx.x >> 4; vrow < ((kAccN + kLmThreads / 16 - 1) / (kLmThreads / 16)) * (kLmThreads / 16); vrow += kLmThreads / 16) {
+      double x = 0.0;
+      if (vrow < kAccN) {
+        const double* rowp = part + vrow * kLmEvalThreads + r;
+        const int nk = ncol >> 4;
 #pragma unroll 8
-      for (int kk = 0; kk < nk; kk++) x += rowp[kk * 16];
+        for (int kk = 0; kk < nk; kk++) x += rowp[kk * 16];
+      }
+      x = row_sum_f64(x);
+      if (vrow < kAccN && r == 0) acc_out[vrow] = x;
     }
-    x = row_sum_f64(x);
-    if (vrow < kAccN && r == 0) acc_out[vrow] = x;
     __syncthreads();
     return;
   }
@@ -442,14 +445,15 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
     const int Q = v.knn_queries;
     const int nb = (E + Q - 1) / Q;
     const double* part = v.knn_part + ((size_t)s * 2 + outer_it) * v.knn_blocks * 32;
-    const int i = tid & 31, r0 = tid >> 5;               // 16 row classes x 32 columns (29 used)
+    constexpr int kRC = kLmThreads / 32;                 // row classes (16 at 512 threads) x 32 columns (29 used)
+    const int i = tid & 31, r0 = tid >> 5;
     double x0 = 0.0, x1 = 0.0;
     if (i <= kAccN) {                                    // (entry 29: the number of accepted correspondences)
-      // 16 independent loads in flight per pass (one memory round trip for up to 256 k_knn workgroups)
-      for (int rb = r0; rb < nb; rb += 256) {
+      // 16 independent loads in flight per pass (one memory round trip for up to 16 kRC k_knn workgroups)
+      for (int rb = r0; rb < nb; rb += 16 * kRC) {
         double xs[16];
 #pragma unroll
-        for (int u = 0; u < 16; u++) { const int r = rb + 16 * u; xs[u] = (r < nb) ? part[(size_t)r * 32 + i] : 0.0; }
+        for (int u = 0; u < 16; u++) { const int r = rb + kRC * u; xs[u] = (r < nb) ? part[(size_t)r * 32 + i] : 0.0; }
 #pragma unroll
         for (int u = 0; u < 16; u += 2) { x0 += xs[u]; x1 += xs[u + 1]; }
       }
@@ -459,7 +463,7 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
     if (tid <= kAccN) {
       double x = 0.0;
 #pragma unroll
-      for (int r = 0; r < 16; r++) x += sh_red[r][tid];
+      for (int r = 0; r < kRC; r++) x += sh_red[r][tid];
       if (tid < kAccN) sh_acc[tid] = x;
       else { sh_nmatch = (int)x; if (g == 0) st.info.matches[outer_it] = (int)x; }      // :346 (sum of small integers: exact)
     }

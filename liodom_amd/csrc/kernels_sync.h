@@ -77,12 +77,13 @@ __device__ __forceinline__ void wt_store_u8(void* p, unsigned char x) {
 // the first solve's result leaves its workgroup: vals = odom[12], q[4], t[3] in LDS; threads 0 .. kOvReplicas * kOvGranules - 1
 __device__ __forceinline__ void ov_publish_pose(const DevView& v, int s, const double* vals, unsigned int tag, int tid) {
   typedef __attribute__((address_space(1))) unsigned long long gu64;
-  if (tid >= kOvReplicas * kOvGranules) return;
-  const int rep = tid / kOvGranules, gi = tid % kOvGranules;
-  const unsigned long long bits = (unsigned long long)__double_as_longlong(vals[gi >> 1]);
-  const unsigned int word = (gi & 1) ? (unsigned int)(bits >> 32) : (unsigned int)bits;
-  __hip_atomic_store((gu64*)(v.pose_xch0 + ((size_t)s * kOvReplicas + rep) * 512 + gi), ((unsigned long long)tag << 32) | word,
-                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int t = tid; t < kOvReplicas * kOvGranules; t += (int)blockDim.x) {      // (one granule per thread at 512 threads)
+    const int rep = t / kOvGranules, gi = t % kOvGranules;
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(vals[gi >> 1]);
+    const unsigned int word = (gi & 1) ? (unsigned int)(bits >> 32) : (unsigned int)bits;
+    __hip_atomic_store((gu64*)(v.pose_xch0 + ((size_t)s * kOvReplicas + rep) * 512 + gi), ((unsigned long long)tag << 32) | word,
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 // whole workgroup; the first wave polls replica rep until every granule carries the tag; out19: LDS.  false: gave up.
 __device__ __forceinline__ bool ov_wait_pose(const DevView& v, int s, int rep, unsigned int tag, double* out19, unsigned int* status) {
@@ -129,8 +130,19 @@ __device__ __forceinline__ void ov_wait_knn_done(const DevView& v, int s, unsign
       if (++spins > 6000000u) { atomicOr(status, LIODOM_STATUS_PIPE_TIMEOUT); break; }
     }
   }
-  // (no acquire fence — an L2 invalidate per waiting workgroup: this launch started, with clean caches, before the pass wrote
-  //  any of its results, and reads none of them before this point; the pass's stores are write-through)
+  // No acquire fence (an L2 invalidate per waiting workgroup; with one per workgroup of the pass the solve beside it took 80 us
+  // instead of 24).  What this relies on instead — ASSUMPTIONS OUTSIDE THE HIP MEMORY MODEL, written down in DESIGN.md §3 and
+  // guarded by tests/test_gpu_parity.py::test_overlapped_pass_long_replay_is_bit_identical and tools/soak_two_process.py:
+  //   (1) every result of the pass that this launch reads (corr_a / corr_b / corr_idx / corr_mask / knn_part of THIS pass) is
+  //       written with agent-scope relaxed atomic stores = sc1, write-through: once acknowledged (s_waitcnt vmcnt(0) in
+  //       ov_signal_knn_done) the bytes are at the memory side, in no XCD's L2 as a dirty line;
+  //   (2) this launch holds none of those lines in its L1 / L2 when it reads them: it has not touched them before this point
+  //       (the code above reads only state words), no other kernel of this handle reads them between the pass's stores and
+  //       here, and the lines it did cache earlier belong to other buffers — the two passes' halves of corr_mask are padded to
+  //       different 128-byte lines (mask_stride), corr_idx / knn_part halves are multiples of 128 bytes apart;
+  //   (3) the launch may well have STARTED after some of the pass's stores (it follows k_rebuild_alloc in stream order): a kernel
+  //       start invalidates the caches, so that order is harmless; the order the argument needs is only (1) before the flag.
+  // A later edit that makes this launch read one of those buffers before this wait breaks (2) silently: don't.
   __syncthreads();
 }
 

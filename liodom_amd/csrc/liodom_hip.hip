@@ -808,7 +808,10 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   ALLOC(v.ov_flags, S, 0);
   ALLOC(v.pose_xch0, S * (size_t)kOvReplicas * 512, 0);
   ALLOC(v.knn_done, S * (size_t)v.knn_grid, 0);
-  ALLOC(v.corr_mask, S * 2 * (size_t)v.knn_blocks, 0);
+  // (the two passes' validity bytes never share a 128-byte line: the overlapped second pass writes its half while the finalising
+  //  solve's launch — which must not read it before ov_wait_knn_done — may hold the first pass's half in its caches)
+  v.mask_stride = round_up(v.knn_blocks, 128);
+  ALLOC(v.corr_mask, S * 2 * (size_t)v.mask_stride, 0);
   {
     void* hp = nullptr;
     if (hipHostMalloc(&hp, sizeof(HostOut) * 2 * S, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { g_last_error = "hipHostMalloc failed"; return fail(LIODOM_ERR_HIP); }
@@ -1737,6 +1740,8 @@ int liodom_debug_knn_times(liodom_handle_t* h, unsigned int* out, int* cap) {
 
 int liodom_get_modes(liodom_handle_t* h, char* buf, int cap) {
   if (!h || !buf || cap < 2) return LIODOM_ERR_INVALID_ARG;
+  if (int rc = enter(h)) return rc;
+  SideLocks lk(h, true, true);
   const DevView& v = h->v;
   snprintf(buf, (size_t)cap,
            "n_streams=%d early_rebuild=%d hash_build=%s pipe_flags=%d flag_gate=%d lm_groups=%d knn_instance=%d knn_queries=%d "

@@ -37,7 +37,10 @@ namespace liodom_dev {
 
 constexpr int kWave = 64;
 constexpr uint64_t kEmptyKey = 0xFFFFFFFFFFFFFFFFull;
-constexpr int kLmThreads = 512;           // k_lm_solve: 8 waves, two per SIMD, all evaluate residual blocks
+#ifndef LIODOM_LM_THREADS
+#define LIODOM_LM_THREADS 512
+#endif
+constexpr int kLmThreads = LIODOM_LM_THREADS;   // k_lm_solve: 8 waves, two per SIMD, all evaluate residual blocks
 constexpr int kLmEvalThreads = kLmThreads;
 constexpr int kLmCtl = kLmThreads - 64;   // lane 0 of the last wave also runs the trust-region logic; waves 0..6 prepare (compaction, register cache) meanwhile
 #ifndef LIODOM_LM_GROUPS_MAX
@@ -175,7 +178,8 @@ struct DevView {
   float4* filt_pts;         // [S][map_cap] centroid xyz + voxel-index bits
   float* filt_int;          // [S][map_cap] centroid intensity
   double* knn_part;         // [S][2][knn_blocks][32] per-k_knn-workgroup sums of the 29-entry normal-equation accumulator at the pose the pass searched with (= the solve's first evaluation)
-  unsigned char* corr_mask; // [S][2][knn_blocks] bit q: query q of that k_knn workgroup has an accepted correspondence
+  unsigned char* corr_mask; // [S][2][mask_stride] bit q: query q of that k_knn workgroup has an accepted correspondence
+  int mask_stride;          // knn_blocks rounded up to 128: the two passes' halves lie in different cache lines
   int knn_partials;         // k_knn also evaluates every accepted block at the solve's start pose and leaves per-workgroup sums (handles with < 16 streams)
   int knn_queries;          // queries per k_knn workgroup (8, or 4 for handles with >= 16 streams)
   unsigned int* cell_pad;   // [2 S][table_size] early_rebuild: room reserved in the cell for points of the new frame; after the allocation: end of the cell's range

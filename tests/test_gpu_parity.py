@@ -903,3 +903,14 @@ def test_sixteen_streams_headline_size_against_the_oracle(orc, synth):
                 assert ig.lm[it].termination == info_o.lm[it].termination, (k, d, it)
     gb.close()
     assert worst_t < 1e-6 and worst_r < 1e-6
+
+
+@pytest.mark.parametrize("shape,scans", [("hdl64", 600), ("vlp16", 900)])
+def test_overlapped_pass_long_replay_is_bit_identical(shape, scans):
+    """tools/overlap_equal.py: the same long replay with and without the overlapped second kNN pass (LIODOM_KNN_OVERLAP, read at
+    handle creation: one process per mode) gives bit-identical pose logs.  Guards the fence-free hand-offs of kernels_sync.h:
+    a stale line read by the finalising solve would show up here as a differing pose."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "overlap_equal.py"), shape, str(scans)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "bit-identical" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])

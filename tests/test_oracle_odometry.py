@@ -354,3 +354,23 @@ def test_match_edges_equals_the_odometers_own_loop(orc, synth):
             assert np.array_equal(v, v2) and np.array_equal(a, a2) and np.array_equal(b, b2)
             assert v.sum() > 10
     od.close()
+
+
+def test_parameter_tolerance_on_squares_vs_ceres_form():
+    """lm_update (liodom_math.h) tests the parameter tolerance on squares, step_sq <= ptol^2, where Ceres' TrustRegionMinimizer
+    tests sqrt(step_sq) <= ptol with ptol = 1e-8 (|x| + 1e-8).  The two decisions can differ only in a band of a few ulp around
+    the boundary: for step norms further than 4 ulp from ptol they agree, always."""
+    rng = np.random.default_rng(11)
+    x_norm = rng.uniform(0.5, 200.0, size=200000)
+    ptol = 1e-8 * (x_norm + 1e-8)
+    # step norms within +-64 ulp of the boundary, and a broad sample
+    k = rng.integers(-64, 65, size=x_norm.size)
+    step = ptol * (1.0 + k * np.finfo(np.float64).eps)
+    step_sq = step * step
+    lit = np.sqrt(step_sq) <= ptol
+    sq = step_sq <= ptol * ptol
+    differ = lit != sq
+    assert np.all(np.abs(k[differ]) <= 4), "decisions differ %d ulp from the boundary" % np.abs(k[differ]).max()
+    broad = ptol * rng.uniform(0.0, 3.0, size=x_norm.size)
+    far = np.abs(broad / ptol - 1.0) > 1e-12
+    assert np.array_equal((np.sqrt(broad * broad) <= ptol)[far], (broad * broad <= ptol * ptol)[far])
