@@ -110,6 +110,7 @@ struct liodom_handle {
   int pin_next = 0;
   bool safe_mode = false;            // no in-kernel waits at all: events between the streams, one workgroup per solve, three-kernel hash rebuild
   bool streams_concurrent = true;    // liodom_create's probe: kernels of two streams of this handle ran side by side
+  std::atomic<bool> ov_off_for_copies{false};  // the overlapped pass's stream carries the hand-off's uploads (LIODOM_COPY_STREAM=2)
   std::atomic<bool> pipe_active{false};        // scans went through the pipeline edge buffers by ticket since the last drain
   std::atomic<bool> fallback_pending{false};   // a kernel of this handle gave up an in-kernel wait (LIODOM_STATUS_PIPE_TIMEOUT): liodom_reset() switches to events
   int pf_slot = -1;                  // resident slot whose extraction has been issued ahead
@@ -263,7 +264,7 @@ int enqueue_odometry(liodom_handle* h, int eb, int s0, int count, unsigned int w
   // the kernel; it needs kernels of different streams to run side by side (as the flags of the pipelined replay do) and the
   // GPU mostly to itself: not while a second handle lives in this process (its waiting workgroups and ours could end up
   // behind each other in a shared hardware queue), not under per-kernel profiling.
-  const bool overlap_ok = early && h->ov_ok && h->use_flags && !h->profiling && !h->ov_suppress && count == 1 && g_live_handles.load() <= 1;
+  const bool overlap_ok = early && h->ov_ok && h->use_flags && !h->profiling && !h->ov_suppress && !h->ov_off_for_copies.load() && count == 1 && g_live_handles.load() <= 1;
   // The first scans of a handle are not overlapped: their launches are the first of every kernel of the chain on this queue
   // (scratch set-up, code upload), which can hold the odometry stream back for longer than a waiting kernel is willing to
   // poll.  At a switch to overlapped scans stream_k waits (event) for the odometry stream to have drained, so that its
@@ -1029,14 +1030,25 @@ static int ensure_pin_ring(liodom_handle* h) {
   // Measured (MI355X, HDL-64 shape, two C++ threads): 10.3k scans/s WITHOUT it, 7.5k with it, with GPU_MAX_HW_QUEUES=8 as well —
   // the same loss the host-fed replay saw with a fourth stream per handle (the two cross-stream event edges per scan cost more
   // than the overlap gains).  Off by default; kept for runtimes where a fourth stream is cheap.
-  bool want = false;
-  if (const char* e = std::getenv("LIODOM_COPY_STREAM")) want = std::atoi(e) != 0;
-  if (want && !h->profiling) {
+  // LIODOM_COPY_STREAM=2: the uploads take the stream of the overlapped second kNN pass (as the host-fed replay does), which is
+  // then not overlapped on this handle any more: three streams per handle, the upload beside the previous extraction.
+  int want = 0;
+  if (const char* e = std::getenv("LIODOM_COPY_STREAM")) want = std::atoi(e);
+  if (want != 0 && !h->profiling) {
     void* d = nullptr;
     HIP_TRY(hipMalloc(&d, sizeof(float4) * (size_t)kEdgePipeBufs * (size_t)h->v.max_points));
     h->stage_ring = static_cast<float4*>(d);
     h->allocs.push_back(d);
-    if (!h->stream_c) HIP_TRY(hipStreamCreateWithFlags(&h->stream_c, hipStreamNonBlocking));
+    if (!h->stream_c) {
+      if (want == 2 && h->stream_k) {
+        // (the odometry side may be enqueueing an overlapped pass right now: from here on it does not — ov_off_for_copies is read
+        //  by enqueue_odometry — and what is already in that stream simply runs ahead of the first copy)
+        h->ov_off_for_copies.store(true);
+        h->stream_c = h->stream_k; h->stream_c_shared = true;
+      } else {
+        HIP_TRY(hipStreamCreateWithFlags(&h->stream_c, hipStreamNonBlocking));
+      }
+    }
     for (int b = 0; b < kEdgePipeBufs; b++) {
       HIP_TRY(hipEventCreateWithFlags(&h->ev_sdone[b], hipEventDisableTiming));
       HIP_TRY(hipEventCreateWithFlags(&h->ev_cp[b], hipEventDisableTiming));
