@@ -957,6 +957,12 @@ __device__ __forceinline__ void knn_pass(const DevView& v, int s, int bxi, int b
 template <int kKnnThreads, bool kOv = false>
 __global__ __launch_bounds__(kKnnThreads, (kKnnThreads >= 256 ? 1 : LIODOM_TUNE_B_WAVES)) void k_knn(DevView v, int s0, int outer_it, int eb, unsigned int wait_edges, unsigned int signal_odo, unsigned int seq) {
   constexpr int kKnnQueries = kKnnThreads / kKnnGroup;
+#if defined(LIODOM_CHAIN_PRIO)
+  // Few-stream handles: this kernel is a link of the scan's dependent chain, the next scan's extraction kernels (other HIP stream)
+  // are not; where both have waves on one SIMD the issue arbiter goes by wave priority first (MI355X_MICROARCH.md, "two waves per
+  // SIMD").  The stream priority only orders dispatch.
+  if (kKnnThreads >= 256) __builtin_amdgcn_s_setprio(LIODOM_CHAIN_PRIO);
+#endif
   __shared__ KnnShared<kKnnQueries> shs[kOv ? 2 : 1];      // (overlapped pass: one per query block — their tails run side by side)
   KnnShared<kKnnQueries>& sh = shs[0];
   __shared__ double sh_ov[kOv ? 20 : 1];       // overlapped pass: the first solve's odom[12], q[4], t[3]

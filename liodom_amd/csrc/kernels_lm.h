@@ -364,6 +364,9 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
   __shared__ int sh_flag;
   __shared__ int sh_C;
   const int s = s0 + blockIdx.y;
+#if defined(LIODOM_CHAIN_PRIO)
+  if (v.n_streams <= 4) __builtin_amdgcn_s_setprio(LIODOM_CHAIN_PRIO);      // (see k_knn)
+#endif
   // G cooperating workgroups per stream, on block indices 0, 8, 16, ... when G > 1 (workgroups are handed to the XCDs
   // round-robin by linear index, so these share an XCD — see lm_exchange); every other block is a rebuild workgroup
   const int G = v.lm_groups, gstride = G > 1 ? 8 : 1, bxl = (int)blockIdx.x;

@@ -392,3 +392,35 @@ def test_second_process_saturating_the_gpu_never_gives_a_wrong_pose(hog):
     tail = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ""
     assert r.returncode == 0, (tail, r.stderr[-1500:])
     assert "bit-identical" in tail
+
+
+def test_device_handoff_in_safe_mode_uses_events(synth, monkeypatch):
+    """LIODOM_SAFE_MODE=1 (what liodom_reset() enters after a timeout): no in-kernel waits — the ticket path then orders the
+    odometry behind the extraction with events.  Same bits as liodom_process_scan on a safe-mode handle; agrees with the normal
+    mode to rounding (one workgroup per solve: the sums come in another order)."""
+    c = CONFIGS["cfg3_64x1800"]
+    H, W, K = c["H"], c["W"], 26
+    cfg = synth.make_cfg(H, W, 0)
+    scans = [synth.scan(cfg, 6, k)[0] for k in range(K)]
+    g = _handle(c)
+    normal = [g.process_scan(scans[k], H, W)[0] for k in range(K)]
+    g.close()
+    monkeypatch.setenv("LIODOM_SAFE_MODE", "1")
+    g = _handle(c)
+    m = g.modes()
+    assert m["safe_mode"] == "1" and m["pipe_flags"] == "0" and m["lm_groups"] == "1" and m["early_rebuild"] == "0" and m["knn_overlap"] == "0"
+    ref = [g.process_scan(scans[k], H, W)[0] for k in range(K)]
+    g.reset()
+    got = []
+    pending = []
+    for k in range(K):
+        t = g.extract_edges_device(scans[k], H, W)
+        assert t is not None
+        pending.append(t)
+        if len(pending) == 2:                       # the extractor one scan ahead of the odometer
+            got.append(g.odometry_step_device(pending.pop(0))[0])
+    got.append(g.odometry_step_device(pending.pop(0))[0])
+    g.close()
+    for k in range(K):
+        assert np.array_equal(got[k].view(np.uint64), ref[k].view(np.uint64)), k
+        assert np.max(np.abs(got[k] - normal[k])) < 1e-9, k
