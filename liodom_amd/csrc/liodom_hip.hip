@@ -596,14 +596,17 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   int prio_least = 0, prio_greatest = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
   const bool use_prio = std::getenv("LIODOM_NO_STREAM_PRIORITY") == nullptr && prio_least != prio_greatest;
-  if ((use_prio ? hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_greatest)
-                : hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) { g_last_error = "hipStreamCreate failed"; return fail(LIODOM_ERR_HIP); }
+  // (a CU split — hipExtStreamCreateWithCUMask: the extraction stream on 32 / 64 / 96 CUs, the chain's streams on the rest —
+  //  was measured: -0.1 / -1.5 / -2.7 %; the wave priority of the chain's kernels, LIODOM_CHAIN_PRIO, is what helps)
+  auto make_stream = [&](hipStream_t* st, int prio) {
+    return use_prio ? hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio) : hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+  };
+  if (make_stream(&h->stream, prio_greatest) != hipSuccess) { g_last_error = "hipStreamCreate failed"; return fail(LIODOM_ERR_HIP); }
   if (hipEventCreateWithFlags(&h->ev_ov, hipEventDisableTiming) != hipSuccess) { g_last_error = "hipEventCreate failed"; return fail(LIODOM_ERR_HIP); }
   if (hipEventCreateWithFlags(&h->pose_event, hipEventDisableTiming) != hipSuccess) { g_last_error = "hipEventCreate failed"; return fail(LIODOM_ERR_HIP); }
   // (extraction: one level below the odometry stream, not the lowest: kernels of the odometry stream may wait in-kernel for it)
   const int prio_x = (prio_least - prio_greatest >= 2) ? prio_greatest + 1 : prio_least;
-  if ((use_prio ? hipStreamCreateWithPriority(&h->stream_x, hipStreamNonBlocking, prio_x)
-                : hipStreamCreateWithFlags(&h->stream_x, hipStreamNonBlocking)) != hipSuccess) { g_last_error = "hipStreamCreate failed"; return fail(LIODOM_ERR_HIP); }
+  if (make_stream(&h->stream_x, prio_x) != hipSuccess) { g_last_error = "hipStreamCreate failed"; return fail(LIODOM_ERR_HIP); }
   for (int b = 0; b < kEdgePipeBufs; b++) {
     if (hipEventCreateWithFlags(&h->ev_edges[b], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_free[b], hipEventDisableTiming) != hipSuccess) { g_last_error = "hipEventCreate failed"; return fail(LIODOM_ERR_HIP); }
@@ -859,8 +862,7 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
     if (const char* e = std::getenv("LIODOM_KNN_OVERLAP")) { if (std::atoi(e) == 0) h->ov_ok = false; }
     // (the stream exists only on handles that use it: HIP multiplexes its streams onto a few hardware queues, and one more
     //  stream made the host-fed replay's copy stream share a queue — 11.3k -> 7.5k scans/s on every workload)
-    if (h->ov_ok && (use_prio ? hipStreamCreateWithPriority(&h->stream_k, hipStreamNonBlocking, prio_greatest)
-                              : hipStreamCreateWithFlags(&h->stream_k, hipStreamNonBlocking)) != hipSuccess) { g_last_error = "hipStreamCreate failed"; return fail(LIODOM_ERR_HIP); }
+    if (h->ov_ok && make_stream(&h->stream_k, prio_greatest) != hipSuccess) { g_last_error = "hipStreamCreate failed"; return fail(LIODOM_ERR_HIP); }
   }
   ALLOC(h->d_view, 1, 0);
   if (hipMemcpy(h->d_view, &h->v, sizeof(DevView), hipMemcpyHostToDevice) != hipSuccess) { g_last_error = "DevView upload failed"; return fail(LIODOM_ERR_HIP); }
