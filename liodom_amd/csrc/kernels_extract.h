@@ -19,8 +19,12 @@ constexpr int kTilePts = 2048;
 constexpr int kTileThreads = 512;
 constexpr int kTileChunks = kTilePts / 64;   // 32
 
+// copy_out (optional): `in` is HOST memory read over PCIe (page-locked, mapped: the scan is never uploaded by a copy call — this
+// kernel's coalesced loads are the upload) and every point is also written to copy_out[stream * copy_stride + i], the device
+// copy k_ring_scatter re-reads.
 __global__ __launch_bounds__(kTileThreads) void k_classify(DevView v, int s0, const float4* __restrict__ in,
-                                                           size_t in_stride, int n, int height, int width) {
+                                                           size_t in_stride, int n, int height, int width,
+                                                           float4* __restrict__ copy_out, size_t copy_stride) {
   __shared__ int hist[256];
   const int s = s0 + blockIdx.y;
   const int tile = blockIdx.x;
@@ -32,6 +36,13 @@ __global__ __launch_bounds__(kTileThreads) void k_classify(DevView v, int s0, co
   for (int j = 0; j < 4; j++) {
     const int i = tile * kTilePts + j * kTileThreads + threadIdx.x;
     if (i < n) p[j] = in[(size_t)blockIdx.y * in_stride + i];
+  }
+  if (copy_out) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int i = tile * kTilePts + j * kTileThreads + threadIdx.x;
+      if (i < n) copy_out[(size_t)blockIdx.y * copy_stride + i] = p[j];
+    }
   }
 #pragma unroll
   for (int j = 0; j < 4; j++) {

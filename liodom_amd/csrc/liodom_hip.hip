@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -108,6 +109,11 @@ struct liodom_handle {
   hipEvent_t ev_pin[kEdgePipeBufs] = {nullptr, nullptr, nullptr};     // the upload out of staging slot r has completed
   bool ev_pin_valid[kEdgePipeBufs] = {false, false, false};
   int pin_next = 0;
+  const float4* replay_host_dev = nullptr;   // host-fed replay in progress with zero-copy input: device-visible address of the caller's buffer ...
+  const float4* replay_host_base = nullptr;  // ... whose host address is this
+  bool zero_copy = false;            // LIODOM_ZERO_COPY=1: page-locked scans are read over PCIe by the extraction's first kernel instead of being
+                                     // uploaded by a copy call.  Measured slower (shader loads reach the host as 64-byte PCIe reads: two-thread
+                                     // binding 10.3k -> 9.0k scans/s, host-fed replay 11.5k -> 8.9k): off by default
   bool safe_mode = false;            // no in-kernel waits at all: events between the streams, one workgroup per solve, three-kernel hash rebuild
   bool streams_concurrent = true;    // liodom_create's probe: kernels of two streams of this handle ran side by side
   std::atomic<bool> ov_off_for_copies{false};  // the overlapped pass's stream carries the hand-off's uploads (LIODOM_COPY_STREAM=2)
@@ -191,18 +197,22 @@ inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // ---- launch sequences -----------------------------------------------------------------------
 // Feature extraction of `count` streams starting at s0; input scan for stream s0+i at in + i*stride.
+// host_in (optional, device-visible pointer to page-locked HOST memory, stride host_stride per stream): the scan is read from
+// there by the first kernel of the chain — no upload call — and `in` is the device buffer that kernel leaves a copy in.
 int launch_extract(liodom_handle* h, hipStream_t q, int eb, int s0, int count, const float4* in, size_t in_stride,
-                   int n, int height, int width, unsigned int wait_odo = 0, int mirror = 0) {
+                   int n, int height, int width, unsigned int wait_odo = 0, int mirror = 0,
+                   const float4* host_in = nullptr, size_t host_stride = 0) {
   const DevView& v = h->v;
   const int tiles = std::max(1, cdiv(n, kTilePts));
   if (v.lidar_type == 1 && width > 0 && (long long)h->H * width <= (long long)v.max_points) {
-    // organised cloud: ring = row, the split is a per-row compaction (no classify / scatter passes)
+    // organised cloud: ring = row, the split is a per-row compaction (no classify / scatter passes): one pass over the scan
     ProfScope ps(h, KID_RING_SCATTER, q);
-    hipLaunchKernelGGL(k_row_compact, dim3(h->H, count), dim3(kRowThreads), 0, q, v, s0, in, in_stride, n, height, width);
+    hipLaunchKernelGGL(k_row_compact, dim3(h->H, count), dim3(kRowThreads), 0, q, v, s0, host_in ? host_in : in, host_in ? host_stride : in_stride, n, height, width);
   } else {
     {
       ProfScope ps(h, KID_CLASSIFY, q);
-      hipLaunchKernelGGL(k_classify, dim3(tiles, count), dim3(kTileThreads), 0, q, v, s0, in, in_stride, n, height, width);
+      if (host_in) hipLaunchKernelGGL(k_classify, dim3(tiles, count), dim3(kTileThreads), 0, q, v, s0, host_in, host_stride, n, height, width, const_cast<float4*>(in), in_stride);
+      else hipLaunchKernelGGL(k_classify, dim3(tiles, count), dim3(kTileThreads), 0, q, v, s0, in, in_stride, n, height, width, (float4*)nullptr, (size_t)0);
     }
     {
       ProfScope ps(h, KID_RING_SCATTER, q);
@@ -449,7 +459,7 @@ int enqueue_pipeline_odometry(liodom_handle* h, int eb, unsigned int wait_seq) {
 }
 
 // Extraction of resident slot `slot` into edge buffer `eb` on the extraction stream.
-int issue_extract(liodom_handle* h, int slot, int eb, int n, int height, int width) {
+int issue_extract(liodom_handle* h, int slot, int eb, int n, int height, int width, const float4* host_dev = nullptr, size_t host_stride = 0) {
   // while per-kernel profiling is on, everything runs on one stream so that the HIP-event
   // durations are not inflated by kernels of the other stream sharing the GPU
   hipStream_t q = extract_queue(h);
@@ -457,7 +467,7 @@ int issue_extract(liodom_handle* h, int slot, int eb, int n, int height, int wid
   if (h->use_flags) {
     // dependencies through flags in device memory (pipe_wait / k_set_flag): the buffer's last reader must have
     // completed before k_compact_edges rewrites it; the flag of this extraction is set by a launch that follows it
-    int rc = launch_extract(h, q, eb, 0, h->S, in, (size_t)h->v.max_points, n, height, width, h->eb_reader[eb]);
+    int rc = launch_extract(h, q, eb, 0, h->S, in, (size_t)h->v.max_points, n, height, width, h->eb_reader[eb], 0, host_dev, host_stride);
     if (rc) return rc;
     h->eb_seq[eb] = ++h->ext_seq;
     if (h->ext_seq == 0) h->eb_seq[eb] = ++h->ext_seq;      // (0 means "nothing to wait for")
@@ -466,7 +476,7 @@ int issue_extract(liodom_handle* h, int slot, int eb, int n, int height, int wid
     return LIODOM_OK;
   }
   if (h->ev_free_valid[eb]) HIP_TRY(hipStreamWaitEvent(q, h->ev_free[eb], 0));
-  int rc = launch_extract(h, q, eb, 0, h->S, in, (size_t)h->v.max_points, n, height, width);
+  int rc = launch_extract(h, q, eb, 0, h->S, in, (size_t)h->v.max_points, n, height, width, 0u, 0, host_dev, host_stride);
   if (rc) return rc;
   HIP_TRY(hipEventRecord(h->ev_edges[eb], q));
   return LIODOM_OK;
@@ -680,6 +690,7 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   v.early_rebuild = (!h->lds_hash_build && !v.filter_local_map && !params->mapping && config->n_streams <= 4) ? 1 : 0;
   if (const char* e = std::getenv("LIODOM_EARLY_REBUILD")) { if (std::atoi(e) == 0) v.early_rebuild = 0; }
   if (const char* e = std::getenv("LIODOM_SAFE_MODE")) { if (std::atoi(e) != 0) enter_safe_mode(h); }
+  if (const char* e = std::getenv("LIODOM_ZERO_COPY")) h->zero_copy = std::atoi(e) != 0;
   v.recv_cap = v.mapping ? (config->recv_capacity > 0 ? config->recv_capacity : 262144) : 0;
   v.map_cap = v.edge_cap * h->P + v.recv_cap;
   int ts = 1024;
@@ -1092,6 +1103,8 @@ int liodom_extract_edges_device(liodom_handle_t* h, int stream, const float* xyz
   }
   hipStream_t q = extract_queue(h);
   float4* in = h->stage_in + (size_t)stream * h->v.max_points;
+  const float4* host_dev = nullptr;                  // device-visible address of the page-locked scan (zero-copy)
+  int pin_slot_used = -1;
   if (n) {
     // The scan's upload is asynchronous when it starts from page-locked memory: a slot of the handle's own ring
     // (liodom_scan_buffer), or a buffer the caller registered (liodom_pin_host_buffer) — which must stay untouched until
@@ -1112,8 +1125,18 @@ int liodom_extract_edges_device(liodom_handle_t* h, int stream, const float* xyz
       std::memcpy(h->pin_ring + (size_t)r * h->v.max_points, xyzi, sizeof(float4) * (size_t)n);
       xyzi = reinterpret_cast<const float*>(h->pin_ring + (size_t)r * h->v.max_points);
     }
+    // Zero-copy (LIODOM_ZERO_COPY=1; default is hipMemcpyAsync): the extraction's first kernel reads the page-locked scan over
+    // PCIe itself — no copy call, no second stream, no event.  Measured slower than the DMA upload (see zero_copy).
+    if (h->zero_copy && (reinterpret_cast<uintptr_t>(xyzi) & 15u) == 0) {
+      void* dp = nullptr;
+      if (hipHostGetDevicePointer(&dp, const_cast<float*>(xyzi), 0) == hipSuccess && dp) host_dev = static_cast<const float4*>(dp);
+      else (void)hipGetLastError();
+    }
     hipStream_t qc = q;
     int sr = -1;
+    if (host_dev) {
+      if (own || !pinned) { pin_slot_used = r; h->pin_next = (r + 1) % kEdgePipeBufs; }
+    } else
     if (h->tk_copy_stream && !h->profiling) {
       // device staging slot sr: free once the extraction that last read it has run (ev_sdone, recorded on the extraction stream)
       sr = h->stage_next;
@@ -1122,8 +1145,8 @@ int liodom_extract_edges_device(liodom_handle_t* h, int stream, const float* xyz
       in = h->stage_ring + (size_t)sr * h->v.max_points;
       if (h->ev_sdone_valid[sr]) HIP_TRY(hipStreamWaitEvent(qc, h->ev_sdone[sr], 0));
     }
-    HIP_TRY(hipMemcpyAsync(in, xyzi, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, qc));
-    if (own || !pinned) {                            // the page-locked ring slot may be refilled once this upload has left it
+    if (!host_dev) HIP_TRY(hipMemcpyAsync(in, xyzi, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, qc));
+    if (!host_dev && (own || !pinned)) {             // the page-locked ring slot may be refilled once this upload has left it
       HIP_TRY(hipEventRecord(h->ev_pin[r], qc));
       h->ev_pin_valid[r] = true;
       h->pin_next = (r + 1) % kEdgePipeBufs;
@@ -1133,23 +1156,27 @@ int liodom_extract_edges_device(liodom_handle_t* h, int stream, const float* xyz
       HIP_TRY(hipStreamWaitEvent(q, h->ev_cp[sr], 0));
     }
   }
-  const bool staged_on_ring = n > 0 && h->tk_copy_stream && !h->profiling;
+  const bool staged_on_ring = n > 0 && !host_dev && h->tk_copy_stream && !h->profiling;
   unsigned int seq = ++h->ext_seq;
   if (seq == 0u) seq = ++h->ext_seq;                 // (0 means "nothing to wait for")
   unsigned int* host_seq = h->v.host_edges_hdr ? h->v.host_edges_hdr + eb : nullptr;
   // (the slot is free: the odometry that last read buffer eb has been collected, i.e. has completed — no wait on the device,
   //  which would depend on when the other thread submits its next scan)
   if (h->use_flags) {
-    rc = launch_extract(h, q, eb, stream, 1, in, 0, (int)n, height, width, 0u, 1);
+    rc = launch_extract(h, q, eb, stream, 1, in, 0, (int)n, height, width, 0u, 1, host_dev, 0);
     if (rc) return rc;
     hipLaunchKernelGGL(k_publish_edges, dim3(1), dim3(1), 0, q, h->v.pipe_flags + eb, host_seq, seq);
   } else {
-    rc = launch_extract(h, q, eb, stream, 1, in, 0, (int)n, height, width, 0u, 1);
+    rc = launch_extract(h, q, eb, stream, 1, in, 0, (int)n, height, width, 0u, 1, host_dev, 0);
     if (rc) return rc;
     hipLaunchKernelGGL(k_publish_edges, dim3(1), dim3(1), 0, q, (unsigned int*)nullptr, host_seq, seq);
     HIP_TRY(hipEventRecord(h->ev_edges[eb], q));
   }
   HIP_TRY(hipGetLastError());
+  if (pin_slot_used >= 0) {                          // (zero-copy) the ring slot may be refilled once the extraction's first kernel has read it
+    HIP_TRY(hipEventRecord(h->ev_pin[pin_slot_used], q));
+    h->ev_pin_valid[pin_slot_used] = true;
+  }
   if (staged_on_ring) {
     const int sr = (h->stage_next + kEdgePipeBufs - 1) % kEdgePipeBufs;
     HIP_TRY(hipEventRecord(h->ev_sdone[sr], q));
@@ -1476,10 +1503,19 @@ static int replay_one(liodom_handle_t* h, int slot, int next_slot, int64_t n, in
   if (rc) return rc;
   h->parity = (eb + 1) % kEdgePipeBufs;
   if (next_slot >= 0) {                           // overlap the next scan's (upload and) extraction with this odometry
-    if (next_host) { rc = upload_slot_async(h, next_slot, next_host, host_stride, n); if (rc) return rc; }
-    rc = issue_extract(h, next_slot, h->parity, (int)n, height, width);
+    if (next_host && !h->replay_host_dev) { rc = upload_slot_async(h, next_slot, next_host, host_stride, n); if (rc) return rc; }
+    // (a gate in front of the next scan's extraction — start it when this scan's first solve starts, so that it runs beside the
+    //  solves instead of beside the first kNN pass — was measured: -1.6 %; removed)
+    if (next_host && h->replay_host_dev) {
+      // zero-copy: the extraction's first kernel reads the page-locked scan itself (device-visible address of next_host) and
+      // leaves its device copy in the resident slot; no upload, no copy stream, no events
+      const float4* hd = h->replay_host_dev + (reinterpret_cast<const float4*>(next_host) - h->replay_host_base);
+      rc = issue_extract(h, next_slot, h->parity, (int)n, height, width, hd, (size_t)host_stride / 4);
+    } else {
+      rc = issue_extract(h, next_slot, h->parity, (int)n, height, width);
+    }
     if (rc) return rc;
-    if (next_host) { rc = upload_slot_consumed(h, next_slot); if (rc) return rc; }
+    if (next_host && !h->replay_host_dev) { rc = upload_slot_consumed(h, next_slot); if (rc) return rc; }
     h->pf_slot = next_slot;
   }
   if (wait) return wait_pose(h, 0, h->S, poses_out, infos_out);
@@ -1502,21 +1538,39 @@ int liodom_replay_host(liodom_handle_t* h, const float* xyzi_base, int64_t scan_
   // Measured (MI355X, HDL-64 shape): with uploads the loop is bound by the host's enqueue work (an upload, three event
   // operations, six extraction and five odometry launches per scan: 88 us); the overlapped second kNN pass adds a gate and an
   // ALLOC launch on a third stream and made it 133 us.  So not here.
-  struct Suppress { liodom_handle* h; ~Suppress() { h->ov_suppress = false; } } suppress{h};
+  struct Suppress { liodom_handle* h; ~Suppress() { h->ov_suppress = false; h->replay_host_dev = nullptr; h->replay_host_base = nullptr; } } suppress{h};
   h->ov_suppress = true;
+  if (h->zero_copy && count > 0 && n > 0 && scan_stride_floats % 4 == 0 && (reinterpret_cast<uintptr_t>(xyzi_base) & 15u) == 0) {
+    // page-locked AND mapped (liodom_pin_host_buffer, hipHostMalloc): the extraction reads the scans in place — the loop then
+    // enqueues no upload and no event, and the overlapped second kNN pass stays on (its stream is not needed for copies)
+    void* dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, const_cast<float*>(xyzi_base), 0) == hipSuccess && dp) {
+      h->replay_host_dev = static_cast<const float4*>(dp);
+      h->replay_host_base = reinterpret_cast<const float4*>(xyzi_base);
+      h->ov_suppress = false;
+    } else {
+      (void)hipGetLastError();
+    }
+  }
   auto out_p = [&](int i) { return poses_out ? poses_out + (size_t)i * h->S * 7 : nullptr; };
   auto out_i = [&](int i) { return infos_out ? infos_out + (size_t)i * h->S : nullptr; };
   auto src = [&](int i) { return xyzi_base + (size_t)i * (size_t)h->S * (size_t)scan_stride_floats; };
   for (int i = 0; i < count; i++) {
     const int slot = i % kRing, next = (i + 1 < count) ? (i + 1) % kRing : -1;
     if (i == 0) {                                 // first scan: upload + extraction now
-      rc = upload_slot_async(h, slot, src(0), scan_stride_floats, n);
-      if (rc) return rc;
-      rc = issue_extract(h, slot, h->parity, (int)n, height, width);
-      if (rc) return rc;
-      h->pf_slot = slot;
-      rc = upload_slot_consumed(h, slot);
-      if (rc) return rc;
+      if (h->replay_host_dev) {
+        rc = issue_extract(h, slot, h->parity, (int)n, height, width, h->replay_host_dev, (size_t)scan_stride_floats / 4);
+        if (rc) return rc;
+        h->pf_slot = slot;
+      } else {
+        rc = upload_slot_async(h, slot, src(0), scan_stride_floats, n);
+        if (rc) return rc;
+        rc = issue_extract(h, slot, h->parity, (int)n, height, width);
+        if (rc) return rc;
+        h->pf_slot = slot;
+        rc = upload_slot_consumed(h, slot);
+        if (rc) return rc;
+      }
     }
     const float* nh = next >= 0 ? src(i + 1) : nullptr;
     if (depth == 0) {
