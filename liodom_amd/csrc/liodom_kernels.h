@@ -145,6 +145,7 @@ struct DevView {
   float4* edges_pad;        // [S][H][slots_per_ring]
   int2* edges_pad_meta;     // (idx_in_ring, src)
   int* ring_nedges;         // [S][H]
+  unsigned int* ring_done;  // [S + 1] fused extraction tail: ring workgroups that have finished per stream, streams compacted (monotonic)
   int* ring_npoints;        // [S][H]
   double* ring_c;           // [S][max_points] smoothness per ring-sorted point: debug dump (debug & 1) and generic-path scratch
   unsigned char* ring_picked;  // [S][max_points] picked_ marks of the generic path
