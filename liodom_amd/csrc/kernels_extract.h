@@ -19,6 +19,47 @@ constexpr int kTilePts = 2048;
 constexpr int kTileThreads = 512;
 constexpr int kTileChunks = kTilePts / 64;   // 32
 
+// isValidPoint + ring id of one point (feature_extractor.cc:84-102,115-175); 0xFF: dropped.
+__device__ __forceinline__ unsigned char classify_point(const DevView& v, const float4& pt, int i, int H, int height, int width) {
+  // Fast decision in float for the points that are nowhere near a decision boundary (99.9 %): the FP64 sqrt + atan
+  // of the reference's expressions (~350 instructions per point) made this kernel FP64-bound, not bandwidth-bound.
+  // The float range / elevation angle are within 1e-4 relative / 1e-5 degrees of the double values, so a point whose
+  // float range is further than 1e-4 (relative) from both range limits and whose ring is the same at angle -+ 1e-4
+  // degrees gets exactly the reference's verdict; every other point takes the reference's FP64 expressions below.
+  bool sure = false;
+  int r_fast = -1;
+  if (v.lidar_type == 0) {
+    const float px = pt.x, py = pt.y, pz = pt.z;
+    const bool fin = (px - px) == 0.f && (py - py) == 0.f && (pz - pz) == 0.f;
+    if (!fin) {
+      sure = true;                                   // isValidPoint: not finite (:89-92)
+    } else {
+      const float df = sqrtf(px * px + py * py);
+      const float lo = (float)v.min_range, hi = (float)v.max_range;
+      const bool range_sure = fabsf(df - lo) > 1e-4f * lo + 1e-6f && fabsf(df - hi) > 1e-4f * hi + 1e-6f && df < 1e18f;
+      if (range_sure && (df < lo || df > hi)) {
+        sure = true;                                 // out of range (:96-97)
+      } else if (range_sure) {
+        const float a = atanf(pz / df) * 57.29577951308232f;
+        const int r0 = velodyne_ring_from_angle((double)(a - 1e-4f), H), r1 = velodyne_ring_from_angle((double)(a + 1e-4f), H);
+        sure = r0 == r1;
+        r_fast = r0;
+      }
+    }
+  }
+  double dist;
+  if (sure) return r_fast >= 0 ? (unsigned char)r_fast : (unsigned char)0xFF;
+  if (!valid_point((double)pt.x, (double)pt.y, (double)pt.z, v.min_range, v.max_range, &dist)) return 0xFF;
+  int r;
+  if (v.lidar_type == 0) {
+    r = velodyne_ring((double)pt.z, dist, H);
+  } else {
+    r = (width > 0) ? i / width : -1;     // ring = row (feature_extractor.cc:160-173)
+    if (r >= H || r >= height) r = -1;
+  }
+  return r >= 0 ? (unsigned char)r : (unsigned char)0xFF;
+}
+
 // copy_out (optional): `in` is HOST memory read over PCIe (page-locked, mapped: the scan is never uploaded by a copy call — this
 // kernel's coalesced loads are the upload) and every point is also written to copy_out[stream * copy_stride + i], the device
 // copy k_ring_scatter re-reads.
@@ -47,47 +88,9 @@ __global__ __launch_bounds__(kTileThreads) void k_classify(DevView v, int s0, co
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const int i = tile * kTilePts + j * kTileThreads + threadIdx.x;
-    unsigned char id = 0xFF;
     if (i < n) {
-      // Fast decision in float for the points that are nowhere near a decision boundary (99.9 %): the FP64 sqrt + atan
-      // of the reference's expressions (~350 instructions per point) made this kernel FP64-bound, not bandwidth-bound.
-      // The float range / elevation angle are within 1e-4 relative / 1e-5 degrees of the double values, so a point whose
-      // float range is further than 1e-4 (relative) from both range limits and whose ring is the same at angle -+ 1e-4
-      // degrees gets exactly the reference's verdict; every other point takes the reference's FP64 expressions below.
-      bool sure = false;
-      int r_fast = -1;
-      if (v.lidar_type == 0) {
-        const float px = p[j].x, py = p[j].y, pz = p[j].z;
-        const bool fin = (px - px) == 0.f && (py - py) == 0.f && (pz - pz) == 0.f;
-        if (!fin) {
-          sure = true;                                   // isValidPoint: not finite (:89-92)
-        } else {
-          const float df = sqrtf(px * px + py * py);
-          const float lo = (float)v.min_range, hi = (float)v.max_range;
-          const bool range_sure = fabsf(df - lo) > 1e-4f * lo + 1e-6f && fabsf(df - hi) > 1e-4f * hi + 1e-6f && df < 1e18f;
-          if (range_sure && (df < lo || df > hi)) {
-            sure = true;                                 // out of range (:96-97)
-          } else if (range_sure) {
-            const float a = atanf(pz / df) * 57.29577951308232f;
-            const int r0 = velodyne_ring_from_angle((double)(a - 1e-4f), H), r1 = velodyne_ring_from_angle((double)(a + 1e-4f), H);
-            sure = r0 == r1;
-            r_fast = r0;
-          }
-        }
-      }
-      double dist;
-      if (sure) {
-        if (r_fast >= 0) { id = (unsigned char)r_fast; atomicAdd(&hist[r_fast], 1); }
-      } else if (valid_point((double)p[j].x, (double)p[j].y, (double)p[j].z, v.min_range, v.max_range, &dist)) {
-        int r;
-        if (v.lidar_type == 0) {
-          r = velodyne_ring((double)p[j].z, dist, H);
-        } else {
-          r = (width > 0) ? i / width : -1;     // ring = row (feature_extractor.cc:160-173)
-          if (r >= H || r >= height) r = -1;
-        }
-        if (r >= 0) { id = (unsigned char)r; atomicAdd(&hist[r], 1); }
-      }
+      const unsigned char id = classify_point(v, p[j], i, H, height, width);
+      if (id != 0xFF) atomicAdd(&hist[id], 1);
       v.ring_id[(size_t)s * v.ring_id_stride + i] = id;
     }
   }
@@ -218,6 +221,179 @@ __global__ __launch_bounds__(kTileThreads) void k_ring_scatter(DevView v, int s0
     const int d = sdst[stage_swz4(p)];
     out[d] = spts[stage_swz16(p)];
     osrc[d] = ssrc[stage_swz4(p)];
+  }
+}
+
+// =============================================================================================
+// k_ring_split (handles of a few streams): k_classify and k_ring_scatter in ONE pass over the scan — the points stay in
+// registers between the two, the scan is read once, the id bytes are never written, one launch less on the extraction stream.
+// The scatter needs the ring histograms of ALL tiles of its stream (ring starts = totals over every tile), so a workgroup
+// publishes its histogram (write-through stores), counts itself on its stream and waits inside the kernel until the stream's
+// other tiles have done the same; then it reads the table at agent scope.  Every workgroup of the launch must be resident at
+// once for that: the host uses this kernel only when tiles x streams <= 256 (one workgroup per CU always fits: 50 KB of LDS),
+// i.e. up to four HDL-64 streams per launch.  Arrivals are counted in split_ctr[2 s + 1]; the k_ring_extract launch that
+// follows every split in stream order zeroes them.
+// On lock-step batches the same kernel (workgroups taking their tile from a ticket counter in start order, so that waiting
+// workgroups never depend on one that has not started) was measured 3x SLOWER than the two launches — 1 270 us against
+// 135 + 305 us per 256-stream step: a waiting workgroup holds its 50 KB of LDS, three per CU, and the tiles of a stream are
+// spread over eight XCDs that advance at their own pace — so batches keep k_classify + k_ring_scatter.
+// =============================================================================================
+__global__ __launch_bounds__(kTileThreads) void k_ring_split(DevView v, int s0, const float4* __restrict__ in,
+                                                             size_t in_stride, int n, int height, int width) {
+  typedef __attribute__((address_space(1))) unsigned int gu32;
+  typedef __attribute__((address_space(1))) unsigned short gu16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ int hist[256];
+  __shared__ int sh_ok;
+  const int ntiles = gridDim.x;
+  const int H = v.scan_lines;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < 256) hist[tid] = 0;
+  __syncthreads();
+  const int sy = blockIdx.y, tile = blockIdx.x;
+  const int s = s0 + sy;
+  const int Hp = ring_scatter_stride(H);
+  unsigned long long* wmask = reinterpret_cast<unsigned long long*>(smem);          // [32][Hp]   (phase A)
+  unsigned short* cbase = reinterpret_cast<unsigned short*>(wmask + kTileChunks * Hp);  // [32][Hp]   (phase A)
+  float4* spts = reinterpret_cast<float4*>(smem);                                   // [2048]     (phase B, same bytes)
+  int* sdst = reinterpret_cast<int*>(smem + (size_t)kTilePts * 16);                 // [2048]
+  int* ssrc = sdst + kTilePts;                                                      // [2048]
+  int* rbase = reinterpret_cast<int*>(smem + ring_scatter_stage_bytes(H));          // [H] ring start + tile prefix
+  int* lofs = rbase + H;                                                            // [H] first staging slot of the ring
+  int* wtot = lofs + H;                                                             // [8] ring totals per wave
+  int* wloc = wtot + 16;                                                            // [8] this tile's counts per wave
+  for (int k = tid; k < kTileChunks * Hp; k += kTileThreads) wmask[k] = 0ull;
+  // ---- classify (k_classify) ----
+  float4 p[4];
+  int id[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int i = tile * kTilePts + j * kTileThreads + tid;
+    if (i < n) p[j] = in[(size_t)sy * in_stride + i];
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int i = tile * kTilePts + j * kTileThreads + tid;
+    id[j] = 0xFF;
+    if (i < n) {
+      id[j] = (int)classify_point(v, p[j], i, H, height, width);
+      if (id[j] != 0xFF) atomicAdd(&hist[id[j]], 1);
+    }
+  }
+  __syncthreads();
+  // split_hist[s][ring][tile] (row = v.split_pad tiles, a multiple of 8: a ring's row is read back as 16-byte words)
+  unsigned short* th_all = v.split_hist + (size_t)s * H * v.split_pad;
+  if (tid < H) __hip_atomic_store((gu16*)(th_all + (size_t)tid * v.split_pad + tile), (unsigned short)hist[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // lane masks per (chunk, ring) meanwhile (k_ring_scatter, phase A)
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+    if (id[j] != 0xFF) atomicOr(&wmask[(j * (kTileThreads / 64) + wave) * Hp + id[j]], 1ull << lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    // arrive; then wait for the stream's other tiles
+    atomicAdd(&v.split_ctr[2 * s + 1], 1u);
+    unsigned int spins = 0;
+    bool ok = true;
+    while (__hip_atomic_load((gu32*)(v.split_ctr + 2 * s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)ntiles) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > 4000000u) { ok = false; break; }
+    }
+    if (!ok) atomicOr(&v.state[s].status, LIODOM_STATUS_PIPE_TIMEOUT);
+    sh_ok = ok ? 1 : 0;
+  }
+  // prefix over the 32 chunks for every ring: one half-wave per ring (needs only this tile's masks)
+  for (int r = wave * 2 + (lane >> 5); r < H; r += 2 * (kTileThreads / 64)) {
+    const int c = lane & 31;
+    const int cnt = __popcll(wmask[c * Hp + r]);
+    const int ic = half_incl_scan_i32(cnt);
+    cbase[c * Hp + r] = (unsigned short)(ic - cnt);
+  }
+  __syncthreads();
+  if (!sh_ok) return;
+  // row prefix / totals of the histogram table for "my" ring (thread r < H): 16-byte loads that bypass the non-coherent cache
+  // levels (sc1: the other tiles' workgroups ran on other XCDs), up to eight in flight, one wait per batch
+  int pre = 0, tot = 0;
+  const int mine = tid < H ? hist[tid] : 0;
+  if (tid < H) {
+    const unsigned short* row = th_all + (size_t)tid * v.split_pad;
+    for (int t0 = 0; t0 < ntiles; t0 += 64) {
+      // (one asm statement: issued as separate statements the compiler moved the destination registers before the wait.  All
+      //  eight words are loaded whatever ntiles is — the table is padded by one batch — and masked below.)
+      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+      u32x4 w[8];
+      asm volatile(
+          "global_load_dwordx4 %0, %8, off sc1\n\t"
+          "global_load_dwordx4 %1, %8, off offset:16 sc1\n\t"
+          "global_load_dwordx4 %2, %8, off offset:32 sc1\n\t"
+          "global_load_dwordx4 %3, %8, off offset:48 sc1\n\t"
+          "global_load_dwordx4 %4, %8, off offset:64 sc1\n\t"
+          "global_load_dwordx4 %5, %8, off offset:80 sc1\n\t"
+          "global_load_dwordx4 %6, %8, off offset:96 sc1\n\t"
+          "global_load_dwordx4 %7, %8, off offset:112 sc1\n\t"
+          "s_waitcnt vmcnt(0)"
+          : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]), "=&v"(w[6]), "=&v"(w[7])
+          : "v"(row + t0)
+          : "memory");
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const unsigned int ww[4] = {w[u].x, w[u].y, w[u].z, w[u].w};
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const int t = t0 + 8 * u + k;
+          const int c = (t < ntiles) ? (int)((ww[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu) : 0;
+          tot += c;
+          if (t < tile) pre += c;
+        }
+      }
+    }
+  }
+  const int incl = wave_incl_scan_i32(tot);
+  const int incl_l = wave_incl_scan_i32(mine);
+  if (lane == 63) { wtot[wave] = incl; wloc[wave] = incl_l; }
+  __syncthreads();
+  {
+    int base = 0, base_l = 0;
+    for (int w = 0; w < wave; w++) { base += wtot[w]; base_l += wloc[w]; }
+    const int rstart = base + incl - tot;
+    if (tid < H) {
+      rbase[tid] = rstart + pre;
+      lofs[tid] = base_l + incl_l - mine;
+      if (tile == 0) { v.ring_start[(size_t)s * (H + 1) + tid] = rstart; v.ring_len[(size_t)s * H + tid] = tot; }
+    }
+    if (tile == 0 && tid == H - 1) v.ring_start[(size_t)s * (H + 1) + H] = rstart + tot;
+  }
+  __syncthreads();
+  const unsigned long long below = (1ull << lane) - 1ull;
+  int slot[4], dst[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    slot[j] = -1; dst[j] = 0;
+    if (id[j] != 0xFF) {
+      const int chunk = j * (kTileThreads / 64) + wave;
+      const int rank = (int)cbase[chunk * Hp + id[j]] + __popcll(wmask[chunk * Hp + id[j]] & below);
+      slot[j] = lofs[id[j]] + rank;
+      dst[j] = rbase[id[j]] + rank;
+    }
+  }
+  __syncthreads();                  // masks / prefixes are dead: their bytes become the staging tile
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    if (slot[j] >= 0) {
+      const int i = tile * kTilePts + j * kTileThreads + tid;
+      spts[stage_swz16(slot[j])] = p[j];
+      sdst[stage_swz4(slot[j])] = dst[j];
+      ssrc[stage_swz4(slot[j])] = i;
+    }
+  }
+  __syncthreads();
+  float4* out = v.ring_pts + (size_t)s * v.max_points;
+  int* osrc = v.ring_src + (size_t)s * v.max_points;
+  const int nvalid = wloc[0] + wloc[1] + wloc[2] + wloc[3] + wloc[4] + wloc[5] + wloc[6] + wloc[7];
+  for (int q = tid; q < nvalid; q += kTileThreads) {
+    const int d = sdst[stage_swz4(q)];
+    out[d] = spts[stage_swz16(q)];
+    osrc[d] = ssrc[stage_swz4(q)];
   }
 }
 
@@ -739,6 +915,9 @@ __device__ __forceinline__ void ring_extract_ring(const DevView& v, int s, int r
 template <int kMaxThreads, int IPL>
 __global__ __launch_bounds__(kMaxThreads) void k_ring_extract(DevView v, int s0, ExtractTail tail) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (v.split_ctr && blockIdx.x == 0 && threadIdx.x == 0) {      // (k_ring_split's counters, for the next scan)
+    v.split_ctr[2 * (s0 + (int)blockIdx.y) + 1] = 0u;
+  }
   ring_extract_ring<IPL>(v, s0 + (int)blockIdx.y, (int)blockIdx.x, smem);
   if (tail.eb >= 0) ring_extract_tail(v, s0, tail);
 }

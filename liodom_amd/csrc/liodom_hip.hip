@@ -115,6 +115,7 @@ struct liodom_handle {
                                      // uploaded by a copy call.  Measured slower (shader loads reach the host as 64-byte PCIe reads: two-thread
                                      // binding 10.3k -> 9.0k scans/s, host-fed replay 11.5k -> 8.9k): off by default
   bool safe_mode = false;            // no in-kernel waits at all: events between the streams, one workgroup per solve, three-kernel hash rebuild
+  bool ring_split = true;            // ring split in one pass (k_ring_split) where a launch has at most 256 workgroups; LIODOM_RING_SPLIT=0: always k_classify + k_ring_scatter
   bool fuse_tail = false;            // few-stream handles: k_ring_extract's last workgroups compact and publish (no k_compact_edges / flag launches); LIODOM_FUSE_TAIL=0: off
   bool streams_concurrent = true;    // liodom_create's probe: kernels of two streams of this handle ran side by side
   std::atomic<bool> ov_off_for_copies{false};  // the overlapped pass's stream carries the hand-off's uploads (LIODOM_COPY_STREAM=2)
@@ -224,6 +225,11 @@ int launch_extract(liodom_handle* h, hipStream_t q, int eb, int s0, int count, c
     ProfScope ps(h, KID_RING_SCATTER, q);
     hipLaunchKernelGGL(k_row_compact, dim3(h->H, count), dim3(kRowThreads), 0, q, v, s0, host_in ? host_in : in, host_in ? host_stride : in_stride, n, height, width);
   } else {
+    if (h->ring_split && !host_in && (long long)tiles * count <= 256) {      // (every workgroup resident at once: k_ring_split waits inside the launch)
+      // one pass: classification and scatter in one kernel (booked as the scatter)
+      ProfScope ps(h, KID_RING_SCATTER, q);
+      hipLaunchKernelGGL(k_ring_split, dim3(tiles, count), dim3(kTileThreads), ring_scatter_lds_bytes(h->H), q, v, s0, in, in_stride, n, height, width);
+    } else {
     {
       ProfScope ps(h, KID_CLASSIFY, q);
       if (host_in) hipLaunchKernelGGL(k_classify, dim3(tiles, count), dim3(kTileThreads), 0, q, v, s0, host_in, host_stride, n, height, width, const_cast<float4*>(in), in_stride);
@@ -232,6 +238,7 @@ int launch_extract(liodom_handle* h, hipStream_t q, int eb, int s0, int count, c
     {
       ProfScope ps(h, KID_RING_SCATTER, q);
       hipLaunchKernelGGL(k_ring_scatter, dim3(tiles, count), dim3(kTileThreads), ring_scatter_lds_bytes(h->H), q, v, s0, in, in_stride, n);
+    }
     }
   }
   {
@@ -743,6 +750,10 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
     if (const char* e = std::getenv("LIODOM_FUSE_TAIL")) { if (std::atoi(e) == 0) h->fuse_tail = false; }
     v.ring_done = nullptr;
     if (h->fuse_tail) ALLOC(v.ring_done, S + 1, 0);
+    if (const char* e = std::getenv("LIODOM_RING_SPLIT")) h->ring_split = std::atoi(e) != 0;
+    v.split_ctr = nullptr;
+    v.split_hist = nullptr; v.split_pad = round_up(v.tile_cap, 8);
+    if (h->ring_split) { ALLOC(v.split_ctr, 2 * S, 0); ALLOC(v.split_hist, S * (size_t)h->H * v.split_pad + 64, 0); }      // (+ one batch of 64 tiles: k_ring_split reads whole batches)
   }
   ALLOC(v.ring_npoints, S * h->H, 0);
   ALLOC(v.ring_c, S * (size_t)config->max_points, 0);
@@ -1836,12 +1847,12 @@ int liodom_get_modes(liodom_handle_t* h, char* buf, int cap) {
   snprintf(buf, (size_t)cap,
            "n_streams=%d early_rebuild=%d hash_build=%s pipe_flags=%d flag_gate=%d lm_groups=%d knn_instance=%d knn_queries=%d "
            "knn_grid=%d/%d knn_partials=%d knn_saved_bound=%d knn_exact_only=%d line_gate_kernel=%d filter_local_map=%d mapping=%d "
-           "rotation_mode=%d table_size=%d rebuild_delta=%.3f knn_overlap=%d streams_concurrent=%d safe_mode=%d fused_extract_tail=%d debug=%d",
+           "rotation_mode=%d table_size=%d rebuild_delta=%.3f knn_overlap=%d streams_concurrent=%d safe_mode=%d fused_extract_tail=%d ring_split=%d debug=%d",
            h->S, v.early_rebuild, v.early_rebuild ? "streamed" : (h->lds_hash_build ? "lds" : "global"), h->use_flags ? 1 : 0,
            (h->use_flags && h->flag_gate) ? 1 : 0, v.lm_groups, h->S >= 16 ? 128 : 256, v.knn_queries, v.knn_grid,
            v.knn_blocks, v.knn_partials, v.knn_save_pos ? 2 : (v.knn_save_q ? 1 : 0), v.knn_exact_only, v.knn_nn ? 1 : 0, v.filter_local_map, v.mapping,
            v.rotation_mode, v.table_size, (double)v.rebuild_delta,
-           (v.early_rebuild && h->ov_ok && h->use_flags && g_live_handles.load() <= 1) ? 1 : 0, h->streams_concurrent ? 1 : 0, h->safe_mode ? 1 : 0, h->fuse_tail ? 1 : 0, v.debug);
+           (v.early_rebuild && h->ov_ok && h->use_flags && g_live_handles.load() <= 1) ? 1 : 0, h->streams_concurrent ? 1 : 0, h->safe_mode ? 1 : 0, h->fuse_tail ? 1 : 0, h->ring_split ? 1 : 0, v.debug);
   return LIODOM_OK;
 }
 
