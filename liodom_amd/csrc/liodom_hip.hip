@@ -905,7 +905,7 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, config->device);
     // (measured with half of the slots allowed: Ouster-128, 704 workgroups = 2 816 waves, loses — 9.0k -> 8.4k scans/s)
     h->ov_ok = v.early_rebuild && S == 1 && v.knn_partials && (long long)v.knn_grid * 4 * 3 <= (long long)cus * 24;
-    if (const char* e = std::getenv("LIODOM_KNN_OVERLAP")) { if (std::atoi(e) == 0) h->ov_ok = false; }
+    if (const char* e = std::getenv("LIODOM_KNN_OVERLAP")) { if (std::atoi(e) == 0) h->ov_ok = false; if (std::atoi(e) == 2) h->ov_ok = v.early_rebuild && S == 1 && v.knn_partials; }      // (2: also where the pass takes more than a third of the wave slots)
     // (the stream exists only on handles that use it: HIP multiplexes its streams onto a few hardware queues, and one more
     //  stream made the host-fed replay's copy stream share a queue — 11.3k -> 7.5k scans/s on every workload)
     if (h->ov_ok && make_stream(&h->stream_k, prio_greatest) != hipSuccess) { g_last_error = "hipStreamCreate failed"; return fail(LIODOM_ERR_HIP); }
