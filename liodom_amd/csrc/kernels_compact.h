@@ -53,66 +53,6 @@ __global__ __launch_bounds__(256) void k_compact_edges(DevView v, int s0, int eb
   }
 }
 
-// Fused tail of k_ring_extract (ExtractTail, kernels_extract.h).  Every workgroup of the launch, its ring's edges written:
-// release, count itself on its stream; the one that completes the stream's H arrivals acquires, compacts the stream with its
-// own threads (same output as k_compact_edges: positions are a function of the ring counts only), releases, counts the stream;
-// the one that completes the launch's streams publishes.  Counters are monotonic (every launch adds exactly H per stream and
-// one per stream): nothing to reset between scans.
-__device__ void ring_extract_tail(const DevView& v, int s0, const ExtractTail& tail) {
-  typedef __attribute__((address_space(1))) unsigned int gu32;
-  __shared__ int t_last, t_E;
-  __shared__ int t_pre[257];
-  const int s = s0 + blockIdx.y;
-  const int H = v.scan_lines, eb = tail.eb;
-  const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63;
-  __syncthreads();                                   // (this workgroup's stores have been issued by all its waves)
-  if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    const unsigned int old = atomicAdd(&v.ring_done[s], 1u);
-    t_last = ((old + 1u) % (unsigned int)H) == 0u ? 1 : 0;
-    if (t_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  }
-  __syncthreads();
-  if (!t_last) return;
-  // (pipelined replay) the odometry that last read edge buffer eb must have completed before it is rewritten
-  if (tail.wait_odo && !pipe_wait(v.pipe_flags + kEdgePipeBufs, tail.wait_odo, &v.state[s].status)) return;
-  if (tid < 64) {
-    // exclusive prefix over the H <= 256 ring counts (agent-scope loads: written by the other workgroups of this launch)
-    const int* rn = v.ring_nedges + (size_t)s * H;
-    int base = 0;
-    for (int c = 0; c < H; c += 64) {
-      const int mine = (c + lane < H) ? (int)__hip_atomic_load((gu32*)(rn + c + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-      const int incl = wave_incl_scan_i32(mine);
-      if (c + lane < H) t_pre[c + lane] = base + incl - mine;
-      base += readlane_i32(incl, 63);
-    }
-    if (lane == 0) { t_pre[H] = base; t_E = base > v.edge_cap ? v.edge_cap : base; }
-  }
-  __syncthreads();
-  const int E = t_E;
-  if (tid == 0) v.state[s].n_edges_buf[eb] = E;
-  for (int e = tid; e < E; e += nt) {
-    int lo = 0, hi = H;            // largest r with t_pre[r] <= e
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (t_pre[mid] <= e) lo = mid; else hi = mid; }
-    const int r = lo, k = e - t_pre[r];
-    const size_t pi = ((size_t)s * H + r) * v.slots_per_ring + k;
-    const size_t eo = ((size_t)eb * v.n_streams + s) * v.edge_cap + e;
-    const float4 pt = v.edges_pad[pi];
-    v.edges[eo] = pt;
-    const int2 m = v.edges_pad_meta[pi];
-    v.edges_meta[eo] = make_int4(r, m.x, m.y, 0);
-  }
-  __syncthreads();
-  if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    const unsigned int old = atomicAdd(&v.ring_done[v.n_streams], 1u);
-    if (((old + 1u) % (unsigned int)gridDim.y) == 0u) {
-      if (tail.dev_flag) __hip_atomic_store((gu32*)tail.dev_flag, tail.value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (tail.host_seq) __hip_atomic_store(tail.host_seq, tail.value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-  }
-}
-
 // Behind k_compact_edges in stream order (that launch has ended: its stores, to HBM and to host memory, are complete):
 // the extraction's sequence number for the odometry side's kernels (dev_flag, as k_set_flag; may be null) and for the host
 // thread that waits for the edges (host_seq, system scope; may be null).

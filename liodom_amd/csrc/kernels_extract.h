@@ -809,21 +809,6 @@ __device__ __forceinline__ void ring_select_rows(const DevView& v, const float4*
     DBG_STAMP(v, dbgb, 0, 6);
 }
 
-// Tail of the extraction chain for handles of a few streams (ExtractTail.eb >= 0): the workgroup that finishes a stream's last
-// ring compacts that stream's edges (what k_compact_edges does in a launch of its own) and, when every stream of the launch has
-// been compacted, publishes the extraction's number (k_set_flag / k_publish_edges) — three launches per scan instead of five on
-// the extraction stream, whose length bounds the scan rate of short odometry chains (VLP-16) and whose enqueue cost bounds the
-// host-fed replay.  Not used with the host mirror of the edge tickets (one workgroup writing across PCIe is slower than
-// k_compact_edges' eight).  Defined in kernels_compact.h.
-struct ExtractTail {
-  int eb;                    // pipeline buffer the dense edges go to; < 0: no tail (k_compact_edges follows as a launch)
-  unsigned int wait_odo;     // as k_compact_edges
-  unsigned int* dev_flag;    // as k_publish_edges (each may be null)
-  unsigned int* host_seq;
-  unsigned int value;
-};
-__device__ void ring_extract_tail(const DevView& v, int s0, const ExtractTail& tail);
-
 template <int IPL>
 __device__ __forceinline__ void ring_extract_ring(const DevView& v, int s, int ring, unsigned char* smem) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
@@ -913,11 +898,10 @@ __device__ __forceinline__ void ring_extract_ring(const DevView& v, int s, int r
 }
 
 template <int kMaxThreads, int IPL>
-__global__ __launch_bounds__(kMaxThreads) void k_ring_extract(DevView v, int s0, ExtractTail tail) {
+__global__ __launch_bounds__(kMaxThreads) void k_ring_extract(DevView v, int s0) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if (v.split_ctr && blockIdx.x == 0 && threadIdx.x == 0) {      // (k_ring_split's counters, for the next scan)
     v.split_ctr[2 * (s0 + (int)blockIdx.y) + 1] = 0u;
   }
   ring_extract_ring<IPL>(v, s0 + (int)blockIdx.y, (int)blockIdx.x, smem);
-  if (tail.eb >= 0) ring_extract_tail(v, s0, tail);
 }

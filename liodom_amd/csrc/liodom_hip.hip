@@ -116,7 +116,6 @@ struct liodom_handle {
                                      // binding 10.3k -> 9.0k scans/s, host-fed replay 11.5k -> 8.9k): off by default
   bool safe_mode = false;            // no in-kernel waits at all: events between the streams, one workgroup per solve, three-kernel hash rebuild
   bool ring_split = true;            // ring split in one pass (k_ring_split) where a launch has at most 256 workgroups; LIODOM_RING_SPLIT=0: always k_classify + k_ring_scatter
-  bool fuse_tail = false;            // few-stream handles: k_ring_extract's last workgroups compact and publish (no k_compact_edges / flag launches); LIODOM_FUSE_TAIL=0: off
   bool streams_concurrent = true;    // liodom_create's probe: kernels of two streams of this handle ran side by side
   std::atomic<bool> ov_off_for_copies{false};  // the overlapped pass's stream carries the hand-off's uploads (LIODOM_COPY_STREAM=2)
   std::atomic<bool> pipe_active{false};        // scans went through the pipeline edge buffers by ticket since the last drain
@@ -201,24 +200,10 @@ inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 // Feature extraction of `count` streams starting at s0; input scan for stream s0+i at in + i*stride.
 // host_in (optional, device-visible pointer to page-locked HOST memory, stride host_stride per stream): the scan is read from
 // there by the first kernel of the chain — no upload call — and `in` is the device buffer that kernel leaves a copy in.
-// publish (optional): the flag words and the number the extraction is published under.  On handles of a few streams the chain's
-// tail is fused into k_ring_extract (ring_extract_tail): no k_compact_edges launch, and *published = true tells the caller that
-// the flag launch (k_set_flag / k_publish_edges) is not needed either.
-struct ExtractPublish { unsigned int* dev_flag; unsigned int* host_seq; unsigned int value; };
 int launch_extract(liodom_handle* h, hipStream_t q, int eb, int s0, int count, const float4* in, size_t in_stride,
                    int n, int height, int width, unsigned int wait_odo = 0, int mirror = 0,
-                   const float4* host_in = nullptr, size_t host_stride = 0,
-                   const ExtractPublish* publish = nullptr, bool* published = nullptr) {
+                   const float4* host_in = nullptr, size_t host_stride = 0) {
   const DevView& v = h->v;
-  // (not with the host mirror: one workgroup writing the edges across PCIe was measured slower than k_compact_edges' eight —
-  //  two-thread replay 10.4k -> 9.3k scans/s)
-  const bool fuse = h->fuse_tail && v.ring_done != nullptr && mirror == 0;
-  ExtractTail tail;
-  tail.eb = fuse ? eb : -1; tail.wait_odo = wait_odo;
-  tail.dev_flag = (fuse && publish) ? publish->dev_flag : nullptr;
-  tail.host_seq = (fuse && publish) ? publish->host_seq : nullptr;
-  tail.value = publish ? publish->value : 0u;
-  if (published) *published = fuse;
   const int tiles = std::max(1, cdiv(n, kTilePts));
   if (v.lidar_type == 1 && width > 0 && (long long)h->H * width <= (long long)v.max_points) {
     // organised cloud: ring = row, the split is a per-row compaction (no classify / scatter passes): one pass over the scan
@@ -250,14 +235,14 @@ int launch_extract(liodom_handle* h, hipStream_t q, int eb, int s0, int count, c
     const bool big = total - sector * (v.scan_regions - 1) > kExLPR * kExIPL;
     const dim3 grid(h->H, count), block(ext);
     if (ext <= 256) {
-      if (big) hipLaunchKernelGGL((k_ring_extract<256, kExIPLBig>), grid, block, h->ring_lds_bytes, q, v, s0, tail);
-      else hipLaunchKernelGGL((k_ring_extract<256, kExIPL>), grid, block, h->ring_lds_bytes, q, v, s0, tail);
+      if (big) hipLaunchKernelGGL((k_ring_extract<256, kExIPLBig>), grid, block, h->ring_lds_bytes, q, v, s0);
+      else hipLaunchKernelGGL((k_ring_extract<256, kExIPL>), grid, block, h->ring_lds_bytes, q, v, s0);
     } else {
-      if (big) hipLaunchKernelGGL((k_ring_extract<1024, kExIPLBig>), grid, block, h->ring_lds_bytes, q, v, s0, tail);
-      else hipLaunchKernelGGL((k_ring_extract<1024, kExIPL>), grid, block, h->ring_lds_bytes, q, v, s0, tail);
+      if (big) hipLaunchKernelGGL((k_ring_extract<1024, kExIPLBig>), grid, block, h->ring_lds_bytes, q, v, s0);
+      else hipLaunchKernelGGL((k_ring_extract<1024, kExIPL>), grid, block, h->ring_lds_bytes, q, v, s0);
     }
   }
-  if (!fuse) {
+  {
     ProfScope ps(h, KID_COMPACT, q);
     hipLaunchKernelGGL(k_compact_edges, dim3(kCompactBlocks, count), dim3(256), 0, q, v, s0, eb, wait_odo, mirror);
   }
@@ -489,14 +474,11 @@ int issue_extract(liodom_handle* h, int slot, int eb, int n, int height, int wid
   if (h->use_flags) {
     // dependencies through flags in device memory (pipe_wait / k_set_flag): the buffer's last reader must have
     // completed before k_compact_edges rewrites it; the flag of this extraction is set by a launch that follows it
-    unsigned int seq = ++h->ext_seq;
-    if (seq == 0u) seq = ++h->ext_seq;                      // (0 means "nothing to wait for")
-    const ExtractPublish pub{h->v.pipe_flags + eb, nullptr, seq};
-    bool published = false;
-    int rc = launch_extract(h, q, eb, 0, h->S, in, (size_t)h->v.max_points, n, height, width, h->eb_reader[eb], 0, host_dev, host_stride, &pub, &published);
+    int rc = launch_extract(h, q, eb, 0, h->S, in, (size_t)h->v.max_points, n, height, width, h->eb_reader[eb], 0, host_dev, host_stride);
     if (rc) return rc;
-    h->eb_seq[eb] = seq;
-    if (!published) hipLaunchKernelGGL(k_set_flag, dim3(1), dim3(1), 0, q, h->v.pipe_flags + eb, h->eb_seq[eb]);
+    h->eb_seq[eb] = ++h->ext_seq;
+    if (h->ext_seq == 0) h->eb_seq[eb] = ++h->ext_seq;      // (0 means "nothing to wait for")
+    hipLaunchKernelGGL(k_set_flag, dim3(1), dim3(1), 0, q, h->v.pipe_flags + eb, h->eb_seq[eb]);
     HIP_TRY(hipGetLastError());
     return LIODOM_OK;
   }
@@ -514,6 +496,7 @@ int issue_extract(liodom_handle* h, int slot, int eb, int n, int height, int wid
 //   second kNN pass       beside the first solve, polling     -> behind it in stream order
 //   pose solve            G workgroups exchanging partial sums in the launch -> one workgroup (sums in a different order: poses
 //                         agree with the G-workgroup solve to rounding, not to the bit)
+//   ring split            one pass whose tiles wait for each other's histograms -> k_classify + k_ring_scatter (bit-identical)
 //   hash rebuild          workgroups inside the solve launches waiting for its pose -> k_window_insert / k_hash_alloc /
 //                         k_hash_scatter behind the solve (bit-identical: test_early_rebuild_equals_three_kernel_rebuild)
 // Entered by liodom_reset() after a timeout, or at creation with LIODOM_SAFE_MODE=1.
@@ -522,6 +505,7 @@ void enter_safe_mode(liodom_handle* h) {
   h->use_flags = false;
   h->v.lm_groups = 1;
   h->v.early_rebuild = 0;      // (the second table, the padding and the overflow list stay allocated and unused)
+  h->ring_split = false;       // k_ring_split's workgroups wait for each other inside the launch: k_classify + k_ring_scatter instead
 }
 
 int reset_state(liodom_handle* h) {
@@ -746,10 +730,6 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   ALLOC(v.edges_pad_meta, S * h->H * v.slots_per_ring, 0);
   ALLOC(v.ring_nedges, S * h->H, 0);
   {
-    h->fuse_tail = h->S <= 4;
-    if (const char* e = std::getenv("LIODOM_FUSE_TAIL")) { if (std::atoi(e) == 0) h->fuse_tail = false; }
-    v.ring_done = nullptr;
-    if (h->fuse_tail) ALLOC(v.ring_done, S + 1, 0);
     if (const char* e = std::getenv("LIODOM_RING_SPLIT")) h->ring_split = std::atoi(e) != 0;
     v.split_ctr = nullptr;
     v.split_hist = nullptr; v.split_pad = round_up(v.tile_cap, 8);
@@ -1197,14 +1177,10 @@ int liodom_extract_edges_device(liodom_handle_t* h, int stream, const float* xyz
   unsigned int* host_seq = h->v.host_edges_hdr ? h->v.host_edges_hdr + eb : nullptr;
   // (the slot is free: the odometry that last read buffer eb has been collected, i.e. has completed — no wait on the device,
   //  which would depend on when the other thread submits its next scan)
-  {
-    const ExtractPublish pub{h->use_flags ? h->v.pipe_flags + eb : nullptr, host_seq, seq};
-    bool published = false;
-    rc = launch_extract(h, q, eb, stream, 1, in, 0, (int)n, height, width, 0u, 1, host_dev, 0, &pub, &published);
-    if (rc) return rc;
-    if (!published) hipLaunchKernelGGL(k_publish_edges, dim3(1), dim3(1), 0, q, pub.dev_flag, host_seq, seq);
-    if (!h->use_flags) HIP_TRY(hipEventRecord(h->ev_edges[eb], q));
-  }
+  rc = launch_extract(h, q, eb, stream, 1, in, 0, (int)n, height, width, 0u, 1, host_dev, 0);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_publish_edges, dim3(1), dim3(1), 0, q, h->use_flags ? h->v.pipe_flags + eb : (unsigned int*)nullptr, host_seq, seq);
+  if (!h->use_flags) HIP_TRY(hipEventRecord(h->ev_edges[eb], q));
   HIP_TRY(hipGetLastError());
   if (pin_slot_used >= 0) {                          // (zero-copy) the ring slot may be refilled once the extraction's first kernel has read it
     HIP_TRY(hipEventRecord(h->ev_pin[pin_slot_used], q));
@@ -1847,12 +1823,12 @@ int liodom_get_modes(liodom_handle_t* h, char* buf, int cap) {
   snprintf(buf, (size_t)cap,
            "n_streams=%d early_rebuild=%d hash_build=%s pipe_flags=%d flag_gate=%d lm_groups=%d knn_instance=%d knn_queries=%d "
            "knn_grid=%d/%d knn_partials=%d knn_saved_bound=%d knn_exact_only=%d line_gate_kernel=%d filter_local_map=%d mapping=%d "
-           "rotation_mode=%d table_size=%d rebuild_delta=%.3f knn_overlap=%d streams_concurrent=%d safe_mode=%d fused_extract_tail=%d ring_split=%d debug=%d",
+           "rotation_mode=%d table_size=%d rebuild_delta=%.3f knn_overlap=%d streams_concurrent=%d safe_mode=%d ring_split=%d debug=%d",
            h->S, v.early_rebuild, v.early_rebuild ? "streamed" : (h->lds_hash_build ? "lds" : "global"), h->use_flags ? 1 : 0,
            (h->use_flags && h->flag_gate) ? 1 : 0, v.lm_groups, h->S >= 16 ? 128 : 256, v.knn_queries, v.knn_grid,
            v.knn_blocks, v.knn_partials, v.knn_save_pos ? 2 : (v.knn_save_q ? 1 : 0), v.knn_exact_only, v.knn_nn ? 1 : 0, v.filter_local_map, v.mapping,
            v.rotation_mode, v.table_size, (double)v.rebuild_delta,
-           (v.early_rebuild && h->ov_ok && h->use_flags && g_live_handles.load() <= 1) ? 1 : 0, h->streams_concurrent ? 1 : 0, h->safe_mode ? 1 : 0, h->fuse_tail ? 1 : 0, h->ring_split ? 1 : 0, v.debug);
+           (v.early_rebuild && h->ov_ok && h->use_flags && g_live_handles.load() <= 1) ? 1 : 0, h->streams_concurrent ? 1 : 0, h->safe_mode ? 1 : 0, h->ring_split ? 1 : 0, v.debug);
   return LIODOM_OK;
 }
 

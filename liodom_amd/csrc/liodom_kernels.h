@@ -147,7 +147,6 @@ struct DevView {
   int* ring_nedges;         // [S][H]
   unsigned short* split_hist; int split_pad;   // [S][H][split_pad] k_ring_split: points per (ring, 2048-point tile); split_pad = tiles rounded up to 8
   unsigned int* split_ctr;  // [2 S] k_ring_split: tiles of stream s that have published their histogram [2 s + 1]
-  unsigned int* ring_done;  // [S + 1] fused extraction tail: ring workgroups that have finished per stream, streams compacted (monotonic)
   int* ring_npoints;        // [S][H]
   double* ring_c;           // [S][max_points] smoothness per ring-sorted point: debug dump (debug & 1) and generic-path scratch
   unsigned char* ring_picked;  // [S][max_points] picked_ marks of the generic path
