@@ -63,6 +63,33 @@ def test_extract_bit_exact(orc, synth, H, W, lt, R, epr):
     g.close()
 
 
+@pytest.mark.parametrize("S", [1, 3])
+def test_ring_split_equals_two_kernel_split(orc, synth, monkeypatch, S):
+    """Handles whose extraction launch has at most 256 workgroups split the scan into rings with ONE kernel (k_ring_split:
+    the tiles of a stream wait for each other's histograms inside the launch); LIODOM_RING_SPLIT=0 — and every lock-step batch,
+    and safe mode — uses k_classify + k_ring_scatter.  Both against the oracle, on ragged scans (NaN no-returns, rings of unequal
+    length, dead rings) so that tiles, ranks and ring starts differ from the regular grid; S = 3: three streams in one launch."""
+    H, W, R, epr = 64, 1800, 8, 10
+    cfg = synth.make_cfg(H, W, 0)
+    scans = [[synth.ragged(synth.scan(cfg, 5 + s, k)[0], H, W, 0, seed=100 * s + k) for k in (0, 3)] for s in range(S)]
+    for mode in ("1", "0"):
+        monkeypatch.setenv("LIODOM_RING_SPLIT", mode)
+        po, g = mk(orc, H, W, 0, R, epr, S=S)
+        assert g.modes()["ring_split"] == mode
+        for k in range(2):
+            for s in range(S):
+                e = g.extract_edges(scans[s][k], H, W, stream=s)
+                assert_edges_equal(e, orc.extract(po, scans[s][k], H, W))
+        if S > 1:      # all streams through one lock-step launch
+            g.alloc_resident(1)
+            for s in range(S):
+                g.upload_scan(s, 0, scans[s][1])
+            g.process_resident(0, H * W, H, W, readback=True)
+            for s in range(S):
+                assert_edges_equal(g.get_edges(s), orc.extract(po, scans[s][1], H, W))
+        g.close()
+
+
 def test_extract_edge_cases(orc):
     po, g = mk(orc, 16, 1800, 0, 8, 10)
     # empty cloud, all-NaN cloud
