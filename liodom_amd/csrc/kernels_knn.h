@@ -348,9 +348,14 @@ struct KnnPre {
 // re-ranked five are certified by the same guard argument as the non-overlapped re-ranking, practically always — the
 // search a non-certified query falls back to (which a launch lasts as long as) disappears from the critical path.
 constexpr float kOvMargin = 0.03f;
+#ifndef LIODOM_OV_MARGIN_PER_M
+#define LIODOM_OV_MARGIN_PER_M 0.004f
+#endif
+constexpr float kOvMarginPerMetre = LIODOM_OV_MARGIN_PER_M;      // + 4 mm per metre of range (sensor frame)
+constexpr float kOvMarginMax = 0.30f;
 template <int kKnnThreads>
 __device__ __forceinline__ void knn_presearch(const DevView& v, int s, const StreamState& st, int e, int E,
-                                              KnnShared<kKnnThreads / kKnnGroup>& sh, KnnPre& pre) {
+                                              KnnShared<kKnnThreads / kKnnGroup>& sh, KnnPre& pre, float range) {
   typedef KnnTune<(kKnnThreads >= 256)> Tune;
   const int grp = threadIdx.x / kKnnGroup, hl = threadIdx.x & (kKnnGroup - 1);
   const int ec = e < v.edge_cap ? e : v.edge_cap - 1;
@@ -373,8 +378,12 @@ __device__ __forceinline__ void knn_presearch(const DevView& v, int s, const Str
   unsigned int start = 0, cnt = 0;
   float lb = 0.0f;
   knn_probe_cells<Tune>(v, st, hl, cx, cy, cz, qx, qy, qz, cells, bits, tmask, start, cnt, lb);
-  // everything within sqrt(min(d5_old, 1)) + margin of q_old (beyond the 1.0 gate nothing can matter: :324)
-  const float r = fminf(sqrtf(pre.sq.w), 1.0f) + kOvMargin;
+  // everything within sqrt(min(d5_old, 1)) + margin of q_old (beyond the 1.0 gate nothing can matter: :324).  The margin grows
+  // with the point's range: the first solve corrects the predicted pose by a rotation too, which moves a point 50 m out by
+  // centimetres (measured: 7.7 % of the queries moved by more than 1 cm, 4.3 % by more than the flat 3 cm margin of round 3 —
+  // every one of them a full search on the launch's critical path); far points are sparse, the wider shell adds few candidates
+  const float margin = fminf(kOvMargin + kOvMarginPerMetre * range, kOvMarginMax);
+  const float r = fminf(sqrtf(pre.sq.w), 1.0f) + margin;
   const float B = r * r * (1.0f + 1e-5f);
   Top5Acc ta;
   {
@@ -384,20 +393,12 @@ __device__ __forceinline__ void knn_presearch(const DevView& v, int s, const Str
   }
   const bool all = cnt > 0 && !(lb > B);
   knn_stream_cells<Top5Acc, 2, 2, 64>(ta, sp, sh.incl[grp], sh.adj[grp], start, all ? cnt : 0u, hl, qx, qy, qz);
-  // guard: B itself (segments with lb > B and points beyond B were left out), the fifth entry of a lane whose list is full
-  // (it may have dropped candidates at or beyond that distance), the border of the 27-cell block
+  // guard for the points INSIDE the 27-cell block that were not collected: B itself (segments with lb > B and points beyond B
+  // were left out) and the fifth entry of a lane whose list is full (it may have dropped candidates at or beyond that distance).
+  // Points outside the block are bounded by the re-ranking pass from the new query's position (knn_block, kPre).
   float gl = B;
   if (ta.t.p4 >= 0) gl = fminf(gl, top5_dist(ta.t.k4));
-  float guard = __int_as_float((int)half_min_u32((unsigned int)__float_as_int(gl)));
-  {
-    const float cs = (float)kCellSize;
-    const float fx = qx - (float)cx * cs, fy = qy - (float)cy * cs, fz = qz - (float)cz * cs;
-    float edge = fminf(fminf(fminf(fx, cs - fx), fminf(fy, cs - fy)), fminf(fz, cs - fz));
-    edge = edge > 0.f ? edge : 0.f;
-    const float outer = (cs + edge) * (cs + edge) * (1.0f - 1e-6f);
-    guard = guard < outer ? guard : outer;
-  }
-  pre.gsq = guard;
+  pre.gsq = __int_as_float((int)half_min_u32((unsigned int)__float_as_int(gl)));
   pre.p[0] = ta.t.p0; pre.p[1] = ta.t.p1; pre.p[2] = ta.t.p2; pre.p[3] = ta.t.p3; pre.p[4] = ta.t.p4;
 #pragma unroll
   for (int k = 0; k < 5; k++) pre.c[k] = sp[pre.p[k] >= 0 ? pre.p[k] : 0];
@@ -461,6 +462,7 @@ __device__ __forceinline__ void knn_block(const DevView& v, int s, StreamState& 
     if (kPre) {
       // overlapped pass: re-rank what knn_presearch collected around the first pass's query (sorted lists, exact merge:
       // ties by window index as in the exact path)
+      if ((kInstrument && (v.debug & 64)) && hl == 0 && !(pre.gsq > 0.f)) atomicAdd(&v.dbg_clk[262], 1ull);
       if (pre.gsq > 0.f) {                                       // (uniform over the half-wave)
         Top5 t, g;
         top5_clear(t);
@@ -472,9 +474,32 @@ __device__ __forceinline__ void knn_block(const DevView& v, int s, StreamState& 
         const float d5n = g.p4 >= 0 ? top5_dist(g.k4) : __int_as_float(0x7f800000);
         const double ddx = (double)qx - (double)pre.sq.x, ddy = (double)qy - (double)pre.sq.y, ddz = (double)qz - (double)pre.sq.z;
         const double delta = sqrt(ddx * ddx + ddy * ddy + ddz * ddz) * (1.0 + 1e-12);
-        const double r = sqrt((double)pre.gsq) * (1.0 - 2e-7) - delta;     // every point outside the collected set is at least this far now
-        const double limit = r > 0.0 ? r * r * (1.0 - 1e-6) : 0.0;         // (float rounding of the new distances included)
+        const double r = sqrt((double)pre.gsq) * (1.0 - 2e-7) - delta;     // every uncollected point of the 27-cell block is at least this far now
+        double limit = r > 0.0 ? r * r * (1.0 - 1e-6) : 0.0;               // (float rounding of the new distances included)
+        {
+          // ... and every point outside that block (the cells around the OLD query's cell) at least one cell size plus the new
+          // query's distance to the nearest face of that cell (negative once it has left the cell)
+          const double cs = kCellSize;
+          // (the cell index exactly as knn_presearch formed it)
+          const double fx = (double)qx - (double)(int)floorf(pre.sq.x * kCellInv) * cs, fy = (double)qy - (double)(int)floorf(pre.sq.y * kCellInv) * cs,
+                       fz = (double)qz - (double)(int)floorf(pre.sq.z * kCellInv) * cs;
+          const double edge = fmin(fmin(fmin(fx, cs - fx), fmin(fy, cs - fy)), fmin(fz, cs - fz));
+          const double ro = (cs + edge) * (1.0 - 2e-7);
+          const double lo = ro > 0.0 ? ro * ro * (1.0 - 1e-6) : 0.0;
+          limit = limit < lo ? limit : lo;
+        }
         reranked = (double)d5n < limit || limit > 1.0;                     // beyond the 1.0 gate nothing uncollected can matter
+        if ((kInstrument && (v.debug & 64)) && hl == 0) {       // (debug) why a query of the overlapped pass is not certified
+          atomicAdd(&v.dbg_clk[261], 1ull);
+          if (!reranked) {
+            const float rn = fminf(sqrtf(pre.sq.w), 1.0f) + kOvMargin;
+            atomicAdd(&v.dbg_clk[g.p4 < 0 ? 264 : 265], 1ull);
+            if (delta > 0.01) atomicAdd(&v.dbg_clk[266], 1ull);
+            if (pre.gsq < rn * rn) atomicAdd(&v.dbg_clk[267], 1ull);
+            if (!(pre.sq.w < 1.0f)) atomicAdd(&v.dbg_clk[268], 1ull);
+            if (delta > 0.03) atomicAdd(&v.dbg_clk[269], 1ull);
+          }
+        }
         if (reranked) {
           d5_r = d5n;
           pos5[0] = g.p0; pos5[1] = g.p1; pos5[2] = g.p2; pos5[3] = g.p3; pos5[4] = g.p4;
@@ -914,8 +939,8 @@ __device__ __forceinline__ void knn_pass(const DevView& v, int s, int bxi, int b
   if (kOv) {
     // everything the two blocks need apart from the solve's result; then wait for that
     if (second) p_second = v.edges[((size_t)eb * v.n_streams + s) * v.edge_cap + (e_second < v.edge_cap ? e_second : v.edge_cap - 1)];
-    knn_presearch<kKnnThreads>(v, s, st, e_first, E, sh, pre1);
-    if (second) knn_presearch<kKnnThreads>(v, s, st, e_second, E, sh2, pre2);
+    knn_presearch<kKnnThreads>(v, s, st, e_first, E, sh, pre1, sqrtf(p_first.x * p_first.x + p_first.y * p_first.y + p_first.z * p_first.z));
+    if (second) knn_presearch<kKnnThreads>(v, s, st, e_second, E, sh2, pre2, sqrtf(p_second.x * p_second.x + p_second.y * p_second.y + p_second.z * p_second.z));
     else pre2.gsq = 0.f;
     if (!ov_wait_pose(v, s, bxi % kOvReplicas, seq, sh_ov, &st.status)) return;
     OV_STAMP(v, threadIdx.x == 0 && bxi == 0, 10); OV_STAMP(v, threadIdx.x == 0 && bxi == v.knn_grid - 1, 14);

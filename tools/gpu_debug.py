@@ -218,6 +218,7 @@ def sec_clocks(H=64, W=1800, R=8, epr=10, P=20, K=40):
     print('k_ring_extract (carry re-run rounds, edges) of the rings written last (ring & 31):', [(int(x) & 255, int(x) >> 8) for x in allv[96:128]])
     print('k_knn (both passes): %d queries answered by the Best2 fast path, %d repeated with the exact lists; %d needed a second phase' % (int(allv[256]), int(allv[257]), int(allv[258])))
     print('k_knn second pass: %d queries certified by re-ranking the first pass\'s kept candidates, %d searched' % (int(allv[259]), int(allv[260])))
+    print('overlapped second pass: %d queries re-ranked, %d not collected; not certified: %d with fewer than five collected, %d with five; of these: moved > 1 cm %d, > 3 cm %d, guard below the collection radius %d, first-pass fifth distance >= 1 %d' % tuple(int(allv[i]) for i in (261, 262, 264, 265, 266, 269, 267, 268)))
     print('k_knn query (half-wave) time to selection, 1 us bins:', allv[320:384].tolist())
     print('k_knn candidates streamed per query, bins of 64:', allv[384:448].tolist())
     print('k_knn time (rows: 4 us bins) x candidates (<64, <128, <256, <512, <1024, more | two-phase | exact repeat):')
