@@ -23,6 +23,9 @@
 //
 // Determinism: every random number is a pure function of (seed, counter); the output does not
 // depend on the number of OpenMP threads.
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -208,7 +211,15 @@ int synth_scan(const synth_cfg_t* cfg, int stream, int scan, float* xyzi, double
   }
   const uint64_t seed = 1000ull * (uint64_t)stream + (uint64_t)scan;
   const float nanf_ = std::numeric_limits<float>::quiet_NaN();
-#pragma omp parallel for schedule(static)
+  // (a few threads: W is ~2 000 columns; the default team of a 256-thread host costs more in fork / join than the loop takes —
+  //  0.12 s per 16 x 1800 scan on the GPU box's EPYC against 3 ms with 16 threads, which dominated the GPU test suite's run time)
+  int nth = 1;
+#ifdef _OPENMP
+  nth = omp_get_max_threads();
+  if (nth > 16) nth = 16;
+  if (nth < 1) nth = 1;
+#endif
+#pragma omp parallel for schedule(static) num_threads(nth)
   for (int c = 0; c < W; ++c) {
     double phi = 2.0 * M_PI * c / W;
     double cphi = std::cos(phi), sphi = std::sin(phi);
