@@ -932,7 +932,7 @@ def test_sixteen_streams_headline_size_against_the_oracle(orc, synth):
     assert worst_t < 1e-6 and worst_r < 1e-6
 
 
-@pytest.mark.parametrize("shape,scans", [("hdl64", 240), ("vlp16", 300)])
+@pytest.mark.parametrize("shape,scans", [("hdl64", 1200), ("vlp16", 1200)])
 def test_overlapped_pass_long_replay_is_bit_identical(shape, scans):
     """tools/overlap_equal.py: the same long replay with and without the overlapped second kNN pass (LIODOM_KNN_OVERLAP, read at
     handle creation: one process per mode) gives bit-identical pose logs.  Guards the fence-free hand-offs of kernels_sync.h:

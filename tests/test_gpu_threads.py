@@ -387,7 +387,7 @@ def test_second_process_saturating_the_gpu_never_gives_a_wrong_pose(hog):
         import torch  # noqa: F401  (the second process uses it to load the GPU)
     except Exception:
         pytest.skip("torch not importable: no second process to load the GPU with")
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_two_process.py"), "vlp16", "3000", "150", hog],
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_two_process.py"), "vlp16", "10000", "150", hog],
                        capture_output=True, text=True, timeout=900)
     tail = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ""
     assert r.returncode == 0, (tail, r.stderr[-1500:])
