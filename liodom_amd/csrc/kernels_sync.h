@@ -11,6 +11,14 @@
 // streams, e.g. rocprofv3 --pmc: use LIODOM_PIPE_FLAGS=0 there — raises LIODOM_STATUS_PIPE_TIMEOUT instead of hanging; the waiting
 // workgroups then skip their work (nothing reads a half-written buffer or overwrites one still in use), the host reports the scan
 // as failed (wait_pose) and the handle falls back to events.
+// poll intervals (s_sleep units of 64 cycles) of the overlapped pass's two waits: the pass's workgroups for the first solve's
+// pose, the finalising solve's threads for the pass's done flags
+#ifndef LIODOM_POLL_POSE
+#define LIODOM_POLL_POSE 6
+#endif
+#ifndef LIODOM_POLL_DONE
+#define LIODOM_POLL_DONE 4
+#endif
 __device__ __forceinline__ bool pipe_wait(const unsigned int* flag, unsigned int want, unsigned int* status) {
   typedef __attribute__((address_space(1))) unsigned int gu32;
   __shared__ int s_pipe_ok;
@@ -102,7 +110,7 @@ __device__ __forceinline__ bool ov_wait_pose(const DevView& v, int s, int rep, u
       ok = tid >= kOvGranules || (unsigned int)(g >> 32) == tag;
       if (__all(ok)) break;
       if (++spins > 2000000u) break;
-      __builtin_amdgcn_s_sleep(6);
+      __builtin_amdgcn_s_sleep(LIODOM_POLL_POSE);
     }
     const bool all_ok = __all(ok);
     const unsigned long long lo = __shfl(g, 2 * (tid % 19)), hi = __shfl(g, 2 * (tid % 19) + 1);
@@ -126,7 +134,7 @@ __device__ __forceinline__ void ov_wait_knn_done(const DevView& v, int s, unsign
   for (int b = (int)threadIdx.x; b < v.knn_grid; b += (int)blockDim.x) {
     unsigned int spins = 0;
     while ((int)(__hip_atomic_load((gu32*)(f + b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) < 0) {
-      __builtin_amdgcn_s_sleep(4);
+      __builtin_amdgcn_s_sleep(LIODOM_POLL_DONE);
       if (++spins > 6000000u) { atomicOr(status, LIODOM_STATUS_PIPE_TIMEOUT); break; }
     }
   }
