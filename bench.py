@@ -81,6 +81,24 @@ def algorithmic_bytes(kernel, N, E, M, C, evals, streamed=False):
     return 0.0
 
 
+def _traffic_profiles(workload):
+    import glob
+    return sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic_%s.json" % workload)))
+
+
+def traffic_source(workload):
+    """Where `roofline.traffic` comes from: the committed profile's file name and how its PMC passes were run."""
+    files = _traffic_profiles(workload)
+    if not files:
+        return None
+    return {"profile": os.path.relpath(files[-1], ROOT),
+            "collected_with": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (tools/profile_round.sh -> tools/pmc_summary.py); "
+                              "FETCH_SIZE doubled (gfx950 correction of MI355X_MICROARCH.md)",
+            "mode_note": "--pmc serialises kernels across HIP streams, so the PMC passes run the EVENT path of the handle (LIODOM_PIPE_FLAGS=0: no "
+                         "in-kernel waits between streams, second kNN pass behind the first solve instead of beside it); same kernels and bytes per "
+                         "launch as the timed leg, different overlap — a committed profile, not a counter read in this run"}
+
+
 def measured_traffic(kernel, n_streams, workload):
     """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC profile of THIS workload
     (profiles/*_pmc_traffic_<workload>.json, written by tools/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE passes;
@@ -88,8 +106,7 @@ def measured_traffic(kernel, n_streams, workload):
     keeps the single-stream run and the lock-step run (its stream count recorded) apart, launch-weighted over the grids a
     kernel is launched with — never by "smallest grid".  PMC counters cannot be collected from inside this process; null
     when no profile of this workload is committed."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic_%s.json" % workload)))
+    files = _traffic_profiles(workload)
     if not files:
         return None
     try:
@@ -153,6 +170,7 @@ def roofline_from_stats(stats, n_streams, N, E, M, C, evals, workload="hdl64"):
     return {
         "bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": measured_traffic(name, n_streams, workload),
+        "traffic_source": traffic_source(workload),
         "avg_kernel_us": round(avg_s * 1e6, 2), "algorithmic_bytes_per_launch": int(by),
         "share_of_gpu_time": round(ms / tot, 3),
         "per_kernel_us": {k: round(v[1] / max(v[0], 1) * 1e3, 2) for k, v in stats.items()},

@@ -46,7 +46,8 @@ extern "C" {
                                          after liodom_odometry_step_device), or tickets are outstanding where none may be */
 
 /* Sticky per-stream status bits reported in liodom_step_info_t.status */
-/* (bit 1u is not used: rings of any length are processed) */
+#define LIODOM_STATUS_RING_OVERFLOW 1u  /* deprecated, never raised (rings of any length are processed); kept so that callers
+                                           that test the bit keep compiling */
 #define LIODOM_STATUS_EDGE_OVERFLOW 2u
 #define LIODOM_STATUS_HASH_FULL 4u
 #define LIODOM_STATUS_LM_SYNC_TIMEOUT 8u  /* cooperating LM workgroups did not all arrive (result invalid) */
@@ -86,7 +87,11 @@ typedef struct liodom_config_t {
   int32_t max_width;         /* expected points per ring (0 = max_points / scan_lines): picks the extraction kernel instance whose
                                 register tile covers the longest region, (max_width - 10) / scan_regions + remainder items;
                                 not a capacity — longer rings are processed by the generic path of the same kernel */
-  int32_t reserved1;         /* must be 0 */
+  union {                    /* (anonymous union: C11 / C++) */
+    int32_t reserved1;       /* ignored */
+    int32_t max_ring_points; /* deprecated name of the same field (earlier headers: capacity of a ring): ignored, rings have no
+                                capacity any more; kept so that callers that set it keep compiling */
+  };
   int32_t lm_apply_step_on_ftol; /* 0 = Ceres >= 1.12 behaviour (LM section) */
   int32_t pose_log_capacity; /* scans kept in the device-side pose log (resident replay) */
   int32_t debug_buffers;     /* 1 = keep per-ring smoothness dumps for liodom_get_curvature */

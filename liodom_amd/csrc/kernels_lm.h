@@ -1,13 +1,18 @@
 // kernels_lm.h — k_lm_solve: the Ceres-style solve, scan finalisation, in-launch exchanges.
 // Part of liodom_kernels.h (included there, inside namespace liodom_dev, in this order; not a standalone header).
 // =============================================================================================
-// k_lm_solve: one 512-thread workgroup per stream runs the whole Ceres-style solve.
-//   eval: every thread accumulates the 29-entry normal-equation accumulator over its edges
-//   (fused residual + analytic Jacobian + Huber), wavefront shfl butterfly, then a fixed-order
-//   cross-wave sum through LDS (deterministic, no atomics, no MFMA: this is a 6x6 reduction).
-//   Thread 0 runs the LM controller (liodom_math.h) between evaluations.
-//   finalize (second outer iteration, or the very first frame): pose log, constant-velocity
-//   prediction for the next scan, window bookkeeping, hash-generation counters.
+// k_lm_solve: the whole Ceres-style solve of a stream in one launch, by G = lm_groups cooperating 512-thread workgroups
+//   (G = 8 on the headline shape, 4 for >= 512 possible edges, 1 on lock-step batches and in safe mode; block indices 0, 8, 16, ...
+//   so that the G workgroups share an XCD; every other block of the launch is a workgroup of the streamed rebuild, kernels_rebuild.h).
+//   first evaluation: the reduction of the per-workgroup partial normal equations k_knn left (handles with knn_partials);
+//   eval: every workgroup takes a contiguous share of the accepted correspondences; every thread accumulates the 29-entry
+//   normal-equation accumulator over its blocks (fused residual + analytic Jacobian + Huber), transposed LDS reduction in a fixed
+//   order (deterministic, no atomics, no MFMA: this is a 6x6 reduction); with G > 1 the 29 partial sums are exchanged inside the
+//   launch as tagged 8-byte granules (lm_exchange) and every workgroup continues with bit-identical totals.
+//   controller: lane 0 of the last wave (tid kLmCtl) runs lm_begin / lm_update (liodom_math.h) between evaluations, redundantly in
+//   every workgroup; beside its first step waves 0..6 compact the accepted correspondences and cache their triples in registers.
+//   finalize (second outer iteration, or the very first frame; workgroup 0): pose log + host-mapped record, constant-velocity
+//   prediction for the next scan, window bookkeeping, and the solved pose handed to the rebuild workgroups that append the frame.
 // =============================================================================================
 // Indices of the edges with an accepted correspondence, in edge order (deterministic), built once
 // per solve in LDS so that every evaluation runs over C dense items instead of E sparse ones.

@@ -115,10 +115,12 @@ struct liodom_handle {
                                      // uploaded by a copy call.  Measured slower (shader loads reach the host as 64-byte PCIe reads: two-thread
                                      // binding 10.3k -> 9.0k scans/s, host-fed replay 11.5k -> 8.9k): off by default
   bool safe_mode = false;            // no in-kernel waits at all: events between the streams, one workgroup per solve, three-kernel hash rebuild
-  bool ring_split = true;            // ring split in one pass (k_ring_split) where a launch has at most 256 workgroups; LIODOM_RING_SPLIT=0: always k_classify + k_ring_scatter
+  bool ring_split = true;            // ring split in one pass (k_ring_split) where every workgroup of the launch is resident at once; LIODOM_RING_SPLIT=0: always k_classify + k_ring_scatter
+  int ring_split_max_wgs = 0;        // ... i.e. launches of at most this many workgroups (liodom_create: occupancy of k_ring_split x CUs, with headroom for the odometry chain's kernels)
   bool streams_concurrent = true;    // liodom_create's probe: kernels of two streams of this handle ran side by side
   std::atomic<bool> ov_off_for_copies{false};  // the overlapped pass's stream carries the hand-off's uploads (LIODOM_COPY_STREAM=2)
   std::atomic<bool> pipe_active{false};        // scans went through the pipeline edge buffers by ticket since the last drain
+  std::atomic<bool> replay_live{false};        // scans went through them by the pipelined replay since the last drain (their odometries may not have been collected)
   std::atomic<bool> fallback_pending{false};   // a kernel of this handle gave up an in-kernel wait (LIODOM_STATUS_PIPE_TIMEOUT): liodom_reset() switches to events
   int pf_slot = -1;                  // resident slot whose extraction has been issued ahead
   int last_eb = 0;                   // edge buffer of the most recent scan that entered odometry (inspection)
@@ -210,7 +212,7 @@ int launch_extract(liodom_handle* h, hipStream_t q, int eb, int s0, int count, c
     ProfScope ps(h, KID_RING_SCATTER, q);
     hipLaunchKernelGGL(k_row_compact, dim3(h->H, count), dim3(kRowThreads), 0, q, v, s0, host_in ? host_in : in, host_in ? host_stride : in_stride, n, height, width);
   } else {
-    if (h->ring_split && !host_in && (long long)tiles * count <= 256) {      // (every workgroup resident at once: k_ring_split waits inside the launch)
+    if (h->ring_split && !host_in && (long long)tiles * count <= h->ring_split_max_wgs) {      // (every workgroup resident at once: k_ring_split waits inside the launch)
       // one pass: classification and scatter in one kernel (booked as the scatter)
       ProfScope ps(h, KID_RING_SCATTER, q);
       hipLaunchKernelGGL(k_ring_split, dim3(tiles, count), dim3(kTileThreads), ring_scatter_lds_bytes(h->H), q, v, s0, in, in_stride, n, height, width);
@@ -430,7 +432,8 @@ int tickets_idle(liodom_handle* h) {      // the plain entry points use pipeline
   return LIODOM_OK;
 }
 int drain_pipeline(liodom_handle* h) {
-  if (h->pf_slot >= 0 || h->parity != 0 || h->pipe_active.exchange(false)) {
+  const bool replayed = h->replay_live.exchange(false);
+  if (h->pf_slot >= 0 || h->parity != 0 || h->pipe_active.exchange(false) || replayed) {
     HIP_TRY(hipStreamSynchronize(h->stream_x));
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->pf_slot = -1; h->parity = 0; h->ev_free_valid[0] = h->ev_free_valid[1] = h->ev_free_valid[2] = false;
@@ -534,6 +537,7 @@ int reset_state(liodom_handle* h) {
     HIP_TRY(hipGetLastError());
   }
   h->pf_slot = -1; h->parity = 0; h->last_eb = 0; h->ev_free_valid[0] = h->ev_free_valid[1] = h->ev_free_valid[2] = false;
+  h->replay_live.store(false);
   h->ext_seq = h->odo_seq = 0;
   // the first scans after a reset are not overlapped (as after liodom_create): the first one runs with st.initialized == 0, where
   // no first solve publishes the pose an overlapped second kNN pass would wait for
@@ -731,6 +735,28 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   ALLOC(v.ring_nedges, S * h->H, 0);
   {
     if (const char* e = std::getenv("LIODOM_RING_SPLIT")) h->ring_split = std::atoi(e) != 0;
+    h->ring_split = h->ring_split && !h->safe_mode;      // (safe mode = no in-kernel waits at all: it overrides the switch, whatever the order of the variables)
+    if (h->ring_split) {
+      // k_ring_split's tiles wait for each other inside the launch, so EVERY workgroup of a launch must be resident at once.  How
+      // many fit is a property of the device (CUs, LDS per CU: a tile holds ~50 KB), not a constant: occupancy query x CU count,
+      // half of it left to the odometry chain's kernels that run beside the extraction.  Launches above the budget — and devices
+      // or partitions where a single scan's tiles do not fit (CPX partitions, CU-masked runs) — take k_classify + k_ring_scatter.
+      int cus = 0, per_cu = 0;
+      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, config->device);
+      const size_t lds = ring_scatter_lds_bytes(h->H);
+      if (lds > 48 * 1024 &&
+          hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ring_split), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        (void)hipGetLastError(); per_cu = 0;
+      } else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&k_ring_split), kTileThreads, lds) != hipSuccess) {
+        (void)hipGetLastError(); per_cu = 0;
+      }
+      long long budget = (long long)std::max(0, per_cu) * std::max(0, cus) / 2;
+      if (budget > 256) budget = 256;                    // (measured: above ~4 HDL-64 streams per launch the waiting tiles lose to the two-kernel split anyway)
+      if (const char* e = std::getenv("LIODOM_RING_SPLIT_MAX_WGS")) budget = std::max(0, std::atoi(e));      // (tests)
+      h->ring_split_max_wgs = (int)budget;
+      const int tiles_one = std::max(1, cdiv(config->max_points, kTilePts));
+      if (tiles_one > h->ring_split_max_wgs) h->ring_split = false;      // not even one stream's scan fits: never use it
+    }
     v.split_ctr = nullptr;
     v.split_hist = nullptr; v.split_pad = round_up(v.tile_cap, 8);
     if (h->ring_split) { ALLOC(v.split_ctr, 2 * S, 0); ALLOC(v.split_hist, S * (size_t)h->H * v.split_pad + 64, 0); }      // (+ one batch of 64 tiles: k_ring_split reads whole batches)
@@ -801,7 +827,7 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   }
   if (h->use_flags) {
     // Flags need kernels of the handle's streams to run side by side.  Known serialisers are caught by name above; this probe
-    // catches the rest (a profiler collecting counters, a debugger): one wave on the odometry stream waits up to ~10 ms for a flag
+    // catches the rest (a profiler collecting counters, a debugger): one wave on the odometry stream waits up to ~2 ms (k_probe_wait) for a flag
     // that a launch on the extraction stream sets.  If it gives up, the handle uses events from the start.
     unsigned int* probe = nullptr;
     ALLOC(probe, 4, 0);
@@ -1111,6 +1137,10 @@ int liodom_extract_edges_device(liodom_handle_t* h, int stream, const float* xyz
   if (n < 0 || n > h->v.max_points || (n > 0 && !xyzi)) { g_last_error = "bad point count"; return LIODOM_ERR_CAPACITY; }
   SideLocks lk(h, false, true);                      // extraction side only: safe beside a concurrent liodom_odometry_step_device
   if (h->pf_slot >= 0) { g_last_error = "liodom_extract_edges_device: a pipelined replay of this handle has an extraction issued ahead"; return LIODOM_ERR_BUSY; }
+  // The pipelined replay uses the same three edge buffers (h->parity) and may have odometries in flight that nobody has collected
+  // (liodom_process_resident_pipelined without read-back): this extraction would rewrite a buffer under them (wait_odo = 0 below
+  // relies on the ticket discipline: a slot is refilled only after its pose has been collected).
+  if (h->replay_live.load()) { g_last_error = "liodom_extract_edges_device: scans of a pipelined replay (liodom_process_resident / liodom_replay_*) are still in the edge buffers: call liodom_sync() first"; return LIODOM_ERR_BUSY; }
   const int eb = h->x_next;
   if (h->tk_seq[eb].load() != 0u) {
     g_last_error = "liodom_extract_edges_device: all hand-off slots hold edge clouds no liodom_odometry_step_device has taken yet";
@@ -1429,6 +1459,7 @@ int liodom_process_resident_pipelined(liodom_handle_t* h, int slot, int next_slo
   if (rc0) return rc0;
   if ((rc0 = check_usable(h))) return rc0;
   SideLocks lk(h, true, true);
+  if ((rc0 = tickets_idle(h))) return rc0;        // (the replay fills the same pipeline edge buffers)
   return replay_one(h, slot, next_slot, n, height, width, poses_out != nullptr || infos_out != nullptr, poses_out, infos_out);
 }
 
@@ -1439,6 +1470,7 @@ int liodom_replay_resident(liodom_handle_t* h, int first_slot, int count, int ah
   if ((rc0 = check_usable(h))) return rc0;
   if (count < 0 || first_slot < 0 || depth < 0 || depth > 1) { g_last_error = "bad resident range / depth"; return LIODOM_ERR_INVALID_ARG; }
   SideLocks lk(h, true, true);
+  if ((rc0 = tickets_idle(h))) return rc0;
   auto out_p = [&](int i) { return poses_out ? poses_out + (size_t)i * h->S * 7 : nullptr; };
   auto out_i = [&](int i) { return infos_out ? infos_out + (size_t)i * h->S : nullptr; };
   for (int i = 0; i < count; i++) {
@@ -1501,6 +1533,7 @@ static int replay_one(liodom_handle_t* h, int slot, int next_slot, int64_t n, in
     g_last_error = "bad resident slot"; return LIODOM_ERR_INVALID_ARG;
   }
   // resident layout: [slot][stream][max_points]: one lock-step launch reads a contiguous block
+  h->replay_live.store(true);
   const int eb = h->parity;
   int rc;
   if (h->pf_slot != slot) {                       // extraction not issued ahead: do it now
@@ -1542,7 +1575,9 @@ int liodom_replay_host(liodom_handle_t* h, const float* xyzi_base, int64_t scan_
   constexpr int kRing = 3;
   if (h->n_slots < kRing) { const int rc = liodom_alloc_resident(h, kRing); if (rc) return rc; }
   SideLocks lk(h, true, true);
-  int rc = drain_pipeline(h);
+  int rc = tickets_idle(h);
+  if (rc) return rc;
+  rc = drain_pipeline(h);
   if (rc) return rc;
   // Measured (MI355X, HDL-64 shape): with uploads the loop is bound by the host's enqueue work (an upload, three event
   // operations, six extraction and five odometry launches per scan: 88 us); the overlapped second kNN pass adds a gate and an
@@ -1614,6 +1649,10 @@ int liodom_sync(liodom_handle_t* h) {
   SideLocks lk(h, true, true);
   HIP_TRY(hipStreamSynchronize(h->stream_x));
   HIP_TRY(hipStreamSynchronize(h->stream));
+  if (h->stream_k) HIP_TRY(hipStreamSynchronize(h->stream_k));
+  // everything has completed: unless an extraction has been issued ahead for the replay's next scan, the pipeline edge buffers
+  // are free again (for the ticket API, or for a replay that starts over at buffer 0)
+  if (h->pf_slot < 0) return drain_pipeline(h);
   return LIODOM_OK;
 }
 
@@ -1823,12 +1862,12 @@ int liodom_get_modes(liodom_handle_t* h, char* buf, int cap) {
   snprintf(buf, (size_t)cap,
            "n_streams=%d early_rebuild=%d hash_build=%s pipe_flags=%d flag_gate=%d lm_groups=%d knn_instance=%d knn_queries=%d "
            "knn_grid=%d/%d knn_partials=%d knn_saved_bound=%d knn_exact_only=%d line_gate_kernel=%d filter_local_map=%d mapping=%d "
-           "rotation_mode=%d table_size=%d rebuild_delta=%.3f knn_overlap=%d streams_concurrent=%d safe_mode=%d ring_split=%d debug=%d",
+           "rotation_mode=%d table_size=%d rebuild_delta=%.3f knn_overlap=%d streams_concurrent=%d safe_mode=%d ring_split=%d ring_split_max_wgs=%d debug=%d",
            h->S, v.early_rebuild, v.early_rebuild ? "streamed" : (h->lds_hash_build ? "lds" : "global"), h->use_flags ? 1 : 0,
            (h->use_flags && h->flag_gate) ? 1 : 0, v.lm_groups, h->S >= 16 ? 128 : 256, v.knn_queries, v.knn_grid,
            v.knn_blocks, v.knn_partials, v.knn_save_pos ? 2 : (v.knn_save_q ? 1 : 0), v.knn_exact_only, v.knn_nn ? 1 : 0, v.filter_local_map, v.mapping,
            v.rotation_mode, v.table_size, (double)v.rebuild_delta,
-           (v.early_rebuild && h->ov_ok && h->use_flags && g_live_handles.load() <= 1) ? 1 : 0, h->streams_concurrent ? 1 : 0, h->safe_mode ? 1 : 0, h->ring_split ? 1 : 0, v.debug);
+           (v.early_rebuild && h->ov_ok && h->use_flags && g_live_handles.load() <= 1) ? 1 : 0, h->streams_concurrent ? 1 : 0, h->safe_mode ? 1 : 0, h->ring_split ? 1 : 0, h->ring_split ? h->ring_split_max_wgs : 0, v.debug);
   return LIODOM_OK;
 }
 

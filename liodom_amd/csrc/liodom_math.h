@@ -758,13 +758,18 @@ LD_HD int lm_update(LmState& st, const double* acc) {
   LD_UNROLL
   for (int k = 0; k < 3; k++) dt[k] = st.t[k] - st.cand_t[k];
   // parameter tolerance: Ceres tests step_norm <= parameter_tolerance * (x_norm + parameter_tolerance) with step_norm =
-  // sqrt(step_sq).  Here the squares are compared (one FP64 square root less on the controller's lane, which is on the scan's
-  // critical path).  DEVIATION: the two forms can disagree only when sqrt(step_sq) rounds onto / across ptol, i.e. when step_norm
-  // and ptol agree to ~1 ulp (relative 2e-16) — tests/test_oracle_odometry.py::test_parameter_tolerance_on_squares_vs_ceres_form
-  // measures that band; the oracle uses this header, so GPU and oracle take the same decision in every case.
+  // sqrt(step_sq) (the oracle has exactly that expression, oracle/liodom_oracle.cc lm_solve).  The squares are compared first — no
+  // FP64 square root on the controller's lane, which is on the scan's critical path — and decide alone wherever the two forms
+  // cannot differ: sqrt is monotone and correctly rounded, so step_sq <= ptol^2 (1 - 1e-12) implies sqrt(step_sq) < ptol and
+  // step_sq > ptol^2 (1 + 1e-12) implies sqrt(step_sq) > ptol.  Inside that band (practically never) Ceres' own expression is
+  // evaluated, so the decision is Ceres' in every case (tests/test_oracle_odometry.py::test_parameter_tolerance_decision_is_the_ceres_form,
+  // tests/test_hostcheck.py::test_lm_update_on_the_parameter_tolerance_boundary).
   const double step_sq = dq[0] * dq[0] + dq[1] * dq[1] + dq[2] * dq[2] + dq[3] * dq[3] + dt[0] * dt[0] + dt[1] * dt[1] + dt[2] * dt[2];
   const double ptol = 1e-8 * (st.x_norm + 1e-8);
-  if (step_sq <= ptol * ptol) { st.termination = LM_TERM_PARAM_TOL; return LM_DONE; }
+  const double ptol_sq = ptol * ptol;
+  bool ptol_hit = step_sq <= ptol_sq * (1.0 - 1e-12);
+  if (!ptol_hit && step_sq <= ptol_sq * (1.0 + 1e-12)) ptol_hit = sqrt(step_sq) <= ptol;
+  if (ptol_hit) { st.termination = LM_TERM_PARAM_TOL; return LM_DONE; }
   const double cost_change = st.cost - cand_cost;
   if (fabs(cost_change) <= 1e-6 * st.cost) {
     st.termination = LM_TERM_FUNC_TOL;

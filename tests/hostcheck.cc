@@ -81,6 +81,21 @@ int hc_lm_controller(const double* acc29, int n_blocks, const double* q, const d
   *iterations = st.iter; *n_calls = k;
   return st.termination;
 }
+// lm_update's parameter-tolerance decision alone: the state is placed at (q, t) with the given |x|, the candidate at (cq, ct);
+// the accumulator repeats the current cost, so a step that does not end by parameter tolerance (1) ends by function tolerance (2).
+int hc_lm_ptol_decision(const double* q, const double* t, const double* cq, const double* ct, double x_norm) {
+  LmState st;
+  double acc[kAccN];
+  for (int i = 0; i < kAccN; i++) acc[i] = 0.0;
+  acc[0] = 1.0;
+  const double q0[4] = {0, 0, 0, 1}, t0[3] = {0, 0, 0};
+  (void)lm_begin(st, q0, t0, acc, 0, 0);          // (initialises every field; no residual blocks: returns at once)
+  for (int k = 0; k < 4; k++) { st.q[k] = q[k]; st.cand_q[k] = cq[k]; }
+  for (int k = 0; k < 3; k++) { st.t[k] = t[k]; st.cand_t[k] = ct[k]; }
+  st.x_norm = x_norm; st.cost = 1.0; st.model_cost_change = 1.0;
+  (void)lm_update(st, acc);
+  return st.termination;
+}
 float hc_sqdist(const float* a, const float* b) { return sqdist_f(a[0], a[1], a[2], b[0], b[1], b[2]); }
 
 }  // extern "C"

@@ -49,3 +49,23 @@ def test_no_cpu_fallback():
     env = dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env).stdout
     assert "REFUSED" in out and "CREATED" not in out
+
+
+def test_header_compiles_as_c_and_keeps_deprecated_names(tmp_path):
+    """include/liodom_hip.h is a C header: it must compile as C11 and as C++17, and source written against earlier versions of
+    it (LIODOM_STATUS_RING_OVERFLOW, liodom_config_t::max_ring_points) must still compile."""
+    import subprocess
+    src = ('#include "liodom_hip.h"\n'
+           'int f(void) { liodom_config_t c; liodom_config_default(&c); c.max_ring_points = 4096;\n'
+           '  return (int)(LIODOM_STATUS_RING_OVERFLOW | LIODOM_STATUS_EDGE_OVERFLOW) + c.reserved1 + (int)sizeof(liodom_params_t); }\n')
+    for name, cc, std in (("t.c", "gcc", "-std=c11"), ("t.cc", "g++", "-std=c++17")):
+        f = tmp_path / name
+        f.write_text(src)
+        subprocess.check_call([cc, std, "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), "-c", str(f), "-o", str(tmp_path / (name + ".o"))])
+    # the ctypes mirror has the same size as the C struct
+    probe = tmp_path / "sz.c"
+    probe.write_text('#include <stdio.h>\n#include "liodom_hip.h"\nint main(void) { printf("%zu %zu\\n", sizeof(liodom_config_t), sizeof(liodom_params_t)); return 0; }\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(probe), "-o", str(exe)])
+    a, b = subprocess.check_output([str(exe)], text=True).split()
+    assert int(a) == C.sizeof(la.Config) and int(b) == C.sizeof(la.Params)

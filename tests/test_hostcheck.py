@@ -42,6 +42,8 @@ def hc():
     L.hc_lm_solve.restype = C.c_int
     L.hc_lm_solve.argtypes = [dp, C.c_int, dp, dp, C.c_double, C.c_double, C.c_int,
                               C.POINTER(C.c_int), C.POINTER(C.c_int), dp, dp]
+    L.hc_lm_ptol_decision.restype = C.c_int
+    L.hc_lm_ptol_decision.argtypes = [dp, dp, dp, dp, C.c_double]
     return L
 
 
@@ -307,3 +309,26 @@ def test_invalid_step_halves_the_radius(hc, orc):
     orc.lib().orc_debug_fail_linear_solves(1)
     qo, to, tr = orc.lm_solve(blocks, q0, t0)
     assert tr.radius[1] == 1e4 and tr.radius[2] == 5e3 and tr.iterations >= 2
+
+
+def test_lm_update_on_the_parameter_tolerance_boundary(hc):
+    """Ceres' TrustRegionMinimizer ends a solve when step_norm <= parameter_tolerance * (x_norm + parameter_tolerance), with
+    step_norm = sqrt(step . step) (the oracle has that expression literally, oracle/liodom_oracle.cc lm_solve;
+    src/laser_odometry.cc:212-218 keeps the default 1e-8).  The product's lm_update compares squares and evaluates the literal
+    expression only inside a 1e-12 band around the boundary: driven ONTO the boundary (steps within +-40 ulp of ptol, and exactly
+    on it), its decision must be the literal one every time."""
+    eps = np.finfo(np.float64).eps
+    rng = np.random.default_rng(5)
+    n_hit = n_miss = 0
+    for x_norm in list(rng.uniform(0.5, 300.0, size=300)) + [1.0, 2.0, 64.0]:
+        ptol = 1e-8 * (x_norm + 1e-8)
+        for k in list(range(-40, 41)) + [-10 ** 5, 10 ** 5, -10 ** 9, 10 ** 9]:
+            step = ptol * (1.0 + k * eps)
+            q = np.array([0.0, 0.0, 0.0, 1.0]); t = np.array([1.0, 2.0, 3.0])
+            ct = t.copy(); ct[0] = t[0] - step          # dt = t - cand_t: one non-zero component, so step_sq = fl(d * d) in every build
+            d = t[0] - ct[0]
+            literal = np.sqrt(d * d) <= ptol
+            term = hc.hc_lm_ptol_decision(_dp(q), _dp(t), _dp(q.copy()), _dp(ct), x_norm)
+            assert term == (1 if literal else 2), "x_norm %r, %d ulp from the boundary: termination %d, Ceres form says %s" % (x_norm, k, term, literal)
+            n_hit += int(literal); n_miss += int(not literal)
+    assert n_hit > 5000 and n_miss > 5000

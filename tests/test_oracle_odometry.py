@@ -356,21 +356,26 @@ def test_match_edges_equals_the_odometers_own_loop(orc, synth):
     od.close()
 
 
-def test_parameter_tolerance_on_squares_vs_ceres_form():
-    """lm_update (liodom_math.h) tests the parameter tolerance on squares, step_sq <= ptol^2, where Ceres' TrustRegionMinimizer
-    tests sqrt(step_sq) <= ptol with ptol = 1e-8 (|x| + 1e-8).  The two decisions can differ only in a band of a few ulp around
-    the boundary: for step norms further than 4 ulp from ptol they agree, always."""
+def test_parameter_tolerance_decision_is_the_ceres_form():
+    """lm_update (liodom_math.h) decides the parameter tolerance on squares wherever that cannot differ from Ceres' form
+    sqrt(step_sq) <= ptol, ptol = 1e-8 (|x| + 1e-8) — outside a relative band of 1e-12 around ptol^2 — and evaluates Ceres' form itself
+    inside the band.  Checked here in NumPy: (a) the two forms can differ only within a few ulp of the boundary,
+    (b) never outside the band, (c) the banded decision equals the literal one everywhere."""
     rng = np.random.default_rng(11)
     x_norm = rng.uniform(0.5, 200.0, size=200000)
     ptol = 1e-8 * (x_norm + 1e-8)
-    # step norms within +-64 ulp of the boundary, and a broad sample
-    k = rng.integers(-64, 65, size=x_norm.size)
+    k = rng.integers(-64, 65, size=x_norm.size)          # step norms within +-64 ulp of the boundary
     step = ptol * (1.0 + k * np.finfo(np.float64).eps)
-    step_sq = step * step
-    lit = np.sqrt(step_sq) <= ptol
-    sq = step_sq <= ptol * ptol
-    differ = lit != sq
-    assert np.all(np.abs(k[differ]) <= 4), "decisions differ %d ulp from the boundary" % np.abs(k[differ]).max()
     broad = ptol * rng.uniform(0.0, 3.0, size=x_norm.size)
-    far = np.abs(broad / ptol - 1.0) > 1e-12
-    assert np.array_equal((np.sqrt(broad * broad) <= ptol)[far], (broad * broad <= ptol * ptol)[far])
+    for st in (step, broad):
+        step_sq = st * st
+        lit = np.sqrt(step_sq) <= ptol
+        p2 = ptol * ptol
+        banded = step_sq <= p2 * (1.0 - 1e-12)
+        inside = ~banded & (step_sq <= p2 * (1.0 + 1e-12))
+        banded = banded | (inside & lit)
+        assert np.array_equal(banded, lit)
+        squares = step_sq <= p2
+        assert np.array_equal(squares[~inside & ~(step_sq <= p2 * (1.0 - 1e-12))], lit[~inside & ~(step_sq <= p2 * (1.0 - 1e-12))])
+    differ = (np.sqrt(step * step) <= ptol) != (step * step <= ptol * ptol)
+    assert np.all(np.abs(k[differ]) <= 4)      # (a): wherever squares alone differ from Ceres' decision, it is on the knife edge
