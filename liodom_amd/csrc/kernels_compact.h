@@ -33,6 +33,10 @@ __global__ __launch_bounds__(256) void k_compact_edges(DevView v, int s0, int eb
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     const int acc = pre[256];
     v.state[s].n_edges_buf[eb] = acc > v.edge_cap ? v.edge_cap : acc;
+    if (v.edge_cnt && s < 32) {      // (chain mode: the first solve's launch is resident before this extraction may have run)
+      typedef __attribute__((address_space(1))) unsigned int gu32;
+      __hip_atomic_store((gu32*)(v.edge_cnt + eb * 32 + s), (unsigned int)(acc > v.edge_cap ? v.edge_cap : acc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (to_host) v.host_edges_hdr[kEdgePipeBufs + eb] = (unsigned int)(acc > v.edge_cap ? v.edge_cap : acc);
   }
   const int E = pre[H] > v.edge_cap ? v.edge_cap : pre[H];

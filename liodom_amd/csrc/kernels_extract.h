@@ -294,10 +294,11 @@ __global__ __launch_bounds__(kTileThreads) void k_ring_split(DevView v, int s0, 
     // arrive; then wait for the stream's other tiles
     atomicAdd(&v.split_ctr[2 * s + 1], 1u);
     unsigned int spins = 0;
+    unsigned long long t0w = 0;
     bool ok = true;
     while (__hip_atomic_load((gu32*)(v.split_ctr + 2 * s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)ntiles) {
       __builtin_amdgcn_s_sleep(2);
-      if (++spins > 4000000u) { ok = false; break; }
+      if (++spins > 4000000u || wait_expired(spins, t0w)) { ok = false; break; }
     }
     if (!ok) atomicOr(&v.state[s].status, LIODOM_STATUS_PIPE_TIMEOUT);
     sh_ok = ok ? 1 : 0;

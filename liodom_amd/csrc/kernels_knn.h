@@ -263,6 +263,7 @@ __device__ __forceinline__ void knn_merge(Top5& t, Top5& g, int hl, int half_shi
 // win: 8 (256 threads) on handles with few streams, 4 (128 threads) on lock-step batches; two instances, chosen by
 // the host from the stream count.
 __device__ void rebuild_alloc(const DevView& v, int s, StreamState& st, int block, int nblocks);
+__device__ void rebuild_count_and_pad(const DevView& v, int s, StreamState& st, int eb, int block, int* sbase, int* sslot);
 
 // LDS of one k_knn workgroup (kQ queries)
 template <int kQ>
@@ -292,7 +293,7 @@ __device__ __forceinline__ float best2_bound(const Best2Acc& t, int half_shift) 
 // cell is lane 13) and, on lane 27, the overflow list of the streamed rebuild.  lb = lower bound of the float squared
 // distance from q to any point of the segment (see knn_block).
 template <class Tune>
-__device__ __forceinline__ void knn_probe_cells(const DevView& v, const StreamState& st, int hl, int cx, int cy, int cz, float qx, float qy, float qz,
+__device__ __forceinline__ void knn_probe_cells(const DevView& v, const StreamState& st, int fc, int hl, int cx, int cy, int cz, float qx, float qy, float qz,
                                                 const CellSlot* cells, const unsigned int* bits, unsigned int tmask,
                                                 unsigned int& start, unsigned int& cnt, float& lb) {
   if (hl < 27) {
@@ -330,7 +331,7 @@ __device__ __forceinline__ void knn_probe_cells(const DevView& v, const StreamSt
     lb = (ex * ex + ey * ey + ez * ez) * (1.0f - 1e-5f);
   } else if (hl == 27 && v.early_rebuild) {
     start = (unsigned int)v.ovf_base;
-    cnt = (unsigned int)st.n_ovf[LD_TAB_PARITY(v, st.frame_count)];
+    cnt = (unsigned int)st.n_ovf[LD_TAB_PARITY(v, fc)];
   }
 }
 
@@ -354,7 +355,7 @@ constexpr float kOvMargin = 0.03f;
 constexpr float kOvMarginPerMetre = LIODOM_OV_MARGIN_PER_M;      // + 4 mm per metre of range (sensor frame)
 constexpr float kOvMarginMax = 0.30f;
 template <int kKnnThreads>
-__device__ __forceinline__ void knn_presearch(const DevView& v, int s, const StreamState& st, int e, int E,
+__device__ __forceinline__ void knn_presearch(const DevView& v, int s, const StreamState& st, int fc, int e, int E,
                                               KnnShared<kKnnThreads / kKnnGroup>& sh, KnnPre& pre, float range) {
   typedef KnnTune<(kKnnThreads >= 256)> Tune;
   const int grp = threadIdx.x / kKnnGroup, hl = threadIdx.x & (kKnnGroup - 1);
@@ -371,13 +372,13 @@ __device__ __forceinline__ void knn_presearch(const DevView& v, int s, const Str
   if (!act) return;                                // (uniform over the half-wave)
   const int cx = (int)floorf(qx * kCellInv), cy = (int)floorf(qy * kCellInv), cz = (int)floorf(qz * kCellInv);
   const unsigned int tmask = st.table_mask;
-  const int stab = s + LD_TAB_PARITY(v, st.frame_count) * v.n_streams;
+  const int stab = s + LD_TAB_PARITY(v, fc) * v.n_streams;
   const CellSlot* cells = v.cells + (size_t)stab * v.table_size;
   const unsigned int* bits = v.cell_bits + (size_t)stab * (v.table_size >> 5);
   const float4* sp = v.sorted_pts + (size_t)stab * v.sorted_cap;
   unsigned int start = 0, cnt = 0;
   float lb = 0.0f;
-  knn_probe_cells<Tune>(v, st, hl, cx, cy, cz, qx, qy, qz, cells, bits, tmask, start, cnt, lb);
+  knn_probe_cells<Tune>(v, st, fc, hl, cx, cy, cz, qx, qy, qz, cells, bits, tmask, start, cnt, lb);
   // everything within sqrt(min(d5_old, 1)) + margin of q_old (beyond the 1.0 gate nothing can matter: :324).  The margin grows
   // with the point's range: the first solve corrects the predicted pose by a rotation too, which moves a point 50 m out by
   // centimetres (measured: 7.7 % of the queries moved by more than 1 cm, 4.3 % by more than the flat 3 cm margin of round 3 —
@@ -407,8 +408,10 @@ __device__ __forceinline__ void knn_presearch(const DevView& v, int s, const Str
 // One block of kKnnThreads / 32 queries (virtual block index bv).  Whole workgroup; returns are workgroup-uniform.
 // kPre (overlapped second pass): what the re-ranking loads is in `pre` already, and the solve's start point (q, t) comes
 // from qt (LDS) — the stream's state is still being written by the first solve's launch.
-template <int kKnnThreads, bool kPre = false, bool kTail = true>
-__device__ __forceinline__ void knn_block(const DevView& v, int s, StreamState& st, int outer_it, int eb, int bv, int E,
+// kWt: the results leave as write-through stores (another launch of the handle — on another XCD, already running — reads them after
+// this workgroup's done flag): the overlapped second pass, and the first pass in chain mode.  fc: frames appended so far (table parity).
+template <int kKnnThreads, bool kPre = false, bool kTail = true, bool kWt = kPre>
+__device__ __forceinline__ void knn_block(const DevView& v, int s, StreamState& st, int fc, int outer_it, int eb, int bv, int E,
                                           KnnShared<kKnnThreads / kKnnGroup>& sh, const float4& p_in, const double (&T_in)[12],
                                           const KnnPre& pre, const double* qt) {
   constexpr int kKnnQueries = kKnnThreads / kKnnGroup;
@@ -445,7 +448,7 @@ __device__ __forceinline__ void knn_block(const DevView& v, int s, StreamState& 
   if (active) {                                    // uniform over each 32-lane half
     const int cx = (int)floorf(qx * kCellInv), cy = (int)floorf(qy * kCellInv), cz = (int)floorf(qz * kCellInv);
     const unsigned int tmask = st.table_mask;
-    const int stab = s + LD_TAB_PARITY(v, st.frame_count) * v.n_streams;
+    const int stab = s + LD_TAB_PARITY(v, fc) * v.n_streams;
     const CellSlot* cells = v.cells + (size_t)stab * v.table_size;
     const unsigned int* bits = v.cell_bits + (size_t)stab * (v.table_size >> 5);
     const float4* sp = v.sorted_pts + (size_t)stab * v.sorted_cap;
@@ -555,7 +558,7 @@ __device__ __forceinline__ void knn_block(const DevView& v, int s, StreamState& 
     // pruned point look closer than the bound.
     unsigned int start = 0, cnt = 0;
     float lb = 0.0f;
-    knn_probe_cells<Tune>(v, st, hl, cx, cy, cz, qx, qy, qz, cells, bits, tmask, start, cnt, lb);
+    knn_probe_cells<Tune>(v, st, fc, hl, cx, cy, cz, qx, qy, qz, cells, bits, tmask, start, cnt, lb);
     DBG_STAMP(v, dbgb, 1, 2); DBG_QSTAMP(2);
     // Pruning bound B: an upper bound of the query's fifth-nearest distance (never above the 1.0 gate: points at
     // >= 1.0 cannot be part of a match, :324); a segment is skipped only if lb > B, so the result is exact.
@@ -628,7 +631,7 @@ __device__ __forceinline__ void knn_block(const DevView& v, int s, StreamState& 
       d5 = g.p4 >= 0 ? top5_dist(g.k4) : __int_as_float(0x7f800000);       // (a sentinel among the five: fewer than five candidates inside the gate)
       pos5[0] = g.p0; pos5[1] = g.p1; pos5[2] = g.p2; pos5[3] = g.p3; pos5[4] = g.p4;
     }
-    if (outer_it == 0 && v.knn_save_pos) {
+    if (outer_it == 0 && v.knn_save_pos && !(kWt && !kPre)) {      // (chain mode: the second pass is the overlapped one, which searches around knn_save_q itself)
       // what the second pass re-ranks: the lanes' kept candidates and the guard (see above)
       const float sk = (cnt > 0 && !(!(lb > B) || (!have_b && (hl == 13 || hl == 27 || lb <= Tune::kNearSq)))) ? lb : __int_as_float(0x7f800000);   // pruned, non-empty segment
       unsigned int gd = half_min_u32((unsigned int)__float_as_int(sk));
@@ -707,7 +710,7 @@ __device__ __forceinline__ void knn_block(const DevView& v, int s, StreamState& 
       const float4 oa = valid ? make_float4(nx[0], ny[0], nz[0], 1.0f) : make_float4(0, 0, 0, 0);              // :351-353
       const float4 ob = valid ? make_float4(nx[1], ny[1], nz[1], 0.0f) : make_float4(0, 0, 0, 0);              // :355-357
       const int2 oi = valid ? make_int2(sh.res[q][1], sh.res[q][2]) : make_int2(-1, -1);
-      if (kPre) {
+      if (kWt) {
         // (overlapped pass: the finalising solve's launch is already running on other XCDs — write-through stores)
         wt_store_f4(ca, oa); wt_store_f4(cb, ob);
         wt_store_u64(cidx, ((unsigned long long)(unsigned int)oi.y << 32) | (unsigned int)oi.x);
@@ -722,7 +725,7 @@ __device__ __forceinline__ void knn_block(const DevView& v, int s, StreamState& 
       // every workgroup: hot-address atomics delay whatever else maps to that memory channel by microseconds)
       if (nvalid && !v.knn_partials) atomicAdd(&st.info.matches[outer_it], nvalid);
       unsigned char* cm = &v.corr_mask[((size_t)s * 2 + outer_it) * v.mask_stride + bv];   // bit q = query q accepted
-      if (kPre) wt_store_u8(cm, (unsigned char)vb); else *cm = (unsigned char)vb;
+      if (kWt) wt_store_u8(cm, (unsigned char)vb); else *cm = (unsigned char)vb;
     }
     sh.res[q][3] = valid ? 1 : 0;
   } else if (kKnnThreads > 64 && v.knn_partials && threadIdx.x >= 64 && threadIdx.x < 64 + kKnnQueries) {
@@ -774,7 +777,7 @@ __device__ __forceinline__ void knn_block(const DevView& v, int s, StreamState& 
 #pragma unroll
     for (int q = 0; q < kKnnQueries; q++) x += sh.part[q][threadIdx.x];      // fixed order: deterministic
     double* dst = &v.knn_part[(((size_t)s * 2 + outer_it) * v.knn_blocks + bv) * 32 + threadIdx.x];
-    if (kPre) wt_store_u64(dst, (unsigned long long)__double_as_longlong(x)); else *dst = x;
+    if (kWt) wt_store_u64(dst, (unsigned long long)__double_as_longlong(x)); else *dst = x;
   }
   DBG_STAMP(v, dbgb, 1, 7); DBG_QSTAMP(7);
   if ((kInstrument && (v.debug & 64)) && s == 0 && threadIdx.x == 0) {      // histogram of workgroup durations, 1 us bins
@@ -873,16 +876,30 @@ __device__ __forceinline__ void knn_tail_dual(const DevView& v, int s, int outer
 // that found nothing to do.
 // kOv: the overlapped second pass (see "Overlapped second kNN pass" above; one-stream handles, the 256-thread instance):
 // launched on stream_k beside the scan's first solve, seq = the launch sequence number the flags carry.
-template <int kKnnThreads, bool kOv>
+// kChain: the FIRST pass of a scan in chain mode (kernels_sync.h "Chain mode"): it runs on the stream of the kNN passes and the
+// rebuild, behind the previous scan's APPEND launch; the scan's first solve — on the other stream — is resident already and waits
+// for this pass's done flags, so the results leave write-through.  The prediction the scan starts from comes from pred_xch
+// (the previous scan's finalize_scan may still be running: its plain stores to the stream's state are not visible yet);
+// everything else this pass needs of that state follows from scan_no, the number of scans completed before this one.
+template <int kKnnThreads, bool kOv, bool kChain>
 __device__ __forceinline__ void knn_pass(const DevView& v, int s, int bxi, int byi, int outer_it, int eb, unsigned int wait_edges,
-                                         unsigned int signal_odo, unsigned int seq, KnnShared<kKnnThreads / kKnnGroup>& sh, KnnShared<kKnnThreads / kKnnGroup>& sh2, double* sh_ov) {
+                                         unsigned int signal_odo, unsigned int seq, int scan_no, KnnShared<kKnnThreads / kKnnGroup>& sh, KnnShared<kKnnThreads / kKnnGroup>& sh2, double* sh_ov) {
   constexpr int kKnnQueries = kKnnThreads / kKnnGroup;
+  static_assert(!(kOv && kChain), "the overlapped pass is the second pass, the chain-mode instance the first");
   StreamState& st = v.state[s];
   if (kOv) {
     // the scan's first solve launch has started: the first kNN pass (and everything before it) has completed
     // (k_ov_gate in front of this launch has seen the flag already: the launch started, with clean caches, after the first pass ended)
     if (!pipe_wait(v.ov_flags + s, seq, &st.status)) return;
     OV_STAMP(v, threadIdx.x == 0 && bxi == 0, 9); OV_STAMP(v, threadIdx.x == 0 && bxi == v.knn_grid - 1, 13);
+  } else if (kChain) {
+    // the prediction (12 doubles, tag = scans completed; normally there long before this launch starts) and, in the same round
+    // trip, the flag of the extraction that fills edge buffer eb
+    if (!pred_wait(v, s, bxi % kOvReplicas, (unsigned int)scan_no, sh_ov, &st.status, v.pipe_flags + eb, wait_edges)) return;
+    OV_STAMP(v, threadIdx.x == 0 && bxi == 0, 27);
+    // bookkeeping of the streamed rebuild, as below — from scan_no: every scan appends exactly one frame (finalize_scan)
+    if (bxi == 0 && threadIdx.x == 0) { st.reb_frame_count = scan_no; st.n_used_tab[(scan_no + 1) & 1] = 0; st.reb_initialized = 1; st.cursor = 0; }
+    if (bxi == 0 && threadIdx.x >= 64 && threadIdx.x < 76) st.pred_odom[threadIdx.x - 64] = sh_ov[threadIdx.x - 64];
   } else if (v.early_rebuild) {
     if (bxi >= v.knn_grid) { if (outer_it == 1) rebuild_alloc(v, s, st, bxi - v.knn_grid, (int)gridDim.x - v.knn_grid); return; }
     // streamed rebuild, bookkeeping before the first builders start (next launch): the frame count the build refers to
@@ -890,17 +907,19 @@ __device__ __forceinline__ void knn_pass(const DevView& v, int s, int bxi, int b
     // prediction the scan starts from
     if (outer_it == 0 && bxi == 0 && threadIdx.x == 0) {
       st.reb_frame_count = st.frame_count; st.n_used_tab[(st.frame_count + 1) & 1] = 0; st.reb_initialized = st.initialized;
+      st.cursor = 0;      // (finalize_scan has reset it already, unless the previous scan ran in chain mode)
     }
     if (outer_it == 0 && bxi == 0 && threadIdx.x >= 64 && threadIdx.x < 76) st.pred_odom[threadIdx.x - 64] = st.odom[threadIdx.x - 64];
   }
   if (!kOv && outer_it == 0) {
-    // (pipelined replay) this launch follows odometry `signal_odo` in stream order: that odometry has completed entirely;
-    // and the extraction that fills edge buffer eb (other stream) must have completed before anything of it is read
+    // (pipelined replay) this launch follows odometry `signal_odo` in stream order: that odometry has completed entirely
+    // (chain mode: its last reads of its edge buffer have); and the extraction that fills edge buffer eb (other stream) must have
+    // completed before anything of it is read
     if (signal_odo && bxi == 0 && byi == 0 && threadIdx.x == 0) {
       typedef __attribute__((address_space(1))) unsigned int gu32;
       __hip_atomic_store((gu32*)(v.pipe_flags + kEdgePipeBufs), signal_odo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (wait_edges && !pipe_wait(v.pipe_flags + eb, wait_edges, &st.status)) return;
+    if (!kChain && wait_edges && !pipe_wait(v.pipe_flags + eb, wait_edges, &st.status)) return;
   }
   // The block's first loads — its edge, the pose — leave together with the stream's state words instead of behind the
   // branches on them (one memory round trip less on the launch's critical path; the edge index is clamped, an unused
@@ -911,23 +930,29 @@ __device__ __forceinline__ void knn_pass(const DevView& v, int s, int bxi, int b
   double T[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (Tune::kHoistLoads) {
     p_first = v.edges[((size_t)eb * v.n_streams + s) * v.edge_cap + (e_first < v.edge_cap ? e_first : v.edge_cap - 1)];
-    if (!kOv) {
+    if (!kOv && !kChain) {
 #pragma unroll
       for (int i = 0; i < 12; i++) T[i] = st.odom[i];
     }
   }
+  if (kChain) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) T[i] = sh_ov[i];
+  }
   const unsigned int st_status = st.status;
-  const int st_init = st.initialized;
+  const int st_init = kChain ? 1 : st.initialized;
+  const int fc = kChain ? scan_no : st.frame_count;
   const int E = st.n_edges_buf[eb];
   if (st_status & LIODOM_STATUS_PIPE_TIMEOUT) return;      // (uniform) a wait of this handle gave up: the edge buffer may be incomplete
   if (!st_init) return;                            // uniform over the workgroup
   // (two explicit calls, not a loop over bv: as a loop body the block needs 160 VGPRs instead of 69)
   static_assert(kKnnGridDiv == 2, "k_knn handles exactly two query blocks per workgroup");
+  constexpr bool kWt = kOv || kChain;
   if (bxi * kKnnQueries >= E) {             // no query here: empty validity bytes for the solve's compaction
     if (threadIdx.x == 0) {
       unsigned char* cm = &v.corr_mask[((size_t)s * 2 + outer_it) * v.mask_stride + bxi];
-      if (kOv) wt_store_u8(cm, 0); else *cm = 0;
-      if (bxi + v.knn_grid < v.knn_blocks) { if (kOv) wt_store_u8(cm + v.knn_grid, 0); else cm[v.knn_grid] = 0; }
+      if (kWt) wt_store_u8(cm, 0); else *cm = 0;
+      if (bxi + v.knn_grid < v.knn_blocks) { if (kWt) wt_store_u8(cm + v.knn_grid, 0); else cm[v.knn_grid] = 0; }
     }
     return;
   }
@@ -939,8 +964,8 @@ __device__ __forceinline__ void knn_pass(const DevView& v, int s, int bxi, int b
   if (kOv) {
     // everything the two blocks need apart from the solve's result; then wait for that
     if (second) p_second = v.edges[((size_t)eb * v.n_streams + s) * v.edge_cap + (e_second < v.edge_cap ? e_second : v.edge_cap - 1)];
-    knn_presearch<kKnnThreads>(v, s, st, e_first, E, sh, pre1, sqrtf(p_first.x * p_first.x + p_first.y * p_first.y + p_first.z * p_first.z));
-    if (second) knn_presearch<kKnnThreads>(v, s, st, e_second, E, sh2, pre2, sqrtf(p_second.x * p_second.x + p_second.y * p_second.y + p_second.z * p_second.z));
+    knn_presearch<kKnnThreads>(v, s, st, fc, e_first, E, sh, pre1, sqrtf(p_first.x * p_first.x + p_first.y * p_first.y + p_first.z * p_first.z));
+    if (second) knn_presearch<kKnnThreads>(v, s, st, fc, e_second, E, sh2, pre2, sqrtf(p_second.x * p_second.x + p_second.y * p_second.y + p_second.z * p_second.z));
     else pre2.gsq = 0.f;
     if (!ov_wait_pose(v, s, bxi % kOvReplicas, seq, sh_ov, &st.status)) return;
     OV_STAMP(v, threadIdx.x == 0 && bxi == 0, 10); OV_STAMP(v, threadIdx.x == 0 && bxi == v.knn_grid - 1, 14);
@@ -955,17 +980,17 @@ __device__ __forceinline__ void knn_pass(const DevView& v, int s, int bxi, int b
   }
   if constexpr (kOv) {
     // both blocks' queries, then their gates and partial sums side by side
-    knn_block<kKnnThreads, true, false>(v, s, st, outer_it, eb, bxi, E, sh, p_first, T, pre1, sh_ov + 12);
-    if (second) knn_block<kKnnThreads, true, false>(v, s, st, outer_it, eb, bv2, E, sh2, p_second, T, pre2, sh_ov + 12);
+    knn_block<kKnnThreads, true, false>(v, s, st, fc, outer_it, eb, bxi, E, sh, p_first, T, pre1, sh_ov + 12);
+    if (second) knn_block<kKnnThreads, true, false>(v, s, st, fc, outer_it, eb, bv2, E, sh2, p_second, T, pre2, sh_ov + 12);
     else if (bv2 < v.knn_blocks && threadIdx.x == 0) wt_store_u8(&v.corr_mask[((size_t)s * 2 + outer_it) * v.mask_stride + bv2], 0);
     __syncthreads();
     knn_tail_dual<kKnnThreads>(v, s, outer_it, eb, bxi, bv2, second, E, sh, sh2, sh_ov + 12);
     return;
   }
-  knn_block<kKnnThreads, false>(v, s, st, outer_it, eb, bxi, E, sh, p_first, T, pre1, nullptr);
+  knn_block<kKnnThreads, false, true, kWt>(v, s, st, fc, outer_it, eb, bxi, E, sh, p_first, T, pre1, nullptr);
   if (bv2 >= v.knn_blocks) return;
   if (!second) {
-    if (threadIdx.x == 0) { unsigned char* cm = &v.corr_mask[((size_t)s * 2 + outer_it) * v.mask_stride + bv2]; if (kOv) wt_store_u8(cm, 0); else *cm = 0; }
+    if (threadIdx.x == 0) { unsigned char* cm = &v.corr_mask[((size_t)s * 2 + outer_it) * v.mask_stride + bv2]; if (kWt) wt_store_u8(cm, 0); else *cm = 0; }
     return;
   }
   __syncthreads();                          // (the second block reuses the LDS)
@@ -973,14 +998,19 @@ __device__ __forceinline__ void knn_pass(const DevView& v, int s, int bxi, int b
   if (Tune::kHoistLoads) {
     p_second = v.edges[((size_t)eb * v.n_streams + s) * v.edge_cap + (e_second < v.edge_cap ? e_second : v.edge_cap - 1)];
     asm volatile("" ::: "memory");
+    if (kChain) {
 #pragma unroll
-    for (int i = 0; i < 12; i++) T2[i] = st.odom[i];
+      for (int i = 0; i < 12; i++) T2[i] = sh_ov[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 12; i++) T2[i] = st.odom[i];
+    }
   }
-  knn_block<kKnnThreads, false>(v, s, st, outer_it, eb, bv2, E, sh, p_second, T2, pre2, nullptr);
+  knn_block<kKnnThreads, false, true, kWt>(v, s, st, fc, outer_it, eb, bv2, E, sh, p_second, T2, pre2, nullptr);
 }
 
-template <int kKnnThreads, bool kOv = false>
-__global__ __launch_bounds__(kKnnThreads, (kKnnThreads >= 256 ? 1 : LIODOM_TUNE_B_WAVES)) void k_knn(DevView v, int s0, int outer_it, int eb, unsigned int wait_edges, unsigned int signal_odo, unsigned int seq) {
+template <int kKnnThreads, bool kOv = false, bool kChain = false>
+__global__ __launch_bounds__(kKnnThreads, (kKnnThreads >= 256 ? 1 : LIODOM_TUNE_B_WAVES)) void k_knn(DevView v, int s0, int outer_it, int eb, unsigned int wait_edges, unsigned int signal_odo, unsigned int seq, int scan_no) {
   constexpr int kKnnQueries = kKnnThreads / kKnnGroup;
 #if defined(LIODOM_CHAIN_PRIO)
   // Few-stream handles: this kernel is a link of the scan's dependent chain, the next scan's extraction kernels (other HIP stream)
@@ -990,15 +1020,27 @@ __global__ __launch_bounds__(kKnnThreads, (kKnnThreads >= 256 ? 1 : LIODOM_TUNE_
 #endif
   __shared__ KnnShared<kKnnQueries> shs[kOv ? 2 : 1];      // (overlapped pass: one per query block — their tails run side by side)
   KnnShared<kKnnQueries>& sh = shs[0];
-  __shared__ double sh_ov[kOv ? 20 : 1];       // overlapped pass: the first solve's odom[12], q[4], t[3]
+  __shared__ double sh_ov[(kOv || kChain) ? 20 : 1];       // overlapped pass: the first solve's odom[12], q[4], t[3]; chain mode: the prediction
   int bxi = (int)blockIdx.x, byi = (int)blockIdx.y;
   xcd_remap(bxi, byi);
   const int s = s0 + byi;
+  if constexpr (kOv) {
+    // chain mode: COUNT + PAD of the streamed rebuild as extra workgroups of the second pass's launch (light ones: 256 threads at
+    // this kernel's register budget), beside the pass's search and its wait for the first solve.  (As a launch of their own in
+    // front of the pass they took 20 us, and the pass behind them no longer ran beside the solve.)
+    if (bxi >= v.knn_grid) {
+      __shared__ int sh_rb_cnt[kMaxFrames + 1];
+      __shared__ int sh_rb_slot[kMaxFrames];
+      rebuild_count_and_pad(v, s, v.state[s], eb, bxi - v.knn_grid, sh_rb_cnt, sh_rb_slot);
+      return;
+    }
+  }
   if (kInstrument && kOv && threadIdx.x == 0) sh_ov[19] = 0.0;
   if (kOv) { OV_STAMP(v, threadIdx.x == 0 && bxi == 0, 8); OV_STAMP(v, threadIdx.x == 0 && bxi == v.knn_grid - 1, 12); }
   else if (outer_it == 0) OV_STAMP(v, threadIdx.x == 0 && bxi == 0, 16);
-  knn_pass<kKnnThreads, kOv>(v, s, bxi, byi, outer_it, eb, wait_edges, signal_odo, seq, sh, shs[kOv ? 1 : 0], sh_ov);
+  knn_pass<kKnnThreads, kOv, kChain>(v, s, bxi, byi, outer_it, eb, wait_edges, signal_odo, seq, scan_no, sh, shs[kOv ? 1 : 0], sh_ov);
   if (kOv) ov_signal_knn_done(v, s, bxi, seq);       // (every exit of the pass is workgroup-uniform)
+  if (kChain) chain_count_done(v.knn_done0 + s);
   if (kInstrument && (v.debug & 128) && threadIdx.x == 0) {
     if (kOv) {                                         // (debug) pose seen -> flag raised, per workgroup with queries: 0.5 us bins
       const long long t_seen = __double_as_longlong(sh_ov[19]);

@@ -185,7 +185,10 @@ __device__ __forceinline__ void publish_final_pose(const DevView& v, int s, cons
 // Called by the whole workgroup.  sh_cnt: LDS scratch of kMaxFrames + 1 ints.
 // Thread 64 publishes the result (pose log, host-mapped record) while thread `ctl` (the one that wrote st.odom)
 // computes the prediction and the window bookkeeping; the remaining threads fetch the frame sizes.
-__device__ void finalize_scan(const DevView& v, int s, StreamState& st, int* sh_cnt, int eb, bool clear_hash, int ctl) {
+// chain: the rebuild of this scan runs on the other HIP stream, beside this launch (ALLOC may still be allocating cell ranges from
+// st.cursor): the cursor is then reset by the next scan's first kNN pass, which follows the rebuild in stream order.
+__device__ void finalize_scan(const DevView& v, int s, StreamState& st, int* sh_cnt, int eb, bool clear_hash, int ctl, int chain = 0) {
+  __shared__ double sh_pred[12];
   const int P = v.prev_frames;
   const int tid = threadIdx.x;
   // LocalMapManager::addPointCloud (:34-60) on a ring of P frame slots: the new frame goes
@@ -238,7 +241,7 @@ __device__ void finalize_scan(const DevView& v, int s, StreamState& st, int* sh_
     iso_inverse(st.prev_odom, inv);
     iso_mul(inv, st.final_odom, rel);
     iso_mul(st.final_odom, rel, pred);
-    for (int i = 0; i < 12; i++) { st.prev_odom[i] = st.final_odom[i]; st.odom[i] = pred[i]; }
+    for (int i = 0; i < 12; i++) { st.prev_odom[i] = st.final_odom[i]; st.odom[i] = pred[i]; sh_pred[i] = pred[i]; }
     quat_from_pose(pred, v.rotation_mode, st.param_q);               // :186-190 q_curr(odom_.rotation())
     st.param_t[0] = pred[3]; st.param_t[1] = pred[7]; st.param_t[2] = pred[11];   // :192-195
     wn[new_slot] = n_edges;
@@ -250,9 +253,12 @@ __device__ void finalize_scan(const DevView& v, int s, StreamState& st, int* sh_
     st.n_map = acc;
     if (!v.early_rebuild) st.n_used_tab[0] = 0;
     else { st.n_search = acc; st.n_filt = 0; }        // (k_window_insert's job otherwise)
-    st.cursor = 0;
+    if (!chain) st.cursor = 0;
   }
   __syncthreads();
+  // chain mode: the next scan's first kNN pass runs on the other HIP stream and may start before this launch has ended (it follows
+  // the APPEND launch): the prediction it starts from travels as tagged granules (tag = scans completed)
+  if (v.pred_xch) pred_publish(v, s, sh_pred, (unsigned int)fc_new, tid);
   for (int j = tid; j <= nf; j += blockDim.x) wb[j] = sh_cnt[j];
   // (first frame only; in steady state the finalising solve clears the table beside its first
   // controller step instead of extending the kernel by ~4.5 us here)
@@ -292,6 +298,7 @@ __device__ void lm_exchange(const DevView& v, int s, int g, int G, unsigned int 
   if (tid < 64) {
     double tot = 0.0;
     unsigned int spins = 0;
+    unsigned long long t0w = 0;
     bool same = true;
     while (true) {
       bool ok = true;
@@ -317,7 +324,7 @@ __device__ void lm_exchange(const DevView& v, int s, int g, int G, unsigned int 
         }
       }
       if (__all(ok)) break;
-      if (++spins > 4000000u) { if (tid == 0) atomicOr(status, LIODOM_STATUS_LM_SYNC_TIMEOUT); same = false; break; }
+      if (++spins > 4000000u || __any(wait_expired(spins, t0w))) { if (tid == 0) atomicOr(status, LIODOM_STATUS_LM_SYNC_TIMEOUT); same = false; break; }
       __builtin_amdgcn_s_sleep(1);
     }
     if (tid < kAccN) acc_total[tid] = tot;
@@ -362,7 +369,10 @@ __global__ void k_imu_override(DevView v, int s0, int count) {
 
 __device__ void rebuild_beside_solve(const DevView& v, int s, StreamState& st, int eb, int outer_it, int block, int nblocks, unsigned int seq, int* sbase, int* sslot);
 
-__global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int outer_it, int eb, unsigned int seq) {
+// chain != 0 (chain mode, kernels_sync.h; done_target: the first pass's done count to wait for): the launch holds the solving workgroups only (the rebuild rides on the other stream as
+// launches of its own), and the FIRST solve's launch is resident while the first kNN pass still runs: it waits for that pass's
+// done flags before it touches anything the pass or the extraction wrote.
+__global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int outer_it, int eb, unsigned int seq, int chain, unsigned int done_target) {
   __shared__ double sh_pose[12];
   __shared__ double sh_acc[kAccN];
   __shared__ LmState lm;
@@ -388,7 +398,7 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
     __hip_atomic_store((gu32*)(v.ov_flags + s), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (g >= G) {
-    if (!v.early_rebuild) return;                  // (filler blocks between the solvers)
+    if (!v.early_rebuild || chain) return;         // (filler blocks between the solvers)
     // early_rebuild: the workgroups behind the solve build the next cell hash (see "streamed rebuild" below)
     __shared__ int sh_slot[kMaxFrames];
     rebuild_beside_solve(v, s, st, eb, outer_it, g - G, (int)gridDim.x - G, seq, sh_cnt, sh_slot);
@@ -400,8 +410,20 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
   double* sh_part = reinterpret_cast<double*>(sh_idx + ((v.edge_cap + 3) & ~3));   // [kAccN][kLmEvalThreads]
   const int tid = threadIdx.x;
   const bool prep = tid < kLmCtl;               // waves 0..6: compaction + register cache while the controller lane works
+  // chain mode, first solve: nothing of the stream's state that the extraction writes (n_edges_buf) and nothing of the first pass's
+  // results has been read so far; the pass's workgroups store write-through and raise one flag each
+  if (chain && outer_it == 0) chain_wait_count(v.knn_done0 + s, done_target, &st.status);      // (the count the pass's workgroups reach: wrap-safe comparison)
+  // (the edge count: the state word shares a cache line with fields that earlier launches on this XCD have read — since this launch
+  //  started, possibly before the extraction wrote it; k_compact_edges leaves a write-through copy in a line of its own)
+  int E_in;
+  if (chain && outer_it == 0) {
+    typedef __attribute__((address_space(1))) unsigned int gu32;
+    E_in = (int)__hip_atomic_load((gu32*)(v.edge_cnt + eb * 32 + s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    E_in = st.n_edges_buf[eb];
+  }
   if (outer_it == 0 && tid == 0 && g == 0) {     // per-scan diagnostics (matches are counted by k_knn)
-    st.info.n_edges = st.n_edges_buf[eb];
+    st.info.n_edges = E_in;
     st.info.map_points = st.n_search;
     for (int k = 0; k < 2; k++) {
       st.info.lm[k].iterations = 0; st.info.lm[k].accepted = 0; st.info.lm[k].termination = LM_TERM_NO_RESIDUALS;
@@ -431,7 +453,7 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
   const bool dbgb = (s == 0) && (g == 0) && (tid == kLmCtl) && (outer_it == 1);
   const bool dbge = (s == 0) && (g == 0) && (tid == 0) && (outer_it == 1);
   DBG_STAMP(v, dbgb, 2, 0);
-  const int E = st.n_edges_buf[eb];
+  const int E = E_in;
   int nblocks = st.info.matches[outer_it];      // (lock-step batches: counted by k_line_gate; else from k_knn's partial sums below)
   __shared__ int sh_nmatch;
   __shared__ double sh_scale[8];
@@ -562,7 +584,7 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
   }
   DBG_STAMP(v, dbgb, 2, 21);
   if (outer_it == 1) {
-    finalize_scan(v, s, st, sh_cnt, eb, false, kLmCtl);
+    finalize_scan(v, s, st, sh_cnt, eb, false, kLmCtl, chain);
     DBG_STAMP(v, dbgb, 2, 22);
   }
   DBG_STAMP(v, dbgb, 2, 28);

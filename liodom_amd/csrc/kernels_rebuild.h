@@ -328,14 +328,14 @@ __device__ void rebuild_finish(const DevView& v, int s, StreamState& st, int eb,
     typedef __attribute__((address_space(1))) unsigned long long gu64;
     const unsigned long long* base = v.pose_xch + (size_t)s * 32;
     const unsigned int tag = (unsigned int)fc + 1u;
-    unsigned long long g = 0;
+    unsigned long long g = 0, t0w = 0;
     unsigned int spins = 0;
     bool ok;
     while (true) {
       if (tid < 25) g = __hip_atomic_load((gu64*)(base + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       ok = tid >= 25 || (unsigned int)(g >> 32) == tag;
       if (__all(ok)) break;
-      if (++spins > 4000000u) break;
+      if (++spins > 4000000u || wait_expired(spins, t0w)) break;
       __builtin_amdgcn_s_sleep(2);
     }
     const bool all_ok = __all(ok);
@@ -348,6 +348,7 @@ __device__ void rebuild_finish(const DevView& v, int s, StreamState& st, int eb,
   __syncthreads();
   const bool dbga = (s == 0) && (block == 0) && (tid == 0);
   DBG_STAMP(v, dbga, 2, 29);
+  OV_STAMP(v, dbga, 28);
   if (sh_hand == 0 || !live) return;
   float4 pt;
   if (sh_hand == 2) {
@@ -392,12 +393,28 @@ __device__ void rebuild_finish(const DevView& v, int s, StreamState& st, int eb,
     sorted[v.ovf_base + i] = make_float4(pt.x, pt.y, pt.z, __int_as_float(m));
   }
   DBG_STAMP(v, dbga, 2, 30);
+  OV_STAMP(v, dbga, 26);
 }
 
 __device__ void rebuild_beside_solve(const DevView& v, int s, StreamState& st, int eb, int outer_it, int block, int nblocks, unsigned int seq, int* sbase, int* sslot) {
   (void)nblocks;
   if (outer_it == 0) rebuild_count_and_pad(v, s, st, eb, block, sbase, sslot);
   else rebuild_finish(v, s, st, eb, block, seq, sbase, sslot);
+}
+
+// Chain mode: the rebuild's steps as launches of their own on the stream of the kNN passes (light kernels: as extra workgroups of
+// k_lm_solve every one of them owned a whole CU — 256 VGPRs x 8 waves — and could only be placed on a CU that ran nothing else).
+__global__ __launch_bounds__(kLmThreads) void k_rebuild_cp(DevView v, int s0, int eb) {          // COUNT + PAD
+  __shared__ int sh_cnt[kMaxFrames + 1];
+  __shared__ int sh_slot[kMaxFrames];
+  const int s = s0 + blockIdx.y;
+  rebuild_count_and_pad(v, s, v.state[s], eb, (int)blockIdx.x, sh_cnt, sh_slot);
+}
+__global__ __launch_bounds__(kLmThreads) void k_rebuild_fin(DevView v, int s0, int eb) {         // APPEND (waits for the solved pose), CLEAR, SCATTER
+  __shared__ int sh_cnt[kMaxFrames + 1];
+  __shared__ int sh_slot[kMaxFrames];
+  const int s = s0 + blockIdx.y;
+  rebuild_finish(v, s, v.state[s], eb, (int)blockIdx.x, 0u, sh_cnt, sh_slot);      // (seq 0: the second kNN pass precedes this launch in stream order)
 }
 
 // Start offsets of the occupied cells (any order: only contiguity per cell matters).  One atomic

@@ -24,10 +24,11 @@ __device__ __forceinline__ bool pipe_wait(const unsigned int* flag, unsigned int
   __shared__ int s_pipe_ok;
   if (threadIdx.x == 0) {
     unsigned int spins = 0;
+    unsigned long long t0 = 0;
     bool ok = true;
     while ((int)(__hip_atomic_load((gu32*)flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
       __builtin_amdgcn_s_sleep(8);
-      if (++spins > 1500000u) { atomicOr(status, LIODOM_STATUS_PIPE_TIMEOUT); ok = false; break; }
+      if (++spins > 1500000u || wait_expired(spins, t0)) { atomicOr(status, LIODOM_STATUS_PIPE_TIMEOUT); ok = false; break; }
     }
     if (spins) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     s_pipe_ok = ok ? 1 : 0;
@@ -43,6 +44,14 @@ __global__ void k_pipe_gate(DevView v, int s0, int eb, unsigned int wait_edges, 
   if (signal_odo && threadIdx.x == 0) __hip_atomic_store((gu32*)(v.pipe_flags + kEdgePipeBufs), signal_odo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (wait_edges && !pipe_wait(v.pipe_flags + eb, wait_edges, &v.state[s0].status)) {
     // the launches behind the gate check the status bit of their own stream (k_knn) and skip the scan
+    for (int s = (int)threadIdx.x; s < v.n_streams; s += (int)blockDim.x) atomicOr(&v.state[s].status, LIODOM_STATUS_PIPE_TIMEOUT);
+  }
+}
+// Gate in front of the extraction of a host-fed scan: one wave waits until the copy stream has published the upload's sequence
+// number (hipStreamWriteValue32 / k_set_flag behind the hipMemcpyAsync) — the place of a hipStreamWaitEvent, whose barrier packet
+// costs ~11 us of idle stream.  The extraction kernels behind it start when it retires (kernel start: clean caches).
+__global__ void k_up_gate(DevView v, const unsigned int* flag, unsigned int want) {
+  if (!pipe_wait(flag, want, &v.state[0].status)) {
     for (int s = (int)threadIdx.x; s < v.n_streams; s += (int)blockDim.x) atomicOr(&v.state[s].status, LIODOM_STATUS_PIPE_TIMEOUT);
   }
 }
@@ -93,49 +102,120 @@ __device__ __forceinline__ void ov_publish_pose(const DevView& v, int s, const d
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
-// whole workgroup; the first wave polls replica rep until every granule carries the tag; out19: LDS.  false: gave up.
-__device__ __forceinline__ bool ov_wait_pose(const DevView& v, int s, int rep, unsigned int tag, double* out19, unsigned int* status) {
+// whole workgroup; the first wave polls `n_gran` (<= 64, even) tagged granules at `base` until every one carries the tag; out: LDS,
+// n_gran / 2 doubles.  false: gave up.
+template <int kPollSleep>
+__device__ __forceinline__ bool granules_wait(const unsigned long long* base, int n_gran, unsigned int tag, double* out, unsigned int* status) {
   typedef __attribute__((address_space(1))) unsigned long long gu64;
   __shared__ int s_ov_ok;
   const int tid = (int)threadIdx.x;
   if (tid < 64) {
-    const unsigned long long* base = v.pose_xch0 + ((size_t)s * kOvReplicas + rep) * 512;
-    unsigned long long g = 0;
+    unsigned long long g = 0, t0 = 0;
     unsigned int spins = 0;
     bool ok;
-    // (all 38 lanes poll: one round trip after the publication instead of two; what had congested the memory fabric in the
+    // (all lanes poll: one round trip after the publication instead of two; what had congested the memory fabric in the
     //  first version of this pass were release / acquire fences — an L2 write-back / invalidate each —, not these loads)
     while (true) {
-      if (tid < kOvGranules) g = __hip_atomic_load((gu64*)(base + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      ok = tid >= kOvGranules || (unsigned int)(g >> 32) == tag;
+      if (tid < n_gran) g = __hip_atomic_load((gu64*)(base + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ok = tid >= n_gran || (unsigned int)(g >> 32) == tag;
       if (__all(ok)) break;
-      if (++spins > 2000000u) break;
-      __builtin_amdgcn_s_sleep(LIODOM_POLL_POSE);
+      if (++spins > 2000000u || wait_expired(spins, t0)) break;
+      __builtin_amdgcn_s_sleep(kPollSleep);
     }
     const bool all_ok = __all(ok);
-    const unsigned long long lo = __shfl(g, 2 * (tid % 19)), hi = __shfl(g, 2 * (tid % 19) + 1);
-    if (tid < 19) out19[tid] = __longlong_as_double((long long)((hi << 32) | (lo & 0xFFFFFFFFull)));
+    const int nd = n_gran >> 1;
+    const unsigned long long lo = __shfl(g, 2 * (tid % nd)), hi = __shfl(g, 2 * (tid % nd) + 1);
+    if (tid < nd) out[tid] = __longlong_as_double((long long)((hi << 32) | (lo & 0xFFFFFFFFull)));
     if (tid == 0) { s_ov_ok = all_ok ? 1 : 0; if (!all_ok) atomicOr(status, LIODOM_STATUS_PIPE_TIMEOUT); }
   }
   __syncthreads();
   return s_ov_ok != 0;
 }
+// the first solve's result for the overlapped second pass: replica rep of pose_xch0; out19: LDS
+__device__ __forceinline__ bool ov_wait_pose(const DevView& v, int s, int rep, unsigned int tag, double* out19, unsigned int* status) {
+  return granules_wait<LIODOM_POLL_POSE>(v.pose_xch0 + ((size_t)s * kOvReplicas + rep) * 512, kOvGranules, tag, out19, status);
+}
+// Chain mode: the prediction a scan starts from, published by the previous scan's finalize_scan (threads 0 .. kOvReplicas *
+// kPredGranules - 1 of the solving workgroup; vals: 12 doubles in LDS) and read by the scan's first kNN pass (other HIP stream).
+__device__ __forceinline__ void pred_publish(const DevView& v, int s, const double* vals, unsigned int tag, int tid) {
+  typedef __attribute__((address_space(1))) unsigned long long gu64;
+  if (tid < kOvReplicas * kPredGranules) {
+    const int rep = tid / kPredGranules, gi = tid % kPredGranules;
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(vals[gi >> 1]);
+    const unsigned int word = (gi & 1) ? (unsigned int)(bits >> 32) : (unsigned int)bits;
+    __hip_atomic_store((gu64*)(v.pred_xch + ((size_t)s * kOvReplicas + rep) * 512 + gi), ((unsigned long long)tag << 32) | word,
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+// whole workgroup: the prediction (lanes 0 .. 23 of the first wave) and, in the same round trip, the extraction's flag (lane 32;
+// edge_flag may be null / want 0: nothing to wait for).  false: one of them never arrived.
+__device__ __forceinline__ bool pred_wait(const DevView& v, int s, int rep, unsigned int tag, double* out12, unsigned int* status,
+                                          const unsigned int* edge_flag, unsigned int edge_want) {
+  typedef __attribute__((address_space(1))) unsigned long long gu64;
+  typedef __attribute__((address_space(1))) unsigned int gu32;
+  __shared__ int s_pw_ok;
+  const unsigned long long* base = v.pred_xch + ((size_t)s * kOvReplicas + rep) * 512;
+  const int tid = (int)threadIdx.x;
+  if (tid < 64) {
+    unsigned long long g = 0, t0 = 0;
+    unsigned int spins = 0;
+    bool ok;
+    while (true) {
+      ok = true;
+      if (tid < kPredGranules) { g = __hip_atomic_load((gu64*)(base + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = (unsigned int)(g >> 32) == tag; }
+      else if (tid == 32 && edge_flag && edge_want) ok = (int)(__hip_atomic_load((gu32*)edge_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - edge_want) >= 0;
+      if (__all(ok)) break;
+      if (++spins > 1500000u || wait_expired(spins, t0)) break;
+      __builtin_amdgcn_s_sleep(4);
+    }
+    const bool all_ok = __all(ok);
+    if (spins) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (it really waited: as pipe_wait)
+    const unsigned long long lo = __shfl(g, 2 * (tid % 12)), hi = __shfl(g, 2 * (tid % 12) + 1);
+    if (tid < 12) out12[tid] = __longlong_as_double((long long)((hi << 32) | (lo & 0xFFFFFFFFull)));
+    if (tid == 0) { s_pw_ok = all_ok ? 1 : 0; if (!all_ok) atomicOr(status, LIODOM_STATUS_PIPE_TIMEOUT); }
+  }
+  __syncthreads();
+  return s_pw_ok != 0;
+}
+// Chain mode, first pass -> first solve: every workgroup of the pass counts itself on ONE word once its write-through results are
+// acknowledged; one thread per solving workgroup polls that word.  (With a flag per pass workgroup, as the second pass has them,
+// the eight solving workgroups polled 352 words with 352 threads each for the whole length of the pass — which is bound by the
+// latency of its own loads: it got 3-5 us slower.)
+__device__ __forceinline__ void chain_count_done(unsigned int* counter) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void chain_wait_count(const unsigned int* counter, unsigned int target, unsigned int* status) {
+  typedef __attribute__((address_space(1))) unsigned int gu32;
+  if (threadIdx.x == 0) {
+    unsigned int spins = 0;
+    unsigned long long t0 = 0;
+    while ((int)(__hip_atomic_load((gu32*)counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+      __builtin_amdgcn_s_sleep(4);
+      if (++spins > 6000000u || wait_expired(spins, t0)) { atomicOr(status, LIODOM_STATUS_PIPE_TIMEOUT); break; }
+    }
+  }
+  // (no acquire fence: the argument of ov_wait_knn_done — write-through producers, nothing of theirs cached here before this point)
+  __syncthreads();
+}
 // whole workgroup, every exit path of an overlapped k_knn workgroup: its results are visible before the flag is
-__device__ __forceinline__ void ov_signal_knn_done(const DevView& v, int s, int b, unsigned int seq) {
+__device__ __forceinline__ void ov_signal_knn_done(const DevView& v, int s, int b, unsigned int seq, unsigned int* done = nullptr) {
   typedef __attribute__((address_space(1))) unsigned int gu32;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the pass's results are write-through stores: acknowledged = visible to every XCD)
   __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_store((gu32*)(v.knn_done + (size_t)s * v.knn_grid + b), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0) __hip_atomic_store((gu32*)((done ? done : v.knn_done) + (size_t)s * v.knn_grid + b), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // whole workgroup (finalising solve's launch): every workgroup of the overlapped second pass has completed
-__device__ __forceinline__ void ov_wait_knn_done(const DevView& v, int s, unsigned int seq, unsigned int* status) {
+__device__ __forceinline__ void ov_wait_knn_done(const DevView& v, int s, unsigned int seq, unsigned int* status, const unsigned int* done = nullptr) {
   typedef __attribute__((address_space(1))) unsigned int gu32;
-  const unsigned int* f = v.knn_done + (size_t)s * v.knn_grid;
+  const unsigned int* f = (done ? done : v.knn_done) + (size_t)s * v.knn_grid;
   for (int b = (int)threadIdx.x; b < v.knn_grid; b += (int)blockDim.x) {
     unsigned int spins = 0;
+    unsigned long long t0 = 0;
     while ((int)(__hip_atomic_load((gu32*)(f + b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) < 0) {
       __builtin_amdgcn_s_sleep(LIODOM_POLL_DONE);
-      if (++spins > 6000000u) { atomicOr(status, LIODOM_STATUS_PIPE_TIMEOUT); break; }
+      if (++spins > 6000000u || wait_expired(spins, t0)) { atomicOr(status, LIODOM_STATUS_PIPE_TIMEOUT); break; }
     }
   }
   // No acquire fence (an L2 invalidate per waiting workgroup; with one per workgroup of the pass the solve beside it took 80 us

@@ -75,9 +75,26 @@ struct liodom_handle {
   bool stream_c_shared = false;      // stream_c is stream_k
   bool ov_suppress = false;          // host-fed replay: the host's enqueue work per scan is the limit there, and the overlapped pass costs two more launches
   bool ov_prev = false;              // the previous scan of this handle was overlapped
+  // Chain mode (kernels_sync.h "Chain mode"): the scan's kNN passes and the rebuild on stream_k, the two solves — launches of the
+  // solving workgroups alone — on `stream`; the first solve's launch is resident beside the first pass.
+  bool chain_ok = false;             // the handle qualifies (one stream, streamed rebuild, flags, no IMU override; the passes' waiting workgroups
+                                     // may take up to half of the wave slots: the rebuild's workgroups are light there and the solve is resident
+                                     // before the second pass is dispatched; LIODOM_CHAIN=0 switches it off)
+  bool chain_prev = false;           // the previous scan was enqueued in chain mode
+  unsigned int chain_count = 0;      // first-pass workgroups launched in chain mode since the last reset (what knn_done0 counts up to)
+  bool chain_used = false;           // any scan was: the odometry side's results are complete when stream AND stream_k have drained
+  hipEvent_t ev_ch = nullptr;        // at a switch out of chain mode: the odometry stream waits for stream_k
   int ov_warm = 0;                   // scans enqueued so far, up to kOvWarmScans (the first ones run every kernel of the chain for the first time)
   hipStream_t stream_x = nullptr;    // extraction side (liodom_extract_edges, and the next scan's extraction in the pipelined replay)
   hipStream_t stream_c = nullptr;    // host-fed replay: uploads (a copy engine works beside the extraction kernels of the previous scan)
+  // Uploads ordered by FLAGS instead of event pairs (round 5; handles with use_flags): the copy stream writes a sequence number
+  // behind every upload (hipStreamWriteValue32, or a one-thread kernel: up_flag_mode 2), a one-wave gate launch in front of the
+  // extraction polls it.  The reverse edge — the slot may be overwritten — needs nothing on the device: a slot of the three-deep
+  // ring is refilled only after the pose of the scan that last used it has been COLLECTED by the host (so its extraction has
+  // completed).  No hipStreamWaitEvent anywhere, the copy stream is a stream of its own, and the overlapped second kNN pass stays on.
+  int up_flag_mode = 0;              // 0: events (safe mode, profilers that serialise kernels), 1: hipStreamWriteValue32, 2: k_set_flag launch
+  unsigned int* up_flags = nullptr;  // [kEdgePipeBufs] device words: sequence number of the latest upload that has landed in ring slot r
+  unsigned int up_seq = 0;
   hipEvent_t ev_up[3] = {nullptr, nullptr, nullptr};      // staging slot uploaded
   hipEvent_t ev_xdone[3] = {nullptr, nullptr, nullptr};   // extraction that read the staging slot has been issued (recorded on the extraction stream)
   bool ev_xdone_valid[3] = {false, false, false};
@@ -158,6 +175,14 @@ int dev_alloc(liodom_handle* h, T** p, size_t count, int memset_value = 0) {
   HIP_TRY(hipMemsetAsync(raw, memset_value, bytes, h->stream));
   *p = static_cast<T*>(raw);
   return LIODOM_OK;
+}
+
+// The odometry side's device results (window, correspondences, pose log, state) are complete when its streams have drained: in
+// chain mode the kNN passes and the rebuild run on stream_k.
+hipError_t sync_odometry(liodom_handle* h) {
+  hipError_t e = hipStreamSynchronize(h->stream);
+  if (e == hipSuccess && h->chain_used && h->stream_k) e = hipStreamSynchronize(h->stream_k);
+  return e;
 }
 
 int drain_events(liodom_handle* h) {
@@ -283,7 +308,11 @@ int enqueue_odometry(liodom_handle* h, int eb, int s0, int count, unsigned int w
   // the kernel; it needs kernels of different streams to run side by side (as the flags of the pipelined replay do) and the
   // GPU mostly to itself: not while a second handle lives in this process (its waiting workgroups and ours could end up
   // behind each other in a shared hardware queue), not under per-kernel profiling.
-  const bool overlap_ok = early && h->ov_ok && h->use_flags && !h->profiling && !h->ov_suppress && !h->ov_off_for_copies.load() && count == 1 && g_live_handles.load() <= 1;
+  // (chain mode — only for scans whose edges come from the extraction stream by flag, see below — also overlaps the pass on shapes
+  //  where the four-launch chain cannot: Ouster-128's 704 waiting workgroups beside full-CU rebuild workgroups cost 9 %, in chain
+  //  mode the overlapped pass gains 19 % there)
+  const bool chain_cand = h->chain_ok && wait_edges != 0u && !h->flag_gate;
+  const bool overlap_ok = early && (h->ov_ok || chain_cand) && h->use_flags && !h->profiling && !h->ov_suppress && !h->ov_off_for_copies.load() && count == 1 && g_live_handles.load() <= 1;
   // The first scans of a handle are not overlapped: their launches are the first of every kernel of the chain on this queue
   // (scratch set-up, code upload), which can hold the odometry stream back for longer than a waiting kernel is willing to
   // poll.  At a switch to overlapped scans stream_k waits (event) for the odometry stream to have drained, so that its
@@ -300,21 +329,54 @@ int enqueue_odometry(liodom_handle* h, int eb, int s0, int count, unsigned int w
       HIP_TRY(hipStreamWaitEvent(h->stream_k, h->ev_ov, 0));
     }
   }
+  // Chain mode: only for scans whose edges come from the extraction stream by flag (the pipelined replay, the ticket API): the
+  // first pass then runs on stream_k, where nothing orders it behind an extraction enqueued on the odometry stream itself.
+  const bool chain = overlap && chain_cand;
+  if (chain != h->chain_prev) {
+    if (chain) {
+      // (stream_k waits for the odometry stream: recorded above — ev_ov — unless the previous scan was overlapped without the chain)
+      if (h->ov_prev) { HIP_TRY(hipEventRecord(h->ev_ov, h->stream)); HIP_TRY(hipStreamWaitEvent(h->stream_k, h->ev_ov, 0)); }
+    } else {
+      HIP_TRY(hipEventRecord(h->ev_ch, h->stream_k));
+      HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_ch, 0));
+    }
+  }
+  h->chain_prev = chain;
   h->ov_prev = overlap;
+  if (chain) {
+    h->chain_used = true;
+    const int scan_no = h->scans_enqueued[s0];
+    h->chain_count += (unsigned int)v.knn_grid;                        // (wraps with the device counter: the kernels compare differences)
+    const unsigned int done_target = h->chain_count;
+    const int gx = (h->v.lm_groups - 1) * 8 + 1;                       // solvers on blocks 0, 8, 16, ... (one XCD); nothing else in the launch
+    const size_t lds = lm_lds_bytes(h->v.edge_cap);
+    // stream_k: first pass | gate (first solve's launch has started) | second pass + COUNT + PAD | ALLOC | APPEND + CLEAR + SCATTER
+    // stream:   first solve (resident beside the first pass: waits for its done flags) | finalising solve (waits for the second pass's)
+    const int nCP = cdiv(h->v.edge_cap * std::max(1, h->P - 1), 256) + cdiv(h->v.edge_cap, 256);      // COUNT + PAD workgroups of 256 threads
+    hipLaunchKernelGGL((k_knn<256, false, true>), dim3(v.knn_grid, 1), dim3(256), 0, h->stream_k, v, s0, 0, eb, wait_edges, signal_odo, seq_k, scan_no);
+    hipLaunchKernelGGL(k_lm_solve, dim3(gx, 1), dim3(kLmThreads), lds, h->stream, v, s0, 0, eb, seq_k, 1, done_target);
+    hipLaunchKernelGGL(k_ov_gate, dim3(1), dim3(64), 0, h->stream_k, v, s0, seq_k);
+    hipLaunchKernelGGL((k_knn<256, true>), dim3(v.knn_grid + nCP, 1), dim3(256), 0, h->stream_k, v, s0, 1, eb, 0u, 0u, seq_k, scan_no);
+    hipLaunchKernelGGL(k_lm_solve, dim3(gx, 1), dim3(kLmThreads), lds, h->stream, v, s0, 1, eb, seq_k, 1, 0u);
+    hipLaunchKernelGGL(k_rebuild_alloc, dim3(kRebuildAllocBlocks, 1), dim3(256), 0, h->stream_k, v, s0);
+    hipLaunchKernelGGL(k_rebuild_fin, dim3(nP + kRebuildAuxBlocks + nC, 1), dim3(kLmThreads), 0, h->stream_k, v, s0, eb);
+    HIP_TRY(hipGetLastError());
+    return LIODOM_OK;
+  }
   for (int it = 0; it < 2; it++) {
     {
       ProfScope ps(h, KID_KNN);
       const int kx = v.knn_grid + ((early && it == 1 && !seq_k) ? kRebuildAuxBlocks : 0);     // it 1: + ALLOC (overlapped pass: k_rebuild_alloc below)
       if (knn_small) {
-        hipLaunchKernelGGL(k_knn<128>, dim3(kx, count), dim3(128), 0, h->stream, v, s0, it, eb, wait_edges, signal_odo, 0u);
+        hipLaunchKernelGGL(k_knn<128>, dim3(kx, count), dim3(128), 0, h->stream, v, s0, it, eb, wait_edges, signal_odo, 0u, 0);
         if (v.knn_nn) hipLaunchKernelGGL(k_line_gate, dim3(cdiv(h->v.knn_blocks * h->v.knn_queries, 256), count), dim3(256), 0, h->stream, v, s0, it, eb);
       } else if (it == 1 && seq_k) {
         hipLaunchKernelGGL(k_ov_gate, dim3(1), dim3(64), 0, h->stream_k, v, s0, seq_k);
-        hipLaunchKernelGGL((k_knn<256, true>), dim3(kx, count), dim3(256), 0, h->stream_k, v, s0, it, eb, 0u, 0u, seq_k);
+        hipLaunchKernelGGL((k_knn<256, true>), dim3(kx, count), dim3(256), 0, h->stream_k, v, s0, it, eb, 0u, 0u, seq_k, 0);
         // ALLOC between the two solve launches, beside the pass's tail
         hipLaunchKernelGGL(k_rebuild_alloc, dim3(kRebuildAllocBlocks, count), dim3(256), 0, h->stream, v, s0);
       } else {
-        hipLaunchKernelGGL(k_knn<256>, dim3(kx, count), dim3(256), 0, h->stream, v, s0, it, eb, wait_edges, signal_odo, 0u);
+        hipLaunchKernelGGL(k_knn<256>, dim3(kx, count), dim3(256), 0, h->stream, v, s0, it, eb, wait_edges, signal_odo, 0u, 0);
       }
     }
     {
@@ -322,7 +384,7 @@ int enqueue_odometry(liodom_handle* h, int eb, int s0, int count, unsigned int w
       // it 0: + COUNT, PAD; it 1: + APPEND, CLEAR, SCATTER
       const int extra = !early ? 0 : (it == 0 ? nC + nP : nP + kRebuildAuxBlocks + nC);
       const int gx = std::max(h->v.lm_groups + extra, (h->v.lm_groups - 1) * 8 + 1);      // solvers on blocks 0, 8, 16, ... (one XCD)
-      hipLaunchKernelGGL(k_lm_solve, dim3(gx, count), dim3(kLmThreads), lm_lds_bytes(h->v.edge_cap), h->stream, v, s0, it, eb, seq_k);
+      hipLaunchKernelGGL(k_lm_solve, dim3(gx, count), dim3(kLmThreads), lm_lds_bytes(h->v.edge_cap), h->stream, v, s0, it, eb, seq_k, 0, 0u);
     }
   }
   if (v.mapping) {
@@ -435,7 +497,7 @@ int drain_pipeline(liodom_handle* h) {
   const bool replayed = h->replay_live.exchange(false);
   if (h->pf_slot >= 0 || h->parity != 0 || h->pipe_active.exchange(false) || replayed) {
     HIP_TRY(hipStreamSynchronize(h->stream_x));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(sync_odometry(h));
     h->pf_slot = -1; h->parity = 0; h->ev_free_valid[0] = h->ev_free_valid[1] = h->ev_free_valid[2] = false;
     for (int b = 0; b < kEdgePipeBufs; b++) h->eb_reader[b] = 0;      // (everything has completed: nothing to wait for)
   }
@@ -506,6 +568,8 @@ int issue_extract(liodom_handle* h, int slot, int eb, int n, int height, int wid
 void enter_safe_mode(liodom_handle* h) {
   h->safe_mode = true;
   h->use_flags = false;
+  h->chain_ok = false;
+  h->up_flag_mode = 0;
   h->v.lm_groups = 1;
   h->v.early_rebuild = 0;      // (the second table, the padding and the overflow list stay allocated and unused)
   h->ring_split = false;       // k_ring_split's workgroups wait for each other inside the launch: k_classify + k_ring_scatter instead
@@ -548,8 +612,14 @@ int reset_state(liodom_handle* h) {
   if (h->host_edges_hdr) std::memset(h->host_edges_hdr, 0, sizeof(unsigned int) * 2 * kEdgePipeBufs);
   for (int b = 0; b < kEdgePipeBufs; b++) { h->eb_seq[b] = 0; h->eb_reader[b] = 0; }
   HIP_TRY(hipMemsetAsync(h->v.pipe_flags, 0, sizeof(unsigned int) * (kEdgePipeBufs + 1), h->stream));
+  if (h->stream_c && !h->stream_c_shared) HIP_TRY(hipStreamSynchronize(h->stream_c));
+  HIP_TRY(hipMemsetAsync(h->up_flags, 0, sizeof(unsigned int) * kEdgePipeBufs, h->stream));
+  h->up_seq = 0;
   HIP_TRY(hipMemsetAsync(h->v.lm_xch, 0, sizeof(unsigned long long) * (size_t)h->S * 2 * kLmGroupsMax * 64, h->stream));
   HIP_TRY(hipMemsetAsync(h->v.pose_xch, 0, sizeof(unsigned long long) * (size_t)h->S * 32, h->stream));
+  if (h->v.pred_xch) HIP_TRY(hipMemsetAsync(h->v.pred_xch, 0, sizeof(unsigned long long) * (size_t)h->S * kOvReplicas * 512, h->stream));
+  HIP_TRY(hipMemsetAsync(h->v.knn_done0, 0, sizeof(unsigned int) * (size_t)h->S, h->stream));
+  h->chain_prev = false; h->chain_count = 0;
   std::memset(h->host_out, 0, sizeof(HostOut) * 2 * (size_t)h->S);
   std::fill(h->scans_enqueued.begin(), h->scans_enqueued.end(), 0);
   HIP_TRY(hipMemsetAsync(h->v.win_n, 0, sizeof(int) * (size_t)h->S * h->P, h->stream));
@@ -806,6 +876,7 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   ALLOC(v.lm_xch, S * 2 * kLmGroupsMax * 64, 0);
   ALLOC(v.pose_xch, S * 32, 0);
   ALLOC(v.pipe_flags, kEdgePipeBufs + 1, 0);
+  ALLOC(h->up_flags, kEdgePipeBufs, 0);
   v.host_edges = nullptr; v.host_edges_meta = nullptr; v.host_edges_hdr = nullptr;
   if (S == 1) {
     // device-resident hand-off (liodom_extract_edges_device): host-mapped mirror of the dense edges of the three pipeline buffers
@@ -843,6 +914,11 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
     if (!h->streams_concurrent) h->use_flags = false;
   }
   {
+    // uploads of host-fed scans ordered by flags (see up_flag_mode): wherever the stream flags are usable
+    h->up_flag_mode = 0;      // (measured, profiles/r05_*: no gain over the event pairs; kept behind LIODOM_UPLOAD_FLAGS = 1 / 2)
+    if (const char* e = std::getenv("LIODOM_UPLOAD_FLAGS")) { const int m = std::atoi(e); if (m == 0 || (h->use_flags && (m == 1 || m == 2))) h->up_flag_mode = m; }
+  }
+  {
     bool gate_kernel = config->n_streams >= 16;         // lock-step batches: line gates in their own launch (k_line_gate)
     if (const char* e = std::getenv("LIODOM_GATE_KERNEL")) gate_kernel = gate_kernel && std::atoi(e) != 0;
     if (gate_kernel) ALLOC(v.knn_nn, S * (size_t)v.edge_cap * 5, 0); else v.knn_nn = nullptr;
@@ -864,6 +940,9 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   ALLOC(v.ov_flags, S, 0);
   ALLOC(v.pose_xch0, S * (size_t)kOvReplicas * 512, 0);
   ALLOC(v.knn_done, S * (size_t)v.knn_grid, 0);
+  ALLOC(v.knn_done0, S + 32, 0);
+  if (v.early_rebuild) ALLOC(v.pred_xch, S * (size_t)kOvReplicas * 512, 0); else v.pred_xch = nullptr;
+  ALLOC(v.edge_cnt, (size_t)kEdgeBufs * 32, 0);
   // (the two passes' validity bytes never share a 128-byte line: the overlapped second pass writes its half while the finalising
   //  solve's launch — which must not read it before ov_wait_knn_done — may hold the first pass's half in its caches)
   v.mask_stride = round_up(v.knn_blocks, 128);
@@ -914,7 +993,21 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
     if (const char* e = std::getenv("LIODOM_KNN_OVERLAP")) { if (std::atoi(e) == 0) h->ov_ok = false; if (std::atoi(e) == 2) h->ov_ok = v.early_rebuild && S == 1 && v.knn_partials; }      // (2: also where the pass takes more than a third of the wave slots)
     // (the stream exists only on handles that use it: HIP multiplexes its streams onto a few hardware queues, and one more
     //  stream made the host-fed replay's copy stream share a queue — 11.3k -> 7.5k scans/s on every workload)
-    if (h->ov_ok && make_stream(&h->stream_k, prio_greatest) != hipSuccess) { g_last_error = "hipStreamCreate failed"; return fail(LIODOM_ERR_HIP); }
+    // chain mode (kernels_sync.h): one-stream handles with the streamed rebuild whose passes leave at least half of the wave slots
+    // free; the IMU override rewrites the prediction between two scans on the odometry stream (k_imu_override), which the first
+    // pass on stream_k would not be ordered behind
+    h->chain_ok = v.early_rebuild && S == 1 && v.knn_partials && !v.use_imu && (long long)v.knn_grid * 4 * 2 <= (long long)cus * 24;
+    if (const char* e = std::getenv("LIODOM_KNN_OVERLAP")) { if (std::atoi(e) == 0) h->chain_ok = false; }
+    if (const char* e = std::getenv("LIODOM_CHAIN")) { if (std::atoi(e) == 0) h->chain_ok = false; }
+    if ((h->ov_ok || h->chain_ok) && make_stream(&h->stream_k, prio_greatest) != hipSuccess) { g_last_error = "hipStreamCreate failed"; return fail(LIODOM_ERR_HIP); }
+    if (h->chain_ok && hipEventCreateWithFlags(&h->ev_ch, hipEventDisableTiming) != hipSuccess) { g_last_error = "hipEventCreate failed"; return fail(LIODOM_ERR_HIP); }
+  }
+  {
+    // wall-clock bound of every in-kernel wait (g_wait_ticks, 100 MHz ticks): LIODOM_WAIT_MS, default 50 ms
+    double ms = 50.0;
+    if (const char* e = std::getenv("LIODOM_WAIT_MS")) { const double x = std::atof(e); if (x >= 1.0 && x <= 10000.0) ms = x; }
+    const unsigned long long ticks = (unsigned long long)(ms * 1.0e5);
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_wait_ticks), &ticks, sizeof(ticks)) != hipSuccess) { g_last_error = "hipMemcpyToSymbol(g_wait_ticks) failed"; return fail(LIODOM_ERR_HIP); }
   }
   ALLOC(h->d_view, 1, 0);
   if (hipMemcpy(h->d_view, &h->v, sizeof(DevView), hipMemcpyHostToDevice) != hipSuccess) { g_last_error = "DevView upload failed"; return fail(LIODOM_ERR_HIP); }
@@ -934,6 +1027,7 @@ void liodom_destroy(liodom_handle_t* h) {
   if (h->stream) hipStreamSynchronize(h->stream);
   if (h->stream_k) { hipStreamSynchronize(h->stream_k); hipStreamDestroy(h->stream_k); }
   if (h->ev_ov) hipEventDestroy(h->ev_ov);
+  if (h->ev_ch) hipEventDestroy(h->ev_ch);
   for (liodom_map* mp : h->mappers) {          // attached maps outlive the handle: give them a stream of their own again
     if (!mp) continue;
     mp->stream = nullptr; mp->own_stream = false;
@@ -1072,6 +1166,30 @@ int liodom_odometry_step(liodom_handle_t* h, int stream, const float* edges_xyzi
   return wait_pose(h, stream, 1, pose_out, info);
 }
 
+// Flag-ordered uploads: the copy stream of the handle (a stream of its own) and the two halves of the edge "upload r has landed".
+static int ensure_copy_stream(liodom_handle_t* h) {
+  if (h->stream_c && !h->stream_c_shared) return LIODOM_OK;
+  h->stream_c = nullptr; h->stream_c_shared = false;
+  HIP_TRY(hipStreamCreateWithFlags(&h->stream_c, hipStreamNonBlocking));
+  return LIODOM_OK;
+}
+// behind the upload(s) just enqueued on the copy stream: publish their sequence number in up_flags[r]; in front of the extraction
+// that reads them (queue q): a one-wave gate that polls it.  The kernels behind the gate start when it retires — with clean caches.
+static int upload_signal_and_gate(liodom_handle_t* h, int r, hipStream_t q) {
+  unsigned int seq = ++h->up_seq;
+  if (seq == 0u) seq = ++h->up_seq;
+  if (h->up_flag_mode == 1) {
+    if (hipStreamWriteValue32(h->stream_c, h->up_flags + r, seq, 0) != hipSuccess) {      // (not available on this stack: the kernel form from now on)
+      (void)hipGetLastError();
+      h->up_flag_mode = 2;
+    }
+  }
+  if (h->up_flag_mode == 2) hipLaunchKernelGGL(k_set_flag, dim3(1), dim3(1), 0, h->stream_c, h->up_flags + r, seq);
+  hipLaunchKernelGGL(k_up_gate, dim3(1), dim3(64), 0, q, h->v, h->up_flags + r, seq);
+  HIP_TRY(hipGetLastError());
+  return LIODOM_OK;
+}
+
 // ---- device-resident hand-off between the two sides (the reference's feature queue without the cloud leaving HBM) ----
 static int ensure_pin_ring(liodom_handle* h) {
   if (h->pin_ring) return LIODOM_OK;
@@ -1093,7 +1211,9 @@ static int ensure_pin_ring(liodom_handle* h) {
     HIP_TRY(hipMalloc(&d, sizeof(float4) * (size_t)kEdgePipeBufs * (size_t)h->v.max_points));
     h->stage_ring = static_cast<float4*>(d);
     h->allocs.push_back(d);
-    if (!h->stream_c) {
+    if (h->up_flag_mode) {
+      if (int rc = ensure_copy_stream(h)) return rc;
+    } else if (!h->stream_c) {
       if (want == 2 && h->stream_k) {
         // (the odometry side may be enqueueing an overlapped pass right now: from here on it does not — ov_off_for_copies is read
         //  by enqueue_odometry — and what is already in that stream simply runs ahead of the first copy)
@@ -1183,12 +1303,13 @@ int liodom_extract_edges_device(liodom_handle_t* h, int stream, const float* xyz
       if (own || !pinned) { pin_slot_used = r; h->pin_next = (r + 1) % kEdgePipeBufs; }
     } else
     if (h->tk_copy_stream && !h->profiling) {
-      // device staging slot sr: free once the extraction that last read it has run (ev_sdone, recorded on the extraction stream)
-      sr = h->stage_next;
+      // device staging slot sr: free once the extraction that last read it has run (ev_sdone, recorded on the extraction stream;
+      // with flag-ordered uploads: slot = edge buffer, which is refilled only after its scan's pose has been collected)
+      sr = h->up_flag_mode ? eb : h->stage_next;
       h->stage_next = (sr + 1) % kEdgePipeBufs;
       qc = h->stream_c;
       in = h->stage_ring + (size_t)sr * h->v.max_points;
-      if (h->ev_sdone_valid[sr]) HIP_TRY(hipStreamWaitEvent(qc, h->ev_sdone[sr], 0));
+      if (!h->up_flag_mode && h->ev_sdone_valid[sr]) HIP_TRY(hipStreamWaitEvent(qc, h->ev_sdone[sr], 0));
     }
     if (!host_dev) HIP_TRY(hipMemcpyAsync(in, xyzi, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, qc));
     if (!host_dev && (own || !pinned)) {             // the page-locked ring slot may be refilled once this upload has left it
@@ -1196,7 +1317,9 @@ int liodom_extract_edges_device(liodom_handle_t* h, int stream, const float* xyz
       h->ev_pin_valid[r] = true;
       h->pin_next = (r + 1) % kEdgePipeBufs;
     }
-    if (sr >= 0) {                                   // the extraction starts when the upload into its staging slot has completed
+    if (sr >= 0 && h->up_flag_mode) {                // the extraction starts when the upload into its staging slot has completed
+      if ((rc = upload_signal_and_gate(h, sr, q))) return rc;
+    } else if (sr >= 0) {
       HIP_TRY(hipEventRecord(h->ev_cp[sr], qc));
       HIP_TRY(hipStreamWaitEvent(q, h->ev_cp[sr], 0));
     }
@@ -1216,7 +1339,7 @@ int liodom_extract_edges_device(liodom_handle_t* h, int stream, const float* xyz
     HIP_TRY(hipEventRecord(h->ev_pin[pin_slot_used], q));
     h->ev_pin_valid[pin_slot_used] = true;
   }
-  if (staged_on_ring) {
+  if (staged_on_ring && !h->up_flag_mode) {
     const int sr = (h->stage_next + kEdgePipeBufs - 1) % kEdgePipeBufs;
     HIP_TRY(hipEventRecord(h->ev_sdone[sr], q));
     h->ev_sdone_valid[sr] = true;
@@ -1357,7 +1480,7 @@ int liodom_set_received_map(liodom_handle_t* h, int stream, const float* xyzi, i
   HIP_TRY(hipMemcpyAsync(&h->v.state[stream].n_recv, &ni, sizeof(int), hipMemcpyHostToDevice, h->stream));
   rc = rebuild_search_structure(h, stream);
   if (rc) return rc;
-  HIP_TRY(hipStreamSynchronize(h->stream));        // xyzi / ni are the caller's and this frame's memory
+  HIP_TRY(sync_odometry(h));        // xyzi / ni are the caller's and this frame's memory
   return LIODOM_OK;
 }
 
@@ -1384,7 +1507,7 @@ int liodom_get_received_map(liodom_handle_t* h, int stream, float* xyzi, int64_t
   if (rc) return rc;
   if (!h->v.mapping) { if (n_points) *n_points = 0; return LIODOM_OK; }
   SideLocks lk(h, true, false);
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(sync_odometry(h));
   int n = 0;
   HIP_TRY(hipMemcpy(&n, &h->v.state[stream].n_recv, sizeof(int), hipMemcpyDeviceToHost));
   if (n_points) *n_points = n;
@@ -1398,7 +1521,7 @@ int liodom_attach_mapper(liodom_handle_t* h, int stream, liodom_map_t* m, int ce
   if (rc) return rc;
   if (!h->v.mapping) { g_last_error = "liodom_attach_mapper: the handle was created with mapping = 0"; return LIODOM_ERR_UNSUPPORTED; }
   SideLocks lk(h, true, false);
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(sync_odometry(h));
   if (liodom_map* old = h->mappers[stream]) {       // detach: the map gets a stream of its own again
     h->mappers[stream] = nullptr;
     old->stream = nullptr; old->own_stream = false;
@@ -1423,7 +1546,7 @@ int liodom_alloc_resident(liodom_handle_t* h, int n_slots) {
   if (rc0) return rc0;
   SideLocks lk(h, true, true);
   HIP_TRY(hipStreamSynchronize(h->stream_x));       // an extraction issued ahead may still read the old buffer
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(sync_odometry(h));
   h->pf_slot = -1;
   if (h->resident) { hipFree(h->resident); h->resident = nullptr; h->n_slots = 0; }
   const size_t bytes = sizeof(float4) * (size_t)h->S * (size_t)n_slots * (size_t)h->v.max_points;
@@ -1493,6 +1616,21 @@ int liodom_replay_resident(liodom_handle_t* h, int first_slot, int count, int ah
 // Host-fed replay: the scan of every stream for resident slot `slot` is copied from host memory on the extraction stream
 // (ordered behind the extraction that last read the slot).
 static int upload_slot_async(liodom_handle_t* h, int slot, const float* host, int64_t stride, int64_t n) {
+  if (h->up_flag_mode) {
+    // (the slot is free: the scan that last used it — three scans back — has been collected by the host loop, liodom_replay_host)
+    const int r = slot % 3;
+    int rc = ensure_copy_stream(h);
+    if (rc) return rc;
+    static const int chunks = std::getenv("LIODOM_UPLOAD_CHUNKS") ? std::max(1, std::atoi(std::getenv("LIODOM_UPLOAD_CHUNKS"))) : 1;      // (experiment)
+    for (int s = 0; s < h->S && n > 0; s++) {
+      float4* dst = h->resident + ((size_t)slot * h->S + s) * (size_t)h->v.max_points;
+      const float4* src = reinterpret_cast<const float4*>(host + (size_t)s * (size_t)stride);
+      const int64_t per = (n + chunks - 1) / chunks;
+      for (int64_t o = 0; o < n; o += per)
+        HIP_TRY(hipMemcpyAsync(dst + o, src + o, sizeof(float4) * (size_t)std::min<int64_t>(per, n - o), hipMemcpyHostToDevice, h->stream_c));
+    }
+    return upload_signal_and_gate(h, r, extract_queue(h));
+  }
   // copies on their own stream (copy engine) so that they run beside the extraction kernels of the previous scan; the
   // slot is free once the extraction that last read it has completed, and its extraction waits for the upload
   const int r = slot % 3;
@@ -1521,6 +1659,7 @@ static int upload_slot_async(liodom_handle_t* h, int slot, const float* host, in
   return LIODOM_OK;
 }
 static int upload_slot_consumed(liodom_handle_t* h, int slot) {      // call right after the slot's extraction has been issued
+  if (h->up_flag_mode) return LIODOM_OK;      // (flag-ordered uploads: the slot is released by the host loop's own order)
   const int r = slot % 3;
   HIP_TRY(hipEventRecord(h->ev_xdone[r], extract_queue(h)));
   h->ev_xdone_valid[r] = true;
@@ -1583,7 +1722,8 @@ int liodom_replay_host(liodom_handle_t* h, const float* xyzi_base, int64_t scan_
   // operations, six extraction and five odometry launches per scan: 88 us); the overlapped second kNN pass adds a gate and an
   // ALLOC launch on a third stream and made it 133 us.  So not here.
   struct Suppress { liodom_handle* h; ~Suppress() { h->ov_suppress = false; h->replay_host_dev = nullptr; h->replay_host_base = nullptr; } } suppress{h};
-  h->ov_suppress = true;
+  h->ov_suppress = h->up_flag_mode == 0;      // (flag-ordered uploads have a stream of their own: the pass's stream stays free)
+  if (const char* e = std::getenv("LIODOM_HOSTFED_OVERLAP")) { if (std::atoi(e) != 0 && h->up_flag_mode) h->ov_suppress = false; else h->ov_suppress = true; }
   if (h->zero_copy && count > 0 && n > 0 && scan_stride_floats % 4 == 0 && (reinterpret_cast<uintptr_t>(xyzi_base) & 15u) == 0) {
     // page-locked AND mapped (liodom_pin_host_buffer, hipHostMalloc): the extraction reads the scans in place — the loop then
     // enqueues no upload and no event, and the overlapped second kNN pass stays on (its stream is not needed for copies)
@@ -1648,7 +1788,7 @@ int liodom_sync(liodom_handle_t* h) {
   if (rc0) return rc0;
   SideLocks lk(h, true, true);
   HIP_TRY(hipStreamSynchronize(h->stream_x));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(sync_odometry(h));
   if (h->stream_k) HIP_TRY(hipStreamSynchronize(h->stream_k));
   // everything has completed: unless an extraction has been issued ahead for the replay's next scan, the pipeline edge buffers
   // are free again (for the ticket API, or for a replay that starts over at buffer 0)
@@ -1662,7 +1802,7 @@ int liodom_get_pose_log(liodom_handle_t* h, int stream, int first, int count, do
   if (rc) return rc;
   if (first < 0 || count < 0 || first + count > h->v.pose_log_cap) { g_last_error = "pose log range"; return LIODOM_ERR_INVALID_ARG; }
   SideLocks lk(h, true, false);
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(sync_odometry(h));
   if (poses_out && count)
     HIP_TRY(hipMemcpy(poses_out, h->v.pose_log + ((size_t)stream * h->v.pose_log_cap + first) * 7, sizeof(double) * 7 * (size_t)count, hipMemcpyDeviceToHost));
   if (infos_out && count)
@@ -1671,7 +1811,7 @@ int liodom_get_pose_log(liodom_handle_t* h, int stream, int first, int count, do
 }
 
 static int get_window_impl(liodom_handle_t* h, int stream, float* xyzi, int64_t cap, int64_t* n_points, int* n_frames) {
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(sync_odometry(h));
   StreamState st;
   HIP_TRY(hipMemcpy(&st, h->v.state + stream, sizeof(st), hipMemcpyDeviceToHost));
   const int P = h->P;
@@ -1701,7 +1841,7 @@ int liodom_get_local_map(liodom_handle_t* h, int stream, float* xyzi, int64_t ca
   int rc = check_stream(h, stream);
   if (rc) return rc;
   SideLocks lk(h, true, false);
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(sync_odometry(h));
   StreamState st;
   HIP_TRY(hipMemcpy(&st, h->v.state + stream, sizeof(st), hipMemcpyDeviceToHost));
   if (filtered) *filtered = st.n_filt > 0 ? 1 : 0;
@@ -1740,7 +1880,7 @@ int liodom_get_correspondences(liodom_handle_t* h, int stream, int it, int32_t* 
   if (rc) return rc;
   if (it < 0 || it > 1) return LIODOM_ERR_INVALID_ARG;
   SideLocks lk(h, true, false);
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(sync_odometry(h));
   StreamState st;
   HIP_TRY(hipMemcpy(&st, h->v.state + stream, sizeof(st), hipMemcpyDeviceToHost));
   const int E = st.n_edges_buf[h->last_eb];
@@ -1762,7 +1902,7 @@ int liodom_get_knn_queries(liodom_handle_t* h, int stream, int it, float* xyz0, 
   if (it < 0 || it > 1) return LIODOM_ERR_INVALID_ARG;
   if (!h->v.knn_q) { g_last_error = "create the handle with debug_buffers = 1"; return LIODOM_ERR_UNSUPPORTED; }
   SideLocks lk(h, true, false);
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(sync_odometry(h));
   int E = 0;
   HIP_TRY(hipMemcpy(&E, &h->v.state[stream].n_edges_buf[h->last_eb], sizeof(int), hipMemcpyDeviceToHost));
   if (n) *n = E;
@@ -1777,7 +1917,7 @@ int liodom_get_curvature(liodom_handle_t* h, int stream, double* curv, int64_t c
   if (!(h->v.debug & 1)) { g_last_error = "create the handle with debug_buffers = 1"; return LIODOM_ERR_UNSUPPORTED; }
   SideLocks lk(h, true, true);
   HIP_TRY(hipStreamSynchronize(h->stream_x));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(sync_odometry(h));
   std::vector<int> rs((size_t)h->H + 1), rl((size_t)h->H);
   HIP_TRY(hipMemcpy(rs.data(), h->v.ring_start + (size_t)stream * (h->H + 1), sizeof(int) * (h->H + 1), hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(rl.data(), h->v.ring_len + (size_t)stream * h->H, sizeof(int) * h->H, hipMemcpyDeviceToHost));
@@ -1835,7 +1975,7 @@ int liodom_debug_clocks(liodom_handle_t* h, unsigned long long* out512) {
   if (int rc = enter(h)) return rc;
   SideLocks lk(h, true, true);
   HIP_TRY(hipStreamSynchronize(h->stream_x));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(sync_odometry(h));
   HIP_TRY(hipMemcpy(out512, h->v.dbg_clk, sizeof(unsigned long long) * 512, hipMemcpyDeviceToHost));
   return LIODOM_OK;
 }
@@ -1849,7 +1989,7 @@ int liodom_debug_knn_times(liodom_handle_t* h, unsigned int* out, int* cap) {
   if (int rc = enter(h)) return rc;
   SideLocks lk(h, true, true);
   HIP_TRY(hipStreamSynchronize(h->stream_x));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(sync_odometry(h));
   HIP_TRY(hipMemcpy(out, h->v.dbg_q, sizeof(unsigned int) * 2 * (size_t)h->v.edge_cap * 12, hipMemcpyDeviceToHost));
   return LIODOM_OK;
 }
@@ -1862,12 +2002,13 @@ int liodom_get_modes(liodom_handle_t* h, char* buf, int cap) {
   snprintf(buf, (size_t)cap,
            "n_streams=%d early_rebuild=%d hash_build=%s pipe_flags=%d flag_gate=%d lm_groups=%d knn_instance=%d knn_queries=%d "
            "knn_grid=%d/%d knn_partials=%d knn_saved_bound=%d knn_exact_only=%d line_gate_kernel=%d filter_local_map=%d mapping=%d "
-           "rotation_mode=%d table_size=%d rebuild_delta=%.3f knn_overlap=%d streams_concurrent=%d safe_mode=%d ring_split=%d ring_split_max_wgs=%d debug=%d",
+           "rotation_mode=%d table_size=%d rebuild_delta=%.3f knn_overlap=%d streams_concurrent=%d safe_mode=%d ring_split=%d ring_split_max_wgs=%d chain=%d debug=%d",
            h->S, v.early_rebuild, v.early_rebuild ? "streamed" : (h->lds_hash_build ? "lds" : "global"), h->use_flags ? 1 : 0,
            (h->use_flags && h->flag_gate) ? 1 : 0, v.lm_groups, h->S >= 16 ? 128 : 256, v.knn_queries, v.knn_grid,
            v.knn_blocks, v.knn_partials, v.knn_save_pos ? 2 : (v.knn_save_q ? 1 : 0), v.knn_exact_only, v.knn_nn ? 1 : 0, v.filter_local_map, v.mapping,
            v.rotation_mode, v.table_size, (double)v.rebuild_delta,
-           (v.early_rebuild && h->ov_ok && h->use_flags && g_live_handles.load() <= 1) ? 1 : 0, h->streams_concurrent ? 1 : 0, h->safe_mode ? 1 : 0, h->ring_split ? 1 : 0, h->ring_split ? h->ring_split_max_wgs : 0, v.debug);
+           (v.early_rebuild && (h->ov_ok || (h->chain_ok && !h->flag_gate)) && h->use_flags && g_live_handles.load() <= 1) ? 1 : 0, h->streams_concurrent ? 1 : 0, h->safe_mode ? 1 : 0, h->ring_split ? 1 : 0, h->ring_split ? h->ring_split_max_wgs : 0,
+           (v.early_rebuild && h->chain_ok && h->use_flags && !h->flag_gate && g_live_handles.load() <= 1) ? 1 : 0, v.debug);
   return LIODOM_OK;
 }
 

@@ -60,6 +60,7 @@ constexpr int kEdgePipeBufs = 3;
 constexpr int kEdgeBufX = 3;
 constexpr int kOvReplicas = 8;           // copies of the first solve's result, 4 KiB apart, for the polling k_knn workgroups
 constexpr int kOvGranules = 38;          // 19 doubles as {tag, 32 bits} granules
+constexpr int kPredGranules = 24;        // 12 doubles (pred_xch)
 
 // Per-stream device state.
 struct StreamState {
@@ -213,6 +214,14 @@ struct DevView {
   unsigned int* ov_flags;          // [S] sequence number of the latest scan whose first solve launch has started (its first kNN pass has completed)
   unsigned long long* pose_xch0;   // [S][kOvReplicas][512] the first solve's result (odom[12], q[4], t[3]) as 38 tagged granules, replicated over memory channels
   unsigned int* knn_done;          // [S][knn_grid] sequence number of the latest overlapped second pass workgroup b has completed
+  // Chain mode (round 5; "Chain mode" in kernels_sync.h): the kNN passes and the rebuild ride on ONE HIP stream (kNN(0), gate, COUNT/PAD,
+  // kNN(1), ALLOC, SCATTER/CLEAR, APPEND), the two solves on another; the first solve's launch is resident while the first pass
+  // still runs and takes its results through done flags, as the finalising solve takes the second pass's.
+  unsigned int* edge_cnt;          // [kEdgeBufs][32] write-through copy of n_edges_buf[b] of stream s (s < 32) at [b * 32 + s], a 128-byte line per buffer
+  unsigned int* knn_done0;         // [S] chain mode: workgroups of first passes that have completed, counted over the scans since the last reset
+                                   // (one word: the first solve's workgroups poll it with one thread each)
+  unsigned long long* pred_xch;    // [S][kOvReplicas][512] the prediction the next scan starts from (st.odom after finalize_scan: 12 doubles as 24
+                                   // tagged granules, tag = scans completed), for the next scan's first kNN pass, which runs on the other stream
   // Device-resident hand-off of the two-thread binding (liodom_extract_edges_device -> liodom_odometry_step_device, one-stream
   // handles): k_compact_edges also leaves the dense edges of pipeline buffer b in host-mapped memory, so that the extractor
   // thread can publish ~edges (feature_extractor.cc:70-75) without a device-to-host copy call; null on other handles.
@@ -272,6 +281,19 @@ __device__ __forceinline__ unsigned int hash_cell(unsigned long long k, unsigned
   unsigned int h = (x * 73856093u) ^ (y * 19349663u) ^ (z * 83492791u);
   h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
   return h & mask;
+}
+
+// Every in-kernel wait is bounded twice: by an iteration count and — round 5 — by WALL-CLOCK time (g_wait_ticks, 100 MHz ticks;
+// liodom_create sets it from LIODOM_WAIT_MS, default 50 ms = several hundred times the longest wait of an undisturbed scan).
+// Beside a process that saturates the GPU the producers a waiter depends on get their CUs late, but often just in time for an
+// iteration bound sized for ~0.3 s: the replay then crawled at tens of milliseconds per scan instead of failing over to the
+// safe mode (the two-process soak took 5 minutes).  A wait that outlasts the time bound raises the same status bits.
+__device__ unsigned long long g_wait_ticks = 5000000ull;
+__device__ __forceinline__ bool wait_expired(unsigned int spins, unsigned long long& t0) {
+  if ((spins & 31u) != 0u) return false;
+  const unsigned long long now = wall_clock64();
+  if (t0 == 0ull) { t0 = now; return false; }
+  return now - t0 > g_wait_ticks;
 }
 
 // ---- the kernels, by stage (one translation unit; the order matters: later parts use helpers of earlier ones) ----

@@ -943,11 +943,13 @@ def test_sixteen_streams_headline_size_against_the_oracle(orc, synth):
     assert worst_t < 1e-6 and worst_r < 1e-6
 
 
-@pytest.mark.parametrize("shape,scans", [("hdl64", 1200), ("vlp16", 1200)])
+@pytest.mark.parametrize("shape,scans", [("hdl64", 1200), ("vlp16", 1200), ("ouster128", 300)])
 def test_overlapped_pass_long_replay_is_bit_identical(shape, scans):
-    """tools/overlap_equal.py: the same long replay with and without the overlapped second kNN pass (LIODOM_KNN_OVERLAP, read at
-    handle creation: one process per mode) gives bit-identical pose logs.  Guards the fence-free hand-offs of kernels_sync.h:
-    a stale line read by the finalising solve would show up here as a differing pose."""
+    """tools/overlap_equal.py: the same long replay in chain mode (kNN passes + rebuild on one HIP stream, the solves on another, the
+    first solve resident beside the first pass), with the overlapped second kNN pass alone, and with neither (LIODOM_CHAIN /
+    LIODOM_KNN_OVERLAP, read at handle creation: one process per mode) gives bit-identical pose logs.  Guards the fence-free
+    hand-offs of kernels_sync.h: a stale line read by a solve would show up here as a differing pose.  (Ouster-128 overlaps the pass
+    in chain mode only.)"""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "overlap_equal.py"), shape, str(scans)], capture_output=True, text=True, timeout=900)

@@ -270,7 +270,7 @@ def sec_ovclocks(H=64, W=1800, R=8, epr=10, P=20, K=40):
     a = allv[448:480]
     names = ["solve0 wg0 start", "solve0 pose published", "solve0 wg0 end", "solve1 wg0 start", "solve1 wait done", "solve1 wg0 end", "gate start", "gate saw flag",
              "knn1 wg0 start", "knn1 wg0 past flag", "knn1 wg0 pose seen", "knn1 wg0 end", "knn1 wgN start", "knn1 wgN past flag", "knn1 wgN pose seen", "knn1 wgN end",
-             "knn0 wg0 start", "knn0 wgN end", "solve0 partial sums next"]
+             "knn0 wg0 start", "knn0 wgN end", "solve0 partial sums next", "", "", "", "", "", "", "", "append wg0 end", "knn0 wg0 past its waits", "append wg0 pose seen"]
     t0 = a[16] if a[16] else a[0]
     order = sorted(range(len(names)), key=lambda i: a[i])
     for i in order:

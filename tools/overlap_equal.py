@@ -1,4 +1,4 @@
-"""Pose logs of the same replay with and without the overlapped second kNN pass must be bit-identical.
+"""Pose logs of the same replay in chain mode, with the overlapped second kNN pass alone, and with neither must be bit-identical.
 usage: python tools/overlap_equal.py [hdl64|vlp16] [scans]   (spawns itself once per mode: the switch is read at handle creation)"""
 import os, subprocess, sys
 import numpy as np
@@ -9,7 +9,7 @@ K = int(sys.argv[2]) if len(sys.argv) > 2 else 600
 if len(sys.argv) > 3:
     import liodom_amd as la
     from liodom_amd import synth
-    H, W, LT, R, epr, P = {"hdl64": (64, 1800, 0, 8, 10, 20), "vlp16": (16, 1800, 0, 8, 20, 10)}[shape]
+    H, W, LT, R, epr, P = {"hdl64": (64, 1800, 0, 8, 10, 20), "vlp16": (16, 1800, 0, 8, 20, 10), "ouster128": (128, 2048, 1, 8, 10, 30)}[shape]
     cfg = synth.make_cfg(H, W, LT)
     g = la.Liodom(la.make_params(lidar_type=LT, scan_lines=H, scan_regions=R, edges_per_region=epr, prev_frames=P),
                   la.make_config(n_streams=1, max_points=H * W, max_width=W, pose_log_capacity=K + 8))
@@ -25,18 +25,23 @@ if len(sys.argv) > 3:
         assert all(int(i.status) == 0 for i in infos)
         out.append(poses.copy())
     np.save(sys.argv[3], np.concatenate(out))
-    print(g.modes()["knn_overlap"], flush=True)
+    print(g.modes()["knn_overlap"] + g.modes().get("chain", "0"), flush=True)
     g.close()
     sys.exit(0)
 files = []
-for ov in ("1", "0"):
-    f = "/tmp/ov_%s_%s.npy" % (shape, ov)
-    env = dict(os.environ, LIODOM_KNN_OVERLAP=ov)
+for ov, ch in (("1", "1"), ("1", "0"), ("0", "0")):
+    f = "/tmp/ov_%s_%s%s.npy" % (shape, ov, ch)
+    env = dict(os.environ, LIODOM_KNN_OVERLAP=ov, LIODOM_CHAIN=ch)
     r = subprocess.run([sys.executable, os.path.abspath(__file__), shape, str(K), f], env=env, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
-    assert r.stdout.strip().splitlines()[-1] == ov, r.stdout
+    got = r.stdout.strip().splitlines()[-1]
+    assert got == ov + ch or (shape == "ouster128" and ch == "0" and got == "00"), r.stdout      # (Ouster-128: the pass is overlapped in chain mode only)
     files.append(f)
-a, b = np.load(files[0]), np.load(files[1])
-same = np.array_equal(a.view(np.uint64), b.view(np.uint64))
-print("%s: %d scans, overlapped vs not: %s" % (shape, K, "bit-identical" if same else "DIFFERENT"))
+a, b, c = np.load(files[0]), np.load(files[1]), np.load(files[2])
+same = np.array_equal(a.view(np.uint64), b.view(np.uint64)) and np.array_equal(b.view(np.uint64), c.view(np.uint64))
+if not same:
+    for nm, x in (("chain vs overlapped", a), ("plain vs overlapped", c)):
+        d = np.nonzero(np.any(x.view(np.uint64) != b.view(np.uint64), axis=(1, 2)))[0]
+        print("  %s: %d scans differ, first %s" % (nm, len(d), d[:5]))
+print("%s: %d scans, chain mode vs overlapped pass vs neither: %s" % (shape, K, "bit-identical" if same else "DIFFERENT"))
 sys.exit(0 if same else 1)
