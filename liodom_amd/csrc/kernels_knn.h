@@ -120,6 +120,25 @@ template <bool kDeep> struct KnnTune {
   static constexpr bool kCursor = kDeep ? false : LIODOM_TUNE_B_CURSOR;      // flat list: per-lane cursor instead of the binary search
 };
 constexpr int kKnnGridDiv = 2;         // k_knn grid = half of the query blocks the edge capacity allows: a workgroup takes block b and, if the scan has that many edges, b + grid
+// Candidate distance with packed FP32 arithmetic (experiment LIODOM_KNN_PK, round 5): dx and dy of one candidate share a
+// v_pk_add_f32 and a v_pk_mul_f32 (x and y of a loaded float4 are an aligned register pair); the same operations in the same
+// order as sqdist_f, each rounded on its own: bit-identical.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float sqdist_cand(float qx, float qy, float qz, const float4& m) {
+#if defined(LIODOM_KNN_PK)
+  const f32x2_t q = {qx, qy};
+  const f32x2_t mm = {m.x, m.y};
+  const f32x2_t d = q - mm;
+  const f32x2_t sq = d * d;
+  float r = sq.x;
+  r = r + sq.y;
+  const float dz = qz - m.z;
+  r = r + dz * dz;
+  return r;
+#else
+  return sqdist_f(qx, qy, qz, m.x, m.y, m.z);
+#endif
+}
 template <class Acc, int UB, int U, int kBigCell, bool kCursor = false>
 __device__ __forceinline__ void knn_stream_cells(Acc& t, const float4* sp, int* s_incl, int* s_adj,
                                                  unsigned int start, unsigned int cnt, int hl,
@@ -140,7 +159,7 @@ __device__ __forceinline__ void knn_stream_cells(Acc& t, const float4* sp, int* 
 #pragma unroll
         for (int u = 0; u < UB; u++) {
           const int iu = i + u * kKnnGroup;
-          t.consider(iu < cc, sqdist_f(qx, qy, qz, m[u].x, m[u].y, m[u].z), __float_as_int(m[u].w), cs + iu);
+          t.consider(iu < cc, sqdist_cand(qx, qy, qz, m[u]), __float_as_int(m[u].w), cs + iu);
         }
       }
     }
@@ -189,7 +208,7 @@ __device__ __forceinline__ void knn_stream_cells(Acc& t, const float4* sp, int* 
     for (int u = 0; u < U; u++) m[u] = sp[a[u]];
 #pragma unroll
     for (int u = 0; u < U; u++)
-      t.consider(i + u * kKnnGroup < T, sqdist_f(qx, qy, qz, m[u].x, m[u].y, m[u].z), __float_as_int(m[u].w), a[u]);
+      t.consider(i + u * kKnnGroup < T, sqdist_cand(qx, qy, qz, m[u]), __float_as_int(m[u].w), a[u]);
   }
   __builtin_amdgcn_wave_barrier();
   if (dbg && hl == 0) {
@@ -1039,7 +1058,9 @@ __global__ __launch_bounds__(kKnnThreads, (kKnnThreads >= 256 ? 1 : LIODOM_TUNE_
   if (kOv) { OV_STAMP(v, threadIdx.x == 0 && bxi == 0, 8); OV_STAMP(v, threadIdx.x == 0 && bxi == v.knn_grid - 1, 12); }
   else if (outer_it == 0) OV_STAMP(v, threadIdx.x == 0 && bxi == 0, 16);
   knn_pass<kKnnThreads, kOv, kChain>(v, s, bxi, byi, outer_it, eb, wait_edges, signal_odo, seq, scan_no, sh, shs[kOv ? 1 : 0], sh_ov);
-  if (kOv) ov_signal_knn_done(v, s, bxi, seq);       // (every exit of the pass is workgroup-uniform)
+  // (every exit of the pass is workgroup-uniform)  chain mode (scan_no >= 0 on this instance): the pass's workgroups count themselves
+  // on one word, as the first pass's do; else one flag per workgroup
+  if (kOv) { if (scan_no >= 0) chain_count_done(v.knn_done0 + 32 + s); else ov_signal_knn_done(v, s, bxi, seq); }
   if (kChain) chain_count_done(v.knn_done0 + s);
   if (kInstrument && (v.debug & 128) && threadIdx.x == 0) {
     if (kOv) {                                         // (debug) pose seen -> flag raised, per workgroup with queries: 0.5 us bins

@@ -467,7 +467,8 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
     c_lo = g * chunk < C ? g * chunk : C;
     c_hi = (g + 1) * chunk < C ? (g + 1) * chunk : C;
   };
-  if (seq && outer_it == 1) ov_wait_knn_done(v, s, seq, &st.status);      // the overlapped second kNN pass has completed
+  // the overlapped second kNN pass has completed (chain mode: its workgroups count themselves on one word; else a flag each)
+  if (seq && outer_it == 1) { if (chain) chain_wait_count(v.knn_done0 + 32 + s, done_target, &st.status); else ov_wait_knn_done(v, s, seq, &st.status); }
   OV_STAMP(v, g == 0 && tid == 0 && outer_it == 1, 4);
   OV_STAMP(v, g == 0 && tid == 0 && outer_it == 0, 18);
   if (v.knn_partials) {

@@ -404,12 +404,7 @@ __device__ void rebuild_beside_solve(const DevView& v, int s, StreamState& st, i
 
 // Chain mode: the rebuild's steps as launches of their own on the stream of the kNN passes (light kernels: as extra workgroups of
 // k_lm_solve every one of them owned a whole CU — 256 VGPRs x 8 waves — and could only be placed on a CU that ran nothing else).
-__global__ __launch_bounds__(kLmThreads) void k_rebuild_cp(DevView v, int s0, int eb) {          // COUNT + PAD
-  __shared__ int sh_cnt[kMaxFrames + 1];
-  __shared__ int sh_slot[kMaxFrames];
-  const int s = s0 + blockIdx.y;
-  rebuild_count_and_pad(v, s, v.state[s], eb, (int)blockIdx.x, sh_cnt, sh_slot);
-}
+// COUNT + PAD ride on the second kNN pass's launch (k_knn<256, true>: its extra workgroups), ALLOC is k_rebuild_alloc.
 __global__ __launch_bounds__(kLmThreads) void k_rebuild_fin(DevView v, int s0, int eb) {         // APPEND (waits for the solved pose), CLEAR, SCATTER
   __shared__ int sh_cnt[kMaxFrames + 1];
   __shared__ int sh_slot[kMaxFrames];

@@ -47,6 +47,29 @@ __global__ void k_pipe_gate(DevView v, int s0, int eb, unsigned int wait_edges, 
     for (int s = (int)threadIdx.x; s < v.n_streams; s += (int)blockDim.x) atomicOr(&v.state[s].status, LIODOM_STATUS_PIPE_TIMEOUT);
   }
 }
+// =============================================================================================
+// Chain mode (round 5; one-stream handles with the streamed rebuild and flags, scans whose edges arrive by flag from the
+// extraction stream — the pipelined replay and the ticket API).  The scan's launches are split over two HIP streams by ROLE:
+//   stream_k:  kNN(0) | gate | kNN(1) + COUNT + PAD | ALLOC | APPEND + CLEAR + SCATTER            (light kernels)
+//   stream:    solve(0) | solve(1)                                                                 (the solving workgroups alone)
+// * solve(0) of scan k follows solve(1) of scan k-1 in stream order, i.e. its launch is RESIDENT while kNN(0) of scan k still runs:
+//   the pass's workgroups store their results write-through and count themselves on one word (chain_count_done), one thread per
+//   solving workgroup polls it (chain_wait_count) — the hand-off the finalising solve has had from the overlapped second pass
+//   since round 3, now also between the first pass and the first solve.
+// * kNN(0) of scan k+1 follows APPEND of scan k in stream order: a true kernel boundary, which is what makes the rebuilt cell
+//   hash — megabytes written by plain stores and atomics from every XCD — visible to it (a pass pre-launched across the rebuild
+//   would have to invalidate its L2: the eight L2s are not coherent).  The one thing it needs from solve(1), which may still be in
+//   finalize_scan, is the prediction: pred_xch, tagged granules.  Everything else it reads of the stream's state follows from
+//   scan_no (frames appended = scans completed) or was written by launches of its own stream.
+// * the rebuild's steps are launches of their own (k_rebuild_alloc, k_rebuild_fin) or extra workgroups of the LIGHT second pass
+//   (COUNT + PAD): as extra workgroups of k_lm_solve each of them owned a whole CU (256 VGPRs x 8 waves) and could only be placed
+//   on a CU that ran nothing else — the reason why shapes whose second pass has many waiting workgroups (Ouster-128: 704) lost
+//   9 % with the overlapped pass; in chain mode the same pass gains 19 % there.
+// * finalize_scan must not touch what the rebuild of its own scan still uses on the other stream: st.cursor is reset by the next
+//   scan's kNN(0) instead (ALLOC may still be allocating from it).
+// What it does NOT buy (measured, in-kernel stamps, profiles/r05_*): the kNN(0) -> solve(0) boundary costs ~1.5 us on this stack,
+// and the write-through tail + count + granule read of the chain cost about the same: HDL-64 is unchanged within +-2.5 %.
+// Bit-identical to the four-launch path: same workgroups, same partial sums, same order (tools/overlap_equal.py).
 // Gate in front of the extraction of a host-fed scan: one wave waits until the copy stream has published the upload's sequence
 // number (hipStreamWriteValue32 / k_set_flag behind the hipMemcpyAsync) — the place of a hipStreamWaitEvent, whose barrier packet
 // costs ~11 us of idle stream.  The extraction kernels behind it start when it retires (kernel start: clean caches).

@@ -357,7 +357,7 @@ int enqueue_odometry(liodom_handle* h, int eb, int s0, int count, unsigned int w
     hipLaunchKernelGGL(k_lm_solve, dim3(gx, 1), dim3(kLmThreads), lds, h->stream, v, s0, 0, eb, seq_k, 1, done_target);
     hipLaunchKernelGGL(k_ov_gate, dim3(1), dim3(64), 0, h->stream_k, v, s0, seq_k);
     hipLaunchKernelGGL((k_knn<256, true>), dim3(v.knn_grid + nCP, 1), dim3(256), 0, h->stream_k, v, s0, 1, eb, 0u, 0u, seq_k, scan_no);
-    hipLaunchKernelGGL(k_lm_solve, dim3(gx, 1), dim3(kLmThreads), lds, h->stream, v, s0, 1, eb, seq_k, 1, 0u);
+    hipLaunchKernelGGL(k_lm_solve, dim3(gx, 1), dim3(kLmThreads), lds, h->stream, v, s0, 1, eb, seq_k, 1, done_target);
     hipLaunchKernelGGL(k_rebuild_alloc, dim3(kRebuildAllocBlocks, 1), dim3(256), 0, h->stream_k, v, s0);
     hipLaunchKernelGGL(k_rebuild_fin, dim3(nP + kRebuildAuxBlocks + nC, 1), dim3(kLmThreads), 0, h->stream_k, v, s0, eb);
     HIP_TRY(hipGetLastError());
@@ -372,7 +372,7 @@ int enqueue_odometry(liodom_handle* h, int eb, int s0, int count, unsigned int w
         if (v.knn_nn) hipLaunchKernelGGL(k_line_gate, dim3(cdiv(h->v.knn_blocks * h->v.knn_queries, 256), count), dim3(256), 0, h->stream, v, s0, it, eb);
       } else if (it == 1 && seq_k) {
         hipLaunchKernelGGL(k_ov_gate, dim3(1), dim3(64), 0, h->stream_k, v, s0, seq_k);
-        hipLaunchKernelGGL((k_knn<256, true>), dim3(kx, count), dim3(256), 0, h->stream_k, v, s0, it, eb, 0u, 0u, seq_k, 0);
+        hipLaunchKernelGGL((k_knn<256, true>), dim3(kx, count), dim3(256), 0, h->stream_k, v, s0, it, eb, 0u, 0u, seq_k, -1);
         // ALLOC between the two solve launches, beside the pass's tail
         hipLaunchKernelGGL(k_rebuild_alloc, dim3(kRebuildAllocBlocks, count), dim3(256), 0, h->stream, v, s0);
       } else {
@@ -618,7 +618,7 @@ int reset_state(liodom_handle* h) {
   HIP_TRY(hipMemsetAsync(h->v.lm_xch, 0, sizeof(unsigned long long) * (size_t)h->S * 2 * kLmGroupsMax * 64, h->stream));
   HIP_TRY(hipMemsetAsync(h->v.pose_xch, 0, sizeof(unsigned long long) * (size_t)h->S * 32, h->stream));
   if (h->v.pred_xch) HIP_TRY(hipMemsetAsync(h->v.pred_xch, 0, sizeof(unsigned long long) * (size_t)h->S * kOvReplicas * 512, h->stream));
-  HIP_TRY(hipMemsetAsync(h->v.knn_done0, 0, sizeof(unsigned int) * (size_t)h->S, h->stream));
+  HIP_TRY(hipMemsetAsync(h->v.knn_done0, 0, sizeof(unsigned int) * ((size_t)h->S + 64), h->stream));
   h->chain_prev = false; h->chain_count = 0;
   std::memset(h->host_out, 0, sizeof(HostOut) * 2 * (size_t)h->S);
   std::fill(h->scans_enqueued.begin(), h->scans_enqueued.end(), 0);
@@ -940,7 +940,7 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   ALLOC(v.ov_flags, S, 0);
   ALLOC(v.pose_xch0, S * (size_t)kOvReplicas * 512, 0);
   ALLOC(v.knn_done, S * (size_t)v.knn_grid, 0);
-  ALLOC(v.knn_done0, S + 32, 0);
+  ALLOC(v.knn_done0, S + 64, 0);
   if (v.early_rebuild) ALLOC(v.pred_xch, S * (size_t)kOvReplicas * 512, 0); else v.pred_xch = nullptr;
   ALLOC(v.edge_cnt, (size_t)kEdgeBufs * 32, 0);
   // (the two passes' validity bytes never share a 128-byte line: the overlapped second pass writes its half while the finalising

@@ -218,8 +218,8 @@ struct DevView {
   // kNN(1), ALLOC, SCATTER/CLEAR, APPEND), the two solves on another; the first solve's launch is resident while the first pass
   // still runs and takes its results through done flags, as the finalising solve takes the second pass's.
   unsigned int* edge_cnt;          // [kEdgeBufs][32] write-through copy of n_edges_buf[b] of stream s (s < 32) at [b * 32 + s], a 128-byte line per buffer
-  unsigned int* knn_done0;         // [S] chain mode: workgroups of first passes that have completed, counted over the scans since the last reset
-                                   // (one word: the first solve's workgroups poll it with one thread each)
+  unsigned int* knn_done0;         // [S + 64] chain mode (S = 1): [s] workgroups of first passes that have completed, counted over the scans since the
+                                   // last reset (one word: the first solve's workgroups poll it with one thread each); [32 + s] (a cache line of its own) the same for second passes
   unsigned long long* pred_xch;    // [S][kOvReplicas][512] the prediction the next scan starts from (st.odom after finalize_scan: 12 doubles as 24
                                    // tagged granules, tag = scans completed), for the next scan's first kNN pass, which runs on the other stream
   // Device-resident hand-off of the two-thread binding (liodom_extract_edges_device -> liodom_odometry_step_device, one-stream

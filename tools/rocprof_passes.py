@@ -54,3 +54,34 @@ if any("true" in r[0] for r in rows):
               (len(scans), avg(lambda c: c["k0"][1] - c["k0"][0]), avg(lambda c: c["l0"][1] - c["l0"][0]), avg(lambda c: c["k1"][1] - c["l0"][1]),
                avg(lambda c: c["al"][1] - c["al"][0]), avg(lambda c: c["l1"][0] - c["l0"][1]), avg(lambda c: c["l1"][1] - c["l1"][0]),
                avg(lambda c: c["l1"][1] - c["k0"][0])))
+
+# Chain mode (round 5): k_knn<256, false, true> (first pass) | k_ov_gate | k_knn<256, true, false> (+ COUNT / PAD) | k_rebuild_alloc |
+# k_rebuild_fin on one stream, the two k_lm_solve launches (solving workgroups only) on the other; a solve launch is RESIDENT while
+# the pass before it still runs, so its duration is not its work: the phases are measured between the ends of the links.
+rows = db.execute("select name, start, end from kernels where name like '%k_knn%' or name like '%k_lm_solve%' or name like '%k_rebuild_fin%' order by start").fetchall()
+if any("false, true" in r[0] for r in rows):
+    k0 = [r for r in rows if "k_knn" in r[0] and "false, true" in r[0]]
+    k1 = [r for r in rows if "k_knn" in r[0] and "true, false" in r[0]]
+    lm = [r for r in rows if "k_lm_solve" in r[0]]
+    fin = [r for r in rows if "k_rebuild_fin" in r[0]]
+    scans = []
+    for i in range(len(k0) - 1):
+        a, nxt = k0[i], k0[i + 1]
+        b1 = [e for e in k1 if a[1] <= e[1] < nxt[1]]
+        fn = [e for e in fin if a[1] <= e[1] < nxt[2]]
+        # the scan's two solves: those that END after this first pass has ended and before the next first pass has (the first
+        # solve of the next scan is resident by then but ends later)
+        sol = [e for e in lm if a[2] <= e[2] <= nxt[2]]
+        if len(b1) != 1 or len(fn) != 1 or len(sol) != 2:
+            continue
+        s0, s1 = sol
+        end = max(s1[2], fn[0][2])
+        scans.append((a[2] - a[1], s0[2] - a[2], b1[0][2] - s0[2], s1[2] - b1[0][2], end - s1[2], end - a[1], nxt[1] - a[1], s0[1] - a[1]))
+    scans = [c for c in scans if c[6] < 300e3]
+    scans = scans[len(scans) // 10: len(scans) // 5] if len(scans) >= 500 else scans[-150:]
+    if scans:
+        import statistics as st
+        col = lambda j: st.median(c[j] for c in scans) / 1e3
+        print("chain-mode scans (n=%d, medians): first pass %.2f us; first solve ends %.2f after it (its launch starts %.2f after the pass's); second pass "
+              "ends %.2f after the first solve; finalising solve ends %.2f after the second pass; APPEND launch ends %.2f after that; first pass start -> "
+              "end of the scan %.2f us; period %.2f us" % (len(scans), col(0), col(1), col(7), col(2), col(3), col(4), col(5), col(6)))
