@@ -282,7 +282,7 @@ __device__ __forceinline__ void knn_merge(Top5& t, Top5& g, int hl, int half_shi
 // win: 8 (256 threads) on handles with few streams, 4 (128 threads) on lock-step batches; two instances, chosen by
 // the host from the stream count.
 __device__ void rebuild_alloc(const DevView& v, int s, StreamState& st, int block, int nblocks);
-__device__ void rebuild_count_and_pad(const DevView& v, int s, StreamState& st, int eb, int block, int* sbase, int* sslot);
+__device__ void rebuild_count_and_pad(const DevView& v, int s, StreamState& st, int eb, int block, int* sbase, int* sslot, bool keep);
 
 // LDS of one k_knn workgroup (kQ queries)
 template <int kQ>
@@ -760,9 +760,9 @@ __device__ __forceinline__ void knn_block(const DevView& v, int s, StreamState& 
     if (eq < E && sh.res[q][0] != 0) {
       double Rm[12], pq[4], pt[3];
 #pragma unroll
-      for (int i = 0; i < 4; i++) pq[i] = kPre ? qt[i] : st.param_q[i];
+      for (int i = 0; i < 4; i++) pq[i] = kWt ? qt[i] : st.param_q[i];      // (kWt: the state's copy is being written by a launch that may still run)
 #pragma unroll
-      for (int i = 0; i < 3; i++) pt[i] = kPre ? qt[4 + i] : st.param_t[i];
+      for (int i = 0; i < 3; i++) pt[i] = kWt ? qt[4 + i] : st.param_t[i];
       iso_from_qt(pq, pt, Rm);
       const float4 pe = v.edges[((size_t)eb * v.n_streams + s) * v.edge_cap + eq];
       const double p[3] = {(double)pe.x, (double)pe.y, (double)pe.z};       // :347-349 sensor frame
@@ -898,7 +898,10 @@ __device__ __forceinline__ void knn_tail_dual(const DevView& v, int s, int outer
 // kChain: the FIRST pass of a scan in chain mode (kernels_sync.h "Chain mode"): it runs on the stream of the kNN passes and the
 // rebuild, behind the previous scan's APPEND launch; the scan's first solve — on the other stream — is resident already and waits
 // for this pass's done flags, so the results leave write-through.  The prediction the scan starts from comes from pred_xch
-// (the previous scan's finalize_scan may still be running: its plain stores to the stream's state are not visible yet);
+// (the previous scan's finalize_scan may still be running: its plain stores to the stream's state are not visible yet) — the
+// matrix the queries are transformed with AND the quaternion / translation the residual blocks of the partial sums are evaluated at
+// (st.param_q / st.param_t: on the short solves of the 16-ring shapes the pass got there before finalize_scan's stores: wrong
+// partial sums, poses off by millimetres, found by the two-thread and soak tests);
 // everything else this pass needs of that state follows from scan_no, the number of scans completed before this one.
 template <int kKnnThreads, bool kOv, bool kChain>
 __device__ __forceinline__ void knn_pass(const DevView& v, int s, int bxi, int byi, int outer_it, int eb, unsigned int wait_edges,
@@ -961,7 +964,17 @@ __device__ __forceinline__ void knn_pass(const DevView& v, int s, int bxi, int b
   const unsigned int st_status = st.status;
   const int st_init = kChain ? 1 : st.initialized;
   const int fc = kChain ? scan_no : st.frame_count;
-  const int E = st.n_edges_buf[eb];
+  // (chain mode: the edge count comes from k_compact_edges' write-through copy in a cache line of its own.  The state word shares
+  //  its line with fields that the previous scan's finalize_scan — possibly still running on this XCD when this launch started —
+  //  has cached; when the extraction finished after that, a workgroup on that XCD read the count of the scan that used this edge
+  //  buffer three scans ago: wrong poses in the two-thread binding on a cold box, where the extraction runs late)
+  int E;
+  if (kChain) {
+    typedef __attribute__((address_space(1))) unsigned int gu32;
+    E = (int)__hip_atomic_load((gu32*)(v.edge_cnt + eb * 32 + s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    E = st.n_edges_buf[eb];
+  }
   if (st_status & LIODOM_STATUS_PIPE_TIMEOUT) return;      // (uniform) a wait of this handle gave up: the edge buffer may be incomplete
   if (!st_init) return;                            // uniform over the workgroup
   // (two explicit calls, not a loop over bv: as a loop body the block needs 160 VGPRs instead of 69)
@@ -1006,7 +1019,7 @@ __device__ __forceinline__ void knn_pass(const DevView& v, int s, int bxi, int b
     knn_tail_dual<kKnnThreads>(v, s, outer_it, eb, bxi, bv2, second, E, sh, sh2, sh_ov + 12);
     return;
   }
-  knn_block<kKnnThreads, false, true, kWt>(v, s, st, fc, outer_it, eb, bxi, E, sh, p_first, T, pre1, nullptr);
+  knn_block<kKnnThreads, false, true, kWt>(v, s, st, fc, outer_it, eb, bxi, E, sh, p_first, T, pre1, kChain ? sh_ov + 12 : nullptr);
   if (bv2 >= v.knn_blocks) return;
   if (!second) {
     if (threadIdx.x == 0) { unsigned char* cm = &v.corr_mask[((size_t)s * 2 + outer_it) * v.mask_stride + bv2]; if (kWt) wt_store_u8(cm, 0); else *cm = 0; }
@@ -1025,7 +1038,7 @@ __device__ __forceinline__ void knn_pass(const DevView& v, int s, int bxi, int b
       for (int i = 0; i < 12; i++) T2[i] = st.odom[i];
     }
   }
-  knn_block<kKnnThreads, false, true, kWt>(v, s, st, fc, outer_it, eb, bv2, E, sh, p_second, T2, pre2, nullptr);
+  knn_block<kKnnThreads, false, true, kWt>(v, s, st, fc, outer_it, eb, bv2, E, sh, p_second, T2, pre2, kChain ? sh_ov + 12 : nullptr);
 }
 
 template <int kKnnThreads, bool kOv = false, bool kChain = false>
@@ -1050,7 +1063,7 @@ __global__ __launch_bounds__(kKnnThreads, (kKnnThreads >= 256 ? 1 : LIODOM_TUNE_
     if (bxi >= v.knn_grid) {
       __shared__ int sh_rb_cnt[kMaxFrames + 1];
       __shared__ int sh_rb_slot[kMaxFrames];
-      rebuild_count_and_pad(v, s, v.state[s], eb, bxi - v.knn_grid, sh_rb_cnt, sh_rb_slot);
+      rebuild_count_and_pad(v, s, v.state[s], eb, bxi - v.knn_grid, sh_rb_cnt, sh_rb_slot, true);
       return;
     }
   }

@@ -188,7 +188,7 @@ __device__ __forceinline__ void publish_final_pose(const DevView& v, int s, cons
 // chain: the rebuild of this scan runs on the other HIP stream, beside this launch (ALLOC may still be allocating cell ranges from
 // st.cursor): the cursor is then reset by the next scan's first kNN pass, which follows the rebuild in stream order.
 __device__ void finalize_scan(const DevView& v, int s, StreamState& st, int* sh_cnt, int eb, bool clear_hash, int ctl, int chain = 0) {
-  __shared__ double sh_pred[12];
+  __shared__ double sh_pred[19];      // the prediction: matrix [12], quaternion [4], translation [3]
   const int P = v.prev_frames;
   const int tid = threadIdx.x;
   // LocalMapManager::addPointCloud (:34-60) on a ring of P frame slots: the new frame goes
@@ -244,6 +244,8 @@ __device__ void finalize_scan(const DevView& v, int s, StreamState& st, int* sh_
     for (int i = 0; i < 12; i++) { st.prev_odom[i] = st.final_odom[i]; st.odom[i] = pred[i]; sh_pred[i] = pred[i]; }
     quat_from_pose(pred, v.rotation_mode, st.param_q);               // :186-190 q_curr(odom_.rotation())
     st.param_t[0] = pred[3]; st.param_t[1] = pred[7]; st.param_t[2] = pred[11];   // :192-195
+    for (int i = 0; i < 4; i++) sh_pred[12 + i] = st.param_q[i];
+    sh_pred[16] = pred[3]; sh_pred[17] = pred[7]; sh_pred[18] = pred[11];
     wn[new_slot] = n_edges;
     st.frame_count = fc_new;
     st.n_frames = nf;

@@ -179,7 +179,12 @@ __device__ __forceinline__ float4 predicted_point(const StreamState& st, const f
 }
 
 // COUNT (block < nC) and PAD (the nP blocks behind them)
-__device__ void rebuild_count_and_pad(const DevView& v, int s, StreamState& st, int eb, int block, int* sbase, int* sslot) {
+// keep (chain mode): PAD also copies the scan's edges into edges_keep, which APPEND reads instead of the edge buffer.  APPEND is a
+// launch of its own there and may start after the scan's pose has been published — i.e. after the host may have collected it and
+// handed the edge buffer's ticket slot to the extraction of a later scan (found by tools/chain_hammer.py: APPEND transformed the
+// edges of scan k + 3, for which nothing had been padded).  On the four-launch chain the appending workgroups are resident, with
+// their edge in registers, before the pose exists.
+__device__ void rebuild_count_and_pad(const DevView& v, int s, StreamState& st, int eb, int block, int* sbase, int* sslot, bool keep = false) {
   const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63;
   const int par = (st.reb_frame_count + 1) & 1;
   const int nC = (v.edge_cap * (v.prev_frames > 1 ? v.prev_frames - 1 : 1) + nt - 1) / nt;
@@ -198,7 +203,10 @@ __device__ void rebuild_count_and_pad(const DevView& v, int s, StreamState& st, 
   const int idx = (block - nC) * nt + tid;
   if ((block - nC) * nt >= n_new) return;
   const bool live = idx < n_new;
-  const float4 q = predicted_point(st, v.edges[((size_t)eb * v.n_streams + s) * v.edge_cap + (live ? idx : 0)]);
+  const float4 e_in = v.edges[((size_t)eb * v.n_streams + s) * v.edge_cap + (live ? idx : 0)];
+  if (keep && live && v.edges_keep) v.edges_keep[(size_t)s * v.edge_cap + idx] = e_in;
+  if (keep && idx == 0) st.reb_pad = n_new;                    // (the count APPEND iterates over, for the same reason)
+  const float4 q = predicted_point(st, e_in);
   const bool fin = live && point_finite(q);
   const float d = v.rebuild_delta;
   const int lx = (int)floorf((q.x - d) * kCellInv), hx = (int)floorf((q.x + d) * kCellInv);
@@ -271,7 +279,7 @@ __global__ __launch_bounds__(256) void k_rebuild_alloc(DevView v, int s0) {
 }
 
 // SCATTER / APPEND / CLEAR, beside the finalising solve
-__device__ void rebuild_finish(const DevView& v, int s, StreamState& st, int eb, int block, unsigned int seq, int* sbase, int* sslot) {
+__device__ void rebuild_finish(const DevView& v, int s, StreamState& st, int eb, int block, unsigned int seq, int* sbase, int* sslot, bool kept = false) {
   __shared__ double sh_T[12];
   __shared__ int sh_hand;
   const int tid = threadIdx.x, nt = blockDim.x;
@@ -303,11 +311,12 @@ __device__ void rebuild_finish(const DevView& v, int s, StreamState& st, int eb,
     return;
   }
   // APPEND the new frame
-  const int n_new = st.n_edges_buf[eb];
+  const int n_new = (kept && v.edges_keep) ? st.reb_pad : st.n_edges_buf[eb];
   if (block * nt >= n_new) return;
   const int idx = block * nt + tid;
   const bool live = idx < n_new;
-  const float4 e = v.edges[((size_t)eb * v.n_streams + s) * v.edge_cap + (live ? idx : 0)];     // (loaded before the wait)
+  const float4 e = (kept && v.edges_keep) ? v.edges_keep[(size_t)s * v.edge_cap + (live ? idx : 0)]
+                                          : v.edges[((size_t)eb * v.n_streams + s) * v.edge_cap + (live ? idx : 0)];     // (loaded before the wait)
   const float4 q = predicted_point(st, e);
   // the cell the prediction puts the point into is where it ends up almost always: look its slot up before the wait
   const unsigned int tmask = (unsigned int)v.table_size - 1u;
@@ -409,7 +418,7 @@ __global__ __launch_bounds__(kLmThreads) void k_rebuild_fin(DevView v, int s0, i
   __shared__ int sh_cnt[kMaxFrames + 1];
   __shared__ int sh_slot[kMaxFrames];
   const int s = s0 + blockIdx.y;
-  rebuild_finish(v, s, v.state[s], eb, (int)blockIdx.x, 0u, sh_cnt, sh_slot);      // (seq 0: the second kNN pass precedes this launch in stream order)
+  rebuild_finish(v, s, v.state[s], eb, (int)blockIdx.x, 0u, sh_cnt, sh_slot, true);      // (seq 0: the second kNN pass precedes this launch in stream order)
 }
 
 // Start offsets of the occupied cells (any order: only contiguity per cell matters).  One atomic

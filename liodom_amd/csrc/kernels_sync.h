@@ -159,7 +159,7 @@ __device__ __forceinline__ bool ov_wait_pose(const DevView& v, int s, int rep, u
   return granules_wait<LIODOM_POLL_POSE>(v.pose_xch0 + ((size_t)s * kOvReplicas + rep) * 512, kOvGranules, tag, out19, status);
 }
 // Chain mode: the prediction a scan starts from, published by the previous scan's finalize_scan (threads 0 .. kOvReplicas *
-// kPredGranules - 1 of the solving workgroup; vals: 12 doubles in LDS) and read by the scan's first kNN pass (other HIP stream).
+// kPredGranules - 1 of the solving workgroup; vals: 19 doubles in LDS) and read by the scan's first kNN pass (other HIP stream).
 __device__ __forceinline__ void pred_publish(const DevView& v, int s, const double* vals, unsigned int tag, int tid) {
   typedef __attribute__((address_space(1))) unsigned long long gu64;
   if (tid < kOvReplicas * kPredGranules) {
@@ -170,8 +170,8 @@ __device__ __forceinline__ void pred_publish(const DevView& v, int s, const doub
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
-// whole workgroup: the prediction (lanes 0 .. 23 of the first wave) and, in the same round trip, the extraction's flag (lane 32;
-// edge_flag may be null / want 0: nothing to wait for).  false: one of them never arrived.
+// whole workgroup: the prediction (lanes 0 .. 37 of the first wave: matrix, quaternion, translation) and, in the same round trip,
+// the extraction's flag (lane 63; edge_flag may be null / want 0: nothing to wait for).  out12: 19 doubles.  false: one of them never arrived.
 __device__ __forceinline__ bool pred_wait(const DevView& v, int s, int rep, unsigned int tag, double* out12, unsigned int* status,
                                           const unsigned int* edge_flag, unsigned int edge_want) {
   typedef __attribute__((address_space(1))) unsigned long long gu64;
@@ -186,15 +186,15 @@ __device__ __forceinline__ bool pred_wait(const DevView& v, int s, int rep, unsi
     while (true) {
       ok = true;
       if (tid < kPredGranules) { g = __hip_atomic_load((gu64*)(base + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = (unsigned int)(g >> 32) == tag; }
-      else if (tid == 32 && edge_flag && edge_want) ok = (int)(__hip_atomic_load((gu32*)edge_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - edge_want) >= 0;
+      else if (tid == 63 && edge_flag && edge_want) ok = (int)(__hip_atomic_load((gu32*)edge_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - edge_want) >= 0;
       if (__all(ok)) break;
       if (++spins > 1500000u || wait_expired(spins, t0)) break;
       __builtin_amdgcn_s_sleep(4);
     }
     const bool all_ok = __all(ok);
     if (spins) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (it really waited: as pipe_wait)
-    const unsigned long long lo = __shfl(g, 2 * (tid % 12)), hi = __shfl(g, 2 * (tid % 12) + 1);
-    if (tid < 12) out12[tid] = __longlong_as_double((long long)((hi << 32) | (lo & 0xFFFFFFFFull)));
+    const unsigned long long lo = __shfl(g, 2 * (tid % 19)), hi = __shfl(g, 2 * (tid % 19) + 1);
+    if (tid < 19) out12[tid] = __longlong_as_double((long long)((hi << 32) | (lo & 0xFFFFFFFFull)));
     if (tid == 0) { s_pw_ok = all_ok ? 1 : 0; if (!all_ok) atomicOr(status, LIODOM_STATUS_PIPE_TIMEOUT); }
   }
   __syncthreads();

@@ -943,6 +943,7 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   ALLOC(v.knn_done0, S + 64, 0);
   if (v.early_rebuild) ALLOC(v.pred_xch, S * (size_t)kOvReplicas * 512, 0); else v.pred_xch = nullptr;
   ALLOC(v.edge_cnt, (size_t)kEdgeBufs * 32, 0);
+  if (v.early_rebuild) ALLOC(v.edges_keep, S * (size_t)v.edge_cap, 0); else v.edges_keep = nullptr;
   // (the two passes' validity bytes never share a 128-byte line: the overlapped second pass writes its half while the finalising
   //  solve's launch — which must not read it before ov_wait_knn_done — may hold the first pass's half in its caches)
   v.mask_stride = round_up(v.knn_blocks, 128);

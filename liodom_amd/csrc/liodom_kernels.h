@@ -60,7 +60,7 @@ constexpr int kEdgePipeBufs = 3;
 constexpr int kEdgeBufX = 3;
 constexpr int kOvReplicas = 8;           // copies of the first solve's result, 4 KiB apart, for the polling k_knn workgroups
 constexpr int kOvGranules = 38;          // 19 doubles as {tag, 32 bits} granules
-constexpr int kPredGranules = 24;        // 12 doubles (pred_xch)
+constexpr int kPredGranules = 38;        // 19 doubles (pred_xch): the prediction's matrix [12], its quaternion [4] and translation [3] (= the next solve's start point)
 
 // Per-stream device state.
 struct StreamState {
@@ -92,7 +92,7 @@ struct StreamState {
   int32_t n_recv;         // points of the received ~map cloud (mapping mode, SharedData::setLocalMap)
   int32_t n_ovf[2];       // early_rebuild: new-frame points kept in the overflow list of table 0 / 1 (sorted_pts[ovf_base ...])
   int32_t reb_initialized; // early_rebuild: `initialized` as of the scan's first kNN pass (the finalising solve sets it beside the builders)
-  int32_t reb_pad;
+  int32_t reb_pad;        // chain mode: the scan's edge count as PAD saw it (APPEND iterates over it, see edges_keep)
   double pred_odom[12];   // early_rebuild: the prediction the scan started from, snapshot taken by the scan's first kNN launch: st.odom moves
                           // on with the solves, and the finalising solve writes the NEXT scan's prediction while builders of this scan still run
   liodom_step_info_t info;
@@ -217,11 +217,14 @@ struct DevView {
   // Chain mode (round 5; "Chain mode" in kernels_sync.h): the kNN passes and the rebuild ride on ONE HIP stream (kNN(0), gate, COUNT/PAD,
   // kNN(1), ALLOC, SCATTER/CLEAR, APPEND), the two solves on another; the first solve's launch is resident while the first pass
   // still runs and takes its results through done flags, as the finalising solve takes the second pass's.
+  float4* edges_keep;              // [S][edge_cap] chain mode: the scan's edges as PAD saw them, for APPEND (the edge buffer itself may belong to a later
+                                   // scan's extraction by the time APPEND's launch starts: the ticket slot is free once the pose has been collected)
   unsigned int* edge_cnt;          // [kEdgeBufs][32] write-through copy of n_edges_buf[b] of stream s (s < 32) at [b * 32 + s], a 128-byte line per buffer
   unsigned int* knn_done0;         // [S + 64] chain mode (S = 1): [s] workgroups of first passes that have completed, counted over the scans since the
                                    // last reset (one word: the first solve's workgroups poll it with one thread each); [32 + s] (a cache line of its own) the same for second passes
-  unsigned long long* pred_xch;    // [S][kOvReplicas][512] the prediction the next scan starts from (st.odom after finalize_scan: 12 doubles as 24
-                                   // tagged granules, tag = scans completed), for the next scan's first kNN pass, which runs on the other stream
+  unsigned long long* pred_xch;    // [S][kOvReplicas][512] the prediction the next scan starts from (st.odom, st.param_q, st.param_t after finalize_scan:
+                                   // 19 doubles as 38 tagged granules, tag = scans completed), for the next scan's first kNN pass, which runs on the
+                                   // other stream and may start before finalize_scan's plain stores to the state are visible
   // Device-resident hand-off of the two-thread binding (liodom_extract_edges_device -> liodom_odometry_step_device, one-stream
   // handles): k_compact_edges also leaves the dense edges of pipeline buffer b in host-mapped memory, so that the extractor
   // thread can publish ~edges (feature_extractor.cc:70-75) without a device-to-host copy call; null on other handles.

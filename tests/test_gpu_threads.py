@@ -371,7 +371,16 @@ def test_cxx_two_thread_replay_equals_resident_replay(synth):
     for depth, fetch, pin in ((1, True, True), (0, True, False), (1, False, True)):
         g.reset()
         got, secs, tot = g.two_thread_replay(scans, N, H, W, timed_from=10, fetch_edges=fetch, depth=depth, pin=pin)
-        assert np.array_equal(got.view(np.uint64), ref[:, 0].view(np.uint64)), (depth, fetch, pin)
+        if not np.array_equal(got.view(np.uint64), ref[:, 0].view(np.uint64)):
+            # (diagnostics: the first scan that differs and what the two runs did there)
+            d = np.nonzero(np.any(got.view(np.uint64) != ref[:, 0].view(np.uint64), axis=1))[0]
+            _, gi = g.pose_log(0, 0, K)
+            k = int(d[0])
+            what = [(kk, int(infos[kk].n_edges), list(infos[kk].matches), [infos[kk].lm[0].iterations, infos[kk].lm[1].iterations],
+                     int(gi[kk].n_edges), list(gi[kk].matches), [gi[kk].lm[0].iterations, gi[kk].lm[1].iterations], int(gi[kk].status),
+                     float(np.abs(got[kk] - ref[kk, 0]).max())) for kk in range(max(0, k - 1), min(K, k + 2))]
+            raise AssertionError("two-thread replay (depth %d, fetch %s, pin %s) differs from the resident replay on %d scans, first %d: "
+                                 "(scan, ref n_edges, matches, iterations | got n_edges, matches, iterations, status, max |dpose|) %s" % (depth, fetch, pin, len(d), k, what))
         assert secs > 0 and tot == (n_edges if fetch else 0)
     g.close()
 
@@ -424,3 +433,15 @@ def test_device_handoff_in_safe_mode_uses_events(synth, monkeypatch):
     for k in range(K):
         assert np.array_equal(got[k].view(np.uint64), ref[k].view(np.uint64)), k
         assert np.max(np.abs(got[k] - normal[k])) < 1e-9, k
+
+
+def test_chain_mode_hammer_small_shape():
+    """tools/chain_hammer.py: fresh handles, 16x900 (short solves: every hand-off of chain mode is at its tightest), resident replay,
+    two-thread ticket replay at both depths and per-call pipelined replay, 25 rounds: every pose log must equal the first, bit for
+    bit.  Found in round 5: the first pass reading the solve's start point and the edge count from state that finalize_scan was still
+    writing, and APPEND reading an edge buffer whose ticket slot the host had already handed to a later scan's extraction."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "chain_hammer.py"), "25", "16x900"], capture_output=True, text=True, timeout=600)
+    tail = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ""
+    assert r.returncode == 0 and "'resident': 0, 'two_thread': 0, 'percall': 0" in tail, (r.stdout[-1500:], r.stderr[-1500:])
