@@ -904,7 +904,7 @@ __device__ __forceinline__ void knn_tail_dual(const DevView& v, int s, int outer
 // partial sums, poses off by millimetres, found by the two-thread and soak tests);
 // everything else this pass needs of that state follows from scan_no, the number of scans completed before this one.
 template <int kKnnThreads, bool kOv, bool kChain>
-__device__ __forceinline__ void knn_pass(const DevView& v, int s, int bxi, int byi, int outer_it, int eb, unsigned int wait_edges,
+__device__ __forceinline__ bool knn_pass(const DevView& v, int s, int bxi, int byi, int outer_it, int eb, unsigned int wait_edges,
                                          unsigned int signal_odo, unsigned int seq, int scan_no, KnnShared<kKnnThreads / kKnnGroup>& sh, KnnShared<kKnnThreads / kKnnGroup>& sh2, double* sh_ov) {
   constexpr int kKnnQueries = kKnnThreads / kKnnGroup;
   static_assert(!(kOv && kChain), "the overlapped pass is the second pass, the chain-mode instance the first");
@@ -912,18 +912,18 @@ __device__ __forceinline__ void knn_pass(const DevView& v, int s, int bxi, int b
   if (kOv) {
     // the scan's first solve launch has started: the first kNN pass (and everything before it) has completed
     // (k_ov_gate in front of this launch has seen the flag already: the launch started, with clean caches, after the first pass ended)
-    if (!pipe_wait(v.ov_flags + s, seq, &st.status)) return;
+    if (!pipe_wait(v.ov_flags + s, seq, &st.status)) return false;
     OV_STAMP(v, threadIdx.x == 0 && bxi == 0, 9); OV_STAMP(v, threadIdx.x == 0 && bxi == v.knn_grid - 1, 13);
   } else if (kChain) {
     // the prediction (12 doubles, tag = scans completed; normally there long before this launch starts) and, in the same round
     // trip, the flag of the extraction that fills edge buffer eb
-    if (!pred_wait(v, s, bxi % kOvReplicas, (unsigned int)scan_no, sh_ov, &st.status, v.pipe_flags + eb, wait_edges)) return;
+    if (!pred_wait(v, s, bxi % kOvReplicas, (unsigned int)scan_no, sh_ov, &st.status, v.pipe_flags + eb, wait_edges)) return false;
     OV_STAMP(v, threadIdx.x == 0 && bxi == 0, 27);
     // bookkeeping of the streamed rebuild, as below — from scan_no: every scan appends exactly one frame (finalize_scan)
     if (bxi == 0 && threadIdx.x == 0) { st.reb_frame_count = scan_no; st.n_used_tab[(scan_no + 1) & 1] = 0; st.reb_initialized = 1; st.cursor = 0; }
     if (bxi == 0 && threadIdx.x >= 64 && threadIdx.x < 76) st.pred_odom[threadIdx.x - 64] = sh_ov[threadIdx.x - 64];
   } else if (v.early_rebuild) {
-    if (bxi >= v.knn_grid) { if (outer_it == 1) rebuild_alloc(v, s, st, bxi - v.knn_grid, (int)gridDim.x - v.knn_grid); return; }
+    if (bxi >= v.knn_grid) { if (outer_it == 1) rebuild_alloc(v, s, st, bxi - v.knn_grid, (int)gridDim.x - v.knn_grid); return true; }
     // streamed rebuild, bookkeeping before the first builders start (next launch): the frame count the build refers to
     // (the finalising solve advances it beside them), an empty list of occupied slots for the table being built, and the
     // prediction the scan starts from
@@ -941,7 +941,7 @@ __device__ __forceinline__ void knn_pass(const DevView& v, int s, int bxi, int b
       typedef __attribute__((address_space(1))) unsigned int gu32;
       __hip_atomic_store((gu32*)(v.pipe_flags + kEdgePipeBufs), signal_odo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (!kChain && wait_edges && !pipe_wait(v.pipe_flags + eb, wait_edges, &st.status)) return;
+    if (!kChain && wait_edges && !pipe_wait(v.pipe_flags + eb, wait_edges, &st.status)) return false;
   }
   // The block's first loads — its edge, the pose — leave together with the stream's state words instead of behind the
   // branches on them (one memory round trip less on the launch's critical path; the edge index is clamped, an unused
@@ -975,8 +975,8 @@ __device__ __forceinline__ void knn_pass(const DevView& v, int s, int bxi, int b
   } else {
     E = st.n_edges_buf[eb];
   }
-  if (st_status & LIODOM_STATUS_PIPE_TIMEOUT) return;      // (uniform) a wait of this handle gave up: the edge buffer may be incomplete
-  if (!st_init) return;                            // uniform over the workgroup
+  if (st_status & LIODOM_STATUS_PIPE_TIMEOUT) return false;      // (uniform) a wait of this handle gave up: the edge buffer may be incomplete
+  if (!st_init) return true;                            // uniform over the workgroup
   // (two explicit calls, not a loop over bv: as a loop body the block needs 160 VGPRs instead of 69)
   static_assert(kKnnGridDiv == 2, "k_knn handles exactly two query blocks per workgroup");
   constexpr bool kWt = kOv || kChain;
@@ -986,7 +986,7 @@ __device__ __forceinline__ void knn_pass(const DevView& v, int s, int bxi, int b
       if (kWt) wt_store_u8(cm, 0); else *cm = 0;
       if (bxi + v.knn_grid < v.knn_blocks) { if (kWt) wt_store_u8(cm + v.knn_grid, 0); else cm[v.knn_grid] = 0; }
     }
-    return;
+    return true;
   }
   const int bv2 = bxi + v.knn_grid;
   const int e_second = bv2 * kKnnQueries + (int)(threadIdx.x / kKnnGroup);
@@ -999,7 +999,7 @@ __device__ __forceinline__ void knn_pass(const DevView& v, int s, int bxi, int b
     knn_presearch<kKnnThreads>(v, s, st, fc, e_first, E, sh, pre1, sqrtf(p_first.x * p_first.x + p_first.y * p_first.y + p_first.z * p_first.z));
     if (second) knn_presearch<kKnnThreads>(v, s, st, fc, e_second, E, sh2, pre2, sqrtf(p_second.x * p_second.x + p_second.y * p_second.y + p_second.z * p_second.z));
     else pre2.gsq = 0.f;
-    if (!ov_wait_pose(v, s, bxi % kOvReplicas, seq, sh_ov, &st.status)) return;
+    if (!ov_wait_pose(v, s, bxi % kOvReplicas, seq, sh_ov, &st.status)) return false;
     OV_STAMP(v, threadIdx.x == 0 && bxi == 0, 10); OV_STAMP(v, threadIdx.x == 0 && bxi == v.knn_grid - 1, 14);
     if (kInstrument && (v.debug & 128) && threadIdx.x == 0) {      // (debug) when this workgroup saw the pose, relative to its publication: 0.25 us bins
       sh_ov[19] = __longlong_as_double((long long)wall_clock64());
@@ -1017,13 +1017,13 @@ __device__ __forceinline__ void knn_pass(const DevView& v, int s, int bxi, int b
     else if (bv2 < v.knn_blocks && threadIdx.x == 0) wt_store_u8(&v.corr_mask[((size_t)s * 2 + outer_it) * v.mask_stride + bv2], 0);
     __syncthreads();
     knn_tail_dual<kKnnThreads>(v, s, outer_it, eb, bxi, bv2, second, E, sh, sh2, sh_ov + 12);
-    return;
+    return true;
   }
   knn_block<kKnnThreads, false, true, kWt>(v, s, st, fc, outer_it, eb, bxi, E, sh, p_first, T, pre1, kChain ? sh_ov + 12 : nullptr);
-  if (bv2 >= v.knn_blocks) return;
+  if (bv2 >= v.knn_blocks) return true;
   if (!second) {
     if (threadIdx.x == 0) { unsigned char* cm = &v.corr_mask[((size_t)s * 2 + outer_it) * v.mask_stride + bv2]; if (kWt) wt_store_u8(cm, 0); else *cm = 0; }
-    return;
+    return true;
   }
   __syncthreads();                          // (the second block reuses the LDS)
   double T2[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // (reloaded: kept live across the first block the pose would cost 24 VGPRs)
@@ -1039,6 +1039,7 @@ __device__ __forceinline__ void knn_pass(const DevView& v, int s, int bxi, int b
     }
   }
   knn_block<kKnnThreads, false, true, kWt>(v, s, st, fc, outer_it, eb, bv2, E, sh, p_second, T2, pre2, kChain ? sh_ov + 12 : nullptr);
+  return true;
 }
 
 template <int kKnnThreads, bool kOv = false, bool kChain = false>
@@ -1070,11 +1071,12 @@ __global__ __launch_bounds__(kKnnThreads, (kKnnThreads >= 256 ? 1 : LIODOM_TUNE_
   if (kInstrument && kOv && threadIdx.x == 0) sh_ov[19] = 0.0;
   if (kOv) { OV_STAMP(v, threadIdx.x == 0 && bxi == 0, 8); OV_STAMP(v, threadIdx.x == 0 && bxi == v.knn_grid - 1, 12); }
   else if (outer_it == 0) OV_STAMP(v, threadIdx.x == 0 && bxi == 0, 16);
-  knn_pass<kKnnThreads, kOv, kChain>(v, s, bxi, byi, outer_it, eb, wait_edges, signal_odo, seq, scan_no, sh, shs[kOv ? 1 : 0], sh_ov);
+  const bool pass_ok = knn_pass<kKnnThreads, kOv, kChain>(v, s, bxi, byi, outer_it, eb, wait_edges, signal_odo, seq, scan_no, sh, shs[kOv ? 1 : 0], sh_ov);
   // (every exit of the pass is workgroup-uniform)  chain mode (scan_no >= 0 on this instance): the pass's workgroups count themselves
   // on one word, as the first pass's do; else one flag per workgroup
-  if (kOv) { if (scan_no >= 0) chain_count_done(v.knn_done0 + 32 + s); else ov_signal_knn_done(v, s, bxi, seq); }
-  if (kChain) chain_count_done(v.knn_done0 + s);
+  // (a workgroup whose own wait gave up leaves the count short: the solve that waits for it gives up in turn and consumes nothing)
+  if (kOv) { if (scan_no >= 0) { if (pass_ok) chain_count_done(v.knn_done0 + 32 + s); } else ov_signal_knn_done(v, s, bxi, seq); }
+  if (kChain && pass_ok) chain_count_done(v.knn_done0 + s);
   if (kInstrument && (v.debug & 128) && threadIdx.x == 0) {
     if (kOv) {                                         // (debug) pose seen -> flag raised, per workgroup with queries: 0.5 us bins
       const long long t_seen = __double_as_longlong(sh_ov[19]);

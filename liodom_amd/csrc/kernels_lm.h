@@ -414,7 +414,10 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
   const bool prep = tid < kLmCtl;               // waves 0..6: compaction + register cache while the controller lane works
   // chain mode, first solve: nothing of the stream's state that the extraction writes (n_edges_buf) and nothing of the first pass's
   // results has been read so far; the pass's workgroups store write-through and raise one flag each
-  if (chain && outer_it == 0) chain_wait_count(v.knn_done0 + s, done_target, &st.status);      // (the count the pass's workgroups reach: wrap-safe comparison)
+  // (dead: a wait of this scan gave up — here or in the pass: nothing the pass was to leave may be consumed; the solve then runs as
+  //  one without residual blocks, the pose stays the prediction, and the status bit fails the scan on the host)
+  bool dead = false;
+  if (chain && outer_it == 0) dead = !chain_wait_count(v.knn_done0 + s, done_target, &st.status);      // (the count the pass's workgroups reach: wrap-safe comparison)
   // (the edge count: the state word shares a cache line with fields that earlier launches on this XCD have read — since this launch
   //  started, possibly before the extraction wrote it; k_compact_edges leaves a write-through copy in a line of its own)
   int E_in;
@@ -470,7 +473,8 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
     c_hi = (g + 1) * chunk < C ? (g + 1) * chunk : C;
   };
   // the overlapped second kNN pass has completed (chain mode: its workgroups count themselves on one word; else a flag each)
-  if (seq && outer_it == 1) { if (chain) chain_wait_count(v.knn_done0 + 32 + s, done_target, &st.status); else ov_wait_knn_done(v, s, seq, &st.status); }
+  if (seq && outer_it == 1) { if (chain) dead = !chain_wait_count(v.knn_done0 + 32 + s, done_target, &st.status) || dead; else ov_wait_knn_done(v, s, seq, &st.status); }
+  // (a pass whose own wait gave up does not count its workgroups: this solve's wait then gives up too)
   OV_STAMP(v, g == 0 && tid == 0 && outer_it == 1, 4);
   OV_STAMP(v, g == 0 && tid == 0 && outer_it == 0, 18);
   if (v.knn_partials) {
@@ -483,7 +487,7 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
     double x0 = 0.0, x1 = 0.0;
     if (i <= kAccN) {                                    // (entry 29: the number of accepted correspondences)
       // 16 independent loads in flight per pass (one memory round trip for up to 16 kRC k_knn workgroups)
-      for (int rb = r0; rb < nb; rb += 16 * kRC) {
+      for (int rb = r0; rb < (dead ? 0 : nb); rb += 16 * kRC) {
         double xs[16];
 #pragma unroll
         for (int u = 0; u < 16; u++) { const int r = rb + kRC * u; xs[u] = (r < nb) ? part[(size_t)r * 32 + i] : 0.0; }
@@ -540,7 +544,7 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
       // (the other lanes of the controller's wave wait at the barrier)
     } else if (step == 0 && v.knn_partials) {
       DBG_STAMP(v, dbge, 2, 24);
-      const int C = lm_compact_bits(v, s, outer_it, E, sh_idx);
+      const int C = dead ? 0 : lm_compact_bits(v, s, outer_it, E, sh_idx);
       if (tid == 0) sh_C = C;
       DBG_STAMP(v, dbge, 2, 25);
       my_share(C);

@@ -70,14 +70,6 @@ __global__ void k_pipe_gate(DevView v, int s0, int eb, unsigned int wait_edges, 
 // What it does NOT buy (measured, in-kernel stamps, profiles/r05_*): the kNN(0) -> solve(0) boundary costs ~1.5 us on this stack,
 // and the write-through tail + count + granule read of the chain cost about the same: HDL-64 is unchanged within +-2.5 %.
 // Bit-identical to the four-launch path: same workgroups, same partial sums, same order (tools/overlap_equal.py).
-// Gate in front of the extraction of a host-fed scan: one wave waits until the copy stream has published the upload's sequence
-// number (hipStreamWriteValue32 / k_set_flag behind the hipMemcpyAsync) — the place of a hipStreamWaitEvent, whose barrier packet
-// costs ~11 us of idle stream.  The extraction kernels behind it start when it retires (kernel start: clean caches).
-__global__ void k_up_gate(DevView v, const unsigned int* flag, unsigned int want) {
-  if (!pipe_wait(flag, want, &v.state[0].status)) {
-    for (int s = (int)threadIdx.x; s < v.n_streams; s += (int)blockDim.x) atomicOr(&v.state[s].status, LIODOM_STATUS_PIPE_TIMEOUT);
-  }
-}
 // =============================================================================================
 // Overlapped second kNN pass (one-stream handles with the streamed rebuild and flags).  The odometry chain of a scan is
 // kNN, solve, kNN, solve; as four launches of one HIP stream every link costs a launch boundary (~0.7 us idle), the ramp of
@@ -209,18 +201,23 @@ __device__ __forceinline__ void chain_count_done(unsigned int* counter) {
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void chain_wait_count(const unsigned int* counter, unsigned int target, unsigned int* status) {
+// (returns false when the wait gave up: the caller must not consume what it waited for)
+__device__ __forceinline__ bool chain_wait_count(const unsigned int* counter, unsigned int target, unsigned int* status) {
   typedef __attribute__((address_space(1))) unsigned int gu32;
+  __shared__ int s_cw_ok;
   if (threadIdx.x == 0) {
     unsigned int spins = 0;
     unsigned long long t0 = 0;
+    bool ok = true;
     while ((int)(__hip_atomic_load((gu32*)counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
       __builtin_amdgcn_s_sleep(4);
-      if (++spins > 6000000u || wait_expired(spins, t0)) { atomicOr(status, LIODOM_STATUS_PIPE_TIMEOUT); break; }
+      if (++spins > 6000000u || wait_expired(spins, t0)) { atomicOr(status, LIODOM_STATUS_PIPE_TIMEOUT); ok = false; break; }
     }
+    s_cw_ok = ok ? 1 : 0;
   }
   // (no acquire fence: the argument of ov_wait_knn_done — write-through producers, nothing of theirs cached here before this point)
   __syncthreads();
+  return s_cw_ok != 0;
 }
 // whole workgroup, every exit path of an overlapped k_knn workgroup: its results are visible before the flag is
 __device__ __forceinline__ void ov_signal_knn_done(const DevView& v, int s, int b, unsigned int seq, unsigned int* done = nullptr) {

@@ -87,14 +87,6 @@ struct liodom_handle {
   int ov_warm = 0;                   // scans enqueued so far, up to kOvWarmScans (the first ones run every kernel of the chain for the first time)
   hipStream_t stream_x = nullptr;    // extraction side (liodom_extract_edges, and the next scan's extraction in the pipelined replay)
   hipStream_t stream_c = nullptr;    // host-fed replay: uploads (a copy engine works beside the extraction kernels of the previous scan)
-  // Uploads ordered by FLAGS instead of event pairs (round 5; handles with use_flags): the copy stream writes a sequence number
-  // behind every upload (hipStreamWriteValue32, or a one-thread kernel: up_flag_mode 2), a one-wave gate launch in front of the
-  // extraction polls it.  The reverse edge — the slot may be overwritten — needs nothing on the device: a slot of the three-deep
-  // ring is refilled only after the pose of the scan that last used it has been COLLECTED by the host (so its extraction has
-  // completed).  No hipStreamWaitEvent anywhere, the copy stream is a stream of its own, and the overlapped second kNN pass stays on.
-  int up_flag_mode = 0;              // 0: events (safe mode, profilers that serialise kernels), 1: hipStreamWriteValue32, 2: k_set_flag launch
-  unsigned int* up_flags = nullptr;  // [kEdgePipeBufs] device words: sequence number of the latest upload that has landed in ring slot r
-  unsigned int up_seq = 0;
   hipEvent_t ev_up[3] = {nullptr, nullptr, nullptr};      // staging slot uploaded
   hipEvent_t ev_xdone[3] = {nullptr, nullptr, nullptr};   // extraction that read the staging slot has been issued (recorded on the extraction stream)
   bool ev_xdone_valid[3] = {false, false, false};
@@ -569,7 +561,6 @@ void enter_safe_mode(liodom_handle* h) {
   h->safe_mode = true;
   h->use_flags = false;
   h->chain_ok = false;
-  h->up_flag_mode = 0;
   h->v.lm_groups = 1;
   h->v.early_rebuild = 0;      // (the second table, the padding and the overflow list stay allocated and unused)
   h->ring_split = false;       // k_ring_split's workgroups wait for each other inside the launch: k_classify + k_ring_scatter instead
@@ -612,9 +603,6 @@ int reset_state(liodom_handle* h) {
   if (h->host_edges_hdr) std::memset(h->host_edges_hdr, 0, sizeof(unsigned int) * 2 * kEdgePipeBufs);
   for (int b = 0; b < kEdgePipeBufs; b++) { h->eb_seq[b] = 0; h->eb_reader[b] = 0; }
   HIP_TRY(hipMemsetAsync(h->v.pipe_flags, 0, sizeof(unsigned int) * (kEdgePipeBufs + 1), h->stream));
-  if (h->stream_c && !h->stream_c_shared) HIP_TRY(hipStreamSynchronize(h->stream_c));
-  HIP_TRY(hipMemsetAsync(h->up_flags, 0, sizeof(unsigned int) * kEdgePipeBufs, h->stream));
-  h->up_seq = 0;
   HIP_TRY(hipMemsetAsync(h->v.lm_xch, 0, sizeof(unsigned long long) * (size_t)h->S * 2 * kLmGroupsMax * 64, h->stream));
   HIP_TRY(hipMemsetAsync(h->v.pose_xch, 0, sizeof(unsigned long long) * (size_t)h->S * 32, h->stream));
   if (h->v.pred_xch) HIP_TRY(hipMemsetAsync(h->v.pred_xch, 0, sizeof(unsigned long long) * (size_t)h->S * kOvReplicas * 512, h->stream));
@@ -876,7 +864,6 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   ALLOC(v.lm_xch, S * 2 * kLmGroupsMax * 64, 0);
   ALLOC(v.pose_xch, S * 32, 0);
   ALLOC(v.pipe_flags, kEdgePipeBufs + 1, 0);
-  ALLOC(h->up_flags, kEdgePipeBufs, 0);
   v.host_edges = nullptr; v.host_edges_meta = nullptr; v.host_edges_hdr = nullptr;
   if (S == 1) {
     // device-resident hand-off (liodom_extract_edges_device): host-mapped mirror of the dense edges of the three pipeline buffers
@@ -912,11 +899,6 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
         hipMemcpy(&res, probe + 1, sizeof(res), hipMemcpyDeviceToHost) != hipSuccess) { g_last_error = "stream probe failed"; return fail(LIODOM_ERR_HIP); }
     h->streams_concurrent = res == 1u;
     if (!h->streams_concurrent) h->use_flags = false;
-  }
-  {
-    // uploads of host-fed scans ordered by flags (see up_flag_mode): wherever the stream flags are usable
-    h->up_flag_mode = 0;      // (measured, profiles/r05_*: no gain over the event pairs; kept behind LIODOM_UPLOAD_FLAGS = 1 / 2)
-    if (const char* e = std::getenv("LIODOM_UPLOAD_FLAGS")) { const int m = std::atoi(e); if (m == 0 || (h->use_flags && (m == 1 || m == 2))) h->up_flag_mode = m; }
   }
   {
     bool gate_kernel = config->n_streams >= 16;         // lock-step batches: line gates in their own launch (k_line_gate)
@@ -1167,30 +1149,6 @@ int liodom_odometry_step(liodom_handle_t* h, int stream, const float* edges_xyzi
   return wait_pose(h, stream, 1, pose_out, info);
 }
 
-// Flag-ordered uploads: the copy stream of the handle (a stream of its own) and the two halves of the edge "upload r has landed".
-static int ensure_copy_stream(liodom_handle_t* h) {
-  if (h->stream_c && !h->stream_c_shared) return LIODOM_OK;
-  h->stream_c = nullptr; h->stream_c_shared = false;
-  HIP_TRY(hipStreamCreateWithFlags(&h->stream_c, hipStreamNonBlocking));
-  return LIODOM_OK;
-}
-// behind the upload(s) just enqueued on the copy stream: publish their sequence number in up_flags[r]; in front of the extraction
-// that reads them (queue q): a one-wave gate that polls it.  The kernels behind the gate start when it retires — with clean caches.
-static int upload_signal_and_gate(liodom_handle_t* h, int r, hipStream_t q) {
-  unsigned int seq = ++h->up_seq;
-  if (seq == 0u) seq = ++h->up_seq;
-  if (h->up_flag_mode == 1) {
-    if (hipStreamWriteValue32(h->stream_c, h->up_flags + r, seq, 0) != hipSuccess) {      // (not available on this stack: the kernel form from now on)
-      (void)hipGetLastError();
-      h->up_flag_mode = 2;
-    }
-  }
-  if (h->up_flag_mode == 2) hipLaunchKernelGGL(k_set_flag, dim3(1), dim3(1), 0, h->stream_c, h->up_flags + r, seq);
-  hipLaunchKernelGGL(k_up_gate, dim3(1), dim3(64), 0, q, h->v, h->up_flags + r, seq);
-  HIP_TRY(hipGetLastError());
-  return LIODOM_OK;
-}
-
 // ---- device-resident hand-off between the two sides (the reference's feature queue without the cloud leaving HBM) ----
 static int ensure_pin_ring(liodom_handle* h) {
   if (h->pin_ring) return LIODOM_OK;
@@ -1212,9 +1170,7 @@ static int ensure_pin_ring(liodom_handle* h) {
     HIP_TRY(hipMalloc(&d, sizeof(float4) * (size_t)kEdgePipeBufs * (size_t)h->v.max_points));
     h->stage_ring = static_cast<float4*>(d);
     h->allocs.push_back(d);
-    if (h->up_flag_mode) {
-      if (int rc = ensure_copy_stream(h)) return rc;
-    } else if (!h->stream_c) {
+    if (!h->stream_c) {
       if (want == 2 && h->stream_k) {
         // (the odometry side may be enqueueing an overlapped pass right now: from here on it does not — ov_off_for_copies is read
         //  by enqueue_odometry — and what is already in that stream simply runs ahead of the first copy)
@@ -1304,13 +1260,12 @@ int liodom_extract_edges_device(liodom_handle_t* h, int stream, const float* xyz
       if (own || !pinned) { pin_slot_used = r; h->pin_next = (r + 1) % kEdgePipeBufs; }
     } else
     if (h->tk_copy_stream && !h->profiling) {
-      // device staging slot sr: free once the extraction that last read it has run (ev_sdone, recorded on the extraction stream;
-      // with flag-ordered uploads: slot = edge buffer, which is refilled only after its scan's pose has been collected)
-      sr = h->up_flag_mode ? eb : h->stage_next;
+      // device staging slot sr: free once the extraction that last read it has run (ev_sdone, recorded on the extraction stream)
+      sr = h->stage_next;
       h->stage_next = (sr + 1) % kEdgePipeBufs;
       qc = h->stream_c;
       in = h->stage_ring + (size_t)sr * h->v.max_points;
-      if (!h->up_flag_mode && h->ev_sdone_valid[sr]) HIP_TRY(hipStreamWaitEvent(qc, h->ev_sdone[sr], 0));
+      if (h->ev_sdone_valid[sr]) HIP_TRY(hipStreamWaitEvent(qc, h->ev_sdone[sr], 0));
     }
     if (!host_dev) HIP_TRY(hipMemcpyAsync(in, xyzi, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, qc));
     if (!host_dev && (own || !pinned)) {             // the page-locked ring slot may be refilled once this upload has left it
@@ -1318,9 +1273,7 @@ int liodom_extract_edges_device(liodom_handle_t* h, int stream, const float* xyz
       h->ev_pin_valid[r] = true;
       h->pin_next = (r + 1) % kEdgePipeBufs;
     }
-    if (sr >= 0 && h->up_flag_mode) {                // the extraction starts when the upload into its staging slot has completed
-      if ((rc = upload_signal_and_gate(h, sr, q))) return rc;
-    } else if (sr >= 0) {
+    if (sr >= 0) {                                   // the extraction starts when the upload into its staging slot has completed
       HIP_TRY(hipEventRecord(h->ev_cp[sr], qc));
       HIP_TRY(hipStreamWaitEvent(q, h->ev_cp[sr], 0));
     }
@@ -1340,7 +1293,7 @@ int liodom_extract_edges_device(liodom_handle_t* h, int stream, const float* xyz
     HIP_TRY(hipEventRecord(h->ev_pin[pin_slot_used], q));
     h->ev_pin_valid[pin_slot_used] = true;
   }
-  if (staged_on_ring && !h->up_flag_mode) {
+  if (staged_on_ring) {
     const int sr = (h->stage_next + kEdgePipeBufs - 1) % kEdgePipeBufs;
     HIP_TRY(hipEventRecord(h->ev_sdone[sr], q));
     h->ev_sdone_valid[sr] = true;
@@ -1617,21 +1570,6 @@ int liodom_replay_resident(liodom_handle_t* h, int first_slot, int count, int ah
 // Host-fed replay: the scan of every stream for resident slot `slot` is copied from host memory on the extraction stream
 // (ordered behind the extraction that last read the slot).
 static int upload_slot_async(liodom_handle_t* h, int slot, const float* host, int64_t stride, int64_t n) {
-  if (h->up_flag_mode) {
-    // (the slot is free: the scan that last used it — three scans back — has been collected by the host loop, liodom_replay_host)
-    const int r = slot % 3;
-    int rc = ensure_copy_stream(h);
-    if (rc) return rc;
-    static const int chunks = std::getenv("LIODOM_UPLOAD_CHUNKS") ? std::max(1, std::atoi(std::getenv("LIODOM_UPLOAD_CHUNKS"))) : 1;      // (experiment)
-    for (int s = 0; s < h->S && n > 0; s++) {
-      float4* dst = h->resident + ((size_t)slot * h->S + s) * (size_t)h->v.max_points;
-      const float4* src = reinterpret_cast<const float4*>(host + (size_t)s * (size_t)stride);
-      const int64_t per = (n + chunks - 1) / chunks;
-      for (int64_t o = 0; o < n; o += per)
-        HIP_TRY(hipMemcpyAsync(dst + o, src + o, sizeof(float4) * (size_t)std::min<int64_t>(per, n - o), hipMemcpyHostToDevice, h->stream_c));
-    }
-    return upload_signal_and_gate(h, r, extract_queue(h));
-  }
   // copies on their own stream (copy engine) so that they run beside the extraction kernels of the previous scan; the
   // slot is free once the extraction that last read it has completed, and its extraction waits for the upload
   const int r = slot % 3;
@@ -1660,7 +1598,6 @@ static int upload_slot_async(liodom_handle_t* h, int slot, const float* host, in
   return LIODOM_OK;
 }
 static int upload_slot_consumed(liodom_handle_t* h, int slot) {      // call right after the slot's extraction has been issued
-  if (h->up_flag_mode) return LIODOM_OK;      // (flag-ordered uploads: the slot is released by the host loop's own order)
   const int r = slot % 3;
   HIP_TRY(hipEventRecord(h->ev_xdone[r], extract_queue(h)));
   h->ev_xdone_valid[r] = true;
@@ -1723,8 +1660,7 @@ int liodom_replay_host(liodom_handle_t* h, const float* xyzi_base, int64_t scan_
   // operations, six extraction and five odometry launches per scan: 88 us); the overlapped second kNN pass adds a gate and an
   // ALLOC launch on a third stream and made it 133 us.  So not here.
   struct Suppress { liodom_handle* h; ~Suppress() { h->ov_suppress = false; h->replay_host_dev = nullptr; h->replay_host_base = nullptr; } } suppress{h};
-  h->ov_suppress = h->up_flag_mode == 0;      // (flag-ordered uploads have a stream of their own: the pass's stream stays free)
-  if (const char* e = std::getenv("LIODOM_HOSTFED_OVERLAP")) { if (std::atoi(e) != 0 && h->up_flag_mode) h->ov_suppress = false; else h->ov_suppress = true; }
+  h->ov_suppress = true;
   if (h->zero_copy && count > 0 && n > 0 && scan_stride_floats % 4 == 0 && (reinterpret_cast<uintptr_t>(xyzi_base) & 15u) == 0) {
     // page-locked AND mapped (liodom_pin_host_buffer, hipHostMalloc): the extraction reads the scans in place — the loop then
     // enqueues no upload and no event, and the overlapped second kNN pass stays on (its stream is not needed for copies)
