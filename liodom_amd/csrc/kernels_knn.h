@@ -1017,7 +1017,13 @@ __device__ __forceinline__ bool knn_pass(const DevView& v, int s, int bxi, int b
     else if (bv2 < v.knn_blocks && threadIdx.x == 0) wt_store_u8(&v.corr_mask[((size_t)s * 2 + outer_it) * v.mask_stride + bv2], 0);
     __syncthreads();
     knn_tail_dual<kKnnThreads>(v, s, outer_it, eb, bxi, bv2, second, E, sh, sh2, sh_ov + 12);
-    return true;
+    // speculative hand-over (kernels_sync.h): the pose this workgroup worked from may have been the solve's iterate before its last
+    // evaluation; what the solve ended with has arrived by now, as a rule — equal bits: done.  Else the workgroup does not count
+    // itself done: its namesake in the k_knn_redo launch behind this one repeats the two blocks from the confirmed pose.
+    if (!v.speculate) return true;
+    const int cf = ov_confirm_pose(v, s, bxi % kOvReplicas, seq, sh_ov, &st.status);
+    if ((kInstrument && (v.debug & 64)) && threadIdx.x == 0) atomicAdd(&v.dbg_clk[271 + (cf == 1 ? 0 : 1)], 1ull);      // (debug) confirmed / not
+    return cf == 1;
   }
   knn_block<kKnnThreads, false, true, kWt>(v, s, st, fc, outer_it, eb, bxi, E, sh, p_first, T, pre1, kChain ? sh_ov + 12 : nullptr);
   if (bv2 >= v.knn_blocks) return true;
@@ -1070,12 +1076,29 @@ __global__ __launch_bounds__(kKnnThreads, (kKnnThreads >= 256 ? 1 : LIODOM_TUNE_
   }
   if (kInstrument && kOv && threadIdx.x == 0) sh_ov[19] = 0.0;
   if (kOv) { OV_STAMP(v, threadIdx.x == 0 && bxi == 0, 8); OV_STAMP(v, threadIdx.x == 0 && bxi == v.knn_grid - 1, 12); }
-  else if (outer_it == 0) OV_STAMP(v, threadIdx.x == 0 && bxi == 0, 16);
+  else if (outer_it == 0) {
+    if (kInstrument && (v.debug & 128) && threadIdx.x == 0 && bxi == 0) {
+      // (debug) the previous scan's stamps are final when the next scan's first pass starts: fold its phases into running sums
+      // (dbg_clk[480..]: first pass, first solve, second pass's tail, finalising solve, period, scans, early hand-overs, APPEND)
+      volatile unsigned long long* c = v.dbg_clk + 448;
+      const unsigned long long t16 = c[16], now = wall_clock64();
+      if (t16 && c[18] > t16 && c[1] > c[18] && c[4] > c[1] && c[28] > c[4] && c[26] > c[28]) {
+        unsigned long long* a = v.dbg_clk + 480;
+        a[0] += c[18] - t16; a[1] += c[1] - c[18]; a[2] += c[4] - c[1]; a[3] += c[28] - c[4]; a[4] += now - t16; a[5] += 1ull;
+        a[6] += c[19] > t16 ? 1ull : 0ull; a[7] += c[26] - c[28];
+        if (c[20] > c[1]) { a[8] += c[20] - c[1]; a[9] += c[4] - c[20]; }      // second pass's last workgroup after the pose's (confirmed) publication; -> the finalising solve has seen the count
+        if (c[19] > t16 && c[21] < t16) { a[10] += c[1] - c[19]; a[11] += c[20] - c[19]; a[12] += 1ull; a[13] += c[4] - c[1]; }      // handed over early and confirmed
+        if (c[19] > t16 && c[21] > t16) { a[14] += 1ull; a[15] += c[4] - c[1]; }                                                       // ... and not confirmed
+      }
+    }
+    OV_STAMP(v, threadIdx.x == 0 && bxi == 0, 16);
+  }
   const bool pass_ok = knn_pass<kKnnThreads, kOv, kChain>(v, s, bxi, byi, outer_it, eb, wait_edges, signal_odo, seq, scan_no, sh, shs[kOv ? 1 : 0], sh_ov);
   // (every exit of the pass is workgroup-uniform)  chain mode (scan_no >= 0 on this instance): the pass's workgroups count themselves
   // on one word, as the first pass's do; else one flag per workgroup
   // (a workgroup whose own wait gave up leaves the count short: the solve that waits for it gives up in turn and consumes nothing)
-  if (kOv) { if (scan_no >= 0) { if (pass_ok) chain_count_done(v.knn_done0 + 32 + s); } else ov_signal_knn_done(v, s, bxi, seq); }
+  // (speculative hand-over not confirmed: pass_ok is false — the workgroup's namesake in k_knn_redo signals in its place)
+  if (kOv) { if (scan_no >= 0) { if (pass_ok) chain_count_done(v.knn_done0 + 32 + s); } else if (pass_ok || !v.speculate) ov_signal_knn_done(v, s, bxi, seq); }
   if (kChain && pass_ok) chain_count_done(v.knn_done0 + s);
   if (kInstrument && (v.debug & 128) && threadIdx.x == 0) {
     if (kOv) {                                         // (debug) pose seen -> flag raised, per workgroup with queries: 0.5 us bins
@@ -1087,8 +1110,66 @@ __global__ __launch_bounds__(kKnnThreads, (kKnnThreads >= 256 ? 1 : LIODOM_TUNE_
       if (t0 && d >= 0 && bxi * kKnnQueries < v.state[s].n_edges_buf[eb]) atomicAdd(&v.dbg_clk[384 + (d / 50 < 63 ? d / 50 : 63)], 1ull);
     }
   }
-  if (kOv) { OV_STAMP(v, threadIdx.x == 0 && bxi == 0, 11); OV_STAMP(v, threadIdx.x == 0 && bxi == v.knn_grid - 1, 15); }
+  if (kOv) {
+    OV_STAMP(v, threadIdx.x == 0 && bxi == 0, 11); OV_STAMP(v, threadIdx.x == 0 && bxi == v.knn_grid - 1, 15);
+    if (kInstrument && (v.debug & 128) && threadIdx.x == 0 && bxi * kKnnQueries < v.state[s].n_edges_buf[eb]) atomicMax(&v.dbg_clk[448 + 20], wall_clock64());      // (debug) the pass's last workgroup with queries
+  }
   else if (outer_it == 0) OV_STAMP(v, threadIdx.x == 0 && bxi == v.knn_grid - 1, 17);
+}
+
+// Speculative hand-over not confirmed (kernels_sync.h; rare): the launch behind the overlapped second pass, same grid.  A workgroup
+// whose namesake worked from the pose the solve really ended with (copy 0 of pose_xch0 == the confirmation copy) has nothing to do;
+// else it searches the two blocks like the non-overlapped second pass (from what the first pass saved) at the confirmed pose, with
+// write-through results, and counts itself done in the namesake's place.  A kernel of its own so that the pass keeps its register
+// budget (as a retry loop in k_knn the pass went from 134 to 324 VGPRs).
+template <int kKnnThreads>
+__global__ __launch_bounds__(kKnnThreads, 1) void k_knn_redo(DevView v, int s0, int eb, unsigned int seq, int scan_no) {
+  constexpr int kKnnQueries = kKnnThreads / kKnnGroup;
+  __shared__ KnnShared<kKnnQueries> shs[2];
+  __shared__ double sh_ov[20];
+  __shared__ double sh_first[20];
+  int bxi = (int)blockIdx.x, byi = (int)blockIdx.y;
+  xcd_remap(bxi, byi);
+  const int s = s0 + byi;
+  StreamState& st = v.state[s];
+  const int rep = bxi % kOvReplicas;
+  // (both copies are there: this launch follows the pass, whose workgroups have seen them — or given up)
+  if (!granules_wait<LIODOM_POLL_POSE>(v.pose_xch0 + ((size_t)s * kOvReplicas + rep) * 512, kOvGranules, seq, sh_first, &st.status)) return;
+  if (!granules_wait<LIODOM_POLL_POSE>(v.pose_xch0 + ((size_t)s * kOvReplicas + rep) * 512 + kOvFinalOffset, kOvGranules, seq, sh_ov, &st.status)) return;
+  bool same = true;
+  for (int i = 0; i < 19; i++) same = same && __double_as_longlong(sh_first[i]) == __double_as_longlong(sh_ov[i]);
+  if (same) return;                                              // (uniform)
+  if ((kInstrument && (v.debug & 64)) && threadIdx.x == 0) atomicAdd(&v.dbg_clk[273], 1ull);      // (debug) workgroups repeated
+  OV_STAMP(v, threadIdx.x == 0, 21);
+  // (chain mode: the first pass saved its queries and fifth distances but not its candidates — the overlapped pass collects its own —:
+  //  search like a first pass, pruned by the saved fifth distance)
+  DevView vr = v;
+  vr.knn_save_pos = nullptr;
+  const int fc = st.frame_count;
+  const int E = st.n_edges_buf[eb];
+  const int outer_it = 1;
+  if (!st.initialized || (st.status & LIODOM_STATUS_PIPE_TIMEOUT)) return;
+  const int bv2 = bxi + v.knn_grid;
+  if (bxi * kKnnQueries < E) {
+    const bool second = bv2 < v.knn_blocks && bv2 * kKnnQueries < E;
+    const float4* ed = v.edges + ((size_t)eb * v.n_streams + s) * v.edge_cap;
+    const int e_first = bxi * kKnnQueries + (int)(threadIdx.x / kKnnGroup), e_second = bv2 * kKnnQueries + (int)(threadIdx.x / kKnnGroup);
+    const float4 p_first = ed[e_first < v.edge_cap ? e_first : v.edge_cap - 1];
+    const float4 p_second = ed[e_second < v.edge_cap ? e_second : v.edge_cap - 1];
+    double T[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) T[i] = sh_ov[i];
+    KnnPre none;
+    none.gsq = 0.f;
+    knn_block<kKnnThreads, false, false, true>(vr, s, st, fc, outer_it, eb, bxi, E, shs[0], p_first, T, none, sh_ov + 12);
+    if (second) knn_block<kKnnThreads, false, false, true>(vr, s, st, fc, outer_it, eb, bv2, E, shs[1], p_second, T, none, sh_ov + 12);
+    else if (bv2 < v.knn_blocks && threadIdx.x == 0) wt_store_u8(&v.corr_mask[((size_t)s * 2 + outer_it) * v.mask_stride + bv2], 0);
+    __syncthreads();
+    knn_tail_dual<kKnnThreads>(v, s, outer_it, eb, bxi, bv2, second, E, shs[0], shs[1], sh_ov + 12);
+  }
+  // (a workgroup without queries: its namesake wrote the empty validity bytes and returned before it compared anything — it counted itself)
+  else return;
+  if (scan_no >= 0) chain_count_done(v.knn_done0 + 32 + s); else ov_signal_knn_done(v, s, bxi, seq);
 }
 
 // One wave in front of the overlapped pass on stream_k: the pass's workgroups must not become resident before the first

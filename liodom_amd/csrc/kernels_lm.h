@@ -183,44 +183,64 @@ __device__ void hash_clear_used(const DevView& v, int s /*table: stream + parity
 __device__ __forceinline__ void publish_final_pose(const DevView& v, int s, const double* T, int raw, unsigned int tag, int lane);
 
 // Called by the whole workgroup.  sh_cnt: LDS scratch of kMaxFrames + 1 ints.
-// Thread 64 publishes the result (pose log, host-mapped record) while thread `ctl` (the one that wrote st.odom)
-// computes the prediction and the window bookkeeping; the remaining threads fetch the frame sizes.
+// T (LDS): the scan's final pose; raw: the frame enters the window untransformed (first frame); publish_pose: the appenders have
+// not been handed T yet (the solve's path publishes it itself, straight after its last step: they have been waiting for it, and the
+// next scan's first kNN pass follows them in stream order); prev (LDS or nullptr): copy of st.prev_odom taken when the launch
+// started (the finalising solve prefetches it while it waits for the second pass).
+// Order: what others wait for leaves first — the pose, then the prediction for the next scan (thread `ctl`, beside the other threads'
+// frame-size loads) — and only then the pose log, the host-mapped record and the window bookkeeping.
 // chain: the rebuild of this scan runs on the other HIP stream, beside this launch (ALLOC may still be allocating cell ranges from
 // st.cursor): the cursor is then reset by the next scan's first kNN pass, which follows the rebuild in stream order.
-__device__ void finalize_scan(const DevView& v, int s, StreamState& st, int* sh_cnt, int eb, bool clear_hash, int ctl, int chain = 0) {
+__device__ __forceinline__ void finalize_scan(const DevView& v, int s, StreamState& st, int* sh_cnt, int eb, bool clear_hash, int ctl, int chain,
+                              const double* T, int raw, bool publish_pose, const double* prev, int fc_old) {
   __shared__ double sh_pred[19];      // the prediction: matrix [12], quaternion [4], translation [3]
   const int P = v.prev_frames;
   const int tid = threadIdx.x;
   // LocalMapManager::addPointCloud (:34-60) on a ring of P frame slots: the new frame goes
   // into slot frame_count % P (overwriting the oldest once the window is full)
-  const int fc_new = st.frame_count + 1;
+  const int fc_new = fc_old + 1;
   const int nf = fc_new < P ? fc_new : P;
-  const int new_slot = st.frame_count % P;
+  const int new_slot = fc_old % P;
   int* wn = v.win_n + (size_t)s * P;
   int* wb = v.win_base + (size_t)s * (P + 1);
   int* ws = v.win_slot + (size_t)s * P;
+  // early_rebuild: hand the pose to the workgroups that append the new frame (they have been waiting for it)
+  if (publish_pose && v.early_rebuild && tid < 25) publish_final_pose(v, s, T, raw, (unsigned int)fc_old + 1u, tid);
   const int n_edges = st.n_edges_buf[eb];
   const int nup = st.n_used_tab[0];      // cells of the build that this scan searched (cleared below)
-  if (tid == ctl) { for (int i = 0; i < 12; i++) st.final_odom[i] = st.odom[i]; }   // (ctl wrote st.odom itself)
   for (int j = tid; j < nf; j += blockDim.x) {           // frame sizes of the new window (nothing here depends on the pose)
     const int sl = (fc_new - nf + j) % P;
     sh_cnt[j] = (sl == new_slot) ? n_edges : wn[sl];     // independent loads, one round trip
     ws[j] = sl;
   }
+  if (tid == ctl) {
+    // prediction for the next scan: odom * (prev^-1 * odom)   (:148-150)
+    double fin[12], po[12], inv[12], rel[12], pred[12], q[4];
+    for (int i = 0; i < 12; i++) { fin[i] = T[i]; po[i] = prev ? prev[i] : st.prev_odom[i]; }
+    iso_inverse(po, inv);
+    iso_mul(inv, fin, rel);
+    iso_mul(fin, rel, pred);
+    quat_from_pose(pred, v.rotation_mode, q);                        // :186-190 q_curr(odom_.rotation())
+    for (int i = 0; i < 12; i++) sh_pred[i] = pred[i];
+    for (int i = 0; i < 4; i++) sh_pred[12 + i] = q[i];
+    sh_pred[16] = pred[3]; sh_pred[17] = pred[7]; sh_pred[18] = pred[11];
+  }
   __syncthreads();
-  // early_rebuild: hand the pose to the workgroups that append the new frame (they have been waiting for it)
-  if (v.early_rebuild && tid < 25) publish_final_pose(v, s, st.final_odom, st.append_raw, (unsigned int)st.reb_frame_count + 1u, tid);
+  // chain mode: the next scan's first kNN pass runs on the other HIP stream and may start before this launch has ended (it follows
+  // the APPEND launch): the prediction it starts from travels as tagged granules (tag = scans completed)
+  if (v.pred_xch) pred_publish(v, s, sh_pred, (unsigned int)fc_new, tid);
   if (tid == 64) {
     // pose as published (laser_odometry.cc:403-412 with identity laser_to_base)
-    double q[4];
-    quat_from_pose(st.final_odom, v.rotation_mode, q);             // :403 q_current(odom_base_link.rotation())
+    double fin[12], q[4];
+    for (int i = 0; i < 12; i++) fin[i] = T[i];
+    quat_from_pose(fin, v.rotation_mode, q);             // :403 q_current(odom_base_link.rotation())
     const int k = st.scan_counter;
     st.info.scan_index = k;
     st.info.status = st.status;
     if (k < v.pose_log_cap) {
       double* pl = v.pose_log + ((size_t)s * v.pose_log_cap + k) * 7;
       pl[0] = q[0]; pl[1] = q[1]; pl[2] = q[2]; pl[3] = q[3];
-      pl[4] = st.final_odom[3]; pl[5] = st.final_odom[7]; pl[6] = st.final_odom[11];
+      pl[4] = fin[3]; pl[5] = fin[7]; pl[6] = fin[11];
       v.info_log[(size_t)s * v.pose_log_cap + k] = st.info;
     }
     st.scan_counter = k + 1;
@@ -228,7 +248,7 @@ __device__ void finalize_scan(const DevView& v, int s, StreamState& st, int* sh_
       // zero-copy publication: payload, system-scope fence, then the sequence word the host polls
       HostOut* ho = v.host_out + (size_t)s * 2 + (k & 1);      // two records per stream: the host may read scan k while scan k + 1 publishes
       ho->pose[0] = q[0]; ho->pose[1] = q[1]; ho->pose[2] = q[2]; ho->pose[3] = q[3];
-      ho->pose[4] = st.final_odom[3]; ho->pose[5] = st.final_odom[7]; ho->pose[6] = st.final_odom[11];
+      ho->pose[4] = fin[3]; ho->pose[5] = fin[7]; ho->pose[6] = fin[11];
       ho->info = st.info;
       // (the system-scope release orders this thread's payload stores before the sequence word: no separate fence)
       __hip_atomic_store(&ho->seq, k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -236,16 +256,9 @@ __device__ void finalize_scan(const DevView& v, int s, StreamState& st, int* sh_
     st.info.matches[0] = 0; st.info.matches[1] = 0;   // counters of the next scan's two kNN passes
   }
   if (tid == ctl) {
-    // prediction for the next scan: odom * (prev^-1 * odom)   (:148-150)
-    double inv[12], rel[12], pred[12];
-    iso_inverse(st.prev_odom, inv);
-    iso_mul(inv, st.final_odom, rel);
-    iso_mul(st.final_odom, rel, pred);
-    for (int i = 0; i < 12; i++) { st.prev_odom[i] = st.final_odom[i]; st.odom[i] = pred[i]; sh_pred[i] = pred[i]; }
-    quat_from_pose(pred, v.rotation_mode, st.param_q);               // :186-190 q_curr(odom_.rotation())
-    st.param_t[0] = pred[3]; st.param_t[1] = pred[7]; st.param_t[2] = pred[11];   // :192-195
-    for (int i = 0; i < 4; i++) sh_pred[12 + i] = st.param_q[i];
-    sh_pred[16] = pred[3]; sh_pred[17] = pred[7]; sh_pred[18] = pred[11];
+    for (int i = 0; i < 12; i++) { const double f = T[i]; st.final_odom[i] = f; st.prev_odom[i] = f; st.odom[i] = sh_pred[i]; }
+    for (int i = 0; i < 4; i++) st.param_q[i] = sh_pred[12 + i];
+    st.param_t[0] = sh_pred[16]; st.param_t[1] = sh_pred[17]; st.param_t[2] = sh_pred[18];   // :192-195
     wn[new_slot] = n_edges;
     st.frame_count = fc_new;
     st.n_frames = nf;
@@ -258,9 +271,6 @@ __device__ void finalize_scan(const DevView& v, int s, StreamState& st, int* sh_
     if (!chain) st.cursor = 0;
   }
   __syncthreads();
-  // chain mode: the next scan's first kNN pass runs on the other HIP stream and may start before this launch has ended (it follows
-  // the APPEND launch): the prediction it starts from travels as tagged granules (tag = scans completed)
-  if (v.pred_xch) pred_publish(v, s, sh_pred, (unsigned int)fc_new, tid);
   for (int j = tid; j <= nf; j += blockDim.x) wb[j] = sh_cnt[j];
   // (first frame only; in steady state the finalising solve clears the table beside its first
   // controller step instead of extending the kernel by ~4.5 us here)
@@ -369,13 +379,18 @@ __global__ void k_imu_override(DevView v, int s0, int count) {
   st.param_t[0] = out[3]; st.param_t[1] = out[7]; st.param_t[2] = out[11];         // :192-195
 }
 
-__device__ void rebuild_beside_solve(const DevView& v, int s, StreamState& st, int eb, int outer_it, int block, int nblocks, unsigned int seq, int* sbase, int* sslot);
+__device__ __forceinline__ void rebuild_beside_solve(const DevView& v, int s, StreamState& st, int eb, int outer_it, int block, int nblocks, unsigned int seq, int* sbase, int* sslot);
 
 // chain != 0 (chain mode, kernels_sync.h; done_target: the first pass's done count to wait for): the launch holds the solving workgroups only (the rebuild rides on the other stream as
 // launches of its own), and the FIRST solve's launch is resident while the first kNN pass still runs: it waits for that pass's
 // done flags before it touches anything the pass or the extraction wrote.
 __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int outer_it, int eb, unsigned int seq, int chain, unsigned int done_target) {
-  __shared__ double sh_pose[12];
+  // the candidate's matrix and the current iterate's (the candidate of the last accepted step): two buffers that swap roles when a
+  // step is accepted, so that the iterate's matrix is at hand — bit for bit the one the solve ends with unless another step is
+  // accepted — without being formed again (speculative hand-over, kernels_sync.h; and the launch's last microsecond)
+  __shared__ double sh_pose2[2][12];
+  __shared__ int sh_pi, sh_ci;           // buffer of the candidate / of the iterate (-1: the start point, no matrix)
+  __shared__ int sh_unapplied;           // the controller's last step left the iterate where it was
   __shared__ double sh_acc[kAccN];
   __shared__ LmState lm;
   __shared__ int sh_flag;
@@ -408,6 +423,19 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
   }
   __shared__ double sh_loc[kAccN];
   __shared__ double sh_red[16][32];
+  // State that earlier launches on THIS stream wrote (the start point: the previous scan's finalising solve, or this scan's first
+  // solve; the previous pose and the frame count: the previous scan's finalising solve) is fetched now — in chain mode and beside an
+  // overlapped second pass the launch is about to wait for a kNN pass, and each of these loads would otherwise be a memory round
+  // trip between that pass's last workgroup and the first trust-region step, or between the last step and the pose's publication.
+  __shared__ double sh_x0[8];          // start point: quaternion [4], translation [3]
+  __shared__ double sh_prev[12];       // st.prev_odom (finalising solve)
+  __shared__ int sh_fc;                // st.frame_count (finalising solve)
+  if (threadIdx.x < 4) sh_x0[threadIdx.x] = st.param_q[threadIdx.x];
+  else if (threadIdx.x < 7) sh_x0[threadIdx.x] = st.param_t[threadIdx.x - 4];
+  else if (threadIdx.x >= 64 && threadIdx.x < 76) sh_prev[threadIdx.x - 64] = st.prev_odom[threadIdx.x - 64];
+  else if (threadIdx.x == 76) sh_fc = st.frame_count;
+  __shared__ int sh_spec_at;           // speculative hand-over: the evaluation before which the iterate leaves (0: none)
+  if (threadIdx.x == 77) sh_spec_at = st.spec_eval[outer_it];
   extern __shared__ __attribute__((aligned(16))) int sh_idx[];   // [edge_cap] compacted correspondence indices, then the reduction matrix
   double* sh_part = reinterpret_cast<double*>(sh_idx + ((v.edge_cap + 3) & ~3));   // [kAccN][kLmEvalThreads]
   const int tid = threadIdx.x;
@@ -442,7 +470,10 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
       //  have read `initialized` before it changes: a workgroup that saw 1 would wait for a pose this branch never publishes)
       if (seq) ov_wait_knn_done(v, s, seq, &st.status);
       if (tid == 0) st.append_raw = 1;
-      finalize_scan(v, s, st, sh_cnt, eb, true, 0);
+      __shared__ double sh_T0[12];
+      if (tid < 12) sh_T0[tid] = st.odom[tid];
+      __syncthreads();                       // (also: the prefetched sh_prev / sh_fc)
+      finalize_scan(v, s, st, sh_cnt, eb, true, 0, 0, sh_T0, 1, true, sh_prev, sh_fc);
       if (tid == 0) st.initialized = 1;
     }
     return;
@@ -486,11 +517,16 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
     const int i = tid & 31, r0 = tid >> 5;
     double x0 = 0.0, x1 = 0.0;
     if (i <= kAccN) {                                    // (entry 29: the number of accepted correspondences)
-      // 16 independent loads in flight per pass (one memory round trip for up to 16 kRC k_knn workgroups)
-      for (int rb = r0; rb < (dead ? 0 : nb); rb += 16 * kRC) {
+      // 16 independent loads in flight per pass (one memory round trip for up to 16 kRC k_knn workgroups).  The first pass's loads
+      // do not wait for the edge count (itself a load that has just been issued): rows up to the table's size are fetched and the
+      // ones at or beyond ceil(E / Q) — left by earlier scans — are dropped when the count has arrived.
+      const int nb_cap = v.knn_blocks;
+      for (int rb = r0; rb < (dead ? 0 : (rb == r0 ? nb_cap : nb)); rb += 16 * kRC) {
         double xs[16];
 #pragma unroll
-        for (int u = 0; u < 16; u++) { const int r = rb + kRC * u; xs[u] = (r < nb) ? part[(size_t)r * 32 + i] : 0.0; }
+        for (int u = 0; u < 16; u++) { const int r = rb + kRC * u; xs[u] = (r < nb_cap) ? part[(size_t)r * 32 + i] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < 16; u++) { const int r = rb + kRC * u; if (r >= nb) xs[u] = 0.0; }
 #pragma unroll
         for (int u = 0; u < 16; u += 2) { x0 += xs[u]; x1 += xs[u + 1]; }
       }
@@ -508,23 +544,28 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
     nblocks = sh_nmatch;
   } else {
     // ---- lock-step batches: k_knn leaves only the validity bytes; compaction, then an ordinary first evaluation ----
+    __syncthreads();                                     // (the prefetched start point)
     if (prep) {
       const int C = lm_compact_bits(v, s, outer_it, E, sh_idx);
       if (tid == 0) sh_C = C;
     } else if (tid == kLmCtl) {
-      iso_from_qt(st.param_q, st.param_t, sh_pose);
+      iso_from_qt(sh_x0, sh_x0 + 4, sh_pose2[0]);
     }
     __syncthreads();
     my_share(sh_C);
     lm_cache_load(v, s, eb, c_lo, c_hi, sh_idx, cache);
-    if (G > 1) { lm_eval(v, s, eb, c_lo, c_hi, sh_idx, sh_pose, sh_part, sh_loc, cache); lm_exchange(v, s, g, G, epoch0 | ++n_eval, sh_loc, sh_acc, &st.status, xch_local, &sh_same_xcc); xch_local = sh_same_xcc != 0; }
-    else lm_eval(v, s, eb, c_lo, c_hi, sh_idx, sh_pose, sh_part, sh_acc, cache);
+    if (G > 1) { lm_eval(v, s, eb, c_lo, c_hi, sh_idx, sh_pose2[0], sh_part, sh_loc, cache); lm_exchange(v, s, g, G, epoch0 | ++n_eval, sh_loc, sh_acc, &st.status, xch_local, &sh_same_xcc); xch_local = sh_same_xcc != 0; }
+    else { lm_eval(v, s, eb, c_lo, c_hi, sh_idx, sh_pose2[0], sh_part, sh_acc, cache); ++n_eval; }
   }
   DBG_STAMP(v, dbgb, 2, 2);
   // ---- trust-region loop.  Controller step on lane 0 of the last wave; beside it waves 0..6 prepare the
   // evaluations (step 0: validity bytes -> index list, triples into registers) or reset the hash slots of the
   // build this scan searched (step 1 of the finalising solve) ----
   int dbg_it = 0;
+  int pi = 0, ci = -1;                 // (controller lane) candidate / iterate buffer
+  const unsigned int n_eval0 = n_eval;       // evaluations of this launch before the loop (lock-step batches: the one at the start point)
+  const bool spec_ok = v.speculate != 0 && g == 0 && seq != 0u && outer_it == 0;
+  bool spec_done = false;
   for (int step = 0;; step++) {
     if (step == 0 && tid > kLmCtl && tid <= kLmCtl + 6) {
       // the six Jacobi scales of lm_begin (an FP64 square root and a division each) on six lanes of the controller's wave
@@ -536,9 +577,18 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
       // (a wave-parallel controller — lane 8 r + c holding entry (r, c) of the 6 x 6 matrices, Cholesky columns
       // broadcast through LDS, solves on readlane'd entries — was measured slower than this single lane:
       // 3.9-5.9 us per step against 3.1)
-      const int f = step == 0 ? lm_begin(lm, st.param_q, st.param_t, sh_acc, nblocks, v.apply_on_ftol, sh_scale) : lm_update(lm, sh_acc);
+      const int acc_before = step == 0 ? 0 : lm.accepted;
+      const int f = step == 0 ? lm_begin(lm, sh_x0, sh_x0 + 4, sh_acc, nblocks, v.apply_on_ftol, sh_scale) : lm_update(lm, sh_acc);
       sh_flag = f;
-      if (f == LM_NEED_EVAL) iso_from_qt(lm.cand_q, lm.cand_t, sh_pose);
+      bool moved = step > 0 && lm.accepted != acc_before;
+      if (step > 0 && !moved && f != LM_NEED_EVAL && lm.termination == LM_TERM_FUNC_TOL) {      // (apply_on_ftol: the step was applied without counting as accepted)
+        moved = true;
+        for (int k = 0; k < 4; k++) moved = moved && lm.q[k] == lm.cand_q[k];
+        for (int k = 0; k < 3; k++) moved = moved && lm.t[k] == lm.cand_t[k];
+      }
+      if (moved) { ci = pi; pi ^= 1; }                       // the candidate became the iterate: its matrix stays where it is
+      if (f == LM_NEED_EVAL) iso_from_qt(lm.cand_q, lm.cand_t, sh_pose2[pi]);
+      sh_pi = pi; sh_ci = ci; sh_unapplied = (step > 0 && !moved) ? 1 : 0;
       if (step == 0) DBG_STAMP(v, dbgb, 2, 23);
     } else if (!prep) {
       // (the other lanes of the controller's wave wait at the barrier)
@@ -556,18 +606,34 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
     if (step == 0) { if (v.knn_partials && !prep) my_share(sh_C); DBG_STAMP(v, dbgb, 2, 3); }
     else { DBG_STAMP(v, dbgb && dbg_it < 5, 2, 5 + 2 * dbg_it); dbg_it++; }
     if (sh_flag != LM_NEED_EVAL) break;
-    if (G > 1) { lm_eval(v, s, eb, c_lo, c_hi, sh_idx, sh_pose, sh_part, sh_loc, cache); DBG_STAMP(v, dbgb && dbg_it < 4, 2, 12 + dbg_it); lm_exchange(v, s, g, G, epoch0 | ++n_eval, sh_loc, sh_acc, &st.status, xch_local, &sh_same_xcc); xch_local = sh_same_xcc != 0; }
-    else lm_eval(v, s, eb, c_lo, c_hi, sh_idx, sh_pose, sh_part, sh_acc, cache);
+    // speculative hand-over (kernels_sync.h): the iterate leaves for the waiting second pass before the evaluation that — going by
+    // the previous scan — will end this solve without moving it
+    if (spec_ok && !spec_done && sh_ci >= 0 &&
+        (v.speculate == 2 || (v.speculate == 3 && (int)(n_eval - n_eval0) + 1 == sh_spec_at) || (v.speculate == 1 && lm.model_cost_change <= v.spec_theta * 1e-6 * lm.cost))) {
+      ov_publish_pose(v, s, sh_pose2[sh_ci], &lm.q[0], seq, tid, 1);
+      OV_STAMP(v, tid == 0, 19);
+      if ((kInstrument && (v.debug & 64)) && tid == 0) atomicAdd(&v.dbg_clk[270], 1ull);      // (debug) iterates handed over early
+      spec_done = true;
+    }
+    const double* pose_c = sh_pose2[sh_pi];
+    if (G > 1) { lm_eval(v, s, eb, c_lo, c_hi, sh_idx, pose_c, sh_part, sh_loc, cache); DBG_STAMP(v, dbgb && dbg_it < 4, 2, 12 + dbg_it); lm_exchange(v, s, g, G, epoch0 | ++n_eval, sh_loc, sh_acc, &st.status, xch_local, &sh_same_xcc); xch_local = sh_same_xcc != 0; }
+    else { lm_eval(v, s, eb, c_lo, c_hi, sh_idx, pose_c, sh_part, sh_acc, cache); ++n_eval; }
     DBG_STAMP(v, dbgb && dbg_it < 5, 2, 4 + 2 * dbg_it);
   }
   if (clr_pending) clear_hash_slots();                   // (the solve ended at its first step)
   DBG_STAMP(v, dbgb, 2, 20);
   if ((kInstrument && (v.debug & 32)) && dbgb) v.dbg_clk[2 * 32 + 27] = (xch_local ? 100ull : 0ull) + 10ull * xcc_id() + (unsigned long long)n_eval;   // (debug) exchange transport, XCC, evaluations
   if (g != 0) return;        // every workgroup reached the same result; workgroup 0 records it
-  if (seq && outer_it == 0) {
-    // overlapped second kNN pass: its workgroups are waiting for exactly these 19 doubles — they leave first
-    __shared__ double sh_ov[20];
-    if (tid == kLmCtl) {
+  // What others are waiting for leaves first: the solved pose — to the overlapped second kNN pass (first solve: matrix, quaternion,
+  // translation) or to the workgroups that append the new frame (finalising solve: the matrix) — straight from LDS; the stream's
+  // state, the trace and the scan's bookkeeping follow.
+  __shared__ double sh_ov[20];
+  {
+    const int cif = sh_ci;
+    if (cif >= 0) {                                                  // the iterate's matrix is at hand (:222-227)
+      if (tid < 12) sh_ov[tid] = sh_pose2[cif][tid];
+      else if (tid >= 64 && tid < 71) sh_ov[12 + tid - 64] = (&lm.q[0])[tid - 64];
+    } else if (tid == kLmCtl) {                                      // no step was applied: the start point's
       double q[4], t[3], T[12];
       for (int k = 0; k < 4; k++) q[k] = lm.q[k];
       for (int k = 0; k < 3; k++) t[k] = lm.t[k];
@@ -576,14 +642,23 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
       for (int k = 0; k < 4; k++) sh_ov[12 + k] = q[k];
       for (int k = 0; k < 3; k++) sh_ov[16 + k] = t[k];
     }
-    __syncthreads();
-    ov_publish_pose(v, s, sh_ov, seq, tid);
-    OV_STAMP(v, tid == 0, 1);
+  }
+  __syncthreads();
+  if (outer_it == 0) {
+    // (the confirmation copy always; the copy the pass starts from unless the iterate left early)
+    if (seq) { ov_publish_pose(v, s, sh_ov, sh_ov + 12, seq, tid, spec_done ? 2 : 3); OV_STAMP(v, tid == 0, 1); }
+  } else if (v.early_rebuild && tid < 25) {
+    publish_final_pose(v, s, sh_ov, 0, (unsigned int)sh_fc + 1u, tid);
   }
   if (tid == kLmCtl) {
-    for (int k = 0; k < 4; k++) st.param_q[k] = lm.q[k];
-    for (int k = 0; k < 3; k++) st.param_t[k] = lm.t[k];
-    iso_from_qt(st.param_q, st.param_t, st.odom);                  // :222-227
+    if (outer_it == 0) {       // (the finalising solve's finalize_scan leaves the prediction for the next scan there instead)
+      for (int k = 0; k < 4; k++) st.param_q[k] = sh_ov[12 + k];
+      for (int k = 0; k < 3; k++) st.param_t[k] = sh_ov[16 + k];
+      for (int k = 0; k < 12; k++) st.odom[k] = sh_ov[k];
+    }
+    // history for the next scan's speculative hand-over: the evaluation (counted within the launch's trust-region loop) that ended
+    // this solve without moving the iterate
+    st.spec_eval[outer_it] = (sh_unapplied && sh_ci >= 0) ? (int)(n_eval - n_eval0) : 0;
     liodom_lm_trace_t& tr = st.info.lm[outer_it];
     tr.iterations = lm.iter; tr.accepted = lm.accepted; tr.termination = lm.termination; tr.pad = 0;
     tr.initial_cost = lm.initial_cost; tr.final_cost = lm.cost;
@@ -591,7 +666,7 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
   }
   DBG_STAMP(v, dbgb, 2, 21);
   if (outer_it == 1) {
-    finalize_scan(v, s, st, sh_cnt, eb, false, kLmCtl, chain);
+    finalize_scan(v, s, st, sh_cnt, eb, false, kLmCtl, chain, sh_ov, 0, false, sh_prev, sh_fc);
     DBG_STAMP(v, dbgb, 2, 22);
   }
   DBG_STAMP(v, dbgb, 2, 28);

@@ -184,7 +184,7 @@ __device__ __forceinline__ float4 predicted_point(const StreamState& st, const f
 // handed the edge buffer's ticket slot to the extraction of a later scan (found by tools/chain_hammer.py: APPEND transformed the
 // edges of scan k + 3, for which nothing had been padded).  On the four-launch chain the appending workgroups are resident, with
 // their edge in registers, before the pose exists.
-__device__ void rebuild_count_and_pad(const DevView& v, int s, StreamState& st, int eb, int block, int* sbase, int* sslot, bool keep = false) {
+__device__ __forceinline__ void rebuild_count_and_pad(const DevView& v, int s, StreamState& st, int eb, int block, int* sbase, int* sslot, bool keep = false) {
   const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63;
   const int par = (st.reb_frame_count + 1) & 1;
   const int nC = (v.edge_cap * (v.prev_frames > 1 ? v.prev_frames - 1 : 1) + nt - 1) / nt;
@@ -247,7 +247,7 @@ __device__ void rebuild_count_and_pad(const DevView& v, int s, StreamState& st, 
 // on a stream of its own, by k_rebuild_alloc between the two solve launches (a launch boundary must separate ALLOC from
 // COUNT / PAD before it and from SCATTER / APPEND behind it) —: start offsets of the occupied cells (any order:
 // only contiguity per cell matters), room = points counted + places padded; cell_pad becomes the end of the range.
-__device__ void rebuild_alloc(const DevView& v, int s, StreamState& st, int block, int nblocks) {
+__device__ __forceinline__ void rebuild_alloc(const DevView& v, int s, StreamState& st, int block, int nblocks) {
   const int par = (st.reb_frame_count + 1) & 1, sp = s + par * v.n_streams;
   const int nu = st.n_used_tab[par];
   const int nt = blockDim.x;
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) void k_rebuild_alloc(DevView v, int s0) {
 }
 
 // SCATTER / APPEND / CLEAR, beside the finalising solve
-__device__ void rebuild_finish(const DevView& v, int s, StreamState& st, int eb, int block, unsigned int seq, int* sbase, int* sslot, bool kept = false) {
+__device__ __forceinline__ void rebuild_finish(const DevView& v, int s, StreamState& st, int eb, int block, unsigned int seq, int* sbase, int* sslot, bool kept = false) {
   __shared__ double sh_T[12];
   __shared__ int sh_hand;
   const int tid = threadIdx.x, nt = blockDim.x;
@@ -405,7 +405,7 @@ __device__ void rebuild_finish(const DevView& v, int s, StreamState& st, int eb,
   OV_STAMP(v, dbga, 26);
 }
 
-__device__ void rebuild_beside_solve(const DevView& v, int s, StreamState& st, int eb, int outer_it, int block, int nblocks, unsigned int seq, int* sbase, int* sslot) {
+__device__ __forceinline__ void rebuild_beside_solve(const DevView& v, int s, StreamState& st, int eb, int outer_it, int block, int nblocks, unsigned int seq, int* sbase, int* sslot) {
   (void)nblocks;
   if (outer_it == 0) rebuild_count_and_pad(v, s, st, eb, block, sbase, sslot);
   else rebuild_finish(v, s, st, eb, block, seq, sbase, sslot);

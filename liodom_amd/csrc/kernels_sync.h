@@ -106,14 +106,21 @@ __device__ __forceinline__ void wt_store_u8(void* p, unsigned char x) {
   typedef __attribute__((address_space(1))) unsigned char gu8;
   __hip_atomic_store((gu8*)p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// the first solve's result leaves its workgroup: vals = odom[12], q[4], t[3] in LDS; threads 0 .. kOvReplicas * kOvGranules - 1
-__device__ __forceinline__ void ov_publish_pose(const DevView& v, int s, const double* vals, unsigned int tag, int tid) {
+// the first solve's result leaves its workgroup: T = odom[12], qt = q[4], t[3] (LDS); one granule per thread and copy.
+// copies: bit 0 = the copy the overlapped second pass starts from (granules 0 .. 37 of every replica), bit 1 = the confirmation copy
+// (granules kOvFinalOffset ..: what the solve really ended with, see "Speculative hand-over" below).
+constexpr int kOvFinalOffset = 64;
+__device__ __forceinline__ void ov_publish_pose(const DevView& v, int s, const double* T, const double* qt, unsigned int tag, int tid, int copies) {
   typedef __attribute__((address_space(1))) unsigned long long gu64;
-  for (int t = tid; t < kOvReplicas * kOvGranules; t += (int)blockDim.x) {      // (one granule per thread at 512 threads)
-    const int rep = t / kOvGranules, gi = t % kOvGranules;
-    const unsigned long long bits = (unsigned long long)__double_as_longlong(vals[gi >> 1]);
+  const int per = kOvReplicas * kOvGranules;
+  for (int t = tid; t < 2 * per; t += (int)blockDim.x) {      // (one or two granules per thread at 512 threads)
+    const int c = t / per, u = t % per;
+    if (!((copies >> c) & 1)) continue;
+    const int rep = u / kOvGranules, gi = u % kOvGranules;
+    const double val = (gi >> 1) < 12 ? T[gi >> 1] : qt[(gi >> 1) - 12];
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(val);
     const unsigned int word = (gi & 1) ? (unsigned int)(bits >> 32) : (unsigned int)bits;
-    __hip_atomic_store((gu64*)(v.pose_xch0 + ((size_t)s * kOvReplicas + rep) * 512 + gi), ((unsigned long long)tag << 32) | word,
+    __hip_atomic_store((gu64*)(v.pose_xch0 + ((size_t)s * kOvReplicas + rep) * 512 + c * kOvFinalOffset + gi), ((unsigned long long)tag << 32) | word,
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
@@ -149,6 +156,42 @@ __device__ __forceinline__ bool granules_wait(const unsigned long long* base, in
 // the first solve's result for the overlapped second pass: replica rep of pose_xch0; out19: LDS
 __device__ __forceinline__ bool ov_wait_pose(const DevView& v, int s, int rep, unsigned int tag, double* out19, unsigned int* status) {
   return granules_wait<LIODOM_POLL_POSE>(v.pose_xch0 + ((size_t)s * kOvReplicas + rep) * 512, kOvGranules, tag, out19, status);
+}
+// Speculative hand-over of the first solve's result.  A solve ends with an evaluation whose step is not applied (function
+// tolerance: the cost no longer changes) practically always; the pose it ends with is then the iterate it held BEFORE that
+// evaluation.  When the previous scan's first solve ended that way at its n-th evaluation, this scan's first solve hands its
+// iterate to the waiting second pass before it runs ITS n-th evaluation (copy 0 of pose_xch0) — an evaluation, its exchange and the
+// controller's last step (~4.5 us) earlier — and always publishes what it really ended with as the confirmation copy.  Every
+// workgroup of the pass compares the two when its work is done, before it counts itself done: equal bits (the rule) -> nothing else
+// happens; different (the step was accepted after all) -> it repeats its two blocks from the confirmed pose.  Results are therefore
+// those of the non-speculative hand-over in every case; the history only decides how often the early start pays.
+// returns 1: the pose in io19 is confirmed; 2: it was not — io19 now holds the confirmed one; 0: gave up.
+__device__ __forceinline__ int ov_confirm_pose(const DevView& v, int s, int rep, unsigned int tag, double* io19, unsigned int* status) {
+  typedef __attribute__((address_space(1))) unsigned long long gu64;
+  __shared__ int s_cf;
+  const unsigned long long* base = v.pose_xch0 + ((size_t)s * kOvReplicas + rep) * 512 + kOvFinalOffset;
+  const int tid = (int)threadIdx.x;
+  if (tid < 64) {
+    unsigned long long g = 0, t0 = 0;
+    unsigned int spins = 0;
+    bool ok;
+    while (true) {
+      if (tid < kOvGranules) g = __hip_atomic_load((gu64*)(base + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ok = tid >= kOvGranules || (unsigned int)(g >> 32) == tag;
+      if (__all(ok)) break;
+      if (++spins > 2000000u || wait_expired(spins, t0)) break;
+      __builtin_amdgcn_s_sleep(LIODOM_POLL_POSE);
+    }
+    const bool all_ok = __all(ok);
+    const unsigned long long lo = __shfl(g, 2 * (tid % 19)), hi = __shfl(g, 2 * (tid % 19) + 1);
+    const unsigned long long fin = (hi << 32) | (lo & 0xFFFFFFFFull);
+    const bool differs = tid < 19 && fin != (unsigned long long)__double_as_longlong(io19[tid]);
+    const bool any = __any(differs);
+    if (all_ok && any && tid < 19) io19[tid] = __longlong_as_double((long long)fin);
+    if (tid == 0) { s_cf = all_ok ? (any ? 2 : 1) : 0; if (!all_ok) atomicOr(status, LIODOM_STATUS_PIPE_TIMEOUT); }
+  }
+  __syncthreads();
+  return s_cf;
 }
 // Chain mode: the prediction a scan starts from, published by the previous scan's finalize_scan (threads 0 .. kOvReplicas *
 // kPredGranules - 1 of the solving workgroup; vals: 19 doubles in LDS) and read by the scan's first kNN pass (other HIP stream).

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <limits>
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -77,6 +78,8 @@ struct liodom_handle {
   bool ov_prev = false;              // the previous scan of this handle was overlapped
   // Chain mode (kernels_sync.h "Chain mode"): the scan's kNN passes and the rebuild on stream_k, the two solves — launches of the
   // solving workgroups alone — on `stream`; the first solve's launch is resident beside the first pass.
+  double replay_enq_ns = 0.0, replay_wait_ns = 0.0;      // depth-1 resident replay: host time per scan spent enqueueing / waiting for the previous pose
+  long long replay_timed = 0;
   bool chain_ok = false;             // the handle qualifies (one stream, streamed rebuild, flags, no IMU override; the passes' waiting workgroups
                                      // may take up to half of the wave slots: the rebuild's workgroups are light there and the solve is resident
                                      // before the second pass is dispatched; LIODOM_CHAIN=0 switches it off)
@@ -349,6 +352,7 @@ int enqueue_odometry(liodom_handle* h, int eb, int s0, int count, unsigned int w
     hipLaunchKernelGGL(k_lm_solve, dim3(gx, 1), dim3(kLmThreads), lds, h->stream, v, s0, 0, eb, seq_k, 1, done_target);
     hipLaunchKernelGGL(k_ov_gate, dim3(1), dim3(64), 0, h->stream_k, v, s0, seq_k);
     hipLaunchKernelGGL((k_knn<256, true>), dim3(v.knn_grid + nCP, 1), dim3(256), 0, h->stream_k, v, s0, 1, eb, 0u, 0u, seq_k, scan_no);
+    if (v.speculate) hipLaunchKernelGGL(k_knn_redo<256>, dim3(v.knn_grid, 1), dim3(256), 0, h->stream_k, v, s0, eb, seq_k, scan_no);      // (speculative hand-over not confirmed: rare)
     hipLaunchKernelGGL(k_lm_solve, dim3(gx, 1), dim3(kLmThreads), lds, h->stream, v, s0, 1, eb, seq_k, 1, done_target);
     hipLaunchKernelGGL(k_rebuild_alloc, dim3(kRebuildAllocBlocks, 1), dim3(256), 0, h->stream_k, v, s0);
     hipLaunchKernelGGL(k_rebuild_fin, dim3(nP + kRebuildAuxBlocks + nC, 1), dim3(kLmThreads), 0, h->stream_k, v, s0, eb);
@@ -365,6 +369,7 @@ int enqueue_odometry(liodom_handle* h, int eb, int s0, int count, unsigned int w
       } else if (it == 1 && seq_k) {
         hipLaunchKernelGGL(k_ov_gate, dim3(1), dim3(64), 0, h->stream_k, v, s0, seq_k);
         hipLaunchKernelGGL((k_knn<256, true>), dim3(kx, count), dim3(256), 0, h->stream_k, v, s0, it, eb, 0u, 0u, seq_k, -1);
+        if (v.speculate) hipLaunchKernelGGL(k_knn_redo<256>, dim3(v.knn_grid, count), dim3(256), 0, h->stream_k, v, s0, eb, seq_k, -1);      // (speculative hand-over not confirmed: rare)
         // ALLOC between the two solve launches, beside the pass's tail
         hipLaunchKernelGGL(k_rebuild_alloc, dim3(kRebuildAllocBlocks, count), dim3(256), 0, h->stream, v, s0);
       } else {
@@ -607,7 +612,7 @@ int reset_state(liodom_handle* h) {
   HIP_TRY(hipMemsetAsync(h->v.pose_xch, 0, sizeof(unsigned long long) * (size_t)h->S * 32, h->stream));
   if (h->v.pred_xch) HIP_TRY(hipMemsetAsync(h->v.pred_xch, 0, sizeof(unsigned long long) * (size_t)h->S * kOvReplicas * 512, h->stream));
   HIP_TRY(hipMemsetAsync(h->v.knn_done0, 0, sizeof(unsigned int) * ((size_t)h->S + 64), h->stream));
-  h->chain_prev = false; h->chain_count = 0;
+  h->chain_prev = false; h->chain_count = 0; h->replay_enq_ns = 0.0; h->replay_wait_ns = 0.0; h->replay_timed = 0;
   std::memset(h->host_out, 0, sizeof(HostOut) * 2 * (size_t)h->S);
   std::fill(h->scans_enqueued.begin(), h->scans_enqueued.end(), 0);
   HIP_TRY(hipMemsetAsync(h->v.win_n, 0, sizeof(int) * (size_t)h->S * h->P, h->stream));
@@ -982,6 +987,12 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
     h->chain_ok = v.early_rebuild && S == 1 && v.knn_partials && !v.use_imu && (long long)v.knn_grid * 4 * 2 <= (long long)cus * 24;
     if (const char* e = std::getenv("LIODOM_KNN_OVERLAP")) { if (std::atoi(e) == 0) h->chain_ok = false; }
     if (const char* e = std::getenv("LIODOM_CHAIN")) { if (std::atoi(e) == 0) h->chain_ok = false; }
+    // speculative hand-over of the first solve's result to the overlapped second pass (kernels_sync.h): LIODOM_SPECULATE=0 off,
+    // 2 (tests): as early as possible, i.e. practically always wrong — the pass then repeats its blocks from the confirmed pose
+    v.speculate = (h->ov_ok || h->chain_ok) ? 1 : 0;
+    if (const char* e = std::getenv("LIODOM_SPECULATE")) { if (v.speculate) v.speculate = std::max(0, std::min(3, std::atoi(e))); }
+    v.spec_theta = 0.8;
+    if (const char* e = std::getenv("LIODOM_SPEC_THETA")) v.spec_theta = std::atof(e);
     if ((h->ov_ok || h->chain_ok) && make_stream(&h->stream_k, prio_greatest) != hipSuccess) { g_last_error = "hipStreamCreate failed"; return fail(LIODOM_ERR_HIP); }
     if (h->chain_ok && hipEventCreateWithFlags(&h->ev_ch, hipEventDisableTiming) != hipSuccess) { g_last_error = "hipEventCreate failed"; return fail(LIODOM_ERR_HIP); }
   }
@@ -1559,9 +1570,16 @@ int liodom_replay_resident(liodom_handle_t* h, int first_slot, int count, int ah
       continue;
     }
     // depth 1: enqueue scan i, then collect the pose of scan i - 1 (its sequence number is one behind the enqueue count)
+    const auto t_a = std::chrono::steady_clock::now();
     int rc = replay_one(h, slot, next, n, height, width, false, nullptr, nullptr);
     if (rc) return rc;
+    const auto t_b = std::chrono::steady_clock::now();
     if (i > 0) { rc = wait_pose(h, 0, h->S, out_p(i - 1), out_i(i - 1), 1); if (rc) return rc; }
+    // (where the host's time goes in this loop: liodom_get_modes reports the two averages — the host has one scan's duration to
+    //  enqueue the next scan's launches; if the first number approaches the scan period the GPU starves)
+    h->replay_enq_ns += std::chrono::duration<double, std::nano>(t_b - t_a).count();
+    h->replay_wait_ns += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t_b).count();
+    h->replay_timed++;
   }
   if (depth == 1 && count > 0) { const int rc = wait_pose(h, 0, h->S, out_p(count - 1), out_i(count - 1), 0); if (rc) return rc; }
   return LIODOM_OK;
@@ -1939,13 +1957,14 @@ int liodom_get_modes(liodom_handle_t* h, char* buf, int cap) {
   snprintf(buf, (size_t)cap,
            "n_streams=%d early_rebuild=%d hash_build=%s pipe_flags=%d flag_gate=%d lm_groups=%d knn_instance=%d knn_queries=%d "
            "knn_grid=%d/%d knn_partials=%d knn_saved_bound=%d knn_exact_only=%d line_gate_kernel=%d filter_local_map=%d mapping=%d "
-           "rotation_mode=%d table_size=%d rebuild_delta=%.3f knn_overlap=%d streams_concurrent=%d safe_mode=%d ring_split=%d ring_split_max_wgs=%d chain=%d debug=%d",
+           "rotation_mode=%d table_size=%d rebuild_delta=%.3f knn_overlap=%d streams_concurrent=%d safe_mode=%d ring_split=%d ring_split_max_wgs=%d chain=%d speculate=%d replay_enqueue_us=%.2f replay_wait_us=%.2f debug=%d",
            h->S, v.early_rebuild, v.early_rebuild ? "streamed" : (h->lds_hash_build ? "lds" : "global"), h->use_flags ? 1 : 0,
            (h->use_flags && h->flag_gate) ? 1 : 0, v.lm_groups, h->S >= 16 ? 128 : 256, v.knn_queries, v.knn_grid,
            v.knn_blocks, v.knn_partials, v.knn_save_pos ? 2 : (v.knn_save_q ? 1 : 0), v.knn_exact_only, v.knn_nn ? 1 : 0, v.filter_local_map, v.mapping,
            v.rotation_mode, v.table_size, (double)v.rebuild_delta,
            (v.early_rebuild && (h->ov_ok || (h->chain_ok && !h->flag_gate)) && h->use_flags && g_live_handles.load() <= 1) ? 1 : 0, h->streams_concurrent ? 1 : 0, h->safe_mode ? 1 : 0, h->ring_split ? 1 : 0, h->ring_split ? h->ring_split_max_wgs : 0,
-           (v.early_rebuild && h->chain_ok && h->use_flags && !h->flag_gate && g_live_handles.load() <= 1) ? 1 : 0, v.debug);
+           (v.early_rebuild && h->chain_ok && h->use_flags && !h->flag_gate && g_live_handles.load() <= 1) ? 1 : 0, v.speculate,
+           h->replay_timed ? h->replay_enq_ns / (1e3 * (double)h->replay_timed) : 0.0, h->replay_timed ? h->replay_wait_ns / (1e3 * (double)h->replay_timed) : 0.0, v.debug);
   return LIODOM_OK;
 }
 

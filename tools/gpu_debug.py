@@ -213,12 +213,13 @@ def sec_clocks(H=64, W=1800, R=8, epr=10, P=20, K=40):
     buf = (C.c_ulonglong * 512)()
     g.L.liodom_debug_clocks.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
     g.L.liodom_debug_clocks(g.h, buf)
-    allv = np.array(list(buf), dtype=np.int64)
+    allv = np.array([int(x) if int(x) < 2 ** 63 else int(x) - 2 ** 64 for x in buf], dtype=np.int64)      # (sums of unsigned differences may have wrapped)
     print('k_ring_extract per-ring workgroup durations (us), rings 0..63:', np.round(allv[128:192] / 100.0, 1).tolist())
     print('k_ring_extract (carry re-run rounds, edges) of the rings written last (ring & 31):', [(int(x) & 255, int(x) >> 8) for x in allv[96:128]])
     print('k_knn (both passes): %d queries answered by the Best2 fast path, %d repeated with the exact lists; %d needed a second phase' % (int(allv[256]), int(allv[257]), int(allv[258])))
     print('k_knn second pass: %d queries certified by re-ranking the first pass\'s kept candidates, %d searched' % (int(allv[259]), int(allv[260])))
     print('overlapped second pass: %d queries re-ranked, %d not collected; not certified: %d with fewer than five collected, %d with five; of these: moved > 1 cm %d, > 3 cm %d, guard below the collection radius %d, first-pass fifth distance >= 1 %d' % tuple(int(allv[i]) for i in (261, 262, 264, 265, 266, 269, 267, 268)))
+    print('speculative hand-over: %d iterates handed over early; second-pass workgroups: %d confirmed, %d not, %d repeated by k_knn_redo' % tuple(int(allv[i]) for i in (270, 271, 272, 273)))
     print('k_knn query (half-wave) time to selection, 1 us bins:', allv[320:384].tolist())
     print('k_knn candidates streamed per query, bins of 64:', allv[384:448].tolist())
     print('k_knn time (rows: 4 us bins) x candidates (<64, <128, <256, <512, <1024, more | two-phase | exact repeat):')
@@ -246,7 +247,7 @@ def sec_clocks(H=64, W=1800, R=8, epr=10, P=20, K=40):
     g.close()
 
 
-def sec_ovclocks(H=64, W=1800, R=8, epr=10, P=20, K=40):
+def sec_ovclocks(H=64, W=1800, R=8, epr=10, P=20, K=int(os.environ.get("OV_SCANS", "40"))):
     """Wall-clock stamps around the overlapped second kNN pass of the last scan (instrumented build, debug bit 7)."""
     import ctypes as C
     os.environ.setdefault("LIODOM_DEBUG_CLOCKS", "128")
@@ -257,20 +258,30 @@ def sec_ovclocks(H=64, W=1800, R=8, epr=10, P=20, K=40):
     for k in range(K):
         g.upload_scan(0, k, synth.scan(cfg, 0, k)[0])
     serial = os.environ.get("KNN_SERIAL", "0") != "0"
-    for k in range(K):
-        g.process_resident(k, H * W, H, W, readback=serial)
+    if os.environ.get("OV_REPLAY", "0") != "0":          # the bench's loop (liodom_replay_resident, depth 1) instead of one call per scan
+        g.replay_resident(0, K, H * W, H, W, depth=1)
+    else:
+        for k in range(K):
+            g.process_resident(k, H * W, H, W, readback=serial)
     g.sync()
     buf = (C.c_ulonglong * 512)()
     g.L.liodom_debug_clocks.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
     g.L.liodom_debug_clocks(g.h, buf)
-    allv = np.array(list(buf), dtype=np.int64)
+    allv = np.array([int(x) if int(x) < 2 ** 63 else int(x) - 2 ** 64 for x in buf], dtype=np.int64)      # (sums of unsigned differences may have wrapped)
     print("overlapped pass: pose publication -> seen by a workgroup, 0.25 us bins (all scans):", allv[320:384].tolist())
     print("overlapped pass: pose seen -> done flag raised, per workgroup with queries, 0.5 us bins (all scans):", allv[256:320].tolist())
     print("first pass: workgroup end relative to the start of workgroup 0, 0.5 us bins (all scans):", allv[384:448].tolist())
     a = allv[448:480]
     names = ["solve0 wg0 start", "solve0 pose published", "solve0 wg0 end", "solve1 wg0 start", "solve1 wait done", "solve1 wg0 end", "gate start", "gate saw flag",
              "knn1 wg0 start", "knn1 wg0 past flag", "knn1 wg0 pose seen", "knn1 wg0 end", "knn1 wgN start", "knn1 wgN past flag", "knn1 wgN pose seen", "knn1 wgN end",
-             "knn0 wg0 start", "knn0 wgN end", "solve0 partial sums next", "", "", "", "", "", "", "", "append wg0 end", "knn0 wg0 past its waits", "append wg0 pose seen"]
+             "knn0 wg0 start", "knn0 wgN end", "solve0 partial sums next", "solve0 iterate left early", "", "", "", "", "", "", "append wg0 end", "knn0 wg0 past its waits", "append wg0 pose seen"]
+    sm = allv[480:496].astype(np.float64)
+    if sm[5] > 0:
+        print("phase means over %d scans (us): first pass %.2f | first solve %.2f | second pass's tail (pose published -> finalising solve has its sums' inputs) %.2f | finalising solve %.2f | APPEND %.2f | period %.2f; iterate handed over early in %d scans" % (
+            int(sm[5]), sm[0] / sm[5] / 100, sm[1] / sm[5] / 100, sm[2] / sm[5] / 100, sm[3] / sm[5] / 100, sm[7] / sm[5] / 100, sm[4] / sm[5] / 100, int(sm[6])))
+    if sm[5] > 0:
+        print("   second pass: last workgroup done %.2f us after the (confirmed) pose's publication; the finalising solve has seen the count %.2f us later; early hand-overs that were confirmed (%d scans): %.2f us before the confirmation, last workgroup %.2f us after the hand-over, tail %.2f us; not confirmed (%d scans): tail %.2f us" % (
+            sm[8] / sm[5] / 100, sm[9] / sm[5] / 100, int(sm[12]), sm[10] / max(sm[12], 1) / 100, sm[11] / max(sm[12], 1) / 100, sm[13] / max(sm[12], 1) / 100, int(sm[14]), sm[15] / max(sm[14], 1) / 100))
     t0 = a[16] if a[16] else a[0]
     order = sorted(range(len(names)), key=lambda i: a[i])
     for i in order:

@@ -28,20 +28,23 @@ if len(sys.argv) > 3:
     print(g.modes()["knn_overlap"] + g.modes().get("chain", "0"), flush=True)
     g.close()
     sys.exit(0)
-files = []
-for ov, ch in (("1", "1"), ("1", "0"), ("0", "0")):
-    f = "/tmp/ov_%s_%s%s.npy" % (shape, ov, ch)
-    env = dict(os.environ, LIODOM_KNN_OVERLAP=ov, LIODOM_CHAIN=ch)
+files, names = [], []
+# (overlap, chain, speculative hand-over: 1 by history, 2 as early as possible — practically always wrong: every workgroup of the
+#  second pass is then repeated by k_knn_redo —, 0 off)
+for ov, ch, sp in (("1", "1", "1"), ("1", "1", "2"), ("1", "1", "0"), ("1", "0", "2"), ("0", "0", "0")):
+    f = "/tmp/ov_%s_%s%s%s.npy" % (shape, ov, ch, sp)
+    env = dict(os.environ, LIODOM_KNN_OVERLAP=ov, LIODOM_CHAIN=ch, LIODOM_SPECULATE=sp)
     r = subprocess.run([sys.executable, os.path.abspath(__file__), shape, str(K), f], env=env, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     got = r.stdout.strip().splitlines()[-1]
     assert got == ov + ch or (shape == "ouster128" and ch == "0" and got == "00"), r.stdout      # (Ouster-128: the pass is overlapped in chain mode only)
     files.append(f)
-a, b, c = np.load(files[0]), np.load(files[1]), np.load(files[2])
-same = np.array_equal(a.view(np.uint64), b.view(np.uint64)) and np.array_equal(b.view(np.uint64), c.view(np.uint64))
+    names.append("overlap %s chain %s speculate %s" % (ov, ch, sp))
+logs = [np.load(f) for f in files]
+same = all(np.array_equal(logs[0].view(np.uint64), x.view(np.uint64)) for x in logs[1:])
 if not same:
-    for nm, x in (("chain vs overlapped", a), ("plain vs overlapped", c)):
-        d = np.nonzero(np.any(x.view(np.uint64) != b.view(np.uint64), axis=(1, 2)))[0]
-        print("  %s: %d scans differ, first %s" % (nm, len(d), d[:5]))
-print("%s: %d scans, chain mode vs overlapped pass vs neither: %s" % (shape, K, "bit-identical" if same else "DIFFERENT"))
+    for nm, x in zip(names[1:], logs[1:]):
+        d = np.nonzero(np.any(x.view(np.uint64) != logs[0].view(np.uint64), axis=(1, 2)))[0]
+        print("  %s vs %s: %d scans differ, first %s" % (nm, names[0], len(d), d[:5]))
+print("%s: %d scans, chain mode (speculative hand-over by history / always wrong / off) vs overlapped pass vs neither: %s" % (shape, K, "bit-identical" if same else "DIFFERENT"))
 sys.exit(0 if same else 1)

@@ -20,5 +20,6 @@ t = time.perf_counter()
 g.replay_resident(F, K, H * W, H, W, depth=1)
 dt = time.perf_counter() - t
 m = g.modes()
-print("%s: %.1f scans/s (%.2f us/scan)  chain=%s knn_overlap=%s" % (name, K / dt, dt / K * 1e6, m.get("chain"), m.get("knn_overlap")))
+print("%s: %.1f scans/s (%.2f us/scan)  chain=%s knn_overlap=%s speculate=%s; host per scan: enqueue %s us, waiting for the previous pose %s us" % (
+    name, K / dt, dt / K * 1e6, m.get("chain"), m.get("knn_overlap"), m.get("speculate"), m.get("replay_enqueue_us"), m.get("replay_wait_us")))
 g.close()
