@@ -723,8 +723,8 @@ __device__ __forceinline__ void knn_block(const DevView& v, int s, StreamState& 
     for (int j = 0; j < 5; j++) { nx[j] = sh.nn[q][j * 3]; ny[j] = sh.nn[q][j * 3 + 1]; nz[j] = sh.nn[q][j * 3 + 2]; }
     if (valid) valid = line_gate(nx, ny, nz);
     if (eq < E) {
-      float4* ca = v.corr_a + (size_t)s * v.edge_cap + eq;
-      float4* cb = v.corr_b + (size_t)s * v.edge_cap + eq;
+      float4* ca = v.corr_a + ((size_t)s * 2 + outer_it) * v.edge_cap + eq;
+      float4* cb = v.corr_b + ((size_t)s * 2 + outer_it) * v.edge_cap + eq;
       int2* cidx = v.corr_idx + ((size_t)s * 2 + outer_it) * v.edge_cap + eq;
       const float4 oa = valid ? make_float4(nx[0], ny[0], nz[0], 1.0f) : make_float4(0, 0, 0, 0);              // :351-353
       const float4 ob = valid ? make_float4(nx[1], ny[1], nz[1], 0.0f) : make_float4(0, 0, 0, 0);              // :355-357
@@ -832,8 +832,8 @@ __device__ __forceinline__ void knn_tail_dual(const DevView& v, int s, int outer
       const float4 oa = valid ? make_float4(nx[0], ny[0], nz[0], 1.0f) : make_float4(0, 0, 0, 0);              // :351-353
       const float4 ob = valid ? make_float4(nx[1], ny[1], nz[1], 0.0f) : make_float4(0, 0, 0, 0);              // :355-357
       const int2 oi = valid ? make_int2(sh.res[q][1], sh.res[q][2]) : make_int2(-1, -1);
-      wt_store_f4(v.corr_a + (size_t)s * v.edge_cap + eq, oa);
-      wt_store_f4(v.corr_b + (size_t)s * v.edge_cap + eq, ob);
+      wt_store_f4(v.corr_a + ((size_t)s * 2 + outer_it) * v.edge_cap + eq, oa);
+      wt_store_f4(v.corr_b + ((size_t)s * 2 + outer_it) * v.edge_cap + eq, ob);
       wt_store_u64(v.corr_idx + ((size_t)s * 2 + outer_it) * v.edge_cap + eq, ((unsigned long long)(unsigned int)oi.y << 32) | (unsigned int)oi.x);
     }
     const unsigned long long vb = __ballot(valid);
@@ -889,6 +889,15 @@ __device__ __forceinline__ void knn_tail_dual(const DevView& v, int s, int outer
   }
 }
 
+// Chain mode, first pass, workgroup 0: the release of the previous scan's edge buffer to the extraction (signal_odo: that odometry
+// has completed its last evaluation) — when the pass has seen the verdict on the prediction it started from (speculative hand-over,
+// kernels_sync.h: the prediction may have left the previous scan's finalising solve BEFORE that evaluation; the verdict is
+// published after it).
+__device__ __forceinline__ void chain_release_edges(const DevView& v, unsigned int signal_odo) {
+  typedef __attribute__((address_space(1))) unsigned int gu32;
+  if (signal_odo && threadIdx.x == 0) __hip_atomic_store((gu32*)(v.pipe_flags + kEdgePipeBufs), signal_odo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // grid.x = v.knn_grid workgroups per stream (+ the streamed rebuild's ALLOC workgroups on the second pass): workgroup b
 // takes the query blocks b, b + knn_grid, ... below ceil(E / queries) — the grid is sized for the usual edge count
 // (half of the capacity), not for edge_cap: on lock-step batches two thirds of an edge_cap-sized grid were workgroups
@@ -905,7 +914,7 @@ __device__ __forceinline__ void knn_tail_dual(const DevView& v, int s, int outer
 // everything else this pass needs of that state follows from scan_no, the number of scans completed before this one.
 template <int kKnnThreads, bool kOv, bool kChain>
 __device__ __forceinline__ bool knn_pass(const DevView& v, int s, int bxi, int byi, int outer_it, int eb, unsigned int wait_edges,
-                                         unsigned int signal_odo, unsigned int seq, int scan_no, KnnShared<kKnnThreads / kKnnGroup>& sh, KnnShared<kKnnThreads / kKnnGroup>& sh2, double* sh_ov) {
+                                         unsigned int signal_odo, unsigned int seq, int scan_no, KnnShared<kKnnThreads / kKnnGroup>& sh, KnnShared<kKnnThreads / kKnnGroup>& sh2, double* sh_ov, int pred_copy = 0) {
   constexpr int kKnnQueries = kKnnThreads / kKnnGroup;
   static_assert(!(kOv && kChain), "the overlapped pass is the second pass, the chain-mode instance the first");
   StreamState& st = v.state[s];
@@ -917,11 +926,13 @@ __device__ __forceinline__ bool knn_pass(const DevView& v, int s, int bxi, int b
   } else if (kChain) {
     // the prediction (12 doubles, tag = scans completed; normally there long before this launch starts) and, in the same round
     // trip, the flag of the extraction that fills edge buffer eb
-    if (!pred_wait(v, s, bxi % kOvReplicas, (unsigned int)scan_no, sh_ov, &st.status, v.pipe_flags + eb, wait_edges)) return false;
+    if (!pred_wait(v, s, bxi % kOvReplicas, (unsigned int)scan_no, sh_ov, &st.status, v.pipe_flags + eb, wait_edges, pred_copy)) return false;
     OV_STAMP(v, threadIdx.x == 0 && bxi == 0, 27);
-    // bookkeeping of the streamed rebuild, as below — from scan_no: every scan appends exactly one frame (finalize_scan)
+    // bookkeeping of the streamed rebuild, as below — from scan_no: every scan appends exactly one frame (finalize_scan).  (With a
+    // speculative hand-over the prediction may turn out not to be what the previous scan ended with: the repeated pass of
+    // k_chain_redo0 then writes the confirmed one; the repair of the previous scan's APPEND works from its own parity of pred_odom.)
     if (bxi == 0 && threadIdx.x == 0) { st.reb_frame_count = scan_no; st.n_used_tab[(scan_no + 1) & 1] = 0; st.reb_initialized = 1; st.cursor = 0; }
-    if (bxi == 0 && threadIdx.x >= 64 && threadIdx.x < 76) st.pred_odom[threadIdx.x - 64] = sh_ov[threadIdx.x - 64];
+    if (bxi == 0 && threadIdx.x >= 64 && threadIdx.x < 76) st.pred_odom[scan_no & 1][threadIdx.x - 64] = sh_ov[threadIdx.x - 64];
   } else if (v.early_rebuild) {
     if (bxi >= v.knn_grid) { if (outer_it == 1) rebuild_alloc(v, s, st, bxi - v.knn_grid, (int)gridDim.x - v.knn_grid); return true; }
     // streamed rebuild, bookkeeping before the first builders start (next launch): the frame count the build refers to
@@ -931,13 +942,13 @@ __device__ __forceinline__ bool knn_pass(const DevView& v, int s, int bxi, int b
       st.reb_frame_count = st.frame_count; st.n_used_tab[(st.frame_count + 1) & 1] = 0; st.reb_initialized = st.initialized;
       st.cursor = 0;      // (finalize_scan has reset it already, unless the previous scan ran in chain mode)
     }
-    if (outer_it == 0 && bxi == 0 && threadIdx.x >= 64 && threadIdx.x < 76) st.pred_odom[threadIdx.x - 64] = st.odom[threadIdx.x - 64];
+    if (outer_it == 0 && bxi == 0 && threadIdx.x >= 64 && threadIdx.x < 76) st.pred_odom[st.frame_count & 1][threadIdx.x - 64] = st.odom[threadIdx.x - 64];
   }
   if (!kOv && outer_it == 0) {
     // (pipelined replay) this launch follows odometry `signal_odo` in stream order: that odometry has completed entirely
     // (chain mode: its last reads of its edge buffer have); and the extraction that fills edge buffer eb (other stream) must have
     // completed before anything of it is read
-    if (signal_odo && bxi == 0 && byi == 0 && threadIdx.x == 0) {
+    if (!kChain && signal_odo && bxi == 0 && byi == 0 && threadIdx.x == 0) {
       typedef __attribute__((address_space(1))) unsigned int gu32;
       __hip_atomic_store((gu32*)(v.pipe_flags + kEdgePipeBufs), signal_odo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -1099,7 +1110,15 @@ __global__ __launch_bounds__(kKnnThreads, (kKnnThreads >= 256 ? 1 : LIODOM_TUNE_
   // (a workgroup whose own wait gave up leaves the count short: the solve that waits for it gives up in turn and consumes nothing)
   // (speculative hand-over not confirmed: pass_ok is false — the workgroup's namesake in k_knn_redo signals in its place)
   if (kOv) { if (scan_no >= 0) { if (pass_ok) chain_count_done(v.knn_done0 + 32 + s); } else if (pass_ok || !v.speculate) ov_signal_knn_done(v, s, bxi, seq); }
-  if (kChain && pass_ok) chain_count_done(v.knn_done0 + s);
+  if (kChain) {
+    // speculative hand-over: the prediction this pass started from may have left the previous scan's finalising solve before its last
+    // evaluation; the verdict has arrived by now, as a rule.  Not confirmed: the workgroup does not count itself — its namesake in
+    // k_chain_redo0, behind this launch, repeats the pass from the confirmed prediction (after the new frame has been re-appended).
+    int vd = 1;
+    if (v.speculate) vd = pred_verdict_wait(v, s, bxi % kOvReplicas, (unsigned int)scan_no, &v.state[s].status);
+    if (vd != 2 && bxi == 0) chain_release_edges(v, signal_odo);      // (also when the wait gave up: the extraction must not starve)
+    if (pass_ok && vd == 1) chain_count_done(v.knn_done0 + s);
+  }
   if (kInstrument && (v.debug & 128) && threadIdx.x == 0) {
     if (kOv) {                                         // (debug) pose seen -> flag raised, per workgroup with queries: 0.5 us bins
       const long long t_seen = __double_as_longlong(sh_ov[19]);
@@ -1123,13 +1142,15 @@ __global__ __launch_bounds__(kKnnThreads, (kKnnThreads >= 256 ? 1 : LIODOM_TUNE_
 // write-through results, and counts itself done in the namesake's place.  A kernel of its own so that the pass keeps its register
 // budget (as a retry loop in k_knn the pass went from 134 to 324 VGPRs).
 template <int kKnnThreads>
-__global__ __launch_bounds__(kKnnThreads, 1) void k_knn_redo(DevView v, int s0, int eb, unsigned int seq, int scan_no) {
+// alloc_blocks (chain mode): the launch's first workgroups are the streamed rebuild's ALLOC step (k_rebuild_alloc), which follows
+// the pass on its stream anyway — one launch less per scan for the host to enqueue.
+__global__ __launch_bounds__(kKnnThreads, 1) void k_knn_redo(DevView v, int s0, int eb, unsigned int seq, int scan_no, int alloc_blocks) {
   constexpr int kKnnQueries = kKnnThreads / kKnnGroup;
   __shared__ KnnShared<kKnnQueries> shs[2];
   __shared__ double sh_ov[20];
   __shared__ double sh_first[20];
-  int bxi = (int)blockIdx.x, byi = (int)blockIdx.y;
-  xcd_remap(bxi, byi);
+  if ((int)blockIdx.x < alloc_blocks) { rebuild_alloc(v, s0 + (int)blockIdx.y, v.state[s0 + (int)blockIdx.y], (int)blockIdx.x, alloc_blocks); return; }
+  int bxi = (int)blockIdx.x - alloc_blocks, byi = (int)blockIdx.y;
   const int s = s0 + byi;
   StreamState& st = v.state[s];
   const int rep = bxi % kOvReplicas;
@@ -1212,8 +1233,8 @@ __global__ __launch_bounds__(256) void k_line_gate(DevView v, int s0, int outer_
   bool valid = (eq < E) && (found != 0);
   if (valid) valid = line_gate(nx, ny, nz);
   if (eq < E) {
-    float4* ca = v.corr_a + (size_t)s * v.edge_cap + eq;
-    float4* cb = v.corr_b + (size_t)s * v.edge_cap + eq;
+    float4* ca = v.corr_a + ((size_t)s * 2 + outer_it) * v.edge_cap + eq;
+    float4* cb = v.corr_b + ((size_t)s * 2 + outer_it) * v.edge_cap + eq;
     int2* cidx = v.corr_idx + ((size_t)s * 2 + outer_it) * v.edge_cap + eq;
     if (valid) {
       *ca = make_float4(nx[0], ny[0], nz[0], 1.0f);              // :351-353

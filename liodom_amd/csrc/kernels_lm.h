@@ -59,10 +59,10 @@ __device__ int lm_compact_bits(const DevView& v, int s, int outer_it, int E, int
 // of up to kLmCached * kLmEvalThreads blocks touches no memory before the reduction.
 constexpr int kLmCached = 1;
 struct LmCache { float4 P[kLmCached], A[kLmCached], B[kLmCached]; };
-__device__ __forceinline__ void lm_cache_load(const DevView& v, int s, int eb, int c_lo, int c_hi, const int* idx, LmCache& k) {
+__device__ __forceinline__ void lm_cache_load(const DevView& v, int s, int outer_it, int eb, int c_lo, int c_hi, const int* idx, LmCache& k) {
   const float4* ed = v.edges + ((size_t)eb * v.n_streams + s) * v.edge_cap;
-  const float4* ca = v.corr_a + (size_t)s * v.edge_cap;
-  const float4* cb = v.corr_b + (size_t)s * v.edge_cap;
+  const float4* ca = v.corr_a + ((size_t)s * 2 + outer_it) * v.edge_cap;
+  const float4* cb = v.corr_b + ((size_t)s * 2 + outer_it) * v.edge_cap;
   const int et = (int)threadIdx.x;
 #pragma unroll
   for (int j = 0; j < kLmCached; j++) {
@@ -74,7 +74,7 @@ __device__ __forceinline__ void lm_cache_load(const DevView& v, int s, int eb, i
 
 // Evaluation of the blocks c_lo .. c_hi of the compacted list by the evaluator waves, then the reduction by
 // everybody.  part: [kAccN][kLmEvalThreads] or [kLmThreads/16][kAccN].
-__device__ __forceinline__ void lm_eval(const DevView& v, int s, int eb, int c_lo, int c_hi, const int* idx, const double* Rm_sh,
+__device__ __forceinline__ void lm_eval(const DevView& v, int s, int outer_it, int eb, int c_lo, int c_hi, const int* idx, const double* Rm_sh,
                                         double* part, double* acc_out /*[kAccN]*/, const LmCache& k) {
   const int et = (int)threadIdx.x;
   const bool cached = et < kLmCtl;
@@ -86,8 +86,8 @@ __device__ __forceinline__ void lm_eval(const DevView& v, int s, int eb, int c_l
 #pragma unroll
     for (int i = 0; i < 12; i++) Rm[i] = Rm_sh[i];
     const float4* ed = v.edges + ((size_t)eb * v.n_streams + s) * v.edge_cap;
-    const float4* ca = v.corr_a + (size_t)s * v.edge_cap;
-    const float4* cb = v.corr_b + (size_t)s * v.edge_cap;
+    const float4* ca = v.corr_a + ((size_t)s * 2 + outer_it) * v.edge_cap;
+    const float4* cb = v.corr_b + ((size_t)s * 2 + outer_it) * v.edge_cap;
     int c = c_lo + et;
     if (cached) {
 #pragma unroll
@@ -180,7 +180,21 @@ __device__ void hash_clear_used(const DevView& v, int s /*table: stream + parity
   }
 }
 
-__device__ __forceinline__ void publish_final_pose(const DevView& v, int s, const double* T, int raw, unsigned int tag, int lane);
+__device__ __forceinline__ void publish_final_pose(const DevView& v, int s, const double* T, int raw, unsigned int tag, int lane, int copy = 0);
+
+// The prediction for the next scan: odom * (prev^-1 * odom) (:148-150), its quaternion (:186-190 q_curr(odom_.rotation())) and
+// translation (:192-195): out19 = matrix [12], quaternion [4], translation [3].  One thread.
+__device__ __forceinline__ void predict_next(const double* T, const double* prev, int rotation_mode, double* out19) {
+  double fin[12], po[12], inv[12], rel[12], pred[12], q[4];
+  for (int i = 0; i < 12; i++) { fin[i] = T[i]; po[i] = prev[i]; }
+  iso_inverse(po, inv);
+  iso_mul(inv, fin, rel);
+  iso_mul(fin, rel, pred);
+  quat_from_pose(pred, rotation_mode, q);
+  for (int i = 0; i < 12; i++) out19[i] = pred[i];
+  for (int i = 0; i < 4; i++) out19[12 + i] = q[i];
+  out19[16] = pred[3]; out19[17] = pred[7]; out19[18] = pred[11];
+}
 
 // Called by the whole workgroup.  sh_cnt: LDS scratch of kMaxFrames + 1 ints.
 // T (LDS): the scan's final pose; raw: the frame enters the window untransformed (first frame); publish_pose: the appenders have
@@ -192,7 +206,7 @@ __device__ __forceinline__ void publish_final_pose(const DevView& v, int s, cons
 // chain: the rebuild of this scan runs on the other HIP stream, beside this launch (ALLOC may still be allocating cell ranges from
 // st.cursor): the cursor is then reset by the next scan's first kNN pass, which follows the rebuild in stream order.
 __device__ __forceinline__ void finalize_scan(const DevView& v, int s, StreamState& st, int* sh_cnt, int eb, bool clear_hash, int ctl, int chain,
-                              const double* T, int raw, bool publish_pose, const double* prev, int fc_old) {
+                              const double* T, int raw, bool publish_pose, const double* prev, int fc_old, int pred_copies = 3, unsigned int verdict = 1u) {
   __shared__ double sh_pred[19];      // the prediction: matrix [12], quaternion [4], translation [3]
   const int P = v.prev_frames;
   const int tid = threadIdx.x;
@@ -205,7 +219,7 @@ __device__ __forceinline__ void finalize_scan(const DevView& v, int s, StreamSta
   int* wb = v.win_base + (size_t)s * (P + 1);
   int* ws = v.win_slot + (size_t)s * P;
   // early_rebuild: hand the pose to the workgroups that append the new frame (they have been waiting for it)
-  if (publish_pose && v.early_rebuild && tid < 25) publish_final_pose(v, s, T, raw, (unsigned int)fc_old + 1u, tid);
+  if (publish_pose && v.early_rebuild && tid < 50) publish_final_pose(v, s, T, raw, (unsigned int)fc_old + 1u, tid % 25, tid / 25);
   const int n_edges = st.n_edges_buf[eb];
   const int nup = st.n_used_tab[0];      // cells of the build that this scan searched (cleared below)
   for (int j = tid; j < nf; j += blockDim.x) {           // frame sizes of the new window (nothing here depends on the pose)
@@ -214,21 +228,15 @@ __device__ __forceinline__ void finalize_scan(const DevView& v, int s, StreamSta
     ws[j] = sl;
   }
   if (tid == ctl) {
-    // prediction for the next scan: odom * (prev^-1 * odom)   (:148-150)
-    double fin[12], po[12], inv[12], rel[12], pred[12], q[4];
-    for (int i = 0; i < 12; i++) { fin[i] = T[i]; po[i] = prev ? prev[i] : st.prev_odom[i]; }
-    iso_inverse(po, inv);
-    iso_mul(inv, fin, rel);
-    iso_mul(fin, rel, pred);
-    quat_from_pose(pred, v.rotation_mode, q);                        // :186-190 q_curr(odom_.rotation())
-    for (int i = 0; i < 12; i++) sh_pred[i] = pred[i];
-    for (int i = 0; i < 4; i++) sh_pred[12 + i] = q[i];
-    sh_pred[16] = pred[3]; sh_pred[17] = pred[7]; sh_pred[18] = pred[11];
+    double po[12];
+    for (int i = 0; i < 12; i++) po[i] = prev ? prev[i] : st.prev_odom[i];
+    predict_next(T, po, v.rotation_mode, sh_pred);
   }
   __syncthreads();
   // chain mode: the next scan's first kNN pass runs on the other HIP stream and may start before this launch has ended (it follows
-  // the APPEND launch): the prediction it starts from travels as tagged granules (tag = scans completed)
-  if (v.pred_xch) pred_publish(v, s, sh_pred, (unsigned int)fc_new, tid);
+  // the APPEND launch): the prediction it starts from travels as tagged granules (tag = scans completed); pred_copies / verdict:
+  // speculative hand-over (kernels_sync.h) — the copy the pass starts from may have left before the solve's last evaluation
+  if (v.pred_xch) { pred_publish(v, s, sh_pred, (unsigned int)fc_new, tid, (int)blockDim.x, pred_copies); pred_verdict_publish(v, s, (unsigned int)fc_new, verdict, tid); }
   if (tid == 64) {
     // pose as published (laser_odometry.cc:403-412 with identity laser_to_base)
     double fin[12], q[4];
@@ -349,9 +357,10 @@ __device__ void lm_exchange(const DevView& v, int s, int g, int G, unsigned int 
 // the same launch (MI355X guide, G16 form R2: the data is the flag): 12 doubles as 24 granules {tag, 32 data bits} + one
 // granule of flags, relaxed agent-scope stores, one granule per lane (a single thread storing all 25 took 4.7 us);
 // tag = frames appended so far + 1 (never 0, the reset value).
-__device__ __forceinline__ void publish_final_pose(const DevView& v, int s, const double* T, int raw, unsigned int tag, int lane /*0..24*/) {
+// copy 0: what the appending workgroups start from; copy 1: what the solve ended with (speculative hand-over: the repair reads both)
+__device__ __forceinline__ void publish_final_pose(const DevView& v, int s, const double* T, int raw, unsigned int tag, int lane /*0..24*/, int copy) {
   typedef __attribute__((address_space(1))) unsigned long long gu64;
-  unsigned long long* base = v.pose_xch + (size_t)s * 32;
+  unsigned long long* base = v.pose_xch + (size_t)s * 64 + copy * 32;
   unsigned int word = (unsigned int)raw;
   if (lane < 24) {
     const unsigned long long bits = (unsigned long long)__double_as_longlong(T[lane >> 1]);
@@ -384,12 +393,19 @@ __device__ __forceinline__ void rebuild_beside_solve(const DevView& v, int s, St
 // chain != 0 (chain mode, kernels_sync.h; done_target: the first pass's done count to wait for): the launch holds the solving workgroups only (the rebuild rides on the other stream as
 // launches of its own), and the FIRST solve's launch is resident while the first kNN pass still runs: it waits for that pass's
 // done flags before it touches anything the pass or the extraction wrote.
-__global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int outer_it, int eb, unsigned int seq, int chain, unsigned int done_target) {
+// (one instance per solve of the scan: the first solve's code holds neither the scan's finalisation nor the appending workgroups,
+//  the finalising solve's neither COUNT / PAD nor the hand-over to the second pass — as one kernel with a run-time outer_it the
+//  controller's steps spilled more with every addition to either side)
+template <int kOuterIt>
+__global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int eb, unsigned int seq, int chain, unsigned int done_target) {
+  constexpr int outer_it = kOuterIt;
   // the candidate's matrix and the current iterate's (the candidate of the last accepted step): two buffers that swap roles when a
   // step is accepted, so that the iterate's matrix is at hand — bit for bit the one the solve ends with unless another step is
   // accepted — without being formed again (speculative hand-over, kernels_sync.h; and the launch's last microsecond)
   __shared__ double sh_pose2[2][12];
   __shared__ int sh_pi, sh_ci;           // buffer of the candidate / of the iterate (-1: the start point, no matrix)
+  __shared__ int sh_nmoved;              // how often the iterate has moved (a hand-over is confirmed iff it has not moved since)
+  __shared__ double sh_pred_s[20];       // finalising solve, speculative hand-over: the prediction formed from the iterate
   __shared__ int sh_unapplied;           // the controller's last step left the iterate where it was
   __shared__ double sh_acc[kAccN];
   __shared__ LmState lm;
@@ -553,19 +569,23 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
     }
     __syncthreads();
     my_share(sh_C);
-    lm_cache_load(v, s, eb, c_lo, c_hi, sh_idx, cache);
-    if (G > 1) { lm_eval(v, s, eb, c_lo, c_hi, sh_idx, sh_pose2[0], sh_part, sh_loc, cache); lm_exchange(v, s, g, G, epoch0 | ++n_eval, sh_loc, sh_acc, &st.status, xch_local, &sh_same_xcc); xch_local = sh_same_xcc != 0; }
-    else { lm_eval(v, s, eb, c_lo, c_hi, sh_idx, sh_pose2[0], sh_part, sh_acc, cache); ++n_eval; }
+    lm_cache_load(v, s, outer_it, eb, c_lo, c_hi, sh_idx, cache);
+    if (G > 1) { lm_eval(v, s, outer_it, eb, c_lo, c_hi, sh_idx, sh_pose2[0], sh_part, sh_loc, cache); lm_exchange(v, s, g, G, epoch0 | ++n_eval, sh_loc, sh_acc, &st.status, xch_local, &sh_same_xcc); xch_local = sh_same_xcc != 0; }
+    else { lm_eval(v, s, outer_it, eb, c_lo, c_hi, sh_idx, sh_pose2[0], sh_part, sh_acc, cache); ++n_eval; }
   }
   DBG_STAMP(v, dbgb, 2, 2);
   // ---- trust-region loop.  Controller step on lane 0 of the last wave; beside it waves 0..6 prepare the
   // evaluations (step 0: validity bytes -> index list, triples into registers) or reset the hash slots of the
   // build this scan searched (step 1 of the finalising solve) ----
   int dbg_it = 0;
-  int pi = 0, ci = -1;                 // (controller lane) candidate / iterate buffer
+  int pi = 0, ci = -1, nmoved = 0;     // (controller lane) candidate / iterate buffer, moves of the iterate
   const unsigned int n_eval0 = n_eval;       // evaluations of this launch before the loop (lock-step batches: the one at the start point)
   const bool spec_ok = v.speculate != 0 && g == 0 && seq != 0u && outer_it == 0;
+  // ... and of the finalising solve's, in chain mode: to the workgroups that append the new frame (the pose) and to the next scan's
+  // first kNN pass, which follows them on their stream (the prediction formed from it)
+  const bool spec_ok1 = v.speculate != 0 && g == 0 && chain != 0 && outer_it == 1 && v.early_rebuild && v.pred_xch != nullptr;
   bool spec_done = false;
+  int spec_moves = -1;
   for (int step = 0;; step++) {
     if (step == 0 && tid > kLmCtl && tid <= kLmCtl + 6) {
       // the six Jacobi scales of lm_begin (an FP64 square root and a division each) on six lanes of the controller's wave
@@ -586,9 +606,9 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
         for (int k = 0; k < 4; k++) moved = moved && lm.q[k] == lm.cand_q[k];
         for (int k = 0; k < 3; k++) moved = moved && lm.t[k] == lm.cand_t[k];
       }
-      if (moved) { ci = pi; pi ^= 1; }                       // the candidate became the iterate: its matrix stays where it is
+      if (moved) { ci = pi; pi ^= 1; nmoved++; }             // the candidate became the iterate: its matrix stays where it is
       if (f == LM_NEED_EVAL) iso_from_qt(lm.cand_q, lm.cand_t, sh_pose2[pi]);
-      sh_pi = pi; sh_ci = ci; sh_unapplied = (step > 0 && !moved) ? 1 : 0;
+      sh_pi = pi; sh_ci = ci; sh_nmoved = nmoved; sh_unapplied = (step > 0 && !moved) ? 1 : 0;
       if (step == 0) DBG_STAMP(v, dbgb, 2, 23);
     } else if (!prep) {
       // (the other lanes of the controller's wave wait at the barrier)
@@ -598,7 +618,7 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
       if (tid == 0) sh_C = C;
       DBG_STAMP(v, dbge, 2, 25);
       my_share(C);
-      lm_cache_load(v, s, eb, c_lo, c_hi, sh_idx, cache);
+      lm_cache_load(v, s, outer_it, eb, c_lo, c_hi, sh_idx, cache);
     } else if (clr_pending) {
       clear_hash_slots();
     }
@@ -608,16 +628,29 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
     if (sh_flag != LM_NEED_EVAL) break;
     // speculative hand-over (kernels_sync.h): the iterate leaves for the waiting second pass before the evaluation that — going by
     // the previous scan — will end this solve without moving it
-    if (spec_ok && !spec_done && sh_ci >= 0 &&
+    if ((spec_ok || spec_ok1) && !spec_done && sh_ci >= 0 &&
         (v.speculate == 2 || (v.speculate == 3 && (int)(n_eval - n_eval0) + 1 == sh_spec_at) || (v.speculate == 1 && lm.model_cost_change <= v.spec_theta * 1e-6 * lm.cost))) {
-      ov_publish_pose(v, s, sh_pose2[sh_ci], &lm.q[0], seq, tid, 1);
-      OV_STAMP(v, tid == 0, 19);
+      if (spec_ok) {
+        ov_publish_pose(v, s, sh_pose2[sh_ci], &lm.q[0], seq, tid, 1);
+        OV_STAMP(v, tid == 0, 19);
+      } else if (tid >= kLmCtl) {
+        // the controller's wave has no residual blocks (they go to the lowest threads): it hands the pose to the appenders, forms
+        // the prediction (one lane, ~0.6 us: less than the evaluation the other waves start meanwhile) and publishes it
+        const int l = tid - kLmCtl;
+        if (l < 25) publish_final_pose(v, s, sh_pose2[sh_ci], 0, (unsigned int)sh_fc + 1u, l, 0);
+        if (l == 0) predict_next(sh_pose2[sh_ci], sh_prev, v.rotation_mode, sh_pred_s);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        pred_publish(v, s, sh_pred_s, (unsigned int)sh_fc + 1u, l, 64, 1);
+        OV_STAMP(v, l == 0, 22);
+      }
       if ((kInstrument && (v.debug & 64)) && tid == 0) atomicAdd(&v.dbg_clk[270], 1ull);      // (debug) iterates handed over early
       spec_done = true;
+      spec_moves = sh_nmoved;
     }
     const double* pose_c = sh_pose2[sh_pi];
-    if (G > 1) { lm_eval(v, s, eb, c_lo, c_hi, sh_idx, pose_c, sh_part, sh_loc, cache); DBG_STAMP(v, dbgb && dbg_it < 4, 2, 12 + dbg_it); lm_exchange(v, s, g, G, epoch0 | ++n_eval, sh_loc, sh_acc, &st.status, xch_local, &sh_same_xcc); xch_local = sh_same_xcc != 0; }
-    else { lm_eval(v, s, eb, c_lo, c_hi, sh_idx, pose_c, sh_part, sh_acc, cache); ++n_eval; }
+    if (G > 1) { lm_eval(v, s, outer_it, eb, c_lo, c_hi, sh_idx, pose_c, sh_part, sh_loc, cache); DBG_STAMP(v, dbgb && dbg_it < 4, 2, 12 + dbg_it); lm_exchange(v, s, g, G, epoch0 | ++n_eval, sh_loc, sh_acc, &st.status, xch_local, &sh_same_xcc); xch_local = sh_same_xcc != 0; }
+    else { lm_eval(v, s, outer_it, eb, c_lo, c_hi, sh_idx, pose_c, sh_part, sh_acc, cache); ++n_eval; }
     DBG_STAMP(v, dbgb && dbg_it < 5, 2, 4 + 2 * dbg_it);
   }
   if (clr_pending) clear_hash_slots();                   // (the solve ended at its first step)
@@ -647,8 +680,9 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
   if (outer_it == 0) {
     // (the confirmation copy always; the copy the pass starts from unless the iterate left early)
     if (seq) { ov_publish_pose(v, s, sh_ov, sh_ov + 12, seq, tid, spec_done ? 2 : 3); OV_STAMP(v, tid == 0, 1); }
-  } else if (v.early_rebuild && tid < 25) {
-    publish_final_pose(v, s, sh_ov, 0, (unsigned int)sh_fc + 1u, tid);
+  } else if (v.early_rebuild && tid < 50) {
+    // (the confirmation copy always; the copy the appenders start from unless the iterate left early)
+    if (tid >= 25 || !spec_done) publish_final_pose(v, s, sh_ov, 0, (unsigned int)sh_fc + 1u, tid % 25, tid / 25);
   }
   if (tid == kLmCtl) {
     if (outer_it == 0) {       // (the finalising solve's finalize_scan leaves the prediction for the next scan there instead)
@@ -666,7 +700,7 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
   }
   DBG_STAMP(v, dbgb, 2, 21);
   if (outer_it == 1) {
-    finalize_scan(v, s, st, sh_cnt, eb, false, kLmCtl, chain, sh_ov, 0, false, sh_prev, sh_fc);
+    finalize_scan(v, s, st, sh_cnt, eb, false, kLmCtl, chain, sh_ov, 0, false, sh_prev, sh_fc, spec_done ? 2 : 3, (!spec_done || sh_nmoved == spec_moves) ? 1u : 2u);
     DBG_STAMP(v, dbgb, 2, 22);
   }
   DBG_STAMP(v, dbgb, 2, 28);

@@ -137,8 +137,8 @@ constexpr int kRebuildAuxBlocks = 8;      // workgroups for ALLOC (inside k_knn)
 constexpr int kRebuildAllocBlocks = 32;   // k_rebuild_alloc: the ~8 000 occupied cells of a headline scan in one sweep (it sits between the two solve launches)
 
 // Prefix table of the kept frames (chronological): sbase[0 .. nk], sslot[0 .. nk).  Returns nk; whole workgroup.
-__device__ __forceinline__ int kept_frames_table(const DevView& v, int s, const StreamState& st, int* sbase, int* sslot) {
-  const int P = v.prev_frames, fc = st.reb_frame_count;
+__device__ __forceinline__ int kept_frames_table(const DevView& v, int s, const StreamState& st, int* sbase, int* sslot, int fc_of = -1) {
+  const int P = v.prev_frames, fc = fc_of >= 0 ? fc_of : st.reb_frame_count;
   const int nf_old = fc < P ? fc : P;
   const int drop = nf_old == P ? 1 : 0;
   const int nk = nf_old - drop;
@@ -167,11 +167,12 @@ __device__ __forceinline__ bool point_finite(const float4& pt) {
          fabsf(pt.x) < 1.0e9f && fabsf(pt.y) < 1.0e9f && fabsf(pt.z) < 1.0e9f;
 }
 // the scan's edge idx at the pose the scan started from (the first frame enters the window untransformed, :123)
-__device__ __forceinline__ float4 predicted_point(const StreamState& st, const float4& e) {
-  if (!st.reb_initialized) return e;
+__device__ __forceinline__ float4 predicted_point(const StreamState& st, const float4& e, int fc_of = -1) {
+  if (fc_of < 0 && !st.reb_initialized) return e;
+  const int fc = fc_of >= 0 ? fc_of : st.reb_frame_count;
   double T[12];
 #pragma unroll
-  for (int i = 0; i < 12; i++) T[i] = st.pred_odom[i];
+  for (int i = 0; i < 12; i++) T[i] = st.pred_odom[fc & 1][i];
   float4 q;
   transform_point(T, e.x, e.y, e.z, &q.x, &q.y, &q.z);
   q.w = e.w;
@@ -335,7 +336,7 @@ __device__ __forceinline__ void rebuild_finish(const DevView& v, int s, StreamSt
   }
   if (tid < 64) {
     typedef __attribute__((address_space(1))) unsigned long long gu64;
-    const unsigned long long* base = v.pose_xch + (size_t)s * 32;
+    const unsigned long long* base = v.pose_xch + (size_t)s * 64;
     const unsigned int tag = (unsigned int)fc + 1u;
     unsigned long long g = 0, t0w = 0;
     unsigned int spins = 0;
@@ -405,6 +406,105 @@ __device__ __forceinline__ void rebuild_finish(const DevView& v, int s, StreamSt
   OV_STAMP(v, dbga, 26);
 }
 
+// Speculative hand-over not confirmed (kernels_sync.h; rare): the new frame was appended at the pose the finalising solve held before
+// its last evaluation, and that evaluation's step was accepted after all.  Repair, by the first `nblocks` workgroups of k_chain_redo0
+// (behind the next scan's first pass, whose bookkeeping has not been committed: the stream's state is as the rebuild left it):
+// every workgroup takes back what APPEND did with its points (the same decisions, from the same inputs: the place in the cell is
+// given back by decrementing the cell's count — the order inside a cell carries no meaning), all of them meet, then the points
+// are appended again at the confirmed pose.  Results: those of an APPEND that had waited for the confirmed pose.
+__device__ __forceinline__ bool append_pose_copy(const DevView& v, int s, unsigned int tag, int copy, double* T /*LDS [12]*/, unsigned int* status) {
+  typedef __attribute__((address_space(1))) unsigned long long gu64;
+  __shared__ int sh_ok;
+  const int tid = threadIdx.x;
+  if (tid < 64) {
+    const unsigned long long* base = v.pose_xch + (size_t)s * 64 + copy * 32;
+    unsigned long long g = 0, t0w = 0;
+    unsigned int spins = 0;
+    bool ok;
+    while (true) {
+      if (tid < 25) g = __hip_atomic_load((gu64*)(base + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ok = tid >= 25 || (unsigned int)(g >> 32) == tag;
+      if (__all(ok)) break;
+      if (++spins > 2000000u || wait_expired(spins, t0w)) break;
+      __builtin_amdgcn_s_sleep(4);
+    }
+    const bool all_ok = __all(ok);
+    const unsigned long long lo = __shfl(g, 2 * (tid % 12)), hi = __shfl(g, 2 * (tid % 12) + 1);
+    if (tid < 12) T[tid] = __longlong_as_double((long long)((hi << 32) | (lo & 0xFFFFFFFFull)));
+    if (tid == 0) { sh_ok = all_ok ? 1 : 0; if (!all_ok) atomicOr(status, LIODOM_STATUS_LM_SYNC_TIMEOUT); }
+  }
+  __syncthreads();
+  return sh_ok != 0;
+}
+__device__ __forceinline__ void append_fix(const DevView& v, int s, StreamState& st, int block, int nblocks, unsigned int epoch, int fc, int* sbase, int* sslot) {
+  __shared__ double sh_Ts[12], sh_Tf[12];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int P = v.prev_frames;      // (fc: frames appended before the scan under repair — the next scan's first pass has advanced the stream's own count)
+  const int par = (fc + 1) & 1, sp = s + par * v.n_streams;
+  float4* sorted = v.sorted_pts + (size_t)sp * v.sorted_cap;
+  CellSlot* cells = v.cells + (size_t)sp * v.table_size;
+  const unsigned int tmask = (unsigned int)v.table_size - 1u;
+  const unsigned int tag = (unsigned int)fc + 1u;
+  const bool have = append_pose_copy(v, s, tag, 0, sh_Ts, &st.status) && append_pose_copy(v, s, tag, 1, sh_Tf, &st.status);
+  const int nk = kept_frames_table(v, s, st, sbase, sslot, fc);
+  const int Mk = nk > 0 ? sbase[nk] : 0;
+  const int n_new = v.edges_keep ? st.reb_pad : 0;
+  const int idx = block * nt + tid;
+  const bool live = have && idx < n_new;
+  const float4 e = v.edges_keep[(size_t)s * v.edge_cap + (live ? idx : 0)];
+  const float4 q = predicted_point(st, e, fc);
+  const bool q_fin = point_finite(q);
+  const float dc = v.rebuild_delta - 1.0e-3f;
+  // the cell a point ends up in at pose T (-1: the overflow list; -2: the point is not part of the map) — as rebuild_finish decides it
+  auto place_of = [&](const double* Tl, float4& pt) -> int {
+    double T[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) T[i] = Tl[i];
+    transform_point(T, e.x, e.y, e.z, &pt.x, &pt.y, &pt.z);
+    pt.w = e.w;
+    if (!point_finite(pt)) return -2;
+    if (!(q_fin && fabsf(pt.x - q.x) < dc && fabsf(pt.y - q.y) < dc && fabsf(pt.z - q.z) < dc)) return -1;
+    const unsigned long long key = pack_cell((int)floorf(pt.x * kCellInv), (int)floorf(pt.y * kCellInv), (int)floorf(pt.z * kCellInv));
+    unsigned int h = hash_cell(key, tmask);
+    for (int probe = 0; probe < v.table_size; probe++) {
+      const unsigned long long k = cells[h].key;
+      if (k == key) return (int)h;
+      if (k == kEmptyKey) break;
+      h = (h + 1) & tmask;
+    }
+    return -1;
+  };
+  float4 pt;
+  if (live) {
+    const int hf = place_of(sh_Ts, pt);
+    if (hf >= 0) atomicSub(&cells[hf].cnt, 1u);
+    else if (hf == -1) atomicSub(&st.n_ovf[par], 1);
+  }
+  // all workgroups of the repair have taken their points back before any of them appends again
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __syncthreads();
+  if (tid == 0) { epoch_arrive(v.redo_sync + 0, epoch); (void)epoch_wait(v.redo_sync + 0, epoch, (unsigned int)nblocks, &st.status); }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (live) {
+    const int hf = place_of(sh_Tf, pt);
+    v.win_pts[((size_t)s * P + (fc % P)) * v.edge_cap + idx] = pt;
+    const int m = Mk + idx;
+    if (hf >= 0) {
+      const unsigned int pos = cells[hf].start + atomicAdd(&cells[hf].cnt, 1u);
+      if (pos < v.cell_pad[(size_t)sp * v.table_size + hf]) sorted[pos] = make_float4(pt.x, pt.y, pt.z, __int_as_float(m));
+      else atomicOr(&st.status, LIODOM_STATUS_HASH_FULL);
+    } else if (hf == -1) {
+      const int i = atomicAdd(&st.n_ovf[par], 1);
+      sorted[v.ovf_base + i] = make_float4(pt.x, pt.y, pt.z, __int_as_float(m));
+    }
+  }
+  // ... and all of them have appended before the pass is repeated (the waiting workgroups of k_chain_redo0)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __syncthreads();
+  if (tid == 0) epoch_arrive(v.redo_sync + 1, epoch);
+}
+
 __device__ __forceinline__ void rebuild_beside_solve(const DevView& v, int s, StreamState& st, int eb, int outer_it, int block, int nblocks, unsigned int seq, int* sbase, int* sslot) {
   (void)nblocks;
   if (outer_it == 0) rebuild_count_and_pad(v, s, st, eb, block, sbase, sslot);
@@ -419,6 +519,45 @@ __global__ __launch_bounds__(kLmThreads) void k_rebuild_fin(DevView v, int s0, i
   __shared__ int sh_slot[kMaxFrames];
   const int s = s0 + blockIdx.y;
   rebuild_finish(v, s, v.state[s], eb, (int)blockIdx.x, 0u, sh_cnt, sh_slot, true);      // (seq 0: the second kNN pass precedes this launch in stream order)
+}
+
+// Chain mode, speculative hand-over of the finalising solve's result (kernels_sync.h): the launch behind the next scan's first kNN
+// pass.  Verdict 1 (the rule): nothing to do.  Verdict 2: the first nA workgroups re-append the previous scan's frame at the confirmed
+// pose (append_fix); the others wait for them and repeat the first pass from the confirmed prediction, commit its bookkeeping and
+// count themselves done in their namesakes' place.  with_pass 0: repair only (the handle leaves chain mode or is synchronised: no
+// pass has been started from the prediction); with_fix 0: the frame has been re-appended already, by such a launch.
+template <int kKnnThreads>
+__global__ __launch_bounds__(kKnnThreads, 1) void k_chain_redo0(DevView v, int s0, int eb, unsigned int wait_edges, unsigned int signal_odo, unsigned int seq, int scan_no, int nA, int with_pass, int with_fix) {
+  constexpr int kKnnQueries = kKnnThreads / kKnnGroup;
+  const int s = s0 + (int)blockIdx.y;
+  StreamState& st = v.state[s];
+  // (with_pass: the launch's last workgroup is the gate in front of the overlapped second pass — k_ov_gate: the pass's launch, next on
+  //  this stream, must not start before the first solve's workgroups are on their CUs; one launch less per scan for the host)
+  if (with_pass && (int)blockIdx.x == (int)gridDim.x - 1) {
+    (void)pipe_wait(v.ov_flags + s, seq, &st.status);
+    return;
+  }
+  const int bx = (int)blockIdx.x;
+  if (pred_verdict_wait(v, s, bx % kOvReplicas, (unsigned int)scan_no, &st.status) != 2) return;
+  if ((kInstrument && (v.debug & 64)) && threadIdx.x == 0) atomicAdd(&v.dbg_clk[274], 1ull);      // (debug) workgroups of the repair
+  if (bx < nA) {
+    __shared__ int sh_cnt[kMaxFrames + 1];
+    __shared__ int sh_slot[kMaxFrames];
+    if (with_fix) append_fix(v, s, st, bx, nA, (unsigned int)scan_no, scan_no - 1, sh_cnt, sh_slot);      // (else: repaired already, by a launch of its own when the host synchronised)
+    return;
+  }
+  if (!with_pass) return;
+  __shared__ KnnShared<kKnnQueries> shs[1];
+  __shared__ double sh_ov[20];
+  __shared__ int sh_go;
+  if (threadIdx.x == 0) sh_go = (!with_fix || epoch_wait(v.redo_sync + 1, (unsigned int)scan_no, (unsigned int)nA, &st.status)) ? 1 : 0;
+  __syncthreads();
+  if (!sh_go) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  int bxi = bx - nA, byi = (int)blockIdx.y;
+  const bool pass_ok = knn_pass<kKnnThreads, false, true>(v, s, bxi, byi, 0, eb, wait_edges, signal_odo, seq, scan_no, shs[0], shs[0], sh_ov, 1);
+  if (bxi == 0) chain_release_edges(v, signal_odo);
+  if (pass_ok) chain_count_done(v.knn_done0 + s);
 }
 
 // Start offsets of the occupied cells (any order: only contiguity per cell matters).  One atomic

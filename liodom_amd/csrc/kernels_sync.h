@@ -195,24 +195,76 @@ __device__ __forceinline__ int ov_confirm_pose(const DevView& v, int s, int rep,
 }
 // Chain mode: the prediction a scan starts from, published by the previous scan's finalize_scan (threads 0 .. kOvReplicas *
 // kPredGranules - 1 of the solving workgroup; vals: 19 doubles in LDS) and read by the scan's first kNN pass (other HIP stream).
-__device__ __forceinline__ void pred_publish(const DevView& v, int s, const double* vals, unsigned int tag, int tid) {
+// copies: bit 0 = the copy the next scan's first pass starts from (granules 0 .. 37 of every replica), bit 1 = the confirmation copy
+// (granules kOvFinalOffset ..); lane / nlanes: the publishing threads (the whole workgroup, or one wave beside the evaluators).
+constexpr int kPredVerdict = 127;      // granule of every replica: {tag, 1 = the copy the pass started from is what the solve ended with, 2 = it is not}
+__device__ __forceinline__ void pred_publish(const DevView& v, int s, const double* vals, unsigned int tag, int lane, int nlanes, int copies) {
   typedef __attribute__((address_space(1))) unsigned long long gu64;
-  if (tid < kOvReplicas * kPredGranules) {
-    const int rep = tid / kPredGranules, gi = tid % kPredGranules;
+  const int per = kOvReplicas * kPredGranules;
+  for (int t = lane; t < 2 * per; t += nlanes) {
+    const int c = t / per, u = t % per;
+    if (!((copies >> c) & 1)) continue;
+    const int rep = u / kPredGranules, gi = u % kPredGranules;
     const unsigned long long bits = (unsigned long long)__double_as_longlong(vals[gi >> 1]);
     const unsigned int word = (gi & 1) ? (unsigned int)(bits >> 32) : (unsigned int)bits;
-    __hip_atomic_store((gu64*)(v.pred_xch + ((size_t)s * kOvReplicas + rep) * 512 + gi), ((unsigned long long)tag << 32) | word,
+    __hip_atomic_store((gu64*)(v.pred_xch + ((size_t)s * kOvReplicas + rep) * 512 + c * kOvFinalOffset + gi), ((unsigned long long)tag << 32) | word,
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+}
+__device__ __forceinline__ void pred_verdict_publish(const DevView& v, int s, unsigned int tag, unsigned int verdict, int lane) {
+  typedef __attribute__((address_space(1))) unsigned long long gu64;
+  if (lane < kOvReplicas) __hip_atomic_store((gu64*)(v.pred_xch + ((size_t)s * kOvReplicas + lane) * 512 + kPredVerdict), ((unsigned long long)tag << 32) | verdict,
+                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// whole workgroup; 0: gave up, else the verdict
+__device__ __forceinline__ int pred_verdict_wait(const DevView& v, int s, int rep, unsigned int tag, unsigned int* status) {
+  typedef __attribute__((address_space(1))) unsigned long long gu64;
+  __shared__ int s_vd;
+  if (threadIdx.x == 0) {
+    const unsigned long long* p = v.pred_xch + ((size_t)s * kOvReplicas + rep) * 512 + kPredVerdict;
+    unsigned int spins = 0;
+    unsigned long long t0 = 0, g;
+    int r = 0;
+    while (true) {
+      g = __hip_atomic_load((gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((unsigned int)(g >> 32) == tag) { r = (int)(unsigned int)g; break; }
+      if (++spins > 2000000u || wait_expired(spins, t0)) { atomicOr(status, LIODOM_STATUS_PIPE_TIMEOUT); break; }
+      __builtin_amdgcn_s_sleep(4);
+    }
+    s_vd = r;
+  }
+  __syncthreads();
+  return s_vd;
+}
+// Self-resetting arrival counter for the rare repair paths: the word is {epoch, arrivals}; the first arrival of a new epoch resets it.
+__device__ __forceinline__ void epoch_arrive(unsigned int* word, unsigned int epoch) {
+  typedef __attribute__((address_space(1))) unsigned int gu32;
+  unsigned int old = __hip_atomic_load((gu32*)word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  while (true) {
+    const unsigned int want = ((old >> 12) == (epoch & 0xFFFFFu)) ? old + 1u : (((epoch & 0xFFFFFu) << 12) | 1u);
+    const unsigned int seen = atomicCAS(word, old, want);
+    if (seen == old) break;
+    old = seen;
+  }
+}
+__device__ __forceinline__ bool epoch_wait(const unsigned int* word, unsigned int epoch, unsigned int n, unsigned int* status) {
+  typedef __attribute__((address_space(1))) unsigned int gu32;
+  unsigned int spins = 0;
+  unsigned long long t0 = 0;
+  while (__hip_atomic_load((gu32*)word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (((epoch & 0xFFFFFu) << 12) | n)) {
+    __builtin_amdgcn_s_sleep(8);
+    if (++spins > 2000000u || wait_expired(spins, t0)) { atomicOr(status, LIODOM_STATUS_PIPE_TIMEOUT); return false; }
+  }
+  return true;
 }
 // whole workgroup: the prediction (lanes 0 .. 37 of the first wave: matrix, quaternion, translation) and, in the same round trip,
 // the extraction's flag (lane 63; edge_flag may be null / want 0: nothing to wait for).  out12: 19 doubles.  false: one of them never arrived.
 __device__ __forceinline__ bool pred_wait(const DevView& v, int s, int rep, unsigned int tag, double* out12, unsigned int* status,
-                                          const unsigned int* edge_flag, unsigned int edge_want) {
+                                          const unsigned int* edge_flag, unsigned int edge_want, int copy = 0) {
   typedef __attribute__((address_space(1))) unsigned long long gu64;
   typedef __attribute__((address_space(1))) unsigned int gu32;
   __shared__ int s_pw_ok;
-  const unsigned long long* base = v.pred_xch + ((size_t)s * kOvReplicas + rep) * 512;
+  const unsigned long long* base = v.pred_xch + ((size_t)s * kOvReplicas + rep) * 512 + copy * kOvFinalOffset;
   const int tid = (int)threadIdx.x;
   if (tid < 64) {
     unsigned long long g = 0, t0 = 0;

@@ -85,6 +85,7 @@ struct liodom_handle {
                                      // before the second pass is dispatched; LIODOM_CHAIN=0 switches it off)
   bool chain_prev = false;           // the previous scan was enqueued in chain mode
   unsigned int chain_count = 0;      // first-pass workgroups launched in chain mode since the last reset (what knn_done0 counts up to)
+  bool chain_fix_pending = false;    // the last chain-mode scan's APPEND may need the repair of k_chain_redo0 (speculative hand-over)
   bool chain_used = false;           // any scan was: the odometry side's results are complete when stream AND stream_k have drained
   hipEvent_t ev_ch = nullptr;        // at a switch out of chain mode: the odometry stream waits for stream_k
   int ov_warm = 0;                   // scans enqueued so far, up to kOvWarmScans (the first ones run every kernel of the chain for the first time)
@@ -174,7 +175,18 @@ int dev_alloc(liodom_handle* h, T** p, size_t count, int memset_value = 0) {
 
 // The odometry side's device results (window, correspondences, pose log, state) are complete when its streams have drained: in
 // chain mode the kNN passes and the rebuild run on stream_k.
+// Speculative hand-over of a chain-mode scan's result (kernels_sync.h): the repair of an APPEND that started from a pose the solve
+// did not end with rides behind the NEXT scan's first pass (k_chain_redo0).  When no such pass follows — the handle leaves chain
+// mode, or the host is about to read the odometry side's results — the repair is enqueued on its own (it waits for the scan's
+// verdict; normally it finds nothing to do).
+void chain_flush(liodom_handle* h) {
+  if (!h->chain_fix_pending) return;
+  h->chain_fix_pending = false;
+  const int nA = (h->v.edge_cap + 255) / 256;
+  hipLaunchKernelGGL(k_chain_redo0<256>, dim3(nA, 1), dim3(256), 0, h->stream_k, h->v, 0, 0, 0u, 0u, 0u, h->scans_enqueued[0], nA, 0, 1);
+}
 hipError_t sync_odometry(liodom_handle* h) {
+  chain_flush(h);
   hipError_t e = hipStreamSynchronize(h->stream);
   if (e == hipSuccess && h->chain_used && h->stream_k) e = hipStreamSynchronize(h->stream_k);
   return e;
@@ -332,6 +344,7 @@ int enqueue_odometry(liodom_handle* h, int eb, int s0, int count, unsigned int w
       // (stream_k waits for the odometry stream: recorded above — ev_ov — unless the previous scan was overlapped without the chain)
       if (h->ov_prev) { HIP_TRY(hipEventRecord(h->ev_ov, h->stream)); HIP_TRY(hipStreamWaitEvent(h->stream_k, h->ev_ov, 0)); }
     } else {
+      chain_flush(h);
       HIP_TRY(hipEventRecord(h->ev_ch, h->stream_k));
       HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_ch, 0));
     }
@@ -349,12 +362,19 @@ int enqueue_odometry(liodom_handle* h, int eb, int s0, int count, unsigned int w
     // stream:   first solve (resident beside the first pass: waits for its done flags) | finalising solve (waits for the second pass's)
     const int nCP = cdiv(h->v.edge_cap * std::max(1, h->P - 1), 256) + cdiv(h->v.edge_cap, 256);      // COUNT + PAD workgroups of 256 threads
     hipLaunchKernelGGL((k_knn<256, false, true>), dim3(v.knn_grid, 1), dim3(256), 0, h->stream_k, v, s0, 0, eb, wait_edges, signal_odo, seq_k, scan_no);
-    hipLaunchKernelGGL(k_lm_solve, dim3(gx, 1), dim3(kLmThreads), lds, h->stream, v, s0, 0, eb, seq_k, 1, done_target);
-    hipLaunchKernelGGL(k_ov_gate, dim3(1), dim3(64), 0, h->stream_k, v, s0, seq_k);
+    if (v.speculate) {      // (speculative hand-over of the previous scan's result not confirmed: rare)
+      const int nA = cdiv(h->v.edge_cap, 256);
+      // (+ 1: the gate in front of the second pass, k_ov_gate's job otherwise)
+      hipLaunchKernelGGL(k_chain_redo0<256>, dim3(nA + v.knn_grid + 1, 1), dim3(256), 0, h->stream_k, v, s0, eb, wait_edges, signal_odo, seq_k, scan_no, nA, 1, h->chain_fix_pending ? 1 : 0);
+    }
+    h->chain_fix_pending = v.speculate != 0;
+    hipLaunchKernelGGL(k_lm_solve<0>, dim3(gx, 1), dim3(kLmThreads), lds, h->stream, v, s0, eb, seq_k, 1, done_target);
+    if (!v.speculate) hipLaunchKernelGGL(k_ov_gate, dim3(1), dim3(64), 0, h->stream_k, v, s0, seq_k);
     hipLaunchKernelGGL((k_knn<256, true>), dim3(v.knn_grid + nCP, 1), dim3(256), 0, h->stream_k, v, s0, 1, eb, 0u, 0u, seq_k, scan_no);
-    if (v.speculate) hipLaunchKernelGGL(k_knn_redo<256>, dim3(v.knn_grid, 1), dim3(256), 0, h->stream_k, v, s0, eb, seq_k, scan_no);      // (speculative hand-over not confirmed: rare)
-    hipLaunchKernelGGL(k_lm_solve, dim3(gx, 1), dim3(kLmThreads), lds, h->stream, v, s0, 1, eb, seq_k, 1, done_target);
-    hipLaunchKernelGGL(k_rebuild_alloc, dim3(kRebuildAllocBlocks, 1), dim3(256), 0, h->stream_k, v, s0);
+    // (speculative hand-over not confirmed — rare —: the pass's workgroups once more; the launch's first workgroups are ALLOC)
+    if (v.speculate) hipLaunchKernelGGL(k_knn_redo<256>, dim3(kRebuildAllocBlocks + v.knn_grid, 1), dim3(256), 0, h->stream_k, v, s0, eb, seq_k, scan_no, kRebuildAllocBlocks);
+    hipLaunchKernelGGL(k_lm_solve<1>, dim3(gx, 1), dim3(kLmThreads), lds, h->stream, v, s0, eb, seq_k, 1, done_target);
+    if (!v.speculate) hipLaunchKernelGGL(k_rebuild_alloc, dim3(kRebuildAllocBlocks, 1), dim3(256), 0, h->stream_k, v, s0);
     hipLaunchKernelGGL(k_rebuild_fin, dim3(nP + kRebuildAuxBlocks + nC, 1), dim3(kLmThreads), 0, h->stream_k, v, s0, eb);
     HIP_TRY(hipGetLastError());
     return LIODOM_OK;
@@ -369,7 +389,7 @@ int enqueue_odometry(liodom_handle* h, int eb, int s0, int count, unsigned int w
       } else if (it == 1 && seq_k) {
         hipLaunchKernelGGL(k_ov_gate, dim3(1), dim3(64), 0, h->stream_k, v, s0, seq_k);
         hipLaunchKernelGGL((k_knn<256, true>), dim3(kx, count), dim3(256), 0, h->stream_k, v, s0, it, eb, 0u, 0u, seq_k, -1);
-        if (v.speculate) hipLaunchKernelGGL(k_knn_redo<256>, dim3(v.knn_grid, count), dim3(256), 0, h->stream_k, v, s0, eb, seq_k, -1);      // (speculative hand-over not confirmed: rare)
+        if (v.speculate) hipLaunchKernelGGL(k_knn_redo<256>, dim3(v.knn_grid, count), dim3(256), 0, h->stream_k, v, s0, eb, seq_k, -1, 0);      // (speculative hand-over not confirmed: rare)
         // ALLOC between the two solve launches, beside the pass's tail
         hipLaunchKernelGGL(k_rebuild_alloc, dim3(kRebuildAllocBlocks, count), dim3(256), 0, h->stream, v, s0);
       } else {
@@ -381,7 +401,8 @@ int enqueue_odometry(liodom_handle* h, int eb, int s0, int count, unsigned int w
       // it 0: + COUNT, PAD; it 1: + APPEND, CLEAR, SCATTER
       const int extra = !early ? 0 : (it == 0 ? nC + nP : nP + kRebuildAuxBlocks + nC);
       const int gx = std::max(h->v.lm_groups + extra, (h->v.lm_groups - 1) * 8 + 1);      // solvers on blocks 0, 8, 16, ... (one XCD)
-      hipLaunchKernelGGL(k_lm_solve, dim3(gx, count), dim3(kLmThreads), lm_lds_bytes(h->v.edge_cap), h->stream, v, s0, it, eb, seq_k, 0, 0u);
+      if (it == 0) hipLaunchKernelGGL(k_lm_solve<0>, dim3(gx, count), dim3(kLmThreads), lm_lds_bytes(h->v.edge_cap), h->stream, v, s0, eb, seq_k, 0, 0u);
+      else hipLaunchKernelGGL(k_lm_solve<1>, dim3(gx, count), dim3(kLmThreads), lm_lds_bytes(h->v.edge_cap), h->stream, v, s0, eb, seq_k, 0, 0u);
     }
   }
   if (v.mapping) {
@@ -581,7 +602,7 @@ int reset_state(liodom_handle* h) {
   std::vector<StreamState> init((size_t)h->S);
   for (auto& st : init) {
     std::memset(&st, 0, sizeof(st));
-    iso_identity(st.odom); iso_identity(st.prev_odom); iso_identity(st.final_odom); iso_identity(st.pred_odom);
+    iso_identity(st.odom); iso_identity(st.prev_odom); iso_identity(st.final_odom); iso_identity(st.pred_odom[0]); iso_identity(st.pred_odom[1]);
     st.param_q[3] = 1.0;
     st.table_mask = (uint32_t)h->v.table_size - 1u;
   }
@@ -609,10 +630,11 @@ int reset_state(liodom_handle* h) {
   for (int b = 0; b < kEdgePipeBufs; b++) { h->eb_seq[b] = 0; h->eb_reader[b] = 0; }
   HIP_TRY(hipMemsetAsync(h->v.pipe_flags, 0, sizeof(unsigned int) * (kEdgePipeBufs + 1), h->stream));
   HIP_TRY(hipMemsetAsync(h->v.lm_xch, 0, sizeof(unsigned long long) * (size_t)h->S * 2 * kLmGroupsMax * 64, h->stream));
-  HIP_TRY(hipMemsetAsync(h->v.pose_xch, 0, sizeof(unsigned long long) * (size_t)h->S * 32, h->stream));
+  HIP_TRY(hipMemsetAsync(h->v.pose_xch, 0, sizeof(unsigned long long) * (size_t)h->S * 64, h->stream));
+  HIP_TRY(hipMemsetAsync(h->v.redo_sync, 0, sizeof(unsigned int) * 64, h->stream));
   if (h->v.pred_xch) HIP_TRY(hipMemsetAsync(h->v.pred_xch, 0, sizeof(unsigned long long) * (size_t)h->S * kOvReplicas * 512, h->stream));
   HIP_TRY(hipMemsetAsync(h->v.knn_done0, 0, sizeof(unsigned int) * ((size_t)h->S + 64), h->stream));
-  h->chain_prev = false; h->chain_count = 0; h->replay_enq_ns = 0.0; h->replay_wait_ns = 0.0; h->replay_timed = 0;
+  h->chain_prev = false; h->chain_count = 0; h->chain_fix_pending = false; h->replay_enq_ns = 0.0; h->replay_wait_ns = 0.0; h->replay_timed = 0;
   std::memset(h->host_out, 0, sizeof(HostOut) * 2 * (size_t)h->S);
   std::fill(h->scans_enqueued.begin(), h->scans_enqueued.end(), 0);
   HIP_TRY(hipMemsetAsync(h->v.win_n, 0, sizeof(int) * (size_t)h->S * h->P, h->stream));
@@ -829,8 +851,8 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   ALLOC(v.ring_picked, S * (size_t)config->max_points, 0);
   ALLOC(v.edges, kEdgeBufs * S * v.edge_cap, 0);
   ALLOC(v.edges_meta, kEdgeBufs * S * v.edge_cap, 0);
-  ALLOC(v.corr_a, S * v.edge_cap, 0);
-  ALLOC(v.corr_b, S * v.edge_cap, 0);
+  ALLOC(v.corr_a, S * 2 * v.edge_cap, 0);
+  ALLOC(v.corr_b, S * 2 * v.edge_cap, 0);
   ALLOC(v.corr_idx, S * 2 * v.edge_cap, 0xFF);
   if (v.debug & 1) ALLOC(v.knn_q, S * 2 * v.edge_cap, 0); else v.knn_q = nullptr;
   ALLOC(v.win_pts, S * h->P * v.edge_cap, 0);
@@ -867,7 +889,8 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   ALLOC(v.dbg_clk, 16 * 32, 0);
   if (v.debug & 32) ALLOC(v.dbg_q, 2 * (size_t)v.edge_cap * 12, 0); else v.dbg_q = nullptr;
   ALLOC(v.lm_xch, S * 2 * kLmGroupsMax * 64, 0);
-  ALLOC(v.pose_xch, S * 32, 0);
+  ALLOC(v.pose_xch, S * 64, 0);
+  ALLOC(v.redo_sync, 64, 0);
   ALLOC(v.pipe_flags, kEdgePipeBufs + 1, 0);
   v.host_edges = nullptr; v.host_edges_meta = nullptr; v.host_edges_hdr = nullptr;
   if (S == 1) {
@@ -958,8 +981,8 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   }
   v.lm_lds_reduce = lm_lds_reduce_fits(v.edge_cap) ? 1 : 0;
   if (lm_lds_bytes(v.edge_cap) + 8192 > 160 * 1024) { g_last_error = "liodom_create: edge capacity too large for the solve's LDS tile"; return fail(LIODOM_ERR_INVALID_ARG); }
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lm_solve), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)lm_lds_bytes(h->v.edge_cap)) != hipSuccess) {
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lm_solve<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm_lds_bytes(h->v.edge_cap)) != hipSuccess ||
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lm_solve<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm_lds_bytes(h->v.edge_cap)) != hipSuccess) {
     g_last_error = "hipFuncSetAttribute(max dynamic LDS) failed"; return fail(LIODOM_ERR_HIP);
   }
   if (h->ring_lds_bytes > 48 * 1024) {

@@ -95,7 +95,9 @@ struct StreamState {
   int32_t reb_pad;        // chain mode: the scan's edge count as PAD saw it (APPEND iterates over it, see edges_keep)
   int32_t spec_eval[2];   // speculative hand-over (kernels_sync.h): the evaluation at which the previous scan's first / finalising solve ended without
                           // applying its step (0: it ended otherwise)
-  double pred_odom[12];   // early_rebuild: the prediction the scan started from, snapshot taken by the scan's first kNN launch: st.odom moves
+  double pred_odom[2][12]; // early_rebuild: the prediction the scan started from ([frames appended so far & 1]: the repair of a speculative hand-over
+                          // that was not confirmed, kernels_sync.h, needs the previous scan's while the next scan's is already there),
+                          // snapshot taken by the scan's first kNN launch: st.odom moves
                           // on with the solves, and the finalising solve writes the NEXT scan's prediction while builders of this scan still run
   liodom_step_info_t info;
 };
@@ -155,8 +157,9 @@ struct DevView {
   unsigned char* ring_picked;  // [S][max_points] picked_ marks of the generic path
   float4* edges;            // [kEdgeBufs][S][edge_cap] dense
   int4* edges_meta;         // [kEdgeBufs][S][edge_cap] (ring, idx_in_ring, src, 0)
-  float4* corr_a;           // [S][edge_cap]  xyz of NN0, w = valid
-  float4* corr_b;           // [S][edge_cap]  xyz of NN1
+  float4* corr_a;           // [S][2][edge_cap]  xyz of NN0, w = valid; one half per kNN pass: a pass that starts from a pose handed over early
+                            // (kernels_sync.h, speculative hand-over) writes while the previous solve's last evaluation still reads
+  float4* corr_b;           // [S][2][edge_cap]  xyz of NN1
   int2* corr_idx;           // [S][2][edge_cap] window indices of (NN0, NN1), debug/parity
   float4* knn_q;            // [S][2][edge_cap] world-frame float query of every edge and pass (debug_buffers only, else null)
   float4* win_pts;          // [S][P][edge_cap]
@@ -201,7 +204,9 @@ struct DevView {
   float4* knn_nn;           // [S][edge_cap][5] lock-step batches: the five neighbours of every query (w: found flag, index of NN0, NN1) for k_line_gate
   unsigned int* pipe_flags; // [kEdgePipeBufs + 1] pipelined replay without cross-stream events: [b] = sequence number of the extraction whose edges
                             // are complete in edge buffer b; [kEdgePipeBufs] = number of the last odometry (of this handle) that has completed entirely
-  unsigned long long* pose_xch;   // [S][32] early_rebuild: solved pose handed to the workgroups that append the new frame (tagged 8-byte granules)
+  unsigned long long* pose_xch;   // [S][2][32] early_rebuild: solved pose handed to the workgroups that append the new frame (tagged 8-byte granules);
+                                  // second copy: what the solve ended with (speculative hand-over)
+  unsigned int* redo_sync;        // [2] self-resetting arrival counters of the repair path (append_fix)
   int early_rebuild;        // streamed rebuild: extra workgroups of the scan's four launches build the next scan's cell hash in the
                             // second table ("Streamed rebuild" below); no k_window_insert / k_hash_alloc / k_hash_scatter launches
   int knn_grid;             // k_knn workgroups launched per stream (each takes the query blocks b, b + knn_grid, ...)

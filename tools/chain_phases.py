@@ -10,7 +10,7 @@ def short(n):
 ev = [(short(n), a, b) for n, a, b in rows]
 k0 = [e for e in ev if e[0].startswith("k_knn<256, false")]
 k1 = [e for e in ev if e[0].startswith("k_knn<256, true")]
-lm = [e for e in ev if e[0] == "k_lm_solve"]
+lm = [e for e in ev if e[0].startswith("k_lm_solve")]
 fin = [e for e in ev if e[0] == "k_rebuild_fin"]
 scans = []
 for a in k0[-N - 1:-1]:
