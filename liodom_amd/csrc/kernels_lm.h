@@ -227,16 +227,7 @@ __device__ __forceinline__ void finalize_scan(const DevView& v, int s, StreamSta
     sh_cnt[j] = (sl == new_slot) ? n_edges : wn[sl];     // independent loads, one round trip
     ws[j] = sl;
   }
-  if (tid == ctl) {
-    double po[12];
-    for (int i = 0; i < 12; i++) po[i] = prev ? prev[i] : st.prev_odom[i];
-    predict_next(T, po, v.rotation_mode, sh_pred);
-  }
-  __syncthreads();
-  // chain mode: the next scan's first kNN pass runs on the other HIP stream and may start before this launch has ended (it follows
-  // the APPEND launch): the prediction it starts from travels as tagged granules (tag = scans completed); pred_copies / verdict:
-  // speculative hand-over (kernels_sync.h) — the copy the pass starts from may have left before the solve's last evaluation
-  if (v.pred_xch) { pred_publish(v, s, sh_pred, (unsigned int)fc_new, tid, (int)blockDim.x, pred_copies); pred_verdict_publish(v, s, (unsigned int)fc_new, verdict, tid); }
+  // (the pose log / host-mapped record by thread 64, beside thread `ctl`'s prediction)
   if (tid == 64) {
     // pose as published (laser_odometry.cc:403-412 with identity laser_to_base)
     double fin[12], q[4];
@@ -263,6 +254,16 @@ __device__ __forceinline__ void finalize_scan(const DevView& v, int s, StreamSta
     }
     st.info.matches[0] = 0; st.info.matches[1] = 0;   // counters of the next scan's two kNN passes
   }
+  if (tid == ctl) {
+    double po[12];
+    for (int i = 0; i < 12; i++) po[i] = prev ? prev[i] : st.prev_odom[i];
+    predict_next(T, po, v.rotation_mode, sh_pred);
+  }
+  __syncthreads();
+  // chain mode: the next scan's first kNN pass runs on the other HIP stream and may start before this launch has ended (it follows
+  // the APPEND launch): the prediction it starts from travels as tagged granules (tag = scans completed); pred_copies / verdict:
+  // speculative hand-over (kernels_sync.h) — the copy the pass starts from may have left before the solve's last evaluation
+  if (v.pred_xch) { pred_publish(v, s, sh_pred, (unsigned int)fc_new, tid, (int)blockDim.x, pred_copies); pred_verdict_publish(v, s, (unsigned int)fc_new, verdict, tid); }
   if (tid == ctl) {
     for (int i = 0; i < 12; i++) { const double f = T[i]; st.final_odom[i] = f; st.prev_odom[i] = f; st.odom[i] = sh_pred[i]; }
     for (int i = 0; i < 4; i++) st.param_q[i] = sh_pred[12 + i];
