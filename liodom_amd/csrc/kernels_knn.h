@@ -926,13 +926,17 @@ __device__ __forceinline__ bool knn_pass(const DevView& v, int s, int bxi, int b
   } else if (kChain) {
     // the prediction (12 doubles, tag = scans completed; normally there long before this launch starts) and, in the same round
     // trip, the flag of the extraction that fills edge buffer eb
-    if (!pred_wait(v, s, bxi % kOvReplicas, (unsigned int)scan_no, sh_ov, &st.status, v.pipe_flags + eb, wait_edges, pred_copy)) return false;
+    const bool pred_ok = pred_wait(v, s, bxi % kOvReplicas, (unsigned int)scan_no, sh_ov, &st.status, v.pipe_flags + eb, wait_edges, pred_copy);
     OV_STAMP(v, threadIdx.x == 0 && bxi == 0, 27);
     // bookkeeping of the streamed rebuild, as below — from scan_no: every scan appends exactly one frame (finalize_scan).  (With a
     // speculative hand-over the prediction may turn out not to be what the previous scan ended with: the repeated pass of
     // k_chain_redo0 then writes the confirmed one; the repair of the previous scan's APPEND works from its own parity of pred_odom.)
+    // (ALSO when the wait above gave up — beside a saturating second process it does —: the scan has failed through the status bit, but
+    //  the rebuild's launches behind this pass run whatever happens, and on a list of occupied cells that was not emptied they wrote
+    //  past its end: a GPU memory fault in the two-process soak on the 64-ring shape, found with the ROCm debug agent)
     if (bxi == 0 && threadIdx.x == 0) { st.reb_frame_count = scan_no; st.n_used_tab[(scan_no + 1) & 1] = 0; st.reb_initialized = 1; st.cursor = 0; }
-    if (bxi == 0 && threadIdx.x >= 64 && threadIdx.x < 76) st.pred_odom[scan_no & 1][threadIdx.x - 64] = sh_ov[threadIdx.x - 64];
+    if (pred_ok && bxi == 0 && threadIdx.x >= 64 && threadIdx.x < 76) st.pred_odom[scan_no & 1][threadIdx.x - 64] = sh_ov[threadIdx.x - 64];
+    if (!pred_ok) return false;
   } else if (v.early_rebuild) {
     if (bxi >= v.knn_grid) { if (outer_it == 1) rebuild_alloc(v, s, st, bxi - v.knn_grid, (int)gridDim.x - v.knn_grid); return true; }
     // streamed rebuild, bookkeeping before the first builders start (next launch): the frame count the build refers to
@@ -1160,6 +1164,7 @@ __global__ __launch_bounds__(kKnnThreads, 1) void k_knn_redo(DevView v, int s0, 
   bool same = true;
   for (int i = 0; i < 19; i++) same = same && __double_as_longlong(sh_first[i]) == __double_as_longlong(sh_ov[i]);
   if (same) return;                                              // (uniform)
+  if (st.status & (LIODOM_STATUS_PIPE_TIMEOUT | LIODOM_STATUS_LM_SYNC_TIMEOUT)) return;      // (a wait of the handle has given up: the scan has failed, nothing is repeated)
   if ((kInstrument && (v.debug & 64)) && threadIdx.x == 0) atomicAdd(&v.dbg_clk[273], 1ull);      // (debug) workgroups repeated
   OV_STAMP(v, threadIdx.x == 0, 21);
   // (chain mode: the first pass saved its queries and fifth distances but not its candidates — the overlapped pass collects its own —:

@@ -164,6 +164,7 @@ __device__ __forceinline__ void lm_eval(const DevView& v, int s, int outer_it, i
 __device__ void hash_clear_used(const DevView& v, int s /*table: stream + parity * n_streams*/, int nup, int t, int nt) {
   CellSlot empty; empty.key = kEmptyKey; empty.start = 0; empty.cnt = 0;
   const int* used = v.used_cells + (size_t)s * v.used_cap;
+  if (nup > v.used_cap) nup = v.used_cap;      // (a scan that failed half-way may have left more cells counted than listed)
   for (int u0 = t; u0 < nup; u0 += 8 * nt) {   // 8 index loads in flight per thread
     int hh[8];
 #pragma unroll
@@ -451,7 +452,7 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
   else if (threadIdx.x < 7) sh_x0[threadIdx.x] = st.param_t[threadIdx.x - 4];
   else if (threadIdx.x >= 64 && threadIdx.x < 76) sh_prev[threadIdx.x - 64] = st.prev_odom[threadIdx.x - 64];
   else if (threadIdx.x == 76) sh_fc = st.frame_count;
-  __shared__ int sh_spec_at;           // speculative hand-over: the evaluation before which the iterate leaves (0: none)
+  __shared__ int sh_spec_at;           // speculative hand-over: solves of this kind still to sit out after one that was not confirmed
   if (threadIdx.x == 77) sh_spec_at = st.spec_eval[outer_it];
   extern __shared__ __attribute__((aligned(16))) int sh_idx[];   // [edge_cap] compacted correspondence indices, then the reduction matrix
   double* sh_part = reinterpret_cast<double*>(sh_idx + ((v.edge_cap + 3) & ~3));   // [kAccN][kLmEvalThreads]
@@ -581,10 +582,10 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
   int dbg_it = 0;
   int pi = 0, ci = -1, nmoved = 0;     // (controller lane) candidate / iterate buffer, moves of the iterate
   const unsigned int n_eval0 = n_eval;       // evaluations of this launch before the loop (lock-step batches: the one at the start point)
-  const bool spec_ok = v.speculate != 0 && g == 0 && seq != 0u && outer_it == 0;
+  const bool spec_ok = v.speculate != 0 && v.speculate != 5 && g == 0 && seq != 0u && outer_it == 0;      // (4 / 5, debugging: only the first / only the finalising solve)
   // ... and of the finalising solve's, in chain mode: to the workgroups that append the new frame (the pose) and to the next scan's
   // first kNN pass, which follows them on their stream (the prediction formed from it)
-  const bool spec_ok1 = v.speculate != 0 && g == 0 && chain != 0 && outer_it == 1 && v.early_rebuild && v.pred_xch != nullptr;
+  const bool spec_ok1 = v.speculate != 0 && v.speculate != 4 && g == 0 && chain != 0 && outer_it == 1 && v.early_rebuild && v.pred_xch != nullptr;
   bool spec_done = false;
   int spec_moves = -1;
   for (int step = 0;; step++) {
@@ -630,7 +631,7 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
     // speculative hand-over (kernels_sync.h): the iterate leaves for the waiting second pass before the evaluation that — going by
     // the previous scan — will end this solve without moving it
     if ((spec_ok || spec_ok1) && !spec_done && sh_ci >= 0 &&
-        (v.speculate == 2 || (v.speculate == 3 && (int)(n_eval - n_eval0) + 1 == sh_spec_at) || (v.speculate == 1 && lm.model_cost_change <= v.spec_theta * 1e-6 * lm.cost))) {
+        (v.speculate == 2 || (v.speculate != 2 && sh_spec_at == 0 && lm.model_cost_change <= v.spec_theta * 1e-6 * lm.cost))) {
       if (spec_ok) {
         ov_publish_pose(v, s, sh_pose2[sh_ci], &lm.q[0], seq, tid, 1);
         OV_STAMP(v, tid == 0, 19);
@@ -691,9 +692,11 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
       for (int k = 0; k < 3; k++) st.param_t[k] = sh_ov[16 + k];
       for (int k = 0; k < 12; k++) st.odom[k] = sh_ov[k];
     }
-    // history for the next scan's speculative hand-over: the evaluation (counted within the launch's trust-region loop) that ended
-    // this solve without moving the iterate
-    st.spec_eval[outer_it] = (sh_unapplied && sh_ci >= 0) ? (int)(n_eval - n_eval0) : 0;
+    // speculative hand-over, back-off: a hand-over that was not confirmed costs the receivers a repeated pass (10-25 us); where
+    // the model's prediction fails once it tends to fail again (the first scans of a young window converge more slowly): the next
+    // kSpecBackoff solves of this kind hand nothing over early
+    constexpr int kSpecBackoff = 16;
+    st.spec_eval[outer_it] = (spec_done && sh_nmoved != spec_moves) ? kSpecBackoff : (sh_spec_at > 0 ? sh_spec_at - 1 : 0);
     liodom_lm_trace_t& tr = st.info.lm[outer_it];
     tr.iterations = lm.iter; tr.accepted = lm.accepted; tr.termination = lm.termination; tr.pad = 0;
     tr.initial_cost = lm.initial_cost; tr.final_cost = lm.cost;

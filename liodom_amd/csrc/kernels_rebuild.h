@@ -53,7 +53,8 @@ __device__ __forceinline__ void hash_count_point(const DevView& v, int s, int pa
       int base = 0;
       if (lane == (int)__builtin_ctzll(cm)) base = atomicAdd(&st.n_used_tab[par], (int)__popcll(cm));
       base = __shfl(base, (int)__builtin_ctzll(cm));
-      if (created) v.used_cells[(size_t)sp * v.used_cap + base + (int)__popcll(cm & ((1ull << lane) - 1ull))] = (int)h;
+      const int slot_u = base + (int)__popcll(cm & ((1ull << lane) - 1ull));
+      if (created) { if (slot_u < v.used_cap) v.used_cells[(size_t)sp * v.used_cap + slot_u] = (int)h; else atomicOr(&st.status, LIODOM_STATUS_HASH_FULL); }
     }
   }
   if (!live) return;
@@ -239,7 +240,8 @@ __device__ __forceinline__ void rebuild_count_and_pad(const DevView& v, int s, S
       int base = 0;
       if (lane == (int)__builtin_ctzll(cm)) base = atomicAdd(&st.n_used_tab[par], (int)__popcll(cm));
       base = __shfl(base, (int)__builtin_ctzll(cm));
-      if (created) v.used_cells[(size_t)sp * v.used_cap + base + (int)__popcll(cm & ((1ull << lane) - 1ull))] = (int)h;
+      const int slot_u = base + (int)__popcll(cm & ((1ull << lane) - 1ull));
+      if (created) { if (slot_u < v.used_cap) v.used_cells[(size_t)sp * v.used_cap + slot_u] = (int)h; else atomicOr(&st.status, LIODOM_STATUS_HASH_FULL); }      // (never past the list's end, whatever state a failed scan left)
     }
   }
 }
@@ -250,7 +252,7 @@ __device__ __forceinline__ void rebuild_count_and_pad(const DevView& v, int s, S
 // only contiguity per cell matters), room = points counted + places padded; cell_pad becomes the end of the range.
 __device__ __forceinline__ void rebuild_alloc(const DevView& v, int s, StreamState& st, int block, int nblocks) {
   const int par = (st.reb_frame_count + 1) & 1, sp = s + par * v.n_streams;
-  const int nu = st.n_used_tab[par];
+  const int nu = min(st.n_used_tab[par], v.used_cap);      // (bounded: see hash_clear_used)
   const int nt = blockDim.x;
   for (int u0 = block * nt; u0 < nu; u0 += nblocks * nt) {
     const int u = u0 + (int)threadIdx.x;
@@ -533,12 +535,15 @@ __global__ __launch_bounds__(kKnnThreads, 1) void k_chain_redo0(DevView v, int s
   StreamState& st = v.state[s];
   // (with_pass: the launch's last workgroup is the gate in front of the overlapped second pass — k_ov_gate: the pass's launch, next on
   //  this stream, must not start before the first solve's workgroups are on their CUs; one launch less per scan for the host)
-  if (with_pass && (int)blockIdx.x == (int)gridDim.x - 1) {
+  if (with_pass == 1 && (int)blockIdx.x == (int)gridDim.x - 1) {      // (with_pass 2, debugging: the gate is a launch of its own)
     (void)pipe_wait(v.ov_flags + s, seq, &st.status);
     return;
   }
   const int bx = (int)blockIdx.x;
   if (pred_verdict_wait(v, s, bx % kOvReplicas, (unsigned int)scan_no, &st.status) != 2) return;
+  // (a wait of the handle has given up — beside a saturating second process the appenders may have stopped waiting for the pose before
+  //  it came: there may be nothing to take back; the scan has failed through the status bit and the host resets the handle)
+  if (st.status & (LIODOM_STATUS_PIPE_TIMEOUT | LIODOM_STATUS_LM_SYNC_TIMEOUT)) return;
   if ((kInstrument && (v.debug & 64)) && threadIdx.x == 0) atomicAdd(&v.dbg_clk[274], 1ull);      // (debug) workgroups of the repair
   if (bx < nA) {
     __shared__ int sh_cnt[kMaxFrames + 1];

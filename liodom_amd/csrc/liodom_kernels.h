@@ -93,8 +93,8 @@ struct StreamState {
   int32_t n_ovf[2];       // early_rebuild: new-frame points kept in the overflow list of table 0 / 1 (sorted_pts[ovf_base ...])
   int32_t reb_initialized; // early_rebuild: `initialized` as of the scan's first kNN pass (the finalising solve sets it beside the builders)
   int32_t reb_pad;        // chain mode: the scan's edge count as PAD saw it (APPEND iterates over it, see edges_keep)
-  int32_t spec_eval[2];   // speculative hand-over (kernels_sync.h): the evaluation at which the previous scan's first / finalising solve ended without
-                          // applying its step (0: it ended otherwise)
+  int32_t spec_eval[2];   // speculative hand-over (kernels_sync.h), back-off: first / finalising solves still to sit out after a hand-over that was
+                          // not confirmed
   double pred_odom[2][12]; // early_rebuild: the prediction the scan started from ([frames appended so far & 1]: the repair of a speculative hand-over
                           // that was not confirmed, kernels_sync.h, needs the previous scan's while the next scan's is already there),
                           // snapshot taken by the scan's first kNN launch: st.odom moves
@@ -220,7 +220,7 @@ struct DevView {
   // launched on its own HIP stream beside the scan's first solve and waits inside the kernel; tags = the launch sequence number.
   unsigned int* ov_flags;          // [S] sequence number of the latest scan whose first solve launch has started (its first kNN pass has completed)
   double spec_theta;               // ... by the model: the iterate leaves before an evaluation whose predicted cost change is below spec_theta x the function tolerance
-  int speculate;                   // speculative hand-over of the first solve's result (kernels_sync.h): 0 off, 1 by history, 2 (test) as early as possible
+  int speculate;                   // speculative hand-over of the first solve's result (kernels_sync.h): 0 off, 1 by the model's predicted cost change, 2 (test) as early as possible
   unsigned long long* pose_xch0;   // [S][kOvReplicas][512] the first solve's result (odom[12], q[4], t[3]) as 38 tagged granules, replicated over memory channels; granules 64 .. 101: the confirmation copy
   unsigned int* knn_done;          // [S][knn_grid] sequence number of the latest overlapped second pass workgroup b has completed
   // Chain mode (round 5; "Chain mode" in kernels_sync.h): the kNN passes and the rebuild ride on ONE HIP stream (kNN(0), gate, COUNT/PAD,

@@ -385,19 +385,17 @@ def test_cxx_two_thread_replay_equals_resident_replay(synth):
     g.close()
 
 
-@pytest.mark.parametrize("hog", ["spin", "matmul"])
-def test_second_process_saturating_the_gpu_never_gives_a_wrong_pose(hog):
-    """tools/soak_two_process.py: a replay with every in-kernel wait active (pipe flags, overlapped second kNN pass, in-launch
-    exchanges) while a SECOND PROCESS keeps every CU busy.  Either bit-identical to the solo run, or a clean LIODOM_ERR_HIP and —
-    after liodom_reset(), which enters the safe mode (no in-kernel waits) — bit-identical to a solo safe-mode run."""
+@pytest.mark.parametrize("shape,scans,distinct,hog", [("vlp16", 10000, 150, "spin"), ("vlp16", 10000, 150, "matmul"), ("hdl64", 3000, 200, "matmul")])
+def test_second_process_saturating_the_gpu_never_gives_a_wrong_pose(shape, scans, distinct, hog):
+    """tools/soak_two_process.py: a replay with every in-kernel wait active (pipe flags, chain mode, speculative hand-overs, in-launch
+    exchanges) while a SECOND PROCESS keeps every CU busy (tools/gpu_hog.hip: bandwidth-bound kernels / 10 ms compute-bound ones).
+    Either bit-identical to the solo run, or a clean LIODOM_ERR_HIP and — after liodom_reset(), which enters the safe mode (no
+    in-kernel waits) — bit-identical to a solo safe-mode run.  The 64-ring shape beside the compute-bound hog is the one where waits
+    really give up: it found the first pass skipping the rebuild's bookkeeping when its own wait had given up (GPU memory fault)."""
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    try:
-        import torch  # noqa: F401  (the second process uses it to load the GPU)
-    except Exception:
-        pytest.skip("torch not importable: no second process to load the GPU with")
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_two_process.py"), "vlp16", "10000", "150", hog],
-                       capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_two_process.py"), shape, str(scans), str(distinct), hog],
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, SOAK_BUDGET_S="12"))
     tail = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ""
     assert r.returncode == 0, (tail, r.stderr[-1500:])
     assert "bit-identical" in tail
@@ -445,3 +443,15 @@ def test_chain_mode_hammer_small_shape():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "chain_hammer.py"), "25", "16x900"], capture_output=True, text=True, timeout=600)
     tail = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ""
     assert r.returncode == 0 and "'resident': 0, 'two_thread': 0, 'percall': 0" in tail, (r.stdout[-1500:], r.stderr[-1500:])
+
+
+@pytest.mark.parametrize("shape,scans", [("hdl64", 240), ("16x900", 400)])
+def test_speculative_hand_over_survives_mode_switches(shape, scans):
+    """tools/spec_switches.py: the speculative hand-over of the solves' results (kernels_sync.h) with the predictor forced wrong — every
+    second pass, every APPEND and every first pass is repaired — across switches into and out of chain mode (per-kernel profiling,
+    per-call pipelined path, synchronisations, getters: the repair the host enqueues on its own, chain_flush), and with the model
+    predictor: the pose log of a straight replay without speculation, bit for bit."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "spec_switches.py"), shape, str(scans)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "bit-identical" in r.stdout, (r.stdout[-800:], r.stderr[-1500:])

@@ -12,27 +12,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-if len(sys.argv) > 1 and sys.argv[1] == "--hog":
-    # the second process: keeps every CU busy until the stop file appears
-    import torch
-    kind, stop = sys.argv[2], sys.argv[3]
-    dev = torch.device("cuda:0")
-    a = torch.randn(8192, 8192, device=dev, dtype=torch.float32)
-    b = torch.randn(8192, 8192, device=dev, dtype=torch.float32)
-    x = torch.randn(64 * 1024 * 1024, device=dev)
-    open(stop + ".ready", "w").write("1")
-    n = 0
-    while not os.path.exists(stop):
-        if kind == "matmul":
-            for _ in range(8):
-                a = (a @ b).clamp_(-1, 1)
-        else:
-            for _ in range(32):
-                x = x * 1.0001 + 0.5          # bandwidth-bound elementwise kernels, every CU
-        torch.cuda.synchronize()
-        n += 1
-    print("hog iterations", n)
-    sys.exit(0)
+HOG = os.path.join(ROOT, "build", "gpu_hog")          # tools/gpu_hog.hip, built by __graft_entry__.build() (no torch: its first import on a fresh box takes minutes)
+if not os.path.exists(HOG):
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-o", HOG, os.path.join(ROOT, "tools", "gpu_hog.hip")])
 
 import liodom_amd as la
 from liodom_amd import synth
@@ -76,6 +58,8 @@ def replay(g, label, budget=None):
             i = k % len(order)
             if i < D - 1:
                 n = min(D - i, K - k)
+                if budget is not None:
+                    n = min(n, 40)          # (beside the second process a scan can take tens of milliseconds: look at the clock often)
                 poses, infos = g.replay_resident(order[i], n, N, H, W, depth=1)
                 st = 0
                 for inf in infos:
@@ -117,7 +101,12 @@ stop = "/tmp/liodom_soak_stop_%d" % os.getpid()
 for f in (stop, stop + ".ready"):
     if os.path.exists(f):
         os.remove(f)
-hog = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--hog", hog_kind, stop], stdout=subprocess.PIPE, text=True)
+def _die_with_parent():
+    import ctypes
+    ctypes.CDLL("libc.so.6").prctl(1, 9)      # PR_SET_PDEATHSIG = SIGKILL: the hog must not outlive a killed soak (it would keep the GPU busy — and inherited pipes open — for ever)
+
+
+hog = subprocess.Popen([HOG, hog_kind, stop], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, preexec_fn=_die_with_parent)
 t_wait = time.time()
 while not os.path.exists(stop + ".ready") and time.time() - t_wait < 180:
     time.sleep(0.2)
