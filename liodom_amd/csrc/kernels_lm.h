@@ -250,6 +250,7 @@ __device__ __forceinline__ void finalize_scan(const DevView& v, int s, StreamSta
       ho->pose[0] = q[0]; ho->pose[1] = q[1]; ho->pose[2] = q[2]; ho->pose[3] = q[3];
       ho->pose[4] = fin[3]; ho->pose[5] = fin[7]; ho->pose[6] = fin[11];
       ho->info = st.info;
+      ho->pad = (int)verdict;      // (speculative hand-over: 1 = confirmed, the host then skips the repair launch when it synchronises)
       // (the system-scope release orders this thread's payload stores before the sequence word: no separate fence)
       __hip_atomic_store(&ho->seq, k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }

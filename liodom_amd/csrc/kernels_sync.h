@@ -50,7 +50,8 @@ __global__ void k_pipe_gate(DevView v, int s0, int eb, unsigned int wait_edges, 
 // =============================================================================================
 // Chain mode (round 5; one-stream handles with the streamed rebuild and flags, scans whose edges arrive by flag from the
 // extraction stream — the pipelined replay and the ticket API).  The scan's launches are split over two HIP streams by ROLE:
-//   stream_k:  kNN(0) | gate | kNN(1) + COUNT + PAD | ALLOC | APPEND + CLEAR + SCATTER            (light kernels)
+//   stream_k:  kNN(0) | gate | kNN(1) + COUNT + PAD | ALLOC | APPEND + CLEAR + SCATTER            (light kernels; with the speculative
+//              hand-overs below the gate is the last workgroup of k_chain_redo0 and ALLOC the first workgroups of k_knn_redo)
 //   stream:    solve(0) | solve(1)                                                                 (the solving workgroups alone)
 // * solve(0) of scan k follows solve(1) of scan k-1 in stream order, i.e. its launch is RESIDENT while kNN(0) of scan k still runs:
 //   the pass's workgroups store their results write-through and count themselves on one word (chain_count_done), one thread per
@@ -157,14 +158,34 @@ __device__ __forceinline__ bool granules_wait(const unsigned long long* base, in
 __device__ __forceinline__ bool ov_wait_pose(const DevView& v, int s, int rep, unsigned int tag, double* out19, unsigned int* status) {
   return granules_wait<LIODOM_POLL_POSE>(v.pose_xch0 + ((size_t)s * kOvReplicas + rep) * 512, kOvGranules, tag, out19, status);
 }
-// Speculative hand-over of the first solve's result.  A solve ends with an evaluation whose step is not applied (function
-// tolerance: the cost no longer changes) practically always; the pose it ends with is then the iterate it held BEFORE that
-// evaluation.  When the previous scan's first solve ended that way at its n-th evaluation, this scan's first solve hands its
-// iterate to the waiting second pass before it runs ITS n-th evaluation (copy 0 of pose_xch0) — an evaluation, its exchange and the
-// controller's last step (~4.5 us) earlier — and always publishes what it really ended with as the confirmation copy.  Every
-// workgroup of the pass compares the two when its work is done, before it counts itself done: equal bits (the rule) -> nothing else
-// happens; different (the step was accepted after all) -> it repeats its two blocks from the confirmed pose.  Results are therefore
-// those of the non-speculative hand-over in every case; the history only decides how often the early start pays.
+// =============================================================================================
+// Speculative hand-over of a solve's result (round 5).  A solve ends, practically always, with an evaluation whose step is not applied
+// (function tolerance: the cost no longer changes); the pose it ends with is then the iterate it held BEFORE that evaluation, and
+// the evaluation, its exchange, the controller's last step and the publication (4.4-4.6 us) sit between the result and whatever
+// waits for it.  The controller can tell beforehand: the cost change its quadratic model predicts for the step it has just proposed
+// (LmState::model_cost_change) is what the evaluation will measure, to a few percent near convergence.  When that prediction is
+// below spec_theta (0.8) x the function tolerance, the solving workgroup hands its ITERATE over before the evaluation starts:
+//   first solve -> overlapped second pass: copy 0 of pose_xch0 (granules 0..37); what the solve really ended with is always
+//     published as the confirmation copy (granules 64..101).  Every workgroup of the pass compares the two when its work is done
+//     (ov_confirm_pose) and counts itself done only on equal bits; the others are repeated, from the confirmed pose, by their
+//     namesakes in k_knn_redo, the launch behind the pass.
+//   finalising solve (chain mode) -> the appending workgroups (pose_xch copy 0) and the next scan's first pass (pred_xch copy 0: the
+//     prediction formed from the iterate, by the controller's wave beside the other waves' evaluation).  finalize_scan publishes
+//     the confirmed copies and a verdict granule {tag, 1 confirmed / 2 not}.  The first pass waits for the verdict when its work
+//     is done: 1 -> it counts itself done; 2 -> it does not, and k_chain_redo0 — the launch behind it, which is also the gate in front
+//     of the second pass — takes the frame's points back out of their cells, re-appends them at the confirmed pose (append_fix)
+//     and repeats the pass from the confirmed prediction.  When no pass follows, the host enqueues the repair on its own
+//     (chain_flush in liodom_hip.hip; not when the scan's host record already says "confirmed").
+// Results are those of the non-speculative hand-over in every case (LIODOM_SPECULATE=0 / 1 / 2 = off / model / always as early as
+// possible, i.e. practically always wrong: bit-identical pose logs, tools/overlap_equal.py, tools/spec_switches.py); the predictor
+// only decides how often the early start pays.  A hand-over that was not confirmed costs the receivers a repeated pass (10-25 us):
+// it suspends the hand-overs of that solve for the next 16 scans (StreamState::spec_eval; the first scans behind a freshly filled
+// window mispredict in a row).  What the early start required elsewhere: correspondences per kNN pass (corr_a / corr_b [S][2]: a
+// pass that starts early writes while the sender's last evaluation still reads), the release of the previous scan's edge buffer
+// after the verdict instead of at the first pass's start (chain_release_edges), the scan's prediction kept per parity (pred_odom[2]:
+// the repair of scan k runs behind scan k+1's pass).  Once a wait of the handle has given up, nothing is repaired (the scan has
+// failed through its status bits; the repairs would work from state that may not have been written).
+// =============================================================================================
 // returns 1: the pose in io19 is confirmed; 2: it was not — io19 now holds the confirmed one; 0: gave up.
 __device__ __forceinline__ int ov_confirm_pose(const DevView& v, int s, int rep, unsigned int tag, double* io19, unsigned int* status) {
   typedef __attribute__((address_space(1))) unsigned long long gu64;

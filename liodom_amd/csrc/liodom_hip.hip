@@ -85,6 +85,8 @@ struct liodom_handle {
                                      // before the second pass is dispatched; LIODOM_CHAIN=0 switches it off)
   bool chain_prev = false;           // the previous scan was enqueued in chain mode
   unsigned int chain_count = 0;      // first-pass workgroups launched in chain mode since the last reset (what knn_done0 counts up to)
+  int verdict_scan = -1;             // scans completed when the host last collected stream 0's pose, and whether that scan's speculative
+  bool verdict_confirmed = false;    // hand-over was confirmed (HostOut::pad, written by finalize_scan)
   bool chain_fix_pending = false;    // the last chain-mode scan's APPEND may need the repair of k_chain_redo0 (speculative hand-over)
   bool chain_used = false;           // any scan was: the odometry side's results are complete when stream AND stream_k have drained
   hipEvent_t ev_ch = nullptr;        // at a switch out of chain mode: the odometry stream waits for stream_k
@@ -182,6 +184,9 @@ int dev_alloc(liodom_handle* h, T** p, size_t count, int memset_value = 0) {
 void chain_flush(liodom_handle* h) {
   if (!h->chain_fix_pending) return;
   h->chain_fix_pending = false;
+  // (the last chain-mode scan's pose has been collected and its record says "confirmed": nothing to repair, no launch — the usual
+  //  case when the host synchronises after a replay)
+  if (h->verdict_scan == h->scans_enqueued[0] && h->verdict_confirmed) return;
   const int nA = (h->v.edge_cap + 255) / 256;
   hipLaunchKernelGGL(k_chain_redo0<256>, dim3(nA, 1), dim3(256), 0, h->stream_k, h->v, 0, 0, 0u, 0u, 0u, h->scans_enqueued[0], nA, 0, 1);
 }
@@ -358,7 +363,8 @@ int enqueue_odometry(liodom_handle* h, int eb, int s0, int count, unsigned int w
     const unsigned int done_target = h->chain_count;
     const int gx = (h->v.lm_groups - 1) * 8 + 1;                       // solvers on blocks 0, 8, 16, ... (one XCD); nothing else in the launch
     const size_t lds = lm_lds_bytes(h->v.edge_cap);
-    // stream_k: first pass | gate (first solve's launch has started) | second pass + COUNT + PAD | ALLOC | APPEND + CLEAR + SCATTER
+    // stream_k: first pass | gate (first solve's launch has started; + repair of the previous scan's hand-over: k_chain_redo0) | second pass + COUNT + PAD |
+    //           ALLOC (+ repeat of unconfirmed second-pass workgroups: k_knn_redo) | APPEND + CLEAR + SCATTER
     // stream:   first solve (resident beside the first pass: waits for its done flags) | finalising solve (waits for the second pass's)
     const int nCP = cdiv(h->v.edge_cap * std::max(1, h->P - 1), 256) + cdiv(h->v.edge_cap, 256);      // COUNT + PAD workgroups of 256 threads
     hipLaunchKernelGGL((k_knn<256, false, true>), dim3(v.knn_grid, 1), dim3(256), 0, h->stream_k, v, s0, 0, eb, wait_edges, signal_odo, seq_k, scan_no);
@@ -636,7 +642,7 @@ int reset_state(liodom_handle* h) {
   HIP_TRY(hipMemsetAsync(h->v.redo_sync, 0, sizeof(unsigned int) * 64, h->stream));
   if (h->v.pred_xch) HIP_TRY(hipMemsetAsync(h->v.pred_xch, 0, sizeof(unsigned long long) * (size_t)h->S * kOvReplicas * 512, h->stream));
   HIP_TRY(hipMemsetAsync(h->v.knn_done0, 0, sizeof(unsigned int) * ((size_t)h->S + 64), h->stream));
-  h->chain_prev = false; h->chain_count = 0; h->chain_fix_pending = false; h->replay_enq_ns = 0.0; h->replay_wait_ns = 0.0; h->replay_timed = 0;
+  h->chain_prev = false; h->chain_count = 0; h->chain_fix_pending = false; h->verdict_scan = -1; h->replay_enq_ns = 0.0; h->replay_wait_ns = 0.0; h->replay_timed = 0;
   std::memset(h->host_out, 0, sizeof(HostOut) * 2 * (size_t)h->S);
   std::fill(h->scans_enqueued.begin(), h->scans_enqueued.end(), 0);
   HIP_TRY(hipMemsetAsync(h->v.win_n, 0, sizeof(int) * (size_t)h->S * h->P, h->stream));
@@ -1147,6 +1153,8 @@ static int wait_pose(liodom_handle_t* h, int s0, int count, double* pose_out, li
     if (pose_out) std::memcpy(pose_out + 7 * i, r->pose, sizeof(double) * 7);
     if (info) info[i] = r->info;
     if (r->info.status & (LIODOM_STATUS_PIPE_TIMEOUT | LIODOM_STATUS_LM_SYNC_TIMEOUT)) timed_out = true;
+    // (speculative hand-over: the record carries the scan's verdict — a confirmed scan needs no repair, chain_flush)
+    if (s0 + i == 0) { h->verdict_scan = expect; h->verdict_confirmed = r->pad == 1; }
   }
   if (timed_out) {
     // A kernel gave up waiting for another HIP stream of the handle (pipe_wait / ov_wait_*): its workgroups skipped the scan, the
