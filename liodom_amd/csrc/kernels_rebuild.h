@@ -535,7 +535,7 @@ __global__ __launch_bounds__(kKnnThreads, 1) void k_chain_redo0(DevView v, int s
   StreamState& st = v.state[s];
   // (with_pass: the launch's last workgroup is the gate in front of the overlapped second pass — k_ov_gate: the pass's launch, next on
   //  this stream, must not start before the first solve's workgroups are on their CUs; one launch less per scan for the host)
-  if (with_pass == 1 && (int)blockIdx.x == (int)gridDim.x - 1) {      // (with_pass 2, debugging: the gate is a launch of its own)
+  if (with_pass && (int)blockIdx.x == (int)gridDim.x - 1) {
     (void)pipe_wait(v.ov_flags + s, seq, &st.status);
     return;
   }

@@ -371,18 +371,16 @@ int enqueue_odometry(liodom_handle* h, int eb, int s0, int count, unsigned int w
     if (v.speculate) {      // (speculative hand-over of the previous scan's result not confirmed: rare)
       const int nA = cdiv(h->v.edge_cap, 256);
       // (+ 1: the gate in front of the second pass, k_ov_gate's job otherwise)
-      static const bool fold = !(std::getenv("LIODOM_SPEC_FOLD") && std::atoi(std::getenv("LIODOM_SPEC_FOLD")) == 0);      // (debugging: 0 = gate and ALLOC as launches of their own)
-      hipLaunchKernelGGL(k_chain_redo0<256>, dim3(nA + v.knn_grid + (fold ? 1 : 0), 1), dim3(256), 0, h->stream_k, v, s0, eb, wait_edges, signal_odo, seq_k, scan_no, nA, fold ? 1 : 2, h->chain_fix_pending ? 1 : 0);
+      hipLaunchKernelGGL(k_chain_redo0<256>, dim3(nA + v.knn_grid + 1, 1), dim3(256), 0, h->stream_k, v, s0, eb, wait_edges, signal_odo, seq_k, scan_no, nA, 1, h->chain_fix_pending ? 1 : 0);
     }
     h->chain_fix_pending = v.speculate != 0;
     hipLaunchKernelGGL(k_lm_solve<0>, dim3(gx, 1), dim3(kLmThreads), lds, h->stream, v, s0, eb, seq_k, 1, done_target);
-    static const bool fold2 = !(std::getenv("LIODOM_SPEC_FOLD") && std::atoi(std::getenv("LIODOM_SPEC_FOLD")) == 0);
-    if (!v.speculate || !fold2) hipLaunchKernelGGL(k_ov_gate, dim3(1), dim3(64), 0, h->stream_k, v, s0, seq_k);
+    if (!v.speculate) hipLaunchKernelGGL(k_ov_gate, dim3(1), dim3(64), 0, h->stream_k, v, s0, seq_k);
     hipLaunchKernelGGL((k_knn<256, true>), dim3(v.knn_grid + nCP, 1), dim3(256), 0, h->stream_k, v, s0, 1, eb, 0u, 0u, seq_k, scan_no);
     // (speculative hand-over not confirmed — rare —: the pass's workgroups once more; the launch's first workgroups are ALLOC)
-    if (v.speculate) hipLaunchKernelGGL(k_knn_redo<256>, dim3((fold2 ? kRebuildAllocBlocks : 0) + v.knn_grid, 1), dim3(256), 0, h->stream_k, v, s0, eb, seq_k, scan_no, fold2 ? kRebuildAllocBlocks : 0);
+    if (v.speculate) hipLaunchKernelGGL(k_knn_redo<256>, dim3(kRebuildAllocBlocks + v.knn_grid, 1), dim3(256), 0, h->stream_k, v, s0, eb, seq_k, scan_no, kRebuildAllocBlocks);
     hipLaunchKernelGGL(k_lm_solve<1>, dim3(gx, 1), dim3(kLmThreads), lds, h->stream, v, s0, eb, seq_k, 1, done_target);
-    if (!v.speculate || !fold2) hipLaunchKernelGGL(k_rebuild_alloc, dim3(kRebuildAllocBlocks, 1), dim3(256), 0, h->stream_k, v, s0);
+    if (!v.speculate) hipLaunchKernelGGL(k_rebuild_alloc, dim3(kRebuildAllocBlocks, 1), dim3(256), 0, h->stream_k, v, s0);
     hipLaunchKernelGGL(k_rebuild_fin, dim3(nP + kRebuildAuxBlocks + nC, 1), dim3(kLmThreads), 0, h->stream_k, v, s0, eb);
     HIP_TRY(hipGetLastError());
     return LIODOM_OK;
