@@ -3,6 +3,10 @@ steady-state period, the intercept what the region pays once (pipeline fill, dra
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+if os.environ.get("REGION_LIB"):          # a variant built by tools/variant_build.sh instead of the product library
+    import liodom_amd.api as _api
+    _api._LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build", "variants", "lib%s.so" % os.environ["REGION_LIB"])
+    _api.is_stale = lambda: False
 import liodom_amd as la
 from liodom_amd import synth
 H, W, lt, R, epr, P = 64, 1800, 0, 8, 10, 20
