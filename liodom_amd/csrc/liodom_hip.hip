@@ -1016,8 +1016,10 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
     h->chain_ok = v.early_rebuild && S == 1 && v.knn_partials && !v.use_imu && (long long)v.knn_grid * 4 * 2 <= (long long)cus * 24;
     if (const char* e = std::getenv("LIODOM_KNN_OVERLAP")) { if (std::atoi(e) == 0) h->chain_ok = false; }
     if (const char* e = std::getenv("LIODOM_CHAIN")) { if (std::atoi(e) == 0) h->chain_ok = false; }
-    // speculative hand-over of the first solve's result to the overlapped second pass (kernels_sync.h): LIODOM_SPECULATE=0 off,
-    // 2 (tests): as early as possible, i.e. practically always wrong — the pass then repeats its blocks from the confirmed pose
+    // speculative hand-over of the solves' results (kernels_sync.h): LIODOM_SPECULATE=0 off, 1 by the model's predicted cost change
+    // (default), 2 (tests): as early as possible, i.e. practically always wrong — every receiver is then repeated from the confirmed
+    // result; 4 / 5 (debugging): only the first / only the finalising solve's hand-over.  LIODOM_SPEC_THETA: the predictor's threshold
+    // (fraction of the function tolerance, default 0.8)
     v.speculate = (h->ov_ok || h->chain_ok) ? 1 : 0;
     if (const char* e = std::getenv("LIODOM_SPECULATE")) { if (v.speculate) v.speculate = std::max(0, std::min(5, std::atoi(e))); }
     v.spec_theta = 0.8;
