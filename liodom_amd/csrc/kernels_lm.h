@@ -695,9 +695,8 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
     }
     // speculative hand-over, back-off: a hand-over that was not confirmed costs the receivers a repeated pass (10-25 us); where
     // the model's prediction fails once it tends to fail again (the first scans of a young window converge more slowly): the next
-    // kSpecBackoff solves of this kind hand nothing over early
-    constexpr int kSpecBackoff = 16;
-    st.spec_eval[outer_it] = (spec_done && sh_nmoved != spec_moves) ? kSpecBackoff : (sh_spec_at > 0 ? sh_spec_at - 1 : 0);
+    // spec_backoff (16) solves of this kind hand nothing over early
+    st.spec_eval[outer_it] = (spec_done && sh_nmoved != spec_moves) ? v.spec_backoff : (sh_spec_at > 0 ? sh_spec_at - 1 : 0);
     liodom_lm_trace_t& tr = st.info.lm[outer_it];
     tr.iterations = lm.iter; tr.accepted = lm.accepted; tr.termination = lm.termination; tr.pad = 0;
     tr.initial_cost = lm.initial_cost; tr.final_cost = lm.cost;

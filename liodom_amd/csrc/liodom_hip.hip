@@ -1022,6 +1022,8 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
     // (fraction of the function tolerance, default 0.8)
     v.speculate = (h->ov_ok || h->chain_ok) ? 1 : 0;
     if (const char* e = std::getenv("LIODOM_SPECULATE")) { if (v.speculate) v.speculate = std::max(0, std::min(5, std::atoi(e))); }
+    v.spec_backoff = 16;
+    if (const char* e = std::getenv("LIODOM_SPEC_BACKOFF")) v.spec_backoff = std::max(0, std::atoi(e));
     v.spec_theta = 0.8;
     if (const char* e = std::getenv("LIODOM_SPEC_THETA")) v.spec_theta = std::atof(e);
     if ((h->ov_ok || h->chain_ok) && make_stream(&h->stream_k, prio_greatest) != hipSuccess) { g_last_error = "hipStreamCreate failed"; return fail(LIODOM_ERR_HIP); }

@@ -220,6 +220,7 @@ struct DevView {
   // launched on its own HIP stream beside the scan's first solve and waits inside the kernel; tags = the launch sequence number.
   unsigned int* ov_flags;          // [S] sequence number of the latest scan whose first solve launch has started (its first kNN pass has completed)
   double spec_theta;               // ... by the model: the iterate leaves before an evaluation whose predicted cost change is below spec_theta x the function tolerance
+  int spec_backoff;                // ... scans a solve sits out after a hand-over of its own that was not confirmed
   int speculate;                   // speculative hand-over of the first solve's result (kernels_sync.h): 0 off, 1 by the model's predicted cost change, 2 (test) as early as possible
   unsigned long long* pose_xch0;   // [S][kOvReplicas][512] the first solve's result (odom[12], q[4], t[3]) as 38 tagged granules, replicated over memory channels; granules 64 .. 101: the confirmation copy
   unsigned int* knn_done;          // [S][knn_grid] sequence number of the latest overlapped second pass workgroup b has completed
