@@ -13,6 +13,15 @@
 //   every workgroup; beside its first step waves 0..6 compact the accepted correspondences and cache their triples in registers.
 //   finalize (second outer iteration, or the very first frame; workgroup 0): pose log + host-mapped record, constant-velocity
 //   prediction for the next scan, window bookkeeping, and the solved pose handed to the rebuild workgroups that append the frame.
+//   Two instances, k_lm_solve<0> (first solve of a scan) and <1> (finalising solve): one kernel with a run-time outer iteration
+//   spilled more with every addition to either side.  What a launch would otherwise fetch between the kNN pass it waits for and its
+//   first step — start point, previous pose, frame count — is prefetched into LDS while it waits; the solved pose leaves straight
+//   from LDS when the loop ends, before any bookkeeping.
+//   Speculative hand-over (kernels_sync.h): the candidate's and the iterate's matrices live in two LDS buffers that swap roles when a
+//   step is accepted; before an evaluation whose predicted cost change is below spec_theta x the function tolerance workgroup 0 hands
+//   the ITERATE to whoever waits for the solve's result (first solve: the overlapped second pass; finalising solve in chain mode:
+//   the appenders and — as the prediction formed from it by the controller's wave — the next scan's first pass), and publishes the
+//   confirmation (copy / verdict) when the solve has ended.
 // =============================================================================================
 // Indices of the edges with an accepted correspondence, in edge order (deterministic), built once
 // per solve in LDS so that every evaluation runs over C dense items instead of E sparse ones.
