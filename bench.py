@@ -231,6 +231,22 @@ def main():
     ap.add_argument("--parity-scans", type=int, default=0, help="scans compared with the oracle per replica (0 = prefill + warm-up + min(steps, 100))")
     args = ap.parse_args()
 
+    # The process that drives the GPU on ONE core, from before the HIP runtime starts its own threads (they inherit the mask) — what
+    # `taskset -c <core> python bench.py` does.  Measured on the 2 x 64-core host of the MI355X boxes (tools/replay_trace.py,
+    # PIN_CPUS): the host needs 26 us to enqueue the launches of one chain-mode scan that way, 42 us when the scheduler may move the
+    # threads within the GPU's NUMA node and 54 us within the other node — against a scan period of 70 us: 14.4k scans/s instead of
+    # 13.0-13.9k depending on where the process happened to land.  The two-thread leg and the CPU baselines get the full mask
+    # back.  LIODOM_BENCH_PIN=0: no pinning beyond the GPU's NUMA node.
+    orig_affinity = os.sched_getaffinity(0)
+    pin_core = None
+    if os.environ.get("LIODOM_BENCH_PIN", "1") != "0":
+        try:
+            base = sorted(orig_affinity)
+            pin_core = base[(8 * int(os.environ.get("LOCAL_RANK", "0"))) % len(base)]
+            os.sched_setaffinity(0, {pin_core})
+        except Exception:
+            pin_core = None
+
     # The HIP library is loaded before torch so that libamdhip64 resolves to /opt/rocm's copy.
     import liodom_amd as la
     from liodom_amd import synth
@@ -251,8 +267,8 @@ def main():
         # processes that share a GPU cannot see each other's handles: the in-kernel waits of the overlapped second kNN pass
         # are meant for a GPU one handle has to itself (the library switches it off for a second handle in ONE process)
         os.environ.setdefault("LIODOM_KNN_OVERLAP", "0")
-    orig_affinity = os.sched_getaffinity(0)
-    rep.pin_cpus(local_rank)                 # host thread near the GPU's NUMA node (busy-polls the result record)
+    if pin_core is None:
+        rep.pin_cpus(local_rank)             # host thread near the GPU's NUMA node (busy-polls the result record)
 
     wl = WORKLOADS[args.workload]
     H, W, R, epr, P = wl["H"], wl["W"], wl["R"], wl["epr"], wl["P"]
@@ -417,6 +433,11 @@ def main():
         # memory, extracts and fetches the ~edges cloud, the edge cloud itself stays on the device (ticket queue), the odometer
         # thread reads every pose back
         g.reset()
+        if pin_core is not None:                 # two busy threads from here on: the full mask again
+            try:
+                os.sched_setaffinity(0, orig_affinity)
+            except Exception:
+                pass
         nrun = F + Wm + K
         tt_poses, tt, tt_edges = g.two_thread_replay(host[:nrun, 0], N, H, W, timed_from=F + Wm, fetch_edges=True, depth=1)
         two_thread = {"scans_per_s": round(K / tt, 2), "us_per_scan": round(tt / K * 1e6, 2),
@@ -455,6 +476,9 @@ def main():
                        "mean_lm_evals_per_solve": round(mean_evals, 2), "device": dev_name, "compute_units": cus,
                        "library_source_hash": la.api.build_info().get("source_hash") or la.api.built_hash(),
                        "modes": modes,
+                       "host_affinity": ("single-threaded legs (value, strict, async, serial, host_fed, batched): this process and the HIP runtime's threads on CPU %d "
+                                         "(as `taskset -c`; LIODOM_BENCH_PIN=0: the CPU list of the GPU's NUMA node); "
+                                         "two_thread and the CPU baselines: the full mask" % pin_core) if pin_core is not None else "the GPU's NUMA node (no single core)",
                        "environment": {k: v for k, v in os.environ.items() if k.startswith("LIODOM_") or k in ("HIP_FORCE_DEV_KERNARG", "AMD_SERIALIZE_KERNEL", "HIP_LAUNCH_BLOCKING")}},
             "value_spread": {"min": round(world * K / max(kept), 2), "max": round(world * K / min(kept), 2),
                              "first_discarded": round(world * K / samples[0], 2) if len(samples) > 1 else None},
@@ -527,6 +551,11 @@ def main():
     # ---- batched leg: lock-step streams on one GPU (throughput mode; separately labelled) ----
     if rank == 0 and args.batched_streams > 0 and world == 1:
         S = args.batched_streams
+        if pin_core is not None:
+            try:
+                os.sched_setaffinity(0, {pin_core})      # (single enqueueing thread again)
+            except Exception:
+                pass
         Kb, Wb = min(K, 20), F + min(Wm, 4)      # pre-fill + a few warm-up steps, then Kb timed steps
         tb = Kb + Wb
         n_data = max(1, min(args.batched_data_streams, S))   # distinct synthetic streams; stream s replays data stream s % n_data

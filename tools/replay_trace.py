@@ -2,6 +2,12 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+if os.environ.get("PIN_CPUS"):          # e.g. PIN_CPUS=0-63 or 8: where the enqueueing thread runs (NUMA distance to the GPU shows in replay_enqueue_us)
+    cpus = set()
+    for part in os.environ["PIN_CPUS"].split(","):
+        a, _, b = part.partition("-")
+        cpus.update(range(int(a), int(b or a) + 1))
+    os.sched_setaffinity(0, cpus)
 import liodom_amd as la
 from liodom_amd import synth
 WL = {"hdl64": (64, 1800, 0, 8, 10, 20), "vlp16": (16, 1800, 0, 8, 20, 10), "ouster128": (128, 2048, 1, 8, 10, 30)}
