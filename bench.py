@@ -242,7 +242,7 @@ def main():
     if os.environ.get("LIODOM_BENCH_PIN", "1") != "0":
         try:
             base = sorted(orig_affinity)
-            pin_core = base[(8 * int(os.environ.get("LOCAL_RANK", "0"))) % len(base)]
+            pin_core = base[int(os.environ.get("LOCAL_RANK", "0")) % len(base)]      # (one core per replica)
             os.sched_setaffinity(0, {pin_core})
         except Exception:
             pin_core = None
