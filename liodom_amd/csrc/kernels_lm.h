@@ -216,7 +216,8 @@ __device__ __forceinline__ void predict_next(const double* T, const double* prev
 // chain: the rebuild of this scan runs on the other HIP stream, beside this launch (ALLOC may still be allocating cell ranges from
 // st.cursor): the cursor is then reset by the next scan's first kNN pass, which follows the rebuild in stream order.
 __device__ __forceinline__ void finalize_scan(const DevView& v, int s, StreamState& st, int* sh_cnt, int eb, bool clear_hash, int ctl, int chain,
-                              const double* T, int raw, bool publish_pose, const double* prev, int fc_old, int pred_copies = 3, unsigned int verdict = 1u) {
+                              const double* T, int raw, bool publish_pose, const double* prev, int fc_old, int pred_copies = 3, unsigned int verdict = 1u,
+                              const liodom_lm_trace_t* trace1 = nullptr) {
   __shared__ double sh_pred[19];      // the prediction: matrix [12], quaternion [4], translation [3]
   const int P = v.prev_frames;
   const int tid = threadIdx.x;
@@ -246,6 +247,9 @@ __device__ __forceinline__ void finalize_scan(const DevView& v, int s, StreamSta
     const int k = st.scan_counter;
     st.info.scan_index = k;
     st.info.status = st.status;
+    // trace1 (LDS): the finalising solve's trace.  The controller's thread wrote it before the barrier this call follows — as stores
+    // to st.info by that thread, issued just before the call, they raced with the copies below
+    if (trace1) st.info.lm[1] = *trace1;
     if (k < v.pose_log_cap) {
       double* pl = v.pose_log + ((size_t)s * v.pose_log_cap + k) * 7;
       pl[0] = q[0]; pl[1] = q[1]; pl[2] = q[2]; pl[3] = q[3];
@@ -673,7 +677,12 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
   // translation) or to the workgroups that append the new frame (finalising solve: the matrix) — straight from LDS; the stream's
   // state, the trace and the scan's bookkeeping follow.
   __shared__ double sh_ov[20];
+  __shared__ liodom_lm_trace_t sh_trace;      // the solve's trace, from the controller's thread to whoever records it (finalize_scan: thread 64)
   {
+    if (tid == kLmCtl) {
+      sh_trace.iterations = lm.iter; sh_trace.accepted = lm.accepted; sh_trace.termination = lm.termination; sh_trace.pad = 0;
+      sh_trace.initial_cost = lm.initial_cost; sh_trace.final_cost = lm.cost;
+    }
     const int cif = sh_ci;
     if (cif >= 0) {                                                  // the iterate's matrix is at hand (:222-227)
       if (tid < 12) sh_ov[tid] = sh_pose2[cif][tid];
@@ -706,14 +715,12 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
     // the model's prediction fails once it tends to fail again (the first scans of a young window converge more slowly): the next
     // spec_backoff (16) solves of this kind hand nothing over early
     st.spec_eval[outer_it] = (spec_done && sh_nmoved != spec_moves) ? v.spec_backoff : (sh_spec_at > 0 ? sh_spec_at - 1 : 0);
-    liodom_lm_trace_t& tr = st.info.lm[outer_it];
-    tr.iterations = lm.iter; tr.accepted = lm.accepted; tr.termination = lm.termination; tr.pad = 0;
-    tr.initial_cost = lm.initial_cost; tr.final_cost = lm.cost;
+    if (outer_it == 0) st.info.lm[0] = sh_trace;      // (read by the finalising solve's launch; the finalising solve's own trace travels through LDS)
     if (outer_it == 1) st.append_raw = 0;
   }
   DBG_STAMP(v, dbgb, 2, 21);
   if (outer_it == 1) {
-    finalize_scan(v, s, st, sh_cnt, eb, false, kLmCtl, chain, sh_ov, 0, false, sh_prev, sh_fc, spec_done ? 2 : 3, (!spec_done || sh_nmoved == spec_moves) ? 1u : 2u);
+    finalize_scan(v, s, st, sh_cnt, eb, false, kLmCtl, chain, sh_ov, 0, false, sh_prev, sh_fc, spec_done ? 2 : 3, (!spec_done || sh_nmoved == spec_moves) ? 1u : 2u, &sh_trace);
     DBG_STAMP(v, dbgb, 2, 22);
   }
   DBG_STAMP(v, dbgb, 2, 28);
