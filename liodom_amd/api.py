@@ -11,7 +11,7 @@ _LIB = os.path.join(_HERE, "lib", "libliodom_hip.so")
 _HASH = _LIB + ".srchash"
 _BUILD_INFO = {"rebuilt": None, "source_hash": None}
 _SRC = [os.path.join(_HERE, "csrc", f) for f in ("liodom_hip.hip", "liodom_kernels.h", "kernels_extract.h", "kernels_sync.h",
-                                                  "kernels_compact.h", "kernels_knn.h", "kernels_lm.h", "kernels_rebuild.h",
+                                                  "kernels_compact.h", "kernels_knn.h", "kernels_knn8.h", "kernels_lm.h", "kernels_rebuild.h",
                                                   "kernels_filter.h", "liodom_math.h", "wave_ops.h",
                                                   "liodom_map.h", "liodom_map_host.h")] + [
     os.path.join(_ROOT, "include", "liodom_hip.h")]

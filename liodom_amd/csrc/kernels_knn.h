@@ -1214,6 +1214,7 @@ __global__ void k_ov_gate(DevView v, int s, unsigned int seq) {
 __global__ __launch_bounds__(256) void k_line_gate(DevView v, int s0, int outer_it, int eb) {
   const int s = s0 + blockIdx.y;
   StreamState& st = v.state[s];
+  if (v.knn8_cnt && blockIdx.x == 0 && threadIdx.x == 0) v.knn8_cnt[s] = 0;      // (k_knn8's list for k_knn8_exact, the launch before this one: consumed)
   if (!st.initialized) return;
   const int E = st.n_edges_buf[eb];
   const int eq = blockIdx.x * 256 + threadIdx.x;

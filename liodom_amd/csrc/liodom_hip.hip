@@ -153,6 +153,8 @@ struct liodom_handle {
   std::atomic<bool> profiling{false};   // read without a lock by SideLocks / extract_queue, written under both mutexes
   std::vector<liodom_map*> mappers;   // per stream: attached device map (mapping replay) or null
   std::vector<int> mapper_cells_xy, mapper_cells_z;
+  int knn8_grid = 1;            // k_knn8 workgroups per stream (each walks the blocks b, b + grid, ... of 32 queries)
+  bool knn8 = false;            // handles with >= 16 streams: k_knn8 (eight lanes per query) instead of k_knn<128>; LIODOM_KNN8=0 keeps the latter
   bool lds_hash_build = false;  // k_hash_build (one workgroup per stream, LDS) instead of the 3 global-atomic kernels
   bool use_flags = false;       // pipelined replay: dependencies between the two streams through flags in device memory instead of events
   bool flag_gate = false;       // ... polled by a one-wave gate launch in front of the scan's first k_knn launch instead of by that launch itself
@@ -389,7 +391,14 @@ int enqueue_odometry(liodom_handle* h, int eb, int s0, int count, unsigned int w
     {
       ProfScope ps(h, KID_KNN);
       const int kx = v.knn_grid + ((early && it == 1 && !seq_k) ? kRebuildAuxBlocks : 0);     // it 1: + ALLOC (overlapped pass: k_rebuild_alloc below)
-      if (knn_small) {
+      if (knn_small && h->knn8) {
+        // lock-step batches: eight lanes per query (kernels_knn8.h); the workgroups of a stream walk its blocks of 32 queries
+        const dim3 g8(h->knn8_grid, count);
+        if (it == 0) hipLaunchKernelGGL(k_knn8<0>, g8, dim3(kKnn8Threads), 0, h->stream, v, s0, eb);
+        else hipLaunchKernelGGL(k_knn8<1>, g8, dim3(kKnn8Threads), 0, h->stream, v, s0, eb);
+        hipLaunchKernelGGL(k_knn8_exact, dim3(kKnn8ExactBlocks, count), dim3(kKnn8Threads), 0, h->stream, v, s0, it, eb);      // (the ~1 % of the queries the fast path cannot certify)
+        hipLaunchKernelGGL(k_line_gate, dim3(cdiv(h->v.knn_blocks * h->v.knn_queries, 256), count), dim3(256), 0, h->stream, v, s0, it, eb);
+      } else if (knn_small) {
         hipLaunchKernelGGL(k_knn<128>, dim3(kx, count), dim3(128), 0, h->stream, v, s0, it, eb, wait_edges, signal_odo, 0u, 0);
         if (v.knn_nn) hipLaunchKernelGGL(k_line_gate, dim3(cdiv(h->v.knn_blocks * h->v.knn_queries, 256), count), dim3(256), 0, h->stream, v, s0, it, eb);
       } else if (it == 1 && seq_k) {
@@ -939,7 +948,12 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
     if (const char* e = std::getenv("LIODOM_GATE_KERNEL")) gate_kernel = gate_kernel && std::atoi(e) != 0;
     if (gate_kernel) ALLOC(v.knn_nn, S * (size_t)v.edge_cap * 5, 0); else v.knn_nn = nullptr;
   }
-  v.knn_queries = config->n_streams >= 16 ? 4 : 8;          // must match the k_knn instance launch_odometry picks
+  h->knn8 = config->n_streams >= 16 && v.knn_nn != nullptr;
+  if (const char* e = std::getenv("LIODOM_KNN8")) { if (std::atoi(e) == 0) h->knn8 = false; }
+  h->knn8_grid = std::max(1, cdiv(cdiv(v.edge_cap, kKnn8Queries), kKnnGridDiv));
+  if (const char* e = std::getenv("LIODOM_KNN8_GRID")) h->knn8_grid = std::max(1, std::min(65535, std::atoi(e)));      // (experiments)
+  if (h->knn8) { ALLOC(v.knn8_cnt, S, 0); ALLOC(v.knn8_list, S * (size_t)v.edge_cap, 0); } else { v.knn8_cnt = nullptr; v.knn8_list = nullptr; }
+  v.knn_queries = config->n_streams >= 16 ? 4 : 8;          // must match the k_knn instance launch_odometry picks (k_knn8 leaves k_line_gate the same layout)
   v.knn_partials = config->n_streams >= 16 ? 0 : 1;         // measured: +37 % on the VALU-bound 256-stream kNN pass, -2 us per solve on one stream
   v.knn_blocks = round_up(cdiv(v.edge_cap, v.knn_queries), 4);
   v.knn_grid = std::max(1, cdiv(v.knn_blocks, kKnnGridDiv));   // sized for the usual edge count (~1/3 of the capacity): a workgroup takes a second block if there are more
@@ -1991,11 +2005,11 @@ int liodom_get_modes(liodom_handle_t* h, char* buf, int cap) {
   const DevView& v = h->v;
   snprintf(buf, (size_t)cap,
            "n_streams=%d early_rebuild=%d hash_build=%s pipe_flags=%d flag_gate=%d lm_groups=%d knn_instance=%d knn_queries=%d "
-           "knn_grid=%d/%d knn_partials=%d knn_saved_bound=%d knn_exact_only=%d line_gate_kernel=%d filter_local_map=%d mapping=%d "
+           "knn_grid=%d/%d knn8=%d knn_partials=%d knn_saved_bound=%d knn_exact_only=%d line_gate_kernel=%d filter_local_map=%d mapping=%d "
            "rotation_mode=%d table_size=%d rebuild_delta=%.3f knn_overlap=%d streams_concurrent=%d safe_mode=%d ring_split=%d ring_split_max_wgs=%d chain=%d speculate=%d replay_enqueue_us=%.2f replay_wait_us=%.2f debug=%d",
            h->S, v.early_rebuild, v.early_rebuild ? "streamed" : (h->lds_hash_build ? "lds" : "global"), h->use_flags ? 1 : 0,
            (h->use_flags && h->flag_gate) ? 1 : 0, v.lm_groups, h->S >= 16 ? 128 : 256, v.knn_queries, v.knn_grid,
-           v.knn_blocks, v.knn_partials, v.knn_save_pos ? 2 : (v.knn_save_q ? 1 : 0), v.knn_exact_only, v.knn_nn ? 1 : 0, v.filter_local_map, v.mapping,
+           v.knn_blocks, h->knn8 ? 1 : 0, v.knn_partials, v.knn_save_pos ? 2 : (v.knn_save_q ? 1 : 0), v.knn_exact_only, v.knn_nn ? 1 : 0, v.filter_local_map, v.mapping,
            v.rotation_mode, v.table_size, (double)v.rebuild_delta,
            (v.early_rebuild && (h->ov_ok || (h->chain_ok && !h->flag_gate)) && h->use_flags && g_live_handles.load() <= 1) ? 1 : 0, h->streams_concurrent ? 1 : 0, h->safe_mode ? 1 : 0, h->ring_split ? 1 : 0, h->ring_split ? h->ring_split_max_wgs : 0,
            (v.early_rebuild && h->chain_ok && h->use_flags && !h->flag_gate && g_live_handles.load() <= 1) ? 1 : 0, v.speculate,

@@ -201,6 +201,8 @@ struct DevView {
   int sorted_cap;           // sorted_pts entries per table (early_rebuild: map_cap + 8 edge_cap of padding + edge_cap of overflow list; else map_cap)
   int ovf_base;             // first entry of the overflow list inside a table's sorted_pts
   float rebuild_delta;      // early_rebuild: a new-frame point may move this far (per axis) between the prediction and the solved pose and still land in a padded cell
+  int* knn8_cnt;            // [S] k_knn8: queries of the pass left to k_knn8_exact (k_line_gate resets it)
+  int* knn8_list;           // [S][edge_cap] ... their numbers
   float4* knn_nn;           // [S][edge_cap][5] lock-step batches: the five neighbours of every query (w: found flag, index of NN0, NN1) for k_line_gate
   unsigned int* pipe_flags; // [kEdgePipeBufs + 1] pipelined replay without cross-stream events: [b] = sequence number of the extraction whose edges
                             // are complete in edge buffer b; [kEdgePipeBufs] = number of the last odometry (of this handle) that has completed entirely
@@ -314,6 +316,7 @@ __device__ __forceinline__ bool wait_expired(unsigned int spins, unsigned long l
 #include "kernels_sync.h"
 #include "kernels_compact.h"
 #include "kernels_knn.h"
+#include "kernels_knn8.h"
 #include "kernels_lm.h"
 #include "kernels_rebuild.h"
 #include "kernels_filter.h"

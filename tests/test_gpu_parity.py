@@ -1024,3 +1024,77 @@ def test_chain_mode_replay_against_the_oracle_every_hand_over_wrong(orc, synth, 
     modes, wt, wr = _chain_replay_against_the_oracle(orc, synth, "hdl64", 12, data_stream=8)
     assert modes["chain"] == "1" and modes["speculate"] == "2", modes
     assert wt < 1e-6 and wr < 1e-6
+
+
+def _batch_run(orc, synth, scans, H, W, R, epr, P, S, env, monkeypatch, check_oracle=False):
+    """One replay of `scans` (per data stream d: scans[d][k]) on an S-stream handle under `env`; returns per scan (poses, matches,
+    correspondences of both passes for streams 0 .. D-1)."""
+    for name in ("LIODOM_KNN8", "LIODOM_KNN_EXACT_ONLY", "LIODOM_KNN_SAVE"):
+        monkeypatch.delenv(name, raising=False)
+    for name, val in env.items():
+        monkeypatch.setenv(name, val)
+    D, K = len(scans), len(scans[0])
+    po, g = mk(orc, H, W, 0, R, epr, P, S=S, debug=1, pose_log_capacity=K + 8)
+    modes = g.modes()
+    g.alloc_resident(K)
+    for s in range(S):
+        for k in range(K):
+            g.upload_scan(s, k, scans[s % D][k])
+    out = []
+    for k in range(K):
+        maps = [g.local_map(d)[0] for d in range(D)] if check_oracle else None
+        poses, infos = g.process_resident(k, H * W, H, W, readback=True, next_slot=(k + 1 if k + 1 < K else -1))
+        assert all(i.status == 0 for i in infos), k
+        corr = [[tuple(a.copy() for a in g.correspondences(it, stream=d)) for it in (0, 1)] for d in range(D)]
+        if check_oracle and k > 0:
+            for d in range(D):
+                for it in (0, 1):
+                    vk, ak, bk = orc.match_edges(po, maps[d], g.knn_queries(it, stream=d))
+                    vg, ag, bg = corr[d][it]
+                    assert np.array_equal(vk, vg) and np.array_equal(ak, ag) and np.array_equal(bk, bg), (k, d, it, np.nonzero((vk != vg) | (ak != ag) | (bk != bg))[0][:10])
+        out.append((poses.copy(), [tuple(i.matches) for i in infos], corr))
+    g.close()
+    return modes, out
+
+
+def _assert_batch_runs_equal(a, b, what):
+    for k, (x, y) in enumerate(zip(a, b)):
+        assert np.array_equal(x[0].view(np.uint64), y[0].view(np.uint64)), (what, k)
+        assert x[1] == y[1], (what, k)
+        for cx, cy in zip(x[2], y[2]):
+            for it in (0, 1):
+                assert all(np.array_equal(p, q) for p, q in zip(cx[it], cy[it])), (what, k, it)
+
+
+def test_knn8_equals_the_half_wave_kernel_and_its_own_modes(orc, synth, monkeypatch):
+    """Lock-step batches search with k_knn8 (eight lanes per query: Best3 candidates per lane, neighbour cells probed lazily, 24
+    candidates kept for the second pass — kernels_knn8.h).  Against k_knn<128> (LIODOM_KNN8=0: a half-wave per query) and against its
+    own exact-list path (LIODOM_KNN_EXACT_ONLY=1), bound-only second pass (LIODOM_KNN_SAVE=1) and search-again second pass (=0):
+    poses, match counts and the correspondences of both passes bit-identical, on a gentle and on a violent trajectory (many
+    second-pass queries that the guard cannot certify).  Matches laser_odometry.cc:318-361."""
+    H, W, R, epr, P, S, K = 16, 900, 6, 10, 5, 16, 12
+    for yaw, speed in ((0.5, 0.1), (3.0, 0.6)):
+        cfg = synth.make_cfg(H, W, 0, yaw_rate_deg=yaw, speed=speed)
+        scans = [[synth.scan(cfg, 30 + d, k)[0] for k in range(K)] for d in range(3)]
+        modes, base = _batch_run(orc, synth, scans, H, W, R, epr, P, S, {}, monkeypatch)
+        assert modes["knn8"] == "1" and modes["line_gate_kernel"] == "1"
+        modes, old = _batch_run(orc, synth, scans, H, W, R, epr, P, S, {"LIODOM_KNN8": "0"}, monkeypatch)
+        assert modes["knn8"] == "0"
+        _assert_batch_runs_equal(base, old, ("half-wave kernel", yaw))
+        for env in ({"LIODOM_KNN_EXACT_ONLY": "1"}, {"LIODOM_KNN_SAVE": "1"}, {"LIODOM_KNN_SAVE": "0"}):
+            _, other = _batch_run(orc, synth, scans, H, W, R, epr, P, S, env, monkeypatch)
+            _assert_batch_runs_equal(base, other, (env, yaw))
+    assert sum(m[1] for m in base[-1][1]) > 100
+
+
+def test_knn8_ties_are_ordered_by_window_index(orc, synth, monkeypatch):
+    """test_knn_ties_are_ordered_by_window_index on the batch instance: a static sensor in a noise-free world, P = 2 — every
+    query's neighbours come in pairs of equal float distance, FLANN's order (lower window index first) decides the line points;
+    k_knn8 must send those queries through its exact lists.  Valid flags and both line-point indices equal the oracle's loop
+    (laser_odometry.cc:320-361) on the GPU's own inputs."""
+    H, W, R, epr, P, S, K = 16, 900, 6, 10, 2, 16, 6
+    cfg = synth.make_cfg(H, W, 0, noise_sigma=0.0, yaw_rate_deg=0.0, speed=0.0)
+    x = synth.scan(cfg, 2, 0)[0]
+    modes, out = _batch_run(orc, synth, [[x] * K], H, W, R, epr, P, S, {}, monkeypatch, check_oracle=True)
+    assert modes["knn8"] == "1"
+    assert sum(int(c[0][1][0].sum()) for _, _, c in out[2:]) > 0      # accepted correspondences whose NN0 / NN1 are two copies of one point
