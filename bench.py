@@ -239,13 +239,29 @@ def main():
     # back.  LIODOM_BENCH_PIN=0: no pinning beyond the GPU's NUMA node.
     orig_affinity = os.sched_getaffinity(0)
     pin_core = None
+    pin_source = "none"
+    wide_affinity = orig_affinity            # what the multi-threaded legs (two_thread) get back: the GPU's socket if known
     if os.environ.get("LIODOM_BENCH_PIN", "1") != "0":
         try:
-            base = sorted(orig_affinity)
-            pin_core = base[int(os.environ.get("LOCAL_RANK", "0")) % len(base)]      # (one core per replica)
+            # the core comes from the GPU's own socket (sysfs, before HIP loads): with `sorted(affinity)[LOCAL_RANK]` the replicas of
+            # an 8-GPU node all sat on socket 0, half of them driving their GPU across the socket link (54 us of enqueue per scan
+            # instead of 26: round-5 measurement above)
+            from liodom_amd.replicas import gpu_local_cpus, choose_core
+            lr = int(os.environ.get("LOCAL_RANK", "0"))
+            local = gpu_local_cpus()
+            pin_core = choose_core(lr % len(local), local, orig_affinity) if local else None
+            pin_source = "gpu local_cpulist (sysfs)"
+            if pin_core is not None and len(local[lr % len(local)] & orig_affinity) >= 2:
+                wide_affinity = local[lr % len(local)] & orig_affinity
+            if pin_core is None:
+                base = sorted(orig_affinity)
+                usable = base[1:] if len(base) > 1 and base[0] == 0 else base
+                pin_core = usable[lr % len(usable)]      # (one core per replica; no topology to go by)
+                pin_source = "affinity mask (no GPU topology in sysfs)"
             os.sched_setaffinity(0, {pin_core})
         except Exception:
             pin_core = None
+            pin_source = "none"
 
     # The HIP library is loaded before torch so that libamdhip64 resolves to /opt/rocm's copy.
     import liodom_amd as la
@@ -420,13 +436,16 @@ def main():
         th2 = sorted(t_2k)[1]
         # (continues the same trajectory: must equal the resident replay's poses)
         hf_ok = bool(np.array_equal(hp[:, 0].view(np.uint64), poses_gpu[F + Wm:F + Wm + K].view(np.uint64)))
-        steady = K / max(th2 - th, 1e-9)
-        host_fed = {"scans_per_s": round(steady, 2), "us_per_scan": round((th2 - th) / K * 1e6, 2),
-                    "single_call_scans_per_s": round(K / th, 2),
+        # (scans_per_s keeps its meaning of rounds 1-4 — one call over the K timed scans —; the differential figure has a name of its own
+        #  and is only quoted when the difference of the two medians is a measurement: at least a quarter of the single call)
+        steady = K / (th2 - th) if (th2 - th) > 0.25 * th else None
+        host_fed = {"scans_per_s": round(K / th, 2), "us_per_scan": round(th / K * 1e6, 2),
+                    "steady_state_scans_per_s": round(steady, 2) if steady else None,
+                    "single_call_spread_s": [round(x, 6) for x in sorted(t_k)], "double_call_spread_s": [round(x, 6) for x in sorted(t_2k)],
                     "mode": "liodom_replay_host, depth 1: page-locked host ring (pinned once, outside the timed region) -> hipMemcpyAsync (%.2f MB per scan), "
-                            "upload + extraction of scan k+1 beside the odometry of scan k, every pose read back in order; scans_per_s = steady state "
-                            "(K / (T(2K scans) - T(K scans)), medians of 3); single_call_scans_per_s = one call over the K timed scans, cold start and "
-                            "drain included" % (N * 16 / 1e6),
+                            "upload + extraction of scan k+1 beside the odometry of scan k, every pose read back in order; scans_per_s = one call over the "
+                            "K timed scans, cold start and drain included (median of 3); steady_state_scans_per_s = K / (T(2K scans) - T(K scans)), "
+                            "the second K scans being the first K walked backwards" % (N * 16 / 1e6),
                     "poses_bit_equal_to_resident_replay": hf_ok}
         # (b) two threads through the C-ABI, as the reference node runs its FeatureExtractor / LaserOdometer threads (liodom_node.cc:89-91):
         # two C++ threads (liodom_host_two_thread_replay, liodom_amd/host) — the extractor thread uploads every scan from host
@@ -435,7 +454,7 @@ def main():
         g.reset()
         if pin_core is not None:                 # two busy threads from here on: the full mask again
             try:
-                os.sched_setaffinity(0, orig_affinity)
+                os.sched_setaffinity(0, wide_affinity)      # (the GPU's own socket where the topology is known)
             except Exception:
                 pass
         nrun = F + Wm + K
@@ -478,7 +497,7 @@ def main():
                        "modes": modes,
                        "host_affinity": ("single-threaded legs (value, strict, async, serial, host_fed, batched): this process and the HIP runtime's threads on CPU %d "
                                          "(as `taskset -c`; LIODOM_BENCH_PIN=0: the CPU list of the GPU's NUMA node); "
-                                         "two_thread and the CPU baselines: the full mask" % pin_core) if pin_core is not None else "the GPU's NUMA node (no single core)",
+                                         "(chosen from: %s); two_thread: %d CPUs of the GPU's socket; CPU baselines: the full mask" % (pin_core, pin_source, len(wide_affinity))) if pin_core is not None else "the GPU's NUMA node (no single core)",
                        "environment": {k: v for k, v in os.environ.items() if k.startswith("LIODOM_") or k in ("HIP_FORCE_DEV_KERNARG", "AMD_SERIALIZE_KERNEL", "HIP_LAUNCH_BLOCKING")}},
             "value_spread": {"min": round(world * K / max(kept), 2), "max": round(world * K / min(kept), 2),
                              "first_discarded": round(world * K / samples[0], 2) if len(samples) > 1 else None},

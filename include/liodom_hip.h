@@ -44,6 +44,9 @@ extern "C" {
 #define LIODOM_ERR_NO_DEVICE (-5)
 #define LIODOM_ERR_BUSY (-6)          /* device-resident hand-off: every slot holds an edge cloud that has not been consumed yet (retry
                                          after liodom_odometry_step_device), or tickets are outstanding where none may be */
+#define LIODOM_ERR_NEEDS_SYNC (-7)    /* liodom_extract_edges_device while scans of a resident / host replay (liodom_process_resident*,
+                                         liodom_replay_*) still occupy the pipeline edge buffers: retrying cannot help — call liodom_sync()
+                                         (or liodom_reset()) first, then hand clouds over by ticket */
 
 /* Sticky per-stream status bits reported in liodom_step_info_t.status */
 #define LIODOM_STATUS_RING_OVERFLOW 1u  /* deprecated, never raised (rings of any length are processed); kept so that callers

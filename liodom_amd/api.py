@@ -135,6 +135,7 @@ class EdgeTicket(C.Structure):
 
 
 ERR_BUSY = -6
+ERR_NEEDS_SYNC = -7
 
 
 class KernelStat(C.Structure):

@@ -1273,11 +1273,11 @@ int liodom_extract_edges_device(liodom_handle_t* h, int stream, const float* xyz
   if (h->S != 1) { g_last_error = "liodom_extract_edges_device: one-stream handles only (lock-step handles advance all streams together: liodom_process_resident)"; return LIODOM_ERR_UNSUPPORTED; }
   if (n < 0 || n > h->v.max_points || (n > 0 && !xyzi)) { g_last_error = "bad point count"; return LIODOM_ERR_CAPACITY; }
   SideLocks lk(h, false, true);                      // extraction side only: safe beside a concurrent liodom_odometry_step_device
-  if (h->pf_slot >= 0) { g_last_error = "liodom_extract_edges_device: a pipelined replay of this handle has an extraction issued ahead"; return LIODOM_ERR_BUSY; }
+  if (h->pf_slot >= 0) { g_last_error = "liodom_extract_edges_device: a pipelined replay of this handle has an extraction issued ahead: call liodom_sync() first"; return LIODOM_ERR_NEEDS_SYNC; }
   // The pipelined replay uses the same three edge buffers (h->parity) and may have odometries in flight that nobody has collected
   // (liodom_process_resident_pipelined without read-back): this extraction would rewrite a buffer under them (wait_odo = 0 below
   // relies on the ticket discipline: a slot is refilled only after its pose has been collected).
-  if (h->replay_live.load()) { g_last_error = "liodom_extract_edges_device: scans of a pipelined replay (liodom_process_resident / liodom_replay_*) are still in the edge buffers: call liodom_sync() first"; return LIODOM_ERR_BUSY; }
+  if (h->replay_live.load()) { g_last_error = "liodom_extract_edges_device: scans of a pipelined replay (liodom_process_resident / liodom_replay_*) are still in the edge buffers: call liodom_sync() first"; return LIODOM_ERR_NEEDS_SYNC; }      // (not BUSY: a caller that keeps the cloud and retries would spin forever)
   const int eb = h->x_next;
   if (h->tk_seq[eb].load() != 0u) {
     g_last_error = "liodom_extract_edges_device: all hand-off slots hold edge clouds no liodom_odometry_step_device has taken yet";

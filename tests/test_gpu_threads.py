@@ -3,6 +3,7 @@ scans ahead of a LaserOdometer thread on the SAME handle (src/liodom_node.cc:89-
 src/shared_data.cc:64-89).  liodom_extract_edges works on the handle's extraction side,
 liodom_odometry_step on its odometry side; run concurrently they must give the same bits as the
 serial order extract(k) -> odometry(k) -> extract(k+1) -> ..."""
+import ctypes as C
 import os
 import queue
 import subprocess
@@ -353,6 +354,32 @@ def test_device_handoff_back_pressure_and_stale_tickets(synth):
     g.close()
 
 
+def test_ticket_after_a_replay_needs_a_sync_not_a_retry(synth):
+    """A node that prefills with liodom_replay_resident and then switches to the ticket API: while scans of the replay still occupy
+    the pipeline edge buffers, liodom_extract_edges_device answers LIODOM_ERR_NEEDS_SYNC (-7) — not LIODOM_ERR_BUSY, whose documented
+    reaction is "keep the cloud and retry", which would spin forever — and works after liodom_sync()."""
+    import liodom_amd as la
+    c = CONFIGS["cfg1_16x900"]
+    H, W = c["H"], c["W"]
+    cfg = synth.make_cfg(H, W, 0)
+    scans = [synth.scan(cfg, 2, k)[0] for k in range(5)]
+    g = _handle(c)
+    g.alloc_resident(4)
+    for k in range(4):
+        g.upload_scan(0, k, scans[k])
+    poses, _ = g.replay_resident(0, 4, H * W, H, W, depth=1)          # every pose collected; the handle has not been synchronised
+    x = np.ascontiguousarray(scans[4], dtype=np.float32)
+    t = la.api.EdgeTicket()
+    rc = g.L.liodom_extract_edges_device(g.h, 0, x.ctypes.data_as(C.POINTER(C.c_float)), x.size // 4, H, W, C.byref(t))
+    assert rc == la.api.ERR_NEEDS_SYNC and rc != la.api.ERR_BUSY
+    g.sync()
+    tk = g.extract_edges_device(scans[4], H, W)
+    assert tk is not None
+    p4, info = g.odometry_step_device(tk)
+    assert info.status == 0 and info.scan_index == 4
+    g.close()
+
+
 def test_cxx_two_thread_replay_equals_resident_replay(synth):
     """liodom_host_two_thread_replay (two std::threads through the C-ABI, what bench.py's two_thread leg times) gives the
     bits of the resident replay, at both depths, with and without fetching the ~edges clouds."""
@@ -399,6 +426,10 @@ def test_second_process_saturating_the_gpu_never_gives_a_wrong_pose(shape, scans
     tail = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ""
     assert r.returncode == 0, (tail, r.stderr[-1500:])
     assert "bit-identical" in tail
+    # (the time budget cuts the replay short beside a hog that time-slices the GPU: at least one chunk of the walk must have been compared)
+    import re
+    m = re.search(r"(\d+) poses compared beside the second process", tail)
+    assert m and int(m.group(1)) >= 40, tail
 
 
 def test_device_handoff_in_safe_mode_uses_events(synth, monkeypatch):

@@ -73,3 +73,42 @@ def test_bench_under_the_launcher_agrees_on_the_world(tmp_path):
                          capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
     assert out.returncode != 0
     assert "WORLD_SIZE is" not in out.stderr          # the launcher check passed on both ranks
+
+
+def test_replica_cores_come_from_the_gpus_own_socket(tmp_path, monkeypatch):
+    """bench.py pins every replica to ONE core before the HIP runtime loads (its threads inherit the mask).  The core must lie in the
+    local_cpulist of the replica's own GPU, differ between replicas that share a socket, and avoid CPU 0 — round 5 took
+    sorted(affinity)[LOCAL_RANK], i.e. socket 0 for all eight replicas of a two-socket node.  Mocked sysfs: 8 GPUs, 4 per socket."""
+    sys.path.insert(0, ROOT)
+    from liodom_amd.replicas import gpu_local_cpus, choose_core
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    root = tmp_path / "sys"
+    nodes = root / "class" / "kfd" / "kfd" / "topology" / "nodes"
+    # two CPU nodes without SIMDs, then eight GPUs
+    for n in range(2):
+        (nodes / str(n)).mkdir(parents=True)
+        (nodes / str(n) / "properties").write_text("cpu_cores_count 64\nsimd_count 0\nlocation_id 0\ndomain 0\n")
+    for g in range(8):
+        bus = 0x10 + 0x10 * g
+        d = nodes / str(2 + g)
+        d.mkdir(parents=True)
+        d.joinpath("properties").write_text("cpu_cores_count 0\nsimd_count 1024\nlocation_id %d\ndomain 0\n" % (bus << 8))
+        pci = root / "bus" / "pci" / "devices" / ("0000:%02x:00.0" % bus)
+        pci.mkdir(parents=True)
+        pci.joinpath("local_cpulist").write_text("0-63,128-191\n" if g < 4 else "64-127,192-255\n")
+    local = gpu_local_cpus(str(root))
+    assert len(local) == 8 and 0 in local[0] and 64 in local[7] and 0 not in local[7]
+    affinity = set(range(256))
+    cores = [choose_core(g, local, affinity) for g in range(8)]
+    assert all(cores[g] in local[g] for g in range(8)), cores
+    assert len(set(cores)) == 8 and 0 not in cores, cores
+    assert all(c < 64 or 128 <= c < 192 for c in cores[:4]) and all(64 <= c < 128 or c >= 192 for c in cores[4:]), cores
+    # a restricted affinity mask (container quota) is respected; a GPU without a usable local core yields None
+    assert choose_core(5, local, set(range(64, 72))) in range(64, 72)
+    assert choose_core(5, local, set(range(0, 8))) is None
+    # HIP_VISIBLE_DEVICES re-orders the devices the runtime will see
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "6,1")
+    sel = gpu_local_cpus(str(root))
+    assert len(sel) == 2 and 64 in sel[0] and 0 in sel[1]
+    assert gpu_local_cpus(str(tmp_path / "nothing")) == []

@@ -113,17 +113,20 @@ while not os.path.exists(stop + ".ready") and time.time() - t_wait < 180:
 assert os.path.exists(stop + ".ready"), "the second process did not start"
 time.sleep(1.0)
 verdict = "FAIL"
+n_checked = 0
 try:
     g.reset()
     loaded, err = replay(g, "beside the second process (%s)" % hog_kind, budget=BUDGET_S)
     if err is None:
         same = np.array_equal(loaded.view(np.uint64), solo[:len(loaded)].view(np.uint64))
+        n_checked = len(loaded)
         verdict = "bit-identical to the solo run" if same else "WRONG POSES (no error reported)"
     else:
         print("clean error beside the second process:", err[:300], flush=True)
         g.reset()                                   # applies the event-path fallback
         print("modes after reset:", g.modes(), flush=True)
         again, err2 = replay(g, "after liodom_reset (safe mode), still beside the second process", budget=BUDGET_S)
+        n_checked = 0 if again is None else len(again)
         if err2 is None and np.array_equal(again.view(np.uint64), solo_safe[:len(again)].view(np.uint64)):
             verdict = "clean LIODOM_ERR_HIP, then bit-identical to the solo safe-mode run after liodom_reset"
         else:
@@ -137,6 +140,6 @@ finally:
     for f in (stop, stop + ".ready"):
         if os.path.exists(f):
             os.remove(f)
-print("%s, %d scans, overlap %s: %s" % (shape, K, g.modes().get("knn_overlap"), verdict))
+print("%s, %d scans, overlap %s, %d poses compared beside the second process: %s" % (shape, K, g.modes().get("knn_overlap"), n_checked, verdict))
 g.close()
 sys.exit(0 if verdict.startswith(("bit-identical", "clean")) else 1)
