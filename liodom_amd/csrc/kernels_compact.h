@@ -62,6 +62,7 @@ __global__ __launch_bounds__(256) void k_compact_edges(DevView v, int s0, int eb
 // thread that waits for the edges (host_seq, system scope; may be null).
 __global__ void k_publish_edges(unsigned int* dev_flag, unsigned int* host_seq, unsigned int value) {
   typedef __attribute__((address_space(1))) unsigned int gu32;
+  INJECT_DELAY(19);
   if (dev_flag) __hip_atomic_store((gu32*)dev_flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (host_seq) __hip_atomic_store(host_seq, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }

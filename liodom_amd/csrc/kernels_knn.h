@@ -895,6 +895,7 @@ __device__ __forceinline__ void knn_tail_dual(const DevView& v, int s, int outer
 // published after it).
 __device__ __forceinline__ void chain_release_edges(const DevView& v, unsigned int signal_odo) {
   typedef __attribute__((address_space(1))) unsigned int gu32;
+  if (signal_odo && threadIdx.x == 0) INJECT_DELAY(14);
   if (signal_odo && threadIdx.x == 0) __hip_atomic_store((gu32*)(v.pipe_flags + kEdgePipeBufs), signal_odo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 

@@ -319,6 +319,7 @@ __device__ void lm_exchange(const DevView& v, int s, int g, int G, unsigned int 
   typedef __attribute__((address_space(1))) unsigned long long gu64;
   unsigned long long* base = v.lm_xch + ((size_t)s * 2 + (epoch & 1u)) * kLmGroupsMax * 64;
   const int tid = threadIdx.x;
+  INJECT_DELAY(16);
   if (tid <= 2 * kAccN) {
     unsigned long long half;
     if (tid < 2 * kAccN) {
@@ -377,6 +378,7 @@ __device__ void lm_exchange(const DevView& v, int s, int g, int G, unsigned int 
 __device__ __forceinline__ void publish_final_pose(const DevView& v, int s, const double* T, int raw, unsigned int tag, int lane /*0..24*/, int copy) {
   typedef __attribute__((address_space(1))) unsigned long long gu64;
   unsigned long long* base = v.pose_xch + (size_t)s * 64 + copy * 32;
+  INJECT_DELAY(15);
   unsigned int word = (unsigned int)raw;
   if (lane < 24) {
     const unsigned long long bits = (unsigned long long)__double_as_longlong(T[lane >> 1]);

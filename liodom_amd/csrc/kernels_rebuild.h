@@ -356,6 +356,7 @@ __device__ __forceinline__ void rebuild_finish(const DevView& v, int s, StreamSt
     const unsigned long long lo = __shfl(g, 2 * (tid % 12)), hi = __shfl(g, 2 * (tid % 12) + 1);
     if (tid < 12) sh_T[tid] = __longlong_as_double((long long)((hi << 32) | (lo & 0xFFFFFFFFull)));
     if (!all_ok && tid == 0) atomicOr(&st.status, LIODOM_STATUS_LM_SYNC_TIMEOUT);
+    INJECT_DELAY(17);
   }
   __syncthreads();
   const bool dbga = (s == 0) && (block == 0) && (tid == 0);
@@ -434,6 +435,7 @@ __device__ __forceinline__ bool append_pose_copy(const DevView& v, int s, unsign
     const unsigned long long lo = __shfl(g, 2 * (tid % 12)), hi = __shfl(g, 2 * (tid % 12) + 1);
     if (tid < 12) T[tid] = __longlong_as_double((long long)((hi << 32) | (lo & 0xFFFFFFFFull)));
     if (tid == 0) { sh_ok = all_ok ? 1 : 0; if (!all_ok) atomicOr(status, LIODOM_STATUS_LM_SYNC_TIMEOUT); }
+    INJECT_DELAY(18);
   }
   __syncthreads();
   return sh_ok != 0;

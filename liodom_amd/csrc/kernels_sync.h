@@ -32,6 +32,7 @@ __device__ __forceinline__ bool pipe_wait(const unsigned int* flag, unsigned int
     }
     if (spins) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     s_pipe_ok = ok ? 1 : 0;
+    INJECT_DELAY(1);
   }
   __syncthreads();
   return s_pipe_ok != 0;      // false: the producer never arrived — the caller must not touch the buffer (it returns)
@@ -41,6 +42,7 @@ __device__ __forceinline__ bool pipe_wait(const unsigned int* flag, unsigned int
 // publishes that the previous odometry has completed; the launches behind it start when it retires.
 __global__ void k_pipe_gate(DevView v, int s0, int eb, unsigned int wait_edges, unsigned int signal_odo) {
   typedef __attribute__((address_space(1))) unsigned int gu32;
+  INJECT_DELAY(2);
   if (signal_odo && threadIdx.x == 0) __hip_atomic_store((gu32*)(v.pipe_flags + kEdgePipeBufs), signal_odo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (wait_edges && !pipe_wait(v.pipe_flags + eb, wait_edges, &v.state[s0].status)) {
     // the launches behind the gate check the status bit of their own stream (k_knn) and skip the scan
@@ -114,6 +116,7 @@ constexpr int kOvFinalOffset = 64;
 __device__ __forceinline__ void ov_publish_pose(const DevView& v, int s, const double* T, const double* qt, unsigned int tag, int tid, int copies) {
   typedef __attribute__((address_space(1))) unsigned long long gu64;
   const int per = kOvReplicas * kOvGranules;
+  INJECT_DELAY(3);
   for (int t = tid; t < 2 * per; t += (int)blockDim.x) {      // (one or two granules per thread at 512 threads)
     const int c = t / per, u = t % per;
     if (!((copies >> c) & 1)) continue;
@@ -150,6 +153,7 @@ __device__ __forceinline__ bool granules_wait(const unsigned long long* base, in
     const unsigned long long lo = __shfl(g, 2 * (tid % nd)), hi = __shfl(g, 2 * (tid % nd) + 1);
     if (tid < nd) out[tid] = __longlong_as_double((long long)((hi << 32) | (lo & 0xFFFFFFFFull)));
     if (tid == 0) { s_ov_ok = all_ok ? 1 : 0; if (!all_ok) atomicOr(status, LIODOM_STATUS_PIPE_TIMEOUT); }
+    INJECT_DELAY(4);
   }
   __syncthreads();
   return s_ov_ok != 0;
@@ -210,6 +214,7 @@ __device__ __forceinline__ int ov_confirm_pose(const DevView& v, int s, int rep,
     const bool any = __any(differs);
     if (all_ok && any && tid < 19) io19[tid] = __longlong_as_double((long long)fin);
     if (tid == 0) { s_cf = all_ok ? (any ? 2 : 1) : 0; if (!all_ok) atomicOr(status, LIODOM_STATUS_PIPE_TIMEOUT); }
+    INJECT_DELAY(5);
   }
   __syncthreads();
   return s_cf;
@@ -222,6 +227,7 @@ constexpr int kPredVerdict = 127;      // granule of every replica: {tag, 1 = th
 __device__ __forceinline__ void pred_publish(const DevView& v, int s, const double* vals, unsigned int tag, int lane, int nlanes, int copies) {
   typedef __attribute__((address_space(1))) unsigned long long gu64;
   const int per = kOvReplicas * kPredGranules;
+  INJECT_DELAY(6);
   for (int t = lane; t < 2 * per; t += nlanes) {
     const int c = t / per, u = t % per;
     if (!((copies >> c) & 1)) continue;
@@ -234,6 +240,7 @@ __device__ __forceinline__ void pred_publish(const DevView& v, int s, const doub
 }
 __device__ __forceinline__ void pred_verdict_publish(const DevView& v, int s, unsigned int tag, unsigned int verdict, int lane) {
   typedef __attribute__((address_space(1))) unsigned long long gu64;
+  INJECT_DELAY(7);
   if (lane < kOvReplicas) __hip_atomic_store((gu64*)(v.pred_xch + ((size_t)s * kOvReplicas + lane) * 512 + kPredVerdict), ((unsigned long long)tag << 32) | verdict,
                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -253,6 +260,7 @@ __device__ __forceinline__ int pred_verdict_wait(const DevView& v, int s, int re
       __builtin_amdgcn_s_sleep(4);
     }
     s_vd = r;
+    INJECT_DELAY(8);
   }
   __syncthreads();
   return s_vd;
@@ -304,6 +312,7 @@ __device__ __forceinline__ bool pred_wait(const DevView& v, int s, int rep, unsi
     const unsigned long long lo = __shfl(g, 2 * (tid % 19)), hi = __shfl(g, 2 * (tid % 19) + 1);
     if (tid < 19) out12[tid] = __longlong_as_double((long long)((hi << 32) | (lo & 0xFFFFFFFFull)));
     if (tid == 0) { s_pw_ok = all_ok ? 1 : 0; if (!all_ok) atomicOr(status, LIODOM_STATUS_PIPE_TIMEOUT); }
+    INJECT_DELAY(9);
   }
   __syncthreads();
   return s_pw_ok != 0;
@@ -315,6 +324,7 @@ __device__ __forceinline__ bool pred_wait(const DevView& v, int s, int rep, unsi
 __device__ __forceinline__ void chain_count_done(unsigned int* counter) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  if (threadIdx.x == 0) INJECT_DELAY(10);
   if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // (returns false when the wait gave up: the caller must not consume what it waited for)
@@ -330,6 +340,7 @@ __device__ __forceinline__ bool chain_wait_count(const unsigned int* counter, un
       if (++spins > 6000000u || wait_expired(spins, t0)) { atomicOr(status, LIODOM_STATUS_PIPE_TIMEOUT); ok = false; break; }
     }
     s_cw_ok = ok ? 1 : 0;
+    INJECT_DELAY(11);
   }
   // (no acquire fence: the argument of ov_wait_knn_done — write-through producers, nothing of theirs cached here before this point)
   __syncthreads();
@@ -340,6 +351,7 @@ __device__ __forceinline__ void ov_signal_knn_done(const DevView& v, int s, int 
   typedef __attribute__((address_space(1))) unsigned int gu32;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the pass's results are write-through stores: acknowledged = visible to every XCD)
   __syncthreads();
+  if (threadIdx.x == 0) INJECT_DELAY(12);
   if (threadIdx.x == 0) __hip_atomic_store((gu32*)((done ? done : v.knn_done) + (size_t)s * v.knn_grid + b), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // whole workgroup (finalising solve's launch): every workgroup of the overlapped second pass has completed
@@ -354,6 +366,7 @@ __device__ __forceinline__ void ov_wait_knn_done(const DevView& v, int s, unsign
       if (++spins > 6000000u || wait_expired(spins, t0)) { atomicOr(status, LIODOM_STATUS_PIPE_TIMEOUT); break; }
     }
   }
+  INJECT_DELAY(13);
   // No acquire fence (an L2 invalidate per waiting workgroup; with one per workgroup of the pass the solve beside it took 80 us
   // instead of 24).  What this relies on instead — ASSUMPTIONS OUTSIDE THE HIP MEMORY MODEL, written down in DESIGN.md §3 and
   // guarded by tests/test_gpu_parity.py::test_overlapped_pass_long_replay_is_bit_identical and tools/soak_two_process.py:
@@ -386,5 +399,6 @@ __global__ void k_probe_wait(const unsigned int* flag, unsigned int* result) {
 
 __global__ void k_set_flag(unsigned int* flag, unsigned int value) {
   typedef __attribute__((address_space(1))) unsigned int gu32;
+  INJECT_DELAY(20);
   __hip_atomic_store((gu32*)flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

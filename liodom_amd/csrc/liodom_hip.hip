@@ -1972,6 +1972,24 @@ int liodom_reset_kernel_stats(liodom_handle_t* h) {
   return rc;
 }
 
+/* debug (schedule perturbation, tools/inject_delay.py): seed of the pseudo-random delays in front of every publication and behind
+ * every successful in-kernel wait; 0 switches them off.  Only in a library built with -DLIODOM_INJECT_DELAY. */
+int liodom_debug_set_inject_seed(liodom_handle_t* h, unsigned int seed) {
+#if defined(LIODOM_INJECT_DELAY)
+  if (!h) return LIODOM_ERR_INVALID_ARG;
+  if (int rc = enter(h)) return rc;
+  SideLocks lk(h, true, true);
+  HIP_TRY(hipStreamSynchronize(h->stream_x));
+  HIP_TRY(sync_odometry(h));
+  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_inject_seed), &seed, sizeof(seed)));
+  return LIODOM_OK;
+#else
+  (void)h; (void)seed;
+  g_last_error = "liodom_debug_set_inject_seed: the product library carries no delay injection; build a variant with -DLIODOM_INJECT_DELAY (tools/variant_build.sh)";
+  return LIODOM_ERR_UNSUPPORTED;
+#endif
+}
+
 /* debug: raw phase timestamps (100 MHz) written by the kernels when LIODOM_DEBUG_CLOCKS is set */
 int liodom_debug_clocks(liodom_handle_t* h, unsigned long long* out512) {
   if (!h || !out512) return LIODOM_ERR_INVALID_ARG;

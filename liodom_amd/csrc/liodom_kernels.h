@@ -311,6 +311,28 @@ __device__ __forceinline__ bool wait_expired(unsigned int spins, unsigned long l
   return now - t0 > g_wait_ticks;
 }
 
+// Schedule perturbation (tools/inject_delay.py; builds with -DLIODOM_INJECT_DELAY only — the product library carries none of it): every
+// hand-off between kernels of a handle — pose / prediction granules, done counts and flags, the verdict, the pipe flags, the solve's
+// exchanges, the appenders' pose — delays its publisher before the store and its waiter after a successful wait by a pseudo-random
+// 0 .. 20 us (three calls in four: none), so that the orders natural timing never produces are exercised.  The faults round 5 found
+// in these protocols (three races, one memory fault) were all found by waiting for natural timing to hit them.
+#if defined(LIODOM_INJECT_DELAY)
+__device__ unsigned int g_inject_seed = 0u;       // 0: no delays (liodom_debug_set_inject_seed)
+__device__ __forceinline__ void inject_delay(unsigned int site) {
+  const unsigned int seed = g_inject_seed;
+  if (!seed) return;
+  unsigned int h = seed ^ (site * 0x9E3779B1u) ^ ((unsigned int)blockIdx.x * 0x85EBCA6Bu) ^ ((unsigned int)blockIdx.y * 0xC2B2AE35u) ^ (unsigned int)wall_clock64();
+  h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+  h = __builtin_amdgcn_readfirstlane(h);          // (one decision per wave: s_sleep is a wave instruction)
+  if ((h & 3u) != 0u) return;
+  const unsigned int n = (h >> 2) % 48u;          // x s_sleep 16 (1024 cycles, ~0.43 us): 0 .. 20 us
+  for (unsigned int i = 0; i < n; i++) __builtin_amdgcn_s_sleep(16);
+}
+#define INJECT_DELAY(site) inject_delay(site)
+#else
+#define INJECT_DELAY(site) do { } while (0)
+#endif
+
 // ---- the kernels, by stage (one translation unit; the order matters: later parts use helpers of earlier ones) ----
 #include "kernels_extract.h"
 #include "kernels_sync.h"
