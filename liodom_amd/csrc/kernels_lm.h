@@ -717,6 +717,7 @@ __global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int 
     // the model's prediction fails once it tends to fail again (the first scans of a young window converge more slowly): the next
     // spec_backoff (16) solves of this kind hand nothing over early
     st.spec_eval[outer_it] = (spec_done && sh_nmoved != spec_moves) ? v.spec_backoff : (sh_spec_at > 0 ? sh_spec_at - 1 : 0);
+    if (spec_done) { st.spec_stats[2 * outer_it] += 1; if (sh_nmoved != spec_moves) st.spec_stats[2 * outer_it + 1] += 1; }
     if (outer_it == 0) st.info.lm[0] = sh_trace;      // (read by the finalising solve's launch; the finalising solve's own trace travels through LDS)
     if (outer_it == 1) st.append_raw = 0;
   }

@@ -2021,16 +2021,20 @@ int liodom_get_modes(liodom_handle_t* h, char* buf, int cap) {
   if (int rc = enter(h)) return rc;
   SideLocks lk(h, true, true);
   const DevView& v = h->v;
+  // (speculative hand-overs of stream 0 since the last reset: the launches enqueued so far have to have run for the figures to mean
+  //  anything — a caller that wants them synchronises first; this call does not)
+  int spec[4] = {0, 0, 0, 0};
+  (void)hipMemcpy(spec, reinterpret_cast<const char*>(v.state) + offsetof(StreamState, spec_stats), sizeof(spec), hipMemcpyDeviceToHost);
   snprintf(buf, (size_t)cap,
            "n_streams=%d early_rebuild=%d hash_build=%s pipe_flags=%d flag_gate=%d lm_groups=%d knn_instance=%d knn_queries=%d "
            "knn_grid=%d/%d knn8=%d knn_partials=%d knn_saved_bound=%d knn_exact_only=%d line_gate_kernel=%d filter_local_map=%d mapping=%d "
-           "rotation_mode=%d table_size=%d rebuild_delta=%.3f knn_overlap=%d streams_concurrent=%d safe_mode=%d ring_split=%d ring_split_max_wgs=%d chain=%d speculate=%d replay_enqueue_us=%.2f replay_wait_us=%.2f debug=%d",
+           "rotation_mode=%d table_size=%d rebuild_delta=%.3f knn_overlap=%d streams_concurrent=%d safe_mode=%d ring_split=%d ring_split_max_wgs=%d chain=%d speculate=%d spec_early=%d/%d spec_unconfirmed=%d/%d replay_enqueue_us=%.2f replay_wait_us=%.2f debug=%d",
            h->S, v.early_rebuild, v.early_rebuild ? "streamed" : (h->lds_hash_build ? "lds" : "global"), h->use_flags ? 1 : 0,
            (h->use_flags && h->flag_gate) ? 1 : 0, v.lm_groups, h->S >= 16 ? 128 : 256, v.knn_queries, v.knn_grid,
            v.knn_blocks, h->knn8 ? 1 : 0, v.knn_partials, v.knn_save_pos ? 2 : (v.knn_save_q ? 1 : 0), v.knn_exact_only, v.knn_nn ? 1 : 0, v.filter_local_map, v.mapping,
            v.rotation_mode, v.table_size, (double)v.rebuild_delta,
            (v.early_rebuild && (h->ov_ok || (h->chain_ok && !h->flag_gate)) && h->use_flags && g_live_handles.load() <= 1) ? 1 : 0, h->streams_concurrent ? 1 : 0, h->safe_mode ? 1 : 0, h->ring_split ? 1 : 0, h->ring_split ? h->ring_split_max_wgs : 0,
-           (v.early_rebuild && h->chain_ok && h->use_flags && !h->flag_gate && g_live_handles.load() <= 1) ? 1 : 0, v.speculate,
+           (v.early_rebuild && h->chain_ok && h->use_flags && !h->flag_gate && g_live_handles.load() <= 1) ? 1 : 0, v.speculate, spec[0], spec[2], spec[1], spec[3],
            h->replay_timed ? h->replay_enq_ns / (1e3 * (double)h->replay_timed) : 0.0, h->replay_timed ? h->replay_wait_ns / (1e3 * (double)h->replay_timed) : 0.0, v.debug);
   return LIODOM_OK;
 }

@@ -95,6 +95,8 @@ struct StreamState {
   int32_t reb_pad;        // chain mode: the scan's edge count as PAD saw it (APPEND iterates over it, see edges_keep)
   int32_t spec_eval[2];   // speculative hand-over (kernels_sync.h), back-off: first / finalising solves still to sit out after a hand-over that was
                           // not confirmed
+  int32_t spec_stats[4];  // ... how it went since the last reset: first solve's iterates handed over early, of them not confirmed; the same for the
+                          // finalising solve (liodom_get_modes: spec_early / spec_unconfirmed)
   double pred_odom[2][12]; // early_rebuild: the prediction the scan started from ([frames appended so far & 1]: the repair of a speculative hand-over
                           // that was not confirmed, kernels_sync.h, needs the previous scan's while the next scan's is already there),
                           // snapshot taken by the scan's first kNN launch: st.odom moves
