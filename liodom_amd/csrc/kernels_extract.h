@@ -113,6 +113,9 @@ __host__ __device__ __forceinline__ size_t ring_scatter_stage_bytes(int H) {
 __host__ __device__ __forceinline__ size_t ring_scatter_lds_bytes(int H) {
   return ring_scatter_stage_bytes(H) + (size_t)(2 * H + 2 * 16) * 4;
 }
+__host__ __device__ __forceinline__ size_t ring_split_lb_lds_bytes(int H) {      // + rlim [H]
+  return ring_scatter_stage_bytes(H) + (size_t)(3 * H + 16) * 4;
+}
 
 // staging-slot swizzles of k_ring_scatter (bijections on [0, 2048)): 16-byte elements have 16 bank groups (low 4 bits of
 // the slot), 4-byte elements 64 banks (low 6 bits); the XOR term is constant over an aligned run of 32 / 64 slots
@@ -214,8 +217,8 @@ __global__ __launch_bounds__(kTileThreads) void k_ring_scatter(DevView v, int s0
   __syncthreads();
   // Staging slots are ring-major, so consecutive lanes now write consecutive positions of a ring:
   // ~32-point (512-byte) runs instead of 64 different rings per wave store.
-  float4* out = v.ring_pts + (size_t)s * v.max_points;
-  int* osrc = v.ring_src + (size_t)s * v.max_points;
+  float4* out = v.ring_pts + (size_t)s * v.ring_stride;
+  int* osrc = v.ring_src + (size_t)s * v.ring_stride;
   const int nvalid = wloc[0] + wloc[1] + wloc[2] + wloc[3] + wloc[4] + wloc[5] + wloc[6] + wloc[7];
   for (int p = tid; p < nvalid; p += kTileThreads) {
     const int d = sdst[stage_swz4(p)];
@@ -388,14 +391,268 @@ __global__ __launch_bounds__(kTileThreads) void k_ring_split(DevView v, int s0, 
     }
   }
   __syncthreads();
-  float4* out = v.ring_pts + (size_t)s * v.max_points;
-  int* osrc = v.ring_src + (size_t)s * v.max_points;
+  float4* out = v.ring_pts + (size_t)s * v.ring_stride;
+  int* osrc = v.ring_src + (size_t)s * v.ring_stride;
   const int nvalid = wloc[0] + wloc[1] + wloc[2] + wloc[3] + wloc[4] + wloc[5] + wloc[6] + wloc[7];
   for (int q = tid; q < nvalid; q += kTileThreads) {
     const int d = sdst[stage_swz4(q)];
     out[d] = spts[stage_swz16(q)];
     osrc[d] = ssrc[stage_swz4(q)];
   }
+}
+
+// =============================================================================================
+// k_ring_split_lb (lock-step batches, round 6): the ring split in ONE pass over the scan for any number of streams.
+// k_ring_split above waits for ALL tiles of its stream (ring starts of the compact layout = totals over every tile), which needs
+// every workgroup of the launch resident and lost 3x on batches.  Here the rings have a FIXED PITCH — ring r of a stream starts at
+// r * ring_pitch (9/8 of the nominal ring length; k_ring_extract takes starts and lengths from ring_start / ring_len, as for the
+// organised clouds of k_row_compact) — so a tile needs only the counts of the tiles BEFORE it:
+//   * workgroups take their (stream, tile) from a ticket counter in start order, stream-major: a tile's predecessors have all
+//     started before it — no workgroup ever waits for one that has not started, whatever the launch's size;
+//   * a tile publishes its per-ring counts as tagged 8-byte words {launch tag, count} (agent-scope stores: the eight L2s are not
+//     coherent) right after the classification, and sums its predecessors' words as they appear — all of them in flight at once
+//     (thread (w, r) takes the tiles w, w + G, ... for ring r; a stream's 57 tiles start within microseconds of each other, so this
+//     is one or two round trips, not a chain of look-backs);
+//   * the points stay in registers between classification and scatter: the scan is read once, no id bytes, no second launch.
+// A ring that outgrows its pitch (more than 9/8 of the nominal length: not a spinning LiDAR, but the reference takes any cloud)
+// raises lb_ovf[stream]; the points beyond the pitch are not written, and k_ring_split_fix — one workgroup per stream, behind this
+// launch, idle unless the flag is up — redoes that stream's split into the compact layout, tile by tile.
+// =============================================================================================
+__device__ __forceinline__ void ring_tile_masks_prefix(unsigned long long* wmask, unsigned short* cbase, int H, int Hp, int wave, int lane) {
+  // prefix over the 32 chunks for every ring: one half-wave per ring
+  for (int r = wave * 2 + (lane >> 5); r < H; r += 2 * (kTileThreads / 64)) {
+    const int c = lane & 31;
+    const int cnt = __popcll(wmask[c * Hp + r]);
+    const int ic = half_incl_scan_i32(cnt);
+    cbase[c * Hp + r] = (unsigned short)(ic - cnt);
+  }
+}
+
+__global__ __launch_bounds__(kTileThreads) void k_ring_split_lb(DevView v, int s0, const float4* __restrict__ in, size_t in_stride, int n,
+                                                                int height, int width, int ntiles, unsigned int tag) {
+  typedef __attribute__((address_space(1))) unsigned long long gu64;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ int hist[256];
+  __shared__ int sh_pre[256];
+  __shared__ int sh_ticket, sh_ok;
+  const int H = v.scan_lines;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < 256) { hist[tid] = 0; sh_pre[tid] = 0; }
+  if (tid == 0) { sh_ticket = (int)atomicAdd(v.lb_ticket, 1u); sh_ok = 1; }
+  __syncthreads();
+  const int sy = sh_ticket / ntiles, tile = sh_ticket - sy * ntiles;      // stream-major: the tiles before this one have started
+  const int s = s0 + sy;
+  const int Hp = ring_scatter_stride(H);
+  unsigned long long* wmask = reinterpret_cast<unsigned long long*>(smem);          // [32][Hp]   (phase A)
+  unsigned short* cbase = reinterpret_cast<unsigned short*>(wmask + kTileChunks * Hp);  // [32][Hp]   (phase A)
+  float4* spts = reinterpret_cast<float4*>(smem);                                   // [2048]     (phase B, same bytes)
+  int* sdst = reinterpret_cast<int*>(smem + (size_t)kTilePts * 16);                 // [2048]
+  int* ssrc = sdst + kTilePts;                                                      // [2048]
+  int* rbase = reinterpret_cast<int*>(smem + ring_scatter_stage_bytes(H));          // [H] first position of this tile's points of the ring
+  int* lofs = rbase + H;                                                            // [H] first staging slot of the ring
+  int* rlim = lofs + H;                                                             // [H] end of the ring's segment
+  int* wloc = rlim + H;                                                             // [8] this tile's counts per wave
+  for (int k = tid; k < kTileChunks * Hp; k += kTileThreads) wmask[k] = 0ull;
+  // ---- classify (k_classify) ----
+  float4 p[4];
+  int id[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int i = tile * kTilePts + j * kTileThreads + tid;
+    if (i < n) p[j] = in[(size_t)sy * in_stride + i];
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int i = tile * kTilePts + j * kTileThreads + tid;
+    id[j] = 0xFF;
+    if (i < n) {
+      id[j] = (int)classify_point(v, p[j], i, H, height, width);
+      if (id[j] != 0xFF) atomicAdd(&hist[id[j]], 1);
+    }
+  }
+  __syncthreads();
+  // ---- publish this tile's counts; lane masks meanwhile ----
+  unsigned long long* desc = v.lb_desc + (size_t)s * v.tile_cap * v.lb_hpad;
+  if (tid < H) __hip_atomic_store((gu64*)(desc + (size_t)tile * v.lb_hpad + tid), ((unsigned long long)tag << 32) | (unsigned int)hist[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+    if (id[j] != 0xFF) atomicOr(&wmask[(j * (kTileThreads / 64) + wave) * Hp + id[j]], 1ull << lane);
+  // ---- the counts of the tiles before this one: thread (w, r) takes tiles w, w + G, ... of ring r, eight loads in flight ----
+  {
+    const int G = kTileThreads / H > 0 ? kTileThreads / H : 1;      // (H <= 254 < 512)
+    const int r = tid % H, w = tid / H;
+    if (w < G) {
+      int sum = 0;
+      unsigned int spins = 0;
+      unsigned long long t0w = 0;
+      for (int t0 = w; t0 < tile; t0 += 8 * G) {         // batches of eight predecessors
+        unsigned int pend = 0u;
+#pragma unroll
+        for (int k = 0; k < 8; k++) pend |= (t0 + k * G < tile) ? (1u << k) : 0u;
+        while (pend) {
+          unsigned long long d[8];
+#pragma unroll
+          for (int k = 0; k < 8; k++) {
+            const int t = t0 + k * G < tile ? t0 + k * G : w;          // (clamped: the loads leave together, results are masked)
+            d[k] = __hip_atomic_load((gu64*)(desc + (size_t)t * v.lb_hpad + r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+#pragma unroll
+          for (int k = 0; k < 8; k++) {
+            if (((pend >> k) & 1u) && (unsigned int)(d[k] >> 32) == tag) { sum += (int)(unsigned int)d[k]; pend &= ~(1u << k); }
+          }
+          if (!pend) break;
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > 4000000u || wait_expired(spins, t0w)) { sh_ok = 0; atomicOr(&v.state[s].status, LIODOM_STATUS_PIPE_TIMEOUT); pend = 0u; t0 = tile; }
+        }
+      }
+      if (sum) atomicAdd(&sh_pre[r], sum);
+    }
+  }
+  __syncthreads();
+  ring_tile_masks_prefix(wmask, cbase, H, Hp, wave, lane);
+  // staging offsets: exclusive scan of this tile's counts over the rings
+  const int mine = tid < H ? hist[tid] : 0;
+  const int incl_l = wave_incl_scan_i32(mine);
+  if (lane == 63) wloc[wave] = incl_l;
+  __syncthreads();
+  if (!sh_ok) return;
+  {
+    int base_l = 0;
+    for (int w = 0; w < wave; w++) base_l += wloc[w];
+    if (tid < H) {
+      const int pitch = v.ring_pitch;
+      const int pre = sh_pre[tid];
+      rbase[tid] = tid * pitch + pre;
+      rlim[tid] = (tid + 1) * pitch;
+      lofs[tid] = base_l + incl_l - mine;
+      if (pre + mine > pitch) atomicOr(&v.lb_ovf[s], 1u);
+      if (tile == 0) v.ring_start[(size_t)s * (H + 1) + tid] = tid * pitch;
+      if (tile == ntiles - 1) { const int tot = pre + mine; v.ring_len[(size_t)s * H + tid] = tot < pitch ? tot : pitch; }
+    }
+    if (tile == 0 && tid == H - 1) v.ring_start[(size_t)s * (H + 1) + H] = H * v.ring_pitch;
+  }
+  __syncthreads();
+  const unsigned long long below = (1ull << lane) - 1ull;
+  int slot[4], dst[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    slot[j] = -1; dst[j] = -1;
+    if (id[j] != 0xFF) {
+      const int chunk = j * (kTileThreads / 64) + wave;
+      const int rank = (int)cbase[chunk * Hp + id[j]] + __popcll(wmask[chunk * Hp + id[j]] & below);
+      slot[j] = lofs[id[j]] + rank;
+      const int d = rbase[id[j]] + rank;
+      dst[j] = d < rlim[id[j]] ? d : -1;                 // (beyond the pitch: k_ring_split_fix redoes the stream)
+    }
+  }
+  __syncthreads();                  // masks / prefixes are dead: their bytes become the staging tile
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    if (slot[j] >= 0) {
+      const int i = tile * kTilePts + j * kTileThreads + tid;
+      spts[stage_swz16(slot[j])] = p[j];
+      sdst[stage_swz4(slot[j])] = dst[j];
+      ssrc[stage_swz4(slot[j])] = i;
+    }
+  }
+  __syncthreads();
+  float4* out = v.ring_pts + (size_t)s * v.ring_stride;
+  int* osrc = v.ring_src + (size_t)s * v.ring_stride;
+  const int nvalid = wloc[0] + wloc[1] + wloc[2] + wloc[3] + wloc[4] + wloc[5] + wloc[6] + wloc[7];
+  for (int q = tid; q < nvalid; q += kTileThreads) {
+    const int d = sdst[stage_swz4(q)];
+    if (d >= 0) {
+      out[d] = spts[stage_swz16(q)];
+      osrc[d] = ssrc[stage_swz4(q)];
+    }
+  }
+}
+
+// One workgroup per stream behind k_ring_split_lb: nothing to do unless a ring of the stream outgrew its pitch; then the stream's
+// split once more, into the COMPACT layout (ring starts = running totals, as k_ring_scatter writes it: any ring length up to the
+// scan itself fits), tile by tile: a first sweep counts, a second places every point at ring start + points of the ring in earlier
+// tiles + rank inside the tile (stable: feature_extractor.cc:115-175 appends in input order).  Slow — one workgroup walks the
+// whole scan twice — and only ever run for clouds no spinning LiDAR produces.
+__global__ __launch_bounds__(kTileThreads) void k_ring_split_fix(DevView v, int s0, const float4* __restrict__ in, size_t in_stride, int n,
+                                                                 int height, int width, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ int tot[256];          // points of every ring (first sweep), then its running position (second sweep)
+  __shared__ int wtot[16];
+  const int sy = blockIdx.y, s = s0 + sy;
+  if (!v.lb_ovf[s]) return;         // (uniform)
+  const int H = v.scan_lines;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Hp = ring_scatter_stride(H);
+  unsigned long long* wmask = reinterpret_cast<unsigned long long*>(smem);
+  unsigned short* cbase = reinterpret_cast<unsigned short*>(wmask + kTileChunks * Hp);
+  if (tid < 256) tot[tid] = 0;
+  __syncthreads();
+  for (int tile = 0; tile < ntiles; tile++) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int i = tile * kTilePts + j * kTileThreads + tid;
+      if (i < n) {
+        const int id = (int)classify_point(v, in[(size_t)sy * in_stride + i], i, H, height, width);
+        if (id != 0xFF) atomicAdd(&tot[id], 1);
+      }
+    }
+  }
+  __syncthreads();
+  {
+    // ring starts: exclusive scan of the totals over the rings (H <= 254)
+    const int mine = tid < H ? tot[tid] : 0;
+    const int incl = wave_incl_scan_i32(mine);
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; w++) base += wtot[w];
+    const int rstart = base + incl - mine;
+    __syncthreads();
+    if (tid < H) {
+      v.ring_start[(size_t)s * (H + 1) + tid] = rstart;
+      v.ring_len[(size_t)s * H + tid] = mine;
+      tot[tid] = rstart;                                 // running position of the ring
+    }
+    if (tid == H - 1) v.ring_start[(size_t)s * (H + 1) + H] = rstart + mine;
+  }
+  __syncthreads();
+  float4* out = v.ring_pts + (size_t)s * v.ring_stride;
+  int* osrc = v.ring_src + (size_t)s * v.ring_stride;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  for (int tile = 0; tile < ntiles; tile++) {
+    for (int k = tid; k < kTileChunks * Hp; k += kTileThreads) wmask[k] = 0ull;
+    __syncthreads();
+    float4 p[4];
+    int id[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int i = tile * kTilePts + j * kTileThreads + tid;
+      id[j] = 0xFF;
+      if (i < n) {
+        p[j] = in[(size_t)sy * in_stride + i];
+        id[j] = (int)classify_point(v, p[j], i, H, height, width);
+        if (id[j] != 0xFF) atomicOr(&wmask[(j * (kTileThreads / 64) + wave) * Hp + id[j]], 1ull << lane);
+      }
+    }
+    __syncthreads();
+    ring_tile_masks_prefix(wmask, cbase, H, Hp, wave, lane);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (id[j] != 0xFF) {
+        const int chunk = j * (kTileThreads / 64) + wave;
+        const int rank = (int)cbase[chunk * Hp + id[j]] + __popcll(wmask[chunk * Hp + id[j]] & below);
+        const int d = tot[id[j]] + rank;
+        out[d] = p[j];
+        osrc[d] = tile * kTilePts + j * kTileThreads + tid;
+      }
+    }
+    __syncthreads();
+    // advance the rings' running positions by this tile's counts (chunk 31's prefix + its own count)
+    if (tid < H) tot[tid] += (int)cbase[(kTileChunks - 1) * Hp + tid] + __popcll(wmask[(kTileChunks - 1) * Hp + tid]);
+    __syncthreads();
+  }
+  if (tid == 0) v.lb_ovf[s] = 0u;
 }
 
 // =============================================================================================
@@ -414,8 +671,8 @@ __global__ __launch_bounds__(kRowThreads) void k_row_compact(DevView v, int s0, 
   const int s = s0 + blockIdx.y, row = blockIdx.x, H = v.scan_lines;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float4* src = in + (size_t)blockIdx.y * in_stride;
-  float4* out = v.ring_pts + (size_t)s * v.max_points + (size_t)row * width;
-  int* osrc = v.ring_src + (size_t)s * v.max_points + (size_t)row * width;
+  float4* out = v.ring_pts + (size_t)s * v.ring_stride + (size_t)row * width;
+  int* osrc = v.ring_src + (size_t)s * v.ring_stride + (size_t)row * width;
   if (tid == 0) { s_base = 0; v.ring_start[(size_t)s * (H + 1) + row] = row * width; if (row == H - 1) v.ring_start[(size_t)s * (H + 1) + H] = H * width; }
   int total = 0;
   if (row < height && (size_t)(row + 1) * (size_t)width <= (size_t)v.max_points) {
@@ -832,9 +1089,9 @@ __device__ __forceinline__ void ring_extract_ring(const DevView& v, int s, int r
   // ---- the ring's points are contiguous in the ring-sorted copy written by k_ring_scatter ----
   const int rbeg = v.ring_start[(size_t)s * (H + 1) + ring];
   const int nr = v.ring_len[(size_t)s * H + ring];
-  const float4* rpts = v.ring_pts + (size_t)s * v.max_points + rbeg;
-  const int* rsrc = v.ring_src + (size_t)s * v.max_points + rbeg;
-  double* rc = v.ring_c + (size_t)s * v.max_points + rbeg;                // debug dump / generic-path scratch
+  const float4* rpts = v.ring_pts + (size_t)s * v.ring_stride + rbeg;
+  const int* rsrc = v.ring_src + (size_t)s * v.ring_stride + rbeg;
+  double* rc = v.ring_c + (size_t)s * v.ring_stride + rbeg;                // debug dump / generic-path scratch
   const bool dump = (v.debug & 1) != 0;
   if (tid == 0) *npoints_out = nr;
   // rings below min_points_per_scan are skipped (feature_extractor.cc:188)
@@ -856,7 +1113,7 @@ __device__ __forceinline__ void ring_extract_ring(const DevView& v, int s, int r
     ring_select_rows<IPL>(v, rpts, rc, dump, nr, total, sector, R, epr, ppr, gb, pick_idx, pick_nfnb, region_cnt, used_mask, new_mask, flags, dbgb, dbg_rounds);
   } else {
     // ---- generic path: curvature + marks in global scratch, regions in order on one wave ----
-    unsigned char* picked = v.ring_picked + (size_t)s * v.max_points + rbeg;
+    unsigned char* picked = v.ring_picked + (size_t)s * v.ring_stride + rbeg;
     for (int j = 5 + tid; j < nr - 5; j += nthreads) {
       rc[j] = curvature_at(rpts, j);
       picked[j] = 0;                                                // :230
@@ -904,5 +1161,6 @@ __global__ __launch_bounds__(kMaxThreads) void k_ring_extract(DevView v, int s0)
   if (v.split_ctr && blockIdx.x == 0 && threadIdx.x == 0) {      // (k_ring_split's counters, for the next scan)
     v.split_ctr[2 * (s0 + (int)blockIdx.y) + 1] = 0u;
   }
+  if (v.lb_ticket && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *v.lb_ticket = 0u;      // (k_ring_split_lb's ticket counter)
   ring_extract_ring<IPL>(v, s0 + (int)blockIdx.y, (int)blockIdx.x, smem);
 }

@@ -130,6 +130,8 @@ struct liodom_handle {
                                      // uploaded by a copy call.  Measured slower (shader loads reach the host as 64-byte PCIe reads: two-thread
                                      // binding 10.3k -> 9.0k scans/s, host-fed replay 11.5k -> 8.9k): off by default
   bool safe_mode = false;            // no in-kernel waits at all: events between the streams, one workgroup per solve, three-kernel hash rebuild
+  bool ring_split_lb = false;        // lock-step batches: k_ring_split_lb (one pass, rings at a fixed pitch, predecessors' counts summed as they appear); LIODOM_RING_SPLIT_LB=0: k_classify + k_ring_scatter
+  unsigned int lb_tag = 0;           // launch tag its count words carry
   bool ring_split = true;            // ring split in one pass (k_ring_split) where every workgroup of the launch is resident at once; LIODOM_RING_SPLIT=0: always k_classify + k_ring_scatter
   int ring_split_max_wgs = 0;        // ... i.e. launches of at most this many workgroups (liodom_create: occupancy of k_ring_split x CUs, with headroom for the odometry chain's kernels)
   bool streams_concurrent = true;    // liodom_create's probe: kernels of two streams of this handle ran side by side
@@ -251,7 +253,13 @@ int launch_extract(liodom_handle* h, hipStream_t q, int eb, int s0, int count, c
     ProfScope ps(h, KID_RING_SCATTER, q);
     hipLaunchKernelGGL(k_row_compact, dim3(h->H, count), dim3(kRowThreads), 0, q, v, s0, host_in ? host_in : in, host_in ? host_stride : in_stride, n, height, width);
   } else {
-    if (h->ring_split && !host_in && (long long)tiles * count <= h->ring_split_max_wgs) {      // (every workgroup resident at once: k_ring_split waits inside the launch)
+    if (h->ring_split_lb && !host_in && !((long long)tiles * count <= h->ring_split_max_wgs && h->ring_split)) {
+      // lock-step batches: one pass, rings at a fixed pitch, tiles sum their predecessors' counts (booked as the scatter)
+      ProfScope ps(h, KID_RING_SCATTER, q);
+      if (++h->lb_tag == 0u) h->lb_tag = 1u;
+      hipLaunchKernelGGL(k_ring_split_lb, dim3(tiles * count), dim3(kTileThreads), ring_split_lb_lds_bytes(h->H), q, v, s0, in, in_stride, n, height, width, tiles, h->lb_tag);
+      hipLaunchKernelGGL(k_ring_split_fix, dim3(1, count), dim3(kTileThreads), ring_split_lb_lds_bytes(h->H), q, v, s0, in, in_stride, n, height, width, tiles);
+    } else if (h->ring_split && !host_in && (long long)tiles * count <= h->ring_split_max_wgs) {      // (every workgroup resident at once: k_ring_split waits inside the launch)
       // one pass: classification and scatter in one kernel (booked as the scatter)
       ProfScope ps(h, KID_RING_SCATTER, q);
       hipLaunchKernelGGL(k_ring_split, dim3(tiles, count), dim3(kTileThreads), ring_scatter_lds_bytes(h->H), q, v, s0, in, in_stride, n, height, width);
@@ -605,6 +613,7 @@ void enter_safe_mode(liodom_handle* h) {
   h->v.lm_groups = 1;
   h->v.early_rebuild = 0;      // (the second table, the padding and the overflow list stay allocated and unused)
   h->ring_split = false;       // k_ring_split's workgroups wait for each other inside the launch: k_classify + k_ring_scatter instead
+  h->ring_split_lb = false;    // (k_ring_split_lb's tiles wait for their predecessors' counts; the pitched buffers stay allocated)
 }
 
 int reset_state(liodom_handle* h) {
@@ -622,6 +631,7 @@ int reset_state(liodom_handle* h) {
     st.table_mask = (uint32_t)h->v.table_size - 1u;
   }
   HIP_TRY(hipMemcpyAsync(h->v.state, init.data(), sizeof(StreamState) * init.size(), hipMemcpyHostToDevice, h->stream));
+  if (h->v.lb_ticket) { HIP_TRY(hipMemsetAsync(h->v.lb_ticket, 0, sizeof(unsigned int), h->stream)); HIP_TRY(hipMemsetAsync(h->v.lb_ovf, 0, sizeof(unsigned int) * (size_t)h->S, h->stream)); }
   {
     std::vector<double> qid((size_t)h->S * 4, 0.0);          // IMU orientation: identity until imuClb delivers one
     for (int s = 0; s < h->S; s++) qid[(size_t)s * 4 + 3] = 1.0;
@@ -826,8 +836,23 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   ALLOC(v.tile_hist, S * (size_t)v.tile_cap * h->H, 0);
   // + padding: region_keys_load reads unconditionally up to 16 * IPL + 10 points past the start of a ring's last region,
   // i.e. up to kExLPR * kExIPLBig + 10 points past the end of the last ring of the last stream (values never used)
-  ALLOC(v.ring_pts, S * (size_t)config->max_points + kExLPR * kExIPLBig + 64, 0);
-  ALLOC(v.ring_src, S * (size_t)config->max_points, 0);
+  // k_ring_split_lb (lock-step batches of Velodyne-type clouds): rings at a fixed pitch of 9/8 of the nominal ring length
+  h->ring_split_lb = config->n_streams >= 16 && params->lidar_type == 0 && !h->safe_mode;
+  if (const char* e = std::getenv("LIODOM_RING_SPLIT_LB")) h->ring_split_lb = h->ring_split_lb && std::atoi(e) != 0;
+  v.ring_pitch = round_up(cdiv((long long)config->max_points * 9, (long long)std::max(1, h->H) * 8), 8);
+  if (const char* e = std::getenv("LIODOM_RING_PITCH")) v.ring_pitch = std::max(8, std::atoi(e));      // (tests: a pitch that real rings outgrow)
+  v.ring_stride = h->ring_split_lb ? std::max((size_t)config->max_points, (size_t)h->H * (size_t)v.ring_pitch) : (size_t)config->max_points;
+  v.lb_hpad = round_up(h->H, 64);
+  if (h->ring_split_lb) {
+    ALLOC(v.lb_desc, S * (size_t)v.tile_cap * v.lb_hpad, 0); ALLOC(v.lb_ticket, 1, 0); ALLOC(v.lb_ovf, S, 0);
+    const size_t lds = ring_split_lb_lds_bytes(h->H);
+    if (lds > 48 * 1024 && (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ring_split_lb), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+                            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ring_split_fix), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)) {
+      (void)hipGetLastError(); h->ring_split_lb = false;
+    }
+  } else { v.lb_desc = nullptr; v.lb_ticket = nullptr; v.lb_ovf = nullptr; }
+  ALLOC(v.ring_pts, S * v.ring_stride + kExLPR * kExIPLBig + 64, 0);
+  ALLOC(v.ring_src, S * v.ring_stride, 0);
   ALLOC(v.ring_start, S * (size_t)(h->H + 1), 0);
   ALLOC(v.ring_len, S * (size_t)h->H, 0);
   ALLOC(v.edges_pad, S * h->H * v.slots_per_ring, 0);
@@ -862,8 +887,8 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
     if (h->ring_split) { ALLOC(v.split_ctr, 2 * S, 0); ALLOC(v.split_hist, S * (size_t)h->H * v.split_pad + 64, 0); }      // (+ one batch of 64 tiles: k_ring_split reads whole batches)
   }
   ALLOC(v.ring_npoints, S * h->H, 0);
-  ALLOC(v.ring_c, S * (size_t)config->max_points, 0);
-  ALLOC(v.ring_picked, S * (size_t)config->max_points, 0);
+  ALLOC(v.ring_c, S * v.ring_stride, 0);
+  ALLOC(v.ring_picked, S * v.ring_stride, 0);
   ALLOC(v.edges, kEdgeBufs * S * v.edge_cap, 0);
   ALLOC(v.edges_meta, kEdgeBufs * S * v.edge_cap, 0);
   ALLOC(v.corr_a, S * 2 * v.edge_cap, 0);
@@ -1932,7 +1957,7 @@ int liodom_get_curvature(liodom_handle_t* h, int stream, double* curv, int64_t c
   if (off > cap) { g_last_error = "curvature buffer too small"; return LIODOM_ERR_CAPACITY; }
   int64_t o = 0;
   for (int r = 0; r < h->H && curv; r++) {
-    if (rl[r]) HIP_TRY(hipMemcpy(curv + o, h->v.ring_c + (size_t)stream * h->v.max_points + rs[r], sizeof(double) * (size_t)rl[r], hipMemcpyDeviceToHost));
+    if (rl[r]) HIP_TRY(hipMemcpy(curv + o, h->v.ring_c + (size_t)stream * h->v.ring_stride + rs[r], sizeof(double) * (size_t)rl[r], hipMemcpyDeviceToHost));
     o += rl[r];
   }
   return LIODOM_OK;
@@ -2028,12 +2053,12 @@ int liodom_get_modes(liodom_handle_t* h, char* buf, int cap) {
   snprintf(buf, (size_t)cap,
            "n_streams=%d early_rebuild=%d hash_build=%s pipe_flags=%d flag_gate=%d lm_groups=%d knn_instance=%d knn_queries=%d "
            "knn_grid=%d/%d knn8=%d knn_partials=%d knn_saved_bound=%d knn_exact_only=%d line_gate_kernel=%d filter_local_map=%d mapping=%d "
-           "rotation_mode=%d table_size=%d rebuild_delta=%.3f knn_overlap=%d streams_concurrent=%d safe_mode=%d ring_split=%d ring_split_max_wgs=%d chain=%d speculate=%d spec_early=%d/%d spec_unconfirmed=%d/%d replay_enqueue_us=%.2f replay_wait_us=%.2f debug=%d",
+           "rotation_mode=%d table_size=%d rebuild_delta=%.3f knn_overlap=%d streams_concurrent=%d safe_mode=%d ring_split=%d ring_split_max_wgs=%d ring_split_lb=%d chain=%d speculate=%d spec_early=%d/%d spec_unconfirmed=%d/%d replay_enqueue_us=%.2f replay_wait_us=%.2f debug=%d",
            h->S, v.early_rebuild, v.early_rebuild ? "streamed" : (h->lds_hash_build ? "lds" : "global"), h->use_flags ? 1 : 0,
            (h->use_flags && h->flag_gate) ? 1 : 0, v.lm_groups, h->S >= 16 ? 128 : 256, v.knn_queries, v.knn_grid,
            v.knn_blocks, h->knn8 ? 1 : 0, v.knn_partials, v.knn_save_pos ? 2 : (v.knn_save_q ? 1 : 0), v.knn_exact_only, v.knn_nn ? 1 : 0, v.filter_local_map, v.mapping,
            v.rotation_mode, v.table_size, (double)v.rebuild_delta,
-           (v.early_rebuild && (h->ov_ok || (h->chain_ok && !h->flag_gate)) && h->use_flags && g_live_handles.load() <= 1) ? 1 : 0, h->streams_concurrent ? 1 : 0, h->safe_mode ? 1 : 0, h->ring_split ? 1 : 0, h->ring_split ? h->ring_split_max_wgs : 0,
+           (v.early_rebuild && (h->ov_ok || (h->chain_ok && !h->flag_gate)) && h->use_flags && g_live_handles.load() <= 1) ? 1 : 0, h->streams_concurrent ? 1 : 0, h->safe_mode ? 1 : 0, h->ring_split ? 1 : 0, h->ring_split ? h->ring_split_max_wgs : 0, h->ring_split_lb ? 1 : 0,
            (v.early_rebuild && h->chain_ok && h->use_flags && !h->flag_gate && g_live_handles.load() <= 1) ? 1 : 0, v.speculate, spec[0], spec[2], spec[1], spec[3],
            h->replay_timed ? h->replay_enq_ns / (1e3 * (double)h->replay_timed) : 0.0, h->replay_timed ? h->replay_wait_ns / (1e3 * (double)h->replay_timed) : 0.0, v.debug);
   return LIODOM_OK;

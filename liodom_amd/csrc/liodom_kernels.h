@@ -154,6 +154,12 @@ struct DevView {
   int* ring_nedges;         // [S][H]
   unsigned short* split_hist; int split_pad;   // [S][H][split_pad] k_ring_split: points per (ring, 2048-point tile); split_pad = tiles rounded up to 8
   unsigned int* split_ctr;  // [2 S] k_ring_split: tiles of stream s that have published their histogram [2 s + 1]
+  // k_ring_split_lb (lock-step batches): rings at a fixed pitch, tiles sum their predecessors' tagged counts
+  unsigned long long* lb_desc;   // [S][tile_cap][lb_hpad] {launch tag, points of (tile, ring)}
+  unsigned int* lb_ticket;       // [1] tiles started in the current launch (k_ring_extract zeroes it)
+  unsigned int* lb_ovf;          // [S] a ring of the stream outgrew its pitch: k_ring_split_fix redoes the stream
+  int lb_hpad, ring_pitch;       // row of lb_desc (H rounded up to 64); points a ring may hold in the pitched layout
+  size_t ring_stride;            // per-stream stride of ring_pts / ring_src / ring_c / ring_picked (>= max_points, >= H * ring_pitch)
   int* ring_npoints;        // [S][H]
   double* ring_c;           // [S][max_points] smoothness per ring-sorted point: debug dump (debug & 1) and generic-path scratch
   unsigned char* ring_picked;  // [S][max_points] picked_ marks of the generic path

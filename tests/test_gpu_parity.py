@@ -90,6 +90,40 @@ def test_ring_split_equals_two_kernel_split(orc, synth, monkeypatch, S):
         g.close()
 
 
+@pytest.mark.parametrize("pitch", [None, "1500", "40"])
+def test_ring_split_look_back_on_batches(orc, synth, monkeypatch, pitch):
+    """Lock-step batches split the scan in ONE pass too (k_ring_split_lb): rings at a fixed pitch, tiles take their number from a
+    ticket counter and sum their predecessors' tagged counts as they appear.  16 streams in one launch, ragged scans (tiles, ranks
+    and ring lengths off the regular grid) and regular ones, against the oracle and against k_classify + k_ring_scatter
+    (LIODOM_RING_SPLIT_LB=0).  pitch 1500 (LIODOM_RING_PITCH): the full rings of the regular scans (1800 points) outgrow their
+    segment, the ragged streams' mostly do not — k_ring_split_fix redoes exactly the streams whose flag is up; pitch 40: every ring
+    of every stream.  Matches feature_extractor.cc:104-179 (stable per-ring order)."""
+    H, W, R, epr, S = 64, 1800, 8, 10, 16
+    cfg = synth.make_cfg(H, W, 0)
+    scans = [[(synth.ragged(synth.scan(cfg, 5 + s, k)[0], H, W, 0, seed=100 * s + k) if s % 2 else synth.scan(cfg, 5 + s, k)[0]) for k in (0, 3)] for s in range(4)]
+    want = [[orc.extract(orc.make_params(scan_lines=H, scan_regions=R, edges_per_region=epr), scans[s][k], H, W) for k in range(2)] for s in range(4)]
+    for lb in ("1", "0"):
+        monkeypatch.setenv("LIODOM_RING_SPLIT_LB", lb)
+        if pitch is None:
+            monkeypatch.delenv("LIODOM_RING_PITCH", raising=False)
+        else:
+            monkeypatch.setenv("LIODOM_RING_PITCH", pitch)
+        po, g = mk(orc, H, W, 0, R, epr, S=S)
+        assert g.modes()["ring_split_lb"] == lb
+        g.alloc_resident(2)
+        for s in range(S):
+            for k in range(2):
+                g.upload_scan(s, k, scans[s % 4][k])
+        for k in range(2):      # (two launches: the ticket counter and the tags of the first must not confuse the second)
+            _, infos = g.process_resident(k, H * W, H, W, readback=True)
+            assert all(i.status == 0 for i in infos)
+            for s in range(S):
+                assert_edges_equal(g.get_edges(s), want[s % 4][k])
+        # one stream on its own through the same handle (a launch of 57 workgroups: k_ring_split's domain when it is on)
+        assert_edges_equal(g.extract_edges(scans[1][1], H, W, stream=3), want[1][1])
+        g.close()
+
+
 def test_extract_edge_cases(orc):
     po, g = mk(orc, 16, 1800, 0, 8, 10)
     # empty cloud, all-NaN cloud
