@@ -245,5 +245,5 @@ __global__ __launch_bounds__(256) void k_filt_scatter(DevView v, int s0) {
   if (h < 0) return;
   const size_t ti = (size_t)s * v.table_size + h;
   const unsigned int pos = v.cells[ti].start + (unsigned int)v.pt_rank[(size_t)s * v.map_cap + u];
-  v.sorted_pts[(size_t)s * v.map_cap + pos] = v.filt_pts[(size_t)s * v.map_cap + u];
+  v.sorted_pts[(size_t)s * v.sorted_cap + pos] = v.filt_pts[(size_t)s * v.map_cap + u];
 }

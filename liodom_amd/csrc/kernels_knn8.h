@@ -86,8 +86,10 @@ struct Best3Acc {
 // The group's 8 lanes walk one cell (start, cnt: uniform over the group, 0 = nothing; groups of a wave differ).  The loads of round
 // r + 1 leave before round r is evaluated (a wave holds eight queries and few waves fit a SIMD: the rounds of a cell would otherwise
 // be a chain of dependent memory round trips); loads are unconditional with clamped indices, results masked.
+// min_wi (hash_incr, k_hash_append): candidates whose stored window index lies below it belong to frames the window has dropped
+// since the table was rebuilt — skipped; the others' indices are handed on minus min_wi (their current window index).
 template <class Acc, int U>
-__device__ __forceinline__ void g8_stream_cell(Acc& t, const float4* sp, int start, int cnt, int j, float qx, float qy, float qz) {
+__device__ __forceinline__ void g8_stream_cell(Acc& t, const float4* sp, int start, int cnt, int j, float qx, float qy, float qz, int min_wi) {
   if (cnt <= 0) return;
   const float4* cp = sp + start;
   float4 cur[U];
@@ -100,7 +102,8 @@ __device__ __forceinline__ void g8_stream_cell(Acc& t, const float4* sp, int sta
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const int iu = i + u * kG8;
-      t.consider(iu < cnt, sqdist_cand(qx, qy, qz, cur[u]), __float_as_int(cur[u].w), start + iu);
+      const int wi = __float_as_int(cur[u].w);
+      t.consider(iu < cnt && wi >= min_wi, sqdist_cand(qx, qy, qz, cur[u]), wi - min_wi, start + iu);
     }
 #pragma unroll
     for (int u = 0; u < U; u++) cur[u] = nxt[u];
@@ -167,12 +170,14 @@ __device__ __forceinline__ bool best3_select(const Best3Acc& t, float& d5, int (
 // streamed (inf: none) — the second pass's guard needs it.
 template <class Acc, int U>
 __device__ __forceinline__ float g8_neighbours(Acc& t, const DevView& v, const CellSlot* cells, const unsigned int* bits, unsigned int tmask,
-                                               const float4* sp, int j, int gshift, int cx, int cy, int cz, float qx, float qy, float qz, float B) {
+                                               const float4* sp, int j, int gshift, int cx, int cy, int cz, float qx, float qy, float qz, float B, int min_wi,
+                                               int spill_base, int n_spill) {
   float lb_skipped = __int_as_float(0x7f800000);
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     const int c27 = k * kG8 + j;
     unsigned int start = 0, cnt = 0;
+    if (c27 == 31) { start = (unsigned int)spill_base; cnt = (unsigned int)n_spill; }      // (k_hash_append's spill list rides as a 28th "cell" of every query: lane 7, last round)
     if (c27 < 27 && c27 != 13) {
       int ox, oy, oz;
       const float lb = g8_cell_lb(c27, cx, cy, cz, qx, qy, qz, ox, oy, oz);
@@ -184,7 +189,7 @@ __device__ __forceinline__ float g8_neighbours(Acc& t, const DevView& v, const C
       const int l = __ffs(pend) - 1;
       pend &= pend - 1u;
       const int cs = __shfl((int)start, l, kG8), cc = __shfl((int)cnt, l, kG8);
-      g8_stream_cell<Acc, U>(t, sp, cs, cc, j, qx, qy, qz);
+      g8_stream_cell<Acc, U>(t, sp, cs, cc, j, qx, qy, qz, min_wi);
     }
   }
   return lb_skipped;
@@ -236,6 +241,8 @@ __global__ __launch_bounds__(kKnn8Threads, LIODOM_KNN8_WAVES) void k_knn8(DevVie
   const unsigned int* bits = v.cell_bits + (size_t)stab * (v.table_size >> 5);
   const float4* sp = v.sorted_pts + (size_t)stab * v.sorted_cap;
   const float inf = __int_as_float(0x7f800000);
+  const int min_wi = v.hash_incr ? st.hb_shift : 0;      // (k_hash_append: stored window indices below it are evicted points)
+  const int n_spill = v.hash_incr ? min(st.hb_spill, v.sorted_cap - v.hb_spill_base) : 0;      // ... appended points without a place in a cell: every query scans them
   // first pass: the workgroup's queries are dealt to its groups in the order of their own cells' populations (see below)
   __shared__ float4 sh_q[2][kKnn8Queries];                // query (xyz) and edge number, per parity of the loop
   __shared__ int2 sh_own[2][kKnn8Queries];                // own cell: start, count (-1: no query)
@@ -336,9 +343,9 @@ __global__ __launch_bounds__(kKnn8Threads, LIODOM_KNN8_WAVES) void k_knn8(DevVie
       if (!(outer_it == 0 && kKnn8Sort)) g8_probe(v, cells, bits, tmask, cx, cy, cz, own_start, own_cnt);
       Best3Acc b3;
       b3.clear();
-      g8_stream_cell<Best3Acc, LIODOM_KNN8_U>(b3, sp, (int)own_start, (int)own_cnt, j, qx, qy, qz);
+      g8_stream_cell<Best3Acc, LIODOM_KNN8_U>(b3, sp, (int)own_start, (int)own_cnt, j, qx, qy, qz, min_wi);
       if (!have_b) B = best3_bound(b3);
-      const float lb_skipped = g8_neighbours<Best3Acc, LIODOM_KNN8_U>(b3, v, cells, bits, tmask, sp, j, gshift, cx, cy, cz, qx, qy, qz, B);
+      const float lb_skipped = g8_neighbours<Best3Acc, LIODOM_KNN8_U>(b3, v, cells, bits, tmask, sp, j, gshift, cx, cy, cz, qx, qy, qz, B, min_wi, v.hb_spill_base, n_spill);
       // not certain (0.8 % of the queries: three of the nearest in one lane with a fourth at or below the fifth distance, or equal
       // distances; all queries with LIODOM_KNN_EXACT_ONLY): the query goes to k_knn8_exact, the launch behind this one, through
       // its knn_nn record.  (d5, the fifth popped distance, bounds the true fifth-nearest distance from above whenever it is finite.)
@@ -377,7 +384,7 @@ __global__ __launch_bounds__(kKnn8Threads, LIODOM_KNN8_WAVES) void k_knn8(DevVie
       const int mypos = j == 0 ? pos5[0] : j == 1 ? pos5[1] : j == 2 ? pos5[2] : j == 3 ? pos5[3] : pos5[4];
       float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
       if (found) m = sp[mypos];
-      const int wprev = dpp_i32<DPP_ROW_SHR1>(__float_as_int(m.w));      // lane j: the window index of neighbour j - 1
+      const int wprev = dpp_i32<DPP_ROW_SHR1>(__float_as_int(m.w)) - min_wi;      // lane j: the (current) window index of neighbour j - 1
       int w = j == 0 ? (found ? 1 : 0) : (j <= 2 ? (found ? wprev : -1) : 0);
       if (exact) {
         // record for k_knn8_exact (+ the query's number in the stream's list: that launch is a handful of workgroups): the query,
@@ -419,6 +426,8 @@ __global__ __launch_bounds__(kKnn8Threads) void k_knn8_exact(DevView v, int s0, 
   const CellSlot* cells = v.cells + (size_t)stab * v.table_size;
   const unsigned int* bits = v.cell_bits + (size_t)stab * (v.table_size >> 5);
   const float4* sp = v.sorted_pts + (size_t)stab * v.sorted_cap;
+  const int min_wi = v.hash_incr ? st.hb_shift : 0;
+  const int n_spill = v.hash_incr ? min(st.hb_spill, v.sorted_cap - v.hb_spill_base) : 0;
   for (int i = (int)blockIdx.x * kWaves + wave; i < n; i += (int)gridDim.x * kWaves) {      // (uniform over the wave)
     const int e = v.knn8_list[(size_t)s * v.edge_cap + i];
     float4* rec = v.knn_nn + ((size_t)s * v.edge_cap + e) * 5;
@@ -436,12 +445,13 @@ __global__ __launch_bounds__(kKnn8Threads) void k_knn8_exact(DevView v, int s0, 
     for (int k = 0; k < 4; k++) {
       const int c27 = k * 8 + g8;                         // (uniform over the group)
       unsigned int start = 0, cnt = 0;
+      if (c27 == 31) { start = (unsigned int)v.hb_spill_base; cnt = (unsigned int)n_spill; }      // (k_hash_append's spill list)
       if (c27 < 27) {
         int ox, oy, oz;
         const float lb = g8_cell_lb(c27, cx, cy, cz, qx, qy, qz, ox, oy, oz);
         if (!(lb > B)) g8_probe(v, cells, bits, tmask, ox, oy, oz, start, cnt);      // (a cell beyond the bound cannot hold one of the five)
       }
-      g8_stream_cell<Top5Acc, 2>(ta, sp, (int)start, (int)cnt, j, qx, qy, qz);
+      g8_stream_cell<Top5Acc, 2>(ta, sp, (int)start, (int)cnt, j, qx, qy, qz, min_wi);
     }
     // merge of the 64 sorted lists: (distance, window index) keys are unique among real candidates; the sentinel (bound, INT_MAX)
     // may sit in several lanes: the lowest lane pops
@@ -464,7 +474,7 @@ __global__ __launch_bounds__(kKnn8Threads) void k_knn8_exact(DevView v, int s0, 
       const int mypos = lane == 0 ? gp[0] : lane == 1 ? gp[1] : lane == 2 ? gp[2] : lane == 3 ? gp[3] : gp[4];
       float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
       if (found) m = sp[mypos];
-      const int wprev = dpp_i32<DPP_ROW_SHR1>(__float_as_int(m.w));
+      const int wprev = dpp_i32<DPP_ROW_SHR1>(__float_as_int(m.w)) - min_wi;
       const int w = lane == 0 ? (found ? 1 : 0) : (lane <= 2 ? (found ? wprev : -1) : 0);
       rec[lane] = make_float4(m.x, m.y, m.z, __int_as_float(w));
     }

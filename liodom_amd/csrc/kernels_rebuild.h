@@ -730,10 +730,203 @@ __device__ __forceinline__ float4 window_point_produce(const DevView& v, int s, 
   return pt;
 }
 
+// The cell hash of one stream in its GLOBAL table (v.table_size slots, global atomics): any map size fits.  k_hash_build's way out when
+// the window occupies more cells than its LDS table holds (kLdsCellsMax), and — with hash_incr — what k_hash_append runs on the scans
+// in between for such a stream (a table without room to append to: rebuilt every scan, as before round 6).  One workgroup; the
+// slots of the previous global build have been emptied through used_cells by the finalising solve.  eb >= 0: the new frame has yet
+// to be transformed and stored (window_point_produce).
+__device__ __forceinline__ void hash_build_global(const DevView& v, int s, StreamState& st, const WinIndex& w, int nf, int Mw, int M, int eb, int tid) {
+  CellSlot* cells = v.cells + (size_t)s * v.table_size;
+  unsigned int* bits = v.cell_bits + (size_t)s * (v.table_size >> 5);
+  int* pcell = v.pt_cell + (size_t)s * v.map_cap;
+  int* prank = v.pt_rank + (size_t)s * v.map_cap;
+  const float4* recv = v.recv_pts + (size_t)s * v.recv_cap;
+  CellSlot empty; empty.key = kEmptyKey; empty.start = 0; empty.cnt = 0;
+  if (st.table_mask != (unsigned int)v.table_size - 1u) {
+    for (int i = tid; i < kLdsSlots; i += kBuildThreads) { cells[i] = empty; }
+    for (int i = tid; i < kLdsSlots / 32; i += kBuildThreads) bits[i] = 0u;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    st.table_mask = (unsigned int)v.table_size - 1u; st.n_used_tab[0] = 0; st.cursor = 0; st.n_search = M; st.n_filt = 0;
+    st.hb_main_fc = 0; st.hb_shift = 0; st.hb_spill = 0;      // (hash_incr: nothing is ever appended to a global table)
+  }
+  __syncthreads();
+  const unsigned int gmask = (unsigned int)v.table_size - 1u;
+  for (int m = tid; m < M; m += kBuildThreads) {
+    const float4 pt = m < Mw ? window_point_produce(v, s, st, eb, w, nf, m) : recv[m - Mw];
+    int found = -1;
+    if (point_ok(pt)) {
+      const unsigned long long key = pack_cell((int)floorf(pt.x * kCellInv), (int)floorf(pt.y * kCellInv), (int)floorf(pt.z * kCellInv));
+      unsigned int h = hash_cell(key, gmask);
+      for (int probe = 0; probe < v.table_size; probe++) {
+        const unsigned long long prev = atomicCAS(&cells[h].key, kEmptyKey, key);
+        if (prev == kEmptyKey) {
+          const int u = atomicAdd(&st.n_used_tab[0], 1);
+          v.used_cells[(size_t)s * v.used_cap + u] = (int)h;
+          atomicOr(&bits[h >> 5], 1u << (h & 31));
+          found = (int)h;
+          break;
+        }
+        if (prev == key) { found = (int)h; break; }
+        h = (h + 1) & gmask;
+      }
+      if (found >= 0) prank[m] = (int)atomicAdd(&cells[found].cnt, 1u);
+      else atomicOr(&st.status, LIODOM_STATUS_HASH_FULL);
+    }
+    pcell[m] = found;
+  }
+  __threadfence();
+  __syncthreads();
+  const int nu = *(volatile int*)&st.n_used_tab[0];
+  for (int u = tid; u < nu; u += kBuildThreads) {
+    CellSlot* slot = cells + v.used_cells[(size_t)s * v.used_cap + u];
+    slot->start = (unsigned int)atomicAdd(&st.cursor, (int)*(volatile unsigned int*)&slot->cnt);
+  }
+  __threadfence();
+  __syncthreads();
+  for (int m = tid; m < M; m += kBuildThreads) {
+    const int h = pcell[m];
+    if (h < 0) continue;
+    const float4 pt = m < Mw ? win_point(v, s, nf, w, m) : recv[m - Mw];
+    const unsigned int pos = *(volatile unsigned int*)&cells[h].start + (unsigned int)prank[m];
+    v.sorted_pts[(size_t)s * v.sorted_cap + pos] = make_float4(pt.x, pt.y, pt.z, __int_as_float(m));
+  }
+}
+
+// Room a cell gets beyond its population at a rebuild (hash_incr): as much again, 32 at least; a cell k_hash_append creates: 96.
+// (Headline stream, tools/knn_budget_cpu.py: a frame puts 2.2 points into a cell it touches, 10 at the 99th percentile, 26 at most —
+//  a pole coming into range —, and three frames arrive between rebuilds: with a quarter of the population / 8 / 16 a cell ran out of
+//  room in every period, with this rule in none of 24; the point array then holds ~195 000 places per stream for 36 600 points.)
+__host__ __device__ __forceinline__ int hash_cell_slack(unsigned int cnt, int slack_min) { return cnt ? ((int)cnt > slack_min ? (int)cnt : slack_min) : 0; }
+constexpr int kHbPeriod = 4;       // scans between two rebuilds from the whole window
+constexpr int kHbNewRoom = 96;     // room of a cell that k_hash_append creates (DevView::hb_new_room; kHbSlackMin = 32: hb_slack_min)
+constexpr int kHbSlackMin = 32;
+
+// =============================================================================================
+// k_hash_append (lock-step batches, round 6): the reference appends one frame to the window and drops the oldest
+// (laser_odometry.cc:34-60); k_hash_build re-binned all M ~ 36 000 window points for it, every scan, on one CU per stream (210 us
+// of a 1.34 ms step at 256 streams: instruction issue of 2 x 36 points per lane).  Now the table lives for kHbPeriod scans — the
+// host launches k_hash_build every kHbPeriod-th scan and this kernel in between:
+//   * the NEW frame's ~1 750 points are transformed, stored in the window and appended to their cells — every cell got room for its
+//     population again at the rebuild (hash_cell_slack); a cell that does not exist yet is created (CAS on the key, room from the
+//     stream's cursor);
+//   * a point that finds no room — its cell is full, the cursor or the table exhausted — goes to the stream's SPILL LIST at the end
+//     of the point array, which every query of the stream scans like a cell until the next rebuild (empty for 32 of 34 appends on
+//     the headline stream; exact in every case, only slower: a rebuild decided on the device would have to be a launch the host
+//     makes every scan, and an idle k_hash_build launch still waits for a CU with 128 KB of free LDS);
+//   * the EVICTED frames' points stay where they are: a stored window index minus hb_shift (the points evicted since the rebuild)
+//     is the point's current window index, and a candidate below hb_shift is dead — one compare per candidate in k_knn8, which
+//     subtracts the shift from the indices it hands on (FLANN's tie order, the correspondence indices).
+// Candidates are a set to k_knn8 (ties go by window index): results are bit-identical to a rebuild every scan (LIODOM_HASH_INCR=0).
+// One workgroup per stream: a barrier separates "every cell exists" from "points take their places".
+// =============================================================================================
+__global__ __launch_bounds__(kBuildThreads) void k_hash_append(DevView v, int s0, int eb) {
+  __shared__ WinIndex w;
+  __shared__ int sh_flag;
+  const int s = s0 + blockIdx.x;
+  StreamState& st = v.state[s];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int nf = st.n_frames, fc = st.frame_count, Mw = st.n_map;
+  const unsigned int tmask = st.table_mask;
+  int d = (fc - nf) - st.hb_main_old;                  // frames evicted since the rebuild (< kHbPeriod <= frames of the window then: hb_base knows them)
+  d = d < 0 ? 0 : (d > 7 ? 7 : d);
+  if (nf < 1) return;
+  win_index_load(v, s, nf, w, tid, kBuildThreads);
+  if (tid == 0) sh_flag = 0;
+  if (tmask != (unsigned int)kLdsSlots - 1u) {            // (uniform) the window outgrew the LDS table: a global table has no room to append to
+    __syncthreads();
+    hash_build_global(v, s, st, w, nf, Mw, Mw, eb, tid);
+    return;
+  }
+  __syncthreads();
+  const int shift = st.hb_base[d];
+  const int first_new = w.sbase[nf - 1];
+  const int E = Mw - first_new;
+  CellSlot* cells = v.cells + (size_t)s * v.table_size;
+  unsigned int* bits = v.cell_bits + (size_t)s * (v.table_size >> 5);
+  unsigned int* ccap = v.cell_cap + (size_t)s * v.table_size;
+  float4* sp = v.sorted_pts + (size_t)s * v.sorted_cap;
+  // One sweep of kHbUnroll points per thread (the whole frame at once for up to 2 048 edges): the points stay in registers between the
+  // two phases.  Everything shared between the threads — keys, starts, counts — is written and read by THIS workgroup only, with a
+  // barrier between creation and use: plain accesses.
+  constexpr int kHbUnroll = 2;
+  for (int i0 = 0; i0 < E; i0 += kHbUnroll * kBuildThreads) {      // (uniform trip count)
+    float4 pt[kHbUnroll];
+    unsigned int slot[kHbUnroll];
+    // ---- the new frame enters the window; every point's cell exists afterwards ----
+#pragma unroll
+    for (int u = 0; u < kHbUnroll; u++) {
+      const int i = i0 + u * kBuildThreads + tid;
+      slot[u] = 0xFFFFFFFFu;
+      pt[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < E) pt[u] = window_point_produce(v, s, st, eb, w, nf, first_new + i);
+    }
+#pragma unroll
+    for (int u = 0; u < kHbUnroll; u++) {
+      const int i = i0 + u * kBuildThreads + tid;
+      if (i >= E || !point_ok(pt[u])) continue;
+      const unsigned long long key = pack_cell((int)floorf(pt[u].x * kCellInv), (int)floorf(pt[u].y * kCellInv), (int)floorf(pt[u].z * kCellInv));
+      unsigned int h = hash_cell(key, tmask);
+      bool placed = false;
+      for (unsigned int probe = 0; probe <= tmask; probe++) {
+        unsigned long long k = *(volatile unsigned long long*)&cells[h].key;
+        if (k == kEmptyKey) {
+          k = atomicCAS(&cells[h].key, kEmptyKey, key);
+          if (k == kEmptyKey) {                           // this thread created the cell: room from the stream's cursor
+            int start = atomicAdd(&st.hb_cursor, v.hb_new_room);
+            const bool room = start >= 0 && start + v.hb_new_room <= v.hb_spill_base;
+            start = room ? start : 0;                       // (no room left behind the cells: the cell exists, empty and full — its points spill)
+            *(volatile unsigned int*)&cells[h].start = (unsigned int)start;
+            *(volatile unsigned int*)&cells[h].cnt = 0u;
+            *(volatile unsigned int*)&ccap[h] = (unsigned int)(room ? start + v.hb_new_room : start);
+            atomicOr(&bits[h >> 5], 1u << (h & 31));
+            k = key;
+          }
+        }
+        if (k == key) { placed = true; break; }
+        h = (h + 1) & tmask;
+      }
+      slot[u] = placed ? h : 0xFFFFFFFEu;                 // (0xFFFFFFFE: table full — the point spills)
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- the points take their places: one atomic per RUN of equal cells in a wave (consecutive edges lie in the same cell) ----
+#pragma unroll
+    for (int u = 0; u < kHbUnroll; u++) {
+      const int i = i0 + u * kBuildThreads + tid;
+      const bool ok = slot[u] < 0xFFFFFFFEu;
+      const KeyRun run = wave_key_runs(ok, (unsigned long long)slot[u], lane);
+      unsigned int pos0 = 0u, cap0 = 0u;
+      if (run.head) {
+        // (a full cell's count is not raised any further: k_knn8 walks `cnt` places of the cell)
+        cap0 = *(volatile unsigned int*)&ccap[slot[u]];
+        const unsigned int st0 = *(volatile unsigned int*)&cells[slot[u]].start;
+        const unsigned int old = atomicAdd(&cells[slot[u]].cnt, (unsigned int)run.len);
+        pos0 = st0 + old;
+        if (pos0 + (unsigned int)run.len > cap0) {          // part of the run (or all of it) does not fit: give the surplus back
+          const unsigned int fit = pos0 < cap0 ? cap0 - pos0 : 0u;
+          atomicSub(&cells[slot[u]].cnt, (unsigned int)run.len - fit);
+        }
+      }
+      pos0 = (unsigned int)__shfl((int)pos0, run.head_lane);
+      cap0 = (unsigned int)__shfl((int)cap0, run.head_lane);
+      if (slot[u] != 0xFFFFFFFFu) {                       // a point of the frame
+        const unsigned int pos = pos0 + (unsigned int)run.rank;
+        const float4 rec = make_float4(pt[u].x, pt[u].y, pt[u].z, __int_as_float(first_new + i + shift));
+        if (ok && pos < cap0) sp[pos] = rec;
+        else { const int k = atomicAdd(&st.hb_spill, 1); if (k < v.sorted_cap - v.hb_spill_base) sp[v.hb_spill_base + k] = rec; sh_flag = 1; atomicAdd(&st.hb_stats[3], 1); }
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) { st.hb_shift = shift; st.n_search = Mw; st.n_filt = 0; st.hb_stats[1] += 1; st.hb_stats[2] += sh_flag; }
+}
+
 __global__ __launch_bounds__(kBuildThreads) void k_hash_build(DevView v, int s0, int eb) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ WinIndex w;
-  __shared__ int sh_used, sh_over, sh_wtot[kBuildThreads / 64];
+  __shared__ int sh_used, sh_over, sh_alloc, sh_wtot[kBuildThreads / 64];
   unsigned long long* lkey = reinterpret_cast<unsigned long long*>(smem);           // [kLdsSlots]
   unsigned int* lcnt = reinterpret_cast<unsigned int*>(lkey + kLdsSlots);           // [kLdsSlots]
   unsigned int* lstart = lcnt + kLdsSlots;                                          // [kLdsSlots]
@@ -803,64 +996,20 @@ __global__ __launch_bounds__(kBuildThreads) void k_hash_build(DevView v, int s0,
   __syncthreads();
   if (sh_over) {
     // ---- fallback: too many occupied cells for the LDS table -> global table, global atomics ----
-    CellSlot empty; empty.key = kEmptyKey; empty.start = 0; empty.cnt = 0;
-    if (st.table_mask != (unsigned int)v.table_size - 1u) {
-      for (int i = tid; i < kLdsSlots; i += kBuildThreads) { cells[i] = empty; }
-      for (int i = tid; i < kLdsSlots / 32; i += kBuildThreads) bits[i] = 0u;
-    }
-    __syncthreads();
-    if (tid == 0) { st.table_mask = (unsigned int)v.table_size - 1u; st.n_used_tab[0] = 0; st.cursor = 0; st.n_search = M; st.n_filt = 0; }
-    __syncthreads();
-    const unsigned int gmask = (unsigned int)v.table_size - 1u;
-    for (int m = tid; m < M; m += kBuildThreads) {
-      const float4 pt = m < Mw ? win_point(v, s, nf, w, m) : recv[m - Mw];
-      int found = -1;
-      if (point_ok(pt)) {
-        const unsigned long long key = pack_cell((int)floorf(pt.x * kCellInv), (int)floorf(pt.y * kCellInv), (int)floorf(pt.z * kCellInv));
-        unsigned int h = hash_cell(key, gmask);
-        for (int probe = 0; probe < v.table_size; probe++) {
-          const unsigned long long prev = atomicCAS(&cells[h].key, kEmptyKey, key);
-          if (prev == kEmptyKey) {
-            const int u = atomicAdd(&st.n_used_tab[0], 1);
-            v.used_cells[(size_t)s * v.used_cap + u] = (int)h;
-            atomicOr(&bits[h >> 5], 1u << (h & 31));
-            found = (int)h;
-            break;
-          }
-          if (prev == key) { found = (int)h; break; }
-          h = (h + 1) & gmask;
-        }
-        if (found >= 0) prank[m] = (int)atomicAdd(&cells[found].cnt, 1u);
-        else atomicOr(&st.status, LIODOM_STATUS_HASH_FULL);
-      }
-      pcell[m] = found;
-    }
-    __threadfence();
-    __syncthreads();
-    const int nu = *(volatile int*)&st.n_used_tab[0];
-    for (int u = tid; u < nu; u += kBuildThreads) {
-      CellSlot* slot = cells + v.used_cells[(size_t)s * v.used_cap + u];
-      slot->start = (unsigned int)atomicAdd(&st.cursor, (int)*(volatile unsigned int*)&slot->cnt);
-    }
-    __threadfence();
-    __syncthreads();
-    for (int m = tid; m < M; m += kBuildThreads) {
-      const int h = pcell[m];
-      if (h < 0) continue;
-      const float4 pt = m < Mw ? win_point(v, s, nf, w, m) : recv[m - Mw];
-      const unsigned int pos = *(volatile unsigned int*)&cells[h].start + (unsigned int)prank[m];
-      v.sorted_pts[(size_t)s * v.map_cap + pos] = make_float4(pt.x, pt.y, pt.z, __int_as_float(m));
-    }
+    hash_build_global(v, s, st, w, nf, Mw, M, -1, tid);      // (the counting pass above has stored the new frame)
     return;
   }
   OV_STAMP(v, tid == 0 && s == 0, 21);
   // ---- exclusive prefix of the counts over the slots (8 consecutive slots per thread) ----
+  // hash_incr: every cell gets ROOM for the points k_hash_append will add until the next rebuild (hash_cell_slack) — if the point
+  // array holds that much
+  const bool slack = v.hash_incr && !v.mapping && 2ll * M + (long long)v.hb_slack_min * sh_used <= (long long)v.sorted_cap;
   {
     constexpr int PER = kLdsSlots / kBuildThreads;   // 8
     unsigned int c[PER];
     int sum = 0;
 #pragma unroll
-    for (int k = 0; k < PER; k++) { c[k] = lcnt[tid * PER + k]; sum += (int)c[k]; }
+    for (int k = 0; k < PER; k++) { c[k] = lcnt[tid * PER + k]; sum += (int)c[k] + (slack ? hash_cell_slack(c[k], v.hb_slack_min) : 0); }
     const int incl = wave_incl_scan_i32(sum);
     if ((tid & 63) == 63) sh_wtot[tid >> 6] = incl;
     __syncthreads();
@@ -868,7 +1017,8 @@ __global__ __launch_bounds__(kBuildThreads) void k_hash_build(DevView v, int s0,
     for (int q = 0; q < (tid >> 6); q++) base += sh_wtot[q];
     int run = base + incl - sum;
 #pragma unroll
-    for (int k = 0; k < PER; k++) { lstart[tid * PER + k] = (unsigned int)run; run += (int)c[k]; }
+    for (int k = 0; k < PER; k++) { lstart[tid * PER + k] = (unsigned int)run; run += (int)c[k] + (slack ? hash_cell_slack(c[k], v.hb_slack_min) : 0); }
+    if (tid == kBuildThreads - 1) sh_alloc = run;      // everything allocated: k_hash_append's new cells go behind it
   }
   __syncthreads();
   OV_STAMP(v, tid == 0 && s == 0, 22);
@@ -899,15 +1049,17 @@ __global__ __launch_bounds__(kBuildThreads) void k_hash_build(DevView v, int s0,
         if (probe < kLdsSlots) pos0 = atomicAdd(&lstart[h], (unsigned int)run.len);
       }
       pos0 = (unsigned int)__shfl((int)pos0, run.head_lane);
-      if (ok && pos0 != 0xFFFFFFFFu) v.sorted_pts[(size_t)s * v.map_cap + pos0 + (unsigned int)run.rank] = make_float4(pt[k].x, pt[k].y, pt[k].z, __int_as_float(m));
+      if (ok && pos0 != 0xFFFFFFFFu) v.sorted_pts[(size_t)s * v.sorted_cap + pos0 + (unsigned int)run.rank] = make_float4(pt[k].x, pt[k].y, pt[k].z, __int_as_float(m));
     }
   }
   __syncthreads();
   OV_STAMP(v, tid == 0 && s == 0, 23);
   // ---- publish the table: slots [0, 8192) of the stream's global table + occupancy bits ----
+  unsigned int* ccap = v.cell_cap ? v.cell_cap + (size_t)s * v.table_size : nullptr;
   for (int i = tid; i < kLdsSlots; i += kBuildThreads) {
     CellSlot o; o.key = lkey[i]; o.cnt = lcnt[i]; o.start = lstart[i] - lcnt[i];      // (the scatter pass advanced the cursors to the cells' ends)
     cells[i] = o;
+    if (ccap) ccap[i] = lstart[i] + (slack ? (unsigned int)hash_cell_slack(o.cnt, v.hb_slack_min) : 0u);
   }
   for (int i = tid; i < kLdsSlots / 32; i += kBuildThreads) {
     unsigned int word = 0;
@@ -915,6 +1067,12 @@ __global__ __launch_bounds__(kBuildThreads) void k_hash_build(DevView v, int s0,
     for (int b = 0; b < 32; b++) word |= (lkey[i * 32 + b] != kEmptyKey) ? (1u << b) : 0u;
     bits[i] = word;
   }
-  if (tid == 0) { st.table_mask = lmask; st.n_used_tab[0] = 0; st.cursor = 0; st.n_search = M; st.n_filt = 0; }
+  if (tid == 0) {
+    st.table_mask = lmask; st.n_used_tab[0] = 0; st.n_search = M; st.n_filt = 0;
+    st.cursor = 0; st.hb_cursor = sh_alloc; st.hb_stats[0] += 1;
+    // what k_hash_append needs to keep this table current: when it was built, and the window's frame offsets then
+    st.hb_main_fc = st.frame_count; st.hb_main_old = st.frame_count - nf; st.hb_main_nf = nf; st.hb_shift = 0; st.hb_spill = 0;
+  }
+  if (tid < 8) st.hb_base[tid] = tid <= nf ? w.sbase[tid] : w.sbase[nf];
   OV_STAMP(v, tid == 0 && s == 0, 24);
 }

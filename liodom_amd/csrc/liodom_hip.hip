@@ -155,6 +155,7 @@ struct liodom_handle {
   std::atomic<bool> profiling{false};   // read without a lock by SideLocks / extract_queue, written under both mutexes
   std::vector<liodom_map*> mappers;   // per stream: attached device map (mapping replay) or null
   std::vector<int> mapper_cells_xy, mapper_cells_z;
+  int hb_since = -1;            // hash_incr: scans since the last k_hash_build (-1: none yet)
   int knn8_grid = 1;            // k_knn8 workgroups per stream (each walks the blocks b, b + grid, ... of 32 queries)
   bool knn8 = false;            // handles with >= 16 streams: k_knn8 (eight lanes per query) instead of k_knn<128>; LIODOM_KNN8=0 keeps the latter
   bool lds_hash_build = false;  // k_hash_build (one workgroup per stream, LDS) instead of the 3 global-atomic kernels
@@ -447,7 +448,12 @@ int enqueue_odometry(liodom_handle* h, int eb, int s0, int count, unsigned int w
     // (nothing: the next cell hash is complete when the finalising solve launch ends)
   } else if (h->lds_hash_build) {
     ProfScope ps(h, KID_HASH_BUILD);        // window append + LDS-built cell hash, one workgroup per stream
-    hipLaunchKernelGGL(k_hash_build, dim3(count), dim3(kBuildThreads), hash_build_lds_bytes(), h->stream, v, s0, eb);
+    // (hash_incr: the new frame is appended to the table of the last rebuild; k_hash_build only works when that says so)
+    // (hash_incr: k_hash_build every kHbPeriod-th scan, k_hash_append — the new frame into the cells of the last rebuild — in between)
+    const bool rebuild = !v.hash_incr || h->hb_since < 0 || h->hb_since >= kHbPeriod - 1;
+    h->hb_since = rebuild ? 0 : h->hb_since + 1;
+    if (!rebuild) hipLaunchKernelGGL(k_hash_append, dim3(count), dim3(kBuildThreads), 0, h->stream, v, s0, eb);
+    else hipLaunchKernelGGL(k_hash_build, dim3(count), dim3(kBuildThreads), hash_build_lds_bytes(), h->stream, v, s0, eb);
   } else {
     {
       ProfScope ps(h, KID_WINDOW_INSERT);   // window append + cell hash in global memory, map_blocks workgroups per stream
@@ -644,6 +650,7 @@ int reset_state(liodom_handle* h) {
   }
   h->pf_slot = -1; h->parity = 0; h->last_eb = 0; h->ev_free_valid[0] = h->ev_free_valid[1] = h->ev_free_valid[2] = false;
   h->replay_live.store(false);
+  h->hb_since = -1;
   h->ext_seq = h->odo_seq = 0;
   // the first scans after a reset are not overlapped (as after liodom_create): the first one runs with st.initialized == 0, where
   // no first solve publishes the pose an overlapped second kNN pass would wait for
@@ -910,6 +917,13 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   ALLOC(v.imu_q, S * 4, 0);
   v.ovf_base = v.early_rebuild ? v.map_cap + 8 * v.edge_cap : v.map_cap;
   v.sorted_cap = v.early_rebuild ? v.ovf_base + v.edge_cap : v.map_cap;
+  {
+    // incremental cell hash (k_hash_append; decided for good below, once the kNN instance is known): every cell keeps room for the
+    // points of the frames that arrive before the next rebuild — twice the window + 64k places per stream
+    bool want = config->n_streams >= 16 && h->lds_hash_build && !params->mapping && !params->filter_local_map;
+    if (const char* e = std::getenv("LIODOM_HASH_INCR")) { if (std::atoi(e) == 0) want = false; }
+    if (want && !v.early_rebuild) v.sorted_cap = 2 * v.map_cap + 65536 + (kHbPeriod - 1) * v.edge_cap;      // (+ the spill list)
+  }
   ALLOC(v.sorted_pts, (v.early_rebuild ? 2 : 1) * S * (size_t)v.sorted_cap, 0);
   if (v.early_rebuild) ALLOC(v.cell_pad, 2 * S * (size_t)v.table_size, 0); else v.cell_pad = nullptr;
   v.rebuild_delta = 0.25f;
@@ -977,6 +991,15 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   if (const char* e = std::getenv("LIODOM_KNN8")) { if (std::atoi(e) == 0) h->knn8 = false; }
   h->knn8_grid = std::max(1, cdiv(cdiv(v.edge_cap, kKnn8Queries), kKnnGridDiv));
   if (const char* e = std::getenv("LIODOM_KNN8_GRID")) h->knn8_grid = std::max(1, std::min(65535, std::atoi(e)));      // (experiments)
+  // incremental cell hash: lock-step batches that search with k_knn8 (it skips evicted points) on the LDS-built table, window only
+  v.hash_incr = (h->knn8 && h->lds_hash_build && !params->mapping && !params->filter_local_map && h->P > kHbPeriod &&
+                 v.sorted_cap >= 2 * v.map_cap + (kHbPeriod - 1) * v.edge_cap) ? 1 : 0;      // (windows of more frames than a period: the evicted frames are frames the rebuild knew)
+  v.hb_spill_base = v.sorted_cap - (kHbPeriod - 1) * v.edge_cap;
+  if (const char* e = std::getenv("LIODOM_HASH_INCR")) { if (std::atoi(e) == 0) v.hash_incr = 0; }
+  if (v.hash_incr) ALLOC(v.cell_cap, S * (size_t)v.table_size, 0); else v.cell_cap = nullptr;
+  v.hb_slack_min = kHbSlackMin; v.hb_new_room = kHbNewRoom;
+  if (const char* e = std::getenv("LIODOM_HB_SLACK")) v.hb_slack_min = std::max(0, std::atoi(e));            // (tests: cells that run out of room)
+  if (const char* e = std::getenv("LIODOM_HB_NEW_ROOM")) v.hb_new_room = std::max(1, std::atoi(e));
   if (h->knn8) { ALLOC(v.knn8_cnt, S, 0); ALLOC(v.knn8_list, S * (size_t)v.edge_cap, 0); } else { v.knn8_cnt = nullptr; v.knn8_list = nullptr; }
   v.knn_queries = config->n_streams >= 16 ? 4 : 8;          // must match the k_knn instance launch_odometry picks (k_knn8 leaves k_line_gate the same layout)
   v.knn_partials = config->n_streams >= 16 ? 0 : 1;         // measured: +37 % on the VALU-bound 256-stream kNN pass, -2 us per solve on one stream
@@ -2048,15 +2071,16 @@ int liodom_get_modes(liodom_handle_t* h, char* buf, int cap) {
   const DevView& v = h->v;
   // (speculative hand-overs of stream 0 since the last reset: the launches enqueued so far have to have run for the figures to mean
   //  anything — a caller that wants them synchronises first; this call does not)
-  int spec[4] = {0, 0, 0, 0};
+  int spec[4] = {0, 0, 0, 0}, hbs[4] = {0, 0, 0, 0};
   (void)hipMemcpy(spec, reinterpret_cast<const char*>(v.state) + offsetof(StreamState, spec_stats), sizeof(spec), hipMemcpyDeviceToHost);
+  (void)hipMemcpy(hbs, reinterpret_cast<const char*>(v.state) + offsetof(StreamState, hb_stats), sizeof(hbs), hipMemcpyDeviceToHost);
   snprintf(buf, (size_t)cap,
            "n_streams=%d early_rebuild=%d hash_build=%s pipe_flags=%d flag_gate=%d lm_groups=%d knn_instance=%d knn_queries=%d "
-           "knn_grid=%d/%d knn8=%d knn_partials=%d knn_saved_bound=%d knn_exact_only=%d line_gate_kernel=%d filter_local_map=%d mapping=%d "
+           "knn_grid=%d/%d knn8=%d hash_incr=%d hash_rebuilds=%d hash_appends=%d hash_appends_spilled=%d hash_points_spilled=%d knn_partials=%d knn_saved_bound=%d knn_exact_only=%d line_gate_kernel=%d filter_local_map=%d mapping=%d "
            "rotation_mode=%d table_size=%d rebuild_delta=%.3f knn_overlap=%d streams_concurrent=%d safe_mode=%d ring_split=%d ring_split_max_wgs=%d ring_split_lb=%d chain=%d speculate=%d spec_early=%d/%d spec_unconfirmed=%d/%d replay_enqueue_us=%.2f replay_wait_us=%.2f debug=%d",
            h->S, v.early_rebuild, v.early_rebuild ? "streamed" : (h->lds_hash_build ? "lds" : "global"), h->use_flags ? 1 : 0,
            (h->use_flags && h->flag_gate) ? 1 : 0, v.lm_groups, h->S >= 16 ? 128 : 256, v.knn_queries, v.knn_grid,
-           v.knn_blocks, h->knn8 ? 1 : 0, v.knn_partials, v.knn_save_pos ? 2 : (v.knn_save_q ? 1 : 0), v.knn_exact_only, v.knn_nn ? 1 : 0, v.filter_local_map, v.mapping,
+           v.knn_blocks, h->knn8 ? 1 : 0, v.hash_incr, hbs[0], hbs[1], hbs[2], hbs[3], v.knn_partials, v.knn_save_pos ? 2 : (v.knn_save_q ? 1 : 0), v.knn_exact_only, v.knn_nn ? 1 : 0, v.filter_local_map, v.mapping,
            v.rotation_mode, v.table_size, (double)v.rebuild_delta,
            (v.early_rebuild && (h->ov_ok || (h->chain_ok && !h->flag_gate)) && h->use_flags && g_live_handles.load() <= 1) ? 1 : 0, h->streams_concurrent ? 1 : 0, h->safe_mode ? 1 : 0, h->ring_split ? 1 : 0, h->ring_split ? h->ring_split_max_wgs : 0, h->ring_split_lb ? 1 : 0,
            (v.early_rebuild && h->chain_ok && h->use_flags && !h->flag_gate && g_live_handles.load() <= 1) ? 1 : 0, v.speculate, spec[0], spec[2], spec[1], spec[3],

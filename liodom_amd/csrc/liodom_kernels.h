@@ -95,6 +95,17 @@ struct StreamState {
   int32_t reb_pad;        // chain mode: the scan's edge count as PAD saw it (APPEND iterates over it, see edges_keep)
   int32_t spec_eval[2];   // speculative hand-over (kernels_sync.h), back-off: first / finalising solves still to sit out after a hand-over that was
                           // not confirmed
+  // incremental cell hash of lock-step batches (kernels_rebuild.h, k_hash_append): between two rebuilds from the whole window the
+  // new frame's points are appended to their cells and evicted frames stay where they are
+  int32_t hb_main_fc;     // frame_count at the last rebuild (0: none yet)
+  int32_t hb_main_old;    // absolute number of the window's oldest frame then
+  int32_t hb_main_nf;     // frames in the window then
+  int32_t hb_base[8];     // the window's frame offsets (win_base[0 .. 7]) then: hb_base[d] points have been evicted once d frames have
+  int32_t hb_shift;       // points evicted since the rebuild: a stored window index minus hb_shift is the current one, below it: evicted
+  int32_t hb_cursor;      // first free place of the point array behind everything the rebuild allocated: room for the cells k_hash_append creates
+  int32_t hb_stats[4];    // since the last reset: rebuilds, appends, appends that spilled, points spilled
+  int32_t hb_spill;       // appended points that found no room in their cell (or no cell): kept in the spill list at the end of the point array,
+                          // which every query scans, until the next rebuild
   int32_t spec_stats[4];  // ... how it went since the last reset: first solve's iterates handed over early, of them not confirmed; the same for the
                           // finalising solve (liodom_get_modes: spec_early / spec_unconfirmed)
   double pred_odom[2][12]; // early_rebuild: the prediction the scan started from ([frames appended so far & 1]: the repair of a speculative hand-over
@@ -209,6 +220,10 @@ struct DevView {
   int sorted_cap;           // sorted_pts entries per table (early_rebuild: map_cap + 8 edge_cap of padding + edge_cap of overflow list; else map_cap)
   int ovf_base;             // first entry of the overflow list inside a table's sorted_pts
   float rebuild_delta;      // early_rebuild: a new-frame point may move this far (per axis) between the prediction and the solved pose and still land in a padded cell
+  int hb_spill_base;        // hash_incr: first place of the spill list in sorted_pts (the last (kHbPeriod - 1) * edge_cap places)
+  int hb_slack_min, hb_new_room;   // hash_incr: room of a cell beyond its population at a rebuild (at least this, else the population again); room of a new cell
+  int hash_incr;            // lock-step batches: k_hash_append between rebuilds (LIODOM_HASH_INCR=0: k_hash_build every scan)
+  unsigned int* cell_cap;   // [S][table_size] hash_incr: end of the room of every cell in sorted_pts (start + points + slack)
   int* knn8_cnt;            // [S] k_knn8: queries of the pass left to k_knn8_exact (k_line_gate resets it)
   int* knn8_list;           // [S][edge_cap] ... their numbers
   float4* knn_nn;           // [S][edge_cap][5] lock-step batches: the five neighbours of every query (w: found flag, index of NN0, NN1) for k_line_gate

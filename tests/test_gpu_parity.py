@@ -1063,7 +1063,7 @@ def test_chain_mode_replay_against_the_oracle_every_hand_over_wrong(orc, synth, 
 def _batch_run(orc, synth, scans, H, W, R, epr, P, S, env, monkeypatch, check_oracle=False):
     """One replay of `scans` (per data stream d: scans[d][k]) on an S-stream handle under `env`; returns per scan (poses, matches,
     correspondences of both passes for streams 0 .. D-1)."""
-    for name in ("LIODOM_KNN8", "LIODOM_KNN_EXACT_ONLY", "LIODOM_KNN_SAVE"):
+    for name in ("LIODOM_KNN8", "LIODOM_KNN_EXACT_ONLY", "LIODOM_KNN_SAVE", "LIODOM_HASH_INCR", "LIODOM_HB_SLACK", "LIODOM_HB_NEW_ROOM"):
         monkeypatch.delenv(name, raising=False)
     for name, val in env.items():
         monkeypatch.setenv(name, val)
@@ -1111,12 +1111,19 @@ def test_knn8_equals_the_half_wave_kernel_and_its_own_modes(orc, synth, monkeypa
         cfg = synth.make_cfg(H, W, 0, yaw_rate_deg=yaw, speed=speed)
         scans = [[synth.scan(cfg, 30 + d, k)[0] for k in range(K)] for d in range(3)]
         modes, base = _batch_run(orc, synth, scans, H, W, R, epr, P, S, {}, monkeypatch)
-        assert modes["knn8"] == "1" and modes["line_gate_kernel"] == "1"
+        assert modes["knn8"] == "1" and modes["line_gate_kernel"] == "1" and modes["hash_incr"] == "1"
         modes, old = _batch_run(orc, synth, scans, H, W, R, epr, P, S, {"LIODOM_KNN8": "0"}, monkeypatch)
         assert modes["knn8"] == "0"
         _assert_batch_runs_equal(base, old, ("half-wave kernel", yaw))
-        for env in ({"LIODOM_KNN_EXACT_ONLY": "1"}, {"LIODOM_KNN_SAVE": "1"}, {"LIODOM_KNN_SAVE": "0"}):
-            _, other = _batch_run(orc, synth, scans, H, W, R, epr, P, S, env, monkeypatch)
+        assert modes["knn8"] == "0" and modes["hash_incr"] == "0"
+        # LIODOM_HASH_INCR=0: the cell hash rebuilt from the whole window every scan (k_hash_build) instead of the new frame appended
+        # to the table of the last rebuild, evicted frames' points skipped by their window index (k_hash_append): 12 scans at P = 5 —
+        # three rebuild periods, seven evictions
+        for env in ({"LIODOM_KNN_EXACT_ONLY": "1"}, {"LIODOM_KNN_SAVE": "1"}, {"LIODOM_KNN_SAVE": "0"}, {"LIODOM_HASH_INCR": "0"},
+                    {"LIODOM_HASH_INCR": "0", "LIODOM_KNN_EXACT_ONLY": "1"},
+                    {"LIODOM_HB_SLACK": "1", "LIODOM_HB_NEW_ROOM": "2"}):      # (cells run out of room almost every scan: the rebuild takes over)
+            m2, other = _batch_run(orc, synth, scans, H, W, R, epr, P, S, env, monkeypatch)
+            assert m2["hash_incr"] == ("0" if "LIODOM_HASH_INCR" in env else "1")
             _assert_batch_runs_equal(base, other, (env, yaw))
     assert sum(m[1] for m in base[-1][1]) > 100
 

@@ -51,5 +51,5 @@ print("batched %d streams x %d steps: %s scans/s (median %.0f), %.3f ms/step, st
     S, Kb, ["%.0f" % v for v in vals], float(np.median(vals)), S * 1e3 / float(np.median(vals)), status,
     hex(int(np.frombuffer(poses.tobytes(), dtype=np.uint64).sum() & 0xFFFFFFFFFFFF))))
 print("per kernel us/launch:", {k: round(ms * 1e3 / max(1, n), 1) for k, (n, ms) in st.items() if n})
-print("modes:", {k: v for k, v in gb.modes().items() if k in ("knn8", "hash_build", "knn_instance", "ring_split")})
+print("modes:", {k: v for k, v in gb.modes().items() if k in ("knn8", "hash_build", "knn_instance", "ring_split", "ring_split_lb", "hash_incr", "hash_rebuilds", "hash_appends", "hash_appends_spilled", "hash_points_spilled")})
 gb.close()
