@@ -414,9 +414,13 @@ __device__ __forceinline__ void rebuild_beside_solve(const DevView& v, int s, St
 // (one instance per solve of the scan: the first solve's code holds neither the scan's finalisation nor the appending workgroups,
 //  the finalising solve's neither COUNT / PAD nor the hand-over to the second pass — as one kernel with a run-time outer_it the
 //  controller's steps spilled more with every addition to either side)
-template <int kOuterIt>
-__global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int eb, unsigned int seq, int chain, unsigned int done_target) {
+// (round 6: and one instance per MODE — the four-launch chain of the host-fed replay, the strict / serial legs, the lock-step batches
+//  and per-kernel profiling never waits for a pass's done count and never hands a result over early: as a run-time `chain` that code
+//  cost its finalising solve 200 B of scratch per lane)
+template <int kOuterIt, bool kChainMode>
+__global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int eb, unsigned int seq, unsigned int done_target) {
   constexpr int outer_it = kOuterIt;
+  constexpr int chain = kChainMode ? 1 : 0;
   // the candidate's matrix and the current iterate's (the candidate of the last accepted step): two buffers that swap roles when a
   // step is accepted, so that the iterate's matrix is at hand — bit for bit the one the solve ends with unless another step is
   // accepted — without being formed again (speculative hand-over, kernels_sync.h; and the launch's last microsecond)

@@ -385,12 +385,12 @@ int enqueue_odometry(liodom_handle* h, int eb, int s0, int count, unsigned int w
       hipLaunchKernelGGL(k_chain_redo0<256>, dim3(nA + v.knn_grid + 1, 1), dim3(256), 0, h->stream_k, v, s0, eb, wait_edges, signal_odo, seq_k, scan_no, nA, 1, h->chain_fix_pending ? 1 : 0);
     }
     h->chain_fix_pending = v.speculate != 0;
-    hipLaunchKernelGGL(k_lm_solve<0>, dim3(gx, 1), dim3(kLmThreads), lds, h->stream, v, s0, eb, seq_k, 1, done_target);
+    hipLaunchKernelGGL((k_lm_solve<0, true>), dim3(gx, 1), dim3(kLmThreads), lds, h->stream, v, s0, eb, seq_k, done_target);
     if (!v.speculate) hipLaunchKernelGGL(k_ov_gate, dim3(1), dim3(64), 0, h->stream_k, v, s0, seq_k);
     hipLaunchKernelGGL((k_knn<256, true>), dim3(v.knn_grid + nCP, 1), dim3(256), 0, h->stream_k, v, s0, 1, eb, 0u, 0u, seq_k, scan_no);
     // (speculative hand-over not confirmed — rare —: the pass's workgroups once more; the launch's first workgroups are ALLOC)
     if (v.speculate) hipLaunchKernelGGL(k_knn_redo<256>, dim3(kRebuildAllocBlocks + v.knn_grid, 1), dim3(256), 0, h->stream_k, v, s0, eb, seq_k, scan_no, kRebuildAllocBlocks);
-    hipLaunchKernelGGL(k_lm_solve<1>, dim3(gx, 1), dim3(kLmThreads), lds, h->stream, v, s0, eb, seq_k, 1, done_target);
+    hipLaunchKernelGGL((k_lm_solve<1, true>), dim3(gx, 1), dim3(kLmThreads), lds, h->stream, v, s0, eb, seq_k, done_target);
     if (!v.speculate) hipLaunchKernelGGL(k_rebuild_alloc, dim3(kRebuildAllocBlocks, 1), dim3(256), 0, h->stream_k, v, s0);
     hipLaunchKernelGGL(k_rebuild_fin, dim3(nP + kRebuildAuxBlocks + nC, 1), dim3(kLmThreads), 0, h->stream_k, v, s0, eb);
     HIP_TRY(hipGetLastError());
@@ -425,8 +425,8 @@ int enqueue_odometry(liodom_handle* h, int eb, int s0, int count, unsigned int w
       // it 0: + COUNT, PAD; it 1: + APPEND, CLEAR, SCATTER
       const int extra = !early ? 0 : (it == 0 ? nC + nP : nP + kRebuildAuxBlocks + nC);
       const int gx = std::max(h->v.lm_groups + extra, (h->v.lm_groups - 1) * 8 + 1);      // solvers on blocks 0, 8, 16, ... (one XCD)
-      if (it == 0) hipLaunchKernelGGL(k_lm_solve<0>, dim3(gx, count), dim3(kLmThreads), lm_lds_bytes(h->v.edge_cap), h->stream, v, s0, eb, seq_k, 0, 0u);
-      else hipLaunchKernelGGL(k_lm_solve<1>, dim3(gx, count), dim3(kLmThreads), lm_lds_bytes(h->v.edge_cap), h->stream, v, s0, eb, seq_k, 0, 0u);
+      if (it == 0) hipLaunchKernelGGL((k_lm_solve<0, false>), dim3(gx, count), dim3(kLmThreads), lm_lds_bytes(h->v.edge_cap), h->stream, v, s0, eb, seq_k, 0u);
+      else hipLaunchKernelGGL((k_lm_solve<1, false>), dim3(gx, count), dim3(kLmThreads), lm_lds_bytes(h->v.edge_cap), h->stream, v, s0, eb, seq_k, 0u);
     }
   }
   if (v.mapping) {
@@ -1049,8 +1049,10 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   }
   v.lm_lds_reduce = lm_lds_reduce_fits(v.edge_cap) ? 1 : 0;
   if (lm_lds_bytes(v.edge_cap) + 8192 > 160 * 1024) { g_last_error = "liodom_create: edge capacity too large for the solve's LDS tile"; return fail(LIODOM_ERR_INVALID_ARG); }
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lm_solve<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm_lds_bytes(h->v.edge_cap)) != hipSuccess ||
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lm_solve<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm_lds_bytes(h->v.edge_cap)) != hipSuccess) {
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lm_solve<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm_lds_bytes(h->v.edge_cap)) != hipSuccess ||
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lm_solve<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm_lds_bytes(h->v.edge_cap)) != hipSuccess ||
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lm_solve<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm_lds_bytes(h->v.edge_cap)) != hipSuccess ||
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lm_solve<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm_lds_bytes(h->v.edge_cap)) != hipSuccess) {
     g_last_error = "hipFuncSetAttribute(max dynamic LDS) failed"; return fail(LIODOM_ERR_HIP);
   }
   if (h->ring_lds_bytes > 48 * 1024) {
