@@ -73,6 +73,26 @@ LD_HD int velodyne_ring_from_angle(double angle, int scan_lines) {
   }
   return scan_id;
 }
+// The same binning evaluated in FLOAT, for k_classify's fast decision only: the caller evaluates it at angle - m and angle + m and
+// trusts the result when both agree (every branch, truncation and drop test is monotone in the angle; float rounding of these
+// expressions is below 2e-5 degrees, the margin m is 2e-4).
+LD_HD int velodyne_ring_from_angle_f(float angle, int scan_lines) {
+  int scan_id;
+  if (scan_lines == 64) {
+    if (angle >= -8.83f) scan_id = (int)((2.0f - angle) * 3.0f + 0.5f);
+    else scan_id = scan_lines / 2 + (int)((-8.83f - angle) * 2.0f + 0.5f);
+    if (angle > 2.0f || angle < -24.33f || scan_id > 63 || scan_id < 0) return -1;
+  } else if (scan_lines == 32) {
+    scan_id = (int)((angle + 92.0f / 3.0f) * 0.75f);
+    if (scan_id > (scan_lines - 1) || scan_id < 0) return -1;
+  } else if (scan_lines == 16) {
+    scan_id = (int)((angle + 15.0f) * 0.5f + 0.5f);
+    if (scan_id > (scan_lines - 1) || scan_id < 0) return -1;
+  } else {
+    return -1;
+  }
+  return scan_id;
+}
 LD_HD int velodyne_ring(double z, double dist, int scan_lines) {
   const double angle = atan(z / dist) * 180 / kPi;
   return velodyne_ring_from_angle(angle, scan_lines);
