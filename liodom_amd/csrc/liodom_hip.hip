@@ -832,7 +832,7 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   // in-kernel phase timestamps (tools/gpu_debug.py clocks): they change no result.  The result-changing ablation bits
   // of earlier rounds (LIODOM_ABLATE) are gone from the product build.
   // instrumented builds only (-DLIODOM_INSTRUMENT, tools/variant_build.sh): 1: stamps, 65: + histograms (shared-counter atomics: they perturb the timing)
-  if (kInstrument) { if (const char* e = getenv("LIODOM_DEBUG_CLOCKS")) { if (atoi(e) != 0) v.debug |= ((atoi(e) & 128) ? (atoi(e) & 32) : 32) | (atoi(e) & (64 | 128)) | ((atoi(e) >> 8) << 8); } }
+  if (kInstrument) { if (const char* e = getenv("LIODOM_DEBUG_CLOCKS")) { if (atoi(e) != 0) v.debug |= ((atoi(e) & (128 | 256)) ? (atoi(e) & 32) : 32) | (atoi(e) & (64 | 128)) | ((atoi(e) >> 8) << 8); } }
   v.ring_id_stride = (size_t)round_up(config->max_points + 512, 256);
 
   const size_t S = (size_t)h->S;

@@ -368,6 +368,40 @@ def sec_hbclocks(H=64, W=1800, R=8, epr=10, P=20, K=36):
     g.close()
 
 
+def sec_knn8phases(H=64, W=1800, R=8, epr=10, P=20, K=30):
+    """Shader cycles per phase of k_knn8 on a lock-step batch, summed over the working waves (instrumented build, debug bit 8)."""
+    import ctypes as C
+    os.environ.setdefault("LIODOM_DEBUG_CLOCKS", "256")
+    S = int(os.environ.get("HB_STREAMS", "256"))
+    cfg = synth.make_cfg(H, W, 0)
+    import liodom_amd as la
+    g = la.Liodom(la.make_params(scan_lines=H, scan_regions=R, edges_per_region=epr, prev_frames=P),
+                  la.make_config(n_streams=S, max_points=H * W, max_width=W, pose_log_capacity=K + 8))
+    g.alloc_resident(K)
+    scans = [synth.scan(cfg, 0, k)[0] for k in range(K)]
+    for s in range(S):
+        for k in range(K):
+            g.upload_scan(s, k, scans[k])
+    for k in range(K):
+        g.process_resident(k, H * W, H, W, readback=False, next_slot=(k + 1 if k + 1 < K else -1))
+    g.sync()
+    buf = (C.c_ulonglong * 512)()
+    g.L.liodom_debug_clocks.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+    g.L.liodom_debug_clocks(g.h, buf)
+    a = np.array(list(buf), dtype=np.float64)
+    names = ["query + own probe + sort", "second pass: re-rank + certificate", "own cell", "bound + neighbour cells", "selection", "save for the second pass", "neighbours fetched, records written"]
+    for it in (0, 1):
+        row = a[64 + 8 * it:64 + 8 * it + 7]
+        tot = row.sum()
+        print("k_knn8<%d>: %s" % (it, ", ".join("%s %.1f %%" % (n, 100.0 * x / max(tot, 1.0)) for n, x in zip(names, row))))
+    for it in (0, 1):
+        row = a[96 + 8 * it:96 + 8 * it + 3]
+        print("k_knn8<%d>, inside 'bound + neighbour cells': %s" % (it, ", ".join("%s %.1f %%" % (n, 100.0 * x / max(row.sum(), 1.0)) for n, x in zip(["ladder bound", "box distances + probes", "cells streamed"], row))))
+    print("second pass: %d wave-iterations, %d with at least one searching query, %d searching queries (%.1f %% of %d)" % (a[64 + 23], a[64 + 7], a[64 + 15], 100.0 * a[64 + 15] / max(8 * a[64 + 23], 1), 8 * a[64 + 23]))
+    g.close()
+
+
+SECTIONS["knn8phases"] = sec_knn8phases
 SECTIONS["hbclocks"] = sec_hbclocks
 SECTIONS["ovclocks"] = sec_ovclocks
 
@@ -415,7 +449,7 @@ SECTIONS["long"] = sec_long
 
 if __name__ == "__main__":
     names = sys.argv[1:] or ["extract", "odom", "odom64", "timing"]
-    if any(n in ("clocks", "knntimes", "ovclocks", "hbclocks") for n in names):
+    if any(n in ("clocks", "knntimes", "ovclocks", "hbclocks", "knn8phases") for n in names):
         _use_instrumented_library()
     for n in names:
         print("=" * 20, n)

@@ -87,6 +87,7 @@ for name, a in (("own 1 m cell", own), ("all 27 cells", all27), ("cells within t
 G = 8
 thr = [0.36, 0.09, 0.0225, 0.0036]
 visited, nbcells, fails = [], [], 0
+nb_lists = []                 # per query: the populations of the neighbour cells it streams
 for p in q:
     c = np.floor(p).astype(np.int64)
     m = np.full((G, 4), np.inf, np.float32)
@@ -106,6 +107,7 @@ for p in q:
         if (kept <= np.float32(t)).sum() >= 5:
             B = np.float32(t)
     v, nb = nown, 0
+    mine = []
     for dz in (-1, 0, 1):
         for dy in (-1, 0, 1):
             for dx in (-1, 0, 1):
@@ -117,11 +119,11 @@ for p in q:
                     continue
                 sc2 = cells.get(key1(cc))
                 if sc2:
-                    stream(*sc2); v += sc2[1]; nb += 1
+                    stream(*sc2); v += sc2[1]; nb += 1; mine.append(sc2[1])
     ent = np.sort(m[:, :3].ravel()); g4 = ent[4]; m4 = m[:, 3].min()
     ok = (g4 < 1.0 and all(ent[i] < ent[i + 1] for i in range(5)) and g4 < m4) or (g4 >= 1.0 and m4 >= 1.0)
     fails += 0 if ok else 1
-    visited.append(v); nbcells.append(nb)
+    visited.append(v); nbcells.append(nb); nb_lists.append(mine)
 visited = np.array(visited)
 print("k_knn8 (8 lanes, Best3, ladder bound after the own cell, lazy neighbours): candidates per query mean %.1f median %.0f p90 %.0f; neighbour cells streamed %.2f per query; results the fast path cannot certify: %d of %d (%.2f %%)" % (
     visited.mean(), np.median(visited), np.percentile(visited, 90), np.mean(nbcells), fails, len(q), 100.0 * fails / len(q)))
@@ -136,6 +138,31 @@ def rounds(a, per_wg):
 for per_wg in (32, 64):
     u, s_ = rounds(own, per_wg)
     print("rounds of the own cell per wave of 8 queries (a wave lasts as long as its most populous cell): edge order %.1f; workgroup of %d queries sorted by cell population %.1f; all equal %.1f" % (u, per_wg, s_, own.mean() / G))
+
+# ---- neighbour cells: rounds per wave under different walks (the groups of a wave hold different lists) ----
+def nb_rounds(per_wg=32):
+    n = len(nb_lists); pad = (-n) % per_wg
+    lists = nb_lists + [[]] * pad
+    order_own = np.concatenate([own, np.zeros(pad)])
+    res = {}
+    def walk(perm, step):
+        cell_by_cell = one_stream = 0.0
+        for w in range(0, len(perm), 8):
+            grp = [lists[i] for i in perm[w:w + 8]]
+            depth = max(len(g) for g in grp)
+            cell_by_cell += sum(max((np.ceil(g[k] / step) if k < len(g) else 0) for g in grp) for k in range(depth))
+            one_stream += max(sum(np.ceil(c / step) for c in g) for g in grp)
+        return cell_by_cell / (len(perm) / 8), one_stream / (len(perm) / 8)
+    perm_own = np.concatenate([w0 + np.argsort(order_own[w0:w0 + per_wg], kind="stable") for w0 in range(0, len(lists), per_wg)])
+    for step in (8, 16):
+        work = np.array([sum(np.ceil(c / step) for c in g) for g in lists])
+        perm_work = np.concatenate([w0 + np.argsort(work[w0:w0 + per_wg], kind="stable") for w0 in range(0, len(lists), per_wg)])
+        a, b = walk(perm_own, step)
+        c_, d = walk(perm_work, step)
+        print("neighbour cells, steps of %2d candidates per group, per wave of 8 queries: mean over queries %.1f; cell by cell %.1f; one stream per group %.1f; "
+              "workgroup of %d re-dealt by neighbour work: cell by cell %.1f, one stream %.1f" % (step, work.mean(), a, b, per_wg, c_, d))
+nb_rounds(32)
+nb_rounds(64)
 
 # ---- k_hash_append: room per cell ----
 def sim(slack_fn, newroom, period=4):
