@@ -6,11 +6,7 @@
 // grid (kCompactBlocks, streams): every workgroup scans the <= 256 ring counts itself (cheaper than a
 // second launch) and copies its interleaved share of the edges.
 constexpr int kCompactBlocks = 8;
-__global__ __launch_bounds__(256) void k_compact_edges(DevView v, int s0, int eb, unsigned int wait_odo, int mirror) {
-  __shared__ int pre[257];
-  __shared__ int cntr[256];
-  // (pipelined replay) the odometry that last read edge buffer eb must have completed before it is rewritten
-  if (wait_odo && !pipe_wait(v.pipe_flags + kEdgePipeBufs, wait_odo, &v.state[s0 + blockIdx.y].status)) return;
+__device__ __forceinline__ void compact_edges_body(const DevView& v, int s0, int eb, int mirror, int* pre, int* cntr) {
   const int s = s0 + blockIdx.y;
   const int H = v.scan_lines;
   const int* rn = v.ring_nedges + (size_t)s * H;
@@ -57,6 +53,35 @@ __global__ __launch_bounds__(256) void k_compact_edges(DevView v, int s0, int eb
   }
 }
 
+// pub_value != 0 (round 6): the launch also PUBLISHES the extraction — what k_publish_edges / k_set_flag did in a launch of their
+// own behind this one (~5 us of the extraction stream per scan, the stream that bounds the two-thread binding): every thread
+// completes its stores (system scope: the mirror in host memory included), the workgroups count themselves on pub_counter[eb],
+// and the last one to arrive writes the sequence number for the odometry side's kernels (pub_flag, may be null) and for the host
+// thread that waits for the edges (pub_host, may be null).  A launch whose wait gave up still counts and publishes, as the
+// separate launch did.
+__global__ __launch_bounds__(256) void k_compact_edges(DevView v, int s0, int eb, unsigned int wait_odo, int mirror,
+                                                       unsigned int* pub_flag, unsigned int* pub_host, unsigned int pub_value) {
+  __shared__ int pre[257];
+  __shared__ int cntr[256];
+  // (pipelined replay) the odometry that last read edge buffer eb must have completed before it is rewritten
+  const bool go = !(wait_odo && !pipe_wait(v.pipe_flags + kEdgePipeBufs, wait_odo, &v.state[s0 + blockIdx.y].status));      // (uniform over the workgroup)
+  if (go) compact_edges_body(v, s0, eb, mirror, pre, cntr);
+  if (pub_value) {
+    typedef __attribute__((address_space(1))) unsigned int gu32;
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned int total = gridDim.x * gridDim.y;
+      const unsigned int prev = __hip_atomic_fetch_add(v.pub_counter + eb, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      if (prev == total - 1u) {
+        __hip_atomic_store(v.pub_counter + eb, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (the next launch on this buffer follows in stream order)
+        INJECT_DELAY(19);
+        if (pub_flag) __hip_atomic_store((gu32*)pub_flag, pub_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (pub_host) __hip_atomic_store(pub_host, pub_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
+}
 // Behind k_compact_edges in stream order (that launch has ended: its stores, to HBM and to host memory, are complete):
 // the extraction's sequence number for the odometry side's kernels (dev_flag, as k_set_flag; may be null) and for the host
 // thread that waits for the edges (host_seq, system scope; may be null).

@@ -116,6 +116,7 @@ struct liodom_handle {
   unsigned int* host_edges_hdr = nullptr;
   float4* pin_ring = nullptr;        // page-locked scan staging ring [kEdgePipeBufs][max_points]: liodom_scan_buffer hands slots out, pageable scans are copied through it
   float4* stage_ring = nullptr;      // device side of the hand-off's uploads [kEdgePipeBufs][max_points] when they run on the copy stream
+  bool fold_publish = true;          // k_compact_edges publishes the extraction itself (LIODOM_FOLD_PUBLISH=0: k_set_flag / k_publish_edges in a launch behind it)
   bool tk_copy_stream = false;       // ... (LIODOM_COPY_STREAM, default on): the upload of scan k+1 runs beside the extraction of scan k
   hipEvent_t ev_cp[kEdgePipeBufs] = {nullptr, nullptr, nullptr};      // the upload into device staging slot r has completed (copy stream)
   hipEvent_t ev_sdone[kEdgePipeBufs] = {nullptr, nullptr, nullptr};   // the extraction that read device staging slot r has been issued (recorded on the extraction stream)
@@ -246,7 +247,8 @@ inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 // there by the first kernel of the chain — no upload call — and `in` is the device buffer that kernel leaves a copy in.
 int launch_extract(liodom_handle* h, hipStream_t q, int eb, int s0, int count, const float4* in, size_t in_stride,
                    int n, int height, int width, unsigned int wait_odo = 0, int mirror = 0,
-                   const float4* host_in = nullptr, size_t host_stride = 0) {
+                   const float4* host_in = nullptr, size_t host_stride = 0,
+                   unsigned int* pub_flag = nullptr, unsigned int* pub_host = nullptr, unsigned int pub_value = 0u) {
   const DevView& v = h->v;
   const int tiles = std::max(1, cdiv(n, kTilePts));
   if (v.lidar_type == 1 && width > 0 && (long long)h->H * width <= (long long)v.max_points) {
@@ -294,7 +296,7 @@ int launch_extract(liodom_handle* h, hipStream_t q, int eb, int s0, int count, c
   }
   {
     ProfScope ps(h, KID_COMPACT, q);
-    hipLaunchKernelGGL(k_compact_edges, dim3(kCompactBlocks, count), dim3(256), 0, q, v, s0, eb, wait_odo, mirror);
+    hipLaunchKernelGGL(k_compact_edges, dim3(kCompactBlocks, count), dim3(256), 0, q, v, s0, eb, wait_odo, mirror, pub_flag, pub_host, pub_value);
   }
   HIP_TRY(hipGetLastError());
   return LIODOM_OK;
@@ -586,11 +588,13 @@ int issue_extract(liodom_handle* h, int slot, int eb, int n, int height, int wid
   if (h->use_flags) {
     // dependencies through flags in device memory (pipe_wait / k_set_flag): the buffer's last reader must have
     // completed before k_compact_edges rewrites it; the flag of this extraction is set by a launch that follows it
-    int rc = launch_extract(h, q, eb, 0, h->S, in, (size_t)h->v.max_points, n, height, width, h->eb_reader[eb], 0, host_dev, host_stride);
-    if (rc) return rc;
     h->eb_seq[eb] = ++h->ext_seq;
     if (h->ext_seq == 0) h->eb_seq[eb] = ++h->ext_seq;      // (0 means "nothing to wait for")
-    hipLaunchKernelGGL(k_set_flag, dim3(1), dim3(1), 0, q, h->v.pipe_flags + eb, h->eb_seq[eb]);
+    // (fold_publish: the last workgroup of k_compact_edges sets the flag; else a launch of its own behind it)
+    int rc = launch_extract(h, q, eb, 0, h->S, in, (size_t)h->v.max_points, n, height, width, h->eb_reader[eb], 0, host_dev, host_stride,
+                            h->fold_publish ? h->v.pipe_flags + eb : nullptr, nullptr, h->fold_publish ? h->eb_seq[eb] : 0u);
+    if (rc) return rc;
+    if (!h->fold_publish) hipLaunchKernelGGL(k_set_flag, dim3(1), dim3(1), 0, q, h->v.pipe_flags + eb, h->eb_seq[eb]);
     HIP_TRY(hipGetLastError());
     return LIODOM_OK;
   }
@@ -637,6 +641,7 @@ int reset_state(liodom_handle* h) {
     st.table_mask = (uint32_t)h->v.table_size - 1u;
   }
   HIP_TRY(hipMemcpyAsync(h->v.state, init.data(), sizeof(StreamState) * init.size(), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemsetAsync(h->v.pub_counter, 0, sizeof(unsigned int) * (size_t)kEdgeBufs, h->stream));
   if (h->v.lb_ticket) { HIP_TRY(hipMemsetAsync(h->v.lb_ticket, 0, sizeof(unsigned int), h->stream)); HIP_TRY(hipMemsetAsync(h->v.lb_ovf, 0, sizeof(unsigned int) * (size_t)h->S, h->stream)); }
   {
     std::vector<double> qid((size_t)h->S * 4, 0.0);          // IMU orientation: identity until imuClb delivers one
@@ -821,6 +826,7 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   if (const char* e = std::getenv("LIODOM_EARLY_REBUILD")) { if (std::atoi(e) == 0) v.early_rebuild = 0; }
   if (const char* e = std::getenv("LIODOM_SAFE_MODE")) { if (std::atoi(e) != 0) enter_safe_mode(h); }
   if (const char* e = std::getenv("LIODOM_ZERO_COPY")) h->zero_copy = std::atoi(e) != 0;
+  if (const char* e = std::getenv("LIODOM_FOLD_PUBLISH")) h->fold_publish = std::atoi(e) != 0;
   v.recv_cap = v.mapping ? (config->recv_capacity > 0 ? config->recv_capacity : 262144) : 0;
   v.map_cap = v.edge_cap * h->P + v.recv_cap;
   int ts = 1024;
@@ -1021,6 +1027,7 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
   ALLOC(v.knn_done0, S + 64, 0);
   if (v.early_rebuild) ALLOC(v.pred_xch, S * (size_t)kOvReplicas * 512, 0); else v.pred_xch = nullptr;
   ALLOC(v.edge_cnt, (size_t)kEdgeBufs * 32, 0);
+  ALLOC(v.pub_counter, (size_t)kEdgeBufs, 0);
   if (v.early_rebuild) ALLOC(v.edges_keep, S * (size_t)v.edge_cap, 0); else v.edges_keep = nullptr;
   // (the two passes' validity bytes never share a 128-byte line: the overlapped second pass writes its half while the finalising
   //  solve's launch — which must not read it before ov_wait_knn_done — may hold the first pass's half in its caches)
@@ -1394,9 +1401,11 @@ int liodom_extract_edges_device(liodom_handle_t* h, int stream, const float* xyz
   unsigned int* host_seq = h->v.host_edges_hdr ? h->v.host_edges_hdr + eb : nullptr;
   // (the slot is free: the odometry that last read buffer eb has been collected, i.e. has completed — no wait on the device,
   //  which would depend on when the other thread submits its next scan)
-  rc = launch_extract(h, q, eb, stream, 1, in, 0, (int)n, height, width, 0u, 1, host_dev, 0);
+  unsigned int* const dev_flag = h->use_flags ? h->v.pipe_flags + eb : (unsigned int*)nullptr;
+  rc = launch_extract(h, q, eb, stream, 1, in, 0, (int)n, height, width, 0u, 1, host_dev, 0,
+                      h->fold_publish ? dev_flag : nullptr, h->fold_publish ? host_seq : nullptr, h->fold_publish ? seq : 0u);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_publish_edges, dim3(1), dim3(1), 0, q, h->use_flags ? h->v.pipe_flags + eb : (unsigned int*)nullptr, host_seq, seq);
+  if (!h->fold_publish) hipLaunchKernelGGL(k_publish_edges, dim3(1), dim3(1), 0, q, dev_flag, host_seq, seq);
   if (!h->use_flags) HIP_TRY(hipEventRecord(h->ev_edges[eb], q));
   HIP_TRY(hipGetLastError());
   if (pin_slot_used >= 0) {                          // (zero-copy) the ring slot may be refilled once the extraction's first kernel has read it
@@ -2079,12 +2088,12 @@ int liodom_get_modes(liodom_handle_t* h, char* buf, int cap) {
   snprintf(buf, (size_t)cap,
            "n_streams=%d early_rebuild=%d hash_build=%s pipe_flags=%d flag_gate=%d lm_groups=%d knn_instance=%d knn_queries=%d "
            "knn_grid=%d/%d knn8=%d hash_incr=%d hash_rebuilds=%d hash_appends=%d hash_appends_spilled=%d hash_points_spilled=%d knn_partials=%d knn_saved_bound=%d knn_exact_only=%d line_gate_kernel=%d filter_local_map=%d mapping=%d "
-           "rotation_mode=%d table_size=%d rebuild_delta=%.3f knn_overlap=%d streams_concurrent=%d safe_mode=%d ring_split=%d ring_split_max_wgs=%d ring_split_lb=%d chain=%d speculate=%d spec_early=%d/%d spec_unconfirmed=%d/%d replay_enqueue_us=%.2f replay_wait_us=%.2f debug=%d",
+           "rotation_mode=%d table_size=%d rebuild_delta=%.3f knn_overlap=%d streams_concurrent=%d safe_mode=%d ring_split=%d ring_split_max_wgs=%d ring_split_lb=%d fold_publish=%d chain=%d speculate=%d spec_early=%d/%d spec_unconfirmed=%d/%d replay_enqueue_us=%.2f replay_wait_us=%.2f debug=%d",
            h->S, v.early_rebuild, v.early_rebuild ? "streamed" : (h->lds_hash_build ? "lds" : "global"), h->use_flags ? 1 : 0,
            (h->use_flags && h->flag_gate) ? 1 : 0, v.lm_groups, h->S >= 16 ? 128 : 256, v.knn_queries, v.knn_grid,
            v.knn_blocks, h->knn8 ? 1 : 0, v.hash_incr, hbs[0], hbs[1], hbs[2], hbs[3], v.knn_partials, v.knn_save_pos ? 2 : (v.knn_save_q ? 1 : 0), v.knn_exact_only, v.knn_nn ? 1 : 0, v.filter_local_map, v.mapping,
            v.rotation_mode, v.table_size, (double)v.rebuild_delta,
-           (v.early_rebuild && (h->ov_ok || (h->chain_ok && !h->flag_gate)) && h->use_flags && g_live_handles.load() <= 1) ? 1 : 0, h->streams_concurrent ? 1 : 0, h->safe_mode ? 1 : 0, h->ring_split ? 1 : 0, h->ring_split ? h->ring_split_max_wgs : 0, h->ring_split_lb ? 1 : 0,
+           (v.early_rebuild && (h->ov_ok || (h->chain_ok && !h->flag_gate)) && h->use_flags && g_live_handles.load() <= 1) ? 1 : 0, h->streams_concurrent ? 1 : 0, h->safe_mode ? 1 : 0, h->ring_split ? 1 : 0, h->ring_split ? h->ring_split_max_wgs : 0, h->ring_split_lb ? 1 : 0, h->fold_publish ? 1 : 0,
            (v.early_rebuild && h->chain_ok && h->use_flags && !h->flag_gate && g_live_handles.load() <= 1) ? 1 : 0, v.speculate, spec[0], spec[2], spec[1], spec[3],
            h->replay_timed ? h->replay_enq_ns / (1e3 * (double)h->replay_timed) : 0.0, h->replay_timed ? h->replay_wait_ns / (1e3 * (double)h->replay_timed) : 0.0, v.debug);
   return LIODOM_OK;

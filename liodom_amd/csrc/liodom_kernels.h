@@ -254,6 +254,7 @@ struct DevView {
   // still runs and takes its results through done flags, as the finalising solve takes the second pass's.
   float4* edges_keep;              // [S][edge_cap] chain mode: the scan's edges as PAD saw them, for APPEND (the edge buffer itself may belong to a later
                                    // scan's extraction by the time APPEND's launch starts: the ticket slot is free once the pose has been collected)
+  unsigned int* pub_counter;       // [kEdgeBufs] k_compact_edges: workgroups of the launch on edge buffer b that have completed their stores (the last one publishes and resets it)
   unsigned int* edge_cnt;          // [kEdgeBufs][32] write-through copy of n_edges_buf[b] of stream s (s < 32) at [b * 32 + s], a 128-byte line per buffer
   unsigned int* knn_done0;         // [S + 64] chain mode (S = 1): [s] workgroups of first passes that have completed, counted over the scans since the
                                    // last reset (one word: the first solve's workgroups poll it with one thread each); [32 + s] (a cache line of its own) the same for second passes
