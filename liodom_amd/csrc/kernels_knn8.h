@@ -30,11 +30,17 @@
 //               block); an uncertified query searches, pruned with the first pass's fifth distance.
 // Results: the five neighbours of every query for k_line_gate (knn_nn), exactly what k_knn<128> leaves there.
 // LIODOM_KNN8=0 keeps k_knn<128> (tests compare the two bit for bit).
+// Measured on top of this form and NOT kept (256 streams, same box, bench.py's slot: search + exact + line gate per pass; this form
+// 320-323 us): queries prepared by one thread each and handed to the groups through LDS, box bounds from the six face distances,
+// the four probes of a lane in two round trips instead of eight, the cells found walked as one list per group — -5 % VALU
+// instructions (1.29e8 -> 1.23e8 in a first pass), 325-335 us in every combination; the workgroup's queries dealt to the groups a
+// second time by the length of their neighbour lists (first pass) / by whether they still search (second pass: 9 % do, spread over
+// 38 % of the waves) — -14 % instructions, +9 % time (two more barriers per workgroup).  A workgroup here is ONE chain of ~20
+// dependent memory round trips; seven of them per SIMD do not hide it, so instructions saved are not time saved.
 // =============================================================================================
-// (instrumented builds, LIODOM_DEBUG_CLOCKS bit 8: shader cycles per phase of k_knn8, summed over the working waves of all streams —
-//  dbg_clk[64 + 8 * pass + phase]; tools/gpu_debug.py knn8phases)
+// (instrumented builds, LIODOM_DEBUG_CLOCKS bit 8: shader cycles per phase of k_knn8, summed over the first lanes of the working waves of
+//  all streams — dbg_clk[64 + 8 * pass + phase]; tools/gpu_debug.py knn8phases)
 #define KNN8_PHASE(i) do { if (kInstrument && (v.debug & 256) && (threadIdx.x & 63) == 0) { const unsigned long long t_now = __builtin_readcyclecounter(); atomicAdd(&v.dbg_clk[64 + 8 * outer_it + (i)], t_now - t_ph); t_ph = t_now; } } while (0)
-#define KNN8_SUB(i) do { if (kInstrument && (v.debug & 256) && (threadIdx.x & 63) == 0) { const unsigned long long t_now = __builtin_readcyclecounter(); atomicAdd(&v.dbg_clk[96 + 8 * outer_it + (i)], t_now - t_sub); t_sub = t_now; } } while (0)
 constexpr int kG8 = 8;                    // lanes per query
 #ifndef LIODOM_KNN8_THREADS
 #define LIODOM_KNN8_THREADS 256
@@ -114,63 +120,6 @@ __device__ __forceinline__ void g8_stream_cell(Acc& t, const float4* sp, int sta
   }
 }
 
-// The group's 8 lanes walk a LIST of cells (sh_nb[k][gbase + l] = start, count for every set bit 8 k + l of pend; pend is uniform over
-// the group) as one stream of rounds of 8 candidates.  The groups of a wave hold different lists: walked cell by cell
-// (g8_stream_cell per entry) a wave pays, for every entry, the rounds of the LONGEST cell any of its eight groups holds at that
-// position — sum over positions of the maximum; walked as one stream it pays the maximum over groups of the sums.  The walker
-// (pos, rem: next unread position / what is left of the current cell) and the cell after it (npos, nrem: read from LDS one cell
-// ahead) are uniform over the group; the loads of round r + 1 leave before round r is evaluated.
-#ifndef LIODOM_KNN8_REDEAL
-#define LIODOM_KNN8_REDEAL 0      // measured at 256 streams: -14 % VALU instructions in the first pass, +9 % time (395 us against 364: two more barriers per workgroup, and a workgroup is one latency chain) — off
-#endif
-constexpr bool kKnn8Redeal = LIODOM_KNN8_REDEAL != 0;      // queries dealt to the groups again: first pass by their neighbour lists, second pass by whether they search
-#ifndef LIODOM_KNN8_U
-#define LIODOM_KNN8_U 2          // candidate loads in flight per lane and round (x 2: the next round's leave before this round is evaluated)
-#endif
-#ifndef LIODOM_KNN8_LIST
-#define LIODOM_KNN8_LIST 2       // 0: cell by cell (g8_stream_cell per entry); 1: one stream, steps of 8; 2: one stream, steps of 16
-#endif
-template <class Acc>
-__device__ __forceinline__ void g8_stream_list(Acc& t, const float4* sp, const uint2* sh_nb, int gbase, unsigned int pend, int j,
-                                               float qx, float qy, float qz, int min_wi) {
-#define G8_POP(P, R) do { const int b_ = __ffs(pend) - 1; pend &= pend - 1u; const uint2 sc_ = sh_nb[(b_ >> 3) * kKnn8Threads + gbase + (b_ & 7)]; P = (int)sc_.x; R = (int)sc_.y; } while (0)
-  if (LIODOM_KNN8_LIST == 0) {
-    while (pend) { int cs, cc; G8_POP(cs, cc); g8_stream_cell<Acc, LIODOM_KNN8_U>(t, sp, cs, cc, j, qx, qy, qz, min_wi); }
-    return;
-  }
-  constexpr int U = LIODOM_KNN8_LIST == 2 ? 2 : 1;
-  int pos = 0, rem = 0, npos = 0, nrem = 0;
-  if (pend) G8_POP(pos, rem);
-  if (pend) G8_POP(npos, nrem);
-  bool have = rem > 0;
-  int cpos[U];
-  float4 c[U];
-#pragma unroll
-  for (int u = 0; u < U; u++) { const int iu = j + u * kG8; cpos[u] = have ? pos + (iu < rem ? iu : rem - 1) : 0; c[u] = sp[cpos[u]]; }
-  int left = rem;                                      // what the step in c[] may use of its cell
-  while (have) {                                       // (divergent between the groups of a wave: exec-masked)
-    pos += U * kG8; rem -= U * kG8;
-    if (rem <= 0) {
-      pos = npos; rem = nrem; nrem = 0;
-      if (pend) G8_POP(npos, nrem);
-    }
-    const bool have_n = rem > 0;
-    int npl[U];
-    float4 n[U];
-#pragma unroll
-    for (int u = 0; u < U; u++) { const int iu = j + u * kG8; npl[u] = have_n ? pos + (iu < rem ? iu : rem - 1) : cpos[0]; n[u] = sp[npl[u]]; }
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      const int wi = __float_as_int(c[u].w);
-      t.consider(j + u * kG8 < left && wi >= min_wi, sqdist_cand(qx, qy, qz, c[u]), wi - min_wi, cpos[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < U; u++) { c[u] = n[u]; cpos[u] = npl[u]; }
-    left = rem; have = have_n;
-  }
-#undef G8_POP
-}
-
 // One probe of the cell hash (occupancy bit first: the slots of empty cells are never loaded).
 __device__ __forceinline__ void g8_probe(const DevView& v, const CellSlot* cells, const unsigned int* bits, unsigned int tmask,
                                          int cx, int cy, int cz, unsigned int& start, unsigned int& cnt) {
@@ -225,85 +174,34 @@ __device__ __forceinline__ bool best3_select(const Best3Acc& t, float& d5, int (
   return s4 >= one;
 }
 
-#ifndef LIODOM_KNN8_NB_BATCH
-#define LIODOM_KNN8_NB_BATCH 2      // slots fetched per round trip in g8_neighbours (4 spills at 72 VGPRs)
-#endif
 // The neighbour cells of a group: lane j owns cells j, j + 8, j + 16, j + 24 (< 27, not the own one) of the 27-cell block.  Round k:
 // every lane looks its cell up if its box distance is <= B (most are not: no probe at all), then the group streams the cells its
 // lanes found, one after the other, with all 8 lanes.  Returns the smallest box distance among this lane's cells that were NOT
 // streamed (inf: none) — the second pass's guard needs it.
-__device__ __forceinline__ float g8_nb_probe(const DevView& v, const CellSlot* cells, const unsigned int* bits, unsigned int tmask,
-                                             int j, int gshift, int cx, int cy, int cz, float qx, float qy, float qz, float B,
-                                             int spill_base, int n_spill, uint2* sh_nb, unsigned int& pend, int& work) {
-  // Phase stamps (instrumented build, 256 streams) had 64 % of a first-pass wave's time in this function as a loop "for each of the
-  // lane's four cells: box distance, probe (occupancy bit -> slot: two dependent loads), stream what the lanes found": eight dependent
-  // round trips of probing per wave whether or not anybody found anything.  Now the four probes of a lane travel TOGETHER — four
-  // occupancy words in one round trip, the slots of the occupied ones in a second — and the cells found are streamed from one list
-  // that lives in LDS (sh_nb[k][thread] = start, count: a lane's own column; read back by the 8 lanes of its group only, so wave order
-  // is all the synchronisation it needs) instead of eight registers and two shuffles per cell.
+template <class Acc, int U>
+__device__ __forceinline__ float g8_neighbours(Acc& t, const DevView& v, const CellSlot* cells, const unsigned int* bits, unsigned int tmask,
+                                               const float4* sp, int j, int gshift, int cx, int cy, int cz, float qx, float qy, float qz, float B, int min_wi,
+                                               int spill_base, int n_spill) {
   float lb_skipped = __int_as_float(0x7f800000);
-  unsigned int h[4];
-  unsigned int need = 0u, found = 0u;
-  int mywork = 0;
-  const int tid = (int)threadIdx.x;
-                               // bit k: this lane's cell k lies within the bound
-  // box distances (g8_cell_lb's values, bit for bit) from the squared distances to the six faces of the own cell: a neighbour cell's
-  // box lies beyond the lower face (d = -1), the upper face (d = +1) or within the slab (d = 0) on every axis
-  const float lox = qx - (float)cx, hix = (float)(cx + 1) - qx, loy = qy - (float)cy, hiy = (float)(cy + 1) - qy, loz = qz - (float)cz, hiz = (float)(cz + 1) - qz;
-  const float lx2 = lox * lox, hx2 = hix * hix, ly2 = loy * loy, hy2 = hiy * hiy, lz2 = loz * loz, hz2 = hiz * hiz;
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     const int c27 = k * kG8 + j;
-    h[k] = 0u;
+    unsigned int start = 0, cnt = 0;
+    if (c27 == 31) { start = (unsigned int)spill_base; cnt = (unsigned int)n_spill; }      // (k_hash_append's spill list rides as a 28th "cell" of every query: lane 7, last round)
     if (c27 < 27 && c27 != 13) {
-      const int dx = c27 % 3 - 1, dy = (c27 / 3) % 3 - 1, dz = c27 / 9 - 1;
-      const float ex2 = dx < 0 ? lx2 : (dx > 0 ? hx2 : 0.0f), ey2 = dy < 0 ? ly2 : (dy > 0 ? hy2 : 0.0f), ez2 = dz < 0 ? lz2 : (dz > 0 ? hz2 : 0.0f);
-      const float lb = (ex2 + ey2 + ez2) * (1.0f - 1e-5f);
-      if (!(lb > B)) { h[k] = hash_cell(pack_cell(cx + dx, cy + dy, cz + dz), tmask); need |= 1u << k; }
+      int ox, oy, oz;
+      const float lb = g8_cell_lb(c27, cx, cy, cz, qx, qy, qz, ox, oy, oz);
+      if (!(lb > B)) g8_probe(v, cells, bits, tmask, ox, oy, oz, start, cnt);
       else lb_skipped = fminf(lb_skipped, lb);
     }
-  }
-  if (__ballot(need != 0u)) {                            // (wave-uniform: most waves of a second pass need nothing here)
-    unsigned int word[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) word[k] = bits[h[k] >> 5];                 // (h = 0 where nothing is needed: a harmless load)
-    unsigned int occ = 0u;
-#pragma unroll
-    for (int k = 0; k < 4; k++) occ |= (((need >> k) & 1u) & ((word[k] >> (h[k] & 31)) & 1u)) << k;
-#pragma unroll
-    for (int k0 = 0; k0 < 4; k0 += LIODOM_KNN8_NB_BATCH) {
-      uint4 raw[LIODOM_KNN8_NB_BATCH];
-#pragma unroll
-      for (int i = 0; i < LIODOM_KNN8_NB_BATCH; i++) raw[i] = *reinterpret_cast<const uint4*>(cells + h[k0 + i]);
-#pragma unroll
-      for (int i = 0; i < LIODOM_KNN8_NB_BATCH; i++) {
-        const int k = k0 + i;
-        if ((occ >> k) & 1u) {
-          const int c27 = k * kG8 + j;                    // (the key again: cheaper than four 64-bit keys kept live across the loads)
-          const unsigned long long key_k = pack_cell(cx + c27 % 3 - 1, cy + (c27 / 3) % 3 - 1, cz + c27 / 9 - 1);
-          const unsigned long long kk = ((unsigned long long)raw[i].y << 32) | raw[i].x;
-          if (kk == key_k) { if (raw[i].w) { sh_nb[k * kKnn8Threads + tid] = make_uint2(raw[i].z, raw[i].w); found |= 1u << k; mywork += (int)((raw[i].w + 15u) >> 4); } }
-          else {
-            // (another cell sits in the first slot: walk the collision chain as g8_probe does — rare at the table's load)
-            unsigned int hh = (h[k] + 1) & tmask;
-            for (int pr = 1; pr < v.table_size; pr++) {
-              if (!((bits[hh >> 5] >> (hh & 31)) & 1u)) break;
-              const uint4 r2 = *reinterpret_cast<const uint4*>(cells + hh);
-              if ((((unsigned long long)r2.y << 32) | r2.x) == key_k) { if (r2.w) { sh_nb[k * kKnn8Threads + tid] = make_uint2(r2.z, r2.w); found |= 1u << k; mywork += (int)((r2.w + 15u) >> 4); } break; }
-              hh = (hh + 1) & tmask;
-            }
-          }
-        }
-      }
+    unsigned int pend = g8_ballot(cnt > 0, gshift);
+    while (pend) {                                   // (divergent between the groups of a wave: exec-masked)
+      const int l = __ffs(pend) - 1;
+      pend &= pend - 1u;
+      const int cs = __shfl((int)start, l, kG8), cc = __shfl((int)cnt, l, kG8);
+      g8_stream_cell<Acc, U>(t, sp, cs, cc, j, qx, qy, qz, min_wi);
     }
   }
-  if (j == 7 && n_spill > 0) { sh_nb[3 * kKnn8Threads + tid] = make_uint2((unsigned int)spill_base, (unsigned int)n_spill); found |= 8u; mywork += (n_spill + 15) >> 4; }      // (k_hash_append's spill list rides as a 28th "cell" of every query: cell 31 = lane 7's fourth)
-  // the cells the group's lanes found, one after the other, with all 8 lanes: bit 8 k + l = cell k of lane l
-  pend = g8_ballot(found & 1u, gshift) | (g8_ballot(found & 2u, gshift) << 8) | (g8_ballot(found & 4u, gshift) << 16) | (g8_ballot(found & 8u, gshift) << 24);
-  work = g8_sum_i32(mywork);                             // steps of 16 candidates the group's list takes
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   return lb_skipped;
 }
 
@@ -328,6 +226,9 @@ __device__ __forceinline__ float best3_bound(const Best3Acc& t) {
 #define LIODOM_KNN8_SORT 1
 #endif
 constexpr bool kKnn8Sort = LIODOM_KNN8_SORT != 0;      // first pass: queries dealt to the groups in the order of their own cells' populations
+#ifndef LIODOM_KNN8_U
+#define LIODOM_KNN8_U 2          // candidate loads in flight per lane and round (x 2: the next round's leave before this round is evaluated)
+#endif
 #ifndef LIODOM_KNN8_WAVES
 #define LIODOM_KNN8_WAVES 7
 #endif
@@ -356,55 +257,35 @@ __global__ __launch_bounds__(kKnn8Threads, LIODOM_KNN8_WAVES) void k_knn8(DevVie
   __shared__ float4 sh_q[2][kKnn8Queries];                // query (xyz) and edge number, per parity of the loop
   __shared__ int2 sh_own[2][kKnn8Queries];                // own cell: start, count (-1: no query)
   __shared__ int sh_perm[2][kKnn8Queries];
-  __shared__ float4 sh_sq[outer_it == 1 ? 2 : 1][kKnn8Queries];      // second pass: the first pass's query and fifth distance
-  __shared__ float sh_gsq[outer_it == 1 ? 2 : 1][kKnn8Queries];      // ... and guard
-  __shared__ uint2 sh_nb[4 * kKnn8Threads];               // g8_nb_probe's found cells
-  __shared__ float4 sh_mva[outer_it == 0 ? kKnn8Threads : 1];      // first pass, second deal: what the lanes have kept
-  __shared__ int4 sh_mvb[outer_it == 0 ? kKnn8Threads : 1];
-  __shared__ int4 sh_ra[kKnn8Queries], sh_rb[kKnn8Queries];         // second deals: what a query is
-  __shared__ int sh_perm2[kKnn8Queries];
   int par = 0;
   for (int blk = bxi; blk * kKnn8Queries < E; blk += (int)gridDim.x, par ^= 1) {
+    int e = blk * kKnn8Queries + grp;
     unsigned long long t_ph = (kInstrument && (v.debug & 256)) ? __builtin_readcyclecounter() : 0ull;
-    // ---- the queries: edge -> world with the pose the pass searches at (laser_odometry.cc:307-308) ----
-    // ONE THREAD PER QUERY (the first 32 threads of the workgroup), handed to the groups through LDS: the FP64 transform, the cell
-    // and the probe of the own cell are the same for the 8 lanes of a group, and a wave-instruction costs the same with 8 useful
-    // lanes as with 64 — done by every group for itself they were ~135 of a first-pass wave's ~2 300 VALU instructions per
-    // iteration, in all four waves; here they are issued once per workgroup.
-    if ((int)threadIdx.x < kKnn8Queries) {
-      const int et = blk * kKnn8Queries + (int)threadIdx.x;
-      bool act = et < E;
-      float tx = 0.f, ty = 0.f, tz = 0.f;
-      unsigned int ostart = 0, ocnt = 0;
-      float4 sqt = make_float4(0.f, 0.f, 0.f, inf);
-      float gsqt = 0.f;
-      if (act) {
-        const float4 p = v.edges[((size_t)eb * v.n_streams + s) * v.edge_cap + et];
-        double T[12];
+    // ---- the query: edge -> world with the pose the pass searches at (laser_odometry.cc:307-308) ----
+    bool active = e < E;                                  // (uniform over the group)
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    if (active) {
+      const float4 p = v.edges[((size_t)eb * v.n_streams + s) * v.edge_cap + e];
+      double T[12];
 #pragma unroll
-        for (int i = 0; i < 12; i++) T[i] = st.odom[i];
-        transform_point(T, p.x, p.y, p.z, &tx, &ty, &tz);
-        if (v.knn_q) v.knn_q[((size_t)s * 2 + outer_it) * v.edge_cap + et] = make_float4(tx, ty, tz, 0.f);
-        act = ld_isfinite((double)tx) && ld_isfinite((double)ty) && ld_isfinite((double)tz) &&
-              fabsf(tx) < 1.0e9f && fabsf(ty) < 1.0e9f && fabsf(tz) < 1.0e9f;
-        if (outer_it == 0 && act)
-          g8_probe(v, cells, bits, tmask, (int)floorf(tx * kCellInv), (int)floorf(ty * kCellInv), (int)floorf(tz * kCellInv), ostart, ocnt);
-        if (outer_it == 1 && act && v.knn_save_q) sqt = v.knn_save_q[(size_t)s * v.edge_cap + et];      // the first pass's query and fifth distance
-        if (outer_it == 1 && act && v.knn_save_pos && !v.knn_exact_only) gsqt = v.knn_save_g[(size_t)s * v.edge_cap + et];
-      }
-      sh_q[par][threadIdx.x] = make_float4(tx, ty, tz, __int_as_float(et));
-      sh_own[par][threadIdx.x] = make_int2((int)ostart, act ? (int)ocnt : -1);
-      if (outer_it == 1) { sh_sq[par][threadIdx.x] = sqt; sh_gsq[par][threadIdx.x] = gsqt; }
+      for (int i = 0; i < 12; i++) T[i] = st.odom[i];
+      transform_point(T, p.x, p.y, p.z, &qx, &qy, &qz);
+      if (v.knn_q && j == 0) v.knn_q[((size_t)s * 2 + outer_it) * v.edge_cap + e] = make_float4(qx, qy, qz, 0.f);
+      active = ld_isfinite((double)qx) && ld_isfinite((double)qy) && ld_isfinite((double)qz) &&
+               fabsf(qx) < 1.0e9f && fabsf(qy) < 1.0e9f && fabsf(qz) < 1.0e9f;
     }
-    __syncthreads();
-    int src = grp;                                        // the query this group works on
+    int cx = (int)floorf(qx * kCellInv), cy = (int)floorf(qy * kCellInv), cz = (int)floorf(qz * kCellInv);
+    unsigned int own_start = 0, own_cnt = 0;
     if (outer_it == 0 && kKnn8Sort) {
       // A wave walks its eight queries' cells in lock-step: it lasts as long as the query with the most populous cell (a pole or a
       // corner seen in 20 frames holds hundreds of points, the cell next to it a dozen).  In edge order the eight differ widely —
       // 21.5 rounds of the own cell per wave on the headline stream where 9.0 would do if all were equal — so the workgroup sorts
       // its queries by the population of their own cell first and deals them to its groups in that order: 13.9 rounds with 32
-      // queries per workgroup (tools/knn_budget_cpu.py).
-      const int key = sh_own[par][grp].y;
+      // queries per workgroup (tools/knn_budget_cpu.py).  The queries swap groups through LDS: 24 bytes each.
+      if (active) g8_probe(v, cells, bits, tmask, cx, cy, cz, own_start, own_cnt);
+      const int key = active ? (int)own_cnt : -1;
+      if (j == 0) { sh_q[par][grp] = make_float4(qx, qy, qz, __int_as_float(e)); sh_own[par][grp] = make_int2((int)own_start, key); }
+      __syncthreads();
       int below = 0;
 #pragma unroll
       for (int i = 0; i < kKnn8Queries / kG8; i++) {
@@ -415,15 +296,14 @@ __global__ __launch_bounds__(kKnn8Threads, LIODOM_KNN8_WAVES) void k_knn8(DevVie
       below = g8_sum_i32(below);                          // this query's place in the order
       if (j == 0) sh_perm[par][below] = grp;
       __syncthreads();
-      src = sh_perm[par][grp];
+      const int src = sh_perm[par][grp];                  // the query this group continues with
+      const float4 q4 = sh_q[par][src];
+      const int2 o2 = sh_own[par][src];
+      qx = q4.x; qy = q4.y; qz = q4.z; e = __float_as_int(q4.w);
+      own_start = (unsigned int)o2.x; own_cnt = o2.y > 0 ? (unsigned int)o2.y : 0u;
+      active = o2.y >= 0;
+      cx = (int)floorf(qx * kCellInv); cy = (int)floorf(qy * kCellInv); cz = (int)floorf(qz * kCellInv);
     }
-    float4 q4 = sh_q[par][src];
-    int2 o2 = sh_own[par][src];
-    float qx = q4.x, qy = q4.y, qz = q4.z;
-    int e = __float_as_int(q4.w);
-    unsigned int own_start = (unsigned int)o2.x, own_cnt = o2.y > 0 ? (unsigned int)o2.y : 0u;
-    bool active = o2.y >= 0;                              // (uniform over the group)
-    int cx = (int)floorf(qx * kCellInv), cy = (int)floorf(qy * kCellInv), cz = (int)floorf(qz * kCellInv);
     KNN8_PHASE(0);      // query, own-cell probe, sort
     float d5 = inf;
     int pos5[5] = {-1, -1, -1, -1, -1};
@@ -431,9 +311,9 @@ __global__ __launch_bounds__(kKnn8Threads, LIODOM_KNN8_WAVES) void k_knn8(DevVie
     bool exact = false;                                   // (uniform over the group) ... are left to k_knn8_exact
     // ---- second pass: re-rank what the first pass kept ----
     float4 sq = make_float4(0.f, 0.f, 0.f, inf);          // the first pass's query and fifth distance
-    if (outer_it == 1) sq = sh_sq[par][src];
+    if (outer_it == 1 && active && v.knn_save_q) sq = v.knn_save_q[(size_t)s * v.edge_cap + e];
     if (outer_it == 1 && active && v.knn_save_pos && !v.knn_exact_only) {
-      const float gsq = sh_gsq[par][src];
+      const float gsq = v.knn_save_g[(size_t)s * v.edge_cap + e];
       if (gsq > 0.f) {                                    // (uniform over the group)
         const int* sv = reinterpret_cast<const int*>(v.knn_save_pos) + ((size_t)s * v.edge_cap + e) * (2 * kKnnGroup) + j * 3;
         const int s0p = sv[0], s1p = sv[1], s2p = sv[2];
@@ -461,43 +341,13 @@ __global__ __launch_bounds__(kKnn8Threads, LIODOM_KNN8_WAVES) void k_knn8(DevVie
         }
       }
     }
+    // ---- search ----
     KNN8_PHASE(1);      // second pass: re-ranking
     if (kInstrument && (v.debug & 256) && outer_it == 1) {          // how many queries of the second pass search, and how many waves that keeps busy
       const unsigned long long srch = __ballot(!done && j == 0);
       if ((threadIdx.x & 63) == 0) { atomicAdd(&v.dbg_clk[64 + 15], (unsigned long long)__popcll(srch)); atomicAdd(&v.dbg_clk[64 + 7], srch ? 1ull : 0ull); atomicAdd(&v.dbg_clk[64 + 23], 1ull); }
     }
-    if (outer_it == 1 && kKnn8Redeal) {
-      // Second pass, 256 streams: 9 % of the queries are left to search after the re-ranking — but 38 % of the waves hold at least one
-      // of them and walk its cells with one group in eight.  The workgroup gathers them: its queries are dealt to the groups again,
-      // the finished ones first, so the searching ones share as few waves as they fill.  (What a query is at this point is uniform
-      // over its group: where it came from, the flag, the five positions and the fifth distance.)
-      if (j == 0) {
-        sh_ra[grp] = make_int4(src, done ? 1 : 0, __float_as_int(d5), pos5[0]);
-        sh_rb[grp] = make_int4(pos5[1], pos5[2], pos5[3], pos5[4]);
-      }
-      __syncthreads();
-      int below = 0;
-#pragma unroll
-      for (int i = 0; i < kKnn8Queries / kG8; i++) {
-        const int o = i * kG8 + j;
-        const int od = sh_ra[o].y;                       // (finished: 1) — finished queries first
-        below += ((od != 0 && !done) || ((od != 0) == done && o < grp)) ? 1 : 0;
-      }
-      below = g8_sum_i32(below);
-      if (j == 0) sh_perm[par][below] = grp;
-      __syncthreads();
-      const int from = sh_perm[par][grp];
-      const int4 ra = sh_ra[from], rb = sh_rb[from];
-      src = ra.x; done = ra.y != 0; d5 = __int_as_float(ra.z);
-      pos5[0] = ra.w; pos5[1] = rb.x; pos5[2] = rb.y; pos5[3] = rb.z; pos5[4] = rb.w;
-      q4 = sh_q[par][src]; o2 = sh_own[par][src]; sq = sh_sq[par][src];
-      qx = q4.x; qy = q4.y; qz = q4.z; e = __float_as_int(q4.w);
-      active = o2.y >= 0;
-      cx = (int)floorf(qx * kCellInv); cy = (int)floorf(qy * kCellInv); cz = (int)floorf(qz * kCellInv);
-    }
-    // ---- search ----
-    // (first pass: every group walks this code — the workgroup meets at a barrier inside it; a group without a query streams nothing)
-    if (outer_it == 0 || !done) {
+    if (!done) {                                          // (uniform over the group)
       float B = 1.0f;
       bool have_b = false;
       if (outer_it == 1 && sq.w < 1.0f) {
@@ -507,59 +357,13 @@ __global__ __launch_bounds__(kKnn8Threads, LIODOM_KNN8_WAVES) void k_knn8(DevVie
         B = fminf(1.0f, r * r * (1.0f + 1e-5f));
         have_b = true;
       }
-      if (outer_it == 1) g8_probe(v, cells, bits, tmask, cx, cy, cz, own_start, own_cnt);
+      if (!(outer_it == 0 && kKnn8Sort)) g8_probe(v, cells, bits, tmask, cx, cy, cz, own_start, own_cnt);
       Best3Acc b3;
       b3.clear();
       g8_stream_cell<Best3Acc, LIODOM_KNN8_U>(b3, sp, (int)own_start, (int)own_cnt, j, qx, qy, qz, min_wi);
-      KNN8_PHASE(2);    // own cell
-      unsigned long long t_sub = (kInstrument && (v.debug & 256)) ? __builtin_readcyclecounter() : 0ull;
       if (!have_b) B = best3_bound(b3);
-      if (outer_it == 0 && !active) B = -1.0f;           // (no query: no cell lies within the bound)
-      KNN8_SUB(0);      // ladder bound
-      unsigned int pend;
-      int work;
-#if defined(LIODOM_KNN8_EXPT) && LIODOM_KNN8_EXPT == 1      // (timing experiments only: wrong results)
-      B = -1.0f;
-#endif
-      float lb_skipped = g8_nb_probe(v, cells, bits, tmask, j, gshift, cx, cy, cz, qx, qy, qz, B, v.hb_spill_base, (outer_it == 0 && !active) ? 0 : n_spill, sh_nb, pend, work);
-#if defined(LIODOM_KNN8_EXPT) && LIODOM_KNN8_EXPT == 2
-      pend = 0u;
-#endif
-      KNN8_SUB(1);      // box distances + probes
-      int gbase = (int)threadIdx.x - j;                  // whose columns of sh_nb the group's list lives in
-      if (outer_it == 0 && kKnn8Redeal) {
-        // The lists the groups of a wave hold now differ far more than their own cells did: 3.0 steps of 16 candidates on average on
-        // the headline stream, 9.5 for the slowest of a wave's eight — and a wave lasts as long as its slowest group.  The workgroup
-        // deals its queries to the groups once more, in the order of the lists' lengths (5.7 steps per wave then,
-        // tools/knn_budget_cpu.py): a query moves with what its lanes have kept so far, the list stays where its finder wrote it.
-        sh_mva[threadIdx.x] = make_float4(b3.m1, b3.m2, b3.m3, b3.m4);
-        sh_mvb[threadIdx.x] = make_int4(b3.p1, b3.p2, b3.p3, __float_as_int(lb_skipped));
-        if (j == 0) sh_ra[grp] = make_int4(src, work, (int)pend, 0);
-        __syncthreads();
-        int below = 0;
-#pragma unroll
-        for (int i = 0; i < kKnn8Queries / kG8; i++) {
-          const int o = i * kG8 + j;
-          const int ow = sh_ra[o].y;
-          below += (ow < work || (ow == work && o < grp)) ? 1 : 0;
-        }
-        below = g8_sum_i32(below);
-        if (j == 0) sh_perm2[below] = grp;
-        __syncthreads();
-        const int from = sh_perm2[grp];
-        const int4 ra = sh_ra[from];
-        const float4 ma = sh_mva[from * kG8 + j];
-        const int4 mb = sh_mvb[from * kG8 + j];
-        b3.m1 = ma.x; b3.m2 = ma.y; b3.m3 = ma.z; b3.m4 = ma.w; b3.p1 = mb.x; b3.p2 = mb.y; b3.p3 = mb.z; lb_skipped = __int_as_float(mb.w);
-        src = ra.x; pend = (unsigned int)ra.z; gbase = from * kG8;
-        q4 = sh_q[par][src]; o2 = sh_own[par][src];
-        qx = q4.x; qy = q4.y; qz = q4.z; e = __float_as_int(q4.w);
-        active = o2.y >= 0;
-        cx = (int)floorf(qx * kCellInv); cy = (int)floorf(qy * kCellInv); cz = (int)floorf(qz * kCellInv);
-      }
-      g8_stream_list<Best3Acc>(b3, sp, sh_nb, gbase, pend, j, qx, qy, qz, min_wi);
-      __builtin_amdgcn_wave_barrier();                   // (the next block's writes to sh_nb stay behind these reads)
-      KNN8_SUB(2);      // neighbour cells streamed
+      KNN8_PHASE(2);    // own cell
+      const float lb_skipped = g8_neighbours<Best3Acc, LIODOM_KNN8_U>(b3, v, cells, bits, tmask, sp, j, gshift, cx, cy, cz, qx, qy, qz, B, min_wi, v.hb_spill_base, n_spill);
       KNN8_PHASE(3);    // bound + neighbour cells
       // not certain (0.8 % of the queries: three of the nearest in one lane with a fourth at or below the fifth distance, or equal
       // distances; all queries with LIODOM_KNN_EXACT_ONLY): the query goes to k_knn8_exact, the launch behind this one, through
@@ -567,9 +371,9 @@ __global__ __launch_bounds__(kKnn8Threads, LIODOM_KNN8_WAVES) void k_knn8(DevVie
       // Measured alternatives: the sorted-list path inside this kernel cost 40 VGPRs — half of the waves a SIMD holds — for every
       // query; a second try with the lanes' shares of every cell rotated, as further rounds of this loop, cost +10 % / +18 % of the
       // passes' instructions and 80 us per pass at 256 streams (a third of the workgroups run a round for one query).
-      if (active) exact = !(best3_select(b3, d5, pos5) && !v.knn_exact_only);
+      exact = !(best3_select(b3, d5, pos5) && !v.knn_exact_only);
       KNN8_PHASE(4);    // selection
-      if (outer_it == 0 && v.knn_save_pos && active) {
+      if (outer_it == 0 && v.knn_save_pos) {
         // what the second pass re-ranks: the lanes' kept candidates, and the guard (see the header)
         unsigned int gd = g8_min_u32((unsigned int)__float_as_int(b3.m4));
         const unsigned int sk = g8_min_u32((unsigned int)__float_as_int(lb_skipped));
@@ -589,8 +393,8 @@ __global__ __launch_bounds__(kKnn8Threads, LIODOM_KNN8_WAVES) void k_knn8(DevVie
         if (j == 0) v.knn_save_g[(size_t)s * v.edge_cap + e] = guard < 3.0e38f ? guard : 3.0e38f;
       }
     }
-    KNN8_PHASE(5);      // save for the second pass
     // ---- what the second pass prunes with: the query and its fifth-nearest distance (inf: fewer than five candidates / no query) ----
+    KNN8_PHASE(5);      // save for the second pass (and, for a lane whose group is done, the wait for the other groups of its wave)
     if (outer_it == 0 && v.knn_save_q && e < E && j == 0) {
       v.knn_save_q[(size_t)s * v.edge_cap + e] = make_float4(qx, qy, qz, d5);
       if (!active && v.knn_save_g) v.knn_save_g[(size_t)s * v.edge_cap + e] = 0.f;       // (no query: nothing to re-rank)

@@ -394,9 +394,6 @@ def sec_knn8phases(H=64, W=1800, R=8, epr=10, P=20, K=30):
         row = a[64 + 8 * it:64 + 8 * it + 7]
         tot = row.sum()
         print("k_knn8<%d>: %s" % (it, ", ".join("%s %.1f %%" % (n, 100.0 * x / max(tot, 1.0)) for n, x in zip(names, row))))
-    for it in (0, 1):
-        row = a[96 + 8 * it:96 + 8 * it + 3]
-        print("k_knn8<%d>, inside 'bound + neighbour cells': %s" % (it, ", ".join("%s %.1f %%" % (n, 100.0 * x / max(row.sum(), 1.0)) for n, x in zip(["ladder bound", "box distances + probes", "cells streamed"], row))))
     print("second pass: %d wave-iterations, %d with at least one searching query, %d searching queries (%.1f %% of %d)" % (a[64 + 23], a[64 + 7], a[64 + 15], 100.0 * a[64 + 15] / max(8 * a[64 + 23], 1), 8 * a[64 + 23]))
     g.close()
 

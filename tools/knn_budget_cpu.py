@@ -164,6 +164,80 @@ def nb_rounds(per_wg=32):
 nb_rounds(32)
 nb_rounds(64)
 
+# ---- sub-cell ordering (the round-5 verdict's lever (a)): the points of a populous cell sorted by 0.5 m octant, a query walks its
+# ---- own octant, forms the ladder bound, then only the octants (own cell and neighbours) whose box lies within it ----
+def octant_model(heavy):
+    c0 = np.floor(win)
+    ob = ((win - c0) >= 0.5).astype(np.int64)
+    oc = ob[:, 0] + 2 * ob[:, 1] + 4 * ob[:, 2]
+    kk = keys(win)
+    order = np.lexsort((oc, kk))
+    ks, ocs, pp = kk[order], oc[order], win[order]
+    u, st_, cn = np.unique(ks, return_index=True, return_counts=True)
+    cl = {a: (b, c, np.bincount(ocs[b:b + c], minlength=8)) for a, b, c in zip(u.tolist(), st_.tolist(), cn.tolist())}
+    tot, r8 = [], []
+    for p in q:
+        c = np.floor(p).astype(np.int64)
+        m = np.full((G, 4), np.inf, np.float32)
+        seen = rounds8 = 0
+        def stream(s, n):
+            nonlocal seen, rounds8
+            if n <= 0:
+                return
+            dd = sqd(p, pp[s:s + n])
+            for i in range(n):
+                m[i % G] = np.sort(np.append(m[i % G], dd[i]))[:4]
+            seen += n; rounds8 += -(-n // 8)
+        pending = []
+        own_oct = int(p[0] - c[0] >= 0.5) + 2 * int(p[1] - c[1] >= 0.5) + 4 * int(p[2] - c[2] >= 0.5)
+        sc = cl.get(key1(c))
+        if sc:
+            s, n, sub = sc
+            if n > heavy:
+                offs = np.concatenate([[0], np.cumsum(sub)])
+                stream(s + offs[own_oct], sub[own_oct])
+                pending += [(c, o, s + offs[o], sub[o]) for o in range(8) if o != own_oct and sub[o]]
+            else:
+                stream(s, n)
+        kept = np.sort(m[:, :3].ravel()); B = np.float32(1.0)
+        for t in thr:
+            if (kept <= np.float32(t)).sum() >= 5:
+                B = np.float32(t)
+        for dz in (-1, 0, 1):
+            for dy in (-1, 0, 1):
+                for dx in (-1, 0, 1):
+                    if dx == 0 and dy == 0 and dz == 0:
+                        continue
+                    cc = c + np.array([dx, dy, dz]); lo = cc.astype(np.float32); hi = lo + 1
+                    e = np.maximum(np.maximum(lo - p, p - hi), 0).astype(np.float32)
+                    if np.float32((e * e).sum()) > B:
+                        continue
+                    sc2 = cl.get(key1(cc))
+                    if not sc2:
+                        continue
+                    s, n, sub = sc2
+                    if n > heavy:
+                        offs = np.concatenate([[0], np.cumsum(sub)])
+                        pending += [(cc, o, s + offs[o], sub[o]) for o in range(8) if sub[o]]
+                    else:
+                        stream(s, n)
+        for cc, o, s, n in pending:
+            lo = cc.astype(np.float32) + 0.5 * np.array([o & 1, (o >> 1) & 1, (o >> 2) & 1], np.float32); hi = lo + 0.5
+            e = np.maximum(np.maximum(lo - p, p - hi), 0).astype(np.float32)
+            if np.float32((e * e).sum()) <= B:
+                stream(s, n)
+        tot.append(seen); r8.append(rounds8)
+    tot, r8 = np.array(tot), np.array(r8)
+    pad = (-len(r8)) % 8
+    per_wave = np.concatenate([r8, np.zeros(pad)]).reshape(-1, 8).max(axis=1).mean()
+    return tot.mean(), np.median(tot), np.percentile(tot, 90), r8.mean(), per_wave
+if os.environ.get("KNN_BUDGET_OCTANTS", "1") != "0":
+    n_heavy = sum(1 for v_ in cells.values() if v_[1] > 32)
+    print("sub-cell ordering: %d of %d cells hold more than 32 points (%d of the %d window points)" % (n_heavy, len(cells), sum(v_[1] for v_ in cells.values() if v_[1] > 32), len(win)))
+    for heavy, name in ((10 ** 9, "no octants (k_knn8 as built)"), (64, "cells > 64 points sorted by octant"), (32, "cells > 32 points sorted by octant"), (16, "cells > 16 points sorted by octant")):
+        a = octant_model(heavy)
+        print("   %-38s candidates per query mean %5.1f median %3.0f p90 %3.0f; rounds of 8 per query %.1f, per wave of 8 queries (edge order) %.1f" % ((name + ":",) + a))
+
 # ---- k_hash_append: room per cell ----
 def sim(slack_fn, newroom, period=4):
     fails = tries = 0
