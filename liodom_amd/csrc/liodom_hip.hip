@@ -116,6 +116,7 @@ struct liodom_handle {
   unsigned int* host_edges_hdr = nullptr;
   float4* pin_ring = nullptr;        // page-locked scan staging ring [kEdgePipeBufs][max_points]: liodom_scan_buffer hands slots out, pageable scans are copied through it
   float4* stage_ring = nullptr;      // device side of the hand-off's uploads [kEdgePipeBufs][max_points] when they run on the copy stream
+  std::vector<double> replay_stamps;  // (debug) host time, us since the call began, at which every pose of the last liodom_replay_resident call was collected
   bool fold_publish = true;          // k_compact_edges publishes the extraction itself (LIODOM_FOLD_PUBLISH=0: k_set_flag / k_publish_edges in a launch behind it)
   bool tk_copy_stream = false;       // ... (LIODOM_COPY_STREAM, default on): the upload of scan k+1 runs beside the extraction of scan k
   hipEvent_t ev_cp[kEdgePipeBufs] = {nullptr, nullptr, nullptr};      // the upload into device staging slot r has completed (copy stream)
@@ -1669,6 +1670,10 @@ int liodom_replay_resident(liodom_handle_t* h, int first_slot, int count, int ah
   if ((rc0 = tickets_idle(h))) return rc0;
   auto out_p = [&](int i) { return poses_out ? poses_out + (size_t)i * h->S * 7 : nullptr; };
   auto out_i = [&](int i) { return infos_out ? infos_out + (size_t)i * h->S : nullptr; };
+  const auto t_call = std::chrono::steady_clock::now();
+  h->replay_stamps.clear();
+  h->replay_stamps.reserve((size_t)count);
+  auto stamp = [&]() { h->replay_stamps.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_call).count()); };
   for (int i = 0; i < count; i++) {
     const int slot = first_slot + i;
     const int next = (i + 1 < count || ahead) ? slot + 1 : -1;
@@ -1682,14 +1687,14 @@ int liodom_replay_resident(liodom_handle_t* h, int first_slot, int count, int ah
     int rc = replay_one(h, slot, next, n, height, width, false, nullptr, nullptr);
     if (rc) return rc;
     const auto t_b = std::chrono::steady_clock::now();
-    if (i > 0) { rc = wait_pose(h, 0, h->S, out_p(i - 1), out_i(i - 1), 1); if (rc) return rc; }
+    if (i > 0) { rc = wait_pose(h, 0, h->S, out_p(i - 1), out_i(i - 1), 1); if (rc) return rc; stamp(); }
     // (where the host's time goes in this loop: liodom_get_modes reports the two averages — the host has one scan's duration to
     //  enqueue the next scan's launches; if the first number approaches the scan period the GPU starves)
     h->replay_enq_ns += std::chrono::duration<double, std::nano>(t_b - t_a).count();
     h->replay_wait_ns += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t_b).count();
     h->replay_timed++;
   }
-  if (depth == 1 && count > 0) { const int rc = wait_pose(h, 0, h->S, out_p(count - 1), out_i(count - 1), 0); if (rc) return rc; }
+  if (depth == 1 && count > 0) { const int rc = wait_pose(h, 0, h->S, out_p(count - 1), out_i(count - 1), 0); if (rc) return rc; stamp(); }
   return LIODOM_OK;
 }
 
@@ -2050,6 +2055,13 @@ int liodom_debug_set_inject_seed(liodom_handle_t* h, unsigned int seed) {
 }
 
 /* debug: raw phase timestamps (100 MHz) written by the kernels when LIODOM_DEBUG_CLOCKS is set */
+// (debug) when the host collected every pose of the last liodom_replay_resident call (depth 1): microseconds since the call began
+int liodom_debug_replay_stamps(liodom_handle_t* h, double* out_us, int cap) {
+  if (!h || !out_us || cap < 0) return LIODOM_ERR_INVALID_ARG;
+  const int n = (int)std::min<size_t>(h->replay_stamps.size(), (size_t)cap);
+  for (int i = 0; i < n; i++) out_us[i] = h->replay_stamps[(size_t)i];
+  return n;
+}
 int liodom_debug_clocks(liodom_handle_t* h, unsigned long long* out512) {
   if (!h || !out512) return LIODOM_ERR_INVALID_ARG;
   if (!kInstrument) { g_last_error = "liodom_debug_clocks: the product library carries no instrumentation; build a variant with -DLIODOM_INSTRUMENT (tools/variant_build.sh)"; return LIODOM_ERR_UNSUPPORTED; }
