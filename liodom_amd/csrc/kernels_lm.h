@@ -418,7 +418,10 @@ __device__ __forceinline__ void rebuild_beside_solve(const DevView& v, int s, St
 //  and per-kernel profiling never waits for a pass's done count and never hands a result over early: as a run-time `chain` that code
 //  cost its finalising solve 200 B of scratch per lane)
 template <int kOuterIt, bool kChainMode>
-__global__ __launch_bounds__(kLmThreads) void k_lm_solve(DevView v, int s0, int eb, unsigned int seq, unsigned int done_target) {
+#ifndef LIODOM_LM_WAVES_PER_SIMD
+#define LIODOM_LM_WAVES_PER_SIMD 1      // (experiments: 256-thread workgroups at 2 -> 256 registers per lane, half of the CU's register file)
+#endif
+__global__ __launch_bounds__(kLmThreads, LIODOM_LM_WAVES_PER_SIMD) void k_lm_solve(DevView v, int s0, int eb, unsigned int seq, unsigned int done_target) {
   constexpr int outer_it = kOuterIt;
   constexpr int chain = kChainMode ? 1 : 0;
   // the candidate's matrix and the current iterate's (the candidate of the last accepted step): two buffers that swap roles when a
