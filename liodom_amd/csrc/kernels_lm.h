@@ -10,7 +10,7 @@
 //   order (deterministic, no atomics, no MFMA: this is a 6x6 reduction); with G > 1 the 29 partial sums are exchanged inside the
 //   launch as tagged 8-byte granules (lm_exchange) and every workgroup continues with bit-identical totals.
 //   controller: lane 0 of the last wave (tid kLmCtl) runs lm_begin / lm_update (liodom_math.h) between evaluations, redundantly in
-//   every workgroup; beside its first step waves 0..6 compact the accepted correspondences and cache their triples in registers.
+//   every workgroup; beside its first step the other waves compact the accepted correspondences and cache their triples in registers.
 //   finalize (second outer iteration, or the very first frame; workgroup 0): pose log + host-mapped record, constant-velocity
 //   prediction for the next scan, window bookkeeping, and the solved pose handed to the rebuild workgroups that append the frame.
 //   Two instances, k_lm_solve<0> (first solve of a scan) and <1> (finalising solve): one kernel with a run-time outer iteration
@@ -66,7 +66,10 @@ __device__ int lm_compact_bits(const DevView& v, int s, int outer_it, int E, int
 // The correspondences of a solve do not change between its evaluations: every evaluator thread keeps its
 // first kLmCached triples (p, a, b) in registers (loaded once by lm_cache_load), so an evaluation
 // of up to kLmCached * kLmEvalThreads blocks touches no memory before the reduction.
-constexpr int kLmCached = 1;
+#ifndef LIODOM_LM_CACHED
+#define LIODOM_LM_CACHED 1
+#endif
+constexpr int kLmCached = LIODOM_LM_CACHED;
 struct LmCache { float4 P[kLmCached], A[kLmCached], B[kLmCached]; };
 __device__ __forceinline__ void lm_cache_load(const DevView& v, int s, int outer_it, int eb, int c_lo, int c_hi, const int* idx, LmCache& k) {
   const float4* ed = v.edges + ((size_t)eb * v.n_streams + s) * v.edge_cap;
@@ -86,7 +89,11 @@ __device__ __forceinline__ void lm_cache_load(const DevView& v, int s, int outer
 __device__ __forceinline__ void lm_eval(const DevView& v, int s, int outer_it, int eb, int c_lo, int c_hi, const int* idx, const double* Rm_sh,
                                         double* part, double* acc_out /*[kAccN]*/, const LmCache& k) {
   const int et = (int)threadIdx.x;
+#ifdef LIODOM_LM_NOCACHE      // (debugging: every evaluation reads its triples from memory)
+  const bool cached = false;
+#else
   const bool cached = et < kLmCtl;
+#endif
   double acc[kAccN];
 #pragma unroll
   for (int i = 0; i < kAccN; i++) acc[i] = 0.0;
@@ -477,16 +484,26 @@ __global__ __launch_bounds__(kLmThreads, LIODOM_LM_WAVES_PER_SIMD) void k_lm_sol
   else if (threadIdx.x == 76) sh_fc = st.frame_count;
   __shared__ int sh_spec_at;           // speculative hand-over: solves of this kind still to sit out after one that was not confirmed
   if (threadIdx.x == 77) sh_spec_at = st.spec_eval[outer_it];
+  // The kNN pass this solve consumes was REPEATED (speculative hand-over not confirmed: rare) — by k_knn_redo / k_chain_redo0, whose
+  // workgroups do not sit where their namesakes of the pass's first edition sat.  This launch has been resident since before either
+  // wrote: what a first-edition workgroup on THIS XCD stored (write-through, but the line stays in this L2) is what a plain load here
+  // still finds after the repeat has overwritten it in memory from another XCD — "nothing of theirs cached here" (ov_wait_knn_done)
+  // no longer holds.  Then, and only then, the solve invalidates its caches behind the wait.  (Found with 256-thread solving
+  // workgroups on the 16 x 900 shape, predictor forced wrong: one repair in four left a solve with the first edition's partial sums
+  // or correspondences — poses off by 1e-8; with 384 / 512 threads the first edition had always finished before this launch began.)
+  __shared__ int sh_redo;
+  if (threadIdx.x == 78) sh_redo = st.spec_redo[outer_it == 0 ? 1 : 0];
   extern __shared__ __attribute__((aligned(16))) int sh_idx[];   // [edge_cap] compacted correspondence indices, then the reduction matrix
   double* sh_part = reinterpret_cast<double*>(sh_idx + ((v.edge_cap + 3) & ~3));   // [kAccN][kLmEvalThreads]
   const int tid = threadIdx.x;
-  const bool prep = tid < kLmCtl;               // waves 0..6: compaction + register cache while the controller lane works
+  const bool prep = tid < kLmCtl;               // the other waves: compaction + register cache while the controller lane works
   // chain mode, first solve: nothing of the stream's state that the extraction writes (n_edges_buf) and nothing of the first pass's
   // results has been read so far; the pass's workgroups store write-through and raise one flag each
   // (dead: a wait of this scan gave up — here or in the pass: nothing the pass was to leave may be consumed; the solve then runs as
   //  one without residual blocks, the pose stays the prediction, and the status bit fails the scan on the host)
   bool dead = false;
   if (chain && outer_it == 0) dead = !chain_wait_count(v.knn_done0 + s, done_target, &st.status);      // (the count the pass's workgroups reach: wrap-safe comparison)
+  if (chain && outer_it == 0 && sh_redo) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (uniform; sh_redo: visible behind the wait's barrier)
   // (the edge count: the state word shares a cache line with fields that earlier launches on this XCD have read — since this launch
   //  started, possibly before the extraction wrote it; k_compact_edges leaves a write-through copy in a line of its own)
   int E_in;
@@ -520,7 +537,7 @@ __global__ __launch_bounds__(kLmThreads, LIODOM_LM_WAVES_PER_SIMD) void k_lm_sol
     return;
   }
   // The second kNN pass of this scan has completed when the finalising solve starts, so the cell hash it
-  // searched is no longer needed: waves 0..6 reset its occupied slots while the controller lane works on its
+  // searched is no longer needed: the other waves reset its occupied slots while the controller lane works on its
   // first update step (they would idle at the barrier otherwise).
   bool clr_pending = outer_it == 1 && g == 0 && prep && !v.early_rebuild;
   auto clear_hash_slots = [&]() {
@@ -546,6 +563,7 @@ __global__ __launch_bounds__(kLmThreads, LIODOM_LM_WAVES_PER_SIMD) void k_lm_sol
   };
   // the overlapped second kNN pass has completed (chain mode: its workgroups count themselves on one word; else a flag each)
   if (seq && outer_it == 1) { if (chain) dead = !chain_wait_count(v.knn_done0 + 32 + s, done_target, &st.status) || dead; else ov_wait_knn_done(v, s, seq, &st.status); }
+  if (seq && outer_it == 1) { __syncthreads(); if (sh_redo) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
   // (a pass whose own wait gave up does not count its workgroups: this solve's wait then gives up too)
   OV_STAMP(v, g == 0 && tid == 0 && outer_it == 1, 4);
   OV_STAMP(v, g == 0 && tid == 0 && outer_it == 0, 18);
@@ -554,7 +572,7 @@ __global__ __launch_bounds__(kLmThreads, LIODOM_LM_WAVES_PER_SIMD) void k_lm_sol
     const int Q = v.knn_queries;
     const int nb = (E + Q - 1) / Q;
     const double* part = v.knn_part + ((size_t)s * 2 + outer_it) * v.knn_blocks * 32;
-    constexpr int kRC = kLmThreads / 32;                 // row classes (16 at 512 threads) x 32 columns (29 used)
+    constexpr int kRC = kLmThreads / 32;                 // row classes (8 at 256 threads) x 32 columns (29 used)
     const int i = tid & 31, r0 = tid >> 5;
     double x0 = 0.0, x1 = 0.0;
     if (i <= kAccN) {                                    // (entry 29: the number of accepted correspondences)
@@ -599,16 +617,17 @@ __global__ __launch_bounds__(kLmThreads, LIODOM_LM_WAVES_PER_SIMD) void k_lm_sol
     else { lm_eval(v, s, outer_it, eb, c_lo, c_hi, sh_idx, sh_pose2[0], sh_part, sh_acc, cache); ++n_eval; }
   }
   DBG_STAMP(v, dbgb, 2, 2);
-  // ---- trust-region loop.  Controller step on lane 0 of the last wave; beside it waves 0..6 prepare the
+  // ---- trust-region loop.  Controller step on lane 0 of the last wave; beside it the other waves prepare the
   // evaluations (step 0: validity bytes -> index list, triples into registers) or reset the hash slots of the
   // build this scan searched (step 1 of the finalising solve) ----
   int dbg_it = 0;
   int pi = 0, ci = -1, nmoved = 0;     // (controller lane) candidate / iterate buffer, moves of the iterate
   const unsigned int n_eval0 = n_eval;       // evaluations of this launch before the loop (lock-step batches: the one at the start point)
-  const bool spec_ok = v.speculate != 0 && v.speculate != 5 && g == 0 && seq != 0u && outer_it == 0;      // (4 / 5, debugging: only the first / only the finalising solve)
+  const bool spec_ok = v.speculate != 0 && v.speculate != 5 && v.speculate != 7 && g == 0 && seq != 0u && outer_it == 0;      // (debugging: 4 / 5 only the first / only the finalising solve; 6 / 7 the same with the predictor forced wrong, as 2 forces both)
   // ... and of the finalising solve's, in chain mode: to the workgroups that append the new frame (the pose) and to the next scan's
   // first kNN pass, which follows them on their stream (the prediction formed from it)
-  const bool spec_ok1 = v.speculate != 0 && v.speculate != 4 && g == 0 && chain != 0 && outer_it == 1 && v.early_rebuild && v.pred_xch != nullptr;
+  const bool spec_ok1 = v.speculate != 0 && v.speculate != 4 && v.speculate != 6 && g == 0 && chain != 0 && outer_it == 1 && v.early_rebuild && v.pred_xch != nullptr;
+  const bool spec_forced = v.speculate == 2 || v.speculate == 6 || v.speculate == 7;
   bool spec_done = false;
   int spec_moves = -1;
   for (int step = 0;; step++) {
@@ -654,7 +673,7 @@ __global__ __launch_bounds__(kLmThreads, LIODOM_LM_WAVES_PER_SIMD) void k_lm_sol
     // speculative hand-over (kernels_sync.h): the iterate leaves for the waiting second pass before the evaluation that — going by
     // the previous scan — will end this solve without moving it
     if ((spec_ok || spec_ok1) && !spec_done && sh_ci >= 0 &&
-        (v.speculate == 2 || (v.speculate != 2 && sh_spec_at == 0 && lm.model_cost_change <= v.spec_theta * 1e-6 * lm.cost))) {
+        (spec_forced || (!spec_forced && sh_spec_at == 0 && lm.model_cost_change <= v.spec_theta * 1e-6 * lm.cost))) {
       if (spec_ok) {
         ov_publish_pose(v, s, sh_pose2[sh_ci], &lm.q[0], seq, tid, 1);
         OV_STAMP(v, tid == 0, 19);
@@ -724,6 +743,7 @@ __global__ __launch_bounds__(kLmThreads, LIODOM_LM_WAVES_PER_SIMD) void k_lm_sol
     // the model's prediction fails once it tends to fail again (the first scans of a young window converge more slowly): the next
     // spec_backoff (16) solves of this kind hand nothing over early
     st.spec_eval[outer_it] = (spec_done && sh_nmoved != spec_moves) ? v.spec_backoff : (sh_spec_at > 0 ? sh_spec_at - 1 : 0);
+    st.spec_redo[outer_it] = (spec_done && sh_nmoved != spec_moves) ? 1 : 0;
     if (spec_done) { st.spec_stats[2 * outer_it] += 1; if (sh_nmoved != spec_moves) st.spec_stats[2 * outer_it + 1] += 1; }
     if (outer_it == 0) st.info.lm[0] = sh_trace;      // (read by the finalising solve's launch; the finalising solve's own trace travels through LDS)
     if (outer_it == 1) st.append_raw = 0;

@@ -518,7 +518,11 @@ __device__ __forceinline__ void rebuild_beside_solve(const DevView& v, int s, St
 // Chain mode: the rebuild's steps as launches of their own on the stream of the kNN passes (light kernels: as extra workgroups of
 // k_lm_solve every one of them owned a whole CU — 256 VGPRs x 8 waves — and could only be placed on a CU that ran nothing else).
 // COUNT + PAD ride on the second kNN pass's launch (k_knn<256, true>: its extra workgroups), ALLOC is k_rebuild_alloc.
-__global__ __launch_bounds__(kLmThreads) void k_rebuild_fin(DevView v, int s0, int eb) {         // APPEND (waits for the solved pose), CLEAR, SCATTER
+#ifndef LIODOM_REBFIN_THREADS
+#define LIODOM_REBFIN_THREADS LIODOM_LM_THREADS
+#endif
+constexpr int kRebFinThreads = LIODOM_REBFIN_THREADS;
+__global__ __launch_bounds__(kRebFinThreads) void k_rebuild_fin(DevView v, int s0, int eb) {         // APPEND (waits for the solved pose), CLEAR, SCATTER
   __shared__ int sh_cnt[kMaxFrames + 1];
   __shared__ int sh_slot[kMaxFrames];
   const int s = s0 + blockIdx.y;

@@ -377,6 +377,8 @@ __device__ __forceinline__ void ov_wait_knn_done(const DevView& v, int s, unsign
   //       (the code above reads only state words), no other kernel of this handle reads them between the pass's stores and
   //       here, and the lines it did cache earlier belong to other buffers — the two passes' halves of corr_mask are padded to
   //       different 128-byte lines (mask_stride), corr_idx / knn_part halves are multiples of 128 bytes apart;
+  //       (round 6: EXCEPT when the pass was repeated after a speculative hand-over that was not confirmed — its first edition's
+  //       workgroups on this XCD have left their lines here: k_lm_solve then invalidates, StreamState::spec_redo);
   //   (3) the launch may well have STARTED after some of the pass's stores (it follows k_rebuild_alloc in stream order): a kernel
   //       start invalidates the caches, so that order is harmless; the order the argument needs is only (1) before the flag.
   // A later edit that makes this launch read one of those buffers before this wait breaks (2) silently: don't.

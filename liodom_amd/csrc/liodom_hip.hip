@@ -395,7 +395,8 @@ int enqueue_odometry(liodom_handle* h, int eb, int s0, int count, unsigned int w
     if (v.speculate) hipLaunchKernelGGL(k_knn_redo<256>, dim3(kRebuildAllocBlocks + v.knn_grid, 1), dim3(256), 0, h->stream_k, v, s0, eb, seq_k, scan_no, kRebuildAllocBlocks);
     hipLaunchKernelGGL((k_lm_solve<1, true>), dim3(gx, 1), dim3(kLmThreads), lds, h->stream, v, s0, eb, seq_k, done_target);
     if (!v.speculate) hipLaunchKernelGGL(k_rebuild_alloc, dim3(kRebuildAllocBlocks, 1), dim3(256), 0, h->stream_k, v, s0);
-    hipLaunchKernelGGL(k_rebuild_fin, dim3(nP + kRebuildAuxBlocks + nC, 1), dim3(kLmThreads), 0, h->stream_k, v, s0, eb);
+    const int nCf = cdiv(h->v.edge_cap * std::max(1, h->P - 1), kRebFinThreads), nPf = cdiv(h->v.edge_cap, kRebFinThreads);
+    hipLaunchKernelGGL(k_rebuild_fin, dim3(nPf + kRebuildAuxBlocks + nCf, 1), dim3(kRebFinThreads), 0, h->stream_k, v, s0, eb);
     HIP_TRY(hipGetLastError());
     return LIODOM_OK;
   }
@@ -1093,7 +1094,7 @@ int liodom_create(const liodom_params_t* params, const liodom_config_t* config, 
     // result; 4 / 5 (debugging): only the first / only the finalising solve's hand-over.  LIODOM_SPEC_THETA: the predictor's threshold
     // (fraction of the function tolerance, default 0.8)
     v.speculate = (h->ov_ok || h->chain_ok) ? 1 : 0;
-    if (const char* e = std::getenv("LIODOM_SPECULATE")) { if (v.speculate) v.speculate = std::max(0, std::min(5, std::atoi(e))); }
+    if (const char* e = std::getenv("LIODOM_SPECULATE")) { if (v.speculate) v.speculate = std::max(0, std::min(7, std::atoi(e))); }
     v.spec_backoff = 16;
     if (const char* e = std::getenv("LIODOM_SPEC_BACKOFF")) v.spec_backoff = std::max(0, std::atoi(e));
     v.spec_theta = 0.8;
@@ -2095,18 +2096,20 @@ int liodom_get_modes(liodom_handle_t* h, char* buf, int cap) {
   // (speculative hand-overs of stream 0 since the last reset: the launches enqueued so far have to have run for the figures to mean
   //  anything — a caller that wants them synchronises first; this call does not)
   int spec[4] = {0, 0, 0, 0}, hbs[4] = {0, 0, 0, 0};
+  unsigned int done_cnt[64] = {0};      // (chain mode: the passes' done counters of stream 0 — first pass [0], second pass [32] — against the host's target)
+  if (v.knn_done0) (void)hipMemcpy(done_cnt, v.knn_done0, sizeof(done_cnt), hipMemcpyDeviceToHost);
   (void)hipMemcpy(spec, reinterpret_cast<const char*>(v.state) + offsetof(StreamState, spec_stats), sizeof(spec), hipMemcpyDeviceToHost);
   (void)hipMemcpy(hbs, reinterpret_cast<const char*>(v.state) + offsetof(StreamState, hb_stats), sizeof(hbs), hipMemcpyDeviceToHost);
   snprintf(buf, (size_t)cap,
            "n_streams=%d early_rebuild=%d hash_build=%s pipe_flags=%d flag_gate=%d lm_groups=%d knn_instance=%d knn_queries=%d "
            "knn_grid=%d/%d knn8=%d hash_incr=%d hash_rebuilds=%d hash_appends=%d hash_appends_spilled=%d hash_points_spilled=%d knn_partials=%d knn_saved_bound=%d knn_exact_only=%d line_gate_kernel=%d filter_local_map=%d mapping=%d "
-           "rotation_mode=%d table_size=%d rebuild_delta=%.3f knn_overlap=%d streams_concurrent=%d safe_mode=%d ring_split=%d ring_split_max_wgs=%d ring_split_lb=%d fold_publish=%d chain=%d speculate=%d spec_early=%d/%d spec_unconfirmed=%d/%d replay_enqueue_us=%.2f replay_wait_us=%.2f debug=%d",
+           "rotation_mode=%d table_size=%d rebuild_delta=%.3f knn_overlap=%d streams_concurrent=%d safe_mode=%d ring_split=%d ring_split_max_wgs=%d ring_split_lb=%d fold_publish=%d chain=%d speculate=%d spec_early=%d/%d spec_unconfirmed=%d/%d chain_done=%u/%u/%u replay_enqueue_us=%.2f replay_wait_us=%.2f debug=%d",
            h->S, v.early_rebuild, v.early_rebuild ? "streamed" : (h->lds_hash_build ? "lds" : "global"), h->use_flags ? 1 : 0,
            (h->use_flags && h->flag_gate) ? 1 : 0, v.lm_groups, h->S >= 16 ? 128 : 256, v.knn_queries, v.knn_grid,
            v.knn_blocks, h->knn8 ? 1 : 0, v.hash_incr, hbs[0], hbs[1], hbs[2], hbs[3], v.knn_partials, v.knn_save_pos ? 2 : (v.knn_save_q ? 1 : 0), v.knn_exact_only, v.knn_nn ? 1 : 0, v.filter_local_map, v.mapping,
            v.rotation_mode, v.table_size, (double)v.rebuild_delta,
            (v.early_rebuild && (h->ov_ok || (h->chain_ok && !h->flag_gate)) && h->use_flags && g_live_handles.load() <= 1) ? 1 : 0, h->streams_concurrent ? 1 : 0, h->safe_mode ? 1 : 0, h->ring_split ? 1 : 0, h->ring_split ? h->ring_split_max_wgs : 0, h->ring_split_lb ? 1 : 0, h->fold_publish ? 1 : 0,
-           (v.early_rebuild && h->chain_ok && h->use_flags && !h->flag_gate && g_live_handles.load() <= 1) ? 1 : 0, v.speculate, spec[0], spec[2], spec[1], spec[3],
+           (v.early_rebuild && h->chain_ok && h->use_flags && !h->flag_gate && g_live_handles.load() <= 1) ? 1 : 0, v.speculate, spec[0], spec[2], spec[1], spec[3], h->chain_count, done_cnt[0], done_cnt[32],
            h->replay_timed ? h->replay_enq_ns / (1e3 * (double)h->replay_timed) : 0.0, h->replay_timed ? h->replay_wait_ns / (1e3 * (double)h->replay_timed) : 0.0, v.debug);
   return LIODOM_OK;
 }

@@ -43,12 +43,17 @@ namespace liodom_dev {
 #endif
 constexpr int kWave = 64;
 constexpr uint64_t kEmptyKey = 0xFFFFFFFFFFFFFFFFull;
+// Solving workgroups of 4 waves (round 6; 8 until then): one wave per SIMD with the whole register file to itself — no scratch in
+// any instance of k_lm_solve (512 threads: 256 registers per lane and 108-172 B of scratch in the controller's path), half as many
+// waves at every barrier.  Interleaved A/B against 512 (same box, bench.py): `value` 14 288 -> 14 577 (K = 200), 13 364 -> 13 503
+// (the driver's K = 20), strict-sync +0.9 %, 256 lock-step streams 203.8k -> 207.1k; round 5 had measured +-1 % for the same switch
+// (then one instance of the kernel per solve, now one per solve and mode).
 #ifndef LIODOM_LM_THREADS
-#define LIODOM_LM_THREADS 512
+#define LIODOM_LM_THREADS 256
 #endif
-constexpr int kLmThreads = LIODOM_LM_THREADS;   // k_lm_solve: 8 waves, two per SIMD, all evaluate residual blocks
+constexpr int kLmThreads = LIODOM_LM_THREADS;   // k_lm_solve: 4 waves, one per SIMD, all evaluate residual blocks
 constexpr int kLmEvalThreads = kLmThreads;
-constexpr int kLmCtl = kLmThreads - 64;   // lane 0 of the last wave also runs the trust-region logic; waves 0..6 prepare (compaction, register cache) meanwhile
+constexpr int kLmCtl = kLmThreads - 64;   // lane 0 of the last wave also runs the trust-region logic; the other waves prepare (compaction, register cache) meanwhile
 #ifndef LIODOM_LM_GROUPS_MAX
 #define LIODOM_LM_GROUPS_MAX 8
 #endif
@@ -106,6 +111,9 @@ struct StreamState {
   int32_t hb_stats[4];    // since the last reset: rebuilds, appends, appends that spilled, points spilled
   int32_t hb_spill;       // appended points that found no room in their cell (or no cell): kept in the spill list at the end of the point array,
                           // which every query scans, until the next rebuild
+  int32_t spec_redo[2];   // ... [0] this scan's first solve / [1] the previous scan's finalising solve handed its iterate over early and did NOT end with
+                          // it: the receiving kNN pass has been repeated by other workgroups, on other XCDs — what the pass's first edition left
+                          // in the L2 of the next solve's XCD is stale (k_lm_solve invalidates before it consumes the pass's results)
   int32_t spec_stats[4];  // ... how it went since the last reset: first solve's iterates handed over early, of them not confirmed; the same for the
                           // finalising solve (liodom_get_modes: spec_early / spec_unconfirmed)
   double pred_odom[2][12]; // early_rebuild: the prediction the scan started from ([frames appended so far & 1]: the repair of a speculative hand-over

@@ -488,6 +488,32 @@ def test_speculative_hand_over_survives_mode_switches(shape, scans):
     assert r.returncode == 0 and "bit-identical" in r.stdout, (r.stdout[-800:], r.stderr[-1500:])
 
 
+@pytest.mark.parametrize("forced", ["6", "7", "2"])
+def test_repeated_pass_is_not_consumed_from_a_stale_l2(forced):
+    """A kNN pass that is repeated after a speculative hand-over that was not confirmed is repeated by OTHER workgroups (k_knn_redo,
+    k_chain_redo0), on other XCDs than its first edition's; the solve that consumes it has been resident since before either wrote and
+    used to rely on "nothing of theirs cached here" — one repair in four left it with the first edition's partial sums or
+    correspondences (16 x 900 shape, 256-thread solving workgroups: poses off by 1e-8, no status bit).  LIODOM_SPECULATE=6 / 7 / 2:
+    the first / the finalising / both solves hand over as early as possible; six straight chain-mode replays each must equal the
+    replay without speculation bit for bit (k_lm_solve invalidates behind its wait when StreamState::spec_redo says so)."""
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "spec_switches.py")
+    with tempfile.TemporaryDirectory() as tmp:
+        def run(spec, tag):
+            f = os.path.join(tmp, tag + ".npy")
+            r = subprocess.run([sys.executable, tool, "16x900", "120", f, "straight"], env=dict(os.environ, LIODOM_SPECULATE=spec),
+                               capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0 and "chain 1" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+            return np.load(f)
+        ref = run("0", "ref")
+        for i in range(6):
+            x = run(forced, "f%d" % i)
+            bad = np.nonzero(np.any(x.view(np.uint64) != ref.view(np.uint64), axis=1))[0]
+            assert len(bad) == 0, "LIODOM_SPECULATE=%s, run %d: %d scans differ from the replay without speculation, first %s" % (forced, i, len(bad), bad[:5])
+
+
 @pytest.mark.parametrize("shape,scans", [("hdl64", 2000), ("vlp16", 2000), ("ouster128", 1000)])
 def test_schedule_perturbation_leaves_the_pose_log_unchanged(shape, scans):
     """tools/inject_delay.py: a library built with -DLIODOM_INJECT_DELAY (never the product library) delays every publisher of an
