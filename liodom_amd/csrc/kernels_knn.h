@@ -13,7 +13,7 @@
 //   path never looks at).  The ~1-2 % of the queries that fail either check repeat the stream with a per-lane sorted
 //   list of five (distance, window index) keys and a 64-bit merge ("Top5"): exact in every case.
 //   Line gate in FP64, then NN0 / NN1 are written as the line points (laser_odometry.cc:351-357).
-//   Round-2 design for the record: per-lane Top5 lists for every query, cells streamed in four
+//   Round-2 design for the record (DESIGN_HISTORY.md): per-lane Top5 lists for every query, cells streamed in four
 //   rounds of increasing box distance with the bound refreshed in between, second pass re-ranking the first pass's
 //   saved lists: ~750 VALU wave instructions per query, 56 % of them fixed cost.
 // =============================================================================================

@@ -640,7 +640,7 @@ __global__ __launch_bounds__(kLmThreads, LIODOM_LM_WAVES_PER_SIMD) void k_lm_sol
     if (tid == kLmCtl) {
       // (a wave-parallel controller — lane 8 r + c holding entry (r, c) of the 6 x 6 matrices, Cholesky columns
       // broadcast through LDS, solves on readlane'd entries — was measured slower than this single lane:
-      // 3.9-5.9 us per step against 3.1)
+      // 3.9-5.9 us per step against 3.1; DESIGN_HISTORY.md)
       const int acc_before = step == 0 ? 0 : lm.accepted;
       const int f = step == 0 ? lm_begin(lm, sh_x0, sh_x0 + 4, sh_acc, nblocks, v.apply_on_ftol, sh_scale) : lm_update(lm, sh_acc);
       sh_flag = f;
