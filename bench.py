@@ -200,6 +200,12 @@ def roofline_from_stats(stats, n_streams, N, E, M, C, evals, workload="hdl64"):
                             for k, v in stats.items() if v[1] > 0 and algorithmic_bytes(k, N, E, M, C, evals, streamed) > 0},
         # all kernels of a step together: algorithmic bytes of one step / summed kernel time of one step
         "end_to_end_frac_of_kernel_time": round(per_scan_bytes / scans * n_streams / (tot / scans * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+        # the batch kernels are not HBM kernels: their second roofline, VALU issue (SQ_ACTIVE_INST_VALU quad-cycles / SIMD cycles of the
+        # launch, 256 lock-step streams) — from the committed PMC profiles, not a counter read in this run
+        **({"valu_issue": {"k_knn8 first pass (256 streams)": 0.60, "k_knn8 both passes (64 streams)": 0.49, "k_ring_split_lb (64 streams)": 0.63, "k_ring_extract (64 streams)": 0.49,
+                           "source": "profiles/r06_knn_budget.txt section 3 (256 streams), profiles/r06_f_sq.txt (64 streams: 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x SQ_BUSY_CYCLES / 32))",
+                           "note": "fraction of the launch's SIMD cycles that issue a VALU instruction; k_knn8's length is set by a chain of ~20 dependent "
+                                   "memory round trips per workgroup at 76 % mean wave occupancy (profiles/r06_knn_budget.txt section 5)"}} if n_streams >= 16 else {}),
     }
 
 
