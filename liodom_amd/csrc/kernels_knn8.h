@@ -98,20 +98,20 @@ struct Best3Acc {
 // be a chain of dependent memory round trips); loads are unconditional with clamped indices, results masked.
 // min_wi (hash_incr, k_hash_append): candidates whose stored window index lies below it belong to frames the window has dropped
 // since the table was rebuilt — skipped; the others' indices are handed on minus min_wi (their current window index).
-template <class Acc, int U>
+template <class Acc, int U, int kLanes = kG8>      // (kLanes: the lanes that share the cell — a group of 8, or the whole wave in k_knn8_exact)
 __device__ __forceinline__ void g8_stream_cell(Acc& t, const float4* sp, int start, int cnt, int j, float qx, float qy, float qz, int min_wi) {
   if (cnt <= 0) return;
   const float4* cp = sp + start;
   float4 cur[U];
 #pragma unroll
-  for (int u = 0; u < U; u++) { const int iu = j + u * kG8; cur[u] = cp[iu < cnt ? iu : cnt - 1]; }
-  for (int i = j; i < cnt; i += U * kG8) {
+  for (int u = 0; u < U; u++) { const int iu = j + u * kLanes; cur[u] = cp[iu < cnt ? iu : cnt - 1]; }
+  for (int i = j; i < cnt; i += U * kLanes) {
     float4 nxt[U];
 #pragma unroll
-    for (int u = 0; u < U; u++) { const int iu = i + (U + u) * kG8; nxt[u] = cp[iu < cnt ? iu : cnt - 1]; }
+    for (int u = 0; u < U; u++) { const int iu = i + (U + u) * kLanes; nxt[u] = cp[iu < cnt ? iu : cnt - 1]; }
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      const int iu = i + u * kG8;
+      const int iu = i + u * kLanes;
       const int wi = __float_as_int(cur[u].w);
       t.consider(iu < cnt && wi >= min_wi, sqdist_cand(qx, qy, qz, cur[u]), wi - min_wi, start + iu);
     }
@@ -426,8 +426,8 @@ __global__ __launch_bounds__(kKnn8Threads, LIODOM_KNN8_WAVES) void k_knn8(DevVie
 // The queries k_knn8 could not certify (three of a query's nearest in one lane with a fourth at or below the fifth distance, equal
 // distances among the six nearest — FLANN orders those by index — or LIODOM_KNN_EXACT_ONLY): sorted (distance, window index) lists
 // per lane, started at the bound k_knn8 left, merged: FLANN's answer in every case.  ONE WAVE PER QUERY here: a dozen queries per
-// stream and pass, and what the launch costs is the length of ONE search — group g of the wave takes the cells g, g + 8, g + 16,
-// g + 24 of the 27-cell block (the own cell among them), its 8 lanes walk them, the 64 lists are merged over the wave.  (With a group
+// stream and pass, and what the launch costs is the length of ONE search — 27 lanes probe the 27 cells, the wave's 64 lanes walk
+// every cell found, the 64 lists are merged over the wave.  (With a group
 // per query — 27 cells one after the other — the launch took 48 us; as a launch of k_knn8's shape that looked for flagged records,
 // 57 us: 90 000 waves of two dependent loads each.)  The workgroups of a stream walk its list; k_line_gate, the next launch, empties it.
 constexpr int kKnn8ExactBlocks = 4;
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(kKnn8Threads) void k_knn8_exact(DevView v, int s0, 
   StreamState& st = v.state[s];
   const int n = v.knn8_cnt[s];
   if (n <= 0 || !st.initialized) return;
-  const int lane = (int)(threadIdx.x & 63), j = lane & 7, g8 = lane >> 3, wave = (int)(threadIdx.x >> 6);
+  const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
   constexpr int kWaves = kKnn8Threads / 64;
   const unsigned int tmask = st.table_mask;
   const int stab = s + LD_TAB_PARITY(v, st.frame_count) * v.n_streams;
@@ -463,17 +463,24 @@ __global__ __launch_bounds__(kKnn8Threads) void k_knn8_exact(DevView v, int s0, 
       ta.t.k0 = ta.t.k1 = ta.t.k2 = ta.t.k3 = ta.t.k4 = sentinel;
       ta.t.p0 = ta.t.p1 = ta.t.p2 = ta.t.p3 = ta.t.p4 = -1;
     }
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int c27 = k * 8 + g8;                         // (uniform over the group)
-      unsigned int start = 0, cnt = 0;
-      if (c27 == 31) { start = (unsigned int)v.hb_spill_base; cnt = (unsigned int)n_spill; }      // (k_hash_append's spill list)
-      if (c27 < 27) {
-        int ox, oy, oz;
-        const float lb = g8_cell_lb(c27, cx, cy, cz, qx, qy, qz, ox, oy, oz);
-        if (!(lb > B)) g8_probe(v, cells, bits, tmask, ox, oy, oz, start, cnt);      // (a cell beyond the bound cannot hold one of the five)
-      }
-      g8_stream_cell<Top5Acc, 2>(ta, sp, (int)start, (int)cnt, j, qx, qy, qz, min_wi);
+    // Lane l < 27 looks cell l of the block up (27 probes side by side: two round trips), lane 27 stands for k_hash_append's spill
+    // list; then the WHOLE WAVE walks the cells found, one after the other, 64 points per round.  (Until late in round 6 every group of 8
+    // lanes took four cells: a query whose own cell holds 300 points — where most uncertain results come from — kept 8 lanes busy
+    // for 38 rounds while 56 idled, and the launch lasts as long as its slowest query.)
+    unsigned int my_start = 0, my_cnt = 0;
+    if (lane < 27) {
+      int ox, oy, oz;
+      const float lb = g8_cell_lb(lane, cx, cy, cz, qx, qy, qz, ox, oy, oz);
+      if (!(lb > B)) g8_probe(v, cells, bits, tmask, ox, oy, oz, my_start, my_cnt);      // (a cell beyond the bound cannot hold one of the five)
+    } else if (lane == 27) {
+      my_start = (unsigned int)v.hb_spill_base; my_cnt = (unsigned int)n_spill;
+    }
+    unsigned long long pend = __ballot(my_cnt > 0);
+    while (pend) {                                       // (uniform over the wave)
+      const int l = (int)__builtin_ctzll(pend);
+      pend &= pend - 1ull;
+      const int cs = __builtin_amdgcn_readlane((int)my_start, l), cc = __builtin_amdgcn_readlane((int)my_cnt, l);
+      g8_stream_cell<Top5Acc, 1, 64>(ta, sp, cs, cc, lane, qx, qy, qz, min_wi);
     }
     // merge of the 64 sorted lists: (distance, window index) keys are unique among real candidates; the sentinel (bound, INT_MAX)
     // may sit in several lanes: the lowest lane pops
