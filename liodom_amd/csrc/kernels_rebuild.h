@@ -803,7 +803,10 @@ __device__ __forceinline__ void hash_build_global(const DevView& v, int s, Strea
 //  a pole coming into range —, and three frames arrive between rebuilds: with a quarter of the population / 8 / 16 a cell ran out of
 //  room in every period, with this rule in none of 24; the point array then holds ~195 000 places per stream for 36 600 points.)
 __host__ __device__ __forceinline__ int hash_cell_slack(unsigned int cnt, int slack_min) { return cnt ? ((int)cnt > slack_min ? (int)cnt : slack_min) : 0; }
-constexpr int kHbPeriod = 4;       // scans between two rebuilds from the whole window
+#ifndef LIODOM_HB_PERIOD
+#define LIODOM_HB_PERIOD 4
+#endif
+constexpr int kHbPeriod = LIODOM_HB_PERIOD;       // scans between two rebuilds from the whole window (<= 8: hb_base)
 constexpr int kHbNewRoom = 96;     // room of a cell that k_hash_append creates (DevView::hb_new_room; kHbSlackMin = 32: hb_slack_min)
 constexpr int kHbSlackMin = 32;
 
